@@ -1,0 +1,278 @@
+"""ctypes binding of the CPU oracle (oracle/libpk_oracle.so).  TEST INFRASTRUCTURE ONLY:
+importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never
+from the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False):
+    """Compile the C restatement (and the real-reference text library when /root/reference exists)."""
+    so = os.path.join(_HERE, "libpk_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("pk_oracle.c", "pk_oracle.h", "pk_oracle_math.h")]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "libpk_oracle.so"], stdout=subprocess.DEVNULL)
+    ref_so = os.path.join(_HERE, "_ref", "libpk_ref_text.so")
+    if os.path.exists("/root/reference/src/vocab.cpp") and (force or not os.path.exists(ref_so)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class AudioConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("n_fft", C.c_int), ("win_length", C.c_int), ("hop_length", C.c_int),
+                ("n_mels", C.c_int), ("f_min", C.c_float), ("f_max", C.c_float), ("normalize", C.c_int),
+                ("window_centered", C.c_int), ("power_via_abs", C.c_int)]
+
+
+def audio_config(n_mels=80, normalize=True, window_centered=True, power_via_abs=True):
+    return AudioConfig(16000, 512, 400, 160, n_mels, 0.0, -1.0, int(normalize), int(window_centered), int(power_via_abs))
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [("mel_bins", C.c_int), ("sub_channels", C.c_int), ("d_model", C.c_int), ("n_layers", C.c_int),
+                ("n_heads", C.c_int), ("ffn", C.c_int), ("conv_k", C.c_int), ("vocab", C.c_int),
+                ("pred_hidden", C.c_int), ("lstm_layers", C.c_int), ("joint_hidden", C.c_int),
+                ("n_durations", C.c_int), ("durations", C.c_int * 8), ("blank_id", C.c_int),
+                ("max_symbols", C.c_int), ("ln_eps", C.c_float), ("bn_eps", C.c_float),
+                ("joint_pred_bias", C.c_int), ("joint_prefix", C.c_char * 32)]
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = build()
+    L = C.CDLL(so)
+    f32p, i32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.orc_last_error.restype = C.c_char_p
+    L.orc_get_max_threads.restype = C.c_int
+    L.orc_sum64_f.restype = C.c_float
+    L.orc_sum64_f.argtypes = [f32p, C.c_int64]
+    L.orc_math_v.argtypes = [C.c_int, f32p, f32p, C.c_int64]
+    L.orc_linear.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p]
+    L.orc_linear_scalar.argtypes = L.orc_linear.argtypes
+    L.orc_layer_norm.argtypes = [f32p, C.c_int64, C.c_int, f32p, f32p, C.c_float, f32p]
+    L.orc_model_new.restype = C.c_void_p
+    L.orc_model_new.argtypes = [C.POINTER(OrcConfig)]
+    L.orc_model_free.argtypes = [C.c_void_p]
+    L.orc_model_add.argtypes = [C.c_void_p, C.c_char_p, f32p, C.c_int, i64p]
+    L.orc_mel_filterbank.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, f32p]
+    L.orc_mel_num_frames.argtypes = [C.c_int64, C.c_int]
+    L.orc_mel.argtypes = [C.POINTER(AudioConfig), f32p, C.c_int64, f32p, f32p]
+    L.orc_pos_emb.argtypes = [C.c_int, C.c_int, f32p]
+    L.orc_subsampled_len.argtypes = [C.c_int]
+    L.orc_subsampling.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, f32p, f32p, f32p]
+    L.orc_conformer_block.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, f32p, C.c_int]
+    L.orc_encoder.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, f32p, f32p]
+    L.orc_ctc_logprobs.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, f32p]
+    L.orc_ctc_greedy.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p]
+    L.orc_tdt_greedy.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p,
+                                 f32p, i32p, f32p]
+    L.orc_rnnt_greedy.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, f32p]
+    _LIB = L
+    return L
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _out(shape, dt=np.float32):
+    """Output buffer, first-touched serially here (see xmalloc in pk_oracle.c)."""
+    a = np.empty(shape, dt)
+    a.fill(0)
+    return a
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+MATH_FN = {"exp": 0, "log": 1, "tanh": 2, "sigmoid": 3, "silu": 4, "sqrt": 5, "rcp": 6}
+
+
+def math_v(fn: str, x):
+    x = _c(x)
+    y = _out(x.shape)
+    lib().orc_math_v(MATH_FN[fn], _f(x), _f(y), x.size)
+    return y
+
+
+def sum64(x):
+    x = _c(x)
+    return np.float32(lib().orc_sum64_f(_f(x), x.size))
+
+
+def linear(A, W, bias=None, scalar=False):
+    A, W = _c(A), _c(W)
+    M, K = A.shape
+    N = W.shape[0]
+    out = _out((M, N), np.float32)
+    b = _c(bias) if bias is not None else None
+    fn = lib().orc_linear_scalar if scalar else lib().orc_linear
+    fn(M, N, K, _f(A), _f(W), _f(b) if b is not None else None, _f(out))
+    return out
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    x, g, b = _c(x), _c(g), _c(b)
+    y = _out(x.shape)
+    lib().orc_layer_norm(_f(x), x.size // x.shape[-1], x.shape[-1], _f(g), _f(b), eps, _f(y))
+    return y
+
+
+def mel_filterbank(n_mels=80, n_freqs=257, sr=16000.0, f_min=0.0, f_max=8000.0):
+    fb = _out((n_freqs, n_mels), np.float32)
+    lib().orc_mel_filterbank(n_freqs, n_mels, sr, f_min, f_max, _f(fb))
+    return fb
+
+
+def mel(pcm, n_mels=80, return_logmel=False, **kw):
+    """pcm[n] -> features [n_frames, n_mels]  (reference: preprocess_audio, src/audio.cpp:100-158)."""
+    pcm = _c(pcm)
+    ac = audio_config(n_mels=n_mels, **kw)
+    nf = lib().orc_mel_num_frames(pcm.size, 160)
+    out = _out((nf, n_mels), np.float32)
+    tap = _out((n_mels, nf), np.float32) if return_logmel else None
+    r = lib().orc_mel(C.byref(ac), _f(pcm), pcm.size, _f(out), _f(tap) if tap is not None else None)
+    if r < 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    return (out, tap) if return_logmel else out
+
+
+def pos_emb(T, d):
+    pe = _out((2 * T - 1, d), np.float32)
+    lib().orc_pos_emb(T, d, _f(pe))
+    return pe
+
+
+def subsampled_len(n):
+    return lib().orc_subsampled_len(n)
+
+
+class Model:
+    """Oracle model: reference tensor names -> numpy arrays (kept alive here)."""
+
+    def __init__(self, cfg, weights: dict, joint_pred_bias=False, ln_eps=1e-5, bn_eps=1e-5):
+        self.cfg = cfg
+        oc = OrcConfig()
+        oc.mel_bins, oc.sub_channels, oc.d_model = cfg.mel_bins, cfg.subsampling_channels, cfg.hidden_size
+        oc.n_layers, oc.n_heads, oc.ffn, oc.conv_k = cfg.num_layers, cfg.num_heads, cfg.ffn_intermediate, cfg.conv_kernel_size
+        oc.vocab, oc.pred_hidden, oc.lstm_layers, oc.joint_hidden = cfg.vocab_size, cfg.pred_hidden, cfg.num_lstm_layers, cfg.joint_hidden
+        oc.n_durations = len(cfg.durations)
+        for i, d in enumerate(cfg.durations):
+            oc.durations[i] = d
+        oc.blank_id, oc.max_symbols = cfg.blank_id, cfg.max_symbols_per_step
+        oc.ln_eps, oc.bn_eps, oc.joint_pred_bias = ln_eps, bn_eps, int(joint_pred_bias)
+        oc.joint_prefix = cfg.joint_prefix.encode()
+        self._h = lib().orc_model_new(C.byref(oc))
+        self._keep = {}
+        for k, v in weights.items():
+            a = _c(v)
+            self._keep[k] = a
+            shp = (C.c_int64 * max(1, a.ndim))(*a.shape)
+            if lib().orc_model_add(self._h, k.encode(), _f(a), a.ndim, shp) != 0:
+                raise RuntimeError(lib().orc_last_error().decode())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_model_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r < 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return r
+
+    def subsampling(self, feats, taps=False):
+        feats = _c(feats)
+        B, Tm, F = feats.shape
+        T = subsampled_len(Tm)
+        out = _out((B, T, self.cfg.hidden_size), np.float32)
+        t1 = t3 = None
+        if taps:
+            H1, W1 = (Tm - 1) // 2 + 1, (F - 1) // 2 + 1
+            H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+            H3, W3 = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
+            t1 = _out((B, H1, W1, self.cfg.subsampling_channels), np.float32)
+            t3 = _out((B, H3, W3, self.cfg.subsampling_channels), np.float32)
+        self._chk(lib().orc_subsampling(self._h, _f(feats), B, Tm, _f(out), _f(t1) if taps else None, _f(t3) if taps else None))
+        return (out, t1, t3) if taps else out
+
+    def conformer_block(self, layer, x, pe=None, stop_after=0):
+        x = _c(x).copy()
+        B, T, d = x.shape
+        pe = pos_emb(T, d) if pe is None else _c(pe)
+        self._chk(lib().orc_conformer_block(self._h, layer, _f(x), B, T, _f(pe), stop_after))
+        return x
+
+    def encoder(self, feats, layer_taps=False):
+        feats = _c(feats)
+        B, Tm, _ = feats.shape
+        T = subsampled_len(Tm)
+        out = _out((B, T, self.cfg.hidden_size), np.float32)
+        taps = _out((self.cfg.num_layers, B, T, self.cfg.hidden_size), np.float32) if layer_taps else None
+        self._chk(lib().orc_encoder(self._h, _f(feats), B, Tm, _f(out), _f(taps) if layer_taps else None))
+        return (out, taps) if layer_taps else out
+
+    def ctc_logprobs(self, enc):
+        enc = _c(enc)
+        B, T, _ = enc.shape
+        V = self.cfg.ctc_vocab_size
+        lp = _out((B, T, V), np.float32)
+        self._chk(lib().orc_ctc_logprobs(self._h, _f(enc), B, T, _f(lp)))
+        return lp
+
+    def tdt_greedy(self, enc, max_tokens=None, max_steps=0, first_logp=False):
+        enc = _c(enc)
+        B, T, _ = enc.shape
+        mt = max_tokens or (T * self.cfg.max_symbols_per_step)
+        ids = np.zeros((B, mt), np.int32); st = np.zeros((B, mt), np.int32); en = np.zeros((B, mt), np.int32)
+        cf = np.zeros((B, mt), np.float32); lens = np.zeros(B, np.int32); steps = np.zeros(B, np.int32)
+        fl = np.zeros((B, self.cfg.vocab_size), np.float32) if first_logp else None
+        r = self._chk(lib().orc_tdt_greedy(self._h, _f(enc), B, T, mt, max_steps, _i(ids), _i(lens), _i(st), _i(en),
+                                           _f(cf), _i(steps), _f(fl) if first_logp else None))
+        res = dict(ids=ids, lens=lens, start=st, end=en, conf=cf, steps=steps, overflow=bool(r))
+        if first_logp:
+            res["first_logp"] = fl
+        return res
+
+    def rnnt_greedy(self, enc, max_tokens=None):
+        enc = _c(enc)
+        B, T, _ = enc.shape
+        mt = max_tokens or (T * self.cfg.max_symbols_per_step)
+        ids = np.zeros((B, mt), np.int32); st = np.zeros((B, mt), np.int32)
+        cf = np.zeros((B, mt), np.float32); lens = np.zeros(B, np.int32)
+        self._chk(lib().orc_rnnt_greedy(self._h, _f(enc), B, T, mt, _i(ids), _i(lens), _i(st), _f(cf)))
+        return dict(ids=ids, lens=lens, start=st, conf=cf)
+
+
+def ctc_greedy(logp, blank_id):
+    """ctc_greedy_decode(+_with_timestamps): src/ctc.cpp:40-127."""
+    logp = _c(logp)
+    B, T, V = logp.shape
+    ids = np.zeros((B, T), np.int32); st = np.zeros((B, T), np.int32); en = np.zeros((B, T), np.int32)
+    cf = np.zeros((B, T), np.float32); lens = np.zeros(B, np.int32)
+    lib().orc_ctc_greedy(_f(logp), B, T, V, blank_id, _i(ids), _i(lens), _i(st), _i(en), _f(cf))
+    return dict(ids=ids, lens=lens, start=st, end=en, conf=cf)
+
+
+def set_threads(n):
+    lib().orc_set_threads(n)
+
+
+def max_threads():
+    return lib().orc_get_max_threads()

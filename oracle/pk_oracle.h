@@ -1,0 +1,75 @@
+/*
+ * oracle/pk_oracle.h -- C interface of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+ * See pk_oracle.c for the parity status and the reference citations.
+ */
+#ifndef PK_ORACLE_H
+#define PK_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* include/parakeet/audio.hpp:7-17 (AudioConfig) + switches A1/A2 */
+typedef struct {
+    int sample_rate;     /* 16000 */
+    int n_fft;           /* 512 */
+    int win_length;      /* 400 */
+    int hop_length;      /* 160 */
+    int n_mels;          /* 80 / 128 */
+    float f_min;         /* 0 */
+    float f_max;         /* <=0 -> sample_rate/2 */
+    int normalize;       /* 1 */
+    int window_centered; /* A1: 1 = torch.stft placement (default), 0 = left-aligned */
+    int power_via_abs;   /* A2: 1 = abs() then square (literal reference, default), 0 = re^2+im^2 */
+} orc_audio_config;
+
+/* include/parakeet/config.hpp:9-95 flattened + switches A3/A5 */
+typedef struct {
+    int mel_bins, sub_channels, d_model, n_layers, n_heads, ffn, conv_k;
+    int vocab;        /* joint label vocab incl. blank */
+    int pred_hidden, lstm_layers, joint_hidden;
+    int n_durations;
+    int durations[8];
+    int blank_id;     /* tdt.hpp:71-74 default 1024 */
+    int max_symbols;  /* 10 */
+    float ln_eps;     /* A3: 1e-5 */
+    float bn_eps;     /* A3: 1e-5 */
+    int joint_pred_bias; /* A5: 0 = drop (literal reference), 1 = add (NeMo) */
+    char joint_prefix[32]; /* "tdt_joint_." (110M hybrid) or "joint_." (TDT/RNNT 600M) */
+} orc_config;
+
+typedef struct orc_model orc_model;
+
+const char *orc_last_error(void);
+void orc_set_threads(int n);
+int orc_get_max_threads(void);
+
+void orc_math_v(int fn, const float *in, float *out, int64_t n);
+float orc_sum64_f(const float *x, int64_t n);
+void orc_linear(int M, int N, int K, const float *A, const float *W, const float *bias, float *out);
+void orc_linear_scalar(int M, int N, int K, const float *A, const float *W, const float *bias, float *out);
+void orc_layer_norm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y);
+
+orc_model *orc_model_new(const orc_config *cfg);
+void orc_model_free(orc_model *m);
+int orc_model_add(orc_model *m, const char *name, const float *data, int ndim, const int64_t *shape);
+
+void orc_mel_filterbank(int n_freqs, int n_mels, float sample_rate, float f_min, float f_max, float *fb);
+int orc_mel_num_frames(int64_t n_samples, int hop);
+int orc_mel(const orc_audio_config *ac, const float *pcm, int64_t n, float *out, float *logmel_tap);
+void orc_pos_emb(int seq_len, int d_model, float *pe);
+int orc_subsampled_len(int n_mel_frames);
+int orc_subsampling(orc_model *m, const float *feats, int B, int Tm, float *out, float *tap_conv1, float *tap_stage3);
+int orc_conformer_block(orc_model *m, int layer, float *x, int B, int T, const float *pos_emb, int stop_after);
+int orc_encoder(orc_model *m, const float *feats, int B, int Tm, float *out, float *layer_taps);
+int orc_ctc_logprobs(orc_model *m, const float *enc, int B, int T, float *logp);
+void orc_ctc_greedy(const float *logp, int B, int T, int V, int blank_id, int32_t *ids, int32_t *lens,
+                    int32_t *start, int32_t *end, float *conf);
+int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, int32_t *ids,
+                   int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps, float *first_label_logp);
+int orc_rnnt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens, int32_t *ids, int32_t *lens,
+                    int32_t *start, float *conf);
+#ifdef __cplusplus
+}
+#endif
+#endif

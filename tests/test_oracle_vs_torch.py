@@ -1,0 +1,90 @@
+"""The C oracle against an independent torch-CPU restatement (the reference itself cannot be
+built here: its arithmetic is the un-vendored axiom submodule).  fp32 round-off tolerances."""
+import numpy as np
+import pytest
+
+import torch_ref
+from parakeet_cpp_amd import synth
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+@pytest.mark.parametrize("n_mels,n", [(80, 16000), (128, 24000), (80, 5433)])
+def test_mel_matches_torch_stft(orc, n_mels, n):
+    pcm = synth.synth_pcm(1, n, seed=5)[0]
+    feats, logmel = orc.mel(pcm, n_mels=n_mels, return_logmel=True)
+    fb = orc.mel_filterbank(n_mels=n_mels)
+    tf, tl = torch_ref.mel_features(pcm, fb, n_mels=n_mels)
+    assert feats.shape == (1 + n // 160, n_mels)
+    assert np.max(np.abs(logmel - tl)) < 2e-3          # log amplifies round-off in near-empty bins
+    assert np.max(np.abs(feats - tf)) < 2e-3
+
+
+def test_mel_left_aligned_window_switch(orc):
+    """Switch A1: the reference author's check script left-aligns the window (compare_features.py:33-37)."""
+    pcm = synth.synth_pcm(1, 16000, seed=6)[0]
+    feats = orc.mel(pcm, window_centered=False)
+    tf, _ = torch_ref.mel_features(pcm, orc.mel_filterbank(), window_centered=False)
+    assert np.max(np.abs(feats - tf)) < 2e-3
+    assert np.max(np.abs(feats - orc.mel(pcm))) > 1e-2   # the two placements are genuinely different
+
+
+def test_filterbank_matches_slaney_formula(orc):
+    fb = orc.mel_filterbank(n_mels=80)
+    assert fb.shape == (257, 80)
+    assert np.all(fb >= 0) and np.all(fb.sum(0) > 0)
+    # Slaney area normalisation: every triangle integrates to ~1 over Hz (bin width 31.25 Hz)
+    area = fb.sum(0) * 31.25
+    assert np.all(np.abs(area[5:] - 1.0) < 0.15)
+
+
+def test_subsampling_matches_torch(orc, tiny_cfg, tiny_weights, tiny_oracle):
+    feats = np.random.default_rng(0).standard_normal((2, 203, tiny_cfg.mel_bins)).astype(np.float32)
+    out = tiny_oracle.subsampling(feats)
+    ref = torch_ref.subsampling(tiny_weights, feats)
+    assert out.shape == ref.shape == (2, 26, tiny_cfg.hidden_size)
+    assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("stop", [1, 2, 3, 4, 0])
+def test_conformer_block_matches_torch(orc, tiny_cfg, tiny_weights, tiny_oracle, stop):
+    x = np.random.default_rng(1).standard_normal((2, 37, tiny_cfg.hidden_size)).astype(np.float32)
+    pe = orc.pos_emb(37, tiny_cfg.hidden_size)
+    out = tiny_oracle.conformer_block(1, x, pe, stop_after=stop)
+    ref = torch_ref.conformer_block(tiny_weights, 1, x, pe, tiny_cfg.num_heads, stop_after=stop)
+    assert rel_err(out, ref) < 2e-5
+
+
+def test_pos_emb_matches_numpy_float(orc):
+    pe = orc.pos_emb(20, 64)
+    ref = torch_ref.pos_emb(20, 64)
+    assert np.max(np.abs(pe - ref)) < 1e-6
+
+
+def test_encoder_ctc_tdt_match_torch(orc, tiny_cfg, tiny_weights, tiny_oracle):
+    pcm = synth.synth_pcm(3, 32000, seed=9)
+    feats = np.stack([orc.mel(p) for p in pcm])
+    enc = tiny_oracle.encoder(feats)
+    ref = torch_ref.encoder(tiny_weights, tiny_cfg, feats)
+    assert rel_err(enc, ref) < 5e-5
+    lp = tiny_oracle.ctc_logprobs(enc)
+    assert np.max(np.abs(lp - torch_ref.ctc_logprobs(tiny_weights, enc))) < 1e-4
+    r = tiny_oracle.tdt_greedy(enc, max_steps=4000)
+    tids = torch_ref.tdt_greedy(tiny_weights, tiny_cfg, enc, max_steps=4000)
+    assert not r["overflow"]
+    for b in range(3):
+        assert r["ids"][b, : r["lens"][b]].tolist() == tids[b]
+
+
+def test_full_width_block_matches_torch(orc):
+    """One real-size (d=512, 8 heads, ffn 2048) layer, T=126."""
+    import dataclasses
+    from conftest import pk
+    cfg = dataclasses.replace(pk.make_110m_config(), num_layers=1)
+    W = synth.synth_weights(cfg, seed=3)
+    m = orc.Model(cfg, W)
+    x = np.random.default_rng(2).standard_normal((1, 126, 512)).astype(np.float32)
+    pe = orc.pos_emb(126, 512)
+    assert rel_err(m.conformer_block(0, x, pe), torch_ref.conformer_block(W, 0, x, pe, 8)) < 2e-5

@@ -1,0 +1,169 @@
+"""A second, independent restatement of the reference hot path in torch-CPU ops
+(F.conv2d, F.layer_norm, torch.stft, ...), modelled on the reference author's own
+scripts/compare_encoder.py:24-284 and scripts/compare_features.py:22-57.  It exists only
+to catch transcription errors in the C oracle (tests/test_oracle_vs_torch.py): the two
+agree to fp32 round-off, not bit-for-bit (torch picks its own summation orders)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def mel_features(pcm, fb, n_mels=80, window_centered=True):
+    x = t(pcm).to(torch.float32)
+    x = torch.cat([x[:1], x[1:] - 0.97 * x[:-1]])                       # src/audio.cpp:104-114
+    win = torch.hann_window(400, periodic=False, dtype=torch.float64).to(torch.float32)
+    w = torch.zeros(512)
+    off = 56 if window_centered else 0
+    w[off:off + 400] = win
+    st = torch.stft(x, n_fft=512, hop_length=160, win_length=512, window=w, center=True,
+                    pad_mode="reflect", return_complex=True)            # :117-120
+    power = st.abs() ** 2                                               # :123-124
+    mel = t(fb).T @ power                                               # :132
+    logmel = torch.log(mel + 2.0 ** -24)                                # :135-136
+    mean = logmel.mean(dim=1, keepdim=True)
+    std = logmel.std(dim=1, keepdim=True, correction=1)                 # :140-149
+    return ((logmel - mean) / (std + 1e-5)).T.contiguous().numpy(), logmel.numpy()
+
+
+def subsampling(W, feats):
+    p = "encoder_.subsampling_."
+    x = t(feats).unsqueeze(1)
+    C = W[p + "conv1_.weight"].shape[0]
+    x = F.relu(F.conv2d(x, t(W[p + "conv1_.weight"]), t(W[p + "conv1_.bias"]), stride=2, padding=1))
+    x = F.conv2d(x, t(W[p + "dw1_.weight"]), t(W[p + "dw1_.bias"]), stride=2, padding=1, groups=C)
+    x = F.relu(F.conv2d(x, t(W[p + "conv2_.weight"]), t(W[p + "conv2_.bias"])))
+    x = F.conv2d(x, t(W[p + "dw2_.weight"]), t(W[p + "dw2_.bias"]), stride=2, padding=1, groups=C)
+    x = F.relu(F.conv2d(x, t(W[p + "conv3_.weight"]), t(W[p + "conv3_.bias"])))
+    b, c, tt, f = x.shape
+    x = x.permute(0, 2, 1, 3).reshape(b, tt, c * f)
+    return F.linear(x, t(W[p + "proj_.weight"]), t(W[p + "proj_.bias"])).numpy()
+
+
+def rel_shift(x):                                                       # src/encoder.cpp:85-109, literally
+    b, h, n, p = x.shape
+    x = F.pad(x, (1, 0))
+    x = x.reshape(b, h, p + 1, n)[:, :, 1:, :].reshape(b, h, n, p)
+    return x[..., :n]
+
+
+def conformer_block(W, layer, x, pe, n_heads, stop_after=0):
+    q = f"encoder_.layers_.{layer}."
+    x = t(x)
+    d = x.shape[-1]
+
+    def ln(name, v):
+        return F.layer_norm(v, (d,), t(W[q + name + ".weight"]), t(W[q + name + ".bias"]), 1e-5)
+
+    def ffn(name, v):
+        h = F.linear(ln(name + ".norm_", v), t(W[q + name + ".fc1_.weight"]), t(W[q + name + ".fc1_.bias"]))
+        h = F.linear(F.silu(h), t(W[q + name + ".fc2_.weight"]), t(W[q + name + ".fc2_.bias"]))
+        return v + 0.5 * h
+
+    x = ffn("ffn1_", x)
+    if stop_after == 1:
+        return x.numpy()
+    # attention  src/encoder.cpp:111-186
+    n = ln("attn_.norm_", x)
+    B, T, _ = n.shape
+    hd = d // n_heads
+    qq = F.linear(n, t(W[q + "attn_.mha_.q_proj.weight"]), t(W[q + "attn_.mha_.q_proj.bias"])).view(B, T, n_heads, hd).transpose(1, 2)
+    kk = F.linear(n, t(W[q + "attn_.mha_.k_proj.weight"]), t(W[q + "attn_.mha_.k_proj.bias"])).view(B, T, n_heads, hd).transpose(1, 2)
+    vv = F.linear(n, t(W[q + "attn_.mha_.v_proj.weight"]), t(W[q + "attn_.mha_.v_proj.bias"])).view(B, T, n_heads, hd).transpose(1, 2)
+    u = t(W[q + "attn_.pos_bias_u_"]).view(1, n_heads, 1, hd)
+    v_ = t(W[q + "attn_.pos_bias_v_"]).view(1, n_heads, 1, hd)
+    p = F.linear(t(pe), t(W[q + "attn_.pos_proj_.weight"])).view(1, -1, n_heads, hd).transpose(1, 2)
+    content = (qq + u) @ kk.transpose(-1, -2)
+    pos = rel_shift((qq + v_) @ p.transpose(-1, -2))
+    a = torch.softmax((content + pos) * (1.0 / math.sqrt(hd)), dim=-1)
+    o = (a @ vv).transpose(1, 2).reshape(B, T, d)
+    x = x + F.linear(o, t(W[q + "attn_.mha_.out_proj.weight"]), t(W[q + "attn_.mha_.out_proj.bias"]))
+    if stop_after == 2:
+        return x.numpy()
+    # conv module  src/encoder.cpp:59-75
+    n = ln("conv_.norm_", x).transpose(1, 2)
+    y = F.glu(F.conv1d(n, t(W[q + "conv_.pointwise_conv1_.weight"]), t(W[q + "conv_.pointwise_conv1_.bias"])), dim=1)
+    K = W[q + "conv_.depthwise_conv_.weight"].shape[-1]
+    y = F.conv1d(y, t(W[q + "conv_.depthwise_conv_.weight"]), t(W[q + "conv_.depthwise_conv_.bias"]), padding=(K - 1) // 2, groups=d)
+    y = F.batch_norm(y, t(W[q + "conv_.batch_norm_.running_mean"]), t(W[q + "conv_.batch_norm_.running_var"]),
+                     t(W[q + "conv_.batch_norm_.weight"]), t(W[q + "conv_.batch_norm_.bias"]), training=False, eps=1e-5)
+    y = F.conv1d(F.silu(y), t(W[q + "conv_.pointwise_conv2_.weight"]), t(W[q + "conv_.pointwise_conv2_.bias"]))
+    x = x + y.transpose(1, 2)
+    if stop_after == 3:
+        return x.numpy()
+    x = ffn("ffn2_", x)
+    if stop_after == 4:
+        return x.numpy()
+    return ln("final_norm_", x).numpy()
+
+
+def pos_emb(T, d):                                                      # src/encoder.cpp:9-30 (float math)
+    pe = np.zeros((2 * T - 1, d), np.float32)
+    for p in range(2 * T - 1):
+        pos = np.float32(T - 1 - p)
+        i = np.arange(0, d, 2, dtype=np.float32)
+        div = np.exp(i * np.float32(-np.log(np.float32(10000.0)) / np.float32(d))).astype(np.float32)
+        pe[p, 0::2] = np.sin(pos * div)
+        pe[p, 1::2] = np.cos(pos * div)
+    return pe
+
+
+def encoder(W, cfg, feats):
+    x = subsampling(W, feats)
+    pe = pos_emb(x.shape[1], x.shape[2])
+    for l in range(cfg.num_layers):
+        x = conformer_block(W, l, x, pe, cfg.num_heads)
+    return x
+
+
+def ctc_logprobs(W, enc):
+    w = t(W["ctc_decoder_.proj_.weight"]).squeeze(-1)
+    return torch.log_softmax(F.linear(t(enc), w, t(W["ctc_decoder_.proj_.bias"])), dim=-1).numpy()
+
+
+def tdt_greedy(W, cfg, enc, max_steps=100000):
+    """src/tdt.cpp:36-110 with src/rnnt.cpp:22-28 and src/lstm.cpp:11-49, one utterance at a time."""
+    jp = cfg.joint_prefix
+    E = t(W["prediction_.embed_.weight"])
+    L, Hp = cfg.num_lstm_layers, cfg.pred_hidden
+    out = []
+    for b in range(enc.shape[0]):
+        e = t(enc[b])
+        ep = F.linear(e, t(W[jp + "enc_proj_.weight"]), t(W[jp + "enc_proj_.bias"]))
+        h = [torch.zeros(Hp) for _ in range(L)]
+        c = [torch.zeros(Hp) for _ in range(L)]
+        tok, tt, ids, steps = cfg.blank_id, 0, [], 0
+        T = e.shape[0]
+        while tt < T and steps < max_steps:
+            for _ in range(cfg.max_symbols_per_step):
+                sh, sc = [v.clone() for v in h], [v.clone() for v in c]
+                x = E[tok]
+                for l in range(L):
+                    g = F.linear(x, t(W[f"prediction_.lstm_.cells_.{l}.input_proj_.weight"]), t(W[f"prediction_.lstm_.cells_.{l}.input_proj_.bias"])) \
+                        + F.linear(h[l], t(W[f"prediction_.lstm_.cells_.{l}.hidden_proj_.weight"]))
+                    i, f, gg, o = g.chunk(4)
+                    c[l] = torch.sigmoid(f) * c[l] + torch.sigmoid(i) * torch.tanh(gg)
+                    h[l] = torch.sigmoid(o) * torch.tanh(c[l])
+                    x = h[l]
+                z = F.relu(ep[tt] + F.linear(x, t(W[jp + "pred_proj_.weight"])))
+                lab = torch.log_softmax(F.linear(z, t(W[jp + "label_proj_.weight"]), t(W[jp + "label_proj_.bias"])), -1)
+                dur = torch.log_softmax(F.linear(z, t(W[jp + "duration_proj_.weight"]), t(W[jp + "duration_proj_.bias"])), -1)
+                steps += 1
+                k, di = int(lab.argmax()), int(dur.argmax())
+                skip = cfg.durations[di] if di < len(cfg.durations) else 1
+                if k == cfg.blank_id:
+                    h, c = sh, sc
+                    tt += max(skip, 1)
+                    break
+                ids.append(k)
+                tok = k
+                if skip > 0:
+                    tt += skip
+                    break
+        out.append(ids)
+    return out
