@@ -1,0 +1,194 @@
+/*
+ * include/parakeet_amd.h -- C ABI of the MI355X-native Parakeet hot path
+ * (libparakeet_amd.so, built from parakeet.cpp_amd/csrc by hipcc for gfx950).
+ *
+ * The reference (Frikallo/parakeet.cpp) has NO plugin / FFI interface: its
+ * boundary is the header-only C++ class API in include/parakeet/transcribe.hpp,
+ * which calls axiom::Tensor methods directly; a flat C API is an unchecked
+ * roadmap item (README.md:518).  This header is therefore the C ABI that the
+ * reference's classes would bind if they delegated their arithmetic: each entry
+ * point cites the reference interface it replaces.  The source-compatible C++
+ * facade (parakeet::Transcriber, TDTTranscriber, TranscribeResult, ...) that sits
+ * on top of it lives in parakeet.cpp_amd/include/parakeet/ ; INTEGRATION.md shows
+ * the binding a reference maintainer would add.
+ *
+ * Conventions: plain C types only; the caller owns every input buffer; outputs
+ * are caller-allocated unless the function returns an opaque handle, which the
+ * library owns until the matching *_free.  Every function returns PK_OK (0) or
+ * a negative pk_status; pk_last_error() holds the message (thread-local).
+ * Host pointers unless a parameter is named dev_*.  One pk_model may be used
+ * from one thread at a time (the reference's objects are not thread-safe
+ * either: vocab.hpp:33-35).  There is no CPU fallback: every compute entry point
+ * fails with PK_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef PARAKEET_AMD_H
+#define PARAKEET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int pk_status;
+enum {
+    PK_OK = 0,
+    PK_ERR_INVALID = -1,     /* bad argument / shape */
+    PK_ERR_IO = -2,          /* unreadable weights / vocab / audio (reference: std::runtime_error, vocab.cpp:12-14, audio_io.cpp:271-286) */
+    PK_ERR_WEIGHTS = -3,     /* missing tensor or wrong shape (the reference loads non-strict, transcribe.hpp:63; we are strict) */
+    PK_ERR_NO_DEVICE = -4,   /* no usable gfx950 device / model not on the GPU */
+    PK_ERR_HIP = -5,         /* HIP runtime failure */
+    PK_ERR_DECODE_CAP = -6,  /* TDT loop hit the safety cap on joint evaluations (the reference has none, tdt.cpp:62-106) */
+    PK_ERR_UNSUPPORTED = -7
+};
+
+/* include/parakeet/config.hpp:9-95 (EncoderConfig, PredictionConfig, JointConfig, TDTCTCConfig) flattened. */
+typedef struct pk_config {
+    int32_t mel_bins;              /* EncoderConfig::mel_bins            80 / 128 */
+    int32_t subsampling_channels;  /* EncoderConfig::subsampling_channels 256 */
+    int32_t hidden_size;           /* EncoderConfig::hidden_size          512 / 1024 */
+    int32_t num_layers;            /* 17 / 24 */
+    int32_t num_heads;             /* 8 */
+    int32_t ffn_intermediate;      /* 2048 / 4096 */
+    int32_t conv_kernel_size;      /* 9 */
+    int32_t vocab_size;            /* joint label vocab incl. blank: 1025 / 8193 */
+    int32_t pred_hidden;           /* 640 */
+    int32_t num_lstm_layers;       /* 1 / 2 */
+    int32_t joint_hidden;          /* 640 */
+    int32_t num_durations;         /* TDT: 5 ; RNNT head: 0 */
+    int32_t durations[8];          /* {0,1,2,3,4} */
+    int32_t ctc_vocab_size;        /* 1025, or 0 when the model has no ctc_decoder_ */
+    int32_t blank_id;              /* tdt.hpp:71-74 default 1024 ; 600M: vocab_size-1 (main.cpp:252) */
+    int32_t max_symbols_per_step;  /* 10 */
+    int32_t joint_pred_bias;       /* switch A5: 0 = drop pred_proj_.bias like the reference's Linear(bias=false) (tdt.cpp:10-11) */
+    int32_t rnnt_head;             /* 1: joint has a single out_proj_ (rnnt.cpp:37-44) instead of label_/duration_proj_ */
+    char joint_prefix[32];         /* "tdt_joint_." (tdt_ctc.cpp:5-9) or "joint_." (tdt.cpp:28-32) */
+} pk_config;
+
+/* make_110m_config / make_tdt_600m_config / make_rnnt_600m_config (config.hpp:77-135). name: "tdt-ctc-110m" | "tdt-600m" | "rnnt-600m". */
+pk_status pk_config_preset(const char *name, pk_config *out);
+
+typedef struct pk_model pk_model;
+
+const char *pk_version(void);
+/* Copies the calling thread's last error message; returns its length. */
+size_t pk_last_error(char *buf, size_t cap);
+int pk_device_count(void);
+
+/* ---- model lifetime: Transcriber::Transcriber (transcribe.hpp:59-65), to_gpu() (:68-71) ------------------ */
+/* safetensors with the reference's tensor names (scripts/convert_nemo.py:98-310); vocab_path may be NULL. */
+pk_status pk_model_load(const char *safetensors_path, const char *vocab_path, const pk_config *cfg, pk_model **out);
+/* Upload (packed) weights to HBM on `device` and build the execution plan.  Idempotent per device. */
+pk_status pk_model_to_gpu(pk_model *m, int device);
+void pk_model_free(pk_model *m);
+pk_status pk_model_config(const pk_model *m, pk_config *out);
+
+/* ---- stage entry points (host buffers; used by the parity tests and the C++ facade) ----------------------- */
+/* preprocess_audio (src/audio.cpp:100-158): n_clips clips of n_samples each -> feats[n_clips][n_frames][mel_bins],
+ * n_frames = 1 + n_samples/160.  logmel (optional, may be NULL): [n_clips][mel_bins][n_frames] before normalisation. */
+pk_status pk_mel(pk_model *m, const float *pcm, int n_clips, int64_t n_samples, float *feats, float *logmel);
+int pk_mel_num_frames(int64_t n_samples);
+int pk_encoder_num_frames(int n_mel_frames); /* floor((n-1)/2)+1 three times (encoder.cpp:208-217) */
+
+/* FastConformerEncoder::forward (src/encoder.cpp:253-271): feats[B][Tm][mel] -> enc[B][T][hidden].
+ * stop_layer / stop_stage cut the pipeline for stage-wise parity checks: run `stop_layer` full blocks, then the
+ * next block up to stop_stage (0 none, 1 ffn1, 2 +attn, 3 +conv, 4 +ffn2); pass (num_layers, 0) -- or (-1, 0) -- for all. */
+pk_status pk_encode(pk_model *m, const float *feats, int B, int Tm, int stop_layer, int stop_stage, float *enc);
+/* ConvSubsampling::forward only (src/encoder.cpp:219-241). */
+pk_status pk_subsample(pk_model *m, const float *feats, int B, int Tm, float *out);
+
+/* CTCDecoder::forward + ctc_greedy_decode(_with_timestamps) (src/ctc.cpp:12-25, :40-127).
+ * ids/start/end/conf: [B][T] (NULL to skip the optional ones); lens[B]; logp (optional) [B][T][ctc_vocab]. */
+pk_status pk_ctc_decode(pk_model *m, const float *enc, int B, int T, int32_t *ids, int32_t *lens, int32_t *start,
+                        int32_t *end, float *conf, float *logp);
+/* tdt_greedy_decode(_with_timestamps) (src/tdt.cpp:36-201; RNNT head: src/rnnt.cpp:56-177).
+ * ids/start/end/conf: [B][max_tokens]; lens[B] (-1 if the safety cap hit); steps[B] joint evaluations (optional). */
+pk_status pk_tdt_decode(pk_model *m, const float *enc, int B, int T, int max_tokens, int32_t *ids, int32_t *lens,
+                        int32_t *start, int32_t *end, float *conf, int32_t *steps);
+
+/* ---- resident batch pipeline (device buffers; what bench.py times) ---------------------------------------- */
+typedef struct pk_batch pk_batch;
+enum { PK_DECODER_CTC = 0, PK_DECODER_TDT = 1 }; /* enum class Decoder (transcribe.hpp:34) */
+/* A batch slot of up to max_clips clips of exactly n_samples samples, all buffers resident in HBM. */
+pk_status pk_batch_create(pk_model *m, int max_clips, int64_t n_samples, pk_batch **out);
+void pk_batch_free(pk_batch *b);
+/* Host -> HBM copy of the PCM (outside bench's timed region). */
+pk_status pk_batch_upload(pk_batch *b, const float *pcm, int n_clips);
+/* mel -> encoder -> decode, enqueued on the batch's stream; returns without synchronising. */
+pk_status pk_batch_run(pk_batch *b, int decoder);
+pk_status pk_batch_sync(pk_batch *b);
+/* Token ids etc. of the last run (synchronises).  Arrays [n_clips][max_tokens]; max_tokens = pk_batch_max_tokens. */
+int pk_batch_max_tokens(const pk_batch *b);
+pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
+/* Stage timers of the last pk_batch_run_timed (ms): mel, encoder, decode, total (hipEvents on the batch stream). */
+pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]);
+/* Raw device pointers for zero-copy producers (e.g. torch tensors): PCM [max_clips][n_samples] f32. */
+void *pk_batch_dev_pcm(pk_batch *b);
+void *pk_batch_stream(pk_batch *b);
+
+/* Per-kernel timing of ONE pk_batch_run with hipEvents around every launch (slow; for the roofline object only).
+ * Fills up to cap records; returns the number of distinct kernels. */
+typedef struct pk_kernel_stat {
+    char name[64];
+    int32_t launches;
+    float total_ms;
+    double flops;  /* algorithmic flops of those launches (0 for memory-bound kernels) */
+    double bytes;  /* algorithmic HBM bytes of those launches */
+} pk_kernel_stat;
+int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap);
+
+/* ---- one-call API: Transcriber::transcribe (transcribe.hpp:74-179) ---------------------------------------- */
+typedef struct pk_options {     /* TranscribeOptions (transcribe.hpp:38-43); boost phrases are out of scope */
+    int32_t decoder;            /* PK_DECODER_* */
+    int32_t timestamps;
+} pk_options;
+typedef struct pk_word {        /* WordTimestamp (timestamp.hpp:18-23) */
+    const char *word;
+    float start, end, confidence;
+} pk_word;
+typedef struct pk_result {      /* TranscribeResult (transcribe.hpp:23-30) + TimestampedToken (timestamp.hpp:11-16) */
+    const char *text;
+    int32_t n_tokens;
+    const int32_t *token_ids;
+    const int32_t *start_frame; /* NULL unless options.timestamps */
+    const int32_t *end_frame;
+    const float *confidence;
+    int32_t n_words;
+    const pk_word *words;
+} pk_result;
+/* Clips are pcm[offsets[i] .. offsets[i+1]); clips of equal length are batched together on the GPU.
+ * results: array of n_clips pk_result, owned by the library until pk_results_free. */
+pk_status pk_transcribe_pcm(pk_model *m, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt,
+                            pk_result **results);
+void pk_results_free(pk_result *results, int n_clips);
+/* read_audio (audio_io.cpp:453-483) restricted to RIFF/WAVE PCM16 / float32; mono-downmix; must be 16 kHz.
+ * Returns a malloc'd buffer the caller frees with pk_free. */
+pk_status pk_read_wav(const char *path, float **pcm, int64_t *n_samples, int *sample_rate);
+void pk_free(void *p);
+
+/* ---- host-side text (src/vocab.cpp:29-117, src/timestamp.cpp:24-111) -------------------------------------- */
+int pk_vocab_size(const pk_model *m);
+/* Tokenizer::decode -> returns needed length; writes at most cap-1 bytes + NUL. */
+int pk_detokenize(const pk_model *m, const int32_t *ids, int n, char *out, int cap);
+/* Tokenizer::encode (greedy longest match) -> number of ids (writes at most cap). */
+int pk_tokenize(const pk_model *m, const char *text, int32_t *ids, int cap);
+/* group_timestamps: words '\n'-joined into `words`; returns the word count. sentences!=0 -> TimestampMode::Sentences. */
+int pk_group_timestamps(const pk_model *m, const int32_t *ids, const int32_t *start, const int32_t *end, const float *conf,
+                        int n, int sentences, char *words, int cap, float *wstart, float *wend, float *wconf, int wcap);
+
+/* ---- diagnostics used by the GPU parity tests (single kernels behind the same ABI) ------------------------ */
+/* Device math, elementwise: fn 0 exp, 1 log, 2 tanh, 3 sigmoid, 4 silu, 5 sqrt, 6 reciprocal. */
+pk_status pk_diag_math(int fn, const float *in, float *out, int64_t n);
+/* out[M][N] = epi(A[M][K] * W[N][K]^T + bias) with the production fp32-MFMA GEMM.  epi: 0 none, 1 relu, 2 silu,
+ * 3 residual: out = resid + alpha*(acc+bias), 4 glu (N even: out[M][N/2] = a * sigmoid(b)). */
+pk_status pk_diag_gemm(int M, int N, int K, const float *A, const float *W, const float *bias, int epi,
+                       const float *resid, float alpha, float *out);
+pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y);
+/* sum64 of each row of x[rows][n] (the canonical wavefront reduction). */
+pk_status pk_diag_sum64(const float *x, int rows, int n, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARAKEET_AMD_H */

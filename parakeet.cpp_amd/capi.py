@@ -1,0 +1,253 @@
+"""ctypes binding of include/parakeet_amd.h (libparakeet_amd.so).  Plumbing for tests and bench.py.
+Fails loudly if the HIP library is missing -- there is no Python / CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .config import ModelConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libparakeet_amd.so")
+_LIB = None
+
+f32p, i32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+
+class PkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pk_status {code}: {msg}")
+        self.code = code
+
+
+class PkConfig(C.Structure):
+    _fields_ = [("mel_bins", C.c_int32), ("subsampling_channels", C.c_int32), ("hidden_size", C.c_int32),
+                ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_intermediate", C.c_int32),
+                ("conv_kernel_size", C.c_int32), ("vocab_size", C.c_int32), ("pred_hidden", C.c_int32),
+                ("num_lstm_layers", C.c_int32), ("joint_hidden", C.c_int32), ("num_durations", C.c_int32),
+                ("durations", C.c_int32 * 8), ("ctc_vocab_size", C.c_int32), ("blank_id", C.c_int32),
+                ("max_symbols_per_step", C.c_int32), ("joint_pred_bias", C.c_int32), ("rnnt_head", C.c_int32),
+                ("joint_prefix", C.c_char * 32)]
+
+
+class PkKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int32), ("total_ms", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+class PkOptions(C.Structure):
+    _fields_ = [("decoder", C.c_int32), ("timestamps", C.c_int32)]
+
+
+class PkWord(C.Structure):
+    _fields_ = [("word", C.c_char_p), ("start", C.c_float), ("end", C.c_float), ("confidence", C.c_float)]
+
+
+class PkResult(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("n_tokens", C.c_int32), ("token_ids", i32p), ("start_frame", i32p),
+                ("end_frame", i32p), ("confidence", f32p), ("n_words", C.c_int32), ("words", C.POINTER(PkWord))]
+
+
+def to_pk_config(cfg: ModelConfig) -> PkConfig:
+    c = PkConfig()
+    c.mel_bins, c.subsampling_channels, c.hidden_size = cfg.mel_bins, cfg.subsampling_channels, cfg.hidden_size
+    c.num_layers, c.num_heads, c.ffn_intermediate = cfg.num_layers, cfg.num_heads, cfg.ffn_intermediate
+    c.conv_kernel_size, c.vocab_size, c.pred_hidden = cfg.conv_kernel_size, cfg.vocab_size, cfg.pred_hidden
+    c.num_lstm_layers, c.joint_hidden, c.num_durations = cfg.num_lstm_layers, cfg.joint_hidden, len(cfg.durations)
+    for i, d in enumerate(cfg.durations):
+        c.durations[i] = d
+    c.ctc_vocab_size, c.blank_id, c.max_symbols_per_step = cfg.ctc_vocab_size, cfg.blank_id, cfg.max_symbols_per_step
+    c.joint_pred_bias, c.rnnt_head = 0, int(cfg.head == "rnnt")
+    c.joint_prefix = cfg.joint_prefix.encode()
+    return c
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.pk_version.restype = C.c_char_p
+    L.pk_last_error.restype = C.c_size_t
+    L.pk_last_error.argtypes = [C.c_char_p, C.c_size_t]
+    L.pk_config_preset.argtypes = [C.c_char_p, C.POINTER(PkConfig)]
+    L.pk_model_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PkConfig), C.POINTER(C.c_void_p)]
+    L.pk_model_to_gpu.argtypes = [C.c_void_p, C.c_int]
+    L.pk_model_free.argtypes = [C.c_void_p]
+    L.pk_model_config.argtypes = [C.c_void_p, C.POINTER(PkConfig)]
+    L.pk_mel.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int64, f32p, f32p]
+    L.pk_mel_num_frames.argtypes = [C.c_int64]
+    L.pk_encoder_num_frames.argtypes = [C.c_int]
+    L.pk_diag_math.argtypes = [C.c_int, f32p, f32p, C.c_int64]
+    L.pk_diag_gemm.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, C.c_int, f32p, C.c_float, f32p]
+    L.pk_diag_layernorm.argtypes = [f32p, C.c_int64, C.c_int, f32p, f32p, C.c_float, f32p]
+    L.pk_diag_sum64.argtypes = [f32p, C.c_int, C.c_int, f32p]
+    for name, at in _LATE_SIGNATURES.items():
+        if hasattr(L, name):
+            getattr(L, name).argtypes = at
+    _LIB = L
+    return L
+
+
+_LATE_SIGNATURES = {
+    "pk_encode": [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p],
+    "pk_subsample": [C.c_void_p, f32p, C.c_int, C.c_int, f32p],
+    "pk_ctc_decode": [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, f32p],
+    "pk_tdt_decode": [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, i32p],
+    "pk_batch_create": [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_void_p)],
+    "pk_batch_free": [C.c_void_p],
+    "pk_batch_upload": [C.c_void_p, f32p, C.c_int],
+    "pk_batch_run": [C.c_void_p, C.c_int],
+    "pk_batch_sync": [C.c_void_p],
+    "pk_batch_max_tokens": [C.c_void_p],
+    "pk_batch_results": [C.c_void_p, i32p, i32p, i32p, i32p, f32p],
+    "pk_batch_run_timed": [C.c_void_p, C.c_int, f32p],
+    "pk_batch_profile": [C.c_void_p, C.c_int, C.POINTER(PkKernelStat), C.c_int],
+    "pk_transcribe_pcm": [C.c_void_p, f32p, i64p, C.c_int, C.POINTER(PkOptions), C.POINTER(C.POINTER(PkResult))],
+    "pk_results_free": [C.POINTER(PkResult), C.c_int],
+    "pk_read_wav": [C.c_char_p, C.POINTER(f32p), i64p, C.POINTER(C.c_int)],
+    "pk_free": [C.c_void_p],
+    "pk_vocab_size": [C.c_void_p],
+    "pk_detokenize": [C.c_void_p, i32p, C.c_int, C.c_char_p, C.c_int],
+    "pk_tokenize": [C.c_void_p, C.c_char_p, i32p, C.c_int],
+    "pk_group_timestamps": [C.c_void_p, i32p, i32p, i32p, f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, f32p, f32p, f32p, C.c_int],
+}
+
+
+def _f(a):
+    return a.ctypes.data_as(f32p)
+
+
+def _i(a):
+    return a.ctypes.data_as(i32p)
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def check(st):
+    if st != 0:
+        buf = C.create_string_buffer(2048)
+        lib().pk_last_error(buf, 2048)
+        raise PkError(st, buf.value.decode(errors="replace"))
+
+
+def device_count():
+    return lib().pk_device_count()
+
+
+# ---- diagnostics ---------------------------------------------------------------------------------
+MATH_FN = {"exp": 0, "log": 1, "tanh": 2, "sigmoid": 3, "silu": 4, "sqrt": 5, "rcp": 6}
+EPI = {"none": 0, "relu": 1, "silu": 2, "resid": 3, "glu": 4}
+
+
+def diag_math(fn, x):
+    x = _c(x)
+    y = np.empty_like(x)
+    check(lib().pk_diag_math(MATH_FN[fn], _f(x), _f(y), x.size))
+    return y
+
+
+def diag_gemm(A, W, bias=None, epi="none", resid=None, alpha=1.0):
+    A, W = _c(A), _c(W)
+    M, K = A.shape
+    N = W.shape[0] // 2 if epi == "glu" else W.shape[0]
+    b = _c(bias) if bias is not None else None
+    r = _c(resid) if resid is not None else None
+    out = np.empty((M, N), np.float32)
+    check(lib().pk_diag_gemm(M, N, K, _f(A), _f(W), _f(b) if b is not None else None, EPI[epi],
+                             _f(r) if r is not None else None, alpha, _f(out)))
+    return out
+
+
+def diag_layernorm(x, g, b, eps=1e-5):
+    x, g, b = _c(x), _c(g), _c(b)
+    y = np.empty_like(x)
+    check(lib().pk_diag_layernorm(_f(x), x.size // x.shape[-1], x.shape[-1], _f(g), _f(b), eps, _f(y)))
+    return y
+
+
+def diag_sum64(x):
+    x = _c(x)
+    out = np.empty(x.shape[0], np.float32)
+    check(lib().pk_diag_sum64(_f(x), x.shape[0], x.shape[1], _f(out)))
+    return out
+
+
+# ---- model -------------------------------------------------------------------------------------------
+class Model:
+    """Thin handle over pk_model (mirrors parakeet::Transcriber's ctor + to_gpu(), transcribe.hpp:59-71)."""
+
+    def __init__(self, weights_path: str, cfg: ModelConfig, vocab_path: str = None, device: int = None):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        pc = to_pk_config(cfg)
+        check(lib().pk_model_load(weights_path.encode(), vocab_path.encode() if vocab_path else None, C.byref(pc), C.byref(self._h)))
+        if device is not None:
+            self.to_gpu(device)
+
+    def to_gpu(self, device: int = 0):
+        check(lib().pk_model_to_gpu(self._h, device))
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pk_model_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # stage entry points ---------------------------------------------------------------------------------
+    def mel(self, pcm, return_logmel=False):
+        pcm = _c(pcm)
+        if pcm.ndim == 1:
+            pcm = pcm[None]
+        B, n = pcm.shape
+        nf = lib().pk_mel_num_frames(n)
+        feats = np.empty((B, nf, self.cfg.mel_bins), np.float32)
+        lm = np.empty((B, self.cfg.mel_bins, nf), np.float32) if return_logmel else None
+        check(lib().pk_mel(self._h, _f(pcm), B, n, _f(feats), _f(lm) if return_logmel else None))
+        return (feats, lm) if return_logmel else feats
+
+    def subsample(self, feats):
+        feats = _c(feats)
+        B, Tm, _ = feats.shape
+        out = np.empty((B, lib().pk_encoder_num_frames(Tm), self.cfg.hidden_size), np.float32)
+        check(lib().pk_subsample(self._h, _f(feats), B, Tm, _f(out)))
+        return out
+
+    def encode(self, feats, stop_layer=-1, stop_stage=0):
+        feats = _c(feats)
+        B, Tm, _ = feats.shape
+        out = np.empty((B, lib().pk_encoder_num_frames(Tm), self.cfg.hidden_size), np.float32)
+        check(lib().pk_encode(self._h, _f(feats), B, Tm, stop_layer, stop_stage, _f(out)))
+        return out
+
+    def ctc_decode(self, enc, return_logp=False):
+        enc = _c(enc)
+        B, T, _ = enc.shape
+        ids = np.zeros((B, T), np.int32); st = np.zeros((B, T), np.int32); en = np.zeros((B, T), np.int32)
+        cf = np.zeros((B, T), np.float32); lens = np.zeros(B, np.int32)
+        lp = np.empty((B, T, self.cfg.ctc_vocab_size), np.float32) if return_logp else None
+        check(lib().pk_ctc_decode(self._h, _f(enc), B, T, _i(ids), _i(lens), _i(st), _i(en), _f(cf), _f(lp) if return_logp else None))
+        r = dict(ids=ids, lens=lens, start=st, end=en, conf=cf)
+        if return_logp:
+            r["logp"] = lp
+        return r
+
+    def tdt_decode(self, enc, max_tokens=None):
+        enc = _c(enc)
+        B, T, _ = enc.shape
+        mt = max_tokens or T * self.cfg.max_symbols_per_step
+        ids = np.zeros((B, mt), np.int32); st = np.zeros((B, mt), np.int32); en = np.zeros((B, mt), np.int32)
+        cf = np.zeros((B, mt), np.float32); lens = np.zeros(B, np.int32); steps = np.zeros(B, np.int32)
+        check(lib().pk_tdt_decode(self._h, _f(enc), B, T, mt, _i(ids), _i(lens), _i(st), _i(en), _f(cf), _i(steps)))
+        return dict(ids=ids, lens=lens, start=st, end=en, conf=cf, steps=steps)

@@ -1,0 +1,216 @@
+// parakeet.cpp_amd/csrc/kernels/gemm.hip -- fp32 MFMA GEMM with fused epilogues (gfx950).
+//
+// out[M][N] = epi(A[M][K] * W[N][K]^T + bias).  This one kernel template carries ~93 % of the
+// encoder's arithmetic: every nn::Linear / 1x1 Conv call site of the reference
+// (src/encoder.cpp:41-45 FFN, :120-122 QKV, :148 pos_proj, :177 out_proj, :63/:70 pointwise convs,
+// :227/:231 subsampling 1x1 convs, :240 proj_; src/ctc.cpp:19; src/tdt.cpp:17 enc_proj_).
+//
+// Design for CDNA4:
+//  * v_mfma_f32_32x32x2_f32: exact fp32, bit-identical to a k-ordered fmaf chain (64 FLOP/clk/SIMD,
+//    157 TF peak).  Lanes 0-31 feed k = 2s, lanes 32-63 feed k = 2s+1, so the accumulation order is
+//    the natural k = 0,1,2,... order the CPU oracle uses: results are bit-identical to the oracle.
+//  * 256-thread workgroup = 4 wavefronts in a 2x2 grid; each wave owns a (BM/2)x(BN/2) sub-tile held
+//    as TMxTN 32x32 accumulators (16 VGPRs each).
+//  * K is tiled by 32: A and W tiles are staged global -> registers (float4, 128-B rows, coalesced)
+//    -> LDS with a 33-float row pitch, so the per-lane scalar ds_read_b32 fragment reads
+//    (32 different rows, same k) hit 32 different banks.  fp32 MFMA is slow enough (64 cycles per
+//    32x32x2) that 2 LDS reads per MFMA use <15 % of the LDS issue rate.
+//  * Double-buffered LDS: the global loads of tile k+1 are issued before the MFMAs of tile k and
+//    written to the other buffer after them -> one __syncthreads per K tile.
+//  * XCD-aware block swizzle: consecutive tiles (sharing A rows / W rows) stay on one XCD's L2.
+//  * Epilogues (bias, ReLU, SiLU, residual + alpha*y, GLU) are applied to the accumulator registers:
+//    no separate elementwise passes over HBM.
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+
+namespace pk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BK = 32;
+static constexpr int LDP = BK + 1;  // LDS row pitch in floats
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int tiles_n, int n_tiles) {
+    constexpr int WM = BM / 2, WN = BN / 2;      // wave sub-tile
+    constexpr int TM = WM / 32, TN = WN / 32;    // 32x32 accumulators per wave
+    constexpr int A_CH = BM * 8 / 256, W_CH = BN * 8 / 256;
+    constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;  // output columns per block
+    static_assert(EPI != EPI_GLU || (TN % 2 == 0), "GLU needs an even number of column tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    // XCD-aware bijective remap (block b runs on XCD b % 8): XCD x gets a contiguous range of tiles.
+    int bid = blockIdx.x;
+    {
+        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * NOUT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // per-thread global source rows of the staging chunks
+    const float *a_src[A_CH];
+    const float *w_src[W_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, c4 = c & 7;
+        int gr = m0 + row;
+        gr = gr < g.M ? gr : g.M - 1;
+        a_src[i] = g.A + (int64_t)gr * g.lda + c4 * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) {
+        const int c = tid + 256 * i, v = c >> 3, c4 = c & 7;
+        int wr;
+        if constexpr (EPI == EPI_GLU) {
+            // virtual column v -> (wave column, tile, lane column); tiles [0,TN/2) are the value half,
+            // tiles [TN/2,TN) the gate half of the SAME output columns, so one lane holds both.
+            constexpr int HT = TN / 2;
+            const int vw = v / WN, rem = v % WN, tn = rem >> 5, cc = rem & 31;
+            int col = n0 + vw * (WN / 2) + (tn % HT) * 32 + cc;
+            col = col < g.N ? col : g.N - 1;
+            wr = (tn / HT) * g.N + col;
+        } else {
+            wr = n0 + v;
+            wr = wr < g.N ? wr : g.N - 1;
+        }
+        w_src[i] = g.W + (int64_t)wr * g.ldw + c4 * 4;
+    }
+
+    float4 ra[A_CH], rw[W_CH];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const float4 *>(w_src[i] + kt * BK);
+    };
+    auto lstore = [&](int buf) {
+        float *As = smem + buf * (BM + BN) * LDP;
+        float *Ws = As + BM * LDP;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int c = tid + 256 * i;
+            float *d = As + (c >> 3) * LDP + (c & 7) * 4;
+            d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) {
+            const int c = tid + 256 * i;
+            float *d = Ws + (c >> 3) * LDP + (c & 7) * 4;
+            d[0] = rw[i].x; d[1] = rw[i].y; d[2] = rw[i].z; d[3] = rw[i].w;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = g.K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int frag = (lane & 31) * LDP + (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float *Ab = smem + cur * (BM + BN) * LDP + wm * WM * LDP + frag;
+        const float *Wb = smem + cur * (BM + BN) * LDP + BM * LDP + wn * WN * LDP + frag;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Ab[i * 32 * LDP + 2 * kk];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Wb[j * 32 * LDP + 2 * kk];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int lc = lane & 31, lr = 4 * (lane >> 5);
+    constexpr int TNO = (EPI == EPI_GLU) ? TN / 2 : TN;
+#pragma unroll
+    for (int j = 0; j < TNO; ++j) {
+        const int col = n0 + wn * (EPI == EPI_GLU ? WN / 2 : WN) + j * 32 + lc;
+        if (col >= g.N) continue;
+        const float bias = g.bias ? g.bias[col] : 0.0f;
+        float bias_g = 0.0f;
+        if constexpr (EPI == EPI_GLU) bias_g = g.bias ? g.bias[g.N + col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + lr;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r];
+                if (g.bias) v = v + bias;
+                if constexpr (EPI == EPI_RELU) {
+                    v = v > 0.0f ? v : 0.0f;
+                } else if constexpr (EPI == EPI_SILU) {
+                    v = dsiluf(v);
+                } else if constexpr (EPI == EPI_RESID) {
+                    const float y = v * g.alpha;
+                    v = g.resid[(int64_t)row * g.ldr + col] + y;
+                } else if constexpr (EPI == EPI_GLU) {
+                    float gt = acc[i][j + TN / 2][r];
+                    if (g.bias) gt = gt + bias_g;
+                    v = v * dsigmoidf(gt);
+                }
+                g.out[(int64_t)row * g.ldo + col] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int EPI>
+static void launch_one(const GemmArgs &a, hipStream_t s) {
+    constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
+    const int n_tiles = tiles_m * tiles_n;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * LDP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_kernel<BM, BN, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI>), dim3(n_tiles), dim3(256), lds, s, a, tiles_n, n_tiles);
+}
+
+template <int EPI>
+static void launch_epi(const GemmArgs &a, hipStream_t s) {
+    // tile choice: fill >= 2 workgroups per CU where the problem allows it (256 CUs)
+    const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.M >= 128 && t128 >= 512) launch_one<128, 128, EPI>(a, s);
+    else if (a.M >= 128 && t128 >= 192) launch_one<128, 64, EPI>(a, s);
+    else launch_one<64, 64, EPI>(a, s);
+}
+
+void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
+    switch (epi) {
+    case EPI_NONE: launch_epi<EPI_NONE>(a, s); break;
+    case EPI_RELU: launch_epi<EPI_RELU>(a, s); break;
+    case EPI_SILU: launch_epi<EPI_SILU>(a, s); break;
+    case EPI_RESID: launch_epi<EPI_RESID>(a, s); break;
+    case EPI_GLU: launch_one<128, 128, EPI_GLU>(a, s); break;
+    default: break;
+    }
+}
+
+double gemm_flops(const GemmArgs &a, int epi) {
+    return 2.0 * (double)a.M * (double)a.N * (double)a.K * (epi == EPI_GLU ? 2.0 : 1.0);
+}
+
+}  // namespace pk

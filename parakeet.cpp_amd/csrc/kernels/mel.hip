@@ -1,0 +1,131 @@
+// parakeet.cpp_amd/csrc/kernels/mel.hip -- mel-spectrogram front end for gfx950.
+//
+// Replaces preprocess_audio (reference src/audio.cpp:100-158): preemphasis -> centred, reflect-padded
+// STFT (n_fft 512, hop 160, symmetric Hann 400) -> |X|^2 -> Slaney mel filterbank -> log(x + 2^-24)
+// -> per-bin mean / unbiased-variance normalisation -> [B][n_frames][n_mels].
+//
+// HBM-bound stage (0.96 MB algorithmic traffic per 10 s clip).  Kernel 1: one wavefront per frame,
+// four frames per workgroup; the 512-point FFT, the power spectrum and the filterbank dot products
+// all stay in LDS / registers, only log-mel [B][n_mels][n_frames] is written.  Kernel 2: one
+// wavefront per (clip, mel bin): two passes over 1001 contiguous frames (L2-resident), canonical
+// sum64 reductions, normalised + transposed store.
+//
+// FFT-512 specification: radix-2 DIT, bit-reversed load order, butterfly
+//   t = w * b with tr = fma(-wi, bi, wr*br), ti = fma(wi, br, wr*bi);  b' = a - t;  a' = a + t.
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+
+namespace pk {
+
+static constexpr int kNfft = 512;
+static constexpr int kHop = 160;
+static constexpr int kFramesPerBlock = 4;
+
+__global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict__ pcm, int64_t n_samples, int n_frames,
+                                                         MelTables tb, float *__restrict__ logmel) {
+    __shared__ float s_re[kFramesPerBlock][kNfft];
+    __shared__ float s_im[kFramesPerBlock][kNfft];
+    __shared__ float s_pw[kFramesPerBlock][260];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * kFramesPerBlock + wave;
+    const bool live = t < n_frames;
+    const float *x = pcm + (int64_t)b * n_samples;
+    float *re = s_re[wave], *im = s_im[wave], *pw = s_pw[wave];
+
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < kNfft / 64; ++i) {
+            const int n = lane + 64 * i;
+            int64_t idx = (int64_t)t * kHop + n - kNfft / 2;      // center=true
+            if (idx < 0) idx = -idx;                              // pad_mode="reflect"
+            if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
+            float v;
+            if (idx == 0) {
+                v = x[0];                                         // preemphasis, src/audio.cpp:104-114
+            } else {
+                const float p = 0.97f * x[idx - 1];
+                v = x[idx] - p;
+            }
+            const int r = (int)(__brev((unsigned)n) >> 23);       // 9-bit reversal
+            re[r] = v * tb.window[n];
+            im[r] = 0.0f;
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int lh = 0; lh < 9; ++lh) {
+        const int h = 1 << lh;
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = lane + 64 * i;
+                const int j = q & (h - 1);
+                const int a = ((q >> lh) << (lh + 1)) + j;
+                const int bb = a + h;
+                const float cr = tb.tw_re[j << (8 - lh)], ci = tb.tw_im[j << (8 - lh)];
+                const float br = re[bb], bi = im[bb];
+                const float tr = __builtin_fmaf(-ci, bi, cr * br);
+                const float ti = __builtin_fmaf(ci, br, cr * bi);
+                const float ar = re[a], ai = im[a];
+                re[bb] = ar - tr;
+                im[bb] = ai - ti;
+                re[a] = ar + tr;
+                im[a] = ai + ti;
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        for (int f = lane; f <= kNfft / 2; f += 64) {
+            const float s = __builtin_fmaf(re[f], re[f], im[f] * im[f]);
+            if (tb.power_via_abs) {                               // abs() then square, src/audio.cpp:123-124
+                const float mag = __builtin_sqrtf(s);
+                pw[f] = mag * mag;
+            } else {
+                pw[f] = s;
+            }
+        }
+    }
+    __syncthreads();
+    if (live) {
+        for (int m = lane; m < tb.n_mels; m += 64) {
+            float acc = 0.0f;
+            const int lo = tb.f_lo[m], hi = tb.f_hi[m];           // zero weights contribute fma(0, p, acc) = acc exactly
+            for (int f = lo; f <= hi; ++f) acc = __builtin_fmaf(tb.fb[f * tb.n_mels + m], pw[f], acc);
+            logmel[((int64_t)b * tb.n_mels + m) * n_frames + t] = dlogf(acc + 5.96046448e-8f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void mel_normalize_kernel(const float *__restrict__ logmel, int n_mels, int n_frames,
+                                                           int normalize, float *__restrict__ feats) {
+    const int m = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float *row = logmel + ((int64_t)b * n_mels + m) * n_frames;
+    float *out = feats + (int64_t)b * n_frames * n_mels + m;
+    if (!normalize) {
+        for (int t = lane; t < n_frames; t += 64) out[(int64_t)t * n_mels] = row[t];
+        return;
+    }
+    float p = 0.0f;
+    for (int t = lane; t < n_frames; t += 64) p = p + row[t];
+    const float mean = wave_sum64(p) / (float)n_frames;            // src/audio.cpp:142
+    float q = 0.0f;
+    for (int t = lane; t < n_frames; t += 64) {
+        const float c = row[t] - mean;
+        q = q + c * c;
+    }
+    const float var = wave_sum64(q) / (float)(n_frames - 1);      // unbiased, :146-148
+    const float den = __builtin_sqrtf(var) + 1e-5f;               // :149
+    for (int t = lane; t < n_frames; t += 64) out[(int64_t)t * n_mels] = (row[t] - mean) / den;
+}
+
+void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s) {
+    dim3 grid((n_frames + kFramesPerBlock - 1) / kFramesPerBlock, B);
+    hipLaunchKernelGGL(mel_logmel_kernel, grid, dim3(256), 0, s, pcm, n_samples, n_frames, t, logmel);
+}
+void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, int normalize, float *feats, hipStream_t s) {
+    hipLaunchKernelGGL(mel_normalize_kernel, dim3(n_mels, B), dim3(64), 0, s, logmel, n_mels, n_frames, normalize, feats);
+}
+
+}  // namespace pk

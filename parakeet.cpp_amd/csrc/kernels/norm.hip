@@ -1,0 +1,87 @@
+// parakeet.cpp_amd/csrc/kernels/norm.hip -- LayerNorm and the small diagnostic kernels.
+//
+// LayerNorm (axiom nn::LayerNorm, eps 1e-5; reference call sites src/encoder.cpp:40,60,182,202):
+// one wavefront per row, the row lives in registers, mean and variance are canonical sum64
+// reductions (strided per-lane accumulate + xor butterfly), y = fma((x-mean)*rstd, gamma, beta).
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+
+namespace pk {
+
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int64_t rows, int d,
+                                                        const float *__restrict__ g, const float *__restrict__ b,
+                                                        float eps, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * d;
+    float v[PER_LANE];
+    float p = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = i < d ? xr[i] : 0.0f;
+        if (i < d) p = p + v[j];
+    }
+    const float mean = wave_sum64(p) / (float)d;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) {
+        const int i = lane + 64 * j;
+        if (i < d) {
+            const float c = v[j] - mean;
+            q = q + c * c;
+        }
+    }
+    const float var = wave_sum64(q) / (float)d;
+    const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+    float *yr = y + row * d;
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) {
+        const int i = lane + 64 * j;
+        if (i < d) yr[i] = __builtin_fmaf((v[j] - mean) * rstd, g[i], b[i]);
+    }
+}
+
+void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (d <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y);
+    else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y);
+    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y);
+}
+
+__global__ __launch_bounds__(64) void sum64_rows_kernel(const float *__restrict__ x, int n, float *__restrict__ out) {
+    const float *row = x + (int64_t)blockIdx.x * n;
+    float p = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 64) p = p + row[i];
+    p = wave_sum64(p);
+    if (threadIdx.x == 0) out[blockIdx.x] = p;
+}
+void launch_sum64_rows(const float *x, int rows, int n, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(sum64_rows_kernel, dim3(rows), dim3(64), 0, s, x, n, out);
+}
+
+__global__ void math_kernel(int fn, const float *__restrict__ in, float *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = in[i];
+        float y;
+        switch (fn) {
+        case 0: y = dexpf(x); break;
+        case 1: y = dlogf(x); break;
+        case 2: y = dtanhf(x); break;
+        case 3: y = dsigmoidf(x); break;
+        case 4: y = dsiluf(x); break;
+        case 5: y = __builtin_sqrtf(x); break;
+        case 6: y = 1.0f / x; break;
+        default: y = x;
+        }
+        out[i] = y;
+    }
+}
+void launch_math(int fn, const float *in, float *out, int64_t n, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(math_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, fn, in, out, n);
+}
+
+}  // namespace pk

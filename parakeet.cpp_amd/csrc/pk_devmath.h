@@ -1,0 +1,115 @@
+// parakeet.cpp_amd/csrc/pk_devmath.h -- deterministic fp32 math for the HIP kernels.
+//
+// DESIGN.md "Numerics contract": exp / log / tanh are fixed polynomial evaluations built from
+// IEEE add / mul / fma only, so a kernel's output does not depend on the ROCm device-libs
+// version and can be compared bit-for-bit with the CPU oracle, which implements the same
+// written specification independently.  Coefficients come from tools/fit_math.py.
+// All translation units are compiled with -ffp-contract=off: every fusion below is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pk {
+
+// e^x.  n = rne(x*log2e) by the 1.5*2^23 trick; r = x - n*ln2 in two parts; e^r = 1 + (r + r^2 E(r));
+// result scaled by 2^n in two exact steps (n/2 floor, remainder).  > 88.7228 -> +inf, < -87.3365 -> 0.
+__device__ __forceinline__ float dexpf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_huge_valf();
+    if (x < -87.33654022216797f) return 0.0f;
+    const float t = __builtin_fmaf(x, 1.44269502162933349609375f, 12582912.0f);
+    const float n = t - 12582912.0f;
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.428606765330187045037746429443359375e-06f, r);
+    float e = 0x1.6d4332p-10f;
+    e = __builtin_fmaf(e, r, 0x1.120b74p-7f);
+    e = __builtin_fmaf(e, r, 0x1.5554e8p-5f);
+    e = __builtin_fmaf(e, r, 0x1.5554dcp-3f);
+    e = __builtin_fmaf(e, r, 0.5f);
+    const float q = __builtin_fmaf(r * r, e, r);
+    const float p = q + 1.0f;
+    const int ni = (int)n;
+    const int n1 = ni >> 1;
+    const int n2 = ni - n1;
+    const float s1 = __int_as_float((n1 + 127) << 23);
+    const float s2 = __int_as_float((n2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+// ln x.  x = m 2^e with m in [sqrt(1/2), sqrt(2)); f = m - 1; ln(1+f) = f - f^2/2 + f^3 L(f); + e ln2 in two parts.
+__device__ __forceinline__ float dlogf(float x) {
+    if (x != x) return x;
+    if (x < 0.0f) return __builtin_nanf("");
+    if (x == 0.0f) return -__builtin_huge_valf();
+    if (x == __builtin_huge_valf()) return x;
+    int e = 0;
+    unsigned ix = __float_as_uint(x);
+    if (ix < 0x00800000u) {
+        x = x * 8388608.0f;
+        e = -23;
+        ix = __float_as_uint(x);
+    }
+    e += (int)(ix >> 23) - 127;
+    float m = __uint_as_float((ix & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421353816986083984375f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float l = 0x1.24df7ap-4f;
+    l = __builtin_fmaf(l, f, -0x1.da0762p-4f);
+    l = __builtin_fmaf(l, f, 0x1.ddaecep-4f);
+    l = __builtin_fmaf(l, f, -0x1.fc5924p-4f);
+    l = __builtin_fmaf(l, f, 0x1.23d638p-3f);
+    l = __builtin_fmaf(l, f, -0x1.555eep-3f);
+    l = __builtin_fmaf(l, f, 0x1.999d54p-3f);
+    l = __builtin_fmaf(l, f, -0x1.fffff2p-3f);
+    l = __builtin_fmaf(l, f, 0x1.555554p-2f);
+    const float fe = (float)e;
+    float y = (f * z) * l;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+// tanh x.  |x| < 0.55: x + x^3 T(x^2); |x| > 9: +-1; otherwise 1 - 2/(e^{2|x|} + 1) with the sign restored.
+__device__ __forceinline__ float dtanhf(float x) {
+    const float ax = __builtin_fabsf(x);
+    if (ax < 0.55f) {
+        const float z = x * x;
+        float t = -0x1.b18f62p-8f;
+        t = __builtin_fmaf(t, z, 0x1.5d2fdp-6f);
+        t = __builtin_fmaf(t, z, -0x1.b9a194p-5f);
+        t = __builtin_fmaf(t, z, 0x1.110ffp-3f);
+        t = __builtin_fmaf(t, z, -0x1.555554p-2f);
+        return __builtin_fmaf(x * z, t, x);
+    }
+    float r;
+    if (ax > 9.0f) {
+        r = 1.0f;
+    } else {
+        const float t = dexpf(2.0f * ax);
+        r = 1.0f - 2.0f / (t + 1.0f);
+    }
+    return __builtin_copysignf(r, x);
+}
+
+__device__ __forceinline__ float dsigmoidf(float x) { return 1.0f / (1.0f + dexpf(-x)); }
+__device__ __forceinline__ float dsiluf(float x) { return x / (1.0f + dexpf(-x)); }
+
+// Butterfly stage of the canonical 64-lane sum ("sum64"): p += p(lane ^ off), off = 32,16,...,1.
+// Every lane ends with the same value (IEEE add commutes).
+__device__ __forceinline__ float wave_sum64(float p) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    return p;
+}
+__device__ __forceinline__ float wave_max64(float p) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = fmaxf(p, __shfl_xor(p, off, 64));
+    return p;
+}
+
+}  // namespace pk

@@ -1,0 +1,138 @@
+// parakeet.cpp_amd/csrc/safetensors.cpp -- minimal safetensors reader: 8-byte LE header length, a JSON
+// object {name: {dtype, shape, data_offsets}}, then the raw little-endian tensor bytes.
+#include "safetensors.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstring>
+
+#include "common.hpp"
+
+namespace pk {
+namespace {
+
+struct Json {  // just enough JSON for the header: objects, arrays, strings, integers
+    const char *p, *end;
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+    bool eat(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
+    void need(char c) { if (!eat(c)) fail(PK_ERR_WEIGHTS, "safetensors header: expected '%c'", c); }
+    std::string str() {
+        ws();
+        if (p >= end || *p != '"') fail(PK_ERR_WEIGHTS, "safetensors header: expected string");
+        ++p;
+        std::string s;
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) {
+                ++p;
+                switch (*p) {
+                case 'n': s += '\n'; break;
+                case 't': s += '\t'; break;
+                case 'u': s += '?'; p += 4; break;
+                default: s += *p;
+                }
+                ++p;
+            } else {
+                s += *p++;
+            }
+        }
+        if (p >= end) fail(PK_ERR_WEIGHTS, "safetensors header: unterminated string");
+        ++p;
+        return s;
+    }
+    int64_t integer() {
+        ws();
+        bool neg = false;
+        if (p < end && *p == '-') { neg = true; ++p; }
+        if (p >= end || *p < '0' || *p > '9') fail(PK_ERR_WEIGHTS, "safetensors header: expected integer");
+        int64_t v = 0;
+        while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+        return neg ? -v : v;
+    }
+    void skip() {  // skip any value
+        ws();
+        if (p >= end) return;
+        if (*p == '"') { (void)str(); return; }
+        if (*p == '{' || *p == '[') {
+            const char open = *p, close = (*p == '{') ? '}' : ']';
+            ++p;
+            if (eat(close)) return;
+            do {
+                if (open == '{') { (void)str(); need(':'); }
+                skip();
+            } while (eat(','));
+            need(close);
+            return;
+        }
+        while (p < end && *p != ',' && *p != '}' && *p != ']') ++p;
+    }
+};
+
+}  // namespace
+
+SafeTensors::SafeTensors(const std::string &path) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) fail(PK_ERR_IO, "Cannot open weights file: %s", path.c_str());
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 8) { ::close(fd); fail(PK_ERR_IO, "Cannot stat weights file: %s", path.c_str()); }
+    map_len_ = (size_t)st.st_size;
+    map_ = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (map_ == MAP_FAILED) { map_ = nullptr; fail(PK_ERR_IO, "mmap failed: %s", path.c_str()); }
+    const uint8_t *base = static_cast<const uint8_t *>(map_);
+    uint64_t hlen;
+    memcpy(&hlen, base, 8);
+    if (hlen > map_len_ - 8) fail(PK_ERR_WEIGHTS, "safetensors: header length %llu exceeds file", (unsigned long long)hlen);
+    const uint8_t *payload = base + 8 + hlen;
+    const size_t payload_len = map_len_ - 8 - hlen;
+    Json j{reinterpret_cast<const char *>(base + 8), reinterpret_cast<const char *>(base + 8 + hlen)};
+    j.need('{');
+    if (!j.eat('}')) {
+        do {
+            const std::string name = j.str();
+            j.need(':');
+            if (name == "__metadata__") { j.skip(); continue; }
+            HostTensor t;
+            int64_t off0 = 0, off1 = 0;
+            j.need('{');
+            do {
+                const std::string key = j.str();
+                j.need(':');
+                if (key == "dtype") {
+                    t.dtype = j.str();
+                } else if (key == "shape") {
+                    j.need('[');
+                    if (!j.eat(']')) { do t.shape.push_back(j.integer()); while (j.eat(',')); j.need(']'); }
+                } else if (key == "data_offsets") {
+                    j.need('[');
+                    off0 = j.integer();
+                    j.need(',');
+                    off1 = j.integer();
+                    j.need(']');
+                } else {
+                    j.skip();
+                }
+            } while (j.eat(','));
+            j.need('}');
+            if (off0 < 0 || off1 < off0 || (size_t)off1 > payload_len) fail(PK_ERR_WEIGHTS, "safetensors: bad offsets for %s", name.c_str());
+            t.data = payload + off0;
+            t.nbytes = (size_t)(off1 - off0);
+            if (t.dtype == "F32" && (size_t)t.numel() * 4 != t.nbytes) fail(PK_ERR_WEIGHTS, "safetensors: %s size/shape mismatch", name.c_str());
+            tensors_.emplace(name, std::move(t));
+        } while (j.eat(','));
+        j.need('}');
+    }
+}
+
+SafeTensors::~SafeTensors() {
+    if (map_) munmap(map_, map_len_);
+}
+
+const HostTensor *SafeTensors::find(const std::string &name) const {
+    auto it = tensors_.find(name);
+    return it == tensors_.end() ? nullptr : &it->second;
+}
+
+}  // namespace pk

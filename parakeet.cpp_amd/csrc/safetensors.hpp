@@ -1,0 +1,39 @@
+// parakeet.cpp_amd/csrc/safetensors.hpp -- read-only safetensors container (what the reference loads with
+// axiom::io::safetensors::load, transcribe.hpp:62).  The file is mmap'd; tensors are views into the mapping.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace pk {
+
+struct HostTensor {
+    std::string dtype;            // "F32" (convert_nemo.py:501 casts everything to fp32)
+    std::vector<int64_t> shape;
+    const uint8_t *data = nullptr;
+    size_t nbytes = 0;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+    const float *f32() const { return reinterpret_cast<const float *>(data); }
+};
+
+class SafeTensors {
+  public:
+    explicit SafeTensors(const std::string &path);   // throws pk::Error(PK_ERR_IO / PK_ERR_WEIGHTS)
+    ~SafeTensors();
+    SafeTensors(const SafeTensors &) = delete;
+    SafeTensors &operator=(const SafeTensors &) = delete;
+    const HostTensor *find(const std::string &name) const;
+    const std::map<std::string, HostTensor> &tensors() const { return tensors_; }
+
+  private:
+    void *map_ = nullptr;
+    size_t map_len_ = 0;
+    std::map<std::string, HostTensor> tensors_;
+};
+
+}  // namespace pk

