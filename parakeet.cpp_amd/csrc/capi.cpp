@@ -1,5 +1,6 @@
 // parakeet.cpp_amd/csrc/capi.cpp -- the extern "C" boundary declared in include/parakeet_amd.h.
 // Every entry point translates pk::Error / std::exception into a status code + thread-local message.
+#include <algorithm>
 #include <cstring>
 #include <functional>
 
@@ -123,6 +124,415 @@ pk_status pk_mel(pk_model *h, const float *pcm, int n_clips, int64_t n_samples, 
         if (logmel) PK_HIP(hipMemcpyAsync(logmel, m.io_tmp.p, n_lm * 4, hipMemcpyDeviceToHost, m.stream));
         PK_HIP(hipStreamSynchronize(m.stream));
     });
+}
+
+
+pk_status pk_subsample(pk_model *h, const float *feats, int B, int Tm, float *out) {
+    return guard([&] {
+        need(h && feats && out && B > 0 && Tm > 0, "model/feats/out/B/Tm");
+        Model &m = *h->m;
+        m.require_gpu();
+        m.ws.size_for(m.cfg, B, 0, Tm);
+        const size_t nin = (size_t)B * Tm * m.cfg.mel_bins, nout = (size_t)B * m.ws.T * m.cfg.hidden_size;
+        PK_HIP(hipMemcpyAsync(m.ws.feats.p, feats, nin * 4, hipMemcpyHostToDevice, m.stream));
+        m.run_subsample(m.ws, m.ws.feats.as<float>(), B, Tm, m.ws.x.as<float>(), m.stream);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpyAsync(out, m.ws.x.p, nout * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+pk_status pk_encode(pk_model *h, const float *feats, int B, int Tm, int stop_layer, int stop_stage, float *enc) {
+    return guard([&] {
+        need(h && feats && enc && B > 0 && Tm > 0, "model/feats/enc/B/Tm");
+        need(stop_stage >= 0 && stop_stage <= 4, "stop_stage");
+        Model &m = *h->m;
+        m.require_gpu();
+        m.ws.size_for(m.cfg, B, 0, Tm);
+        const size_t nin = (size_t)B * Tm * m.cfg.mel_bins, nout = (size_t)B * m.ws.T * m.cfg.hidden_size;
+        PK_HIP(hipMemcpyAsync(m.ws.feats.p, feats, nin * 4, hipMemcpyHostToDevice, m.stream));
+        m.run_encoder(m.ws, m.ws.feats.as<float>(), B, Tm, stop_layer, stop_stage, m.stream);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpyAsync(enc, m.ws.x.p, nout * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+static void size_ws_for_T(Model &m, int B, int T) {
+    // a mel length that subsamples to exactly T frames: Tm = 8(T-1)+1
+    m.ws.size_for(m.cfg, B, 0, 8 * (T - 1) + 1);
+    if (m.ws.T != T) fail(PK_ERR_INVALID, "internal: workspace T %d != %d", m.ws.T, T);
+}
+
+pk_status pk_ctc_decode(pk_model *h, const float *enc, int B, int T, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end,
+                        float *conf, float *logp) {
+    return guard([&] {
+        need(h && enc && ids && lens && B > 0 && T > 0, "model/enc/ids/lens/B/T");
+        Model &m = *h->m;
+        m.require_gpu();
+        size_ws_for_T(m, B, T);
+        const size_t rows = (size_t)B * T;
+        PK_HIP(hipMemcpyAsync(m.ws.x.p, enc, rows * m.cfg.hidden_size * 4, hipMemcpyHostToDevice, m.stream));
+        m.run_ctc(m.ws, m.ws.x.as<float>(), B, T, logp != nullptr, m.stream);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpyAsync(ids, m.ws.ids.p, rows * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipMemcpyAsync(lens, m.ws.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost, m.stream));
+        if (start) PK_HIP(hipMemcpyAsync(start, m.ws.start.p, rows * 4, hipMemcpyDeviceToHost, m.stream));
+        if (end) PK_HIP(hipMemcpyAsync(end, m.ws.end.p, rows * 4, hipMemcpyDeviceToHost, m.stream));
+        if (conf) PK_HIP(hipMemcpyAsync(conf, m.ws.conf.p, rows * 4, hipMemcpyDeviceToHost, m.stream));
+        if (logp) PK_HIP(hipMemcpyAsync(logp, m.ws.ctc_lp.p, rows * m.cfg.ctc_vocab_size * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+pk_status pk_tdt_decode(pk_model *h, const float *enc, int B, int T, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start,
+                        int32_t *end, float *conf, int32_t *steps) {
+    pk_status cap_hit = PK_OK;
+    pk_status st = guard([&] {
+        need(h && enc && ids && lens && B > 0 && T > 0 && max_tokens > 0, "model/enc/ids/lens/B/T/max_tokens");
+        Model &m = *h->m;
+        m.require_gpu();
+        size_ws_for_T(m, B, T);
+        need(max_tokens <= m.ws.max_tokens, "max_tokens exceeds T * max_symbols_per_step");
+        PK_HIP(hipMemcpyAsync(m.ws.x.p, enc, (size_t)B * T * m.cfg.hidden_size * 4, hipMemcpyHostToDevice, m.stream));
+        m.run_tdt(m.ws, m.ws.x.as<float>(), B, T, max_tokens, m.stream);
+        PK_CHECK_LAUNCH();
+        const size_t tok = (size_t)B * max_tokens;
+        PK_HIP(hipMemcpyAsync(ids, m.ws.ids.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipMemcpyAsync(lens, m.ws.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost, m.stream));
+        if (start) PK_HIP(hipMemcpyAsync(start, m.ws.start.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        if (end) PK_HIP(hipMemcpyAsync(end, m.ws.end.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        if (conf) PK_HIP(hipMemcpyAsync(conf, m.ws.conf.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        if (steps) PK_HIP(hipMemcpyAsync(steps, m.ws.ints.as<int>() + 4 * B, (size_t)B * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+        for (int b = 0; b < B; ++b)
+            if (lens[b] < 0) cap_hit = PK_ERR_DECODE_CAP;
+    });
+    if (st == PK_OK && cap_hit != PK_OK) {
+        set_last_error("TDT decode hit the safety cap on joint evaluations for at least one utterance (lens = -1)");
+        return cap_hit;
+    }
+    return st;
+}
+
+
+/* ---- resident batch pipeline ---------------------------------------------------------------------------- */
+struct pk_batch {
+    Model *m;
+    Workspace ws;
+    int n_clips = 0;
+    int last_decoder = -1;
+    hipEvent_t ev[4];
+    bool ev_ok = false;
+};
+
+static void batch_run(pk_batch *b, int decoder, bool timed) {
+    Model &m = *b->m;
+    m.require_gpu();
+    need(b->n_clips > 0, "pk_batch_upload() first");
+    need(decoder == PK_DECODER_CTC || decoder == PK_DECODER_TDT, "decoder");
+    Workspace &w = b->ws;
+    hipStream_t s = m.stream;
+    const int B = b->n_clips;
+    if (timed) PK_HIP(hipEventRecord(b->ev[0], s));
+    m.run_mel(w.pcm.as<float>(), B, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
+    if (timed) PK_HIP(hipEventRecord(b->ev[1], s));
+    m.run_encoder(w, w.feats.as<float>(), B, w.Tm, -1, 0, s);
+    if (timed) PK_HIP(hipEventRecord(b->ev[2], s));
+    if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), B, w.T, false, s);
+    else m.run_tdt(w, w.x.as<float>(), B, w.T, w.max_tokens, s);
+    if (timed) PK_HIP(hipEventRecord(b->ev[3], s));
+    PK_CHECK_LAUNCH();
+    b->last_decoder = decoder;
+}
+
+pk_status pk_batch_create(pk_model *h, int max_clips, int64_t n_samples, pk_batch **out) {
+    return guard([&] {
+        need(h && out && max_clips > 0 && n_samples > 256, "model/out/max_clips/n_samples");
+        Model &m = *h->m;
+        m.require_gpu();
+        auto b = std::make_unique<pk_batch>();
+        b->m = &m;
+        b->ws.size_for(m.cfg, max_clips, n_samples, pk_mel_num_frames(n_samples));
+        for (auto &e : b->ev) PK_HIP(hipEventCreate(&e));
+        b->ev_ok = true;
+        *out = b.release();
+    });
+}
+
+void pk_batch_free(pk_batch *b) {
+    if (!b) return;
+    if (b->ev_ok)
+        for (auto &e : b->ev) (void)hipEventDestroy(e);
+    delete b;
+}
+
+pk_status pk_batch_upload(pk_batch *b, const float *pcm, int n_clips) {
+    return guard([&] {
+        need(b && pcm && n_clips > 0 && n_clips <= b->ws.B, "batch/pcm/n_clips");
+        b->m->require_gpu();
+        PK_HIP(hipMemcpyAsync(b->ws.pcm.p, pcm, (size_t)n_clips * b->ws.n_samples * 4, hipMemcpyHostToDevice, b->m->stream));
+        PK_HIP(hipStreamSynchronize(b->m->stream));
+        b->n_clips = n_clips;
+    });
+}
+
+pk_status pk_batch_run(pk_batch *b, int decoder) {
+    return guard([&] { need(b, "batch"); batch_run(b, decoder, false); });
+}
+
+pk_status pk_batch_sync(pk_batch *b) {
+    return guard([&] { need(b, "batch"); b->m->require_gpu(); PK_HIP(hipStreamSynchronize(b->m->stream)); });
+}
+
+int pk_batch_max_tokens(const pk_batch *b) { return b ? b->ws.max_tokens : 0; }
+
+pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
+    return guard([&] {
+        need(b && ids && lens, "batch/ids/lens");
+        need(b->last_decoder >= 0, "pk_batch_run() first");
+        Model &m = *b->m;
+        m.require_gpu();
+        Workspace &w = b->ws;
+        const int B = b->n_clips, mt = w.max_tokens;
+        PK_HIP(hipStreamSynchronize(m.stream));
+        PK_HIP(hipMemcpy(lens, w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+        if (b->last_decoder == PK_DECODER_TDT) {
+            const size_t n = (size_t)B * mt * 4;
+            PK_HIP(hipMemcpy(ids, w.ids.p, n, hipMemcpyDeviceToHost));
+            if (start) PK_HIP(hipMemcpy(start, w.start.p, n, hipMemcpyDeviceToHost));
+            if (end) PK_HIP(hipMemcpy(end, w.end.p, n, hipMemcpyDeviceToHost));
+            if (conf) PK_HIP(hipMemcpy(conf, w.conf.p, n, hipMemcpyDeviceToHost));
+        } else {   // CTC arrays are [B][T] on the device; present them with the same [B][max_tokens] pitch
+            const size_t wid = (size_t)w.T * 4;
+            auto pitch = [&](void *dst, const void *src) {
+                PK_HIP(hipMemcpy2D(dst, (size_t)mt * 4, src, wid, wid, B, hipMemcpyDeviceToHost));
+            };
+            pitch(ids, w.ids.p);
+            if (start) pitch(start, w.start.p);
+            if (end) pitch(end, w.end.p);
+            if (conf) pitch(conf, w.conf.p);
+        }
+    });
+}
+
+pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]) {
+    return guard([&] {
+        need(b && ms, "batch/ms");
+        batch_run(b, decoder, true);
+        PK_HIP(hipStreamSynchronize(b->m->stream));
+        PK_HIP(hipEventElapsedTime(&ms[0], b->ev[0], b->ev[1]));
+        PK_HIP(hipEventElapsedTime(&ms[1], b->ev[1], b->ev[2]));
+        PK_HIP(hipEventElapsedTime(&ms[2], b->ev[2], b->ev[3]));
+        PK_HIP(hipEventElapsedTime(&ms[3], b->ev[0], b->ev[3]));
+    });
+}
+
+void *pk_batch_dev_pcm(pk_batch *b) { return b ? b->ws.pcm.p : nullptr; }
+void *pk_batch_stream(pk_batch *b) { return b ? (void *)b->m->stream : nullptr; }
+
+int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap) {
+    int n_out = -1;
+    pk_status st = guard([&] {
+        need(b && out && cap > 0, "batch/out/cap");
+        Model &m = *b->m;
+        ProfileSink sink;
+        m.prof = &sink;
+        try {
+            batch_run(b, decoder, false);
+            PK_HIP(hipStreamSynchronize(m.stream));
+        } catch (...) {
+            m.prof = nullptr;
+            throw;
+        }
+        m.prof = nullptr;
+        std::vector<pk_kernel_stat> agg;
+        for (auto &r : sink.recs) {
+            float ms = 0.0f;
+            PK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+            size_t i = 0;
+            for (; i < agg.size(); ++i)
+                if (r.name == agg[i].name) break;
+            if (i == agg.size()) {
+                pk_kernel_stat k;
+                memset(&k, 0, sizeof k);
+                snprintf(k.name, sizeof k.name, "%s", r.name.c_str());
+                agg.push_back(k);
+            }
+            agg[i].launches += 1;
+            agg[i].total_ms += ms;
+            agg[i].flops += r.flops;
+            agg[i].bytes += r.bytes;
+        }
+        n_out = (int)agg.size();
+        for (int i = 0; i < n_out && i < cap; ++i) out[i] = agg[i];
+    });
+    return st == PK_OK ? n_out : (int)st;
+}
+
+/* ---- one-call API ------------------------------------------------------------------------------------------ */
+namespace pk { void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rate); }
+
+namespace {
+struct ResultStore {          // owns everything a pk_result array points into
+    std::vector<pk_result> res;
+    std::vector<std::string> text;
+    std::vector<std::vector<int32_t>> ids, start, end;
+    std::vector<std::vector<float>> conf;
+    std::vector<std::vector<std::string>> word_text;
+    std::vector<std::vector<pk_word>> words;
+};
+}  // namespace
+
+pk_status pk_transcribe_pcm(pk_model *h, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt,
+                            pk_result **results) {
+    return guard([&] {
+        need(h && pcm && offsets && results && n_clips > 0, "model/pcm/offsets/results/n_clips");
+        Model &m = *h->m;
+        m.require_gpu();
+        const int decoder = opt ? opt->decoder : PK_DECODER_TDT;
+        const bool ts = opt && opt->timestamps;
+        need(decoder == PK_DECODER_CTC || decoder == PK_DECODER_TDT, "options.decoder");
+        auto store = std::make_unique<ResultStore>();
+        ResultStore &R = *store;
+        R.res.resize(n_clips + 1);            // one hidden trailing slot keeps the store pointer
+        R.text.resize(n_clips); R.ids.resize(n_clips); R.start.resize(n_clips); R.end.resize(n_clips); R.conf.resize(n_clips);
+        R.word_text.resize(n_clips); R.words.resize(n_clips);
+        // group clips of equal length into batches (the reference has no padding semantics: no masks offline, encoder.cpp:163)
+        std::vector<int> order(n_clips);
+        for (int i = 0; i < n_clips; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offsets[a + 1] - offsets[a] < offsets[b + 1] - offsets[b]; });
+        const int kMaxBatch = 64;
+        for (int g0 = 0; g0 < n_clips;) {
+            const int64_t len = offsets[order[g0] + 1] - offsets[order[g0]];
+            need(len > 256, "every clip needs more than 256 samples");
+            int g1 = g0;
+            while (g1 < n_clips && g1 - g0 < kMaxBatch && offsets[order[g1] + 1] - offsets[order[g1]] == len) ++g1;
+            const int B = g1 - g0;
+            Workspace &w = m.ws;
+            w.size_for(m.cfg, B, len, pk_mel_num_frames(len));
+            for (int i = 0; i < B; ++i)
+                PK_HIP(hipMemcpyAsync(w.pcm.as<float>() + (size_t)i * len, pcm + offsets[order[g0 + i]], (size_t)len * 4, hipMemcpyHostToDevice, m.stream));
+            m.run_mel(w.pcm.as<float>(), B, len, w.logmel.as<float>(), w.feats.as<float>(), m.stream);
+            m.run_encoder(w, w.feats.as<float>(), B, w.Tm, -1, 0, m.stream);
+            const int pitch = decoder == PK_DECODER_CTC ? w.T : w.max_tokens;
+            if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), B, w.T, false, m.stream);
+            else m.run_tdt(w, w.x.as<float>(), B, w.T, w.max_tokens, m.stream);
+            PK_CHECK_LAUNCH();
+            std::vector<int32_t> ids((size_t)B * pitch), st((size_t)B * pitch), en((size_t)B * pitch), lens(B);
+            std::vector<float> cf((size_t)B * pitch);
+            PK_HIP(hipStreamSynchronize(m.stream));
+            PK_HIP(hipMemcpy(lens.data(), w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+            PK_HIP(hipMemcpy(ids.data(), w.ids.p, ids.size() * 4, hipMemcpyDeviceToHost));
+            PK_HIP(hipMemcpy(st.data(), w.start.p, st.size() * 4, hipMemcpyDeviceToHost));
+            PK_HIP(hipMemcpy(en.data(), w.end.p, en.size() * 4, hipMemcpyDeviceToHost));
+            PK_HIP(hipMemcpy(cf.data(), w.conf.p, cf.size() * 4, hipMemcpyDeviceToHost));
+            for (int i = 0; i < B; ++i) {
+                const int c = order[g0 + i];
+                if (lens[i] < 0) fail(PK_ERR_DECODE_CAP, "TDT decode hit the safety cap on clip %d", c);
+                const int n = lens[i];
+                R.ids[c].assign(ids.begin() + (size_t)i * pitch, ids.begin() + (size_t)i * pitch + n);
+                std::vector<int> iv(R.ids[c].begin(), R.ids[c].end());
+                if (m.tok.loaded()) R.text[c] = m.tok.decode(iv);                    // transcribe.hpp:149,172
+                if (ts) {
+                    R.start[c].assign(st.begin() + (size_t)i * pitch, st.begin() + (size_t)i * pitch + n);
+                    R.end[c].assign(en.begin() + (size_t)i * pitch, en.begin() + (size_t)i * pitch + n);
+                    R.conf[c].assign(cf.begin() + (size_t)i * pitch, cf.begin() + (size_t)i * pitch + n);
+                    if (m.tok.loaded()) {                                            // group_timestamps, transcribe.hpp:150-152
+                        std::vector<TimestampedToken> tt(n);
+                        for (int k = 0; k < n; ++k) tt[k] = {R.ids[c][k], R.start[c][k], R.end[c][k], R.conf[c][k]};
+                        auto words = group_timestamps(tt, m.tok.pieces(), false);
+                        for (auto &wd : words) R.word_text[c].push_back(wd.word);
+                        for (size_t k = 0; k < words.size(); ++k)
+                            R.words[c].push_back({R.word_text[c][k].c_str(), words[k].start, words[k].end, words[k].confidence});
+                    }
+                }
+            }
+            g0 = g1;
+        }
+        for (int c = 0; c < n_clips; ++c) {
+            pk_result &r = R.res[c];
+            r.text = R.text[c].c_str();
+            r.n_tokens = (int32_t)R.ids[c].size();
+            r.token_ids = R.ids[c].data();
+            r.start_frame = ts ? R.start[c].data() : nullptr;
+            r.end_frame = ts ? R.end[c].data() : nullptr;
+            r.confidence = ts ? R.conf[c].data() : nullptr;
+            r.n_words = (int32_t)R.words[c].size();
+            r.words = R.words[c].data();
+        }
+        memset(&R.res[n_clips], 0, sizeof(pk_result));
+        R.res[n_clips].text = reinterpret_cast<const char *>(store.get());   // back-pointer for pk_results_free
+        *results = R.res.data();
+        store.release();
+    });
+}
+
+void pk_results_free(pk_result *results, int n_clips) {
+    if (!results || n_clips < 0) return;
+    delete reinterpret_cast<ResultStore *>(const_cast<char *>(results[n_clips].text));
+}
+
+pk_status pk_read_wav(const char *path, float **pcm, int64_t *n_samples, int *sample_rate) {
+    return guard([&] {
+        need(path && pcm && n_samples && sample_rate, "path/pcm/n_samples/sample_rate");
+        std::vector<float> mono;
+        int sr = 0;
+        read_wav(path, mono, sr);
+        float *p = static_cast<float *>(malloc((mono.size() ? mono.size() : 1) * sizeof(float)));
+        if (!p) fail(PK_ERR_IO, "out of memory");
+        memcpy(p, mono.data(), mono.size() * sizeof(float));
+        *pcm = p;
+        *n_samples = (int64_t)mono.size();
+        *sample_rate = sr;
+    });
+}
+void pk_free(void *p) { free(p); }
+
+/* ---- host-side text ---------------------------------------------------------------------------------------- */
+int pk_vocab_size(const pk_model *m) { return m ? (int)m->m->tok.vocab_size() : 0; }
+
+int pk_detokenize(const pk_model *m, const int32_t *ids, int n, char *out, int cap) {
+    if (!m || (!ids && n > 0) || n < 0) return -1;
+    std::vector<int> v(ids, ids + n);
+    const std::string s = m->m->tok.decode(v);
+    if (out && cap > 0) {
+        const int c = (int)s.size() < cap - 1 ? (int)s.size() : cap - 1;
+        memcpy(out, s.data(), c);
+        out[c] = 0;
+    }
+    return (int)s.size();
+}
+
+int pk_tokenize(const pk_model *m, const char *text, int32_t *ids, int cap) {
+    if (!m || !text) return -1;
+    const auto v = m->m->tok.encode(text);
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
+    return (int)v.size();
+}
+
+int pk_group_timestamps(const pk_model *m, const int32_t *ids, const int32_t *start, const int32_t *end, const float *conf, int n,
+                        int sentences, char *words, int cap, float *wstart, float *wend, float *wconf, int wcap) {
+    if (!m || n < 0) return -1;
+    std::vector<TimestampedToken> tt(n);
+    for (int i = 0; i < n; ++i) tt[i] = {ids[i], start[i], end[i], conf ? conf[i] : 1.0f};
+    const auto w = group_timestamps(tt, m->m->tok.pieces(), sentences != 0);
+    std::string joined;
+    for (size_t i = 0; i < w.size(); ++i) {
+        if (i) joined += '\n';
+        joined += w[i].word;
+        if ((int)i < wcap) {
+            if (wstart) wstart[i] = w[i].start;
+            if (wend) wend[i] = w[i].end;
+            if (wconf) wconf[i] = w[i].confidence;
+        }
+    }
+    if (words && cap > 0) {
+        const int c = (int)joined.size() < cap - 1 ? (int)joined.size() : cap - 1;
+        memcpy(words, joined.data(), c);
+        words[c] = 0;
+    }
+    return (int)w.size();
 }
 
 /* ---- diagnostics ---------------------------------------------------------------------------------- */

@@ -10,11 +10,25 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 const std::string &last_error() { return g_last_error; }
 
+ProfileSink::~ProfileSink() {
+    for (auto &r : recs) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+}
+
 Model::Model(const std::string &weights_path, const std::string &vocab_path, const pk_config &c) : cfg(c) {
     if (cfg.hidden_size <= 0 || cfg.num_heads <= 0 || cfg.hidden_size % cfg.num_heads) fail(PK_ERR_INVALID, "bad hidden_size / num_heads");
+    const int hd = cfg.hidden_size / cfg.num_heads;
+    if (hd % 32) fail(PK_ERR_UNSUPPORTED, "head_dim must be a multiple of 32");
     if (cfg.hidden_size % 32 || cfg.ffn_intermediate % 32 || cfg.subsampling_channels % 32 || cfg.pred_hidden % 32 || cfg.joint_hidden % 32)
         fail(PK_ERR_UNSUPPORTED, "hidden / ffn / channel sizes must be multiples of 32 (MFMA K tile)");
+    if (256 % cfg.subsampling_channels) fail(PK_ERR_UNSUPPORTED, "subsampling_channels must divide 256");
     if (cfg.mel_bins > 128 || cfg.mel_bins % 8) fail(PK_ERR_UNSUPPORTED, "mel_bins must be a multiple of 8 and <= 128");
+    if (cfg.conv_kernel_size != 9 && cfg.conv_kernel_size != 31) fail(PK_ERR_UNSUPPORTED, "conv_kernel_size must be 9 or 31");
+    if (cfg.num_lstm_layers < 1 || cfg.num_lstm_layers > 4) fail(PK_ERR_UNSUPPORTED, "num_lstm_layers must be 1..4");
+    if (cfg.hidden_size > 1024) fail(PK_ERR_UNSUPPORTED, "hidden_size > 1024");
+    if (cfg.num_durations < 0 || cfg.num_durations > 8) fail(PK_ERR_INVALID, "num_durations must be 0..8");
     st_ = std::make_unique<SafeTensors>(weights_path);
     if (!vocab_path.empty()) tok.load(vocab_path);
 }
@@ -23,6 +37,7 @@ Model::~Model() {
     if (device_ >= 0) {
         (void)hipSetDevice(device_);
         for (void *p : allocs_) (void)hipFree(p);
+        if (h_done) (void)hipHostFree(h_done);
         if (stream) (void)hipStreamDestroy(stream);
     }
 }
@@ -45,18 +60,22 @@ const float *Model::upload(const float *host, size_t n) {
     return d;
 }
 
-const float *Model::upload_tensor(const std::string &name, std::vector<int64_t> expect) {
+const HostTensor &Model::host_tensor(const std::string &name, int64_t want) {
     const HostTensor *t = st_->find(name);
     if (!t) fail(PK_ERR_WEIGHTS, "missing tensor '%s'", name.c_str());
     if (t->dtype != "F32") fail(PK_ERR_WEIGHTS, "tensor '%s' has dtype %s, expected F32", name.c_str(), t->dtype.c_str());
-    int64_t want = 1;
-    for (auto e : expect) want *= e;
     if (t->numel() != want) {
         std::string got;
         for (auto s : t->shape) got += std::to_string(s) + " ";
         fail(PK_ERR_WEIGHTS, "tensor '%s' has shape [ %s], expected %lld elements", name.c_str(), got.c_str(), (long long)want);
     }
-    return upload(t->f32(), (size_t)want);
+    return *t;
+}
+
+const float *Model::upload_tensor(const std::string &name, std::vector<int64_t> expect) {
+    int64_t want = 1;
+    for (auto e : expect) want *= e;
+    return upload(host_tensor(name, want).f32(), (size_t)want);
 }
 
 // Slaney filterbank, fp64 build / fp32 store -- reference src/audio.cpp:24-94 (hz_to_mel_slaney, mel_to_hz_slaney,
@@ -103,6 +122,111 @@ void Model::build_mel_tables() {
     mel.power_via_abs = 1;               // switch A2 default: abs() then square, as the reference writes it
 }
 
+// Upload every tensor the hot path reads, under the reference's names (scripts/convert_nemo.py:98-310;
+// SURVEY.md Appendix B), strictly shape-checked.  Layout transforms done here, once:
+//   * depthwise taps [C][1][3][3] -> [9][C], [d][1][K] -> [K][d]  (coalesced along channels)
+//   * q/k/v projections stacked into one [3d][d] matrix (one GEMM instead of three)
+//   * BatchNorm running_var -> rstd = 1/sqrt(var + eps) (the same fp32 expression the oracle evaluates)
+//   * label_proj_ and duration_proj_ stacked into one [V+D][J] matrix
+//   * g1[token] = W_ih0 E[token] + b : the layer-0 LSTM input projection of every possible token
+void Model::upload_weights() {
+    const int d = cfg.hidden_size, C = cfg.subsampling_channels, F = cfg.mel_bins, ffn = cfg.ffn_intermediate, K = cfg.conv_kernel_size;
+    const int H = cfg.num_heads, hd = d / H;
+    int f3 = F;
+    for (int i = 0; i < 3; ++i) f3 = (f3 - 1) / 2 + 1;
+    auto taps_last = [&](const std::string &name, int ch, int taps) {   // [ch][1][taps...] -> [taps][ch]
+        const HostTensor &t = host_tensor(name, (int64_t)ch * taps);
+        std::vector<float> w((size_t)ch * taps);
+        for (int c = 0; c < ch; ++c)
+            for (int k = 0; k < taps; ++k) w[(size_t)k * ch + c] = t.f32()[(size_t)c * taps + k];
+        return upload(w.data(), w.size());
+    };
+    const std::string sp = "encoder_.subsampling_.";
+    sub.c1w = taps_last(sp + "conv1_.weight", C, 9);  sub.c1b = upload_tensor(sp + "conv1_.bias", {C});
+    sub.d1w = taps_last(sp + "dw1_.weight", C, 9);    sub.d1b = upload_tensor(sp + "dw1_.bias", {C});
+    sub.c2w = upload_tensor(sp + "conv2_.weight", {C, C}); sub.c2b = upload_tensor(sp + "conv2_.bias", {C});
+    sub.d2w = taps_last(sp + "dw2_.weight", C, 9);    sub.d2b = upload_tensor(sp + "dw2_.bias", {C});
+    sub.c3w = upload_tensor(sp + "conv3_.weight", {C, C}); sub.c3b = upload_tensor(sp + "conv3_.bias", {C});
+    sub.pw = upload_tensor(sp + "proj_.weight", {d, (int64_t)C * f3}); sub.pb = upload_tensor(sp + "proj_.bias", {d});
+
+    layers.resize(cfg.num_layers);
+    for (int i = 0; i < cfg.num_layers; ++i) {
+        LayerW &L = layers[i];
+        const std::string q = "encoder_.layers_." + std::to_string(i) + ".";
+        L.ffn1_ng = upload_tensor(q + "ffn1_.norm_.weight", {d}); L.ffn1_nb = upload_tensor(q + "ffn1_.norm_.bias", {d});
+        L.ffn1_w1 = upload_tensor(q + "ffn1_.fc1_.weight", {ffn, d}); L.ffn1_b1 = upload_tensor(q + "ffn1_.fc1_.bias", {ffn});
+        L.ffn1_w2 = upload_tensor(q + "ffn1_.fc2_.weight", {d, ffn}); L.ffn1_b2 = upload_tensor(q + "ffn1_.fc2_.bias", {d});
+        L.ffn2_ng = upload_tensor(q + "ffn2_.norm_.weight", {d}); L.ffn2_nb = upload_tensor(q + "ffn2_.norm_.bias", {d});
+        L.ffn2_w1 = upload_tensor(q + "ffn2_.fc1_.weight", {ffn, d}); L.ffn2_b1 = upload_tensor(q + "ffn2_.fc1_.bias", {ffn});
+        L.ffn2_w2 = upload_tensor(q + "ffn2_.fc2_.weight", {d, ffn}); L.ffn2_b2 = upload_tensor(q + "ffn2_.fc2_.bias", {d});
+        L.att_ng = upload_tensor(q + "attn_.norm_.weight", {d}); L.att_nb = upload_tensor(q + "attn_.norm_.bias", {d});
+        {
+            std::vector<float> w((size_t)3 * d * d), b((size_t)3 * d);
+            const char *nm[3] = {"q_proj", "k_proj", "v_proj"};
+            for (int j = 0; j < 3; ++j) {
+                const HostTensor &tw = host_tensor(q + "attn_.mha_." + nm[j] + ".weight", (int64_t)d * d);
+                const HostTensor &tb = host_tensor(q + "attn_.mha_." + nm[j] + ".bias", d);
+                memcpy(w.data() + (size_t)j * d * d, tw.f32(), (size_t)d * d * 4);
+                memcpy(b.data() + (size_t)j * d, tb.f32(), (size_t)d * 4);
+            }
+            L.wqkv = upload(w.data(), w.size());
+            L.bqkv = upload(b.data(), b.size());
+        }
+        L.wo = upload_tensor(q + "attn_.mha_.out_proj.weight", {d, d}); L.bo = upload_tensor(q + "attn_.mha_.out_proj.bias", {d});
+        L.wpos = upload_tensor(q + "attn_.pos_proj_.weight", {d, d});
+        L.pos_u = upload_tensor(q + "attn_.pos_bias_u_", {H, hd}); L.pos_v = upload_tensor(q + "attn_.pos_bias_v_", {H, hd});
+        L.cv_ng = upload_tensor(q + "conv_.norm_.weight", {d}); L.cv_nb = upload_tensor(q + "conv_.norm_.bias", {d});
+        L.pw1_w = upload_tensor(q + "conv_.pointwise_conv1_.weight", {2 * d, d}); L.pw1_b = upload_tensor(q + "conv_.pointwise_conv1_.bias", {2 * d});
+        L.dw_w = taps_last(q + "conv_.depthwise_conv_.weight", d, K); L.dw_b = upload_tensor(q + "conv_.depthwise_conv_.bias", {d});
+        L.bn_g = upload_tensor(q + "conv_.batch_norm_.weight", {d}); L.bn_b = upload_tensor(q + "conv_.batch_norm_.bias", {d});
+        L.bn_mean = upload_tensor(q + "conv_.batch_norm_.running_mean", {d});
+        {
+            const HostTensor &tv = host_tensor(q + "conv_.batch_norm_.running_var", d);
+            std::vector<float> r(d);
+            for (int c = 0; c < d; ++c) r[c] = 1.0f / sqrtf(tv.f32()[c] + 1e-5f);   // BatchNorm1d default eps (switch A3)
+            L.bn_rstd = upload(r.data(), r.size());
+        }
+        L.pw2_w = upload_tensor(q + "conv_.pointwise_conv2_.weight", {d, d}); L.pw2_b = upload_tensor(q + "conv_.pointwise_conv2_.bias", {d});
+        L.fin_g = upload_tensor(q + "final_norm_.weight", {d}); L.fin_b = upload_tensor(q + "final_norm_.bias", {d});
+    }
+
+    const int V = cfg.vocab_size, Hp = cfg.pred_hidden, J = cfg.joint_hidden, D = cfg.num_durations;
+    dec.embed = upload_tensor("prediction_.embed_.weight", {V, Hp});
+    for (int l = 0; l < cfg.num_lstm_layers; ++l) {
+        const std::string q = "prediction_.lstm_.cells_." + std::to_string(l) + ".";
+        dec.wih[l] = upload_tensor(q + "input_proj_.weight", {4 * Hp, Hp});
+        dec.bih[l] = upload_tensor(q + "input_proj_.bias", {4 * Hp});       // = b_ih + b_hh (convert_nemo.py:409-417)
+        dec.whh[l] = upload_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp});
+    }
+    const std::string jp = cfg.joint_prefix;
+    dec.we = upload_tensor(jp + "enc_proj_.weight", {J, d}); dec.be = upload_tensor(jp + "enc_proj_.bias", {J});
+    dec.wp = upload_tensor(jp + "pred_proj_.weight", {J, Hp});
+    dec.bp = (cfg.joint_pred_bias && st_->find(jp + "pred_proj_.bias")) ? upload_tensor(jp + "pred_proj_.bias", {J}) : nullptr;
+    {
+        std::vector<float> w((size_t)(V + D) * J), b((size_t)(V + D));
+        const std::string ln = cfg.rnnt_head ? "out_proj_" : "label_proj_";
+        memcpy(w.data(), host_tensor(jp + ln + ".weight", (int64_t)V * J).f32(), (size_t)V * J * 4);
+        memcpy(b.data(), host_tensor(jp + ln + ".bias", V).f32(), (size_t)V * 4);
+        if (D > 0) {
+            memcpy(w.data() + (size_t)V * J, host_tensor(jp + "duration_proj_.weight", (int64_t)D * J).f32(), (size_t)D * J * 4);
+            memcpy(b.data() + V, host_tensor(jp + "duration_proj_.bias", D).f32(), (size_t)D * 4);
+        }
+        wld = upload(w.data(), w.size());
+        bld = upload(b.data(), b.size());
+    }
+    if (cfg.ctc_vocab_size > 0) {
+        dec.ctc_w = upload_tensor("ctc_decoder_.proj_.weight", {cfg.ctc_vocab_size, d});
+        dec.ctc_b = upload_tensor("ctc_decoder_.proj_.bias", {cfg.ctc_vocab_size});
+    }
+    // g1 = E W_ih0^T + b  ([V][4Hp]) on the MFMA GEMM: the same natural-k chains the per-step projection would run
+    float *g1 = dev_alloc((size_t)V * 4 * Hp);
+    gemm("g1_table", dec.embed, Hp, dec.wih[0], Hp, dec.bih[0], g1, 4 * Hp, V, 4 * Hp, Hp, EPI_NONE, nullptr, 0, 1.0f, stream);
+    PK_CHECK_LAUNCH();
+    PK_HIP(hipStreamSynchronize(stream));
+    dec.g1 = g1;
+    st_.reset();   // host mapping no longer needed
+}
+
 void Model::to_gpu(int device) {
     if (device_ == device) return;
     if (device_ >= 0) fail(PK_ERR_INVALID, "model already lives on device %d", device_);
@@ -115,19 +239,227 @@ void Model::to_gpu(int device) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         fail(PK_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 (MI355X) code only", device, prop.gcnArchName);
     PK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    PK_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_done), sizeof(int), hipHostMallocDefault));
     device_ = device;
     build_mel_tables();
     upload_weights();
 }
 
+// ---- profiling hooks ----------------------------------------------------------------------------------------
+void Model::klaunch_begin(const char *name, double flops, double bytes, hipStream_t s) {
+    if (!prof) return;
+    ProfileSink::Rec r;
+    r.name = name; r.flops = flops; r.bytes = bytes;
+    PK_HIP(hipEventCreate(&r.e0));
+    PK_HIP(hipEventCreate(&r.e1));
+    PK_HIP(hipEventRecord(r.e0, s));
+    prof->recs.push_back(r);
+}
+void Model::klaunch_end(hipStream_t s) {
+    if (!prof) return;
+    PK_HIP(hipEventRecord(prof->recs.back().e1, s));
+}
+#define KL(name, flops, bytes, call) do { klaunch_begin(name, flops, bytes, s); call; klaunch_end(s); } while (0)
+
+void Model::gemm(const char *name, const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *out, int64_t ldo,
+                 int M, int N, int K, int epi, const float *resid, int64_t ldr, float alpha, hipStream_t s) {
+    GemmArgs g{A, lda, W, ldw, bias, out, ldo, resid, ldr, alpha, M, N, K};
+    KL(name, gemm_flops(g, epi), 0.0, launch_gemm(g, epi, s));
+}
+
+// ---- workspace ----------------------------------------------------------------------------------------------
+void Workspace::size_for(const pk_config &c, int B_, int64_t n_samples_, int Tm_) {
+    B = B_; n_samples = n_samples_; Tm = Tm_;
+    const int F = c.mel_bins, C = c.subsampling_channels, d = c.hidden_size;
+    auto sl = [](int n) { return (n - 1) / 2 + 1; };
+    const int H1 = sl(Tm), W1 = sl(F), H2 = sl(H1), W2 = sl(W1), H3 = sl(H2), W3 = sl(W2);
+    T = H3;
+    const size_t M = (size_t)B * T, f = sizeof(float);
+    if (n_samples > 0) { pcm.reserve((size_t)B * n_samples * f); logmel.reserve((size_t)B * F * Tm * f); }
+    feats.reserve((size_t)B * Tm * F * f);
+    a2.reserve((size_t)B * H2 * W2 * C * f); a3.reserve((size_t)B * H2 * W2 * C * f);
+    a4.reserve((size_t)B * H3 * W3 * C * f); flat.reserve((size_t)B * H3 * W3 * C * f);
+    x.reserve(M * d * f); n.reserve(M * d * f); hbuf.reserve(M * c.ffn_intermediate * f); qkv.reserve(M * 3 * d * f);
+    ctx.reserve(M * d * f); g.reserve(M * d * f); dwb.reserve(M * d * f);
+    if (c.ctc_vocab_size > 0) { ctc_logits.reserve(M * c.ctc_vocab_size * f); }
+    best_idx.reserve(M * sizeof(int)); best_lp.reserve(M * f);
+    max_tokens = T * (c.max_symbols_per_step > 0 ? c.max_symbols_per_step : 10);
+    const int Hp = c.pred_hidden, J = c.joint_hidden, L = c.num_lstm_layers, VD = c.vocab_size + c.num_durations;
+    ep.reserve(M * J * f); gh.reserve((size_t)B * 4 * Hp * f); gi.reserve((size_t)B * 4 * Hp * f); pp.reserve((size_t)B * J * f);
+    z.reserve((size_t)B * J * f); logits.reserve((size_t)B * VD * f);
+    h.reserve((size_t)L * B * Hp * f); this->c.reserve((size_t)L * B * Hp * f); hn.reserve((size_t)L * B * Hp * f); cn.reserve((size_t)L * B * Hp * f);
+    ints.reserve((size_t)(8 * B + 8) * sizeof(int));
+    const size_t tok = (size_t)B * max_tokens;
+    ids.reserve(tok * sizeof(int)); start.reserve(tok * sizeof(int)); end.reserve(tok * sizeof(int)); conf.reserve(tok * f);
+    lens.reserve((size_t)B * sizeof(int));
+}
+
+// ---- stages ---------------------------------------------------------------------------------------------------
 void Model::run_mel(const float *d_pcm, int B, int64_t n_samples, float *d_logmel, float *d_feats, hipStream_t s) {
     const int n_frames = (int)(1 + n_samples / 160);
-    launch_mel_logmel(d_pcm, B, n_samples, n_frames, mel, d_logmel, s);
-    launch_mel_normalize(d_logmel, B, cfg.mel_bins, n_frames, 1, d_feats, s);
+    const double bytes_in = (double)B * n_samples * 4, bytes_lm = (double)B * cfg.mel_bins * n_frames * 4;
+    KL("mel_logmel", 0.0, bytes_in + bytes_lm, launch_mel_logmel(d_pcm, B, n_samples, n_frames, mel, d_logmel, s));
+    KL("mel_normalize", 0.0, 2.0 * bytes_lm, launch_mel_normalize(d_logmel, B, cfg.mel_bins, n_frames, 1, d_feats, s));
+}
+
+// sinusoidal_position_embedding (src/encoder.cpp:9-30): float math on the host, exactly as the reference does,
+// then pos_proj_ of every layer (src/encoder.cpp:148) -- batch-independent, so computed once per sequence length.
+void Model::ensure_pos_tables(int T, hipStream_t s) {
+    if (T == pos_T) return;
+    const int d = cfg.hidden_size, P = 2 * T - 1;
+    std::vector<float> pe((size_t)P * d);
+    for (int p = 0; p < P; ++p) {
+        const float position = (float)(T - 1 - p);
+        for (int i = 0; i < d; i += 2) {
+            const float div_term = std::exp((float)i * (-std::log(10000.0f) / (float)d));
+            pe[(size_t)p * d + i] = std::sin(position * div_term);
+            if (i + 1 < d) pe[(size_t)p * d + i + 1] = std::cos(position * div_term);
+        }
+    }
+    PK_HIP(hipStreamSynchronize(s));       // previous users of the tables
+    pos_pe.reserve(pe.size() * 4);
+    pos_proj.reserve((size_t)cfg.num_layers * P * d * 4);
+    PK_HIP(hipMemcpy(pos_pe.p, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+    for (int l = 0; l < cfg.num_layers; ++l)
+        gemm("pos_proj", pos_pe.as<float>(), d, layers[l].wpos, d, nullptr, pos_proj.as<float>() + (size_t)l * P * d, d, P, d, d, EPI_NONE,
+             nullptr, 0, 1.0f, s);
+    pos_T = T;
+}
+
+void Model::run_subsample(Workspace &w, const float *d_feats, int B, int Tm, float *d_x, hipStream_t s) {
+    const int F = cfg.mel_bins, C = cfg.subsampling_channels, d = cfg.hidden_size;
+    auto sl = [](int n) { return (n - 1) / 2 + 1; };
+    const int H1 = sl(Tm), W1 = sl(F), H2 = sl(H1), W2 = sl(W1), H3 = sl(H2), W3 = sl(W2);
+    const double px2 = (double)B * H2 * W2, px3 = (double)B * H3 * W3;
+    // conv1 + ReLU + dw1 (fused)  src/encoder.cpp:223-226
+    KL("sub_conv1_dw1", px2 * C * (81.0 + 9.0) * 2.0, (double)B * Tm * F * 4 + px2 * C * 4,
+       launch_sub_conv1_dw1(d_feats, B, Tm, F, C, sub.c1w, sub.c1b, sub.d1w, sub.d1b, w.a2.as<float>(), s));
+    // conv2 (1x1) + ReLU  :227-228
+    gemm("sub_pw", w.a2.as<float>(), C, sub.c2w, C, sub.c2b, w.a3.as<float>(), C, (int)px2, C, C, EPI_RELU, nullptr, 0, 1.0f, s);
+    // dw2  :230
+    KL("sub_dw2", px3 * C * 18.0, (px2 + px3) * C * 4, launch_sub_dw(w.a3.as<float>(), B, H2, W2, C, sub.d2w, sub.d2b, w.a4.as<float>(), s));
+    // conv3 (1x1) + ReLU, written directly in permute(0,2,1,3)+reshape order (feature = c*W3 + f)  :231-238
+    {
+        GemmArgs g{w.a4.as<float>(), C, sub.c3w, C, sub.c3b, w.flat.as<float>(), C, nullptr, 0, 1.0f, (int)px3, C, C};
+        g.remap_rows = W3; g.remap_gs = (int64_t)C * W3; g.remap_rs = 1; g.remap_cs = W3;
+        KL("sub_pw", gemm_flops(g, EPI_RELU), 0.0, launch_gemm(g, EPI_RELU, s));
+    }
+    // proj_  :240
+    gemm("sub_proj", w.flat.as<float>(), (int64_t)C * W3, sub.pw, (int64_t)C * W3, sub.pb, d_x, d, B * H3, d, C * W3, EPI_NONE, nullptr, 0, 1.0f, s);
+    (void)W1; (void)H1;
+}
+
+// FeedForward::forward (src/encoder.cpp:39-46): x += 0.5 * fc2(silu(fc1(LN(x))))
+void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s) {
+    const int d = cfg.hidden_size, f = cfg.ffn_intermediate;
+    float *x = w.x.as<float>(), *n = w.n.as<float>(), *h = w.hbuf.as<float>();
+    KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, s));
+    gemm("ffn_fc1_silu", n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, h, f, (int)rows, f, d, EPI_SILU, nullptr, 0, 1.0f, s);
+    gemm("ffn_fc2_resid", h, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, (int)rows, d, f, EPI_RESID, x, d, 0.5f, s);
+}
+
+// FastConformerEncoder::forward (src/encoder.cpp:253-271) -> w.x [B][T][d]
+void Model::run_encoder(Workspace &w, const float *d_feats, int B, int Tm, int stop_layer, int stop_stage, hipStream_t s) {
+    const int d = cfg.hidden_size, T = w.T, P = 2 * T - 1;
+    const int64_t rows = (int64_t)B * T;
+    float *x = w.x.as<float>(), *n = w.n.as<float>();
+    run_subsample(w, d_feats, B, Tm, x, s);
+    if (stop_layer < 0 || stop_layer > cfg.num_layers) { stop_layer = cfg.num_layers; stop_stage = 0; }
+    if (stop_layer == 0 && stop_stage == 0) return;
+    ensure_pos_tables(T, s);
+    for (int l = 0; l < cfg.num_layers; ++l) {
+        if (l > stop_layer || (l == stop_layer && stop_stage == 0)) break;
+        const LayerW &L = layers[l];
+        const int stage_cap = (l == stop_layer) ? stop_stage : 5;
+        ffn(w, L, false, rows, s);                                                   // ffn1_  :197
+        if (stage_cap == 1) break;
+        // ConformerAttention::forward  :180-186
+        KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, s));
+        gemm("attn_qkv", n, d, L.wqkv, d, L.bqkv, w.qkv.as<float>(), 3 * d, (int)rows, 3 * d, d, EPI_NONE, nullptr, 0, 1.0f, s);
+        {
+            const int hd = d / cfg.num_heads;
+            const double fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);   // QK^T + QP^T(needed band) + AV
+            KL("relpos_attention", fl, 0.0,
+               launch_relpos_attention(w.qkv.as<float>(), B, T, d, cfg.num_heads, pos_proj.as<float>() + (size_t)l * P * d, L.pos_u, L.pos_v,
+                                       w.ctx.as<float>(), s));
+        }
+        gemm("attn_out_resid", w.ctx.as<float>(), d, L.wo, d, L.bo, x, d, (int)rows, d, d, EPI_RESID, x, d, 1.0f, s);
+        if (stage_cap == 2) break;
+        // ConformerConvModule::forward  :59-75
+        KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.cv_ng, L.cv_nb, 1e-5f, n, s));
+        gemm("conv_pw1_glu", n, d, L.pw1_w, d, L.pw1_b, w.g.as<float>(), d, (int)rows, d, d, EPI_GLU, nullptr, 0, 1.0f, s);
+        KL("dwconv_bn_silu", (double)rows * d * cfg.conv_kernel_size * 2.0, 2.0 * rows * d * 4,
+           launch_dwconv_bn_silu(w.g.as<float>(), B, T, d, cfg.conv_kernel_size, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
+                                 w.dwb.as<float>(), s));
+        gemm("conv_pw2_resid", w.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, (int)rows, d, d, EPI_RESID, x, d, 1.0f, s);
+        if (stage_cap == 3) break;
+        ffn(w, L, true, rows, s);                                                    // ffn2_  :201
+        if (stage_cap == 4) break;
+        KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, s));   // final_norm_ :202
+    }
+}
+
+// CTCDecoder::forward + ctc_greedy_decode(_with_timestamps)  (src/ctc.cpp:12-25, :40-127)
+void Model::run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_logp, hipStream_t s) {
+    if (cfg.ctc_vocab_size <= 0) fail(PK_ERR_UNSUPPORTED, "this model has no ctc_decoder_ head");
+    const int V = cfg.ctc_vocab_size, d = cfg.hidden_size;
+    const int64_t rows = (int64_t)B * T;
+    gemm("ctc_head", d_enc, d, dec.ctc_w, d, dec.ctc_b, w.ctc_logits.as<float>(), V, (int)rows, V, d, EPI_NONE, nullptr, 0, 1.0f, s);
+    if (want_logp) w.ctc_lp.reserve((size_t)rows * V * 4);
+    KL("logsoftmax_argmax", 0.0, (double)rows * V * 4,
+       launch_logsoftmax_argmax(w.ctc_logits.as<float>(), rows, V, V, want_logp ? w.ctc_lp.as<float>() : nullptr, w.best_idx.as<int>(), w.best_lp.as<float>(), s));
+    // CTC token arrays are [B][T]; they share the TDT output buffers (sized >= B*T)
+    KL("ctc_collapse", 0.0, 0.0,
+       launch_ctc_collapse(w.best_idx.as<int>(), w.best_lp.as<float>(), B, T, cfg.blank_id < V ? cfg.blank_id : V - 1, w.ids.as<int>(), w.lens.as<int>(),
+                           w.start.as<int>(), w.end.as<int>(), w.conf.as<float>(), s));
+}
+
+// tdt_greedy_decode(_with_timestamps) / rnnt_greedy_decode  (src/tdt.cpp:36-201, src/rnnt.cpp:56-177)
+void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s) {
+    const int d = cfg.hidden_size, Hp = cfg.pred_hidden, J = cfg.joint_hidden, V = cfg.vocab_size, D = cfg.rnnt_head ? 0 : cfg.num_durations;
+    const int L = cfg.num_lstm_layers;
+    // enc_proj_ hoisted out of the symbol loop: one GEMM over all frames (the reference recomputes it per symbol, src/tdt.cpp:17)
+    gemm("joint_enc_proj", d_enc, d, dec.we, d, dec.be, w.ep.as<float>(), J, B * T, J, d, EPI_NONE, nullptr, 0, 1.0f, s);
+    TdtState st{};
+    st.B = B; st.T = T; st.V = V; st.D = D; st.L = L; st.Hp = Hp; st.blank = cfg.blank_id; st.max_symbols = cfg.max_symbols_per_step;
+    st.max_tokens = max_tokens;
+    st.max_steps = T * (cfg.max_symbols_per_step + 1) + 16;          // safety cap (the reference has none)
+    for (int i = 0; i < D; ++i) st.durations[i] = cfg.durations[i];
+    st.logits = w.logits.as<float>();
+    st.h = w.h.as<float>(); st.c = w.c.as<float>(); st.hn = w.hn.as<float>(); st.cn = w.cn.as<float>();
+    int *ib = w.ints.as<int>();
+    st.token = ib; st.t = ib + B; st.nsym = ib + 2 * B; st.n_out = ib + 3 * B; st.steps = ib + 4 * B; st.done = ib + 5 * B;
+    st.done_count = ib + 6 * B;
+    st.lens = w.lens.as<int>();
+    st.ids = w.ids.as<int>(); st.start = w.start.as<int>(); st.end = w.end.as<int>(); st.conf = w.conf.as<float>();
+    PK_HIP(hipMemsetAsync(w.h.p, 0, (size_t)L * B * Hp * 4, s));
+    PK_HIP(hipMemsetAsync(w.c.p, 0, (size_t)L * B * Hp * 4, s));
+    launch_tdt_init(st, s);
+    const int chunk = 16;
+    for (int step = 0; step < st.max_steps; ++step) {
+        for (int l = 0; l < L; ++l) {
+            float *hl = w.h.as<float>() + (size_t)l * B * Hp, *cl = w.c.as<float>() + (size_t)l * B * Hp;
+            float *hnl = w.hn.as<float>() + (size_t)l * B * Hp, *cnl = w.cn.as<float>() + (size_t)l * B * Hp;
+            gemm("lstm_hh", hl, Hp, dec.whh[l], Hp, nullptr, w.gh.as<float>(), 4 * Hp, B, 4 * Hp, Hp, EPI_NONE, nullptr, 0, 1.0f, s);
+            if (l == 0) {
+                KL("lstm_cell", 0.0, 0.0, launch_lstm_cell(dec.g1, 4 * Hp, st.token, w.gh.as<float>(), cl, B, Hp, hnl, cnl, s));
+            } else {
+                const float *prev = w.hn.as<float>() + (size_t)(l - 1) * B * Hp;
+                gemm("lstm_ih", prev, Hp, dec.wih[l], Hp, dec.bih[l], w.gi.as<float>(), 4 * Hp, B, 4 * Hp, Hp, EPI_NONE, nullptr, 0, 1.0f, s);
+                KL("lstm_cell", 0.0, 0.0, launch_lstm_cell(w.gi.as<float>(), 4 * Hp, nullptr, w.gh.as<float>(), cl, B, Hp, hnl, cnl, s));
+            }
+        }
+        const float *pred = w.hn.as<float>() + (size_t)(L - 1) * B * Hp;
+        gemm("joint_pred_proj", pred, Hp, dec.wp, Hp, nullptr, w.pp.as<float>(), J, B, J, Hp, EPI_NONE, nullptr, 0, 1.0f, s);
+        KL("joint_act", 0.0, 0.0, launch_joint_act(w.ep.as<float>(), st.t, T, J, w.pp.as<float>(), dec.bp, B, w.z.as<float>(), s));
+        gemm("joint_heads", w.z.as<float>(), J, wld, J, bld, w.logits.as<float>(), V + D, B, V + D, J, EPI_NONE, nullptr, 0, 1.0f, s);
+        KL("tdt_decide", 0.0, 0.0, launch_tdt_decide(st, s));
+        if ((step + 1) % chunk == 0) {                                 // poll "all finished" once per chunk of steps
+            PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));
+            PK_HIP(hipStreamSynchronize(s));
+            if (*h_done >= B) break;
+        }
+    }
 }
 
 }  // namespace pk
-
-namespace pk {
-void Model::upload_weights() {}  // TEMP-STUB (replaced when the encoder lands)
-}

@@ -34,7 +34,21 @@ struct DecW {
     const float *ctc_w, *ctc_b;
 };
 
-struct ProfileSink;   // per-kernel hipEvent timing (engine.cpp)
+// Per-kernel hipEvent timing: when a sink is attached every launch is bracketed by two events.
+struct ProfileSink {
+    struct Rec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
+    std::vector<Rec> recs;
+    ~ProfileSink();
+};
+
+// Activation workspace of one resident batch (B clips of n_samples): sized once, reused every run.
+struct Workspace {
+    int B = 0; int64_t n_samples = 0; int Tm = 0, T = 0, max_tokens = 0;
+    DevBuf pcm, logmel, feats, a2, a3, a4, a5, flat, x, n, hbuf, qkv, ctx, g, dwb;
+    DevBuf ctc_logits, ctc_lp, best_idx, best_lp;
+    DevBuf ep, gh, gi, pp, z, logits, h, c, hn, cn, ints, ids, start, end, conf, lens;
+    void size_for(const pk_config &cfg, int B, int64_t n_samples, int Tm);
+};
 
 class Model {
   public:
@@ -55,21 +69,42 @@ class Model {
     SubW sub{};
     std::vector<LayerW> layers;
     DecW dec{};
+    const float *wld = nullptr, *bld = nullptr;     // [V+D][J] label_proj rows then duration_proj rows (+ biases)
 
-    // stage drivers (device pointers, enqueue on `s`)
+    // relative-position tables: sinusoidal pe [2T-1][d] (src/encoder.cpp:9-30, host float math) and the
+    // per-layer pos_proj_(pe) [L][2T-1][d]; they depend on (T, weights) only, so they are rebuilt when T changes.
+    int pos_T = 0;
+    DevBuf pos_pe, pos_proj;
+    void ensure_pos_tables(int T, hipStream_t s);
+
+    // stage drivers (device pointers, enqueue on `s`, never synchronise)
     void run_mel(const float *d_pcm, int B, int64_t n_samples, float *d_logmel, float *d_feats, hipStream_t s);
+    void run_subsample(Workspace &w, const float *d_feats, int B, int Tm, float *d_x, hipStream_t s);
+    void run_encoder(Workspace &w, const float *d_feats, int B, int Tm, int stop_layer, int stop_stage, hipStream_t s);  // -> w.x
+    void run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_logp, hipStream_t s);
+    void run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s);
+
+    ProfileSink *prof = nullptr;
+    void klaunch_begin(const char *name, double flops, double bytes, hipStream_t s);
+    void klaunch_end(hipStream_t s);
 
     // grow-only scratch shared by the host-buffer entry points
     DevBuf io_in, io_out, io_tmp;
+    Workspace ws;       // workspace of the host-buffer stage entry points
+    int *h_done = nullptr;   // pinned host word for the decode loop's "all utterances finished" poll
 
     const float *upload(const float *host, size_t n);
     const float *upload_tensor(const std::string &name, std::vector<int64_t> expect_shape);
+    const HostTensor &host_tensor(const std::string &name, int64_t expect_numel);
     float *dev_alloc(size_t n_floats);
 
   private:
     std::unique_ptr<SafeTensors> st_;
     void build_mel_tables();
     void upload_weights();
+    void gemm(const char *name, const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *out, int64_t ldo,
+              int M, int N, int K, int epi, const float *resid, int64_t ldr, float alpha, hipStream_t s);
+    void ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s);
 };
 
 // thread-local error slot of the C ABI

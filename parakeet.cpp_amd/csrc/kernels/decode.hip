@@ -1,0 +1,214 @@
+// parakeet.cpp_amd/csrc/kernels/decode.hip -- on-device greedy decoders.
+//
+// CTC  (reference src/ctc.cpp:12-25, :40-127): row log-softmax + first-max argmax, then the collapse /
+//      timestamp rules, one thread per utterance (T <= a few hundred frames).
+// TDT / RNNT (src/tdt.cpp:36-201, src/rnnt.cpp:56-177, src/lstm.cpp:11-29): the whole greedy loop stays on
+//      the GPU -- the reference does 2 device->host scalar syncs per symbol.  All utterances of a batch
+//      advance in lock-step; one "step" = one joint evaluation per live utterance:
+//        gemm  GH = h W_hh^T            (MFMA)           -> lstm_cell   (gates, c', h' candidates)
+//        gemm  PP = h' W_pred^T         (MFMA)           -> joint_act   z = relu(enc_proj[t_b] + PP)
+//        gemm  LOG = z [W_label;W_dur]^T + b (MFMA)      -> tdt_decide  log-softmax, argmax, control,
+//                                                                        commit / revert of the LSTM state
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+
+namespace pk {
+
+// ---- row log-softmax + first-max argmax (one wavefront per row) ---------------------------------------
+// lsm = (x - max) - log(sum64(exp(x - max))).  argmax over lsm with strict '>' (lowest index wins ties).
+struct BestLP {
+    float lp;
+    int idx;
+};
+__device__ __forceinline__ BestLP wave_logsoftmax_argmax(const float *__restrict__ x, int n, float *__restrict__ lp_out, int lane) {
+    float m = -__builtin_huge_valf();
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, x[i]);
+    m = wave_max64(m);
+    float p = 0.0f;
+    for (int i = lane; i < n; i += 64) p = p + dexpf(x[i] - m);
+    const float lse = dlogf(wave_sum64(p));
+    float best = -__builtin_huge_valf();
+    int bi = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const float l = (x[i] - m) - lse;
+        if (lp_out) lp_out[i] = l;
+        if (bi == 0x7fffffff || l > best) { best = l; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    return {best, bi};
+}
+
+__global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(const float *__restrict__ logits, int64_t rows, int ld, int n,
+                                                                float *__restrict__ lp_out, int *__restrict__ best_idx,
+                                                                float *__restrict__ best_lp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const BestLP r = wave_logsoftmax_argmax(logits + row * ld, n, lp_out ? lp_out + row * n : nullptr, lane);
+    if (lane == 0) {
+        best_idx[row] = r.idx;
+        best_lp[row] = r.lp;
+    }
+}
+void launch_logsoftmax_argmax(const float *logits, int64_t rows, int ld, int n, float *lp_out, int *best_idx, float *best_lp, hipStream_t s) {
+    hipLaunchKernelGGL(logsoftmax_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, rows, ld, n, lp_out, best_idx, best_lp);
+}
+
+// ctc_greedy_decode(_with_timestamps): src/ctc.cpp:52-72 and :93-123, literally.
+__global__ void ctc_collapse_kernel(const int *__restrict__ best_idx, const float *__restrict__ best_lp, int B, int T, int blank,
+                                    int *__restrict__ ids, int *__restrict__ lens, int *__restrict__ start, int *__restrict__ end,
+                                    float *__restrict__ conf) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int prev = -1, n = 0;
+    for (int t = 0; t < T; ++t) {
+        const int best = best_idx[(int64_t)b * T + t];
+        if (best != prev) {
+            if (prev != -1 && prev != blank && n > 0) end[(int64_t)b * T + n - 1] = t - 1;
+            if (best != blank) {
+                ids[(int64_t)b * T + n] = best;
+                start[(int64_t)b * T + n] = t;
+                end[(int64_t)b * T + n] = t;
+                conf[(int64_t)b * T + n] = dexpf(best_lp[(int64_t)b * T + t]);
+                ++n;
+            }
+        }
+        prev = best;
+    }
+    if (n > 0) end[(int64_t)b * T + n - 1] = T - 1;
+    lens[b] = n;
+}
+void launch_ctc_collapse(const int *best_idx, const float *best_lp, int B, int T, int blank, int *ids, int *lens, int *start, int *end,
+                         float *conf, hipStream_t s) {
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, s, best_idx, best_lp, B, T, blank, ids, lens, start, end, conf);
+}
+
+// ---- TDT / RNNT step kernels --------------------------------------------------------------------------
+// LSTMCell::forward (src/lstm.cpp:11-29), gate order i,f,g,o.  gi = W_ih x + b (layer 0: row `token` of the
+// precomputed table g1 = W_ih E + b), gh = W_hh h.  Writes CANDIDATE states hn/cn; tdt_decide commits them.
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float *__restrict__ gi, int gi_ld, const int *__restrict__ gi_row,
+                                                        const float *__restrict__ gh, const float *__restrict__ c,
+                                                        int B, int Hp, float *__restrict__ hn, float *__restrict__ cn) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * Hp) return;
+    const int b = idx / Hp, j = idx % Hp;
+    const float *gir = gi + (int64_t)(gi_row ? gi_row[b] : b) * gi_ld;
+    const float *ghr = gh + (int64_t)b * 4 * Hp;
+    const float ig = dsigmoidf(gir[j] + ghr[j]);
+    const float fg = dsigmoidf(gir[Hp + j] + ghr[Hp + j]);
+    const float gg = dtanhf(gir[2 * Hp + j] + ghr[2 * Hp + j]);
+    const float og = dsigmoidf(gir[3 * Hp + j] + ghr[3 * Hp + j]);
+    const float t1 = fg * c[idx];
+    const float t2 = ig * gg;
+    const float cnew = t1 + t2;
+    cn[idx] = cnew;
+    hn[idx] = og * dtanhf(cnew);
+}
+void launch_lstm_cell(const float *gi, int gi_ld, const int *gi_row, const float *gh, const float *c, int B, int Hp, float *hn,
+                      float *cn, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3((B * Hp + 255) / 256), dim3(256), 0, s, gi, gi_ld, gi_row, gh, c, B, Hp, hn, cn);
+}
+
+// TDTJoint::forward first half (src/tdt.cpp:17-18): z = relu(enc_proj(enc_t) + pred_proj(pred) [+ bp, switch A5])
+__global__ __launch_bounds__(256) void joint_act_kernel(const float *__restrict__ ep, const int *__restrict__ t, int T, int J,
+                                                        const float *__restrict__ pp, const float *__restrict__ bp, int B,
+                                                        float *__restrict__ z) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * J) return;
+    const int b = idx / J, j = idx % J;
+    int tt = t[b];
+    tt = tt < T ? tt : T - 1;
+    float p = pp[idx];
+    if (bp) p = p + bp[j];
+    const float s = ep[((int64_t)b * T + tt) * J + j] + p;
+    z[idx] = s > 0.0f ? s : 0.0f;
+}
+void launch_joint_act(const float *ep, const int *t, int T, int J, const float *pp, const float *bp, int B, float *z, hipStream_t s) {
+    hipLaunchKernelGGL(joint_act_kernel, dim3((B * J + 255) / 256), dim3(256), 0, s, ep, t, T, J, pp, bp, B, z);
+}
+
+// One wavefront per utterance: heads' log-softmax + argmax, then the control flow of
+// tdt_greedy_decode (src/tdt.cpp:62-106; timestamps :157-187) or rnnt_greedy_decode (src/rnnt.cpp:75-107).
+__global__ __launch_bounds__(64) void tdt_decide_kernel(TdtState st) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (st.done[b]) return;
+    const float *lg = st.logits + (int64_t)b * (st.V + st.D);
+    const BestLP lab = wave_logsoftmax_argmax(lg, st.V, nullptr, lane);
+    int skip = 1;
+    if (st.D > 0) {
+        const BestLP dur = wave_logsoftmax_argmax(lg + st.V, st.D, nullptr, lane);
+        skip = dur.idx < st.D ? st.durations[dur.idx] : 1;
+    }
+    // scalar control (wave-uniform values; lane 0 writes)
+    int t = st.t[b];
+    const int nsteps = st.steps[b] + 1;
+    int n_out = st.n_out[b];
+    int nsym = st.nsym[b];
+    const bool commit = lab.idx != st.blank;
+    if (!commit) {
+        // blank: the LSTM state reverts -- the candidates hn/cn are simply not committed (src/tdt.cpp:88-93)
+        t += (st.D > 0) ? (skip > 1 ? skip : 1) : 1;
+        nsym = 0;
+    } else {
+        if (lane == 0) {
+            if (n_out < st.max_tokens) {
+                const int64_t o = (int64_t)b * st.max_tokens + n_out;
+                st.ids[o] = lab.idx;
+                st.start[o] = t;
+                int e = st.D > 0 ? t + (skip > 1 ? skip : 1) - 1 : t;     // src/tdt.cpp:184-187 ; rnnt.cpp:170 (end = t)
+                st.end[o] = e < st.T ? e : st.T - 1;
+                st.conf[o] = dexpf(lab.lp);                                 // confidence = exp(max log-prob) :169
+            }
+            st.token[b] = lab.idx;
+        }
+        ++n_out;
+        if (st.D > 0) {
+            if (skip > 0) t += skip;                  // duration 0: emit another symbol on the same frame (:99-105)
+        } else if (++nsym >= st.max_symbols) {        // RNNT: the inner for runs out -> next frame (rnnt.cpp:82-107)
+            t += 1;
+            nsym = 0;
+        }
+        const int n = st.L * st.Hp;                   // commit the candidate LSTM state, [L][B][Hp]
+        for (int i = lane; i < n; i += 64) {
+            const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
+            st.h[o] = st.hn[o];
+            st.c[o] = st.cn[o];
+        }
+    }
+    if (lane == 0) {
+        bool finished = t >= st.T;
+        int len = n_out < st.max_tokens ? n_out : st.max_tokens;
+        if (!finished && st.max_steps > 0 && nsteps >= st.max_steps) { finished = true; len = -1; }   // safety cap
+        st.t[b] = t;
+        st.steps[b] = nsteps;
+        st.n_out[b] = n_out;
+        st.nsym[b] = nsym;
+        if (finished) {
+            st.lens[b] = len;
+            st.done[b] = 1;
+            atomicAdd(st.done_count, 1);
+        }
+    }
+}
+void launch_tdt_decide(const TdtState &st, hipStream_t s) { hipLaunchKernelGGL(tdt_decide_kernel, dim3(st.B), dim3(64), 0, s, st); }
+
+__global__ void tdt_init_kernel(TdtState st) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) *st.done_count = 0;
+    if (b >= st.B) return;
+    st.token[b] = st.blank;        // SOS = blank (src/tdt.cpp:56-59)
+    st.t[b] = 0;
+    st.nsym[b] = 0;
+    st.n_out[b] = 0;
+    st.steps[b] = 0;
+    st.done[b] = 0;
+    st.lens[b] = 0;
+}
+void launch_tdt_init(const TdtState &st, hipStream_t s) { hipLaunchKernelGGL(tdt_init_kernel, dim3((st.B + 63) / 64), dim3(64), 0, s, st); }
+
+}  // namespace pk

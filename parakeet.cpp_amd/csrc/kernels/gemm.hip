@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int tiles_n, i
                     if (g.bias) gt = gt + bias_g;
                     v = v * dsigmoidf(gt);
                 }
-                g.out[(int64_t)row * g.ldo + col] = v;
+                if (g.remap_rows) g.out[(int64_t)(row / g.remap_rows) * g.remap_gs + (int64_t)(row % g.remap_rows) * g.remap_rs + (int64_t)col * g.remap_cs] = v;
+                else g.out[(int64_t)row * g.ldo + col] = v;
             }
         }
     }

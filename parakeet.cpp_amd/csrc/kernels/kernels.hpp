@@ -30,9 +30,43 @@ struct GemmArgs {
     float *out; int64_t ldo;
     const float *resid; int64_t ldr; float alpha;   // EPI_RESID: out = resid + alpha * (acc + bias)
     int M, N, K;                // N = output width (GLU: W has 2N rows, a-part rows [0,N), gate rows [N,2N))
+    // optional output re-mapping (0 = off): offset = (row / remap_rows) * remap_gs + (row % remap_rows) * remap_rs + col * remap_cs
+    // (used to write the last subsampling conv straight into the permute(0,2,1,3)+reshape layout, src/encoder.cpp:235-238)
+    int remap_rows = 0; int64_t remap_gs = 0, remap_rs = 0, remap_cs = 0;
 };
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
 double gemm_flops(const GemmArgs &a, int epi);
+
+// ---- conv subsampling (src/encoder.cpp:219-241), channels-last ---------------------------------------
+void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
+                          const float *bd, float *out, hipStream_t s);
+void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, float *out, hipStream_t s);
+
+// ---- conformer pieces ---------------------------------------------------------------------------------
+void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
+                             const float *bias_v, float *ctx, hipStream_t s);
+void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
+                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s);
+
+// ---- decoders -------------------------------------------------------------------------------------------
+void launch_logsoftmax_argmax(const float *logits, int64_t rows, int ld, int n, float *lp_out, int *best_idx, float *best_lp, hipStream_t s);
+void launch_ctc_collapse(const int *best_idx, const float *best_lp, int B, int T, int blank, int *ids, int *lens, int *start, int *end,
+                         float *conf, hipStream_t s);
+struct TdtState {
+    int B, T, V, D, L, Hp, blank, max_symbols, max_tokens, max_steps;
+    int durations[8];
+    const float *logits;            // [B][V+D]
+    float *h, *c;                   // committed LSTM state [L][B][Hp]
+    const float *hn, *cn;           // candidates of this step
+    int *token, *t, *nsym, *n_out, *steps, *done, *lens, *done_count;
+    int *ids, *start, *end;         // [B][max_tokens]
+    float *conf;
+};
+void launch_tdt_init(const TdtState &st, hipStream_t s);
+void launch_lstm_cell(const float *gi, int gi_ld, const int *gi_row, const float *gh, const float *c, int B, int Hp, float *hn,
+                      float *cn, hipStream_t s);
+void launch_joint_act(const float *ep, const int *t, int T, int J, const float *pp, const float *bp, int B, float *z, hipStream_t s);
+void launch_tdt_decide(const TdtState &st, hipStream_t s);
 
 // ---- LayerNorm, canonical reductions, math diagnostics ------------------------------------------
 void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s);

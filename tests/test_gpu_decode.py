@@ -1,0 +1,85 @@
+"""GPU parity: CTC head + greedy (pk_ctc_decode; src/ctc.cpp:12-127) and the on-device TDT / RNNT greedy loop
+(pk_tdt_decode; src/tdt.cpp:36-201, src/rnnt.cpp:56-177).  Token ids, frames and lengths must be identical;
+log-probs and confidences bit-identical."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+import gpu_common as G
+from conftest import pk
+
+pytestmark = pytest.mark.gpu
+
+V, BLANK = 65, 64
+
+
+@pytest.fixture(scope="module")
+def tiny_pair(tmp_path_factory):
+    return G.make_pair(tmp_path_factory.mktemp("tiny"), G.tiny())
+
+
+def enc_like(B, T, d, seed):
+    x = np.random.default_rng(seed).standard_normal((B, T, d)).astype(np.float32)
+    return (x - x.mean(-1, keepdims=True)) / x.std(-1, keepdims=True)
+
+
+def test_ctc_bits_and_ids(tiny_pair, orc):
+    W, om, gm = tiny_pair
+    enc = enc_like(5, 126, om.cfg.hidden_size, 1)
+    g = gm.ctc_decode(enc, return_logp=True)
+    lp = om.ctc_logprobs(enc)
+    G.assert_bits_equal(g["logp"], lp, "ctc log-probs")
+    o = orc.ctc_greedy(lp, BLANK)
+    assert np.array_equal(g["lens"], o["lens"])
+    for b in range(5):
+        n = o["lens"][b]
+        assert np.array_equal(g["ids"][b, :n], o["ids"][b, :n])
+        assert np.array_equal(g["start"][b, :n], o["start"][b, :n])
+        assert np.array_equal(g["end"][b, :n], o["end"][b, :n])
+        G.assert_bits_equal(g["conf"][b, :n], o["conf"][b, :n], "ctc confidence")
+    assert o["lens"].sum() > 0, "degenerate test: nothing decoded"
+
+
+def check_tdt(gm, om, enc):
+    g = gm.tdt_decode(enc)
+    o = om.tdt_greedy(enc, max_steps=0)
+    assert not o["overflow"]
+    assert np.array_equal(g["lens"], o["lens"]), (g["lens"], o["lens"])
+    assert np.array_equal(g["steps"], o["steps"])
+    for b in range(enc.shape[0]):
+        n = o["lens"][b]
+        assert np.array_equal(g["ids"][b, :n], o["ids"][b, :n]), b
+        assert np.array_equal(g["start"][b, :n], o["start"][b, :n])
+        assert np.array_equal(g["end"][b, :n], o["end"][b, :n])
+        G.assert_bits_equal(g["conf"][b, :n], o["conf"][b, :n], "tdt confidence")
+    return o
+
+
+def test_tdt_ids_frames_conf(tiny_pair):
+    W, om, gm = tiny_pair
+    o = check_tdt(gm, om, enc_like(7, 126, om.cfg.hidden_size, 2))
+    assert o["lens"].sum() > 5, "degenerate test: nothing decoded"
+    check_tdt(gm, om, enc_like(1, 13, om.cfg.hidden_size, 3))       # tiny T, single utterance
+    check_tdt(gm, om, enc_like(64, 40, om.cfg.hidden_size, 4))      # full batch width
+
+
+def test_tdt_two_lstm_layers(tmp_path_factory):
+    cfg = G.tiny(num_lstm_layers=2, name="tiny2l")
+    W, om, gm = G.make_pair(tmp_path_factory.mktemp("t2"), cfg, seed=11)
+    o = check_tdt(gm, om, enc_like(4, 60, cfg.hidden_size, 5))
+    assert o["lens"].sum() > 0
+
+
+def test_rnnt_head(tmp_path_factory):
+    cfg = G.tiny(head="rnnt", durations=[], joint_prefix="joint_.", ctc_vocab_size=0, name="tinyrnnt")
+    W, om, gm = G.make_pair(tmp_path_factory.mktemp("tr"), cfg, seed=12)
+    enc = enc_like(4, 50, cfg.hidden_size, 6)
+    g = gm.tdt_decode(enc)
+    o = om.rnnt_greedy(enc)
+    assert np.array_equal(g["lens"], o["lens"])
+    for b in range(4):
+        n = o["lens"][b]
+        assert np.array_equal(g["ids"][b, :n], o["ids"][b, :n])
+        assert np.array_equal(g["start"][b, :n], o["start"][b, :n])
+    assert o["lens"].sum() > 0
