@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- RTFx of the Parakeet hot path (mel -> FastConformer encoder -> TDT greedy decode) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of 64 synthetic 10 s / 16 kHz clips (BASELINE.json configs[1]: tdt-ctc-110m, batch 64 x 10 s,
+TDT decode, fp32), PCM already resident in HBM, through the C ABI (libparakeet_amd.so).  value = total audio seconds
+of all ranks / wall seconds (max over ranks).  N > 1: one process per GPU (torch.distributed.run), the batch
+dimension is sharded -- utterances are independent, there is no collective on the data path (weak scaling).
+Random-init weights of the reference architecture (no checkpoints exist offline) -> "data": "synthetic".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+CLIP_SECONDS = 10.0
+CLIP_SAMPLES = 160000
+BATCH = 64
+ENCODER_FLOP_PER_CLIP = 28.23e9        # 14.11 GMAC per 10 s clip, tdt-ctc-110m
+PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def weights_file(cfg, seed=42):
+    """Seeded synthetic safetensors with the reference's tensor names; generated once per box."""
+    import pkload
+    pkload.load()
+    from parakeet_cpp_amd import synth
+    path = os.path.join(os.environ.get("PK_BENCH_CACHE", "/tmp"), f"pk_bench_{cfg.name}_seed{seed}.safetensors")
+    if not os.path.exists(path):
+        t = time.time()
+        W = synth.synth_weights(cfg, seed=seed)
+        tmp = path + f".{os.getpid()}.tmp"
+        synth.save_weights(tmp, W)
+        os.replace(tmp, path)
+        log(f"[bench] generated {path} in {time.time() - t:.1f}s")
+        return path, W
+    return path, None
+
+
+def cpu_baseline(cfg, weights, n_clips, threads):
+    """The CPU oracle (a C restatement of the reference algorithm: the reference itself cannot be built, its
+    arithmetic is the un-vendored axiom) timed on this host, on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+    from parakeet_cpp_amd import synth
+    if weights is None:
+        weights = synth.synth_weights(cfg, seed=42)
+    oracle.set_threads(threads)
+    om = oracle.Model(cfg, weights)
+    pcm = synth.synth_pcm(n_clips, CLIP_SAMPLES, seed=1234)
+    # warm the oracle's lazily built weight transposes / heap on one clip (untimed)
+    f0 = np.stack([oracle.mel(pcm[0])])
+    om.tdt_greedy(om.encoder(f0))
+    t0 = time.time()
+    feats = np.stack([oracle.mel(p) for p in pcm])
+    t1 = time.time()
+    enc = om.encoder(feats)
+    t2 = time.time()
+    r = om.tdt_greedy(enc)
+    t3 = time.time()
+    wall = t3 - t0
+    return {
+        "value": round(n_clips * CLIP_SECONDS / wall, 3), "unit": "RTFx (audio-s / wall-s)", "cores": threads, "kind": "port",
+        "sample": f"{n_clips} of the same seeded 10 s clips, mel+encoder+TDT, oracle/libpk_oracle.so (AVX2 fp32, OpenMP over clips)",
+        "seconds": {"mel": round(t1 - t0, 3), "encoder": round(t2 - t1, 3), "tdt": round(t3 - t2, 3)},
+        "tokens": int(r["lens"].sum()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="clips per step per GPU (BASELINE: 64)")
+    ap.add_argument("--decoder", default="tdt", choices=["tdt", "ctc"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        log(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    n_gpus = world if world > 1 else 1
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import pkload
+    pk = pkload.load()
+    from parakeet_cpp_amd import capi, synth
+
+    if not torch.cuda.is_available() or capi.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    cfg = pk.make_110m_config()
+    W = None
+    if local_rank == 0:
+        wpath, W = weights_file(cfg)
+    barrier()
+    if local_rank != 0:
+        wpath, _ = weights_file(cfg)
+
+    model = capi.Model(wpath, cfg, device=local_rank)
+    L = capi.lib()
+    import ctypes as C
+    batch = C.c_void_p()
+    capi.check(L.pk_batch_create(model._h, args.batch, CLIP_SAMPLES, C.byref(batch)))
+    # every rank gets its own shard of synthetic clips (seeded by rank): utterance-batch data parallelism
+    pcm = synth.synth_pcm(args.batch, CLIP_SAMPLES, seed=1234 + rank)
+    capi.check(L.pk_batch_upload(batch, pcm.ctypes.data_as(capi.f32p), args.batch))
+    dec = 1 if args.decoder == "tdt" else 0
+
+    for _ in range(args.warmup):
+        capi.check(L.pk_batch_run(batch, dec))
+    capi.check(L.pk_batch_sync(batch))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        capi.check(L.pk_batch_run(batch, dec))
+    capi.check(L.pk_batch_sync(batch))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # stage split + per-kernel timing of one extra (untimed) step, hipEvents on the library's own stream
+    ms = (C.c_float * 4)()
+    capi.check(L.pk_batch_run_timed(batch, dec, ms))
+    stats = (capi.PkKernelStat * 64)()
+    nk = L.pk_batch_profile(batch, dec, stats, 64)
+    kernels = {}
+    for i in range(max(0, min(nk, 64))):
+        s = stats[i]
+        kernels[s.name.decode()] = {"launches": s.launches, "ms": round(s.total_ms, 4), "gflop": round(s.flops / 1e9, 3),
+                                    "mbytes": round(s.bytes / 1e6, 3)}
+    mt = L.pk_batch_max_tokens(batch)
+    ids = np.zeros((args.batch, mt), np.int32)
+    lens = np.zeros(args.batch, np.int32)
+    capi.check(L.pk_batch_results(batch, ids.ctypes.data_as(capi.i32p), lens.ctypes.data_as(capi.i32p), None, None, None))
+
+    if rank == 0:
+        audio_s = args.steps * args.batch * CLIP_SECONDS * n_gpus
+        value = audio_s / elapsed
+        # roofline of the dominant kernel: the fp32-MFMA GEMM instantiation that runs ffn fc1 (+SiLU epilogue):
+        # algorithmic FLOP per launch = 2*M*N*K (M = batch*126 frames, N = 2048, K = 512)
+        dom = kernels.get("ffn_fc1_silu")
+        roof = None
+        if dom and dom["launches"]:
+            per_launch_flop = dom["gflop"] * 1e9 / dom["launches"]
+            per_launch_s = dom["ms"] * 1e-3 / dom["launches"]
+            ach = per_launch_flop / per_launch_s / 1e12
+            gemm_names = [k for k, v in kernels.items() if v["gflop"] > 0 and k not in ("sub_conv1_dw1", "sub_dw2", "dwconv_bn_silu", "relpos_attention")]
+            g_fl = sum(kernels[k]["gflop"] for k in gemm_names)
+            g_ms = sum(kernels[k]["ms"] for k in gemm_names)
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("ffn_fc1_silu_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,SILU> (ffn_fc1_silu)", "achieved": round(ach, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "flop_per_launch": per_launch_flop, "us_per_launch": round(per_launch_s * 1e6, 2),
+                    "all_gemms": {"tflops": round(g_fl / max(g_ms, 1e-9), 2), "gflop": round(g_fl, 1), "ms": round(g_ms, 3)}}
+        enc_ms = float(ms[1])
+        out = {
+            "metric": "RTFx (audio-sec/wall-sec), mel+encoder+TDT decode, tdt-ctc-110m 10s@b64",
+            "value": round(value, 1), "unit": "x real-time", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"tdt-ctc-110m, batch={args.batch}x10s clips per GPU, {args.decoder.upper()} greedy decode, fp32 (BASELINE configs[1])",
+                       "clips_per_step_per_gpu": args.batch, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{n_gpus} (utterance shards, no data-path collective)"},
+            "encoder_ms_per_clip": round(enc_ms / args.batch, 4),
+            "stage_ms": {"mel": round(float(ms[0]), 3), "encoder": round(enc_ms, 3), "decode": round(float(ms[2]), 3), "total": round(float(ms[3]), 3)},
+            "encoder_tflops": round(ENCODER_FLOP_PER_CLIP * args.batch / (enc_ms * 1e-3) / 1e12, 2),
+            "encoder_frac_of_f32_mfma_peak": round(ENCODER_FLOP_PER_CLIP * args.batch / (enc_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "decode_tokens_per_clip": round(float(lens.mean()), 1),
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, W, args.cpu_clips, min(8, os.cpu_count() or 1))
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+
+    L.pk_batch_free(batch)
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@
 
 namespace pk {
 const std::string &last_error();
+void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rate);
 }
 
 using namespace pk;
@@ -371,7 +372,6 @@ int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap) {
 }
 
 /* ---- one-call API ------------------------------------------------------------------------------------------ */
-namespace pk { void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rate); }
 
 namespace {
 struct ResultStore {          // owns everything a pk_result array points into

@@ -1,0 +1,6 @@
+// parakeet/parakeet.hpp -- umbrella header of the drop-in facade (reference: include/parakeet/parakeet.hpp).
+#pragma once
+#include "config.hpp"
+#include "timestamp.hpp"
+#include "transcribe.hpp"
+#include "vocab.hpp"
