@@ -1,0 +1,48 @@
+"""GPU: the drop-in C++ surface.  examples/transcribe_wav.cpp is the reference README's usage verbatim
+(parakeet::Transcriber t(weights, vocab); t.to_gpu(); t.transcribe("x.wav")) compiled against the header-only
+facade; its token ids must equal the oracle's on the same 16 kHz WAV (BASELINE configs[0]: single WAV, CTC greedy,
+here checked for both decoders), and its text must equal the detokenisation of those ids."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import gpu_common as G
+from conftest import ROOT, pk
+from parakeet_cpp_amd import synth
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "parakeet.cpp_amd", "examples", "transcribe_wav")
+
+
+def test_transcriber_on_a_wav_matches_oracle(tmp_path, orc):
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.dirname(EXE)])
+    cfg = pk.make_110m_config()
+    W = synth.synth_weights(cfg, seed=42)
+    wp, vp, ap = str(tmp_path / "model.safetensors"), str(tmp_path / "vocab.txt"), str(tmp_path / "clip.wav")
+    synth.save_weights(wp, W)
+    pieces = synth.synth_vocab(1024)
+    synth.save_vocab(vp, pieces)
+    pcm = synth.synth_pcm(1, 48000, seed=21)[0]
+    synth.write_wav_pcm16(ap, pcm)
+    q = (np.clip(pcm, -1, 1) * 32767.0).astype("<i2").astype(np.float32) / 32768.0    # what the WAV holds
+    om = orc.Model(cfg, W)
+    enc = om.encoder(np.stack([orc.mel(q)]))
+    want = {"tdt": om.tdt_greedy(enc), "ctc": orc.ctc_greedy(om.ctc_logprobs(enc), 1024)}
+    for dec in ("tdt", "ctc"):
+        out = subprocess.run([EXE, wp, vp, ap, dec, "--timestamps"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr
+        r = json.loads(out.stdout)
+        n = want[dec]["lens"][0]
+        ids = want[dec]["ids"][0, :n].tolist()
+        assert r["token_ids"] == ids, dec
+        text = "".join(pieces[i] for i in ids).replace("▁", " ")
+        assert r["text"] == (text[1:] if text.startswith(" ") else text)
+        assert n > 3 and len(r["words"]) >= 1
+        starts = [w[1] for w in r["words"]]
+        assert starts == sorted(starts)                      # monotonic word timestamps (tests/test_all.cpp:946-963)
+    bad = subprocess.run([EXE, wp, str(tmp_path / "missing_vocab.txt"), ap], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Cannot open vocab file" in bad.stderr
