@@ -218,33 +218,71 @@ pk_status pk_tdt_decode(pk_model *h, const float *enc, int B, int T, int max_tok
 
 
 /* ---- resident batch pipeline ---------------------------------------------------------------------------- */
+// Two workspaces + two streams: the latency-bound decode loop of batch k (high-priority stream, a few small kernels
+// per step) runs concurrently with the MFMA-bound mel + encoder of batch k+1 (main stream).  pk_batch_run(k) enqueues
+// encoder(k) and then drives decode(k-1); pk_batch_sync / pk_batch_results flush the decode still pending.
 struct pk_batch {
     Model *m;
-    Workspace ws;
+    DevBuf pcm;                 // [max_clips][n_samples], shared by both slots (read-only during a run)
+    Workspace ws[2];
     int n_clips = 0;
-    int last_decoder = -1;
+    int runs = 0;               // pk_batch_run calls so far
+    int pending_slot = -1, pending_decoder = -1;   // decode not yet driven
+    int last_slot = -1, last_decoder = -1;         // where the newest finished results live
     hipEvent_t ev[4];
+    hipEvent_t enc_done[2], dec_done[2];
+    bool used[2] = {false, false};
     bool ev_ok = false;
 };
 
-static void batch_run(pk_batch *b, int decoder, bool timed) {
+static void batch_encode(pk_batch *b, int slot) {
+    Model &m = *b->m;
+    Workspace &w = b->ws[slot];
+    hipStream_t s = m.stream;
+    if (b->used[slot]) PK_HIP(hipStreamWaitEvent(s, b->dec_done[slot], 0));   // decode(k-2) must be done with this slot
+    m.run_mel(b->pcm.as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
+    m.run_encoder(w, w.feats.as<float>(), b->n_clips, w.Tm, -1, 0, s);
+    PK_HIP(hipEventRecord(b->enc_done[slot], s));
+    b->used[slot] = true;
+}
+
+static void batch_decode(pk_batch *b, int slot, int decoder, hipStream_t s) {
+    Model &m = *b->m;
+    Workspace &w = b->ws[slot];
+    if (s != m.stream) PK_HIP(hipStreamWaitEvent(s, b->enc_done[slot], 0));
+    if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), b->n_clips, w.T, false, s);
+    else m.run_tdt(w, w.x.as<float>(), b->n_clips, w.T, w.max_tokens, s);
+    PK_HIP(hipEventRecord(b->dec_done[slot], s));
+    b->last_slot = slot;
+    b->last_decoder = decoder;
+}
+
+static void batch_flush(pk_batch *b) {
+    if (b->pending_slot >= 0) {
+        const int slot = b->pending_slot, dec = b->pending_decoder;
+        b->pending_slot = -1;
+        batch_decode(b, slot, dec, b->m->stream_dec);
+    }
+    PK_HIP(hipStreamSynchronize(b->m->stream_dec));
+    PK_HIP(hipStreamSynchronize(b->m->stream));
+}
+
+static void batch_run(pk_batch *b, int decoder) {
     Model &m = *b->m;
     m.require_gpu();
     need(b->n_clips > 0, "pk_batch_upload() first");
     need(decoder == PK_DECODER_CTC || decoder == PK_DECODER_TDT, "decoder");
-    Workspace &w = b->ws;
-    hipStream_t s = m.stream;
-    const int B = b->n_clips;
-    if (timed) PK_HIP(hipEventRecord(b->ev[0], s));
-    m.run_mel(w.pcm.as<float>(), B, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
-    if (timed) PK_HIP(hipEventRecord(b->ev[1], s));
-    m.run_encoder(w, w.feats.as<float>(), B, w.Tm, -1, 0, s);
-    if (timed) PK_HIP(hipEventRecord(b->ev[2], s));
-    if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), B, w.T, false, s);
-    else m.run_tdt(w, w.x.as<float>(), B, w.T, w.max_tokens, s);
-    if (timed) PK_HIP(hipEventRecord(b->ev[3], s));
+    const int slot = b->runs & 1;
+    batch_encode(b, slot);                                   // encoder(k) is queued first ...
+    if (b->pending_slot >= 0) {                              // ... then the host drives decode(k-1) while it runs
+        const int ps = b->pending_slot, pd = b->pending_decoder;
+        b->pending_slot = -1;
+        batch_decode(b, ps, pd, m.stream_dec);
+    }
+    b->pending_slot = slot;
+    b->pending_decoder = decoder;
+    b->runs += 1;
     PK_CHECK_LAUNCH();
-    b->last_decoder = decoder;
 }
 
 pk_status pk_batch_create(pk_model *h, int max_clips, int64_t n_samples, pk_batch **out) {
@@ -254,8 +292,13 @@ pk_status pk_batch_create(pk_model *h, int max_clips, int64_t n_samples, pk_batc
         m.require_gpu();
         auto b = std::make_unique<pk_batch>();
         b->m = &m;
-        b->ws.size_for(m.cfg, max_clips, n_samples, pk_mel_num_frames(n_samples));
+        b->pcm.reserve((size_t)max_clips * n_samples * 4);
+        for (auto &w : b->ws) w.size_for(m.cfg, max_clips, -n_samples, pk_mel_num_frames(n_samples));
         for (auto &e : b->ev) PK_HIP(hipEventCreate(&e));
+        for (int i = 0; i < 2; ++i) {
+            PK_HIP(hipEventCreateWithFlags(&b->enc_done[i], hipEventDisableTiming));
+            PK_HIP(hipEventCreateWithFlags(&b->dec_done[i], hipEventDisableTiming));
+        }
         b->ev_ok = true;
         *out = b.release();
     });
@@ -263,40 +306,45 @@ pk_status pk_batch_create(pk_model *h, int max_clips, int64_t n_samples, pk_batc
 
 void pk_batch_free(pk_batch *b) {
     if (!b) return;
-    if (b->ev_ok)
+    if (b->ev_ok) {
+        (void)hipStreamSynchronize(b->m->stream_dec);
+        (void)hipStreamSynchronize(b->m->stream);
         for (auto &e : b->ev) (void)hipEventDestroy(e);
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(b->enc_done[i]); (void)hipEventDestroy(b->dec_done[i]); }
+    }
     delete b;
 }
 
 pk_status pk_batch_upload(pk_batch *b, const float *pcm, int n_clips) {
     return guard([&] {
-        need(b && pcm && n_clips > 0 && n_clips <= b->ws.B, "batch/pcm/n_clips");
+        need(b && pcm && n_clips > 0 && n_clips <= b->ws[0].B, "batch/pcm/n_clips");
         b->m->require_gpu();
-        PK_HIP(hipMemcpyAsync(b->ws.pcm.p, pcm, (size_t)n_clips * b->ws.n_samples * 4, hipMemcpyHostToDevice, b->m->stream));
+        batch_flush(b);
+        PK_HIP(hipMemcpyAsync(b->pcm.p, pcm, (size_t)n_clips * b->ws[0].n_samples * 4, hipMemcpyHostToDevice, b->m->stream));
         PK_HIP(hipStreamSynchronize(b->m->stream));
         b->n_clips = n_clips;
     });
 }
 
 pk_status pk_batch_run(pk_batch *b, int decoder) {
-    return guard([&] { need(b, "batch"); batch_run(b, decoder, false); });
+    return guard([&] { need(b, "batch"); batch_run(b, decoder); });
 }
 
 pk_status pk_batch_sync(pk_batch *b) {
-    return guard([&] { need(b, "batch"); b->m->require_gpu(); PK_HIP(hipStreamSynchronize(b->m->stream)); });
+    return guard([&] { need(b, "batch"); b->m->require_gpu(); batch_flush(b); });
 }
 
-int pk_batch_max_tokens(const pk_batch *b) { return b ? b->ws.max_tokens : 0; }
+int pk_batch_max_tokens(const pk_batch *b) { return b ? b->ws[0].max_tokens : 0; }
 
 pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
     return guard([&] {
         need(b && ids && lens, "batch/ids/lens");
-        need(b->last_decoder >= 0, "pk_batch_run() first");
         Model &m = *b->m;
         m.require_gpu();
-        Workspace &w = b->ws;
+        batch_flush(b);
+        need(b->last_slot >= 0, "pk_batch_run() first");
+        Workspace &w = b->ws[b->last_slot];
         const int B = b->n_clips, mt = w.max_tokens;
-        PK_HIP(hipStreamSynchronize(m.stream));
         PK_HIP(hipMemcpy(lens, w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
         if (b->last_decoder == PK_DECODER_TDT) {
             const size_t n = (size_t)B * mt * 4;
@@ -317,11 +365,27 @@ pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *st
     });
 }
 
+// One un-pipelined run on the main stream with hipEvents between the stages (mel / encoder / decode / total, ms).
 pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]) {
     return guard([&] {
         need(b && ms, "batch/ms");
-        batch_run(b, decoder, true);
-        PK_HIP(hipStreamSynchronize(b->m->stream));
+        need(decoder == PK_DECODER_CTC || decoder == PK_DECODER_TDT, "decoder");
+        Model &m = *b->m;
+        m.require_gpu();
+        need(b->n_clips > 0, "pk_batch_upload() first");
+        batch_flush(b);
+        Workspace &w = b->ws[0];
+        hipStream_t s = m.stream;
+        PK_HIP(hipEventRecord(b->ev[0], s));
+        m.run_mel(b->pcm.as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
+        PK_HIP(hipEventRecord(b->ev[1], s));
+        m.run_encoder(w, w.feats.as<float>(), b->n_clips, w.Tm, -1, 0, s);
+        PK_HIP(hipEventRecord(b->ev[2], s));
+        batch_decode(b, 0, decoder, s);
+        PK_HIP(hipEventRecord(b->ev[3], s));
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipStreamSynchronize(s));
+        b->used[0] = true;
         PK_HIP(hipEventElapsedTime(&ms[0], b->ev[0], b->ev[1]));
         PK_HIP(hipEventElapsedTime(&ms[1], b->ev[1], b->ev[2]));
         PK_HIP(hipEventElapsedTime(&ms[2], b->ev[2], b->ev[3]));
@@ -329,7 +393,7 @@ pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]) {
     });
 }
 
-void *pk_batch_dev_pcm(pk_batch *b) { return b ? b->ws.pcm.p : nullptr; }
+void *pk_batch_dev_pcm(pk_batch *b) { return b ? b->pcm.p : nullptr; }
 void *pk_batch_stream(pk_batch *b) { return b ? (void *)b->m->stream : nullptr; }
 
 int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap) {
@@ -339,9 +403,14 @@ int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap) {
         Model &m = *b->m;
         ProfileSink sink;
         m.prof = &sink;
+        batch_flush(b);
         try {
-            batch_run(b, decoder, false);
+            Workspace &w = b->ws[0];
+            m.run_mel(b->pcm.as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), m.stream);
+            m.run_encoder(w, w.feats.as<float>(), b->n_clips, w.Tm, -1, 0, m.stream);
+            batch_decode(b, 0, decoder, m.stream);
             PK_HIP(hipStreamSynchronize(m.stream));
+            b->used[0] = true;
         } catch (...) {
             m.prof = nullptr;
             throw;

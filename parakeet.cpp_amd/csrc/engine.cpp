@@ -28,6 +28,8 @@ Model::Model(const std::string &weights_path, const std::string &vocab_path, con
     if (cfg.conv_kernel_size != 9 && cfg.conv_kernel_size != 31) fail(PK_ERR_UNSUPPORTED, "conv_kernel_size must be 9 or 31");
     if (cfg.num_lstm_layers < 1 || cfg.num_lstm_layers > 4) fail(PK_ERR_UNSUPPORTED, "num_lstm_layers must be 1..4");
     if (cfg.hidden_size > 1024) fail(PK_ERR_UNSUPPORTED, "hidden_size > 1024");
+    if (cfg.num_lstm_layers * cfg.pred_hidden > 12 * 256) fail(PK_ERR_UNSUPPORTED, "num_lstm_layers * pred_hidden > 3072");
+    if (cfg.pred_hidden % 64 || cfg.joint_hidden % 64) fail(PK_ERR_UNSUPPORTED, "pred_hidden / joint_hidden must be multiples of 64 (decode GEMV K chunk)");
     if (cfg.num_durations < 0 || cfg.num_durations > 8) fail(PK_ERR_INVALID, "num_durations must be 0..8");
     st_ = std::make_unique<SafeTensors>(weights_path);
     if (!vocab_path.empty()) tok.load(vocab_path);
@@ -39,6 +41,7 @@ Model::~Model() {
         for (void *p : allocs_) (void)hipFree(p);
         if (h_done) (void)hipHostFree(h_done);
         if (stream) (void)hipStreamDestroy(stream);
+        if (stream_dec) (void)hipStreamDestroy(stream_dec);
     }
 }
 
@@ -191,16 +194,28 @@ void Model::upload_weights() {
     }
 
     const int V = cfg.vocab_size, Hp = cfg.pred_hidden, J = cfg.joint_hidden, D = cfg.num_durations;
+    // "sigma" K layout of the decode-loop weights (kernels/decode_gemv.hip): inside every block of 16 input features the
+    // 4x4 index matrix is transposed, so one float4 holds a lane's k = 4s+kq operands of four consecutive MFMA steps.
+    auto sigma = [](int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); };
+    auto upload_sigma = [&](const float *w, int rows, int K) {
+        std::vector<float> p((size_t)rows * K);
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < K; ++k) p[(size_t)r * K + sigma(k)] = w[(size_t)r * K + k];
+        return upload(p.data(), p.size());
+    };
     dec.embed = upload_tensor("prediction_.embed_.weight", {V, Hp});
     for (int l = 0; l < cfg.num_lstm_layers; ++l) {
         const std::string q = "prediction_.lstm_.cells_." + std::to_string(l) + ".";
         dec.wih[l] = upload_tensor(q + "input_proj_.weight", {4 * Hp, Hp});
         dec.bih[l] = upload_tensor(q + "input_proj_.bias", {4 * Hp});       // = b_ih + b_hh (convert_nemo.py:409-417)
         dec.whh[l] = upload_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp});
+        dec_whh_s[l] = upload_sigma(host_tensor(q + "hidden_proj_.weight", (int64_t)4 * Hp * Hp).f32(), 4 * Hp, Hp);
+        dec_wih_s[l] = l ? upload_sigma(host_tensor(q + "input_proj_.weight", (int64_t)4 * Hp * Hp).f32(), 4 * Hp, Hp) : nullptr;
     }
     const std::string jp = cfg.joint_prefix;
     dec.we = upload_tensor(jp + "enc_proj_.weight", {J, d}); dec.be = upload_tensor(jp + "enc_proj_.bias", {J});
     dec.wp = upload_tensor(jp + "pred_proj_.weight", {J, Hp});
+    dec_wp_s = upload_sigma(host_tensor(jp + "pred_proj_.weight", (int64_t)J * Hp).f32(), J, Hp);
     dec.bp = (cfg.joint_pred_bias && st_->find(jp + "pred_proj_.bias")) ? upload_tensor(jp + "pred_proj_.bias", {J}) : nullptr;
     {
         std::vector<float> w((size_t)(V + D) * J), b((size_t)(V + D));
@@ -213,6 +228,7 @@ void Model::upload_weights() {
         }
         wld = upload(w.data(), w.size());
         bld = upload(b.data(), b.size());
+        wld_s = upload_sigma(w.data(), V + D, J);
     }
     if (cfg.ctc_vocab_size > 0) {
         dec.ctc_w = upload_tensor("ctc_decoder_.proj_.weight", {cfg.ctc_vocab_size, d});
@@ -239,6 +255,11 @@ void Model::to_gpu(int device) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         fail(PK_ERR_NO_DEVICE, "device %d is %s; this library contains gfx950 (MI355X) code only", device, prop.gcnArchName);
     PK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;
+        PK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // numerically lowest = highest priority
+        PK_HIP(hipStreamCreateWithPriority(&stream_dec, hipStreamNonBlocking, hi));
+    }
     PK_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_done), sizeof(int), hipHostMallocDefault));
     device_ = device;
     build_mel_tables();
@@ -269,13 +290,16 @@ void Model::gemm(const char *name, const float *A, int64_t lda, const float *W, 
 
 // ---- workspace ----------------------------------------------------------------------------------------------
 void Workspace::size_for(const pk_config &c, int B_, int64_t n_samples_, int Tm_) {
-    B = B_; n_samples = n_samples_; Tm = Tm_;
+    B = B_; Tm = Tm_;
+    const bool own_pcm = n_samples_ > 0;          // a negative length: the caller owns the PCM buffer (pipelined batch slots)
+    n_samples = n_samples_ < 0 ? -n_samples_ : n_samples_;
     const int F = c.mel_bins, C = c.subsampling_channels, d = c.hidden_size;
     auto sl = [](int n) { return (n - 1) / 2 + 1; };
     const int H1 = sl(Tm), W1 = sl(F), H2 = sl(H1), W2 = sl(W1), H3 = sl(H2), W3 = sl(W2);
     T = H3;
     const size_t M = (size_t)B * T, f = sizeof(float);
-    if (n_samples > 0) { pcm.reserve((size_t)B * n_samples * f); logmel.reserve((size_t)B * F * Tm * f); }
+    if (own_pcm) pcm.reserve((size_t)B * n_samples * f);
+    if (n_samples > 0) logmel.reserve((size_t)B * F * Tm * f);
     feats.reserve((size_t)B * Tm * F * f);
     a2.reserve((size_t)B * H2 * W2 * C * f); a3.reserve((size_t)B * H2 * W2 * C * f);
     a4.reserve((size_t)B * H3 * W3 * C * f); flat.reserve((size_t)B * H3 * W3 * C * f);
@@ -435,24 +459,38 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
     PK_HIP(hipMemsetAsync(w.h.p, 0, (size_t)L * B * Hp * 4, s));
     PK_HIP(hipMemsetAsync(w.c.p, 0, (size_t)L * B * Hp * 4, s));
     launch_tdt_init(st, s);
+    // Per step: [cell GEMV per LSTM layer] -> joint-activation GEMV -> heads GEMV -> decide.  h / h' / z live in the sigma
+    // K layout (they are only ever GEMV operands); c, the g1 table, enc_proj and the logits are in natural order.
+    const double f_hh = 2.0 * B * 4 * Hp * Hp, f_pp = 2.0 * B * J * Hp, f_hd = 2.0 * B * (V + D) * J;
     const int chunk = 16;
     for (int step = 0; step < st.max_steps; ++step) {
         for (int l = 0; l < L; ++l) {
             float *hl = w.h.as<float>() + (size_t)l * B * Hp, *cl = w.c.as<float>() + (size_t)l * B * Hp;
             float *hnl = w.hn.as<float>() + (size_t)l * B * Hp, *cnl = w.cn.as<float>() + (size_t)l * B * Hp;
-            gemm("lstm_hh", hl, Hp, dec.whh[l], Hp, nullptr, w.gh.as<float>(), 4 * Hp, B, 4 * Hp, Hp, EPI_NONE, nullptr, 0, 1.0f, s);
+            SkinnyArgs a{};
+            a.X = hl; a.W = dec_whh_s[l]; a.B = B; a.N = 4 * Hp; a.K = Hp; a.out = hnl; a.c = cl; a.cn = cnl; a.Hp = Hp;
             if (l == 0) {
-                KL("lstm_cell", 0.0, 0.0, launch_lstm_cell(dec.g1, 4 * Hp, st.token, w.gh.as<float>(), cl, B, Hp, hnl, cnl, s));
+                a.gi = dec.g1; a.gi_ld = 4 * Hp; a.gi_row = st.token;
             } else {
-                const float *prev = w.hn.as<float>() + (size_t)(l - 1) * B * Hp;
-                gemm("lstm_ih", prev, Hp, dec.wih[l], Hp, dec.bih[l], w.gi.as<float>(), 4 * Hp, B, 4 * Hp, Hp, EPI_NONE, nullptr, 0, 1.0f, s);
-                KL("lstm_cell", 0.0, 0.0, launch_lstm_cell(w.gi.as<float>(), 4 * Hp, nullptr, w.gh.as<float>(), cl, B, Hp, hnl, cnl, s));
+                SkinnyArgs g{};
+                g.X = w.hn.as<float>() + (size_t)(l - 1) * B * Hp; g.W = dec_wih_s[l]; g.B = B; g.N = 4 * Hp; g.K = Hp;
+                g.bias = dec.bih[l]; g.out = w.gi.as<float>(); g.ldo = 4 * Hp;
+                KL("lstm_ih_gemv", f_hh, 0.0, launch_skinny_gemm(g, SK_BIAS, s));
+                a.gi = w.gi.as<float>(); a.gi_ld = 4 * Hp; a.gi_row = nullptr;
             }
+            KL("lstm_hh_cell", f_hh, 0.0, launch_skinny_gemm(a, SK_CELL, s));
         }
-        const float *pred = w.hn.as<float>() + (size_t)(L - 1) * B * Hp;
-        gemm("joint_pred_proj", pred, Hp, dec.wp, Hp, nullptr, w.pp.as<float>(), J, B, J, Hp, EPI_NONE, nullptr, 0, 1.0f, s);
-        KL("joint_act", 0.0, 0.0, launch_joint_act(w.ep.as<float>(), st.t, T, J, w.pp.as<float>(), dec.bp, B, w.z.as<float>(), s));
-        gemm("joint_heads", w.z.as<float>(), J, wld, J, bld, w.logits.as<float>(), V + D, B, V + D, J, EPI_NONE, nullptr, 0, 1.0f, s);
+        {
+            SkinnyArgs a{};
+            a.X = w.hn.as<float>() + (size_t)(L - 1) * B * Hp; a.W = dec_wp_s; a.B = B; a.N = J; a.K = Hp; a.bias = dec.bp;
+            a.out = w.z.as<float>(); a.ep = w.ep.as<float>(); a.t = st.t; a.T = T;
+            KL("joint_pred_act", f_pp, 0.0, launch_skinny_gemm(a, SK_ACT, s));
+        }
+        {
+            SkinnyArgs a{};
+            a.X = w.z.as<float>(); a.W = wld_s; a.B = B; a.N = V + D; a.K = J; a.bias = bld; a.out = w.logits.as<float>(); a.ldo = V + D;
+            KL("joint_heads_gemv", f_hd, 0.0, launch_skinny_gemm(a, SK_BIAS, s));
+        }
         KL("tdt_decide", 0.0, 0.0, launch_tdt_decide(st, s));
         if ((step + 1) % chunk == 0) {                                 // poll "all finished" once per chunk of steps
             PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -61,7 +61,8 @@ class Model {
     pk_config cfg;
     Tokenizer tok;
     int device_ = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // main stream (mel, encoder, and everything in the staged entry points)
+    hipStream_t stream_dec = nullptr;   // high-priority stream of the decode loop in the pipelined batch path
 
     // device weights
     std::vector<void *> allocs_;
@@ -70,6 +71,8 @@ class Model {
     std::vector<LayerW> layers;
     DecW dec{};
     const float *wld = nullptr, *bld = nullptr;     // [V+D][J] label_proj rows then duration_proj rows (+ biases)
+    // sigma-K-layout copies used by the decode GEMVs
+    const float *wld_s = nullptr, *dec_wp_s = nullptr, *dec_whh_s[4] = {}, *dec_wih_s[4] = {};
 
     // relative-position tables: sinusoidal pe [2T-1][d] (src/encoder.cpp:9-30, host float math) and the
     // per-layer pos_proj_(pe) [L][2T-1][d]; they depend on (T, weights) only, so they are rebuilt when T changes.

@@ -132,30 +132,93 @@ void launch_joint_act(const float *ep, const int *t, int T, int J, const float *
     hipLaunchKernelGGL(joint_act_kernel, dim3((B * J + 255) / 256), dim3(256), 0, s, ep, t, T, J, pp, bp, B, z);
 }
 
-// One wavefront per utterance: heads' log-softmax + argmax, then the control flow of
+// One 256-thread workgroup per utterance: heads' log-softmax + first-max argmax, then the control flow of
 // tdt_greedy_decode (src/tdt.cpp:62-106; timestamps :157-187) or rnnt_greedy_decode (src/rnnt.cpp:75-107).
-__global__ __launch_bounds__(64) void tdt_decide_kernel(TdtState st) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+// The logits row is staged in LDS once; exp() is evaluated by all four wavefronts, the canonical sum64 by one
+// (the summation ORDER is part of the numerics contract; who evaluates the terms is not).
+__global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // x[V+D], e[V+D], scratch[16]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (st.done[b]) return;
-    const float *lg = st.logits + (int64_t)b * (st.V + st.D);
-    const BestLP lab = wave_logsoftmax_argmax(lg, st.V, nullptr, lane);
-    int skip = 1;
-    if (st.D > 0) {
-        const BestLP dur = wave_logsoftmax_argmax(lg + st.V, st.D, nullptr, lane);
-        skip = dur.idx < st.D ? st.durations[dur.idx] : 1;
+    const int VD = st.V + st.D;
+    float *x = sm, *e = sm + VD;
+    float *red = e + VD;                                           // [0..3] wave maxima, [4] lse, [8..11] best val, [12..15] best idx
+    const float *lg = st.logits + (int64_t)b * VD;
+    // issue every independent global load up front (state words, candidate LSTM state): each dependent round trip to
+    // L2/HBM costs ~1-2 us in this latency-bound kernel
+    const int t_in = st.t[b], steps_in = st.steps[b], n_out_in = st.n_out[b], nsym_in = st.nsym[b];
+    constexpr int kMaxCarry = 12;                                  // L * Hp <= 12 * 256
+    float hcar[kMaxCarry], ccar[kMaxCarry];
+    const int n_state = st.L * st.Hp;
+#pragma unroll
+    for (int q = 0; q < kMaxCarry; ++q) {
+        const int i = tid + 256 * q;
+        if (i < n_state) {
+            const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
+            hcar[q] = st.hn[o];
+            ccar[q] = st.cn[o];
+        }
     }
+    float m = -__builtin_huge_valf();
+    for (int i = tid; i < VD; i += 256) {
+        const float v = lg[i];
+        x[i] = v;
+        if (i < st.V) m = fmaxf(m, v);
+    }
+    m = wave_max64(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int i = tid; i < st.V; i += 256) e[i] = dexpf(x[i] - m);
+    __syncthreads();
+    if (wave == 0) {
+        float p = 0.0f;
+        for (int i = lane; i < st.V; i += 64) p = p + e[i];
+        const float lse = dlogf(wave_sum64(p));
+        if (lane == 0) red[4] = lse;
+    }
+    int skip = 1;
+    if (wave == 1 && st.D > 0) {                                   // duration head: a few values, one wavefront
+        const BestLP dur = wave_logsoftmax_argmax(x + st.V, st.D, nullptr, lane);
+        if (lane == 0) red[5] = (float)(dur.idx < st.D ? st.durations[dur.idx] : 1);
+    }
+    __syncthreads();
+    const float lse = red[4];
+    float best = -__builtin_huge_valf();
+    int bi = 0x7fffffff;
+    for (int i = tid; i < st.V; i += 256) {
+        const float l = (x[i] - m) - lse;
+        if (bi == 0x7fffffff || l > best) { best = l; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { red[8 + wave] = best; red[12 + wave] = __int_as_float(bi); }
+    __syncthreads();
+    BestLP lab{red[8], __float_as_int(red[12])};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float ob = red[8 + w];
+        const int oi = __float_as_int(red[12 + w]);
+        if (ob > lab.lp || (ob == lab.lp && oi < lab.idx)) { lab.lp = ob; lab.idx = oi; }
+    }
+    if (st.D > 0) skip = (int)red[5];
+    const int lane0 = tid;                                         // thread 0 writes the scalar state
     // scalar control (wave-uniform values; lane 0 writes)
-    int t = st.t[b];
-    const int nsteps = st.steps[b] + 1;
-    int n_out = st.n_out[b];
-    int nsym = st.nsym[b];
+    int t = t_in;
+    const int nsteps = steps_in + 1;
+    int n_out = n_out_in;
+    int nsym = nsym_in;
     const bool commit = lab.idx != st.blank;
     if (!commit) {
         // blank: the LSTM state reverts -- the candidates hn/cn are simply not committed (src/tdt.cpp:88-93)
         t += (st.D > 0) ? (skip > 1 ? skip : 1) : 1;
         nsym = 0;
     } else {
-        if (lane == 0) {
+        if (lane0 == 0) {
             if (n_out < st.max_tokens) {
                 const int64_t o = (int64_t)b * st.max_tokens + n_out;
                 st.ids[o] = lab.idx;
@@ -173,14 +236,17 @@ __global__ __launch_bounds__(64) void tdt_decide_kernel(TdtState st) {
             t += 1;
             nsym = 0;
         }
-        const int n = st.L * st.Hp;                   // commit the candidate LSTM state, [L][B][Hp]
-        for (int i = lane; i < n; i += 64) {
-            const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
-            st.h[o] = st.hn[o];
-            st.c[o] = st.cn[o];
+#pragma unroll
+        for (int q = 0; q < kMaxCarry; ++q) {         // commit the candidate LSTM state, [L][B][Hp]
+            const int i = tid + 256 * q;
+            if (i < n_state) {
+                const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
+                st.h[o] = hcar[q];
+                st.c[o] = ccar[q];
+            }
         }
     }
-    if (lane == 0) {
+    if (lane0 == 0) {
         bool finished = t >= st.T;
         int len = n_out < st.max_tokens ? n_out : st.max_tokens;
         if (!finished && st.max_steps > 0 && nsteps >= st.max_steps) { finished = true; len = -1; }   // safety cap
@@ -195,7 +261,10 @@ __global__ __launch_bounds__(64) void tdt_decide_kernel(TdtState st) {
         }
     }
 }
-void launch_tdt_decide(const TdtState &st, hipStream_t s) { hipLaunchKernelGGL(tdt_decide_kernel, dim3(st.B), dim3(64), 0, s, st); }
+void launch_tdt_decide(const TdtState &st, hipStream_t s) {
+    const size_t lds = (size_t)(2 * (st.V + st.D) + 16) * sizeof(float);
+    hipLaunchKernelGGL(tdt_decide_kernel, dim3(st.B), dim3(256), lds, s, st);
+}
 
 __global__ void tdt_init_kernel(TdtState st) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -68,6 +68,21 @@ void launch_lstm_cell(const float *gi, int gi_ld, const int *gi_row, const float
 void launch_joint_act(const float *ep, const int *t, int T, int J, const float *pp, const float *bp, int B, float *z, hipStream_t s);
 void launch_tdt_decide(const TdtState &st, hipStream_t s);
 
+// skinny products of the decode loop (kernels/decode_gemv.hip).  X and W are in the "sigma" K layout
+// (4x4 index transpose inside every block of 16 k); K % 16 == 0.
+enum SkinnyEpi { SK_BIAS = 0, SK_ACT = 1, SK_CELL = 2 };
+struct SkinnyArgs {
+    const float *X, *W;            // [B][K], [N][K]
+    int B, N, K;
+    const float *bias;             // SK_BIAS: [N] or null ; SK_ACT: pred_proj bias (switch A5) or null
+    float *out; int ldo;           // SK_BIAS: [B][ldo] natural ; SK_ACT: z [B][N] sigma ; SK_CELL: h' [B][Hp] sigma
+    // SK_ACT
+    const float *ep; const int *t; int T;
+    // SK_CELL (N = 4*Hp)
+    const float *gi; int gi_ld; const int *gi_row; const float *c; float *cn; int Hp;
+};
+void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s);
+
 // ---- LayerNorm, canonical reductions, math diagnostics ------------------------------------------
 void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s);
 void launch_sum64_rows(const float *x, int rows, int n, float *out, hipStream_t s);
