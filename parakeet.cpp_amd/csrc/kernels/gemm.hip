@@ -22,6 +22,7 @@
 //    no separate elementwise passes over HBM.
 #include "../pk_devmath.h"
 #include "kernels.hpp"
+#include "gemm_pipe.hpp"
 
 namespace pk {
 
@@ -190,13 +191,15 @@ static void launch_one(const GemmArgs &a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI>), dim3(n_tiles), dim3(256), lds, s, a, tiles_n, n_tiles);
 }
 
+// Tile choice, from tools/ubench/gemm_sweep on MI355X (profiles/r01_gemm_sweep.txt): the pipelined kernels win where
+// the K loop is short (most of the encoder is K = 512); wide outputs like 128x128 tiles on 8 waves, long-K / narrow-N
+// products 128x64, everything else 64x64 (more resident workgroups to overlap one tile's epilogue with another's MFMAs).
 template <int EPI>
 static void launch_epi(const GemmArgs &a, hipStream_t s) {
-    // tile choice: fill >= 2 workgroups per CU where the problem allows it (256 CUs)
-    const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (a.M >= 128 && t128 >= 512) launch_one<128, 128, EPI>(a, s);
-    else if (a.M >= 128 && t128 >= 192) launch_one<128, 64, EPI>(a, s);
-    else launch_one<64, 64, EPI>(a, s);
+    if (a.K < 64) { launch_one<64, 64, EPI>(a, s); return; }           // pipelined kernels need >= 2 K tiles
+    if (a.M >= 1024 && a.N >= 2048) launch_gemm_pipe<2, 4, 2, 1, 32, false, EPI>(a, s);
+    else if (a.M >= 1024 && a.N >= 256 && (a.K >= 1024 || a.M >= 65536)) launch_gemm_pipe<2, 2, 2, 1, 32, false, EPI>(a, s);
+    else launch_gemm_pipe<2, 2, 1, 1, 32, false, EPI>(a, s);
 }
 
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
@@ -205,7 +208,10 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
     case EPI_RELU: launch_epi<EPI_RELU>(a, s); break;
     case EPI_SILU: launch_epi<EPI_SILU>(a, s); break;
     case EPI_RESID: launch_epi<EPI_RESID>(a, s); break;
-    case EPI_GLU: launch_one<128, 128, EPI_GLU>(a, s); break;
+    case EPI_GLU:
+        if (a.K < 64) launch_one<128, 128, EPI_GLU>(a, s);
+        else launch_gemm_pipe<4, 2, 1, 2, 32, false, EPI_GLU>(a, s);
+        break;
     default: break;
     }
 }

@@ -4,9 +4,8 @@
 // 3x3 depthwise taps are coalesced along C.
 //
 //  sub_conv1_dw1:  Conv2d(1->C,3x3,s2,p1)+ReLU fused with the following depthwise 3x3 s2: the
-//                  [B][C][501][40] conv1 output (1.3 GB at B=64) is never written to HBM; each
-//                  depthwise output recomputes its 3x3 neighbourhood of conv1 values from the 7x7
-//                  input patch (81 fma instead of a 2.6 GB round trip).
+//                  [B][C][501][40] conv1 output (1.3 GB at B=64) is never written to HBM; conv1 rows live
+//                  in registers for the two depthwise output rows that use them.
 //  sub_dw:         depthwise 3x3 s2 p1 on a channels-last tensor.
 // Tap order (ky,kx) and "bias after the chain" follow the oracle exactly (bit-identical results).
 #include "../pk_devmath.h"
@@ -14,49 +13,89 @@
 
 namespace pk {
 
+// One thread = one channel of a strip of YS output rows x XC output columns.  The three conv1 rows a depthwise output row
+// needs (y1 = 2*y2-1 .. 2*y2+1) are computed ONCE into registers (the last one is carried over to the next output row), so
+// a depthwise output costs 2x2 conv1 evaluations (36 fma) + 9 instead of 81 + 9.  The strip's window of mel features
+// ((4*YS+3) x (4*XC+3) values, zero-padded outside the image) is staged in LDS once; every thread of a strip reads the
+// same LDS addresses (broadcast reads with compile-time offsets), so the inner loops have no bounds checks at all.
+// Out-of-range taps multiply a zero instead of being skipped: fma(w, 0, acc) == acc for every acc reachable from +0, so
+// the chain equals the oracle's skip-the-padding chain bit for bit.
+template <int XC>
 __global__ __launch_bounds__(256) void sub_conv1_dw1_kernel(const float *__restrict__ feats, int Tm, int F, int C,
                                                             const float *__restrict__ w1 /*[9][C]*/, const float *__restrict__ b1,
                                                             const float *__restrict__ wd /*[9][C]*/, const float *__restrict__ bd,
-                                                            int H1, int W1, int H2, int W2, int64_t n_pix, float *__restrict__ out) {
-    const int ppb = 256 / C;                                   // pixels per block (C <= 256, C | 256)
-    const int c = threadIdx.x % C;
-    const int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / C;
-    if (pix >= n_pix) return;
-    const int x2 = (int)(pix % W2);
-    const int y2 = (int)((pix / W2) % H2);
-    const int b = (int)(pix / ((int64_t)W2 * H2));
-    const float *in = feats + (int64_t)b * Tm * F;
-    float k1[9];
+                                                            int H1, int W1, int H2, int W2, int n_xc, int n_ys, int64_t n_strips,
+                                                            float *__restrict__ out) {
+    constexpr int NC = 2 * XC + 1, YS = 8;
+    constexpr int WR = 4 * YS + 3, WC = 4 * XC + 3, PW = (WC + 3) & ~3, TILE = WR * PW;   // input window per strip
+    extern __shared__ __attribute__((aligned(16))) float win[];       // [256/C][WR][PW]
+    const int spb = 256 / C;                                           // strips per block
+    // ---- stage the windows: window row wr <-> input row 4*y2_0 - 3 + wr, column wc <-> 4*x2_0 - 3 + wc ----------------
+    for (int e = threadIdx.x; e < spb * TILE; e += 256) {
+        const int sl = e / TILE, rem = e % TILE, wr = rem / PW, wc = rem % PW;
+        const int64_t strip = (int64_t)blockIdx.x * spb + sl;
+        float v = 0.0f;
+        if (strip < n_strips && wc < WC) {
+            const int xc = (int)(strip % n_xc), ys = (int)((strip / n_xc) % n_ys), b = (int)(strip / ((int64_t)n_xc * n_ys));
+            const int iy = 4 * ys * YS - 3 + wr, ix = 4 * xc * XC - 3 + wc;
+            if (iy >= 0 && iy < Tm && ix >= 0 && ix < F) v = feats[((int64_t)b * Tm + iy) * F + ix];
+        }
+        win[e] = v;
+    }
+    __syncthreads();
+    const int c = threadIdx.x % C, sl = threadIdx.x / C;
+    const int64_t strip = (int64_t)blockIdx.x * spb + sl;
+    if (strip >= n_strips) return;
+    const int xc = (int)(strip % n_xc), ys = (int)((strip / n_xc) % n_ys), b = (int)(strip / ((int64_t)n_xc * n_ys));
+    const int x2_0 = xc * XC, y2_0 = ys * YS, x1_0 = 2 * x2_0 - 1;     // r[j] holds conv1 column x1_0 + j
+    const float *tile = win + sl * TILE;
+    float k1[9], kd[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) k1[i] = w1[i * C + c];
-    const float bias1 = b1[c];
-    float acc2 = 0.0f;
+    for (int i = 0; i < 9; ++i) { k1[i] = w1[i * C + c]; kd[i] = wd[i * C + c]; }
+    const float bias1 = b1[c], biasd = bd[c];
+    float r0[NC], r1[NC], r2[NC];
+    // conv1 + ReLU (src/encoder.cpp:223-224) of conv1 row y1 = 2*y2_0 - 1 + q: its input rows are window rows 2q .. 2q+2
+    auto conv_row = [&](int q, float (&r)[NC]) {
+        const int y1 = 2 * y2_0 - 1 + q;
+        const float *rp = tile + 2 * q * PW;
+        const bool row_ok = y1 >= 0 && y1 < H1;                        // else: zero padding of the depthwise conv
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int y1 = 2 * y2 + ky - 1;
-        if (y1 < 0 || y1 >= H1) continue;                      // zero padding of the depthwise conv
+        for (int j = 0; j < NC; ++j) {
+            float acc = 0.0f;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int x1 = 2 * x2 + kx - 1;
-            if (x1 < 0 || x1 >= W1) continue;
-            float acc1 = 0.0f;                                 // conv1 at (y1, x1), src/encoder.cpp:223
+            for (int jy = 0; jy < 3; ++jy)
 #pragma unroll
-            for (int jy = 0; jy < 3; ++jy) {
-                const int iy = 2 * y1 + jy - 1;
-                if (iy < 0 || iy >= Tm) continue;
+                for (int jx = 0; jx < 3; ++jx) acc = __builtin_fmaf(k1[jy * 3 + jx], rp[jy * PW + 2 * j + jx], acc);
+            float v = acc + bias1;
+            v = v > 0.0f ? v : 0.0f;                                   // ReLU :224
+            const int x1 = x1_0 + j;
+            r[j] = (row_ok && x1 >= 0 && x1 < W1) ? v : 0.0f;
+        }
+    };
+    for (int yy = 0; yy < YS; ++yy) {
+        const int y2 = y2_0 + yy;
+        if (y2 >= H2) break;
+        if (yy == 0) {
+            conv_row(0, r0);
+        } else {
 #pragma unroll
-                for (int jx = 0; jx < 3; ++jx) {
-                    const int ix = 2 * x1 + jx - 1;
-                    if (ix < 0 || ix >= F) continue;
-                    acc1 = __builtin_fmaf(k1[jy * 3 + jx], in[(int64_t)iy * F + ix], acc1);
-                }
-            }
-            float v = acc1 + bias1;
-            v = v > 0.0f ? v : 0.0f;                           // ReLU :224
-            acc2 = __builtin_fmaf(wd[(ky * 3 + kx) * C + c], v, acc2);   // dw1 :226
+            for (int j = 0; j < NC; ++j) r0[j] = r2[j];
+        }
+        conv_row(2 * yy + 1, r1);
+        conv_row(2 * yy + 2, r2);
+        float *orow = out + (((int64_t)b * H2 + y2) * W2 + x2_0) * C + c;
+#pragma unroll
+        for (int xl = 0; xl < XC; ++xl) {
+            float acc2 = 0.0f;                                         // dw1 :226, taps in (ky,kx) order
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc2 = __builtin_fmaf(kd[kx], r0[2 * xl + kx], acc2);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc2 = __builtin_fmaf(kd[3 + kx], r1[2 * xl + kx], acc2);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc2 = __builtin_fmaf(kd[6 + kx], r2[2 * xl + kx], acc2);
+            if (x2_0 + xl < W2) orow[(int64_t)xl * C] = acc2 + biasd;
         }
     }
-    out[pix * C + c] = acc2 + bd[c];
 }
 
 __global__ __launch_bounds__(256) void sub_dw_kernel(const float *__restrict__ in, int H, int W, int C,
@@ -85,13 +124,27 @@ __global__ __launch_bounds__(256) void sub_dw_kernel(const float *__restrict__ i
     out[pix * C + c] = acc + bd[c];
 }
 
+template <int XC>
+static void launch_c1d1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
+                        const float *bd, int H1, int W1, int H2, int W2, float *out, hipStream_t s) {
+    constexpr int WR = 4 * 8 + 3, PW = (4 * XC + 3 + 3) & ~3;
+    const int spb = 256 / C, n_ys = (H2 + 7) / 8, n_xc = (W2 + XC - 1) / XC;
+    const int64_t n_strips = (int64_t)B * n_ys * n_xc;
+    const size_t lds = (size_t)spb * WR * PW * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sub_conv1_dw1_kernel<XC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL(sub_conv1_dw1_kernel<XC>, dim3((unsigned)((n_strips + spb - 1) / spb)), dim3(256), lds, s, feats, Tm, F, C, w1, b1,
+                       wd, bd, H1, W1, H2, W2, n_xc, n_ys, n_strips, out);
+}
 void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
                           const float *bd, float *out, hipStream_t s) {
     const int H1 = (Tm - 1) / 2 + 1, W1 = (F - 1) / 2 + 1, H2 = (H1 - 1) / 2 + 1, W2 = (W1 - 1) / 2 + 1;
-    const int64_t n_pix = (int64_t)B * H2 * W2;
-    const int ppb = 256 / C;
-    hipLaunchKernelGGL(sub_conv1_dw1_kernel, dim3((unsigned)((n_pix + ppb - 1) / ppb)), dim3(256), 0, s, feats, Tm, F, C, w1, b1,
-                       wd, bd, H1, W1, H2, W2, n_pix, out);
+    // 80 mel bins -> one 20-column chunk per output row; 128 -> two chunks of 16
+    if (W2 <= 20 || W2 % 20 == 0) launch_c1d1<20>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
+    else launch_c1d1<16>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
 }
 void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, float *out, hipStream_t s) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;

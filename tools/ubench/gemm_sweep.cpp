@@ -1,0 +1,225 @@
+// tools/ubench/gemm_sweep.cpp -- times every tile variant of the fp32-MFMA GEMMs on the encoder's real shapes and checks
+// each against the first-generation kernel bit for bit.  Build: make -C tools/ubench ; run on the GPU box.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#define GP_CLOCKPROBE 1
+#include "../../parakeet.cpp_amd/csrc/kernels/gemm.hip"   // first-generation kernel + launch_gemm
+
+using namespace pk;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void mfma_clock_kernel(long long *out, int iters) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)s; }
+}
+
+struct Shape { const char *name; int M, N, K, epi; };
+struct Variant { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
+
+template <int WGM, int WGN, int TM, int TN, int BK, bool P>
+static void run_pipe(const GemmArgs &a, int epi, hipStream_t s) {
+    switch (epi) {
+    case EPI_NONE: launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_NONE>(a, s); break;
+    case EPI_RELU: launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_RELU>(a, s); break;
+    case EPI_SILU: launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_SILU>(a, s); break;
+    case EPI_RESID: launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_RESID>(a, s); break;
+    case EPI_GLU: if constexpr (TN % 2 == 0) launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_GLU>(a, s); break;
+    }
+}
+template <int BM, int BN>
+static void run_old(const GemmArgs &a, int epi, hipStream_t s) {
+    switch (epi) {
+    case EPI_NONE: launch_one<BM, BN, EPI_NONE>(a, s); break;
+    case EPI_RELU: launch_one<BM, BN, EPI_RELU>(a, s); break;
+    case EPI_SILU: launch_one<BM, BN, EPI_SILU>(a, s); break;
+    case EPI_RESID: launch_one<BM, BN, EPI_RESID>(a, s); break;
+    case EPI_GLU: if constexpr (BN == 128) launch_one<BM, BN, EPI_GLU>(a, s); break;
+    }
+}
+
+int main(int argc, char **argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 20;
+    CK(hipSetDevice(0));
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    {   // sustained MFMA peak on this box
+        float *d;
+        CK(hipMalloc(&d, 4));
+        const int iters = 4000;
+        hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * 2), dim3(256), 0, s, d, 100);
+        CK(hipStreamSynchronize(s));
+        CK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * 2), dim3(256), 0, s, d, iters);
+        CK(hipEventRecord(e1, s));
+        CK(hipStreamSynchronize(s));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double fl = 512.0 * 4 * (double)iters * 32 * 2.0 * 32 * 32 * 2;
+        printf("mfma_peak: %.1f TF (%.3f ms)\n", fl / ms * 1e-9, ms);
+        long long *dc, hc[3];
+        CK(hipMalloc(&dc, 24));
+        hipLaunchKernelGGL(mfma_clock_kernel, dim3(256 * 2), dim3(256), 0, s, dc, iters);
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(hc, dc, 24, hipMemcpyDeviceToHost));
+        int wrate = 0;
+        (void)hipDeviceGetAttribute(&wrate, hipDeviceAttributeWallClockRate, 0);
+        printf("clock probe: clock64 delta %lld, wall_clock64 delta %lld (wall rate %d kHz) -> clock64 rate %.1f MHz; MFMA cycles/instr %.2f\n", hc[0], hc[1], wrate,
+               (double)hc[0] / ((double)hc[1] / (wrate * 1e3)) * 1e-6, (double)hc[0] / (iters * 32.0) / 2.0);
+    }
+    const std::vector<Shape> shapes = {
+        {"fc1_silu   8064x2048x512 ", 8064, 2048, 512, EPI_SILU},
+        {"fc2_resid  8064x512x2048 ", 8064, 512, 2048, EPI_RESID},
+        {"qkv        8064x1536x512 ", 8064, 1536, 512, EPI_NONE},
+        {"out_resid  8064x512x512  ", 8064, 512, 512, EPI_RESID},
+        {"pw1_glu    8064x512x512  ", 8064, 512, 512, EPI_GLU},
+        {"sub_pw     321280x256x256", 321280, 256, 256, EPI_RELU},
+        {"sub_proj   8064x512x2560 ", 8064, 512, 2560, EPI_NONE},
+        {"ctc_head   8064x1025x512 ", 8064, 1025, 512, EPI_NONE},
+        {"B fc1      12032x4096x1024", 12032, 4096, 1024, EPI_SILU},
+        {"B fc2      12032x1024x4096", 12032, 1024, 4096, EPI_RESID},
+        {"B out      12032x1024x1024", 12032, 1024, 1024, EPI_RESID},
+    };
+    const std::vector<Variant> variants = {
+        {"old 128x128", run_old<128, 128>},
+        {"old 128x64", run_old<128, 64>},
+        {"old 64x64", run_old<64, 64>},
+        {"pipe 64x64   w32x32 bk32", run_pipe<2, 2, 1, 1, 32, false>},
+        {"pipe 64x64   w32x32 bk32 persist", run_pipe<2, 2, 1, 1, 32, true>},
+        {"pipe 64x64   w32x32 bk64", run_pipe<2, 2, 1, 1, 64, false>},
+        {"pipe 64x64   w32x32 bk64 persist", run_pipe<2, 2, 1, 1, 64, true>},
+        {"pipe 128x64  w64x32 bk32", run_pipe<2, 2, 2, 1, 32, false>},
+        {"pipe 128x64  w64x32 bk32 persist", run_pipe<2, 2, 2, 1, 32, true>},
+        {"pipe 128x64  w64x32 bk64 persist", run_pipe<2, 2, 2, 1, 64, true>},
+        {"pipe 64x128  w32x64 bk32", run_pipe<2, 2, 1, 2, 32, false>},
+        {"pipe 64x128  w32x64 bk32 persist", run_pipe<2, 2, 1, 2, 32, true>},
+        {"pipe 64x128  w32x64 bk64 persist", run_pipe<2, 2, 1, 2, 64, true>},
+        {"pipe 128x128 w64x64 bk32", run_pipe<2, 2, 2, 2, 32, false>},
+        {"pipe 128x128 w64x64 bk32 persist", run_pipe<2, 2, 2, 2, 32, true>},
+        {"pipe 128x128 w64x32 bk32 512t", run_pipe<2, 4, 2, 1, 32, false>},
+        {"pipe 128x128 w64x32 bk32 512t persist", run_pipe<2, 4, 2, 1, 32, true>},
+        {"pipe 128x128 w32x64 bk32 512t", run_pipe<4, 2, 1, 2, 32, false>},
+        {"pipe 128x128 w32x64 bk32 512t persist", run_pipe<4, 2, 1, 2, 32, true>},
+    };
+    size_t maxA = 0, maxW = 0, maxO = 0;
+    for (auto &sh : shapes) {
+        maxA = std::max(maxA, (size_t)sh.M * sh.K);
+        maxW = std::max(maxW, (size_t)sh.N * sh.K * 2);
+        maxO = std::max(maxO, (size_t)sh.M * sh.N);
+    }
+    float *dA, *dW, *dB, *dR, *dO, *dRef;
+    CK(hipMalloc(&dA, maxA * 4)); CK(hipMalloc(&dW, maxW * 4)); CK(hipMalloc(&dB, 16384 * 4));
+    CK(hipMalloc(&dR, maxO * 4)); CK(hipMalloc(&dO, maxO * 4)); CK(hipMalloc(&dRef, maxO * 4));
+    {
+        std::vector<float> h(std::max(std::max(maxA, maxW), maxO));
+        unsigned x = 12345u;
+        auto fill = [&](float *d, size_t n, float sc) {
+            for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = ((int)(x >> 8) - (1 << 23)) * (sc / (1 << 23)); }
+            CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+        };
+        fill(dA, maxA, 1.0f); fill(dW, maxW, 0.05f); fill(dB, 16384, 0.1f); fill(dR, maxO, 1.0f);
+    }
+    if (argc > 2) {   // K scan: time = fixed + per-K cost
+        struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
+        const std::vector<KV> kv = {{"old 128x128", run_old<128, 128>}, {"pipe 64x64 bk32", run_pipe<2, 2, 1, 1, 32, false>},
+                                    {"pipe 128x128 w64x32 512t", run_pipe<2, 4, 2, 1, 32, false>}, {"pipe 128x128 w64x64", run_pipe<2, 2, 2, 2, 32, false>},
+                                    {"pipe 128x128 w64x64 persist", run_pipe<2, 2, 2, 2, 32, true>}};
+        for (int epi : {(int)EPI_NONE, (int)EPI_SILU, (int)EPI_RESID})
+            for (auto &v : kv) {
+                printf("kscan epi=%d %-28s:", epi, v.name);
+                for (int K : {64, 128, 256, 512, 1024, 2048}) {
+                    GemmArgs g{dA, K, dW, K, dB, dO, 2048, dR, 2048, 0.5f, 8064, 2048, K};
+                    for (int i = 0; i < 2; ++i) v.run(g, epi, s);
+                    CK(hipEventRecord(e0, s));
+                    for (int i = 0; i < reps; ++i) v.run(g, epi, s);
+                    CK(hipEventRecord(e1, s));
+                    CK(hipStreamSynchronize(s));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    long long hc[2];
+                    CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(gp_clk), 16));
+                    printf("  K=%d %.1fus", K, ms / reps * 1e3);
+                    if (K == 2048 && strncmp(v.name, "pipe", 4) == 0) printf(" [blk0 %.0f MHz]", (double)hc[0] / ((double)hc[1] / 100.0));
+                }
+                printf("\n");
+            }
+        return 0;
+    }
+    std::vector<unsigned> href, hout;
+    for (auto &sh : shapes) {
+        GemmArgs g{dA, sh.K, dW, sh.K, dB, dRef, sh.N, dR, sh.N, 0.5f, sh.M, sh.N, sh.K};
+        const double flops = 2.0 * sh.M * (double)sh.N * sh.K * (sh.epi == EPI_GLU ? 2 : 1);
+        const size_t no = (size_t)sh.M * sh.N;
+        // reference = first-generation 64x64 kernel (always available, no GLU) or 128x128 for GLU
+        CK(hipMemsetAsync(dRef, 0, no * 4, s));
+        if (sh.epi == EPI_GLU) run_old<128, 128>(g, sh.epi, s); else run_old<64, 64>(g, sh.epi, s);
+        CK(hipStreamSynchronize(s));
+        href.resize(no);
+        CK(hipMemcpy(href.data(), dRef, no * 4, hipMemcpyDeviceToHost));
+        printf("== %s  %.2f GFLOP\n", sh.name, flops * 1e-9);
+        for (auto &v : variants) {
+            const bool is_old = strncmp(v.name, "old", 3) == 0;
+            if (sh.epi == EPI_GLU) {
+                if (is_old && strstr(v.name, "128x128") == nullptr) continue;
+                if (strstr(v.name, "w64x32") || strstr(v.name, "w32x32")) continue;   // TN odd
+            }
+            g.out = dO;
+            CK(hipMemsetAsync(dO, 0xff, no * 4, s));
+            v.run(g, sh.epi, s);
+            if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { printf("   %-40s LAUNCH FAILED\n", v.name); continue; }
+            hout.resize(no);
+            CK(hipMemcpy(hout.data(), dO, no * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < no; ++i) bad += hout[i] != href[i];
+            for (int i = 0; i < 2; ++i) v.run(g, sh.epi, s);
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < reps; ++i) v.run(g, sh.epi, s);
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= reps;
+            printf("   %-40s %8.1f us  %6.1f TF  %s\n", v.name, ms * 1e3, flops / ms * 1e-9, bad ? "MISMATCH" : "bit-equal");
+            if (bad) printf("      (%zu of %zu elements differ)\n", bad, no);
+        }
+        fflush(stdout);
+    }
+    return 0;
+}
