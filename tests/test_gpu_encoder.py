@@ -60,3 +60,15 @@ def test_encoder_bits_full_width(wide_pair):
     feats = gm.mel(pcm)
     G.assert_bits_equal(gm.subsample(feats), om.subsampling(feats), "full-width subsampling")
     G.assert_bits_equal(gm.encode(feats), om.encoder(feats), "full-width 2-layer encoder")
+
+
+@pytest.mark.parametrize("heads,Tm", [(2, 1233), (2, 2401), (1, 1233), (1, 505), (4, 1233), (4, 2401)])
+def test_attention_long_sequences_and_head_dims(tmp_path_factory, heads, Tm):
+    """The attention kernel streams K / P / V through a fixed chunk buffer: T = 155 and 301 exercise 2-3 chunks per
+    phase (hd = 64 chunk 128, hd = 128 chunk 64), heads = 1 / 4 the hd = 128 / 32 instantiations, odd T the zero pad."""
+    cfg = G.tiny(num_heads=heads, num_layers=1, name=f"tiny-h{heads}")
+    W, om, gm = G.make_pair(tmp_path_factory.mktemp(f"h{heads}"), cfg, seed=11)
+    feats = np.random.default_rng(Tm + heads).standard_normal((2, Tm, 80)).astype(np.float32)
+    x = om.subsampling(feats)
+    want = om.conformer_block(0, x, stop_after=2)
+    G.assert_bits_equal(gm.encode(feats, stop_layer=0, stop_stage=2), want, f"attention heads={heads} Tm={Tm}")
