@@ -344,9 +344,12 @@ void Model::ensure_pos_tables(int T, hipStream_t s) {
     pos_pe.reserve(pe.size() * 4);
     pos_proj.reserve((size_t)cfg.num_layers * P * d * 4);
     PK_HIP(hipMemcpy(pos_pe.p, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
-    for (int l = 0; l < cfg.num_layers; ++l)
-        gemm("pos_proj", pos_pe.as<float>(), d, layers[l].wpos, d, nullptr, pos_proj.as<float>() + (size_t)l * P * d, d, P, d, d, EPI_NONE,
-             nullptr, 0, 1.0f, s);
+    for (int l = 0; l < cfg.num_layers; ++l) {
+        // written in the sigma column layout the attention kernel loads its MFMA operands in (kernels.hpp: GemmArgs::sigma_cols)
+        GemmArgs g{pos_pe.as<float>(), d, layers[l].wpos, d, nullptr, pos_proj.as<float>() + (size_t)l * P * d, d, nullptr, 0, 1.0f, P, d, d};
+        g.sigma_cols = d;
+        KL("pos_proj", gemm_flops(g, EPI_NONE), 0.0, launch_gemm(g, EPI_NONE, s));
+    }
     pos_T = T;
 }
 
@@ -399,7 +402,12 @@ void Model::run_encoder(Workspace &w, const float *d_feats, int B, int Tm, int s
         if (stage_cap == 1) break;
         // ConformerAttention::forward  :180-186
         KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, s));
-        gemm("attn_qkv", n, d, L.wqkv, d, L.bqkv, w.qkv.as<float>(), 3 * d, (int)rows, 3 * d, d, EPI_NONE, nullptr, 0, 1.0f, s);
+        {
+            // q and k columns in the sigma layout (MFMA operands of the attention kernel), v natural
+            GemmArgs g{n, d, L.wqkv, d, L.bqkv, w.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
+            g.sigma_cols = 2 * d;
+            KL("attn_qkv", gemm_flops(g, EPI_NONE), 0.0, launch_gemm(g, EPI_NONE, s));
+        }
         {
             const int hd = d / cfg.num_heads;
             const double fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);   // QK^T + QP^T(needed band) + AV

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g, int tiles_n, i
                     v = v * dsigmoidf(gt);
                 }
                 if (g.remap_rows) g.out[(int64_t)(row / g.remap_rows) * g.remap_gs + (int64_t)(row % g.remap_rows) * g.remap_rs + (int64_t)col * g.remap_cs] = v;
-                else g.out[(int64_t)row * g.ldo + col] = v;
+                else g.out[(int64_t)row * g.ldo + (col < g.sigma_cols ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = v;
             }
         }
     }

@@ -33,6 +33,10 @@ struct GemmArgs {
     // optional output re-mapping (0 = off): offset = (row / remap_rows) * remap_gs + (row % remap_rows) * remap_rs + col * remap_cs
     // (used to write the last subsampling conv straight into the permute(0,2,1,3)+reshape layout, src/encoder.cpp:235-238)
     int remap_rows = 0; int64_t remap_gs = 0, remap_rs = 0, remap_cs = 0;
+    // output columns < sigma_cols (a multiple of 16) are written in the "sigma" layout: inside every block of 16 columns the
+    // 4x4 index matrix is transposed (col -> (col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)).  The attention kernel reads
+    // Q, K and the projected position table that way: a lane's float4 then holds its operands of 4 consecutive MFMA steps.
+    int sigma_cols = 0;
 };
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
 double gemm_flops(const GemmArgs &a, int epi);
