@@ -197,9 +197,9 @@ static void launch_one(const GemmArgs &a, hipStream_t s) {
 template <int EPI>
 static void launch_epi(const GemmArgs &a, hipStream_t s) {
     if (a.K < 64) { launch_one<64, 64, EPI>(a, s); return; }           // pipelined kernels need >= 2 K tiles
-    if (a.M >= 1024 && a.N >= 2048) launch_gemm_pipe<2, 4, 2, 1, 32, false, EPI>(a, s);
-    else if (a.M >= 1024 && a.N >= 256 && (a.K >= 1024 || a.M >= 65536)) launch_gemm_pipe<2, 2, 2, 1, 32, false, EPI>(a, s);
-    else launch_gemm_pipe<2, 2, 1, 1, 32, false, EPI>(a, s);
+    if (a.M >= 1024 && a.N >= 2048) launch_gemm_pipe<2, 4, 2, 1, 32, EPI>(a, s);
+    else if (a.M >= 1024 && a.N >= 256 && (a.K >= 1024 || a.M >= 65536)) launch_gemm_pipe<2, 2, 2, 1, 32, EPI>(a, s);
+    else launch_gemm_pipe<2, 2, 1, 1, 32, EPI>(a, s);
 }
 
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
@@ -210,7 +210,7 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
     case EPI_RESID: launch_epi<EPI_RESID>(a, s); break;
     case EPI_GLU:
         if (a.K < 64) launch_one<128, 128, EPI_GLU>(a, s);
-        else launch_gemm_pipe<4, 2, 1, 2, 32, false, EPI_GLU>(a, s);
+        else launch_gemm_pipe<4, 2, 1, 2, 32, EPI_GLU>(a, s);
         break;
     default: break;
     }

@@ -12,9 +12,9 @@
 //    issued before the 4*TM*TN MFMAs of sub-step s, the global loads of K tile k+2 are issued a whole K tile before
 //    they are stored, and the single barrier per K tile sits before the LAST sub-step, so the first fragment reads
 //    of the next K tile are already in flight while this tile's last MFMAs run.
-//  * PERSIST: a workgroup walks several output tiles and the pipeline runs straight through tile boundaries -- the
-//    first K tiles of the next output tile are loaded, staged and fragment-read while the current tile finishes, so
-//    only the epilogue itself (not the ~2 us load/stage prologue) sits between two tiles' MFMA streams.
+//  * Epilogue through LDS: the accumulators are re-read row-major so that every thread finishes 4 consecutive columns
+//    (16-byte stores / residual loads).  Measured on MI355X (profiles/r01_gemm_*): the main loop runs at ~88 % of the
+//    MFMA rate; what is left is the write burst of the output tile (all workgroups of a round finish together).
 #pragma once
 #include "../pk_devmath.h"
 #include "kernels.hpp"
@@ -24,9 +24,13 @@ namespace pk {
 typedef float gp_f32x16 __attribute__((ext_vector_type(16)));
 #ifdef GP_CLOCKPROBE
 __device__ long long gp_clk[4];     // micro-benchmark builds only: shader / wall clock deltas of block 0
+__device__ long long *gp_trace;     // micro-benchmark builds only: [n_blocks][8] wall-clock stamps of wave 0 + hw id
+#define GP_STAMP(i) do { if (gp_trace && tid == 0) gp_trace[(long long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define GP_STAMP(i) do { } while (0)
 #endif
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool PERSIST, int EPI>
+template <int WGM, int WGN, int TM, int TN, int BK, int EPI>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, int tiles_n, int n_tiles) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
         }
     };
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    auto epilogue = [&](int m0, int n0) {
+    auto epilogue_scalar = [&](int m0, int n0) {
         const int lc = lane & 31, lr = 4 * (lane >> 5);
         constexpr int TNO = (EPI == EPI_GLU) ? TN / 2 : TN;
 #pragma unroll
@@ -187,77 +191,144 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             }
         }
     };
+    // Wide epilogue (row-major outputs whose rows are 16-byte aligned): the accumulators go through LDS (the staging buffers
+    // are free by now) so that every thread finishes 4 CONSECUTIVE output columns -- one 16-byte store per 4 results, a
+    // wave writes whole 256-512 B row segments instead of 32 x 128 B slivers, the residual arrives as float4 too.
+    auto epilogue_wide = [&](int m0, int n0) {
+        constexpr int CP = BN + 4;                                  // C tile pitch (rows stay 16-byte aligned)
+        static_assert((size_t)BM * CP <= 2 * (size_t)BUF, "C tile must fit in the staging buffers");
+        __syncthreads();                                            // every wave is done reading its last fragments
+        {
+            const int lc = lane & 31, lr = 4 * (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        smem[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + lr) * CP + wn * WN + j * 32 + lc] = acc[i][j][r];
+        }
+        __syncthreads();
+        constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT;           // float4 chunks per output row / per thread
+        static_assert((BM * C4) % NT == 0, "output tile must split evenly over the threads");
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = tid + NT * q, rl = c / C4, c4 = c % C4;
+            const int row = m0 + rl, col0 = n0 + 4 * c4;            // 4 consecutive output positions col0..col0+3
+            if (row >= g.M || col0 >= g.N) continue;
+            float v[4], gt[4], bs[4], bg[4];
+            if (col0 < g.sigma_cols) {
+                // sigma layout: position 16b + 4a + e holds natural column 16b + 4e + a
+                const int blk = (4 * c4) & ~15, a = c4 & 3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = smem[rl * CP + blk + 4 * e + a];
+                    bs[e] = g.bias ? g.bias[n0 + blk + 4 * e + a] : 0.0f;
+                }
+            } else {
+                int vc = 4 * c4;                                    // virtual column of the value inside the C tile
+                if constexpr (EPI == EPI_GLU) vc = (vc / (WN / 2)) * WN + vc % (WN / 2);
+                const float4 x = *reinterpret_cast<const float4 *>(smem + rl * CP + vc);
+                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+                if constexpr (EPI == EPI_GLU) {
+                    const float4 y = *reinterpret_cast<const float4 *>(smem + rl * CP + vc + WN / 2);
+                    gt[0] = y.x; gt[1] = y.y; gt[2] = y.z; gt[3] = y.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bs[e] = g.bias ? g.bias[col0 + e] : 0.0f;
+                    if constexpr (EPI == EPI_GLU) bg[e] = g.bias ? g.bias[g.N + col0 + e] : 0.0f;
+                }
+            }
+            float4 rs = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if constexpr (EPI == EPI_RESID) rs = *reinterpret_cast<const float4 *>(g.resid + (int64_t)row * g.ldr + col0);
+            const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                if (g.bias) x = x + bs[e];
+                if constexpr (EPI == EPI_RELU) {
+                    x = x > 0.0f ? x : 0.0f;
+                } else if constexpr (EPI == EPI_SILU) {
+                    x = dsiluf(x);
+                } else if constexpr (EPI == EPI_RESID) {
+                    const float y = x * g.alpha;
+                    x = rsv[e] + y;
+                } else if constexpr (EPI == EPI_GLU) {
+                    float t2 = gt[e];
+                    if (g.bias) t2 = t2 + bg[e];
+                    x = x * dsigmoidf(t2);
+                }
+                v[e] = x;
+            }
+            *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);
+    auto epilogue = [&](int m0, int n0) {
+        if (wide) epilogue_wide(m0, n0);
+        else epilogue_scalar(m0, n0);
+    };
 #define GP_SB() __builtin_amdgcn_sched_barrier(0)
 
 #ifdef GP_CLOCKPROBE
     const long long c0_ = clock64(), w0_ = wall_clock64();
 #endif
-    int t = blockIdx.x;
-    const int t_step = PERSIST ? (int)gridDim.x : n_tiles;
     int m0, n0;
-    set_tile(t, m0, n0);
+    GP_STAMP(0);
+    set_tile(blockIdx.x, m0, n0);
     gload(0);
     lstore(0);
     __syncthreads();
+    GP_STAMP(1);
     gload(1);                      // nk >= 2 (K >= 2*BK, checked by the launcher)
     fragload(0, 0, 0);
     int cur = 0;
     zero_acc();
-    while (true) {
-        const bool has_next = PERSIST && (t + t_step < n_tiles);
-        int m0n = m0, n0n = n0;
-        for (int kt = 0; kt < nk; ++kt) {
-            // K tiles kt+1 / kt+2 of the stream: they belong to the next output tile once they run past nk
-            const bool more1 = (kt + 1 < nk) || has_next;
-            const bool more2 = (kt + 2 < nk) || has_next;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
 #pragma unroll
-            for (int s = 0; s < NSUB - 1; ++s) {
-                fragload(cur, s + 1, (s + 1) & 1);
-                if (s == NSUB - 2 && more1) lstore(cur ^ 1);
-                GP_SB(); mma(s & 1); GP_SB();
-            }
-            __syncthreads();
-            if (more1) fragload(cur ^ 1, 0, 0);
-            if (more2) {
-                if (PERSIST && kt + 2 == nk) set_tile(t + t_step, m0n, n0n);
-                gload(kt + 2 < nk ? kt + 2 : kt + 2 - nk);
-            }
-            GP_SB(); mma((NSUB - 1) & 1); GP_SB();
-            cur ^= 1;
+        for (int s = 0; s < NSUB - 1; ++s) {
+            fragload(cur, s + 1, (s + 1) & 1);
+            if (s == NSUB - 2 && more1) lstore(cur ^ 1);
+            GP_SB(); mma(s & 1); GP_SB();
         }
-        epilogue(m0, n0);
-        if (!has_next) break;
-        t += t_step; m0 = m0n; n0 = n0n;
-        zero_acc();
+        __syncthreads();
+        if (more1) fragload(cur ^ 1, 0, 0);
+        if (more2) gload(kt + 2);
+        GP_SB(); mma((NSUB - 1) & 1); GP_SB();
+        cur ^= 1;
     }
+    GP_STAMP(2);
+    epilogue(m0, n0);
+    GP_STAMP(3);
 #undef GP_SB
 #ifdef GP_CLOCKPROBE
     if (blockIdx.x == 0 && tid == 0) { gp_clk[0] = clock64() - c0_; gp_clk[1] = wall_clock64() - w0_; }
+    if (gp_trace && tid == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        gp_trace[(long long)blockIdx.x * 8 + 4] = (long long)hw | ((long long)(xcc & 0xf) << 32);
+    }
 #endif
 }
 
-// Occupancy-sized grid for the persistent form: as many workgroups as fit (LDS-limited), at most one per tile.
-template <int WGM, int WGN, int TM, int TN, int BK, bool PERSIST, int EPI>
+template <int WGM, int WGN, int TM, int TN, int BK, int EPI>
 static void launch_gemm_pipe(const GemmArgs &a, hipStream_t s) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
     const int n_tiles = tiles_m * tiles_n;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = &gemm_pipe_kernel<WGM, WGN, TM, TN, BK, PERSIST, EPI>;
-    static int wg_per_cu = 0;
-    if (!wg_per_cu) {
+    auto kern = &gemm_pipe_kernel<WGM, WGN, TM, TN, BK, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(kern), 64 * WGM * WGN, lds) != hipSuccess || n < 1) n = 1;
-        wg_per_cu = n;
+        attr_set = true;
     }
-    int grid = n_tiles;
-    if (PERSIST) {
-        const int cap = 256 * wg_per_cu;                 // 256 CUs; a multiple of 8 keeps a workgroup on one XCD's tile range
-        grid = n_tiles < cap ? n_tiles : cap;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
 }
 
 }  // namespace pk

@@ -51,14 +51,14 @@ __global__ __launch_bounds__(256) void mfma_clock_kernel(long long *out, int ite
 struct Shape { const char *name; int M, N, K, epi; };
 struct Variant { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool P>
+template <int WGM, int WGN, int TM, int TN, int BK>
 static void run_pipe(const GemmArgs &a, int epi, hipStream_t s) {
     switch (epi) {
-    case EPI_NONE: launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_NONE>(a, s); break;
-    case EPI_RELU: launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_RELU>(a, s); break;
-    case EPI_SILU: launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_SILU>(a, s); break;
-    case EPI_RESID: launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_RESID>(a, s); break;
-    case EPI_GLU: if constexpr (TN % 2 == 0) launch_gemm_pipe<WGM, WGN, TM, TN, BK, P, EPI_GLU>(a, s); break;
+    case EPI_NONE: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_NONE>(a, s); break;
+    case EPI_RELU: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_RELU>(a, s); break;
+    case EPI_SILU: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_SILU>(a, s); break;
+    case EPI_RESID: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_RESID>(a, s); break;
+    case EPI_GLU: if constexpr (TN % 2 == 0) launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_GLU>(a, s); break;
     }
 }
 template <int BM, int BN>
@@ -121,22 +121,13 @@ int main(int argc, char **argv) {
         {"old 128x128", run_old<128, 128>},
         {"old 128x64", run_old<128, 64>},
         {"old 64x64", run_old<64, 64>},
-        {"pipe 64x64   w32x32 bk32", run_pipe<2, 2, 1, 1, 32, false>},
-        {"pipe 64x64   w32x32 bk32 persist", run_pipe<2, 2, 1, 1, 32, true>},
-        {"pipe 64x64   w32x32 bk64", run_pipe<2, 2, 1, 1, 64, false>},
-        {"pipe 64x64   w32x32 bk64 persist", run_pipe<2, 2, 1, 1, 64, true>},
-        {"pipe 128x64  w64x32 bk32", run_pipe<2, 2, 2, 1, 32, false>},
-        {"pipe 128x64  w64x32 bk32 persist", run_pipe<2, 2, 2, 1, 32, true>},
-        {"pipe 128x64  w64x32 bk64 persist", run_pipe<2, 2, 2, 1, 64, true>},
-        {"pipe 64x128  w32x64 bk32", run_pipe<2, 2, 1, 2, 32, false>},
-        {"pipe 64x128  w32x64 bk32 persist", run_pipe<2, 2, 1, 2, 32, true>},
-        {"pipe 64x128  w32x64 bk64 persist", run_pipe<2, 2, 1, 2, 64, true>},
-        {"pipe 128x128 w64x64 bk32", run_pipe<2, 2, 2, 2, 32, false>},
-        {"pipe 128x128 w64x64 bk32 persist", run_pipe<2, 2, 2, 2, 32, true>},
-        {"pipe 128x128 w64x32 bk32 512t", run_pipe<2, 4, 2, 1, 32, false>},
-        {"pipe 128x128 w64x32 bk32 512t persist", run_pipe<2, 4, 2, 1, 32, true>},
-        {"pipe 128x128 w32x64 bk32 512t", run_pipe<4, 2, 1, 2, 32, false>},
-        {"pipe 128x128 w32x64 bk32 512t persist", run_pipe<4, 2, 1, 2, 32, true>},
+        {"pipe 64x64   w32x32 bk32", run_pipe<2, 2, 1, 1, 32>},
+        {"pipe 64x64   w32x32 bk64", run_pipe<2, 2, 1, 1, 64>},
+        {"pipe 128x64  w64x32 bk32", run_pipe<2, 2, 2, 1, 32>},
+        {"pipe 64x128  w32x64 bk32", run_pipe<2, 2, 1, 2, 32>},
+        {"pipe 128x128 w64x64 bk32", run_pipe<2, 2, 2, 2, 32>},
+        {"pipe 128x128 w64x32 bk32 512t", run_pipe<2, 4, 2, 1, 32>},
+        {"pipe 128x128 w32x64 bk32 512t", run_pipe<4, 2, 1, 2, 32>},
     };
     size_t maxA = 0, maxW = 0, maxO = 0;
     for (auto &sh : shapes) {
@@ -156,11 +147,36 @@ int main(int argc, char **argv) {
         };
         fill(dA, maxA, 1.0f); fill(dW, maxW, 0.05f); fill(dB, 16384, 0.1f); fill(dR, maxO, 1.0f);
     }
+    if (argc > 2 && strcmp(argv[2], "trace") == 0) {   // per-workgroup timeline of one launch -> gpurun_out/gemm_trace_<name>.bin
+        struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; int nblk; };
+        const std::vector<KV> kv = {{"p128x128_512t", run_pipe<2, 4, 2, 1, 32>, 63 * 16}, {"p64x64", run_pipe<2, 2, 1, 1, 32>, 126 * 32},
+                                    {"p128x128_w64x64", run_pipe<2, 2, 2, 2, 32>, 63 * 16},};
+        long long *dtrace;
+        CK(hipMalloc(&dtrace, 8192 * 8 * 8));
+        for (auto &v : kv) {
+            GemmArgs g{dA, 512, dW, 512, dB, dO, 2048, dR, 2048, 0.5f, 8064, 2048, 512};
+            long long *null = nullptr;
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(gp_trace), &null, 8));
+            for (int i = 0; i < 3; ++i) v.run(g, EPI_SILU, s);
+            CK(hipStreamSynchronize(s));
+            CK(hipMemset(dtrace, 0, 8192 * 8 * 8));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(gp_trace), &dtrace, 8));
+            v.run(g, EPI_SILU, s);
+            CK(hipStreamSynchronize(s));
+            std::vector<long long> h((size_t)v.nblk * 8);
+            CK(hipMemcpy(h.data(), dtrace, h.size() * 8, hipMemcpyDeviceToHost));
+            std::string fn = std::string("gpurun_out/gemm_trace_") + v.name + ".bin";
+            FILE *f = fopen(fn.c_str(), "wb");
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+            printf("wrote %s (%d blocks)\n", fn.c_str(), v.nblk);
+        }
+        return 0;
+    }
     if (argc > 2) {   // K scan: time = fixed + per-K cost
         struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
-        const std::vector<KV> kv = {{"old 128x128", run_old<128, 128>}, {"pipe 64x64 bk32", run_pipe<2, 2, 1, 1, 32, false>},
-                                    {"pipe 128x128 w64x32 512t", run_pipe<2, 4, 2, 1, 32, false>}, {"pipe 128x128 w64x64", run_pipe<2, 2, 2, 2, 32, false>},
-                                    {"pipe 128x128 w64x64 persist", run_pipe<2, 2, 2, 2, 32, true>}};
+        const std::vector<KV> kv = {{"old 128x128", run_old<128, 128>}, {"pipe 64x64 bk32", run_pipe<2, 2, 1, 1, 32>},
+                                    {"pipe 128x128 w64x32 512t", run_pipe<2, 4, 2, 1, 32>}, {"pipe 128x128 w64x64", run_pipe<2, 2, 2, 2, 32>},};
         for (int epi : {(int)EPI_NONE, (int)EPI_SILU, (int)EPI_RESID})
             for (auto &v : kv) {
                 printf("kscan epi=%d %-28s:", epi, v.name);
