@@ -95,6 +95,10 @@ int pk_encoder_num_frames(int n_mel_frames); /* floor((n-1)/2)+1 three times (en
  * stop_layer / stop_stage cut the pipeline for stage-wise parity checks: run `stop_layer` full blocks, then the
  * next block up to stop_stage (0 none, 1 ffn1, 2 +attn, 3 +conv, 4 +ffn2); pass (num_layers, 0) -- or (-1, 0) -- for all. */
 pk_status pk_encode(pk_model *m, const float *feats, int B, int Tm, int stop_layer, int stop_stage, float *enc);
+/* ConformerBlock::forward x n_layers starting at first_layer (src/encoder.cpp:196-204, the loop at :267-269), on an encoder
+ * stream x[B][T][hidden] given by the caller.  This is the boundary the reference author's own PyTorch check
+ * (scripts/compare_encoder.py) cuts at: tests/golden/ holds its outputs. */
+pk_status pk_conformer_blocks(pk_model *m, const float *x_in, int B, int T, int first_layer, int n_layers, float *x_out);
 /* ConvSubsampling::forward only (src/encoder.cpp:219-241). */
 pk_status pk_subsample(pk_model *m, const float *feats, int B, int Tm, float *out);
 

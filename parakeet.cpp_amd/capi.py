@@ -94,6 +94,7 @@ def lib():
 
 _LATE_SIGNATURES = {
     "pk_encode": [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p],
+    "pk_conformer_blocks": [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p],
     "pk_subsample": [C.c_void_p, f32p, C.c_int, C.c_int, f32p],
     "pk_ctc_decode": [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, f32p],
     "pk_tdt_decode": [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, i32p],
@@ -229,6 +230,14 @@ class Model:
         B, Tm, _ = feats.shape
         out = np.empty((B, lib().pk_encoder_num_frames(Tm), self.cfg.hidden_size), np.float32)
         check(lib().pk_encode(self._h, _f(feats), B, Tm, stop_layer, stop_stage, _f(out)))
+        return out
+
+    def conformer_blocks(self, x, first_layer=0, n_layers=None):
+        x = _c(x)
+        B, T, _ = x.shape
+        out = np.empty_like(x)
+        n = self.cfg.num_layers - first_layer if n_layers is None else n_layers
+        check(lib().pk_conformer_blocks(self._h, _f(x), B, T, first_layer, n, _f(out)))
         return out
 
     def ctc_decode(self, enc, return_logp=False):

@@ -159,6 +159,24 @@ pk_status pk_encode(pk_model *h, const float *feats, int B, int Tm, int stop_lay
     });
 }
 
+static void size_ws_for_T(Model &m, int B, int T);
+
+pk_status pk_conformer_blocks(pk_model *h, const float *x_in, int B, int T, int first_layer, int n_layers, float *x_out) {
+    return guard([&] {
+        need(h && x_in && x_out && B > 0 && T > 0, "model/x_in/x_out/B/T");
+        Model &m = *h->m;
+        m.require_gpu();
+        need(first_layer >= 0 && n_layers >= 0 && first_layer + n_layers <= m.cfg.num_layers, "layer range");
+        size_ws_for_T(m, B, T);
+        const size_t n = (size_t)B * T * m.cfg.hidden_size;
+        PK_HIP(hipMemcpyAsync(m.ws.x.p, x_in, n * 4, hipMemcpyHostToDevice, m.stream));
+        if (n_layers > 0) m.run_layers(m.ws, B, first_layer, first_layer + n_layers, 0, m.stream);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpyAsync(x_out, m.ws.x.p, n * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
 static void size_ws_for_T(Model &m, int B, int T) {
     // a mel length that subsamples to exactly T frames: Tm = 8(T-1)+1
     m.ws.size_for(m.cfg, B, 0, 8 * (T - 1) + 1);

@@ -387,14 +387,20 @@ void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStr
 
 // FastConformerEncoder::forward (src/encoder.cpp:253-271) -> w.x [B][T][d]
 void Model::run_encoder(Workspace &w, const float *d_feats, int B, int Tm, int stop_layer, int stop_stage, hipStream_t s) {
+    float *x = w.x.as<float>();
+    run_subsample(w, d_feats, B, Tm, x, s);
+    run_layers(w, B, 0, stop_layer, stop_stage, s);
+}
+
+// ConformerBlock::forward x (layers first_layer ..) on w.x [B][T][d]  (src/encoder.cpp:196-204, :267-269)
+void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int stop_stage, hipStream_t s) {
     const int d = cfg.hidden_size, T = w.T, P = 2 * T - 1;
     const int64_t rows = (int64_t)B * T;
     float *x = w.x.as<float>(), *n = w.n.as<float>();
-    run_subsample(w, d_feats, B, Tm, x, s);
     if (stop_layer < 0 || stop_layer > cfg.num_layers) { stop_layer = cfg.num_layers; stop_stage = 0; }
     if (stop_layer == 0 && stop_stage == 0) return;
     ensure_pos_tables(T, s);
-    for (int l = 0; l < cfg.num_layers; ++l) {
+    for (int l = first_layer; l < cfg.num_layers; ++l) {
         if (l > stop_layer || (l == stop_layer && stop_stage == 0)) break;
         const LayerW &L = layers[l];
         const int stage_cap = (l == stop_layer) ? stop_stage : 5;

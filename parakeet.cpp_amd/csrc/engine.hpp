@@ -84,6 +84,7 @@ class Model {
     void run_mel(const float *d_pcm, int B, int64_t n_samples, float *d_logmel, float *d_feats, hipStream_t s);
     void run_subsample(Workspace &w, const float *d_feats, int B, int Tm, float *d_x, hipStream_t s);
     void run_encoder(Workspace &w, const float *d_feats, int B, int Tm, int stop_layer, int stop_stage, hipStream_t s);  // -> w.x
+    void run_layers(Workspace &w, int B, int first_layer, int stop_layer, int stop_stage, hipStream_t s);                 // w.x -> w.x
     void run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_logp, hipStream_t s);
     void run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s);
 
