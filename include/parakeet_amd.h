@@ -63,6 +63,10 @@ typedef struct pk_config {
     int32_t max_symbols_per_step;  /* 10 */
     int32_t joint_pred_bias;       /* switch A5: 0 = drop pred_proj_.bias like the reference's Linear(bias=false) (tdt.cpp:10-11) */
     int32_t rnnt_head;             /* 1: joint has a single out_proj_ (rnnt.cpp:37-44) instead of label_/duration_proj_ */
+    int32_t stft_window_centered;  /* switch A1: placement of the 400-tap Hann window in the 512-point STFT frame (audio.cpp:117-120;
+                                      axiom's stft is not available).  0 (default) = left-aligned, zero-padded on the right: what the
+                                      reference author's own check of the C++ features does (scripts/compare_features.py:33-37; pinned by
+                                      tests/golden/ref_compare_features_seed7.npz).  1 = centred like torch.stft / NeMo. */
     char joint_prefix[32];         /* "tdt_joint_." (tdt_ctc.cpp:5-9) or "joint_." (tdt.cpp:28-32) */
 } pk_config;
 

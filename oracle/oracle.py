@@ -30,7 +30,7 @@ class AudioConfig(C.Structure):
                 ("window_centered", C.c_int), ("power_via_abs", C.c_int)]
 
 
-def audio_config(n_mels=80, normalize=True, window_centered=True, power_via_abs=True):
+def audio_config(n_mels=80, normalize=True, window_centered=False, power_via_abs=True):
     return AudioConfig(16000, 512, 400, 160, n_mels, 0.0, -1.0, int(normalize), int(window_centered), int(power_via_abs))
 
 

@@ -19,7 +19,8 @@ typedef struct {
     float f_min;         /* 0 */
     float f_max;         /* <=0 -> sample_rate/2 */
     int normalize;       /* 1 */
-    int window_centered; /* A1: 1 = torch.stft placement (default), 0 = left-aligned */
+    int window_centered; /* A1: 0 = left-aligned, as scripts/compare_features.py:33-37 checks the C++ (default of oracle.py and of
+                            the product); 1 = torch.stft / NeMo placement */
     int power_via_abs;   /* A2: 1 = abs() then square (literal reference, default), 0 = re^2+im^2 */
 } orc_audio_config;
 

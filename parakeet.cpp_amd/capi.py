@@ -26,7 +26,7 @@ class PkConfig(C.Structure):
                 ("conv_kernel_size", C.c_int32), ("vocab_size", C.c_int32), ("pred_hidden", C.c_int32),
                 ("num_lstm_layers", C.c_int32), ("joint_hidden", C.c_int32), ("num_durations", C.c_int32),
                 ("durations", C.c_int32 * 8), ("ctc_vocab_size", C.c_int32), ("blank_id", C.c_int32),
-                ("max_symbols_per_step", C.c_int32), ("joint_pred_bias", C.c_int32), ("rnnt_head", C.c_int32),
+                ("max_symbols_per_step", C.c_int32), ("joint_pred_bias", C.c_int32), ("rnnt_head", C.c_int32), ("stft_window_centered", C.c_int32),
                 ("joint_prefix", C.c_char * 32)]
 
 
@@ -58,6 +58,7 @@ def to_pk_config(cfg: ModelConfig) -> PkConfig:
         c.durations[i] = d
     c.ctc_vocab_size, c.blank_id, c.max_symbols_per_step = cfg.ctc_vocab_size, cfg.blank_id, cfg.max_symbols_per_step
     c.joint_pred_bias, c.rnnt_head = 0, int(cfg.head == "rnnt")
+    c.stft_window_centered = int(getattr(cfg, "stft_window_centered", False))
     c.joint_prefix = cfg.joint_prefix.encode()
     return c
 

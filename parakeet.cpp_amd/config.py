@@ -29,6 +29,9 @@ class ModelConfig:
     # decode defaults (tdt.hpp:71-74, ctc.hpp:55-56)
     blank_id: int = 1024
     max_symbols_per_step: int = 10
+    # switch A1 (pk_config.stft_window_centered): False = Hann window left-aligned in the FFT frame, as the reference
+    # author's own feature check does (scripts/compare_features.py:33-37); True = centred like torch.stft / NeMo
+    stft_window_centered: bool = False
 
     @property
     def head_dim(self):

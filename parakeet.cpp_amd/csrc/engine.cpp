@@ -108,7 +108,8 @@ void Model::build_mel_tables() {
         }
     }
     std::vector<float> window(n_fft, 0.0f), twr(n_fft / 2), twi(n_fft / 2);
-    const int off = (n_fft - win) / 2;   // switch A1 default: window centred in the FFT frame (torch.stft)
+    // switch A1 (pk_config.stft_window_centered): left-aligned like the reference author's feature check, or centred (torch.stft)
+    const int off = cfg.stft_window_centered ? (n_fft - win) / 2 : 0;
     for (int k = 0; k < win; ++k) window[off + k] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)k / (double)(win - 1)));
     for (int k = 0; k < n_fft / 2; ++k) {
         const double a = 2.0 * M_PI * (double)k / (double)n_fft;

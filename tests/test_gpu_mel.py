@@ -41,3 +41,20 @@ def test_mel_properties_full_batch(tiny_gpu):
     assert f.shape == (64, 1001, 80)
     assert np.max(np.abs(f.mean(axis=1))) < 1e-3
     assert np.max(np.abs(f.std(axis=1, ddof=1) - 1.0)) < 1e-3
+
+
+def test_mel_centered_window_switch_bit_identical(tmp_path_factory, orc):
+    """Switch A1 (pk_config.stft_window_centered = 1): torch.stft / NeMo placement of the Hann window, also bit-for-bit."""
+    import dataclasses
+    from parakeet_cpp_amd import capi
+    cfg = dataclasses.replace(pk.make_tiny_config(), stft_window_centered=True)
+    p = tmp_path_factory.mktemp("wc") / "tiny.safetensors"
+    synth.save_weights(str(p), synth.synth_weights(cfg, seed=42))
+    gm = capi.Model(str(p), cfg, device=0)
+    pcm = synth.synth_pcm(2, 16000, seed=12)
+    feats = gm.mel(pcm)
+    for b in range(2):
+        want = orc.mel(pcm[b], window_centered=True)
+        assert np.array_equal(feats[b].view(np.uint32), want.view(np.uint32))
+        assert not np.array_equal(want, orc.mel(pcm[b]))
+    gm.close()

@@ -11,24 +11,24 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
 
 
+@pytest.mark.parametrize("centered", [False, True])
 @pytest.mark.parametrize("n_mels,n", [(80, 16000), (128, 24000), (80, 5433)])
-def test_mel_matches_torch_stft(orc, n_mels, n):
+def test_mel_matches_torch_stft(orc, n_mels, n, centered):
     pcm = synth.synth_pcm(1, n, seed=5)[0]
-    feats, logmel = orc.mel(pcm, n_mels=n_mels, return_logmel=True)
+    feats, logmel = orc.mel(pcm, n_mels=n_mels, return_logmel=True, window_centered=centered)
     fb = orc.mel_filterbank(n_mels=n_mels)
-    tf, tl = torch_ref.mel_features(pcm, fb, n_mels=n_mels)
+    tf, tl = torch_ref.mel_features(pcm, fb, n_mels=n_mels, window_centered=centered)
     assert feats.shape == (1 + n // 160, n_mels)
     assert np.max(np.abs(logmel - tl)) < 2e-3          # log amplifies round-off in near-empty bins
     assert np.max(np.abs(feats - tf)) < 2e-3
 
 
-def test_mel_left_aligned_window_switch(orc):
-    """Switch A1: the reference author's check script left-aligns the window (compare_features.py:33-37)."""
+def test_mel_window_switch_default_is_left_aligned(orc):
+    """Switch A1: the reference author's check script left-aligns the window (compare_features.py:33-37); that is the default,
+    torch.stft / NeMo centring is the alternative -- and the two are genuinely different features."""
     pcm = synth.synth_pcm(1, 16000, seed=6)[0]
-    feats = orc.mel(pcm, window_centered=False)
-    tf, _ = torch_ref.mel_features(pcm, orc.mel_filterbank(), window_centered=False)
-    assert np.max(np.abs(feats - tf)) < 2e-3
-    assert np.max(np.abs(feats - orc.mel(pcm))) > 1e-2   # the two placements are genuinely different
+    assert np.array_equal(orc.mel(pcm), orc.mel(pcm, window_centered=False))
+    assert np.max(np.abs(orc.mel(pcm) - orc.mel(pcm, window_centered=True))) > 1e-2
 
 
 def test_filterbank_matches_slaney_formula(orc):
