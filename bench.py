@@ -85,9 +85,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="clips per step per GPU (BASELINE: 64)")
     ap.add_argument("--decoder", default="tdt", choices=["tdt", "ctc"])
+    ap.add_argument("--config", default="tdt-ctc-110m", choices=["tdt-ctc-110m", "tdt-600m"],
+                    help="tdt-ctc-110m = BASELINE configs[1] (the headline metric); tdt-600m = configs[2] shapes (32 x 30 s), run in fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
     args = ap.parse_args()
+    global CLIP_SECONDS, CLIP_SAMPLES, ENCODER_FLOP_PER_CLIP
+    big = args.config == "tdt-600m"
+    if big:                                  # 470.9 GFLOP per 30 s clip
+        CLIP_SECONDS, CLIP_SAMPLES, ENCODER_FLOP_PER_CLIP = 30.0, 480000, 470.9e9
+        if args.batch == BATCH:
+            args.batch = 32
+        args.no_cpu_baseline = True          # the scalar oracle needs minutes per 30 s clip of the 24-layer model
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -115,7 +124,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    cfg = pk.make_110m_config()
+    cfg = pk.make_tdt_600m_config() if big else pk.make_110m_config()
     W = None
     if local_rank == 0:
         wpath, W = weights_file(cfg)
@@ -167,7 +176,7 @@ def main():
         audio_s = args.steps * args.batch * CLIP_SECONDS * n_gpus
         value = audio_s / elapsed
         # roofline of the dominant kernel: the fp32-MFMA GEMM instantiation that runs ffn fc1 (+SiLU epilogue):
-        # algorithmic FLOP per launch = 2*M*N*K (M = batch*126 frames, N = 2048, K = 512)
+        # algorithmic FLOP per launch = 2*M*N*K (M = batch*126 frames, N = 2048, K = 512; tdt-600m: M = batch*376, N = 4096, K = 1024)
         dom = kernels.get("ffn_fc1_silu")
         roof = None
         if dom and dom["launches"]:
@@ -190,11 +199,12 @@ def main():
                     "all_gemms": {"tflops": round(g_fl / max(g_ms, 1e-9), 2), "gflop": round(g_fl, 1), "ms": round(g_ms, 3)}}
         enc_ms = float(ms[1])
         out = {
-            "metric": "RTFx (audio-sec/wall-sec), mel+encoder+TDT decode, tdt-ctc-110m 10s@b64",
+            "metric": f"RTFx (audio-sec/wall-sec), mel+encoder+TDT decode, {args.config} {int(CLIP_SECONDS)}s@b{args.batch}",
             "value": round(value, 1), "unit": "x real-time", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"tdt-ctc-110m, batch={args.batch}x10s clips per GPU, {args.decoder.upper()} greedy decode, fp32 (BASELINE configs[1])",
+            "config": {"workload": f"{args.config}, batch={args.batch}x{int(CLIP_SECONDS)}s clips per GPU, {args.decoder.upper()} greedy decode, fp32 "
+                                   f"(BASELINE configs[{2 if big else 1}]{' shapes; BASELINE names bf16, this run is fp32' if big else ''})",
                        "clips_per_step_per_gpu": args.batch, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{n_gpus} (utterance shards, no data-path collective)"},
             "encoder_ms_per_clip": round(enc_ms / args.batch, 4),
             "stage_ms": {"mel": round(float(ms[0]), 3), "encoder": round(enc_ms, 3), "decode": round(float(ms[2]), 3), "total": round(float(ms[3]), 3)},

@@ -22,6 +22,7 @@
 namespace pk {
 
 typedef float gp_f32x16 __attribute__((ext_vector_type(16)));
+
 #ifdef GP_CLOCKPROBE
 __device__ long long gp_clk[4];     // micro-benchmark builds only: shader / wall clock deltas of block 0
 __device__ long long *gp_trace;     // micro-benchmark builds only: [n_blocks][8] wall-clock stamps of wave 0 + hw id
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
                         smem[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + lr) * CP + wn * WN + j * 32 + lc] = acc[i][j][r];
         }
         __syncthreads();
+        GP_STAMP(5);
         constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT;           // float4 chunks per output row / per thread
         static_assert((BM * C4) % NT == 0, "output tile must split evenly over the threads");
 #pragma unroll
