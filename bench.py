@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--decoder", default="tdt", choices=["tdt", "ctc"])
     ap.add_argument("--config", default="tdt-ctc-110m", choices=["tdt-ctc-110m", "tdt-600m"],
                     help="tdt-ctc-110m = BASELINE configs[1] (the headline metric); tdt-600m = configs[2] shapes (32 x 30 s), run in fp32")
+    ap.add_argument("--bf16", action="store_true", help="pk_config.gemm_bf16: encoder products on bf16 operands / fp32 accumulation "
+                    "(the precision BASELINE configs[2] names); the headline metric stays fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
     args = ap.parse_args()
@@ -125,6 +127,10 @@ def main():
         torch.cuda.synchronize()
 
     cfg = pk.make_tdt_600m_config() if big else pk.make_110m_config()
+    if args.bf16:
+        import dataclasses
+        cfg = dataclasses.replace(cfg, gemm_bf16=True)
+        args.no_cpu_baseline = True
     W = None
     if local_rank == 0:
         wpath, W = weights_file(cfg)
@@ -202,9 +208,9 @@ def main():
             "metric": f"RTFx (audio-sec/wall-sec), mel+encoder+TDT decode, {args.config} {int(CLIP_SECONDS)}s@b{args.batch}",
             "value": round(value, 1), "unit": "x real-time", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}, batch={args.batch}x{int(CLIP_SECONDS)}s clips per GPU, {args.decoder.upper()} greedy decode, fp32 "
-                                   f"(BASELINE configs[{2 if big else 1}]{' shapes; BASELINE names bf16, this run is fp32' if big else ''})",
+            "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}, batch={args.batch}x{int(CLIP_SECONDS)}s clips per GPU, {args.decoder.upper()} greedy decode, {'bf16 GEMM operands / fp32 accumulate' if args.bf16 else 'fp32'} "
+                                   f"(BASELINE configs[{2 if big else 1}]{' shapes; BASELINE names bf16, this run is fp32' if (big and not args.bf16) else ''})",
                        "clips_per_step_per_gpu": args.batch, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{n_gpus} (utterance shards, no data-path collective)"},
             "encoder_ms_per_clip": round(enc_ms / args.batch, 4),
             "stage_ms": {"mel": round(float(ms[0]), 3), "encoder": round(enc_ms, 3), "decode": round(float(ms[2]), 3), "total": round(float(ms[3]), 3)},

@@ -67,6 +67,10 @@ typedef struct pk_config {
                                       axiom's stft is not available).  0 (default) = left-aligned, zero-padded on the right: what the
                                       reference author's own check of the C++ features does (scripts/compare_features.py:33-37; pinned by
                                       tests/golden/ref_compare_features_seed7.npz).  1 = centred like torch.stft / NeMo. */
+    int32_t gemm_bf16;             /* 0: every product is an fp32 fma chain (bit-identical to the CPU oracle).  1: the encoder-side Linear /
+                                      1x1-conv products (and the CTC / enc_proj heads) take bf16 operands with fp32 accumulation on
+                                      v_mfma_f32_32x32x16_bf16 -- the precision BASELINE configs[2] names for tdt-600m; the decode loop,
+                                      attention scores, norms and depthwise convs stay fp32.  Needs every such K % 64 == 0. */
     char joint_prefix[32];         /* "tdt_joint_." (tdt_ctc.cpp:5-9) or "joint_." (tdt.cpp:28-32) */
 } pk_config;
 
@@ -192,6 +196,9 @@ pk_status pk_diag_math(int fn, const float *in, float *out, int64_t n);
  * 3 residual: out = resid + alpha*(acc+bias), 4 glu (N even: out[M][N/2] = a * sigmoid(b)). */
 pk_status pk_diag_gemm(int M, int N, int K, const float *A, const float *W, const float *bias, int epi,
                        const float *resid, float alpha, float *out);
+/* The bf16-operand / fp32-accumulate GEMM of pk_config.gemm_bf16 (W is given in fp32 and rounded here like at upload); K % 64 == 0. */
+pk_status pk_diag_gemm_bf16(int M, int N, int K, const float *A, const float *W, const float *bias, int epi,
+                            const float *resid, float alpha, float *out);
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y);
 /* sum64 of each row of x[rows][n] (the canonical wavefront reduction). */
 pk_status pk_diag_sum64(const float *x, int rows, int n, float *out);

@@ -40,7 +40,7 @@ class OrcConfig(C.Structure):
                 ("pred_hidden", C.c_int), ("lstm_layers", C.c_int), ("joint_hidden", C.c_int),
                 ("n_durations", C.c_int), ("durations", C.c_int * 8), ("blank_id", C.c_int),
                 ("max_symbols", C.c_int), ("ln_eps", C.c_float), ("bn_eps", C.c_float),
-                ("joint_pred_bias", C.c_int), ("joint_prefix", C.c_char * 32)]
+                ("joint_pred_bias", C.c_int), ("gemm_bf16", C.c_int), ("joint_prefix", C.c_char * 32)]
 
 
 def lib():
@@ -163,7 +163,7 @@ def subsampled_len(n):
 class Model:
     """Oracle model: reference tensor names -> numpy arrays (kept alive here)."""
 
-    def __init__(self, cfg, weights: dict, joint_pred_bias=False, ln_eps=1e-5, bn_eps=1e-5):
+    def __init__(self, cfg, weights: dict, joint_pred_bias=False, ln_eps=1e-5, bn_eps=1e-5, gemm_bf16=None):
         self.cfg = cfg
         oc = OrcConfig()
         oc.mel_bins, oc.sub_channels, oc.d_model = cfg.mel_bins, cfg.subsampling_channels, cfg.hidden_size
@@ -174,6 +174,7 @@ class Model:
             oc.durations[i] = d
         oc.blank_id, oc.max_symbols = cfg.blank_id, cfg.max_symbols_per_step
         oc.ln_eps, oc.bn_eps, oc.joint_pred_bias = ln_eps, bn_eps, int(joint_pred_bias)
+        oc.gemm_bf16 = int(getattr(cfg, "gemm_bf16", False) if gemm_bf16 is None else gemm_bf16)
         oc.joint_prefix = cfg.joint_prefix.encode()
         self._h = lib().orc_model_new(C.byref(oc))
         self._keep = {}

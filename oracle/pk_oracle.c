@@ -253,6 +253,7 @@ typedef struct {
     int ndim;
     int64_t shape[4];
     float *wt; /* lazily built [K][N] transpose of a [N][K(,1)] matrix */
+    float *wt16; /* the same with every element rounded to bf16 (gemm_bf16 mode) */
 } orc_tensor;
 
 struct orc_model {
@@ -268,7 +269,7 @@ orc_model *orc_model_new(const orc_config *cfg) {
 }
 void orc_model_free(orc_model *m) {
     if (!m) return;
-    for (int i = 0; i < m->nt; ++i) free(m->t[i].wt);
+    for (int i = 0; i < m->nt; ++i) { free(m->t[i].wt); free(m->t[i].wt16); }
     free(m->t);
     free(m);
 }
@@ -317,13 +318,44 @@ static const float *wt_of(orc_tensor *t) {
     return w;
 }
 
-/* y[M][N] = x[M][K] * W^T + b   (Linear / 1x1 conv), W tensor [N][K(,1,1)] */
-static int linear_t(orc_tensor *W, const orc_tensor *b, int M, const float *x, int64_t ldx, float *y,
+/* fp32 -> nearest bf16 (ties to even), returned as the fp32 value it represents: the operand rounding of the product's
+ * gemm_bf16 mode (weights rounded once at upload, activations by v_cvt_pk_bf16_f32 while they are staged). */
+static inline float bf16_round(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return f;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static const float *wt16_of(orc_tensor *t) {
+    if (t->wt16) return t->wt16;
+    const float *w = wt_of(t);
+    const int64_t n = numel(t);
+    float *q = (float *)xmalloc((size_t)n * sizeof(float));
+    for (int64_t i = 0; i < n; ++i) q[i] = bf16_round(w[i]);
+    t->wt16 = q;
+    return q;
+}
+
+/* y[M][N] = x[M][K] * W^T + b   (Linear / 1x1 conv), W tensor [N][K(,1,1)].
+ * bf16 != 0 (orc_config.gemm_bf16): both operands are rounded to bf16 first; products of two bf16 are exact in fp32 and
+ * the accumulation stays a k-ordered fp32 chain (the device's MFMA sums in another order: compare with a tolerance). */
+static int linear_t(int bf16, orc_tensor *W, const orc_tensor *b, int M, const float *x, int64_t ldx, float *y,
                     int64_t ldy, int parallel) {
     if (!W) return -1;
     const int N = (int)W->shape[0];
     const int K = (int)(numel(W) / N);
-    gemm_core(M, N, K, x, ldx, wt_of(W), N, y, ldy, parallel);
+    if (bf16) {
+        float *xq = (float *)xmalloc((size_t)M * K * sizeof(float));
+        for (int64_t m = 0; m < M; ++m)
+            for (int k = 0; k < K; ++k) xq[m * K + k] = bf16_round(x[m * ldx + k]);
+        gemm_core(M, N, K, xq, K, wt16_of(W), N, y, ldy, parallel);
+        free(xq);
+    } else {
+        gemm_core(M, N, K, x, ldx, wt_of(W), N, y, ldy, parallel);
+    }
     if (b) {
         const float *bb = b->data;
         for (int64_t m = 0; m < M; ++m)
@@ -577,11 +609,11 @@ int orc_subsampling(orc_model *m, const float *feats, int B, int Tm, float *out,
         if (tap_conv1) memcpy(tap_conv1 + (int64_t)b * H1 * W1 * C, a1, (size_t)H1 * W1 * C * sizeof(float));
         /* dw1 -> conv2 (1x1) -> ReLU  src/encoder.cpp:226-228 */
         dw3x3s2(a1, H1, W1, C, d1w->data, d1b->data, a2, H2, W2);
-        linear_t(c2w, c2b, H2 * W2, a2, C, a3, C, 0);
+        linear_t(m->cfg.gemm_bf16, c2w, c2b, H2 * W2, a2, C, a3, C, 0);
         for (int64_t i = 0; i < (int64_t)H2 * W2 * C; ++i) a3[i] = a3[i] > 0.0f ? a3[i] : 0.0f;
         /* dw2 -> conv3 (1x1) -> ReLU  src/encoder.cpp:230-232 */
         dw3x3s2(a3, H2, W2, C, d2w->data, d2b->data, a4, H3, W3);
-        linear_t(c3w, c3b, H3 * W3, a4, C, a5, C, 0);
+        linear_t(m->cfg.gemm_bf16, c3w, c3b, H3 * W3, a4, C, a5, C, 0);
         for (int64_t i = 0; i < (int64_t)H3 * W3 * C; ++i) a5[i] = a5[i] > 0.0f ? a5[i] : 0.0f;
         if (tap_stage3) memcpy(tap_stage3 + (int64_t)b * H3 * W3 * C, a5, (size_t)H3 * W3 * C * sizeof(float));
         /* permute(0,2,1,3)+reshape: feature index = c*W3 + f  src/encoder.cpp:235-238 */
@@ -589,7 +621,7 @@ int orc_subsampling(orc_model *m, const float *feats, int B, int Tm, float *out,
             for (int f = 0; f < W3; ++f)
                 for (int ch = 0; ch < C; ++ch) flat[(int64_t)t * C * W3 + ch * W3 + f] = a5[((int64_t)t * W3 + f) * C + ch];
         /* proj_  src/encoder.cpp:240 */
-        linear_t(pw, pb, H3, flat, (int64_t)C * W3, out + (int64_t)b * H3 * d, d, 0);
+        linear_t(m->cfg.gemm_bf16, pw, pb, H3, flat, (int64_t)C * W3, out + (int64_t)b * H3 * d, d, 0);
         free(a1); free(a2); free(a3); free(a4); free(a5); free(flat);
     }
     return H3;
@@ -630,9 +662,9 @@ static int feed_forward(orc_model *m, int layer, const char *which, float *x, in
     float *h = (float *)xmalloc((size_t)rows * ffn * sizeof(float));
     float *y = (float *)xmalloc((size_t)rows * d * sizeof(float));
     layer_norm(x, rows, d, ng->data, nb->data, c->ln_eps, n);
-    linear_t(w1, b1, (int)rows, n, d, h, ffn, 0);
+    linear_t(m->cfg.gemm_bf16, w1, b1, (int)rows, n, d, h, ffn, 0);
     for (int64_t i = 0; i < rows * ffn; ++i) h[i] = orc_siluf(h[i]);
-    linear_t(w2, b2, (int)rows, h, ffn, y, d, 0);
+    linear_t(m->cfg.gemm_bf16, w2, b2, (int)rows, h, ffn, y, d, 0);
     for (int64_t i = 0; i < rows * d; ++i) x[i] = x[i] + y[i] * 0.5f;
     free(n); free(h); free(y);
     return 0;
@@ -646,7 +678,7 @@ static float *pos_proj_heads(orc_model *m, int layer, int T, const float *pos_em
     orc_tensor *wp = getf(m, "encoder_.layers_.%d.attn_.pos_proj_.weight", layer);
     if (!wp) return NULL;
     float *pp = (float *)xmalloc((size_t)P * d * sizeof(float));
-    linear_t(wp, NULL, P, pos_emb, d, pp, d, 0);
+    linear_t(m->cfg.gemm_bf16, wp, NULL, P, pos_emb, d, pp, d, 0);
     float *PT = (float *)xmalloc((size_t)H * hd * P * sizeof(float));
     for (int h = 0; h < H; ++h)
         for (int kk = 0; kk < hd; ++kk)
@@ -675,9 +707,9 @@ static int attention(orc_model *m, int layer, float *x, int T, const float *PT) 
     float *ctx = (float *)xmalloc((size_t)rows * d * sizeof(float));
     float *y = (float *)xmalloc((size_t)rows * d * sizeof(float));
     layer_norm(x, rows, d, ng->data, nb->data, c->ln_eps, n);      /* :182 */
-    linear_t(wq, bq, (int)rows, n, d, q, d, 0);                    /* :120-122 */
-    linear_t(wk, bk, (int)rows, n, d, k, d, 0);
-    linear_t(wv, bv, (int)rows, n, d, v, d, 0);
+    linear_t(m->cfg.gemm_bf16, wq, bq, (int)rows, n, d, q, d, 0);                    /* :120-122 */
+    linear_t(m->cfg.gemm_bf16, wk, bk, (int)rows, n, d, k, d, 0);
+    linear_t(m->cfg.gemm_bf16, wv, bv, (int)rows, n, d, v, d, 0);
     const float scale = 1.0f / sqrtf((float)hd);                   /* :126 */
     float *qu = (float *)xmalloc((size_t)T * hd * sizeof(float));
     float *qv = (float *)xmalloc((size_t)T * hd * sizeof(float));
@@ -715,7 +747,7 @@ static int attention(orc_model *m, int layer, float *x, int T, const float *PT) 
             for (int kk = 0; kk < hd; ++kk) ctx[(int64_t)i * d + h * hd + kk] = oh[i * hd + kk];
     }
     free(qu); free(qv); free(KT); free(Vh); free(cs); free(ps); free(pr); free(oh);
-    linear_t(wo, bo, (int)rows, ctx, d, y, d, 0);                  /* :177 */
+    linear_t(m->cfg.gemm_bf16, wo, bo, (int)rows, ctx, d, y, d, 0);                  /* :177 */
     for (int64_t i = 0; i < rows * d; ++i) x[i] = x[i] + y[i];     /* :185 */
     free(n); free(q); free(k); free(v); free(ctx); free(y);
     return 0;
@@ -739,7 +771,7 @@ static int conv_module(orc_model *m, int layer, float *x, int T) {
     float *dw = (float *)xmalloc((size_t)rows * d * sizeof(float));
     float *y = (float *)xmalloc((size_t)rows * d * sizeof(float));
     layer_norm(x, rows, d, ng->data, nb->data, c->ln_eps, n);                 /* :60 */
-    linear_t(w1, b1, (int)rows, n, d, g2, 2 * d, 0);                          /* :63 */
+    linear_t(m->cfg.gemm_bf16, w1, b1, (int)rows, n, d, g2, 2 * d, 0);                          /* :63 */
     for (int64_t r = 0; r < rows; ++r)                                        /* glu(dim=channels) :64 */
         for (int i = 0; i < d; ++i) g[r * d + i] = g2[r * 2 * d + i] * orc_sigmoidf(g2[r * 2 * d + d + i]);
     for (int t = 0; t < T; ++t)
@@ -756,7 +788,7 @@ static int conv_module(orc_model *m, int layer, float *x, int T) {
             v = fmaf((v - bnm->data[ch]) * rstd, bng->data[ch], bnb->data[ch]);
             dw[(int64_t)t * d + ch] = orc_siluf(v);                           /* :68 */
         }
-    linear_t(w2, b2, (int)rows, dw, d, y, d, 0);                              /* :70 */
+    linear_t(m->cfg.gemm_bf16, w2, b2, (int)rows, dw, d, y, d, 0);                              /* :70 */
     for (int64_t i = 0; i < rows * d; ++i) x[i] = x[i] + y[i];                /* :74 */
     free(n); free(g2); free(g); free(dw); free(y);
     return 0;
@@ -849,7 +881,7 @@ int orc_ctc_logprobs(orc_model *m, const float *enc, int B, int T, float *logp) 
     const int V = (int)w->shape[0], d = m->cfg.d_model;
     const int64_t rows = (int64_t)B * T;
     wt_of(w);
-    linear_t(w, b, (int)rows, enc, d, logp, V, 1);
+    linear_t(m->cfg.gemm_bf16, w, b, (int)rows, enc, d, logp, V, 1);
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < rows; ++r) {
         float tmp[8200];
@@ -984,7 +1016,7 @@ int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens,
     const int Hp = w.Hp, J = w.J, V = w.V, D = w.D, d = c->d_model;
     /* enc_proj hoisted: one GEMM for all frames (bit-identical to the per-frame call) */
     float *ep = (float *)xmalloc((size_t)B * T * J * sizeof(float));
-    linear_t(w.we, w.be, B * T, enc, d, ep, J, 1);
+    linear_t(m->cfg.gemm_bf16, w.we, w.be, B * T, enc, d, ep, J, 1);
     int overflow = 0;
 #pragma omp parallel for schedule(dynamic, 1) reduction(| : overflow)
     for (int b = 0; b < B; ++b) {
@@ -1052,7 +1084,7 @@ int orc_rnnt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens
     if (dec_weights_get(m, &w, 1)) return -1;
     const int Hp = w.Hp, J = w.J, V = w.V, d = c->d_model;
     float *ep = (float *)xmalloc((size_t)B * T * J * sizeof(float));
-    linear_t(w.we, w.be, B * T, enc, d, ep, J, 1);
+    linear_t(m->cfg.gemm_bf16, w.we, w.be, B * T, enc, d, ep, J, 1);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; ++b) {
         float *h = (float *)calloc((size_t)w.L * Hp * 2, sizeof(float)), *cc = h + w.L * Hp;

@@ -36,6 +36,8 @@ typedef struct {
     float ln_eps;     /* A3: 1e-5 */
     float bn_eps;     /* A3: 1e-5 */
     int joint_pred_bias; /* A5: 0 = drop (literal reference), 1 = add (NeMo) */
+    int gemm_bf16;    /* 0: fp32 fma chains.  1: the operands of every Linear / 1x1-conv product of the encoder, the CTC head and
+                         enc_proj are rounded to bf16 first (pk_config.gemm_bf16 of the product); accumulation stays fp32 */
     char joint_prefix[32]; /* "tdt_joint_." (110M hybrid) or "joint_." (TDT/RNNT 600M) */
 } orc_config;
 

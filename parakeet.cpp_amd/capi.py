@@ -26,7 +26,7 @@ class PkConfig(C.Structure):
                 ("conv_kernel_size", C.c_int32), ("vocab_size", C.c_int32), ("pred_hidden", C.c_int32),
                 ("num_lstm_layers", C.c_int32), ("joint_hidden", C.c_int32), ("num_durations", C.c_int32),
                 ("durations", C.c_int32 * 8), ("ctc_vocab_size", C.c_int32), ("blank_id", C.c_int32),
-                ("max_symbols_per_step", C.c_int32), ("joint_pred_bias", C.c_int32), ("rnnt_head", C.c_int32), ("stft_window_centered", C.c_int32),
+                ("max_symbols_per_step", C.c_int32), ("joint_pred_bias", C.c_int32), ("rnnt_head", C.c_int32), ("stft_window_centered", C.c_int32), ("gemm_bf16", C.c_int32),
                 ("joint_prefix", C.c_char * 32)]
 
 
@@ -59,6 +59,7 @@ def to_pk_config(cfg: ModelConfig) -> PkConfig:
     c.ctc_vocab_size, c.blank_id, c.max_symbols_per_step = cfg.ctc_vocab_size, cfg.blank_id, cfg.max_symbols_per_step
     c.joint_pred_bias, c.rnnt_head = 0, int(cfg.head == "rnnt")
     c.stft_window_centered = int(getattr(cfg, "stft_window_centered", False))
+    c.gemm_bf16 = int(getattr(cfg, "gemm_bf16", False))
     c.joint_prefix = cfg.joint_prefix.encode()
     return c
 
@@ -84,6 +85,7 @@ def lib():
     L.pk_encoder_num_frames.argtypes = [C.c_int]
     L.pk_diag_math.argtypes = [C.c_int, f32p, f32p, C.c_int64]
     L.pk_diag_gemm.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, C.c_int, f32p, C.c_float, f32p]
+    L.pk_diag_gemm_bf16.argtypes = L.pk_diag_gemm.argtypes
     L.pk_diag_layernorm.argtypes = [f32p, C.c_int64, C.c_int, f32p, f32p, C.c_float, f32p]
     L.pk_diag_sum64.argtypes = [f32p, C.c_int, C.c_int, f32p]
     for name, at in _LATE_SIGNATURES.items():
@@ -154,15 +156,15 @@ def diag_math(fn, x):
     return y
 
 
-def diag_gemm(A, W, bias=None, epi="none", resid=None, alpha=1.0):
+def diag_gemm(A, W, bias=None, epi="none", resid=None, alpha=1.0, bf16=False):
     A, W = _c(A), _c(W)
     M, K = A.shape
     N = W.shape[0] // 2 if epi == "glu" else W.shape[0]
     b = _c(bias) if bias is not None else None
     r = _c(resid) if resid is not None else None
     out = np.empty((M, N), np.float32)
-    check(lib().pk_diag_gemm(M, N, K, _f(A), _f(W), _f(b) if b is not None else None, EPI[epi],
-                             _f(r) if r is not None else None, alpha, _f(out)))
+    fn = lib().pk_diag_gemm_bf16 if bf16 else lib().pk_diag_gemm
+    check(fn(M, N, K, _f(A), _f(W), _f(b) if b is not None else None, EPI[epi], _f(r) if r is not None else None, alpha, _f(out)))
     return out
 
 

@@ -32,6 +32,8 @@ class ModelConfig:
     # switch A1 (pk_config.stft_window_centered): False = Hann window left-aligned in the FFT frame, as the reference
     # author's own feature check does (scripts/compare_features.py:33-37); True = centred like torch.stft / NeMo
     stft_window_centered: bool = False
+    # pk_config.gemm_bf16: encoder-side products on bf16 operands / fp32 accumulation (BASELINE configs[2] precision)
+    gemm_bf16: bool = False
 
     @property
     def head_dim(self):

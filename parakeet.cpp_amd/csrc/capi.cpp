@@ -674,6 +674,40 @@ pk_status pk_diag_gemm(int M, int N, int K, const float *A, const float *W, cons
     });
 }
 
+pk_status pk_diag_gemm_bf16(int M, int N, int K, const float *A, const float *W, const float *bias, int epi, const float *resid,
+                            float alpha, float *out) {
+    return guard([&] {
+        need(A && W && out && M > 0 && N > 0 && K > 0, "A/W/out/M/N/K");
+        need(K % 64 == 0, "K must be a multiple of 64");
+        need(epi >= 0 && epi <= 4, "epi");
+        need(epi != EPI_RESID || resid, "resid");
+        diag_device();
+        const int wrows = epi == EPI_GLU ? 2 * N : N;
+        std::vector<uint16_t> w16((size_t)wrows * K);
+        for (size_t i = 0; i < w16.size(); ++i) {               // weights: round to nearest even on the host, as at upload
+            uint32_t u;
+            memcpy(&u, &W[i], 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            w16[i] = (uint16_t)(u >> 16);
+        }
+        Scratch s;
+        s.a.reserve((size_t)M * K * 4);
+        s.b.reserve((size_t)wrows * K * 2);
+        s.c.reserve((size_t)wrows * 4);
+        s.d.reserve((size_t)M * N * 4);
+        s.e.reserve((size_t)M * N * 4);
+        PK_HIP(hipMemcpy(s.a.p, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+        PK_HIP(hipMemcpy(s.b.p, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+        if (bias) PK_HIP(hipMemcpy(s.c.p, bias, (size_t)wrows * 4, hipMemcpyHostToDevice));
+        if (resid) PK_HIP(hipMemcpy(s.d.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice));
+        GemmArgs g{s.a.as<float>(), K, s.b.as<float>(), K, bias ? s.c.as<float>() : nullptr, s.e.as<float>(), N,
+                   resid ? s.d.as<float>() : nullptr, N, alpha, M, N, K};
+        launch_gemm_bf16(g, epi, nullptr);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpy(out, s.e.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y) {
     return guard([&] {
         need(x && gamma && beta && y && rows > 0 && d > 0 && d <= 1024, "x/gamma/beta/y/rows/d (d <= 1024)");

@@ -75,6 +75,29 @@ const HostTensor &Model::host_tensor(const std::string &name, int64_t want) {
     return *t;
 }
 
+// fp32 -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does to the activations on the device)
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// Weight of a Linear / 1x1 conv that runs on the MFMA GEMM: fp32 as is, or (pk_config.gemm_bf16) rounded to bf16 once here.
+// The returned pointer is only ever passed to Model::gemm, which knows which of the two it holds.
+const float *Model::upload_gemm_weight(const float *host, size_t n) {
+    if (!cfg.gemm_bf16) return upload(host, n);
+    std::vector<uint16_t> h(n + (n & 1));
+    for (size_t i = 0; i < n; ++i) h[i] = bf16_rne(host[i]);
+    return upload(reinterpret_cast<const float *>(h.data()), (n + 1) / 2);
+}
+const float *Model::upload_gemm_tensor(const std::string &name, std::vector<int64_t> expect) {
+    int64_t want = 1;
+    for (auto e : expect) want *= e;
+    return upload_gemm_weight(host_tensor(name, want).f32(), (size_t)want);
+}
+
 const float *Model::upload_tensor(const std::string &name, std::vector<int64_t> expect) {
     int64_t want = 1;
     for (auto e : expect) want *= e;
@@ -148,21 +171,21 @@ void Model::upload_weights() {
     const std::string sp = "encoder_.subsampling_.";
     sub.c1w = taps_last(sp + "conv1_.weight", C, 9);  sub.c1b = upload_tensor(sp + "conv1_.bias", {C});
     sub.d1w = taps_last(sp + "dw1_.weight", C, 9);    sub.d1b = upload_tensor(sp + "dw1_.bias", {C});
-    sub.c2w = upload_tensor(sp + "conv2_.weight", {C, C}); sub.c2b = upload_tensor(sp + "conv2_.bias", {C});
+    sub.c2w = upload_gemm_tensor(sp + "conv2_.weight", {C, C}); sub.c2b = upload_tensor(sp + "conv2_.bias", {C});
     sub.d2w = taps_last(sp + "dw2_.weight", C, 9);    sub.d2b = upload_tensor(sp + "dw2_.bias", {C});
-    sub.c3w = upload_tensor(sp + "conv3_.weight", {C, C}); sub.c3b = upload_tensor(sp + "conv3_.bias", {C});
-    sub.pw = upload_tensor(sp + "proj_.weight", {d, (int64_t)C * f3}); sub.pb = upload_tensor(sp + "proj_.bias", {d});
+    sub.c3w = upload_gemm_tensor(sp + "conv3_.weight", {C, C}); sub.c3b = upload_tensor(sp + "conv3_.bias", {C});
+    sub.pw = upload_gemm_tensor(sp + "proj_.weight", {d, (int64_t)C * f3}); sub.pb = upload_tensor(sp + "proj_.bias", {d});
 
     layers.resize(cfg.num_layers);
     for (int i = 0; i < cfg.num_layers; ++i) {
         LayerW &L = layers[i];
         const std::string q = "encoder_.layers_." + std::to_string(i) + ".";
         L.ffn1_ng = upload_tensor(q + "ffn1_.norm_.weight", {d}); L.ffn1_nb = upload_tensor(q + "ffn1_.norm_.bias", {d});
-        L.ffn1_w1 = upload_tensor(q + "ffn1_.fc1_.weight", {ffn, d}); L.ffn1_b1 = upload_tensor(q + "ffn1_.fc1_.bias", {ffn});
-        L.ffn1_w2 = upload_tensor(q + "ffn1_.fc2_.weight", {d, ffn}); L.ffn1_b2 = upload_tensor(q + "ffn1_.fc2_.bias", {d});
+        L.ffn1_w1 = upload_gemm_tensor(q + "ffn1_.fc1_.weight", {ffn, d}); L.ffn1_b1 = upload_tensor(q + "ffn1_.fc1_.bias", {ffn});
+        L.ffn1_w2 = upload_gemm_tensor(q + "ffn1_.fc2_.weight", {d, ffn}); L.ffn1_b2 = upload_tensor(q + "ffn1_.fc2_.bias", {d});
         L.ffn2_ng = upload_tensor(q + "ffn2_.norm_.weight", {d}); L.ffn2_nb = upload_tensor(q + "ffn2_.norm_.bias", {d});
-        L.ffn2_w1 = upload_tensor(q + "ffn2_.fc1_.weight", {ffn, d}); L.ffn2_b1 = upload_tensor(q + "ffn2_.fc1_.bias", {ffn});
-        L.ffn2_w2 = upload_tensor(q + "ffn2_.fc2_.weight", {d, ffn}); L.ffn2_b2 = upload_tensor(q + "ffn2_.fc2_.bias", {d});
+        L.ffn2_w1 = upload_gemm_tensor(q + "ffn2_.fc1_.weight", {ffn, d}); L.ffn2_b1 = upload_tensor(q + "ffn2_.fc1_.bias", {ffn});
+        L.ffn2_w2 = upload_gemm_tensor(q + "ffn2_.fc2_.weight", {d, ffn}); L.ffn2_b2 = upload_tensor(q + "ffn2_.fc2_.bias", {d});
         L.att_ng = upload_tensor(q + "attn_.norm_.weight", {d}); L.att_nb = upload_tensor(q + "attn_.norm_.bias", {d});
         {
             std::vector<float> w((size_t)3 * d * d), b((size_t)3 * d);
@@ -173,14 +196,14 @@ void Model::upload_weights() {
                 memcpy(w.data() + (size_t)j * d * d, tw.f32(), (size_t)d * d * 4);
                 memcpy(b.data() + (size_t)j * d, tb.f32(), (size_t)d * 4);
             }
-            L.wqkv = upload(w.data(), w.size());
+            L.wqkv = upload_gemm_weight(w.data(), w.size());
             L.bqkv = upload(b.data(), b.size());
         }
-        L.wo = upload_tensor(q + "attn_.mha_.out_proj.weight", {d, d}); L.bo = upload_tensor(q + "attn_.mha_.out_proj.bias", {d});
-        L.wpos = upload_tensor(q + "attn_.pos_proj_.weight", {d, d});
+        L.wo = upload_gemm_tensor(q + "attn_.mha_.out_proj.weight", {d, d}); L.bo = upload_tensor(q + "attn_.mha_.out_proj.bias", {d});
+        L.wpos = upload_gemm_tensor(q + "attn_.pos_proj_.weight", {d, d});
         L.pos_u = upload_tensor(q + "attn_.pos_bias_u_", {H, hd}); L.pos_v = upload_tensor(q + "attn_.pos_bias_v_", {H, hd});
         L.cv_ng = upload_tensor(q + "conv_.norm_.weight", {d}); L.cv_nb = upload_tensor(q + "conv_.norm_.bias", {d});
-        L.pw1_w = upload_tensor(q + "conv_.pointwise_conv1_.weight", {2 * d, d}); L.pw1_b = upload_tensor(q + "conv_.pointwise_conv1_.bias", {2 * d});
+        L.pw1_w = upload_gemm_tensor(q + "conv_.pointwise_conv1_.weight", {2 * d, d}); L.pw1_b = upload_tensor(q + "conv_.pointwise_conv1_.bias", {2 * d});
         L.dw_w = taps_last(q + "conv_.depthwise_conv_.weight", d, K); L.dw_b = upload_tensor(q + "conv_.depthwise_conv_.bias", {d});
         L.bn_g = upload_tensor(q + "conv_.batch_norm_.weight", {d}); L.bn_b = upload_tensor(q + "conv_.batch_norm_.bias", {d});
         L.bn_mean = upload_tensor(q + "conv_.batch_norm_.running_mean", {d});
@@ -190,7 +213,7 @@ void Model::upload_weights() {
             for (int c = 0; c < d; ++c) r[c] = 1.0f / sqrtf(tv.f32()[c] + 1e-5f);   // BatchNorm1d default eps (switch A3)
             L.bn_rstd = upload(r.data(), r.size());
         }
-        L.pw2_w = upload_tensor(q + "conv_.pointwise_conv2_.weight", {d, d}); L.pw2_b = upload_tensor(q + "conv_.pointwise_conv2_.bias", {d});
+        L.pw2_w = upload_gemm_tensor(q + "conv_.pointwise_conv2_.weight", {d, d}); L.pw2_b = upload_tensor(q + "conv_.pointwise_conv2_.bias", {d});
         L.fin_g = upload_tensor(q + "final_norm_.weight", {d}); L.fin_b = upload_tensor(q + "final_norm_.bias", {d});
     }
 
@@ -214,7 +237,7 @@ void Model::upload_weights() {
         dec_wih_s[l] = l ? upload_sigma(host_tensor(q + "input_proj_.weight", (int64_t)4 * Hp * Hp).f32(), 4 * Hp, Hp) : nullptr;
     }
     const std::string jp = cfg.joint_prefix;
-    dec.we = upload_tensor(jp + "enc_proj_.weight", {J, d}); dec.be = upload_tensor(jp + "enc_proj_.bias", {J});
+    dec.we = upload_gemm_tensor(jp + "enc_proj_.weight", {J, d}); dec.be = upload_tensor(jp + "enc_proj_.bias", {J});
     dec.wp = upload_tensor(jp + "pred_proj_.weight", {J, Hp});
     dec_wp_s = upload_sigma(host_tensor(jp + "pred_proj_.weight", (int64_t)J * Hp).f32(), J, Hp);
     dec.bp = (cfg.joint_pred_bias && st_->find(jp + "pred_proj_.bias")) ? upload_tensor(jp + "pred_proj_.bias", {J}) : nullptr;
@@ -232,12 +255,15 @@ void Model::upload_weights() {
         wld_s = upload_sigma(w.data(), V + D, J);
     }
     if (cfg.ctc_vocab_size > 0) {
-        dec.ctc_w = upload_tensor("ctc_decoder_.proj_.weight", {cfg.ctc_vocab_size, d});
+        dec.ctc_w = upload_gemm_tensor("ctc_decoder_.proj_.weight", {cfg.ctc_vocab_size, d});
         dec.ctc_b = upload_tensor("ctc_decoder_.proj_.bias", {cfg.ctc_vocab_size});
     }
     // g1 = E W_ih0^T + b  ([V][4Hp]) on the MFMA GEMM: the same natural-k chains the per-step projection would run
     float *g1 = dev_alloc((size_t)V * 4 * Hp);
-    gemm("g1_table", dec.embed, Hp, dec.wih[0], Hp, dec.bih[0], g1, 4 * Hp, V, 4 * Hp, Hp, EPI_NONE, nullptr, 0, 1.0f, stream);
+    {   // decode-side table: always the fp32 chain (the per-step products it replaces are fp32)
+        GemmArgs g{dec.embed, Hp, dec.wih[0], Hp, dec.bih[0], g1, 4 * Hp, nullptr, 0, 1.0f, V, 4 * Hp, Hp};
+        run_gemm("g1_table", g, EPI_NONE, stream, /*fp32_weight=*/true);
+    }
     PK_CHECK_LAUNCH();
     PK_HIP(hipStreamSynchronize(stream));
     dec.g1 = g1;
@@ -283,10 +309,20 @@ void Model::klaunch_end(hipStream_t s) {
 }
 #define KL(name, flops, bytes, call) do { klaunch_begin(name, flops, bytes, s); call; klaunch_end(s); } while (0)
 
+// every encoder-side product goes through here: fp32 chains, or bf16 operands when the model was loaded with gemm_bf16
+void Model::run_gemm(const char *name, const GemmArgs &g, int epi, hipStream_t s, bool fp32_weight) {
+    if (cfg.gemm_bf16 && !fp32_weight) {
+        if (g.K % 64) fail(PK_ERR_UNSUPPORTED, "gemm_bf16 needs K %% 64 == 0 (%s has K = %d)", name, g.K);
+        KL(name, gemm_flops(g, epi), 0.0, launch_gemm_bf16(g, epi, s));
+    } else {
+        KL(name, gemm_flops(g, epi), 0.0, launch_gemm(g, epi, s));
+    }
+}
+
 void Model::gemm(const char *name, const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *out, int64_t ldo,
                  int M, int N, int K, int epi, const float *resid, int64_t ldr, float alpha, hipStream_t s) {
     GemmArgs g{A, lda, W, ldw, bias, out, ldo, resid, ldr, alpha, M, N, K};
-    KL(name, gemm_flops(g, epi), 0.0, launch_gemm(g, epi, s));
+    run_gemm(name, g, epi, s);
 }
 
 // ---- workspace ----------------------------------------------------------------------------------------------
@@ -349,7 +385,7 @@ void Model::ensure_pos_tables(int T, hipStream_t s) {
         // written in the sigma column layout the attention kernel loads its MFMA operands in (kernels.hpp: GemmArgs::sigma_cols)
         GemmArgs g{pos_pe.as<float>(), d, layers[l].wpos, d, nullptr, pos_proj.as<float>() + (size_t)l * P * d, d, nullptr, 0, 1.0f, P, d, d};
         g.sigma_cols = d;
-        KL("pos_proj", gemm_flops(g, EPI_NONE), 0.0, launch_gemm(g, EPI_NONE, s));
+        run_gemm("pos_proj", g, EPI_NONE, s);
     }
     pos_T = T;
 }
@@ -370,7 +406,7 @@ void Model::run_subsample(Workspace &w, const float *d_feats, int B, int Tm, flo
     {
         GemmArgs g{w.a4.as<float>(), C, sub.c3w, C, sub.c3b, w.flat.as<float>(), C, nullptr, 0, 1.0f, (int)px3, C, C};
         g.remap_rows = W3; g.remap_gs = (int64_t)C * W3; g.remap_rs = 1; g.remap_cs = W3;
-        KL("sub_pw", gemm_flops(g, EPI_RELU), 0.0, launch_gemm(g, EPI_RELU, s));
+        run_gemm("sub_pw", g, EPI_RELU, s);
     }
     // proj_  :240
     gemm("sub_proj", w.flat.as<float>(), (int64_t)C * W3, sub.pw, (int64_t)C * W3, sub.pb, d_x, d, B * H3, d, C * W3, EPI_NONE, nullptr, 0, 1.0f, s);
@@ -413,7 +449,7 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             // q and k columns in the sigma layout (MFMA operands of the attention kernel), v natural
             GemmArgs g{n, d, L.wqkv, d, L.bqkv, w.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
             g.sigma_cols = 2 * d;
-            KL("attn_qkv", gemm_flops(g, EPI_NONE), 0.0, launch_gemm(g, EPI_NONE, s));
+            run_gemm("attn_qkv", g, EPI_NONE, s);
         }
         {
             const int hd = d / cfg.num_heads;

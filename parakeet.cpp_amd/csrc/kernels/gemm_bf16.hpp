@@ -1,0 +1,237 @@
+// parakeet.cpp_amd/csrc/kernels/gemm_bf16.hpp -- bf16-input / fp32-accumulate MFMA GEMM (gfx950), the precision
+// BASELINE configs[2] (tdt-600m) names.
+//
+// out[M][N] = epi(bf16(A)[M][K] * W16[N][K]^T + bias): the activations stay fp32 in HBM and are rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) while they are staged into LDS; the weights are rounded once at upload and live in HBM as bf16.
+// Products of two bf16 are exact in fp32 and the accumulator is fp32, so the only difference to the fp32 path is the
+// operand rounding plus the summation order inside v_mfma_f32_32x32x16_bf16 (not a sequential chain): results are
+// compared with the oracle's bf16 mode within a stated tolerance, not bit for bit (tests/test_gpu_bf16.py).
+//
+// Structure = gemm_pipe.hpp (register-double-buffered fragments, LDS double buffer, one barrier per K tile, epilogue
+// through LDS with 16-byte stores), with BK = 64: a tile row is 64 bf16 = 128 B (+16 B pad: the same 144-byte pitch, so
+// the conflict-free ds_read_b128 analysis carries over); lane (row, h) reads the 8 consecutive k = 16s + 8h .. +7 of
+// MFMA step s with one ds_read_b128 -- bf16 needs no K permutation.
+#pragma once
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+
+namespace pk {
+
+typedef float bg_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bg_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int WGM, int WGN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, int tiles_n, int n_tiles) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
+    constexpr int BK = 64, PITCH = BK + 8, BUF = (BM + BN) * PITCH, NSUB = BK / 16;     // in bf16 elements
+    constexpr int A_CH = BM * 8 / NT, W_CH = BN * 8 / NT;                                // 8-element chunks per thread per K tile
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile rows must split evenly over the threads");
+    constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
+    static_assert(EPI != EPI_GLU || (TN % 2 == 0), "GLU needs an even number of column tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16 *smem = reinterpret_cast<__bf16 *>(smem_raw);
+    float *smem_f = reinterpret_cast<float *>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nk = g.K / BK;
+    const __bf16 *W16 = reinterpret_cast<const __bf16 *>(g.W);
+
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap (block b runs on XCD b % 8): XCD x gets a contiguous range of tiles
+        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * NOUT;
+
+    const float *a_src[A_CH];
+    const __bf16 *w_src[W_CH];
+    int a_dst[A_CH], w_dst[W_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int c = tid + NT * i, row = c >> 3, c8 = c & 7;
+        int gr = m0 + row;
+        gr = gr < g.M ? gr : g.M - 1;
+        a_src[i] = g.A + (int64_t)gr * g.lda + c8 * 8;
+        a_dst[i] = row * PITCH + c8 * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) {
+        const int c = tid + NT * i, v = c >> 3, c8 = c & 7;
+        int wr;
+        if constexpr (EPI == EPI_GLU) {
+            constexpr int HT = TN / 2;     // tiles [0,HT) = value half, [HT,TN) = gate half of the SAME output columns
+            const int vw = v / WN, rem = v % WN, tn = rem >> 5, cc = rem & 31;
+            int col = n0 + vw * (WN / 2) + (tn % HT) * 32 + cc;
+            col = col < g.N ? col : g.N - 1;
+            wr = (tn / HT) * g.N + col;
+        } else {
+            wr = n0 + v;
+            wr = wr < g.N ? wr : g.N - 1;
+        }
+        w_src[i] = W16 + (int64_t)wr * g.ldw + c8 * 8;
+        w_dst[i] = (BM + v) * PITCH + c8 * 8;
+    }
+
+    float4 ra[A_CH][2];
+    uint4 rw[W_CH];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            ra[i][0] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
+            ra[i][1] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const uint4 *>(w_src[i] + kt * BK);
+    };
+    auto lstore = [&](int buf) {
+        __bf16 *base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            bg_bf16x8 v;
+            v[0] = (__bf16)ra[i][0].x; v[1] = (__bf16)ra[i][0].y; v[2] = (__bf16)ra[i][0].z; v[3] = (__bf16)ra[i][0].w;
+            v[4] = (__bf16)ra[i][1].x; v[5] = (__bf16)ra[i][1].y; v[6] = (__bf16)ra[i][1].z; v[7] = (__bf16)ra[i][1].w;
+            *reinterpret_cast<bg_bf16x8 *>(base + a_dst[i]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) *reinterpret_cast<uint4 *>(base + w_dst[i]) = rw[i];
+    };
+
+    bg_f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int fa_off = (wm * WM + (lane & 31)) * PITCH + 8 * (lane >> 5);
+    const int fb_off = (BM + wn * WN + (lane & 31)) * PITCH + 8 * (lane >> 5);
+    bg_bf16x8 fa[2][TM], fb[2][TN];
+    auto fragload = [&](int buf, int s, int slot) {
+        const __bf16 *base = smem + buf * BUF + 16 * s;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const bg_bf16x8 *>(base + fa_off + i * 32 * PITCH);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const bg_bf16x8 *>(base + fb_off + j * 32 * PITCH);
+    };
+    auto mma = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i], fb[slot][j], acc[i][j], 0, 0, 0);
+    };
+#define BG_SB() __builtin_amdgcn_sched_barrier(0)
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    if (nk > 1) gload(1);
+    fragload(0, 0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+#pragma unroll
+        for (int s = 0; s < NSUB - 1; ++s) {
+            fragload(cur, s + 1, (s + 1) & 1);
+            if (s == NSUB - 2 && more1) lstore(cur ^ 1);
+            BG_SB(); mma(s & 1); BG_SB();
+        }
+        __syncthreads();
+        if (more1) fragload(cur ^ 1, 0, 0);
+        if (more2) gload(kt + 2);
+        BG_SB(); mma((NSUB - 1) & 1); BG_SB();
+        cur ^= 1;
+    }
+#undef BG_SB
+
+    // ---- epilogue: accumulators -> LDS (row-major fp32 C tile) -> 4 consecutive columns per thread ------------------------------
+    constexpr int CP = BN + 4;
+    static_assert((size_t)BM * CP * 4 <= 2 * (size_t)BUF * 2, "C tile must fit in the staging buffers");
+    __syncthreads();
+    {
+        const int lc = lane & 31, lr = 4 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    smem_f[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + lr) * CP + wn * WN + j * 32 + lc] = acc[i][j][r];
+    }
+    __syncthreads();
+    const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);
+    constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT;
+    static_assert((BM * C4) % NT == 0, "output tile must split evenly over the threads");
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int c = tid + NT * q, rl = c / C4, c4 = c % C4;
+        const int row = m0 + rl, col0 = n0 + 4 * c4;
+        if (row >= g.M || col0 >= g.N) continue;
+        float v[4], gt[4] = {0.0f, 0.0f, 0.0f, 0.0f}, rsv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int ncol[4];                                                 // natural output column of each of the 4 results
+        const bool sig = col0 < g.sigma_cols;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int vc;                                                  // virtual column inside the C tile
+            if (sig) {                                               // sigma layout: position 16b + 4a + e holds natural column 16b + 4e + a
+                vc = ((4 * c4) & ~15) + 4 * e + (c4 & 3);
+                ncol[e] = n0 + vc;
+            } else {
+                vc = 4 * c4 + e;
+                ncol[e] = col0 + e;
+                if constexpr (EPI == EPI_GLU) vc = (vc / (WN / 2)) * WN + vc % (WN / 2);
+            }
+            v[e] = smem_f[rl * CP + vc];
+            if constexpr (EPI == EPI_GLU) gt[e] = smem_f[rl * CP + vc + WN / 2];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (ncol[e] >= g.N) continue;
+            float x = v[e];
+            if (g.bias) x = x + g.bias[ncol[e]];
+            if constexpr (EPI == EPI_RELU) {
+                x = x > 0.0f ? x : 0.0f;
+            } else if constexpr (EPI == EPI_SILU) {
+                x = dsiluf(x);
+            } else if constexpr (EPI == EPI_RESID) {
+                rsv[e] = g.resid[(int64_t)row * g.ldr + ncol[e]];
+                x = rsv[e] + x * g.alpha;
+            } else if constexpr (EPI == EPI_GLU) {
+                float t2 = gt[e];
+                if (g.bias) t2 = t2 + g.bias[g.N + ncol[e]];
+                x = x * dsigmoidf(t2);
+            }
+            v[e] = x;
+        }
+        if (wide) {
+            *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = col0 + e;
+                if (col >= g.N) continue;
+                if (g.remap_rows) g.out[(int64_t)(row / g.remap_rows) * g.remap_gs + (int64_t)(row % g.remap_rows) * g.remap_rs + (int64_t)col * g.remap_cs] = v[e];
+                else g.out[(int64_t)row * g.ldo + col] = v[e];
+            }
+        }
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN, int EPI>
+static void launch_gemm_bf16_t(const GemmArgs &a, hipStream_t s) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
+    const int n_tiles = tiles_m * tiles_n;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * (64 + 8) * 2;
+    auto kern = &gemm_bf16_kernel<WGM, WGN, TM, TN, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+}
+
+}  // namespace pk

@@ -39,6 +39,9 @@ struct GemmArgs {
     int sigma_cols = 0;
 };
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
+// same contract with bf16 operands and fp32 accumulation: a.W points to bf16 weights [N][K] (rounded once at upload), A is
+// rounded to bf16 while it is staged; K % 64 == 0.  Not bit-identical to the fp32 chain (kernels/gemm_bf16.hpp).
+void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s);
 double gemm_flops(const GemmArgs &a, int epi);
 
 // ---- conv subsampling (src/encoder.cpp:219-241), channels-last ---------------------------------------

@@ -90,6 +90,7 @@ inline pk_config flatten(const EncoderConfig &e, const PredictionConfig &p, cons
     c.ctc_vocab_size = ctc_vocab; c.blank_id = blank_id; c.max_symbols_per_step = 10;
     c.joint_pred_bias = 0; c.rnnt_head = rnnt_head ? 1 : 0;
     c.stft_window_centered = 0;   // switch A1, see include/parakeet_amd.h
+    c.gemm_bf16 = 0;              // fp32 chains; 1 = bf16 operands / fp32 accumulate (include/parakeet_amd.h)
     std::snprintf(c.joint_prefix, sizeof c.joint_prefix, "%s", joint_prefix);
     return c;
 }
