@@ -2,7 +2,9 @@
 // (reference ConformerConvModule::forward, src/encoder.cpp:66-68): depthwise Conv1d(k, pad (k-1)/2,
 // groups=d) -> BatchNorm1d (inference, running stats) -> SiLU, fused in one pass over [B][T][d].
 // The pointwise convs + GLU on either side are epilogues of the MFMA GEMM.
-// One thread per (frame, channel); channels are the fast axis, so the k taps are k coalesced rows.
+// One thread = 4 adjacent channels x a strip of TT frames: the k input rows slide through registers (each row is loaded once
+// per strip as a float4 instead of k times as scalars), taps / BatchNorm parameters stay in registers for the whole strip.
+// Out-of-range taps multiply a zero row (fma(w, 0, acc) == acc: same bits as the oracle's skip-the-padding chain).
 // BatchNorm is applied as written ((y-mean)*rstd*gamma+beta, rstd precomputed on the host) rather
 // than folded into the taps, so the result is bit-identical to the oracle.
 #include "../pk_devmath.h"
@@ -10,35 +12,64 @@
 
 namespace pk {
 
-template <int KC>
-__global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__restrict__ g, int T, int d,
+template <int KC, int TT>
+__global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__restrict__ g, int T, int d, int n_strips,
                                                              const float *__restrict__ w /*[KC][d]*/, const float *__restrict__ bias,
                                                              const float *__restrict__ bn_mean, const float *__restrict__ bn_rstd,
                                                              const float *__restrict__ bn_g, const float *__restrict__ bn_b,
-                                                             int64_t n, float *__restrict__ out) {
+                                                             int64_t n_items, float *__restrict__ out) {
+    constexpr int HALF = (KC - 1) / 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    const int ch = (int)(idx % d);
-    const int64_t row = idx / d;
-    const int t = (int)(row % T);
-    float acc = 0.0f;
+    if (idx >= n_items) return;
+    const int d4 = d >> 2;
+    const int c4 = (int)(idx % d4);
+    const int strip = (int)((idx / d4) % n_strips);
+    const int b = (int)(idx / ((int64_t)d4 * n_strips));
+    const int t0 = strip * TT;
+    const float4 *gp = reinterpret_cast<const float4 *>(g + (int64_t)b * T * d) + c4;       // row t at gp[t * d4]
+    float4 *op = reinterpret_cast<float4 *>(out + (int64_t)b * T * d) + c4;
+    float4 wt[KC];
 #pragma unroll
-    for (int kk = 0; kk < KC; ++kk) {
-        const int tt = t + kk - (KC - 1) / 2;
-        if (tt < 0 || tt >= T) continue;                       // zero padding
-        acc = __builtin_fmaf(w[kk * d + ch], g[(row + (tt - t)) * d + ch], acc);
+    for (int kk = 0; kk < KC; ++kk) wt[kk] = reinterpret_cast<const float4 *>(w + (int64_t)kk * d)[c4];
+    const float4 bi = reinterpret_cast<const float4 *>(bias)[c4], mu = reinterpret_cast<const float4 *>(bn_mean)[c4];
+    const float4 rs = reinterpret_cast<const float4 *>(bn_rstd)[c4], ga = reinterpret_cast<const float4 *>(bn_g)[c4];
+    const float4 be = reinterpret_cast<const float4 *>(bn_b)[c4];
+    auto row = [&](int t) { return (t >= 0 && t < T) ? gp[(int64_t)t * d4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); };
+    float4 win[KC];                                                     // win[kk] = input row t + kk - HALF
+#pragma unroll
+    for (int kk = 0; kk < KC - 1; ++kk) win[kk + 1] = row(t0 + kk - HALF);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const int t = t0 + tt;
+#pragma unroll
+        for (int kk = 0; kk < KC - 1; ++kk) win[kk] = win[kk + 1];
+        win[KC - 1] = row(t + HALF);
+        if (t >= T) break;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            acc.x = __builtin_fmaf(wt[kk].x, win[kk].x, acc.x);
+            acc.y = __builtin_fmaf(wt[kk].y, win[kk].y, acc.y);
+            acc.z = __builtin_fmaf(wt[kk].z, win[kk].z, acc.z);
+            acc.w = __builtin_fmaf(wt[kk].w, win[kk].w, acc.w);
+        }
+        float4 v;
+        v.x = dsiluf(__builtin_fmaf(((acc.x + bi.x) - mu.x) * rs.x, ga.x, be.x));
+        v.y = dsiluf(__builtin_fmaf(((acc.y + bi.y) - mu.y) * rs.y, ga.y, be.y));
+        v.z = dsiluf(__builtin_fmaf(((acc.z + bi.z) - mu.z) * rs.z, ga.z, be.z));
+        v.w = dsiluf(__builtin_fmaf(((acc.w + bi.w) - mu.w) * rs.w, ga.w, be.w));
+        op[(int64_t)t * d4] = v;
     }
-    float v = acc + bias[ch];
-    v = __builtin_fmaf((v - bn_mean[ch]) * bn_rstd[ch], bn_g[ch], bn_b[ch]);
-    out[idx] = dsiluf(v);
 }
 
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
                            const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s) {
-    const int64_t n = (int64_t)B * T * d;
-    const dim3 grid((unsigned)((n + 255) / 256));
-    if (kc == 9) hipLaunchKernelGGL(dwconv_bn_silu_kernel<9>, grid, dim3(256), 0, s, g, T, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n, out);
-    else if (kc == 31) hipLaunchKernelGGL(dwconv_bn_silu_kernel<31>, grid, dim3(256), 0, s, g, T, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n, out);
+    constexpr int TT = 8;
+    const int n_strips = (T + TT - 1) / TT;
+    const int64_t n_items = (int64_t)B * n_strips * (d / 4);          // d % 4 == 0 (hidden sizes are multiples of 32)
+    const dim3 grid((unsigned)((n_items + 255) / 256));
+    if (kc == 9) hipLaunchKernelGGL((dwconv_bn_silu_kernel<9, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out);
+    else if (kc == 31) hipLaunchKernelGGL((dwconv_bn_silu_kernel<31, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out);
 }
 
 }  // namespace pk
