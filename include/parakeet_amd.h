@@ -179,6 +179,27 @@ void pk_results_free(pk_result *results, int n_clips);
 pk_status pk_read_wav(const char *path, float **pcm, int64_t *n_samples, int *sample_rate);
 void pk_free(void *p);
 
+/* ---- plain Transformer encoder: TransformerEncoder::forward / TransformerBlock::forward (src/transformer.cpp:15-88) ------------ */
+/* include/parakeet/transformer.hpp:12-21 (TransformerConfig), dropout omitted (inference). */
+typedef struct pk_transformer_config {
+    int32_t hidden_size;       /* 192 */
+    int32_t num_layers;        /* 18 */
+    int32_t num_heads;         /* 8 (heads narrower than 32 are zero-padded internally: same bits) */
+    int32_t ffn_intermediate;  /* 768 */
+    int32_t pre_ln;            /* 1 = pre-norm (x + f(LN(x))), 0 = post-norm (LN(x + f(x))) */
+    int32_t has_final_norm;
+    float layer_norm_eps;      /* 1e-5 */
+} pk_transformer_config;
+typedef struct pk_transformer pk_transformer;
+/* Tensors <prefix>layers_.<i>.{norm1_,norm2_,mha_.{q,k,v,out}_proj,fc1_,fc2_}.{weight,bias} [+ <prefix>final_norm_.*] of a
+ * safetensors file (the module tree of transformer.cpp:12,69-73), uploaded to `device`. */
+pk_status pk_transformer_load(const char *safetensors_path, const char *prefix, const pk_transformer_config *cfg, int device,
+                              pk_transformer **out);
+/* x[B][T][hidden] -> y[B][T][hidden] (host buffers).  The optional attention mask of the reference (transformer.cpp:40-42) is
+ * not supported: no caller on the ASR path passes one. */
+pk_status pk_transformer_forward(pk_transformer *t, const float *x, int B, int T, float *y);
+void pk_transformer_free(pk_transformer *t);
+
 /* ---- host-side text (src/vocab.cpp:29-117, src/timestamp.cpp:24-111) -------------------------------------- */
 int pk_vocab_size(const pk_model *m);
 /* Tokenizer::decode -> returns needed length; writes at most cap-1 bytes + NUL. */

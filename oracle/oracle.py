@@ -229,6 +229,16 @@ class Model:
         self._chk(lib().orc_encoder(self._h, _f(feats), B, Tm, _f(out), _f(taps) if layer_taps else None))
         return (out, taps) if layer_taps else out
 
+    def transformer_encoder(self, x, prefix, n_layers, n_heads, pre_ln=True, has_final_norm=False, ln_eps=1e-5):
+        """TransformerEncoder::forward (src/transformer.cpp:78-88) on x[B][T][d]; weights under `prefix` in this model."""
+        x = _c(x).copy()
+        B, T, d = x.shape
+        lib().orc_transformer_encoder.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                  C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]
+        self._chk(lib().orc_transformer_encoder(self._h, prefix.encode(), n_layers, n_heads, int(pre_ln), int(has_final_norm), ln_eps,
+                                                _f(x), B, T, d))
+        return x
+
     def ctc_logprobs(self, enc):
         enc = _c(enc)
         B, T, _ = enc.shape

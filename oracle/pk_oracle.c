@@ -753,6 +753,95 @@ static int attention(orc_model *m, int layer, float *x, int T, const float *PT) 
     return 0;
 }
 
+/* a16: TransformerBlock::forward / TransformerEncoder::forward -- src/transformer.cpp:15-62, :78-88 (the encoder
+ * Sortformer stacks on top of the FastConformer; include/parakeet/transformer.hpp:12-21 for the config).
+ * Standard multi-head attention: no position term, scale applied to Q K^T (:38), softmax, A V, out_proj; ReLU FFN;
+ * pre-LN (x + f(LN(x))) or post-LN (LN(x + f(x))) by `pre_ln`.  Dropout is the identity (inference); the mask branch
+ * (:40-42) is not taken by any caller that passes no mask and is not restated.
+ * Tensor names: <prefix>layers_.<i>.{norm1_,norm2_}.{weight,bias}, mha_.{q,k,v,out}_proj.{weight,bias},
+ * fc1_/fc2_.{weight,bias}, <prefix>final_norm_.{weight,bias} (AX_REGISTER_MODULES order, transformer.cpp:12,69-73).
+ * x[B][T][d] in place. */
+int orc_transformer_encoder(orc_model *m, const char *prefix, int n_layers, int n_heads, int pre_ln, int has_final_norm,
+                            float ln_eps, float *x, int B, int T, int d) {
+    const int H = n_heads, hd = d / H;
+    if (hd * H != d) return orc_fail("transformer: hidden %d not divisible by %d heads", d, H);
+    const float scale = 1.0f / sqrtf((float)hd);                                   /* transformer.cpp:27 */
+    for (int l = 0; l < n_layers; ++l) {
+        orc_tensor *n1g = getf(m, "%slayers_.%d.norm1_.weight", prefix, l), *n1b = getf(m, "%slayers_.%d.norm1_.bias", prefix, l);
+        orc_tensor *n2g = getf(m, "%slayers_.%d.norm2_.weight", prefix, l), *n2b = getf(m, "%slayers_.%d.norm2_.bias", prefix, l);
+        orc_tensor *wq = getf(m, "%slayers_.%d.mha_.q_proj.weight", prefix, l), *bq = getf(m, "%slayers_.%d.mha_.q_proj.bias", prefix, l);
+        orc_tensor *wk = getf(m, "%slayers_.%d.mha_.k_proj.weight", prefix, l), *bk = getf(m, "%slayers_.%d.mha_.k_proj.bias", prefix, l);
+        orc_tensor *wv = getf(m, "%slayers_.%d.mha_.v_proj.weight", prefix, l), *bv = getf(m, "%slayers_.%d.mha_.v_proj.bias", prefix, l);
+        orc_tensor *wo = getf(m, "%slayers_.%d.mha_.out_proj.weight", prefix, l), *bo = getf(m, "%slayers_.%d.mha_.out_proj.bias", prefix, l);
+        orc_tensor *w1 = getf(m, "%slayers_.%d.fc1_.weight", prefix, l), *b1 = getf(m, "%slayers_.%d.fc1_.bias", prefix, l);
+        orc_tensor *w2 = getf(m, "%slayers_.%d.fc2_.weight", prefix, l), *b2 = getf(m, "%slayers_.%d.fc2_.bias", prefix, l);
+        if (!n1g || !n1b || !n2g || !n2b || !wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo || !w1 || !b1 || !w2 || !b2) return -1;
+        const int ffn = (int)w1->shape[0];
+        for (int b = 0; b < B; ++b) {
+            float *xb = x + (int64_t)b * T * d;
+            const int64_t rows = T;
+            float *n = (float *)xmalloc((size_t)rows * d * sizeof(float));
+            float *q = (float *)xmalloc((size_t)rows * d * sizeof(float));
+            float *k = (float *)xmalloc((size_t)rows * d * sizeof(float));
+            float *v = (float *)xmalloc((size_t)rows * d * sizeof(float));
+            float *ctx = (float *)xmalloc((size_t)rows * d * sizeof(float));
+            float *y = (float *)xmalloc((size_t)rows * d * sizeof(float));
+            float *hbuf = (float *)xmalloc((size_t)rows * ffn * sizeof(float));
+            const float *in = xb;
+            if (pre_ln) { layer_norm(xb, rows, d, n1g->data, n1b->data, ln_eps, n); in = n; }       /* :18 */
+            linear_t(0, wq, bq, (int)rows, in, d, q, d, 0);                                          /* :20-22 */
+            linear_t(0, wk, bk, (int)rows, in, d, k, d, 0);
+            linear_t(0, wv, bv, (int)rows, in, d, v, d, 0);
+            float *qh = (float *)xmalloc((size_t)T * hd * sizeof(float));
+            float *KT = (float *)xmalloc((size_t)hd * T * sizeof(float));
+            float *Vh = (float *)xmalloc((size_t)T * hd * sizeof(float));
+            float *cs = (float *)xmalloc((size_t)T * T * sizeof(float));
+            float *oh = (float *)xmalloc((size_t)T * hd * sizeof(float));
+            for (int h = 0; h < H; ++h) {
+                for (int i = 0; i < T; ++i)
+                    for (int kk = 0; kk < hd; ++kk) {
+                        qh[i * hd + kk] = q[(int64_t)i * d + h * hd + kk];
+                        KT[(int64_t)kk * T + i] = k[(int64_t)i * d + h * hd + kk];
+                        Vh[i * hd + kk] = v[(int64_t)i * d + h * hd + kk];
+                    }
+                gemm_core(T, T, hd, qh, hd, KT, T, cs, T, 0);                                        /* :38 */
+                for (int i = 0; i < T; ++i) {
+                    float *row = cs + (int64_t)i * T;
+                    float mx = -INFINITY;
+                    for (int j = 0; j < T; ++j) {
+                        row[j] = row[j] * scale;
+                        mx = row[j] > mx ? row[j] : mx;
+                    }
+                    for (int j = 0; j < T; ++j) row[j] = orc_expf(row[j] - mx);                      /* softmax :44 */
+                    const float sum = orc_sum64(row, T, 1);
+                    for (int j = 0; j < T; ++j) row[j] = row[j] / sum;
+                }
+                gemm_core(T, hd, T, cs, T, Vh, hd, oh, hd, 0);                                       /* :45 */
+                for (int i = 0; i < T; ++i)
+                    for (int kk = 0; kk < hd; ++kk) ctx[(int64_t)i * d + h * hd + kk] = oh[i * hd + kk];
+            }
+            free(qh); free(KT); free(Vh); free(cs); free(oh);
+            linear_t(0, wo, bo, (int)rows, ctx, d, y, d, 0);                                         /* :49 */
+            for (int64_t i = 0; i < rows * d; ++i) xb[i] = xb[i] + y[i];                             /* :51 input + out */
+            if (!pre_ln) layer_norm(xb, rows, d, n1g->data, n1b->data, ln_eps, xb);
+            in = xb;
+            if (pre_ln) { layer_norm(xb, rows, d, n2g->data, n2b->data, ln_eps, n); in = n; }       /* :54 */
+            linear_t(0, w1, b1, (int)rows, in, d, hbuf, ffn, 0);                                     /* :55 */
+            for (int64_t i = 0; i < rows * ffn; ++i) hbuf[i] = hbuf[i] > 0.0f ? hbuf[i] : 0.0f;      /* relu :56 */
+            linear_t(0, w2, b2, (int)rows, hbuf, ffn, y, d, 0);                                      /* :58 */
+            for (int64_t i = 0; i < rows * d; ++i) xb[i] = xb[i] + y[i];                             /* :61 */
+            if (!pre_ln) layer_norm(xb, rows, d, n2g->data, n2b->data, ln_eps, xb);
+            free(n); free(q); free(k); free(v); free(ctx); free(y); free(hbuf);
+        }
+    }
+    if (has_final_norm) {                                                                            /* :84-86 */
+        orc_tensor *fg = getf(m, "%sfinal_norm_.weight", prefix), *fb = getf(m, "%sfinal_norm_.bias", prefix);
+        if (!fg || !fb) return -1;
+        layer_norm(x, (int64_t)B * T, d, fg->data, fb->data, ln_eps, x);
+    }
+    return 0;
+}
+
 /* a7: ConformerConvModule::forward -- src/encoder.cpp:59-75.  One utterance: x[T][d]. */
 static int conv_module(orc_model *m, int layer, float *x, int T) {
     const orc_config *c = &m->cfg;

@@ -59,6 +59,9 @@ int orc_model_add(orc_model *m, const char *name, const float *data, int ndim, c
 
 void orc_mel_filterbank(int n_freqs, int n_mels, float sample_rate, float f_min, float f_max, float *fb);
 int orc_mel_num_frames(int64_t n_samples, int hop);
+/* src/transformer.cpp:15-88 on x[B][T][d] in place; tensors named <prefix>layers_.<i>. ... in the model */
+int orc_transformer_encoder(orc_model *m, const char *prefix, int n_layers, int n_heads, int pre_ln, int has_final_norm,
+                            float ln_eps, float *x, int B, int T, int d);
 int orc_mel(const orc_audio_config *ac, const float *pcm, int64_t n, float *out, float *logmel_tap);
 void orc_pos_emb(int seq_len, int d_model, float *pe);
 int orc_subsampled_len(int n_mel_frames);

@@ -30,6 +30,11 @@ class PkConfig(C.Structure):
                 ("joint_prefix", C.c_char * 32)]
 
 
+class PkTransformerConfig(C.Structure):
+    _fields_ = [("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_intermediate", C.c_int32),
+                ("pre_ln", C.c_int32), ("has_final_norm", C.c_int32), ("layer_norm_eps", C.c_float)]
+
+
 class PkKernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("launches", C.c_int32), ("total_ms", C.c_float), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -166,6 +171,33 @@ def diag_gemm(A, W, bias=None, epi="none", resid=None, alpha=1.0, bf16=False):
     fn = lib().pk_diag_gemm_bf16 if bf16 else lib().pk_diag_gemm
     check(fn(M, N, K, _f(A), _f(W), _f(b) if b is not None else None, EPI[epi], _f(r) if r is not None else None, alpha, _f(out)))
     return out
+
+
+class Transformer:
+    """pk_transformer_*: TransformerEncoder of the reference (src/transformer.cpp) on the GPU."""
+
+    def __init__(self, weights_path, prefix, hidden_size, num_layers, num_heads, ffn_intermediate, pre_ln=True, has_final_norm=False,
+                 layer_norm_eps=1e-5, device=0):
+        L = lib()
+        L.pk_transformer_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PkTransformerConfig), C.c_int, C.POINTER(C.c_void_p)]
+        L.pk_transformer_forward.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, f32p]
+        L.pk_transformer_free.argtypes = [C.c_void_p]
+        L.pk_transformer_free.restype = None
+        c = PkTransformerConfig(hidden_size, num_layers, num_heads, ffn_intermediate, int(pre_ln), int(has_final_norm), layer_norm_eps)
+        self._h = C.c_void_p()
+        check(L.pk_transformer_load(weights_path.encode(), prefix.encode(), C.byref(c), device, C.byref(self._h)))
+
+    def forward(self, x):
+        x = _c(x)
+        B, T, _ = x.shape
+        y = np.empty_like(x)
+        check(lib().pk_transformer_forward(self._h, _f(x), B, T, _f(y)))
+        return y
+
+    def close(self):
+        if self._h:
+            lib().pk_transformer_free(self._h)
+            self._h = None
 
 
 def diag_layernorm(x, g, b, eps=1e-5):

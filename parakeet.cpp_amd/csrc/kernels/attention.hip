@@ -107,12 +107,17 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 1) void relpos_attention_kernel
     {
         float4 q[NQ4];
         load_tile(qb, ldq, i0 + rt * 16, T, q);
-        const float *ur = bias_u + h * HD + kq, *vr = bias_v + h * HD + kq;
+        if (pos) {
+            const float *ur = bias_u + h * HD + kq, *vr = bias_v + h * HD + kq;
 #pragma unroll
-        for (int f = 0; f < NQ4; ++f) {
-            // element e <-> k = 16f + 4e + kq ; (q+u), (q+v) as the reference forms them (src/encoder.cpp:141-142)
-            qu[f] = make_float4(q[f].x + ur[16 * f], q[f].y + ur[16 * f + 4], q[f].z + ur[16 * f + 8], q[f].w + ur[16 * f + 12]);
-            qv[f] = make_float4(q[f].x + vr[16 * f], q[f].y + vr[16 * f + 4], q[f].z + vr[16 * f + 8], q[f].w + vr[16 * f + 12]);
+            for (int f = 0; f < NQ4; ++f) {
+                // element e <-> k = 16f + 4e + kq ; (q+u), (q+v) as the reference forms them (src/encoder.cpp:141-142)
+                qu[f] = make_float4(q[f].x + ur[16 * f], q[f].y + ur[16 * f + 4], q[f].z + ur[16 * f + 8], q[f].w + ur[16 * f + 12]);
+                qv[f] = make_float4(q[f].x + vr[16 * f], q[f].y + vr[16 * f + 4], q[f].z + vr[16 * f + 8], q[f].w + vr[16 * f + 12]);
+            }
+        } else {                                                    // plain multi-head attention (src/transformer.cpp:38): no position term
+#pragma unroll
+            for (int f = 0; f < NQ4; ++f) qu[f] = qv[f] = q[f];
         }
     }
     const int il_base = rt * 16 + 4 * kq;                           // C layout: column = lane & 15, row = 4*(lane>>4) + r
@@ -127,8 +132,9 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 1) void relpos_attention_kernel
             for (int r = 0; r < 4; ++r) {
                 const int il = il_base + r;
                 const int j0 = t * 16 + l15, j1 = j0 + 32;
-                if (j0 < Tpad4) S[sidx(il, j0)] = j0 < T ? a0[r] : 0.0f;         // columns T..Tpad4-1: zero pad of the AV chain
-                if (t + 2 < nct && j1 < Tpad4) S[sidx(il, j1)] = j1 < T ? a1[r] : 0.0f;
+                // columns T..Tpad4-1: zero pad of the AV chain; without a position term the scale is applied here
+                if (j0 < Tpad4) S[sidx(il, j0)] = j0 < T ? (pos ? a0[r] : a0[r] * scale) : 0.0f;
+                if (t + 2 < nct && j1 < Tpad4) S[sidx(il, j1)] = j1 < T ? (pos ? a1[r] : a1[r] * scale) : 0.0f;
             }
         };
         if (cp < nct) { load_tile(kb, ldq, cp * 16, T, bA0); load_tile(kb, ldq, (cp + 2) * 16, T, bA1); }
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 1) void relpos_attention_kernel
     //      p = j - i + T - 1 in [wpmin, wpmax] (T+15 rows): its own tile grid starts at wpmin, tiles t = cp, cp+2, ... ------
     const int w_lo = i0 + rt * 16, w_hi = (w_lo + 15) < (T - 1) ? (w_lo + 15) : (T - 1);
     const int wpmin = T - 1 - w_hi, wpmax = 2 * T - 2 - w_lo;
-    const int npt = w_lo < T ? (wpmax - wpmin) / 16 + 1 : 0;
+    const int npt = (pos && w_lo < T) ? (wpmax - wpmin) / 16 + 1 : 0;
     if (cp < npt) { load_tile(pb, d, wpmin + cp * 16, P, bA0); load_tile(pb, d, wpmin + (cp + 2) * 16, P, bA1); }   // in flight across the barrier
     __syncthreads();                                              // content scores complete; V chunk 0 visible
     {
@@ -258,8 +264,8 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 1) void relpos_attention_kernel
 
 template <int HD, int VCH>
 static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u, const float *bias_v,
-                       float *ctx, hipStream_t s) {
-    const float scale = 1.0f / sqrtf((float)HD);                  // src/encoder.cpp:126
+                       float *ctx, float scale_arg, hipStream_t s) {
+    const float scale = scale_arg > 0.0f ? scale_arg : 1.0f / sqrtf((float)HD);   // src/encoder.cpp:126
     int pits = (T + 3) / 4;                                        // floats per score-plane row, padded so that pits/4 is odd
     pits = (pits + 3) & ~3;
     if (((pits / 4) & 1) == 0) pits += 4;
@@ -275,13 +281,13 @@ static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const
 }
 
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
-                             const float *bias_v, float *ctx, hipStream_t s) {
+                             const float *bias_v, float *ctx, hipStream_t s, float scale) {
     const int hd = d / n_heads;
     // V chunk rows: 64 keeps the footprint at ~39 KB for 10 s clips (4 workgroups per CU at hd = 64)
-    if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, s);
-    else if (hd == 128) launch_att<128, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, s);
-    else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, s);
-    else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, s);
+    if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
+    else if (hd == 128) launch_att<128, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
+    else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
+    else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
 }
 
 }  // namespace pk

@@ -50,8 +50,10 @@ void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const
 void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, float *out, hipStream_t s);
 
 // ---- conformer pieces ---------------------------------------------------------------------------------
+// qkv[B*T][3d]: q and k thirds in the sigma column layout.  pos == nullptr: plain multi-head attention (src/transformer.cpp:38),
+// no position term, bias_u / bias_v ignored.  scale <= 0: 1/sqrt(d / n_heads).
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
-                             const float *bias_v, float *ctx, hipStream_t s);
+                             const float *bias_v, float *ctx, hipStream_t s, float scale = 0.0f);
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
                            const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s);
 
