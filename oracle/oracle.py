@@ -287,3 +287,60 @@ def set_threads(n):
 
 def max_threads():
     return lib().orc_get_max_threads()
+
+
+class Stream:
+    """One streaming session of the oracle: StreamingAudioPreprocessor + EncoderCache + StreamingDecodeState
+    (reference src/audio.cpp:171-259, src/streaming_encoder.cpp:430-472, src/eou.cpp:17-98)."""
+
+    def __init__(self, model: Model, att_context_left=70, att_context_right=0):
+        L = lib()
+        L.orc_stream_new.restype = C.c_void_p
+        L.orc_stream_new.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_stream_free.argtypes = [C.c_void_p]
+        f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.orc_stream_mel.argtypes = [C.c_void_p, f32p, C.c_int, f32p]
+        L.orc_stream_encode.argtypes = [C.c_void_p, f32p, C.c_int, f32p, C.c_int]
+        L.orc_stream_decode.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, f32p]
+        self.model = model
+        self._h = L.orc_stream_new(model._h, att_context_left, att_context_right)
+
+    def mel(self, pcm):
+        pcm = _c(pcm)
+        out = np.zeros((pcm.size // 160 + 8, self.model.cfg.mel_bins), np.float32)
+        n = lib().orc_stream_mel(self._h, _f(pcm), pcm.size, _f(out))
+        return out[:n]
+
+    def encode(self, mel):
+        mel = _c(mel)
+        cap = mel.shape[0] // 8 + 2
+        out = np.zeros((cap, self.model.cfg.hidden_size), np.float32)
+        n = lib().orc_stream_encode(self._h, _f(mel), mel.shape[0], _f(out), cap)
+        if n < 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return out[:n]
+
+    def decode(self, enc):
+        enc = _c(enc)
+        c = enc.shape[0]
+        mt = max(1, c * self.model.cfg.max_symbols_per_step)
+        ids = np.zeros(mt, np.int32); st = np.zeros(mt, np.int32); en = np.zeros(mt, np.int32); cf = np.zeros(mt, np.float32)
+        n = lib().orc_stream_decode(self._h, _f(enc), c, mt, _i(ids), _i(st), _i(en), _f(cf))
+        if n < 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return dict(ids=ids[:n], start=st[:n], end=en[:n], conf=cf[:n])
+
+    def push(self, pcm):
+        """transcribe_chunk (src/nemotron.cpp:24-52): PCM chunk -> new tokens of this chunk (dict) or None."""
+        m = self.mel(pcm)
+        if m.shape[0] == 0:
+            return None
+        e = self.encode(m)
+        if e.shape[0] == 0:
+            return None
+        return self.decode(e)
+
+    def close(self):
+        if self._h:
+            lib().orc_stream_free(self._h)
+            self._h = None

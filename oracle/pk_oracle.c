@@ -1096,9 +1096,11 @@ static void joint_hidden(const dec_weights *w, const float *ep, const float *pre
  * 10 duration-0 emissions repeat on one frame); exceeding it returns 1 and sets
  * lens[b] = -1 for that utterance.
  */
-int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, int32_t *ids,
-                   int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps,
-                   float *first_label_logp /* optional [B][V]: label log-probs of the first joint call */) {
+static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, int32_t *ids,
+                         int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps,
+                         float *first_label_logp /* optional [B][V]: label log-probs of the first joint call */,
+                         float *state_hc /* optional [B][2][L][Hp] carried LSTM state (in/out); NULL: zeros */,
+                         int32_t *state_token /* optional [B] carried last token (in/out); NULL: blank */, int clamp_end) {
     const orc_config *c = &m->cfg;
     dec_weights w;
     if (dec_weights_get(m, &w, 0)) return -1;
@@ -1110,13 +1112,14 @@ int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens,
 #pragma omp parallel for schedule(dynamic, 1) reduction(| : overflow)
     for (int b = 0; b < B; ++b) {
         float *h = (float *)calloc((size_t)w.L * Hp * 2, sizeof(float)), *cc = h + w.L * Hp;
+        if (state_hc) memcpy(h, state_hc + (int64_t)b * 2 * w.L * Hp, (size_t)w.L * Hp * 2 * sizeof(float));
         float *sh = (float *)xmalloc((size_t)w.L * Hp * 2 * sizeof(float));
         float *pred = (float *)xmalloc((size_t)Hp * sizeof(float));
         float *z = (float *)xmalloc((size_t)J * sizeof(float));
         float *scratch = (float *)xmalloc((size_t)(8 * Hp + J) * sizeof(float));
         float *lab = (float *)xmalloc((size_t)V * 2 * sizeof(float)), *lab_lp = lab + V;
         float dur[16], dur_lp[16];
-        int token = c->blank_id, t = 0, n = 0, nsteps = 0, bad = 0;
+        int token = state_token ? state_token[b] : c->blank_id, t = 0, n = 0, nsteps = 0, bad = 0;
         while (t < T && !bad) {
             const float *ept = ep + ((int64_t)b * T + t) * J;
             for (int sym = 0; sym < c->max_symbols; ++sym) {
@@ -1145,7 +1148,7 @@ int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens,
                     if (start) start[(int64_t)b * max_tokens + n] = t;
                     if (end) {
                         int e = t + (skip > 1 ? skip : 1) - 1;                /* :184-187 */
-                        if (e >= T) e = T - 1;
+                        if (clamp_end && e >= T) e = T - 1;                   /* the streaming decoder does not clamp (eou.cpp:78-79) */
                         end[(int64_t)b * max_tokens + n] = e;
                     }
                     if (conf) conf[(int64_t)b * max_tokens + n] = orc_expf(lab_lp[k]); /* :169 */
@@ -1159,10 +1162,16 @@ int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens,
         lens[b] = bad ? -1 : (n < max_tokens ? n : max_tokens);
         if (steps) steps[b] = nsteps;
         overflow |= bad;
+        if (state_hc) memcpy(state_hc + (int64_t)b * 2 * w.L * Hp, h, (size_t)w.L * Hp * 2 * sizeof(float));
+        if (state_token) state_token[b] = token;
         free(h); free(sh); free(pred); free(z); free(scratch); free(lab);
     }
     free(ep);
     return overflow;
+}
+int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, int32_t *ids,
+                   int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps, float *first_label_logp) {
+    return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, first_label_logp, NULL, NULL, 1);
 }
 
 /* rnnt_greedy_decode(+_with_timestamps): src/rnnt.cpp:56-111, :115-177 ; RNNTJoint::forward :37-44 */
@@ -1208,4 +1217,263 @@ int orc_rnnt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens
     }
     free(ep);
     return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Streaming path (BASELINE configs[4]): one stream = the state of                     */
+/* StreamingAudioPreprocessor (src/audio.cpp:171-259), EncoderCache / BlockCache                       */
+/* (include/parakeet/streaming_encoder.hpp:25-41), StreamingDecodeState (include/parakeet/eou.hpp:80-87) */
+/* ------------------------------------------------------------------------- */
+struct orc_stream {
+    orc_model *m;
+    int att_left, att_right, n_mels;
+    /* StreamingAudioPreprocessor */
+    float preemph_last;
+    float *overlap; int n_overlap;
+    /* CausalConvSubsampling::forward_cached: leftover mel frames (< 8) */
+    float *mel_cache; int n_mel_cache;
+    /* per layer: key / value cache [n_kv][d] (n_kv <= att_left), conv cache [Kc-1][d] (has_conv: first chunk zero-pads) */
+    float **kc, **vc; int *n_kv; float **cc; int *has_conv;
+    /* StreamingDecodeState */
+    float *hc; int32_t token; int frame_offset; int dec_init;
+};
+
+orc_stream *orc_stream_new(orc_model *m, int att_left, int att_right) {
+    const orc_config *c = &m->cfg;
+    orc_stream *s = (orc_stream *)calloc(1, sizeof(*s));
+    s->m = m; s->att_left = att_left; s->att_right = att_right; s->n_mels = c->mel_bins;
+    s->overlap = (float *)xmalloc(sizeof(float));
+    s->mel_cache = (float *)xmalloc((size_t)8 * c->mel_bins * sizeof(float));
+    const int L = c->n_layers;
+    s->kc = (float **)calloc((size_t)L, sizeof(float *)); s->vc = (float **)calloc((size_t)L, sizeof(float *));
+    s->cc = (float **)calloc((size_t)L, sizeof(float *));
+    s->n_kv = (int *)calloc((size_t)L, sizeof(int)); s->has_conv = (int *)calloc((size_t)L, sizeof(int));
+    for (int l = 0; l < L; ++l) {
+        s->kc[l] = (float *)xmalloc((size_t)(att_left > 0 ? att_left : 1) * c->d_model * sizeof(float));
+        s->vc[l] = (float *)xmalloc((size_t)(att_left > 0 ? att_left : 1) * c->d_model * sizeof(float));
+        s->cc[l] = (float *)xmalloc((size_t)c->conv_k * c->d_model * sizeof(float));
+    }
+    s->hc = (float *)calloc((size_t)2 * c->lstm_layers * c->pred_hidden, sizeof(float));
+    s->token = c->blank_id;
+    return s;
+}
+void orc_stream_free(orc_stream *s) {
+    if (!s) return;
+    for (int l = 0; l < s->m->cfg.n_layers; ++l) { free(s->kc[l]); free(s->vc[l]); free(s->cc[l]); }
+    free(s->kc); free(s->vc); free(s->cc); free(s->n_kv); free(s->has_conv);
+    free(s->overlap); free(s->mel_cache); free(s->hc); free(s);
+}
+
+/* StreamingAudioPreprocessor::process_chunk -- src/audio.cpp:195-259.  pcm[n] -> out[n_frames][n_mels] (log-mel, NOT
+ * normalised); returns n_frames (0: everything was buffered).  out must hold (n_overlap + n) / 160 + 1 frames.
+ * center=false: a frame is win_length (400) samples -- the reference's own frame count, (total - 400) / 160 + 1 (:222-223),
+ * only makes sense that way -- Hann-windowed and zero-padded on the right to the 512-point FFT (the left-aligned placement
+ * of switch A1; the centred alternative does not exist for this path).  Quirk kept: the next chunk's first frame starts
+ * AFTER the last window (consumed = (n_frames-1)*160 + 400, :230-231), not one hop after the last frame start. */
+int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out) {
+    const int n_fft = 512, win = 400, hop = 160, n_freqs = 257, n_mels = s->n_mels;
+    const int total = s->n_overlap + n;
+    float *buf = (float *)xmalloc((size_t)(total > 0 ? total : 1) * sizeof(float));
+    memcpy(buf, s->overlap, (size_t)s->n_overlap * sizeof(float));
+    for (int i = 0; i < n; ++i) {                                              /* 1. preemphasis with carried sample :204-210 */
+        const float cur = pcm[i];
+        const float t = 0.97f * s->preemph_last;
+        buf[s->n_overlap + i] = cur - t;
+        s->preemph_last = cur;
+    }
+    int n_frames = total < win ? 0 : (total - win) / hop + 1;
+    if (n_frames <= 0) {                                                       /* :216-228 buffer everything */
+        free(s->overlap); s->overlap = buf; s->n_overlap = total;
+        return 0;
+    }
+    const int consumed = (n_frames - 1) * hop + win;
+    float *w = (float *)xmalloc((size_t)win * sizeof(float));
+    for (int k = 0; k < win; ++k) w[k] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)k / (double)(win - 1)));
+    float *twr = (float *)xmalloc((size_t)n_fft / 2 * sizeof(float)), *twi = (float *)xmalloc((size_t)n_fft / 2 * sizeof(float));
+    fft_twiddles(n_fft, twr, twi);
+    float *fb = (float *)xmalloc((size_t)n_freqs * n_mels * sizeof(float));
+    orc_mel_filterbank(n_freqs, n_mels, 16000.0f, 0.0f, 8000.0f, fb);
+    float re[512], im[512], pw[257];
+    for (int t = 0; t < n_frames; ++t) {
+        for (int k = 0; k < n_fft; ++k) {
+            re[k] = k < win ? buf[t * hop + k] * w[k] : 0.0f;
+            im[k] = 0.0f;
+        }
+        fft_radix2(n_fft, 9, re, im, twr, twi);
+        for (int f = 0; f < n_freqs; ++f) {
+            const float q = fmaf(re[f], re[f], im[f] * im[f]);
+            const float mag = sqrtf(q);                                        /* abs() then square :243-244 */
+            pw[f] = mag * mag;
+        }
+        for (int mm = 0; mm < n_mels; ++mm) {
+            float acc = 0.0f;
+            for (int f = 0; f < n_freqs; ++f) acc = fmaf(fb[f * n_mels + mm], pw[f], acc);
+            out[(int64_t)t * n_mels + mm] = orc_logf(acc + 5.96046448e-8f);    /* :251-252 ; no normalisation */
+        }
+    }
+    const int rest = total - consumed;
+    float *ov = (float *)xmalloc((size_t)(rest > 0 ? rest : 1) * sizeof(float));
+    memcpy(ov, buf + consumed, (size_t)rest * sizeof(float));
+    free(s->overlap); s->overlap = ov; s->n_overlap = rest;
+    free(buf); free(w); free(twr); free(twi); free(fb);
+    return n_frames;
+}
+
+/* StreamingConformerAttention::forward_cached -- src/streaming_encoder.cpp:162-272.  x[c][d] in place.
+ * Quirks kept literally: the position scores are NOT rel-shifted here -- the rightmost kv_len columns of (q+v) P^T are
+ * added to the content scores (:215-224); the K/V cache is trimmed to att_left rows AFTER this chunk was appended, yet the
+ * scores use the untrimmed kv (:186-203); masked entries are REPLACED by -1e9 (:226-247). */
+static int stream_attention(orc_stream *s, int layer, float *x, int c, const float *PT /*[H][hd][P]*/, int P) {
+    orc_model *m = s->m;
+    const orc_config *cf = &m->cfg;
+    const int d = cf->d_model, H = cf->n_heads, hd = d / H;
+    orc_tensor *ng = getf(m, "encoder_.layers_.%d.attn_.norm_.weight", layer), *nb = getf(m, "encoder_.layers_.%d.attn_.norm_.bias", layer);
+    orc_tensor *wq = getf(m, "encoder_.layers_.%d.attn_.mha_.q_proj.weight", layer), *bq = getf(m, "encoder_.layers_.%d.attn_.mha_.q_proj.bias", layer);
+    orc_tensor *wk = getf(m, "encoder_.layers_.%d.attn_.mha_.k_proj.weight", layer), *bk = getf(m, "encoder_.layers_.%d.attn_.mha_.k_proj.bias", layer);
+    orc_tensor *wv = getf(m, "encoder_.layers_.%d.attn_.mha_.v_proj.weight", layer), *bv = getf(m, "encoder_.layers_.%d.attn_.mha_.v_proj.bias", layer);
+    orc_tensor *wo = getf(m, "encoder_.layers_.%d.attn_.mha_.out_proj.weight", layer), *bo = getf(m, "encoder_.layers_.%d.attn_.mha_.out_proj.bias", layer);
+    orc_tensor *pu = getf(m, "encoder_.layers_.%d.attn_.pos_bias_u_", layer), *pv = getf(m, "encoder_.layers_.%d.attn_.pos_bias_v_", layer);
+    if (!ng || !nb || !wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo || !pu || !pv) return -1;
+    const int nc = s->n_kv[layer], kv = nc + c;
+    float *n = (float *)xmalloc((size_t)c * d * sizeof(float)), *q = (float *)xmalloc((size_t)c * d * sizeof(float));
+    float *k = (float *)xmalloc((size_t)kv * d * sizeof(float)), *v = (float *)xmalloc((size_t)kv * d * sizeof(float));
+    float *ctx = (float *)xmalloc((size_t)c * d * sizeof(float)), *y = (float *)xmalloc((size_t)c * d * sizeof(float));
+    layer_norm(x, c, d, ng->data, nb->data, cf->ln_eps, n);                          /* :165 */
+    linear_t(0, wq, bq, c, n, d, q, d, 0);                                           /* :168-170 */
+    memcpy(k, s->kc[layer], (size_t)nc * d * sizeof(float));                         /* prepend the cache :186-189 */
+    memcpy(v, s->vc[layer], (size_t)nc * d * sizeof(float));
+    linear_t(0, wk, bk, c, n, d, k + (int64_t)nc * d, d, 0);
+    linear_t(0, wv, bv, c, n, d, v + (int64_t)nc * d, d, 0);
+    {   /* cache <- last att_left rows of kv :193-209 */
+        const int keep = kv > s->att_left ? s->att_left : kv, from = kv - keep;
+        memmove(s->kc[layer], k + (int64_t)from * d, (size_t)keep * d * sizeof(float));
+        memmove(s->vc[layer], v + (int64_t)from * d, (size_t)keep * d * sizeof(float));
+        s->n_kv[layer] = keep;
+    }
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int off = P > kv ? P - kv : 0;                                             /* rightmost kv columns :217-224 */
+    float *row = (float *)xmalloc((size_t)kv * sizeof(float));
+    for (int h = 0; h < H; ++h)
+        for (int i = 0; i < c; ++i) {
+            const int abs_pos = kv - c + i;
+            float mx = -INFINITY;
+            for (int j = 0; j < kv; ++j) {
+                float cs = 0.0f, ps = 0.0f;
+                for (int e = 0; e < hd; ++e) {
+                    const float qq = q[(int64_t)i * d + h * hd + e];
+                    cs = fmaf(qq + pu->data[h * hd + e], k[(int64_t)j * d + h * hd + e], cs);     /* :212 */
+                    ps = fmaf(qq + pv->data[h * hd + e], PT[((int64_t)h * hd + e) * P + off + j], ps);   /* :214-224 */
+                }
+                float sc = (cs + ps) * scale;                                                       /* :226 */
+                const int dist = abs_pos - j;
+                if ((s->att_left >= 0 || s->att_right >= 0) && (dist > s->att_left || -dist > s->att_right)) sc = -1e9f;   /* :231-247 */
+                row[j] = sc;
+                mx = sc > mx ? sc : mx;
+            }
+            for (int j = 0; j < kv; ++j) row[j] = orc_expf(row[j] - mx);
+            const float sum = orc_sum64(row, kv, 1);
+            for (int j = 0; j < kv; ++j) row[j] = row[j] / sum;
+            for (int e = 0; e < hd; ++e) {
+                float acc = 0.0f;
+                for (int j = 0; j < kv; ++j) acc = fmaf(row[j], v[(int64_t)j * d + h * hd + e], acc);   /* :250 */
+                ctx[(int64_t)i * d + h * hd + e] = acc;
+            }
+        }
+    free(row);
+    linear_t(0, wo, bo, c, ctx, d, y, d, 0);                                         /* :255 */
+    for (int64_t i = 0; i < (int64_t)c * d; ++i) x[i] = x[i] + y[i];
+    free(n); free(q); free(k); free(v); free(ctx); free(y);
+    return 0;
+}
+
+/* CausalConformerConvModule::forward_cached -- src/streaming_encoder.cpp:41-78.  x[c][d] in place. */
+static int stream_conv(orc_stream *s, int layer, float *x, int c) {
+    orc_model *m = s->m;
+    const orc_config *cf = &m->cfg;
+    const int d = cf->d_model, Kc = cf->conv_k, cl = Kc - 1;
+    orc_tensor *ng = getf(m, "encoder_.layers_.%d.conv_.norm_.weight", layer), *nb = getf(m, "encoder_.layers_.%d.conv_.norm_.bias", layer);
+    orc_tensor *w1 = getf(m, "encoder_.layers_.%d.conv_.pointwise_conv1_.weight", layer), *b1 = getf(m, "encoder_.layers_.%d.conv_.pointwise_conv1_.bias", layer);
+    orc_tensor *wd = getf(m, "encoder_.layers_.%d.conv_.depthwise_conv_.weight", layer), *bd = getf(m, "encoder_.layers_.%d.conv_.depthwise_conv_.bias", layer);
+    orc_tensor *bng = getf(m, "encoder_.layers_.%d.conv_.batch_norm_.weight", layer), *bnb = getf(m, "encoder_.layers_.%d.conv_.batch_norm_.bias", layer);
+    orc_tensor *bnm = getf(m, "encoder_.layers_.%d.conv_.batch_norm_.running_mean", layer), *bnv = getf(m, "encoder_.layers_.%d.conv_.batch_norm_.running_var", layer);
+    orc_tensor *w2 = getf(m, "encoder_.layers_.%d.conv_.pointwise_conv2_.weight", layer), *b2 = getf(m, "encoder_.layers_.%d.conv_.pointwise_conv2_.bias", layer);
+    if (!ng || !nb || !w1 || !b1 || !wd || !bd || !bng || !bnb || !bnm || !bnv || !w2 || !b2) return -1;
+    float *n = (float *)xmalloc((size_t)c * d * sizeof(float)), *g2 = (float *)xmalloc((size_t)c * 2 * d * sizeof(float));
+    float *cat = (float *)xmalloc((size_t)(cl + c) * d * sizeof(float)), *dw = (float *)xmalloc((size_t)c * d * sizeof(float));
+    float *y = (float *)xmalloc((size_t)c * d * sizeof(float));
+    layer_norm(x, c, d, ng->data, nb->data, cf->ln_eps, n);
+    linear_t(0, w1, b1, c, n, d, g2, 2 * d, 0);
+    if (s->has_conv[layer]) memcpy(cat, s->cc[layer], (size_t)cl * d * sizeof(float));   /* prepend the cache :51-63 */
+    else memset(cat, 0, (size_t)cl * d * sizeof(float));
+    for (int t = 0; t < c; ++t)
+        for (int ch = 0; ch < d; ++ch) cat[(int64_t)(cl + t) * d + ch] = g2[(int64_t)t * 2 * d + ch] * orc_sigmoidf(g2[(int64_t)t * 2 * d + d + ch]);   /* glu :49 */
+    memcpy(s->cc[layer], cat + (int64_t)c * d, (size_t)cl * d * sizeof(float));            /* last Kc-1 frames :66-69 */
+    s->has_conv[layer] = 1;
+    for (int t = 0; t < c; ++t)
+        for (int ch = 0; ch < d; ++ch) {
+            float acc = 0.0f;                                                                /* depthwise, no padding :71 */
+            for (int kk = 0; kk < Kc; ++kk) acc = fmaf(wd->data[ch * Kc + kk], cat[(int64_t)(t + kk) * d + ch], acc);
+            float v = acc + bd->data[ch];
+            const float rstd = 1.0f / sqrtf(bnv->data[ch] + cf->bn_eps);
+            v = fmaf((v - bnm->data[ch]) * rstd, bng->data[ch], bnb->data[ch]);
+            dw[(int64_t)t * d + ch] = orc_siluf(v);
+        }
+    linear_t(0, w2, b2, c, dw, d, y, d, 0);
+    for (int64_t i = 0; i < (int64_t)c * d; ++i) x[i] = x[i] + y[i];
+    free(n); free(g2); free(cat); free(dw); free(y);
+    return 0;
+}
+
+/* StreamingFastConformerEncoder::forward_chunk -- src/streaming_encoder.cpp:430-472 (+ CausalConvSubsampling::forward_cached
+ * :348-385, StreamingConformerBlock::forward_cached :289-301).  mel[n_frames][n_mels] -> enc[c][d]; returns c (0: cached).
+ * xscaling (streaming_encoder.hpp:22, off in every shipped config) is not restated. */
+int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out) {
+    orc_model *m = s->m;
+    const orc_config *cf = &m->cfg;
+    const int F = cf->mel_bins, d = cf->d_model;
+    const int total = s->n_mel_cache + n_frames;
+    float *all = (float *)xmalloc((size_t)(total > 0 ? total : 1) * F * sizeof(float));
+    memcpy(all, s->mel_cache, (size_t)s->n_mel_cache * F * sizeof(float));
+    memcpy(all + (int64_t)s->n_mel_cache * F, mel, (size_t)n_frames * F * sizeof(float));
+    const int consumable = (total / 8) * 8;                                          /* :365 */
+    const int left = total - consumable;
+    memcpy(s->mel_cache, all + (int64_t)consumable * F, (size_t)left * F * sizeof(float));
+    s->n_mel_cache = left;
+    if (consumable == 0) { free(all); return 0; }
+    const int c = orc_subsampled_len(consumable);
+    if (c > max_out) { free(all); return orc_fail("orc_stream_encode: %d frames > max_out %d", c, max_out); }
+    if (orc_subsampling(m, all, 1, consumable, enc, NULL, NULL) < 0) { free(all); return -1; }
+    free(all);
+    const int Tp = s->att_left + c, P = 2 * Tp - 1;                                  /* :452-454 */
+    float *pe = (float *)xmalloc((size_t)P * d * sizeof(float));
+    orc_pos_emb(Tp, d, pe);
+    for (int l = 0; l < cf->n_layers; ++l) {
+        if (prepare_layer(m, l)) { free(pe); return -1; }
+        float *PT = pos_proj_heads(m, l, Tp, pe);
+        if (!PT) { free(pe); return -1; }
+        int r = feed_forward(m, l, "ffn1_", enc, c);
+        if (!r) r = stream_attention(s, l, enc, c, PT, P);
+        if (!r) r = stream_conv(s, l, enc, c);
+        if (!r) r = feed_forward(m, l, "ffn2_", enc, c);
+        free(PT);
+        if (r) { free(pe); return -1; }
+        orc_tensor *fg = getf(m, "encoder_.layers_.%d.final_norm_.weight", l), *fbb = getf(m, "encoder_.layers_.%d.final_norm_.bias", l);
+        if (!fg || !fbb) { free(pe); return -1; }
+        layer_norm(enc, c, d, fg->data, fbb->data, cf->ln_eps, enc);
+    }
+    free(pe);
+    return c;
+}
+
+/* rnnt_streaming_decode_chunk -- src/eou.cpp:17-98: the TDT greedy loop of tdt.cpp on one encoder chunk with the LSTM state
+ * and the last token carried across chunks; frames are reported relative to the stream (frame_offset), end frames are not
+ * clamped to the chunk; a duration that skips past the end of the chunk is simply lost (:31-33,95). */
+int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf) {
+    int32_t len = 0, steps = 0;
+    const int cap = c * (s->m->cfg.max_symbols + 1) + 16;
+    const int r = tdt_greedy_ex(s->m, enc, 1, c, max_tokens, cap, ids, &len, start, end, conf, &steps, NULL, s->hc, &s->token, 0);
+    if (r || len < 0) return orc_fail("orc_stream_decode: decode cap hit");
+    for (int i = 0; i < len; ++i) { if (start) start[i] += s->frame_offset; if (end) end[i] += s->frame_offset; }
+    s->frame_offset += c;
+    return len;
 }

@@ -7,6 +7,14 @@
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
+/* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
+typedef struct orc_stream orc_stream;
+orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);
+void orc_stream_free(orc_stream *s);
+int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out);
+int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out);
+int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
+
 #endif
 
 /* include/parakeet/audio.hpp:7-17 (AudioConfig) + switches A1/A2 */
@@ -77,5 +85,21 @@ int orc_rnnt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens
                     int32_t *start, float *conf);
 #ifdef __cplusplus
 }
+/* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
+typedef struct orc_stream orc_stream;
+orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);
+void orc_stream_free(orc_stream *s);
+int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out);
+int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out);
+int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
+
 #endif
+/* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
+typedef struct orc_stream orc_stream;
+orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);
+void orc_stream_free(orc_stream *s);
+int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out);
+int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out);
+int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
+
 #endif
