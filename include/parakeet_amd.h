@@ -179,6 +179,31 @@ void pk_results_free(pk_result *results, int n_clips);
 pk_status pk_read_wav(const char *path, float **pcm, int64_t *n_samples, int *sample_rate);
 void pk_free(void *p);
 
+/* ---- streaming: NemotronTranscriber / StreamingTranscriber::transcribe_chunk (src/nemotron.cpp:24-52, src/eou.cpp:113-146) -------- */
+/* A pk_stream is n_streams independent streaming sessions advanced in LOCK-STEP on one GPU (BASELINE configs[4]: 16 concurrent
+ * streams per GPU): every push hands EACH stream the same number of samples.  The model is a TDT-joint model loaded with
+ * pk_model_load / pk_model_to_gpu (the streaming encoder uses the offline encoder's tensor names, streaming_encoder.cpp:276-428).
+ * State kept per stream: pre-emphasis carry + overlap samples (StreamingAudioPreprocessor, audio.cpp:171-259), leftover mel
+ * frames, per-layer K/V and conv caches (EncoderCache, streaming_encoder.hpp:25-41), LSTM state + last token + frame offset
+ * (StreamingDecodeState, eou.hpp:80-87).  att_context_left / right: StreamingEncoderConfig (streaming_encoder.hpp:17-23;
+ * Nemotron 70 / latency_frames, EOU 70 / 1).  xscaling and the SiLU subsampling variant of that config are not implemented
+ * (no shipped preset enables them). */
+typedef struct pk_stream pk_stream;
+pk_status pk_stream_create(pk_model *m, int n_streams, int att_context_left, int att_context_right, pk_stream **out);
+void pk_stream_free(pk_stream *s);
+pk_status pk_stream_reset(pk_stream *s);    /* NemotronTranscriber::reset (nemotron.cpp:54-58) */
+/* pcm[n_streams][n_samples] -> the tokens each stream emitted for this chunk: ids/start/end/conf [n_streams][max_tokens]
+ * (start / end: encoder frames since the stream began, eou.cpp:77-79), lens[n_streams] (0 while audio is still being buffered). */
+pk_status pk_stream_push(pk_stream *s, const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start,
+                         int32_t *end, float *conf);
+/* the three stages of a push, on host buffers, for parity tests (each consumes / updates the same carried state):
+ * process_chunk -> out[n_streams][*n_frames][mel_bins] (un-normalised log-mel); forward_chunk -> enc[n_streams][*n_out][hidden];
+ * rnnt_streaming_decode_chunk.  *n_frames / *n_out = 0: everything was buffered. */
+pk_status pk_stream_mel(pk_stream *s, const float *pcm, int n_samples, float *out, int cap_frames, int *n_frames);
+pk_status pk_stream_encode(pk_stream *s, const float *mel, int n_frames, float *enc, int cap_frames, int *n_out);
+pk_status pk_stream_decode(pk_stream *s, const float *enc, int n_frames, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start,
+                           int32_t *end, float *conf);
+
 /* ---- plain Transformer encoder: TransformerEncoder::forward / TransformerBlock::forward (src/transformer.cpp:15-88) ------------ */
 /* include/parakeet/transformer.hpp:12-21 (TransformerConfig), dropout omitted (inference). */
 typedef struct pk_transformer_config {

@@ -173,6 +173,63 @@ def diag_gemm(A, W, bias=None, epi="none", resid=None, alpha=1.0, bf16=False):
     return out
 
 
+class Stream:
+    """pk_stream_*: n lock-step streaming sessions on the GPU (reference NemotronTranscriber::transcribe_chunk)."""
+
+    def __init__(self, model, n_streams, att_context_left=70, att_context_right=0):
+        L = lib()
+        L.pk_stream_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pk_stream_free.argtypes = [C.c_void_p]
+        L.pk_stream_free.restype = None
+        L.pk_stream_reset.argtypes = [C.c_void_p]
+        L.pk_stream_push.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p]
+        L.pk_stream_mel.argtypes = [C.c_void_p, f32p, C.c_int, f32p, C.c_int, C.POINTER(C.c_int)]
+        L.pk_stream_encode.argtypes = [C.c_void_p, f32p, C.c_int, f32p, C.c_int, C.POINTER(C.c_int)]
+        L.pk_stream_decode.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p]
+        self.model, self.S = model, n_streams
+        self._h = C.c_void_p()
+        check(L.pk_stream_create(model._h, n_streams, att_context_left, att_context_right, C.byref(self._h)))
+
+    def _tok(self, fn, x, n, mt):
+        ids = np.zeros((self.S, mt), np.int32); st = np.zeros((self.S, mt), np.int32); en = np.zeros((self.S, mt), np.int32)
+        cf = np.zeros((self.S, mt), np.float32); lens = np.zeros(self.S, np.int32)
+        check(fn(self._h, _f(x), n, mt, _i(ids), _i(lens), _i(st), _i(en), _f(cf)))
+        return dict(ids=ids, lens=lens, start=st, end=en, conf=cf)
+
+    def push(self, pcm, max_tokens=64):
+        pcm = _c(pcm)
+        assert pcm.shape[0] == self.S
+        return self._tok(lib().pk_stream_push, pcm, pcm.shape[1], max_tokens)
+
+    def mel(self, pcm):
+        pcm = _c(pcm)
+        cap = pcm.shape[1] // 160 + 8
+        out = np.zeros((self.S, cap, self.model.cfg.mel_bins), np.float32)
+        n = C.c_int(0)
+        check(lib().pk_stream_mel(self._h, _f(pcm), pcm.shape[1], _f(out), cap, C.byref(n)))
+        return np.ascontiguousarray(out.reshape(-1)[: self.S * n.value * self.model.cfg.mel_bins].reshape(self.S, n.value, -1))
+
+    def encode(self, mel):
+        mel = _c(mel)
+        cap = mel.shape[1] // 8 + 2
+        out = np.zeros((self.S, cap, self.model.cfg.hidden_size), np.float32)
+        n = C.c_int(0)
+        check(lib().pk_stream_encode(self._h, _f(mel), mel.shape[1], _f(out), cap, C.byref(n)))
+        return np.ascontiguousarray(out.reshape(-1)[: self.S * n.value * self.model.cfg.hidden_size].reshape(self.S, n.value, -1))
+
+    def decode(self, enc, max_tokens=64):
+        enc = _c(enc)
+        return self._tok(lib().pk_stream_decode, enc, enc.shape[1], max_tokens)
+
+    def reset(self):
+        check(lib().pk_stream_reset(self._h))
+
+    def close(self):
+        if self._h:
+            lib().pk_stream_free(self._h)
+            self._h = None
+
+
 class Transformer:
     """pk_transformer_*: TransformerEncoder of the reference (src/transformer.cpp) on the GPU."""
 

@@ -13,10 +13,6 @@ void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rat
 
 using namespace pk;
 
-struct pk_model {
-    std::unique_ptr<Model> m;
-};
-
 static pk_status guard(const std::function<void()> &fn) {
     try {
         fn();

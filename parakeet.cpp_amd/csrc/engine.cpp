@@ -140,6 +140,11 @@ void Model::build_mel_tables() {
         twi[k] = (float)(-std::sin(a));
     }
     mel.window = upload(window.data(), window.size());
+    {   // the streaming preprocessor's frames are win_length samples, zero-padded on the right (src/audio.cpp:222-241)
+        std::vector<float> wl(n_fft, 0.0f);
+        for (int k = 0; k < win; ++k) wl[k] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)k / (double)(win - 1)));
+        mel.window_left = upload(wl.data(), wl.size());
+    }
     mel.tw_re = upload(twr.data(), twr.size());
     mel.tw_im = upload(twi.data(), twi.size());
     mel.fb = upload(fb.data(), fb.size());
@@ -490,7 +495,7 @@ void Model::run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_lo
 }
 
 // tdt_greedy_decode(_with_timestamps) / rnnt_greedy_decode  (src/tdt.cpp:36-201, src/rnnt.cpp:56-177)
-void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s) {
+void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s, bool keep_state) {
     const int d = cfg.hidden_size, Hp = cfg.pred_hidden, J = cfg.joint_hidden, V = cfg.vocab_size, D = cfg.rnnt_head ? 0 : cfg.num_durations;
     const int L = cfg.num_lstm_layers;
     // enc_proj_ hoisted out of the symbol loop: one GEMM over all frames (the reference recomputes it per symbol, src/tdt.cpp:17)
@@ -498,6 +503,7 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
     TdtState st{};
     st.B = B; st.T = T; st.V = V; st.D = D; st.L = L; st.Hp = Hp; st.blank = cfg.blank_id; st.max_symbols = cfg.max_symbols_per_step;
     st.max_tokens = max_tokens;
+    st.keep_state = keep_state ? 1 : 0;
     st.max_steps = T * (cfg.max_symbols_per_step + 1) + 16;          // safety cap (the reference has none)
     for (int i = 0; i < D; ++i) st.durations[i] = cfg.durations[i];
     st.logits = w.logits.as<float>();
@@ -507,8 +513,10 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
     st.done_count = ib + 6 * B;
     st.lens = w.lens.as<int>();
     st.ids = w.ids.as<int>(); st.start = w.start.as<int>(); st.end = w.end.as<int>(); st.conf = w.conf.as<float>();
-    PK_HIP(hipMemsetAsync(w.h.p, 0, (size_t)L * B * Hp * 4, s));
-    PK_HIP(hipMemsetAsync(w.c.p, 0, (size_t)L * B * Hp * 4, s));
+    if (!keep_state) {                                               // a streaming chunk continues from the carried LSTM state
+        PK_HIP(hipMemsetAsync(w.h.p, 0, (size_t)L * B * Hp * 4, s));
+        PK_HIP(hipMemsetAsync(w.c.p, 0, (size_t)L * B * Hp * 4, s));
+    }
     launch_tdt_init(st, s);
     // Per step: [cell GEMV per LSTM layer] -> joint-activation GEMV -> heads GEMV -> decide.  h / h' / z live in the sigma
     // K layout (they are only ever GEMV operands); c, the g1 table, enc_proj and the logits are in natural order.

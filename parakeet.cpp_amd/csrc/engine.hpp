@@ -50,6 +50,8 @@ struct Workspace {
     void size_for(const pk_config &cfg, int B, int64_t n_samples, int Tm);
 };
 
+class StreamBatch;
+
 class Model {
   public:
     Model(const std::string &weights_path, const std::string &vocab_path, const pk_config &cfg);
@@ -86,7 +88,7 @@ class Model {
     void run_encoder(Workspace &w, const float *d_feats, int B, int Tm, int stop_layer, int stop_stage, hipStream_t s);  // -> w.x
     void run_layers(Workspace &w, int B, int first_layer, int stop_layer, int stop_stage, hipStream_t s);                 // w.x -> w.x
     void run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_logp, hipStream_t s);
-    void run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s);
+    void run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s, bool keep_state = false);
 
     ProfileSink *prof = nullptr;
     void klaunch_begin(const char *name, double flops, double bytes, hipStream_t s);
@@ -105,6 +107,8 @@ class Model {
     const HostTensor &host_tensor(const std::string &name, int64_t expect_numel);
     float *dev_alloc(size_t n_floats);
 
+    friend class StreamBatch;
+
   private:
     std::unique_ptr<SafeTensors> st_;
     void build_mel_tables();
@@ -118,3 +122,8 @@ class Model {
 void set_last_error(const std::string &msg);
 
 }  // namespace pk
+
+// the opaque handle of the C ABI (include/parakeet_amd.h)
+struct pk_model {
+    std::unique_ptr<pk::Model> m;
+};

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
                 st.ids[o] = lab.idx;
                 st.start[o] = t;
                 int e = st.D > 0 ? t + (skip > 1 ? skip : 1) - 1 : t;     // src/tdt.cpp:184-187 ; rnnt.cpp:170 (end = t)
-                st.end[o] = e < st.T ? e : st.T - 1;
+                st.end[o] = (st.keep_state || e < st.T) ? e : st.T - 1;
                 st.conf[o] = dexpf(lab.lp);                                 // confidence = exp(max log-prob) :169
             }
             st.token[b] = lab.idx;
@@ -270,7 +270,7 @@ __global__ void tdt_init_kernel(TdtState st) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) *st.done_count = 0;
     if (b >= st.B) return;
-    st.token[b] = st.blank;        // SOS = blank (src/tdt.cpp:56-59)
+    if (!st.keep_state) st.token[b] = st.blank;        // SOS = blank (src/tdt.cpp:56-59); a streaming chunk carries its last token
     st.t[b] = 0;
     st.nsym[b] = 0;
     st.n_out[b] = 0;

@@ -9,7 +9,8 @@ namespace pk {
 
 // ---- mel front end (src/audio.cpp:100-158) ----------------------------------------------------
 struct MelTables {
-    const float *window;   // [512] symmetric Hann(400) zero-padded to n_fft (centred: offset 56)
+    const float *window;   // [512] symmetric Hann(400) zero-padded to n_fft, placed per switch A1 (pk_config.stft_window_centered)
+    const float *window_left;  // [512] the same window left-aligned: the streaming preprocessor's frames (center=false)
     const float *tw_re;    // [256] cos(2 pi k / 512)
     const float *tw_im;    // [256] -sin(2 pi k / 512)
     const float *fb;       // [257][n_mels] Slaney filterbank (src/audio.cpp:40-94)
@@ -19,6 +20,9 @@ struct MelTables {
     int power_via_abs;     // switch A2
 };
 void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s);
+// StreamingAudioPreprocessor::process_chunk (src/audio.cpp:222-252) on pre-emphasised buffers pre[B][n_samples]:
+// n_frames = (n_samples - 400) / 160 + 1 frames -> log-mel [B][n_frames][n_mels] (no normalisation)
+void launch_mel_stream(const float *pre, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel_tf, hipStream_t s);
 void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, int normalize, float *feats, hipStream_t s);
 
 // ---- fp32 MFMA GEMM: out = epi(A[M][K] * W[N][K]^T + bias), natural-k fma chains ----------------
@@ -57,12 +61,29 @@ void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads,
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
                            const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s);
 
+// ---- streaming encoder pieces (src/streaming_encoder.cpp) -----------------------------------------------------------------------
+// StreamingConformerAttention::forward_cached (:162-272) core for S streams x c query rows: keys / values = nc cached rows
+// followed by the c rows of this chunk (qkv_new[S*c][3d], natural columns); position scores are the rightmost kv = nc + c
+// columns of (q+v) P^T WITHOUT rel_shift (:215-224), masked to the [left, right] context (:226-247).  ctx[S*c][d].
+void launch_stream_attention(const float *qkv_new, const float *kcache, const float *vcache, int cache_rows, int S, int c, int nc, int d,
+                             int n_heads, const float *pos /*[P][d]*/, int P, const float *bias_u, const float *bias_v, int att_left,
+                             int att_right, float *ctx, hipStream_t s);
+// new cache = the last min(keep_max, nc + c) rows of [cache(nc rows) ; new(c rows)]  (:193-209); row stride of both caches: cache_rows*d
+void launch_stream_cache_update(const float *cache_in, int nc, const float *qkv_new, int col0, int S, int c, int d, int cache_rows,
+                                int keep_max, float *cache_out, hipStream_t s);
+// CausalConformerConvModule::forward_cached middle (:51-73): depthwise conv over [cache(K-1 rows, zeros when !has_cache) ; g(c rows)],
+// BatchNorm, SiLU -> out[S*c][d]; cache_out = last K-1 rows of the concatenation.
+void launch_stream_dwconv(const float *g, const float *cache_in, int has_cache, int S, int c, int d, int kc, const float *w, const float *bias,
+                          const float *bn_mean, const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, float *cache_out,
+                          hipStream_t s);
+
 // ---- decoders -------------------------------------------------------------------------------------------
 void launch_logsoftmax_argmax(const float *logits, int64_t rows, int ld, int n, float *lp_out, int *best_idx, float *best_lp, hipStream_t s);
 void launch_ctc_collapse(const int *best_idx, const float *best_lp, int B, int T, int blank, int *ids, int *lens, int *start, int *end,
                          float *conf, hipStream_t s);
 struct TdtState {
     int B, T, V, D, L, Hp, blank, max_symbols, max_tokens, max_steps;
+    int keep_state;                 // streaming chunks (src/eou.cpp:17-98): the last token and h / c are carried in, end frames are not clamped
     int durations[8];
     const float *logits;            // [B][V+D]
     float *h, *c;                   // committed LSTM state [L][B][Hp]

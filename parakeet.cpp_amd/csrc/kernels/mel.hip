@@ -21,6 +21,11 @@ static constexpr int kNfft = 512;
 static constexpr int kHop = 160;
 static constexpr int kFramesPerBlock = 4;
 
+// STREAM = false: preprocess_audio's framing (pre-emphasis, center=true, reflect padding), output [B][n_mels][n_frames].
+// STREAM = true: StreamingAudioPreprocessor::process_chunk's framing (src/audio.cpp:222-241): the buffer is ALREADY
+// pre-emphasised, center=false, frame t = samples [160 t, 160 t + 400) Hann-windowed and zero-padded on the right to the
+// 512-point FFT; output [B][n_frames][n_mels] (the layout of its result, no normalisation follows).
+template <bool STREAM>
 __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict__ pcm, int64_t n_samples, int n_frames,
                                                          MelTables tb, float *__restrict__ logmel) {
     __shared__ float s_re[kFramesPerBlock][kNfft];
@@ -37,18 +42,22 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
 #pragma unroll
         for (int i = 0; i < kNfft / 64; ++i) {
             const int n = lane + 64 * i;
-            int64_t idx = (int64_t)t * kHop + n - kNfft / 2;      // center=true
-            if (idx < 0) idx = -idx;                              // pad_mode="reflect"
-            if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
-            float v;
-            if (idx == 0) {
-                v = x[0];                                         // preemphasis, src/audio.cpp:104-114
-            } else {
-                const float p = 0.97f * x[idx - 1];
-                v = x[idx] - p;
-            }
             const int r = (int)(__brev((unsigned)n) >> 23);       // 9-bit reversal
-            re[r] = v * tb.window[n];
+            if constexpr (STREAM) {
+                re[r] = n < 400 ? x[(int64_t)t * kHop + n] * tb.window_left[n] : 0.0f;
+            } else {
+                int64_t idx = (int64_t)t * kHop + n - kNfft / 2;  // center=true
+                if (idx < 0) idx = -idx;                          // pad_mode="reflect"
+                if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
+                float v;
+                if (idx == 0) {
+                    v = x[0];                                     // preemphasis, src/audio.cpp:104-114
+                } else {
+                    const float p = 0.97f * x[idx - 1];
+                    v = x[idx] - p;
+                }
+                re[r] = v * tb.window[n];
+            }
             im[r] = 0.0f;
         }
     }
@@ -93,7 +102,9 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
             float acc = 0.0f;
             const int lo = tb.f_lo[m], hi = tb.f_hi[m];           // zero weights contribute fma(0, p, acc) = acc exactly
             for (int f = lo; f <= hi; ++f) acc = __builtin_fmaf(tb.fb[f * tb.n_mels + m], pw[f], acc);
-            logmel[((int64_t)b * tb.n_mels + m) * n_frames + t] = dlogf(acc + 5.96046448e-8f);
+            const float lm = dlogf(acc + 5.96046448e-8f);
+            if constexpr (STREAM) logmel[((int64_t)b * n_frames + t) * tb.n_mels + m] = lm;
+            else logmel[((int64_t)b * tb.n_mels + m) * n_frames + t] = lm;
         }
     }
 }
@@ -122,7 +133,11 @@ __global__ __launch_bounds__(64) void mel_normalize_kernel(const float *__restri
 
 void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s) {
     dim3 grid((n_frames + kFramesPerBlock - 1) / kFramesPerBlock, B);
-    hipLaunchKernelGGL(mel_logmel_kernel, grid, dim3(256), 0, s, pcm, n_samples, n_frames, t, logmel);
+    hipLaunchKernelGGL(mel_logmel_kernel<false>, grid, dim3(256), 0, s, pcm, n_samples, n_frames, t, logmel);
+}
+void launch_mel_stream(const float *pre, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel_tf, hipStream_t s) {
+    dim3 grid((n_frames + kFramesPerBlock - 1) / kFramesPerBlock, B);
+    hipLaunchKernelGGL(mel_logmel_kernel<true>, grid, dim3(256), 0, s, pre, n_samples, n_frames, t, logmel_tf);
 }
 void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, int normalize, float *feats, hipStream_t s) {
     hipLaunchKernelGGL(mel_normalize_kernel, dim3(n_mels, B), dim3(64), 0, s, logmel, n_mels, n_frames, normalize, feats);

@@ -1,0 +1,130 @@
+// parakeet.cpp_amd/csrc/kernels/stream.hip -- the cached pieces of the streaming encoder (reference
+// src/streaming_encoder.cpp: StreamingConformerAttention::forward_cached :162-272, CausalConformerConvModule::forward_cached
+// :41-78).  A chunk is 1-3 encoder frames per stream and a few dozen cached keys, so these are latency kernels: one
+// wavefront per (stream, head, query row), exact k-ordered fp32 fma chains on the VALU (bit-identical to the oracle), the
+// canonical max / sum64 butterflies for the softmax.
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+
+namespace pk {
+
+__global__ __launch_bounds__(64) void stream_attention_kernel(const float *__restrict__ qkv, const float *__restrict__ kcache,
+                                                              const float *__restrict__ vcache, int cache_rows, int c, int nc, int d, int H,
+                                                              const float *__restrict__ pos, int P, const float *__restrict__ bias_u,
+                                                              const float *__restrict__ bias_v, int att_left, int att_right, float scale,
+                                                              float *__restrict__ ctx) {
+    extern __shared__ float sm[];                                   // [hd] q+u, [hd] q+v, [kv] probabilities
+    const int hd = d / H, kv = nc + c;
+    const int sidx = blockIdx.x / H, h = blockIdx.x % H, i = blockIdx.y, lane = threadIdx.x;
+    float *qu = sm, *qv = sm + hd, *pr = sm + 2 * hd;
+    const float *qrow = qkv + ((int64_t)sidx * c + i) * 3 * d + h * hd;
+    for (int e = lane; e < hd; e += 64) {
+        const float q = qrow[e];
+        qu[e] = q + bias_u[h * hd + e];                             // :209-212
+        qv[e] = q + bias_v[h * hd + e];
+    }
+    __syncthreads();
+    auto krow = [&](int j) {                                        // key j: cached rows first, then this chunk's rows (:186-189)
+        return j < nc ? kcache + ((int64_t)sidx * cache_rows + j) * d + h * hd : qkv + ((int64_t)sidx * c + (j - nc)) * 3 * d + d + h * hd;
+    };
+    auto vrow = [&](int j) {
+        return j < nc ? vcache + ((int64_t)sidx * cache_rows + j) * d + h * hd : qkv + ((int64_t)sidx * c + (j - nc)) * 3 * d + 2 * d + h * hd;
+    };
+    const int off = P > kv ? P - kv : 0;                            // rightmost kv columns of the position scores, NOT rel-shifted (:215-224)
+    const int abs_pos = kv - c + i;
+    float m = -__builtin_huge_valf();
+    for (int j = lane; j < kv; j += 64) {
+        const float *kr = krow(j), *pp = pos + (int64_t)(off + j) * d + h * hd;
+        float cs = 0.0f, ps = 0.0f;
+        for (int e = 0; e < hd; ++e) {
+            cs = __builtin_fmaf(qu[e], kr[e], cs);
+            ps = __builtin_fmaf(qv[e], pp[e], ps);
+        }
+        float sc = (cs + ps) * scale;                               // :226
+        const int dist = abs_pos - j;
+        if ((att_left >= 0 || att_right >= 0) && (dist > att_left || -dist > att_right)) sc = -1e9f;   // masked_fill :231-247
+        pr[j] = sc;
+        m = fmaxf(m, sc);
+    }
+    m = wave_max64(m);
+    float p = 0.0f;
+    for (int j = lane; j < kv; j += 64) {
+        const float e = dexpf(pr[j] - m);
+        pr[j] = e;
+        p = p + e;
+    }
+    const float sum = wave_sum64(p);
+    for (int j = lane; j < kv; j += 64) pr[j] = pr[j] / sum;
+    __syncthreads();
+    for (int e = lane; e < hd; e += 64) {                           // softmax(S) V, k = key index in natural order (:250)
+        float acc = 0.0f;
+        for (int j = 0; j < kv; ++j) acc = __builtin_fmaf(pr[j], vrow(j)[e], acc);
+        ctx[((int64_t)sidx * c + i) * d + h * hd + e] = acc;
+    }
+}
+
+void launch_stream_attention(const float *qkv_new, const float *kcache, const float *vcache, int cache_rows, int S, int c, int nc, int d,
+                             int n_heads, const float *pos, int P, const float *bias_u, const float *bias_v, int att_left, int att_right,
+                             float *ctx, hipStream_t s) {
+    const int hd = d / n_heads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const size_t lds = (size_t)(2 * hd + nc + c) * sizeof(float);
+    hipLaunchKernelGGL(stream_attention_kernel, dim3(S * n_heads, c), dim3(64), lds, s, qkv_new, kcache, vcache, cache_rows, c, nc, d, n_heads, pos,
+                       P, bias_u, bias_v, att_left, att_right, scale, ctx);
+}
+
+__global__ void stream_cache_update_kernel(const float *__restrict__ cache_in, int nc, const float *__restrict__ qkv, int col0, int c, int d,
+                                           int cache_rows, int keep, float *__restrict__ cache_out, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int e = (int)(idx % d), r = (int)((idx / d) % keep), sidx = (int)(idx / ((int64_t)d * keep));
+    const int j = nc + c - keep + r;                                // row of [cache ; new]
+    cache_out[((int64_t)sidx * cache_rows + r) * d + e] =
+        j < nc ? cache_in[((int64_t)sidx * cache_rows + j) * d + e] : qkv[((int64_t)sidx * c + (j - nc)) * 3 * d + col0 + e];
+}
+void launch_stream_cache_update(const float *cache_in, int nc, const float *qkv_new, int col0, int S, int c, int d, int cache_rows,
+                                int keep_max, float *cache_out, hipStream_t s) {
+    const int kv = nc + c, keep = kv > keep_max ? keep_max : kv;
+    if (keep <= 0) return;
+    const int64_t n = (int64_t)S * keep * d;
+    hipLaunchKernelGGL(stream_cache_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cache_in, nc, qkv_new, col0, c, d, cache_rows,
+                       keep, cache_out, n);
+}
+
+template <int KC>
+__global__ void stream_dwconv_kernel(const float *__restrict__ g, const float *__restrict__ cache_in, int has_cache, int c, int d,
+                                     const float *__restrict__ w /*[KC][d]*/, const float *__restrict__ bias, const float *__restrict__ bn_mean,
+                                     const float *__restrict__ bn_rstd, const float *__restrict__ bn_g, const float *__restrict__ bn_b,
+                                     float *__restrict__ out, float *__restrict__ cache_out, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (stream, channel)
+    if (idx >= n) return;
+    const int ch = (int)(idx % d), sidx = (int)(idx / d);
+    constexpr int CL = KC - 1;
+    auto cat = [&](int r) {                                         // row r of [cache(CL rows) ; g(c rows)]
+        if (r < CL) return has_cache ? cache_in[((int64_t)sidx * CL + r) * d + ch] : 0.0f;   // first chunk: zero left padding (:55-63)
+        return g[((int64_t)sidx * c + (r - CL)) * d + ch];
+    };
+    for (int t = 0; t < c; ++t) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) acc = __builtin_fmaf(w[kk * d + ch], cat(t + kk), acc);      // depthwise, no padding (:71)
+        float v = acc + bias[ch];
+        v = __builtin_fmaf((v - bn_mean[ch]) * bn_rstd[ch], bn_g[ch], bn_b[ch]);
+        out[((int64_t)sidx * c + t) * d + ch] = dsiluf(v);
+    }
+    float keep[CL];
+#pragma unroll
+    for (int r = 0; r < CL; ++r) keep[r] = cat(c + r);             // last KC-1 rows of the concatenation (:66-69)
+#pragma unroll
+    for (int r = 0; r < CL; ++r) cache_out[((int64_t)sidx * CL + r) * d + ch] = keep[r];
+}
+void launch_stream_dwconv(const float *g, const float *cache_in, int has_cache, int S, int c, int d, int kc, const float *w, const float *bias,
+                          const float *bn_mean, const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, float *cache_out,
+                          hipStream_t s) {
+    const int64_t n = (int64_t)S * d;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (kc == 9) hipLaunchKernelGGL(stream_dwconv_kernel<9>, grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n);
+    else if (kc == 31) hipLaunchKernelGGL(stream_dwconv_kernel<31>, grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n);
+}
+
+}  // namespace pk

@@ -1,0 +1,353 @@
+// parakeet.cpp_amd/csrc/stream.cpp -- the streaming path (BASELINE configs[4]: N concurrent streams per GPU with cached
+// encoder state): StreamingAudioPreprocessor::process_chunk (src/audio.cpp:195-259), StreamingFastConformerEncoder::
+// forward_chunk (src/streaming_encoder.cpp:430-472) and rnnt_streaming_decode_chunk (src/eou.cpp:17-98), the three calls of
+// NemotronTranscriber::transcribe_chunk / StreamingTranscriber::transcribe_chunk (src/nemotron.cpp:24-52, src/eou.cpp:113-146).
+//
+// One pk_stream = S streams advanced in LOCK-STEP (every push hands each stream the same number of samples, so all S share
+// the chunk geometry: frames produced, leftovers, cache lengths) -- the batch dimension of every kernel.  All state lives in
+// HBM (K/V caches [S][left][d] and conv caches [S][K-1][d] per layer, leftover mel frames, LSTM state, last token); the host
+// keeps only the pre-emphasis carry and the < 560 overlap samples per stream.  The per-chunk work is tiny (1-3 encoder frames
+// per stream): FFN / projection products run on the MFMA GEMM with M = S*c rows, the cached attention and causal conv are
+// exact-chain VALU kernels (kernels/stream.hip).  Bit-identical to the oracle's Stream (tests/test_gpu_stream.py).
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "engine.hpp"
+
+namespace pk {
+
+class StreamBatch {
+  public:
+    StreamBatch(Model &m, int n_streams, int att_left, int att_right);
+    void reset();
+    // stage entry points (host buffers); each returns the number of frames it produced per stream (0: buffered / cached)
+    int mel(const float *pcm, int n_samples, float *out /*[S][n_frames][F]*/, int cap_frames);
+    int encode(const float *mel_in, int n_frames, float *enc /*[S][c][d]*/, int cap_frames);
+    void decode(const float *enc, int c, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
+    // NemotronTranscriber::transcribe_chunk for S streams; device-resident between the stages
+    void push(const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
+    int S;
+
+  private:
+    Model &m_;
+    int left_, right_;
+    // StreamingAudioPreprocessor state (host)
+    std::vector<float> preemph_last_;
+    std::vector<std::vector<float>> overlap_;
+    // device state
+    DevBuf mel_cache_;          // [S][8][F] leftover mel frames (first n_mel_cache_ valid)
+    int n_mel_cache_ = 0;
+    struct LayerState { DevBuf k[2], v[2], conv[2]; int cur = 0, ccur = 0, n_kv = 0, has_conv = 0; };
+    std::vector<std::unique_ptr<LayerState>> layers_;
+    int frame_offset_ = 0;
+    Workspace ws_;              // encoder workspace of the current chunk
+    Workspace wd_;              // decode workspace: h / c / token persist across chunks (never re-allocated)
+    int dec_cap_frames_ = 0;
+    DevBuf pre_, mel_dev_, mel_all_, enc_in_;
+    std::map<int, std::unique_ptr<DevBuf>> pos_tables_;   // Tp -> pos_proj of every layer [L][2Tp-1][d], natural columns
+    int encode_device(const float *d_mel, int n_frames);                    // -> ws_.x [S*c][d], returns c
+    const float *pos_table(int Tp);
+    void decode_device(const float *d_enc, int c, int max_tokens);
+};
+
+StreamBatch::StreamBatch(Model &m, int n_streams, int att_left, int att_right) : S(n_streams), m_(m), left_(att_left), right_(att_right) {
+    m_.require_gpu();
+    if (S <= 0 || att_left < 0 || att_right < 0) fail(PK_ERR_INVALID, "n_streams / attention context");
+    if (m_.cfg.rnnt_head) fail(PK_ERR_UNSUPPORTED, "streaming decode is the TDT-joint loop of src/eou.cpp (label + duration heads)");
+    const int d = m_.cfg.hidden_size, F = m_.cfg.mel_bins, K = m_.cfg.conv_kernel_size;
+    mel_cache_.reserve((size_t)S * 8 * F * 4);
+    for (int l = 0; l < m_.cfg.num_layers; ++l) {
+        layers_.push_back(std::make_unique<LayerState>());
+        LayerState &L = *layers_.back();
+        for (int i = 0; i < 2; ++i) {
+            L.k[i].reserve((size_t)S * (left_ > 0 ? left_ : 1) * d * 4);
+            L.v[i].reserve((size_t)S * (left_ > 0 ? left_ : 1) * d * 4);
+            L.conv[i].reserve((size_t)S * (K - 1) * d * 4);
+        }
+    }
+    dec_cap_frames_ = 64;                                           // encoder frames per chunk the decode workspace is sized for
+    wd_.size_for(m_.cfg, S, 0, 8 * (dec_cap_frames_ - 1) + 1);
+    reset();
+}
+
+void StreamBatch::reset() {
+    m_.require_gpu();
+    preemph_last_.assign(S, 0.0f);
+    overlap_.assign(S, {});
+    n_mel_cache_ = 0;
+    frame_offset_ = 0;
+    for (auto &L : layers_) { L->cur = L->ccur = 0; L->n_kv = 0; L->has_conv = 0; }
+    const int Hp = m_.cfg.pred_hidden, Ln = m_.cfg.num_lstm_layers;
+    PK_HIP(hipMemset(wd_.h.p, 0, (size_t)Ln * S * Hp * 4));
+    PK_HIP(hipMemset(wd_.c.p, 0, (size_t)Ln * S * Hp * 4));
+    std::vector<int> tok(S, m_.cfg.blank_id);                       // last_token = blank (src/eou.cpp:33-35)
+    PK_HIP(hipMemcpy(wd_.ints.p, tok.data(), (size_t)S * 4, hipMemcpyHostToDevice));
+}
+
+// ---- StreamingAudioPreprocessor::process_chunk --------------------------------------------------------------------------------
+int StreamBatch::mel(const float *pcm, int n, float *out, int cap_frames) {
+    m_.require_gpu();
+    if (n <= 0) fail(PK_ERR_INVALID, "n_samples");
+    const int F = m_.cfg.mel_bins;
+    const int total = (int)overlap_[0].size() + n;
+    std::vector<float> buf((size_t)S * total);
+    for (int s = 0; s < S; ++s) {                                   // 1. pre-emphasis with the carried sample, 2. prepend the overlap (:204-214)
+        float *b = buf.data() + (size_t)s * total;
+        memcpy(b, overlap_[s].data(), overlap_[s].size() * 4);
+        float last = preemph_last_[s];
+        const float *src = pcm + (size_t)s * n;
+        for (int i = 0; i < n; ++i) {
+            const float cur = src[i];
+            const float t = 0.97f * last;
+            b[overlap_[s].size() + i] = cur - t;
+            last = cur;
+        }
+        preemph_last_[s] = last;
+    }
+    const int n_frames = total < 400 ? 0 : (total - 400) / 160 + 1;
+    if (n_frames <= 0) {                                            // :216-228 buffer everything
+        for (int s = 0; s < S; ++s) overlap_[s].assign(buf.begin() + (size_t)s * total, buf.begin() + (size_t)(s + 1) * total);
+        return 0;
+    }
+    if (out && n_frames > cap_frames) fail(PK_ERR_INVALID, "mel output holds %d frames, chunk produces %d", cap_frames, n_frames);
+    const int consumed = (n_frames - 1) * 160 + 400;               // :230-231
+    for (int s = 0; s < S; ++s) overlap_[s].assign(buf.begin() + (size_t)s * total + consumed, buf.begin() + (size_t)(s + 1) * total);
+    pre_.reserve((size_t)S * consumed * 4);
+    mel_dev_.reserve((size_t)S * n_frames * F * 4);
+    hipStream_t st = m_.stream;
+    PK_HIP(hipMemcpy2DAsync(pre_.p, (size_t)consumed * 4, buf.data(), (size_t)total * 4, (size_t)consumed * 4, S, hipMemcpyHostToDevice, st));
+    launch_mel_stream(pre_.as<float>(), S, consumed, n_frames, m_.mel, mel_dev_.as<float>(), st);
+    PK_CHECK_LAUNCH();
+    if (out) PK_HIP(hipMemcpyAsync(out, mel_dev_.p, (size_t)S * n_frames * F * 4, hipMemcpyDeviceToHost, st));
+    PK_HIP(hipStreamSynchronize(st));                               // `buf` is pageable host memory about to go out of scope
+    return n_frames;
+}
+
+// pos_proj_ of every layer for the position table of length Tp = att_left + c (src/streaming_encoder.cpp:452-454, :214), natural columns
+const float *StreamBatch::pos_table(int Tp) {
+    auto it = pos_tables_.find(Tp);
+    if (it != pos_tables_.end()) return it->second->as<float>();
+    const int d = m_.cfg.hidden_size, P = 2 * Tp - 1;
+    std::vector<float> pe((size_t)P * d);
+    for (int p = 0; p < P; ++p) {                                   // sinusoidal_position_embedding (src/encoder.cpp:9-30), float math
+        const float position = (float)(Tp - 1 - p);
+        for (int i = 0; i < d; i += 2) {
+            const float div_term = std::exp((float)i * (-std::log(10000.0f) / (float)d));
+            pe[(size_t)p * d + i] = std::sin(position * div_term);
+            if (i + 1 < d) pe[(size_t)p * d + i + 1] = std::cos(position * div_term);
+        }
+    }
+    DevBuf tmp;
+    tmp.reserve(pe.size() * 4);
+    auto tab = std::make_unique<DevBuf>();
+    tab->reserve((size_t)m_.cfg.num_layers * P * d * 4);
+    hipStream_t st = m_.stream;
+    PK_HIP(hipMemcpyAsync(tmp.p, pe.data(), pe.size() * 4, hipMemcpyHostToDevice, st));
+    for (int l = 0; l < m_.cfg.num_layers; ++l) {
+        GemmArgs g{tmp.as<float>(), d, m_.layers[l].wpos, d, nullptr, tab->as<float>() + (size_t)l * P * d, d, nullptr, 0, 1.0f, P, d, d};
+        m_.run_gemm("pos_proj", g, EPI_NONE, st);
+    }
+    PK_HIP(hipStreamSynchronize(st));
+    const float *r = tab->as<float>();
+    pos_tables_[Tp] = std::move(tab);
+    return r;
+}
+
+// ---- StreamingFastConformerEncoder::forward_chunk ---------------------------------------------------------------------------------
+int StreamBatch::encode_device(const float *d_mel, int n_frames) {
+    const pk_config &cfg = m_.cfg;
+    const int F = cfg.mel_bins, d = cfg.hidden_size, K = cfg.conv_kernel_size;
+    hipStream_t st = m_.stream;
+    // CausalConvSubsampling::forward_cached (:348-385): prepend the leftover frames, consume a multiple of 8, keep the rest
+    const int total = n_mel_cache_ + n_frames, consumable = (total / 8) * 8, leftover = total - consumable;
+    mel_all_.reserve((size_t)S * (total > 0 ? total : 1) * F * 4);
+    const size_t rowb = (size_t)F * 4;
+    if (n_mel_cache_ > 0)
+        PK_HIP(hipMemcpy2DAsync(mel_all_.p, (size_t)total * rowb, mel_cache_.p, 8 * rowb, (size_t)n_mel_cache_ * rowb, S, hipMemcpyDeviceToDevice, st));
+    PK_HIP(hipMemcpy2DAsync((char *)mel_all_.p + (size_t)n_mel_cache_ * rowb, (size_t)total * rowb, d_mel, (size_t)n_frames * rowb,
+                            (size_t)n_frames * rowb, S, hipMemcpyDeviceToDevice, st));
+    if (leftover > 0)
+        PK_HIP(hipMemcpy2DAsync(mel_cache_.p, 8 * rowb, (char *)mel_all_.p + (size_t)consumable * rowb, (size_t)total * rowb, (size_t)leftover * rowb, S,
+                                hipMemcpyDeviceToDevice, st));
+    n_mel_cache_ = leftover;
+    if (consumable == 0) return 0;
+    // forward() on the consumable frames: the offline conv stack on a contiguous [S][consumable][F] tensor
+    enc_in_.reserve((size_t)S * consumable * F * 4);
+    PK_HIP(hipMemcpy2DAsync(enc_in_.p, (size_t)consumable * rowb, mel_all_.p, (size_t)total * rowb, (size_t)consumable * rowb, S, hipMemcpyDeviceToDevice, st));
+    ws_.size_for(cfg, S, 0, consumable);
+    const int c = ws_.T;
+    float *x = ws_.x.as<float>(), *n = ws_.n.as<float>();
+    m_.run_subsample(ws_, enc_in_.as<float>(), S, consumable, x, st);
+    const int Tp = left_ + c, P = 2 * Tp - 1;
+    const float *ptab = pos_table(Tp);
+    const int64_t rows = (int64_t)S * c;
+    const int cache_rows = left_ > 0 ? left_ : 1;
+    for (int l = 0; l < cfg.num_layers; ++l) {
+        const LayerW &L = m_.layers[l];
+        LayerState &Ls = *layers_[l];
+        m_.ffn(ws_, L, false, rows, st);                                                               // ffn1_ (:294)
+        // StreamingConformerAttention::forward_cached (:162-272)
+        launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, st);
+        {
+            GemmArgs g{n, d, L.wqkv, d, L.bqkv, ws_.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
+            m_.run_gemm("attn_qkv", g, EPI_NONE, st);                                                 // natural columns (no sigma layout here)
+        }
+        const float *kc = Ls.k[Ls.cur].as<float>(), *vc = Ls.v[Ls.cur].as<float>();
+        launch_stream_attention(ws_.qkv.as<float>(), kc, vc, cache_rows, S, c, Ls.n_kv, d, cfg.num_heads, ptab + (size_t)l * P * d, P, L.pos_u, L.pos_v,
+                                left_, right_, ws_.ctx.as<float>(), st);
+        launch_stream_cache_update(kc, Ls.n_kv, ws_.qkv.as<float>(), d, S, c, d, cache_rows, left_, Ls.k[Ls.cur ^ 1].as<float>(), st);
+        launch_stream_cache_update(vc, Ls.n_kv, ws_.qkv.as<float>(), 2 * d, S, c, d, cache_rows, left_, Ls.v[Ls.cur ^ 1].as<float>(), st);
+        Ls.cur ^= 1;
+        Ls.n_kv = (Ls.n_kv + c > left_) ? left_ : Ls.n_kv + c;
+        {
+            GemmArgs g{ws_.ctx.as<float>(), d, L.wo, d, L.bo, x, d, x, d, 1.0f, (int)rows, d, d};
+            m_.run_gemm("attn_out_resid", g, EPI_RESID, st);
+        }
+        // CausalConformerConvModule::forward_cached (:41-78)
+        launch_layernorm(x, rows, d, L.cv_ng, L.cv_nb, 1e-5f, n, st);
+        {
+            GemmArgs g{n, d, L.pw1_w, d, L.pw1_b, ws_.g.as<float>(), d, nullptr, 0, 1.0f, (int)rows, d, d};
+            m_.run_gemm("conv_pw1_glu", g, EPI_GLU, st);
+        }
+        launch_stream_dwconv(ws_.g.as<float>(), Ls.conv[Ls.ccur].as<float>(), Ls.has_conv, S, c, d, K, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
+                             ws_.dwb.as<float>(), Ls.conv[Ls.ccur ^ 1].as<float>(), st);
+        Ls.ccur ^= 1;
+        Ls.has_conv = 1;
+        {
+            GemmArgs g{ws_.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, x, d, 1.0f, (int)rows, d, d};
+            m_.run_gemm("conv_pw2_resid", g, EPI_RESID, st);
+        }
+        m_.ffn(ws_, L, true, rows, st);                                                                // ffn2_
+        launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, st);                                  // final_norm_
+    }
+    PK_CHECK_LAUNCH();
+    return c;
+}
+
+int StreamBatch::encode(const float *mel_in, int n_frames, float *enc, int cap_frames) {
+    m_.require_gpu();
+    if (n_frames <= 0) fail(PK_ERR_INVALID, "n_frames");
+    const int F = m_.cfg.mel_bins, d = m_.cfg.hidden_size;
+    mel_dev_.reserve((size_t)S * n_frames * F * 4);
+    PK_HIP(hipMemcpyAsync(mel_dev_.p, mel_in, (size_t)S * n_frames * F * 4, hipMemcpyHostToDevice, m_.stream));
+    const int c = encode_device(mel_dev_.as<float>(), n_frames);
+    if (c > 0) {
+        if (c > cap_frames) fail(PK_ERR_INVALID, "encoder output holds %d frames, chunk produces %d", cap_frames, c);
+        PK_HIP(hipMemcpyAsync(enc, ws_.x.p, (size_t)S * c * d * 4, hipMemcpyDeviceToHost, m_.stream));
+    }
+    PK_HIP(hipStreamSynchronize(m_.stream));
+    return c;
+}
+
+// ---- rnnt_streaming_decode_chunk -------------------------------------------------------------------------------------------------------
+void StreamBatch::decode_device(const float *d_enc, int c, int max_tokens) {
+    if (c > dec_cap_frames_) fail(PK_ERR_UNSUPPORTED, "chunk of %d encoder frames exceeds the stream's decode workspace (%d)", c, dec_cap_frames_);
+    if (max_tokens > wd_.max_tokens) fail(PK_ERR_INVALID, "max_tokens %d > %d", max_tokens, wd_.max_tokens);
+    wd_.T = c;
+    m_.run_tdt(wd_, d_enc, S, c, max_tokens, m_.stream, /*keep_state=*/true);
+}
+
+static void fetch_tokens(Model &m, Workspace &wd, int S, int max_tokens, int frame_offset, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end,
+                         float *conf) {
+    hipStream_t st = m.stream;
+    const size_t nb = (size_t)S * max_tokens * 4;
+    PK_HIP(hipMemcpyAsync(lens, wd.lens.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+    PK_HIP(hipMemcpyAsync(ids, wd.ids.p, nb, hipMemcpyDeviceToHost, st));
+    if (start) PK_HIP(hipMemcpyAsync(start, wd.start.p, nb, hipMemcpyDeviceToHost, st));
+    if (end) PK_HIP(hipMemcpyAsync(end, wd.end.p, nb, hipMemcpyDeviceToHost, st));
+    if (conf) PK_HIP(hipMemcpyAsync(conf, wd.conf.p, nb, hipMemcpyDeviceToHost, st));
+    PK_HIP(hipStreamSynchronize(st));
+    for (int s = 0; s < S; ++s) {
+        if (lens[s] < 0) fail(PK_ERR_DECODE_CAP, "stream %d: TDT loop hit the safety cap", s);
+        for (int i = 0; i < lens[s]; ++i) {                        // frames relative to the stream (src/eou.cpp:77-79)
+            if (start) start[(size_t)s * max_tokens + i] += frame_offset;
+            if (end) end[(size_t)s * max_tokens + i] += frame_offset;
+        }
+    }
+}
+
+void StreamBatch::decode(const float *enc, int c, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
+    m_.require_gpu();
+    if (c <= 0 || max_tokens <= 0) fail(PK_ERR_INVALID, "c / max_tokens");
+    const int d = m_.cfg.hidden_size;
+    enc_in_.reserve((size_t)S * c * d * 4);
+    PK_HIP(hipMemcpyAsync(enc_in_.p, enc, (size_t)S * c * d * 4, hipMemcpyHostToDevice, m_.stream));
+    decode_device(enc_in_.as<float>(), c, max_tokens);
+    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf);
+    frame_offset_ += c;
+}
+
+void StreamBatch::push(const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
+    for (int s = 0; s < S; ++s) lens[s] = 0;
+    const int n_frames = mel(pcm, n_samples, nullptr, 0);
+    if (n_frames == 0) return;
+    const int c = encode_device(mel_dev_.as<float>(), n_frames);
+    if (c == 0) { PK_HIP(hipStreamSynchronize(m_.stream)); return; }
+    decode_device(ws_.x.as<float>(), c, max_tokens);
+    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf);
+    frame_offset_ += c;
+}
+
+}  // namespace pk
+
+using namespace pk;
+
+struct pk_stream { std::unique_ptr<StreamBatch> s; };
+
+template <class F>
+static pk_status stream_guard(F &&fn) {
+    try {
+        fn();
+        return PK_OK;
+    } catch (const Error &e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return PK_ERR_INVALID;
+    }
+}
+
+extern "C" {
+
+pk_status pk_stream_create(pk_model *m, int n_streams, int att_context_left, int att_context_right, pk_stream **out) {
+    return stream_guard([&] {
+        if (!m || !out) fail(PK_ERR_INVALID, "invalid argument: model/out");
+        auto h = std::make_unique<pk_stream>();
+        h->s = std::make_unique<StreamBatch>(*m->m, n_streams, att_context_left, att_context_right);
+        *out = h.release();
+    });
+}
+void pk_stream_free(pk_stream *s) { delete s; }
+pk_status pk_stream_reset(pk_stream *s) {
+    return stream_guard([&] { if (!s) fail(PK_ERR_INVALID, "stream"); s->s->reset(); });
+}
+pk_status pk_stream_push(pk_stream *s, const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start,
+                         int32_t *end, float *conf) {
+    return stream_guard([&] {
+        if (!s || !pcm || !ids || !lens || n_samples <= 0 || max_tokens <= 0) fail(PK_ERR_INVALID, "invalid argument: stream/pcm/ids/lens/sizes");
+        s->s->push(pcm, n_samples, max_tokens, ids, lens, start, end, conf);
+    });
+}
+pk_status pk_stream_mel(pk_stream *s, const float *pcm, int n_samples, float *out, int cap_frames, int *n_frames) {
+    return stream_guard([&] {
+        if (!s || !pcm || !out || !n_frames) fail(PK_ERR_INVALID, "invalid argument: stream/pcm/out/n_frames");
+        *n_frames = s->s->mel(pcm, n_samples, out, cap_frames);
+    });
+}
+pk_status pk_stream_encode(pk_stream *s, const float *mel, int n_frames, float *enc, int cap_frames, int *n_out) {
+    return stream_guard([&] {
+        if (!s || !mel || !enc || !n_out) fail(PK_ERR_INVALID, "invalid argument: stream/mel/enc/n_out");
+        *n_out = s->s->encode(mel, n_frames, enc, cap_frames);
+    });
+}
+pk_status pk_stream_decode(pk_stream *s, const float *enc, int n_frames, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start,
+                           int32_t *end, float *conf) {
+    return stream_guard([&] {
+        if (!s || !enc || !ids || !lens) fail(PK_ERR_INVALID, "invalid argument: stream/enc/ids/lens");
+        s->s->decode(enc, n_frames, max_tokens, ids, lens, start, end, conf);
+    });
+}
+
+}  // extern "C"
