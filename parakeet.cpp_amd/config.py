@@ -56,6 +56,13 @@ def make_rnnt_600m_config() -> ModelConfig:      # config.hpp:119-135
                        joint_prefix="joint_.", head="rnnt", durations=[], blank_id=1024)
 
 
+def make_nemotron_600m_config() -> ModelConfig:  # nemotron.hpp:31-52 (streaming; att_context_left 70, right = latency_frames)
+    # blank_id: NemotronTranscriber::transcribe_chunk calls rnnt_streaming_decode_chunk with its DEFAULT blank_id = 1024
+    # (nemotron.cpp:40-42, eou.hpp:91-94) although the vocabulary has 8193 entries -- kept literally.
+    return ModelConfig(name="nemotron-600m", mel_bins=80, hidden_size=1024, num_layers=24, num_heads=8, ffn_intermediate=4096,
+                       vocab_size=8193, num_lstm_layers=2, ctc_vocab_size=0, joint_prefix="joint_.", blank_id=1024)
+
+
 def make_tiny_config(**kw) -> ModelConfig:
     """Small model of the same architecture for fast parity tests (not a reference preset)."""
     cfg = ModelConfig(name="tiny", mel_bins=80, subsampling_channels=32, hidden_size=128, num_layers=2,
@@ -68,5 +75,6 @@ PRESETS = {
     "tdt-ctc-110m": make_110m_config,
     "tdt-600m": make_tdt_600m_config,
     "rnnt-600m": make_rnnt_600m_config,
+    "nemotron-600m": make_nemotron_600m_config,
     "tiny": make_tiny_config,
 }

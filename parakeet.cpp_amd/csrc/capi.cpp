@@ -30,6 +30,17 @@ static void need(bool ok, const char *what) {
     if (!ok) fail(PK_ERR_INVALID, "invalid argument: %s", what);
 }
 
+// Token arrays come back as whole [B][pitch] blocks; the device only writes the first lens[b] entries of a row.  Zero the rest
+// on the host so that a caller comparing / hashing whole arrays sees deterministic contents (never stale device memory).
+template <class T>
+static void zero_tail(T *a, const int32_t *lens, int B, int pitch) {
+    if (!a) return;
+    for (int b = 0; b < B; ++b) {
+        const int n = lens[b] < 0 ? 0 : (lens[b] < pitch ? lens[b] : pitch);
+        for (int i = n; i < pitch; ++i) a[(size_t)b * pitch + i] = T(0);
+    }
+}
+
 extern "C" {
 
 const char *pk_version(void) { return "parakeet.cpp_amd 0.1 (gfx950)"; }
@@ -69,6 +80,11 @@ pk_status pk_config_preset(const char *name, pk_config *out) {
         } else if (n == "rnnt-600m") {          // make_rnnt_600m_config, config.hpp:119-135
             c.hidden_size = 1024; c.num_layers = 24; c.ffn_intermediate = 4096; c.vocab_size = 1025; c.num_lstm_layers = 2;
             c.num_durations = 0; c.ctc_vocab_size = 0; c.blank_id = 1024; c.rnnt_head = 1;
+            snprintf(c.joint_prefix, sizeof c.joint_prefix, "joint_.");
+        } else if (n == "nemotron-600m") {      // make_nemotron_600m_config, nemotron.hpp:31-52 (streaming: use with pk_stream_*)
+            c.hidden_size = 1024; c.num_layers = 24; c.ffn_intermediate = 4096; c.vocab_size = 8193; c.num_lstm_layers = 2;
+            c.num_durations = 5; c.ctc_vocab_size = 0;
+            c.blank_id = 1024;                  // transcribe_chunk decodes with the DEFAULT blank_id of eou.hpp:91-94 (nemotron.cpp:40-42): kept literally
             snprintf(c.joint_prefix, sizeof c.joint_prefix, "joint_.");
         } else {
             fail(PK_ERR_INVALID, "unknown preset '%s'", name);
@@ -157,6 +173,7 @@ pk_status pk_encode(pk_model *h, const float *feats, int B, int Tm, int stop_lay
 
 static void size_ws_for_T(Model &m, int B, int T);
 
+
 pk_status pk_conformer_blocks(pk_model *h, const float *x_in, int B, int T, int first_layer, int n_layers, float *x_out) {
     return guard([&] {
         need(h && x_in && x_out && B > 0 && T > 0, "model/x_in/x_out/B/T");
@@ -197,6 +214,7 @@ pk_status pk_ctc_decode(pk_model *h, const float *enc, int B, int T, int32_t *id
         if (conf) PK_HIP(hipMemcpyAsync(conf, m.ws.conf.p, rows * 4, hipMemcpyDeviceToHost, m.stream));
         if (logp) PK_HIP(hipMemcpyAsync(logp, m.ws.ctc_lp.p, rows * m.cfg.ctc_vocab_size * 4, hipMemcpyDeviceToHost, m.stream));
         PK_HIP(hipStreamSynchronize(m.stream));
+        zero_tail(ids, lens, B, T); zero_tail(start, lens, B, T); zero_tail(end, lens, B, T); zero_tail(conf, lens, B, T);
     });
 }
 
@@ -220,6 +238,7 @@ pk_status pk_tdt_decode(pk_model *h, const float *enc, int B, int T, int max_tok
         if (conf) PK_HIP(hipMemcpyAsync(conf, m.ws.conf.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
         if (steps) PK_HIP(hipMemcpyAsync(steps, m.ws.ints.as<int>() + 4 * B, (size_t)B * 4, hipMemcpyDeviceToHost, m.stream));
         PK_HIP(hipStreamSynchronize(m.stream));
+        zero_tail(ids, lens, B, max_tokens); zero_tail(start, lens, B, max_tokens); zero_tail(end, lens, B, max_tokens); zero_tail(conf, lens, B, max_tokens);
         for (int b = 0; b < B; ++b)
             if (lens[b] < 0) cap_hit = PK_ERR_DECODE_CAP;
     });
@@ -376,6 +395,7 @@ pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *st
             if (end) pitch(end, w.end.p);
             if (conf) pitch(conf, w.conf.p);
         }
+        zero_tail(ids, lens, B, mt); zero_tail(start, lens, B, mt); zero_tail(end, lens, B, mt); zero_tail(conf, lens, B, mt);
     });
 }
 

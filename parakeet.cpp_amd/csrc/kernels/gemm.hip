@@ -203,7 +203,11 @@ static void launch_epi(const GemmArgs &a, hipStream_t s) {
     else launch_gemm_pipe<2, 2, 1, 1, 32, EPI>(a, s);
 }
 
+void launch_gemm_smallm(const GemmArgs &a, int epi, hipStream_t s);   // kernels/gemm_smallm.hip
+
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
+    // a handful of rows (streaming chunks, tiny test shapes): one wavefront per 16x16 tile instead of N/64 fat workgroups
+    if (a.M <= 64 && a.K % 64 == 0) { launch_gemm_smallm(a, epi, s); return; }
     switch (epi) {
     case EPI_NONE: launch_epi<EPI_NONE>(a, s); break;
     case EPI_RELU: launch_epi<EPI_RELU>(a, s); break;

@@ -260,9 +260,17 @@ static void fetch_tokens(Model &m, Workspace &wd, int S, int max_tokens, int fra
     PK_HIP(hipStreamSynchronize(st));
     for (int s = 0; s < S; ++s) {
         if (lens[s] < 0) fail(PK_ERR_DECODE_CAP, "stream %d: TDT loop hit the safety cap", s);
-        for (int i = 0; i < lens[s]; ++i) {                        // frames relative to the stream (src/eou.cpp:77-79)
-            if (start) start[(size_t)s * max_tokens + i] += frame_offset;
-            if (end) end[(size_t)s * max_tokens + i] += frame_offset;
+        for (int i = 0; i < max_tokens; ++i) {
+            const size_t o = (size_t)s * max_tokens + i;
+            if (i < lens[s]) {                                      // frames relative to the stream (src/eou.cpp:77-79)
+                if (start) start[o] += frame_offset;
+                if (end) end[o] += frame_offset;
+            } else {                                                // never hand stale device memory to the caller
+                ids[o] = 0;
+                if (start) start[o] = 0;
+                if (end) end[o] = 0;
+                if (conf) conf[o] = 0.0f;
+            }
         }
     }
 }

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4]: nemotron-600m streaming, 16 concurrent lock-step streams on one GPU, 2560-sample (160 ms) chunks, cached
+encoder state.  Prints one JSON line: per-chunk latency (median / p95 over the timed chunks, host wall clock around pk_stream_push
+including the token copy-back) and aggregate RTFx = streams x chunk seconds / latency.
+usage: python tools/bench_stream.py [--streams 16] [--latency-frames 1] [--chunks 200] [--config nemotron-600m]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=16)
+    ap.add_argument("--latency-frames", type=int, default=1)
+    ap.add_argument("--chunks", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chunk-samples", type=int, default=2560)
+    ap.add_argument("--config", default="nemotron-600m")
+    a = ap.parse_args()
+    import pkload
+    pk = pkload.load()
+    from parakeet_cpp_amd import capi, synth, config
+    import bench
+    cfg = config.PRESETS[a.config]()
+    path, _ = bench.weights_file(cfg)
+    m = capi.Model(path, cfg, device=0)
+    st = capi.Stream(m, a.streams, 70, a.latency_frames)
+    n = a.chunk_samples
+    pcm = synth.synth_pcm(a.streams, n * (a.warmup + a.chunks), seed=99)
+    lat, toks = [], 0
+    for i in range(a.warmup + a.chunks):
+        seg = np.ascontiguousarray(pcm[:, i * n:(i + 1) * n])
+        t0 = time.perf_counter()
+        r = st.push(seg)
+        dt = time.perf_counter() - t0
+        if i >= a.warmup:
+            lat.append(dt)
+            toks += int(r["lens"].sum())
+    lat = np.array(lat)
+    chunk_s = n / 16000.0
+    out = {"metric": f"streaming {a.config}: per-chunk latency and aggregate RTFx, {a.streams} lock-step streams/GPU, att_context_right={a.latency_frames}",
+           "streams": a.streams, "chunk_ms": chunk_s * 1e3, "latency_ms_median": round(float(np.median(lat)) * 1e3, 3),
+           "latency_ms_p95": round(float(np.percentile(lat, 95)) * 1e3, 3), "latency_ms_mean": round(float(lat.mean()) * 1e3, 3),
+           "aggregate_rtfx": round(a.streams * chunk_s / float(lat.mean()), 1), "tokens_emitted": toks, "chunks": a.chunks,
+           "dtype": "f32", "data": "synthetic"}
+    print(json.dumps(out))
+    st.close(); m.close()
+
+
+if __name__ == "__main__":
+    main()
