@@ -8,8 +8,8 @@
 //    workgroups (128 for N = 1024, M = 32), no barriers at all;
 //  * K advances in chunks of 64: the lane (row, quarter) loads one float4 of A and of W per 16 k (coalesced 64-byte row
 //    segments), parks it k-planar in LDS (plane k&3, so that the lane that feeds k = 4s + kq reads four consecutive steps with
-//    one ds_read_b128 -- the same trick as the attention kernel), the loads of chunk i+1 are in flight under the 16 MFMAs of
-//    chunk i;
+//    one ds_read_b128 -- the same trick as the attention kernel), the loads of the next three chunks are in flight under the
+//    MFMAs of chunk i;
 //  * GLU keeps the value and the gate tile of the same 16 columns in one wave (two interleaved chains).
 #include "../pk_devmath.h"
 #include "kernels.hpp"
@@ -39,24 +39,27 @@ __global__ __launch_bounds__(64) void gemm_smallm_kernel(GemmArgs g) {
         wrow = wrow < g.N ? wrow : g.N - 1;
         wp[b] = g.W + (int64_t)(b * g.N + wrow) * g.ldw + 4 * kq;
     }
-    float4 ra[4], rw[NB][4];
-    auto gload = [&](int kc) {
+    // register ring of DEPTH chunks: the loads of chunk i+DEPTH-1 are issued before chunk i is consumed, so ~DEPTH x 640 cycles of
+    // MFMA chain cover the L2 / HBM latency of the weight stream (one chunk ahead left every iteration waiting ~1 us)
+    constexpr int DEPTH = 4;
+    float4 ra[DEPTH][4], rw[DEPTH][NB][4];
+    auto gload = [&](int kc, int set) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            ra[q] = *reinterpret_cast<const float4 *>(ap + kc * KC + 16 * q);
+            ra[set][q] = *reinterpret_cast<const float4 *>(ap + kc * KC + 16 * q);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) rw[b][q] = *reinterpret_cast<const float4 *>(wp[b] + kc * KC + 16 * q);
+            for (int b = 0; b < NB; ++b) rw[set][b][q] = *reinterpret_cast<const float4 *>(wp[b] + kc * KC + 16 * q);
         }
     };
-    auto park = [&]() {                          // element k = 16q + 4kq + e  ->  plane e, row r, column (k >> 2) = 4q + kq
+    auto park = [&](int set) {                   // element k = 16q + 4kq + e  ->  plane e, row r, column (k >> 2) = 4q + kq
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float *a = As + r * PIT + 4 * q + kq;
-            a[0] = ra[q].x; a[PLANE] = ra[q].y; a[2 * PLANE] = ra[q].z; a[3 * PLANE] = ra[q].w;
+            a[0] = ra[set][q].x; a[PLANE] = ra[set][q].y; a[2 * PLANE] = ra[set][q].z; a[3 * PLANE] = ra[set][q].w;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 float *w = Ws + b * 4 * PLANE + r * PIT + 4 * q + kq;
-                w[0] = rw[b][q].x; w[PLANE] = rw[b][q].y; w[2 * PLANE] = rw[b][q].z; w[3 * PLANE] = rw[b][q].w;
+                w[0] = rw[set][b][q].x; w[PLANE] = rw[set][b][q].y; w[2 * PLANE] = rw[set][b][q].z; w[3 * PLANE] = rw[set][b][q].w;
             }
         }
     };
@@ -64,28 +67,36 @@ __global__ __launch_bounds__(64) void gemm_smallm_kernel(GemmArgs g) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = sm_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int nkc = g.K / KC;
-    gload(0);
-    for (int kc = 0; kc < nkc; ++kc) {
-        __builtin_amdgcn_wave_barrier();         // the previous chunk's fragment reads are done (single wavefront: program order)
-        park();
-        if (kc + 1 < nkc) gload(kc + 1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // the lane that feeds k = 4s + kq reads plane kq: steps s = 4f .. 4f+3 per ds_read_b128
-        const float *af = As + kq * PLANE + r * PIT;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const float4 a = *reinterpret_cast<const float4 *>(af + 4 * f);
-            float4 w[NB];
+    for (int j = 0; j < DEPTH - 1; ++j)
+        if (j < nkc) gload(j, j);
+    for (int kc0 = 0; kc0 < nkc; kc0 += DEPTH) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) w[b] = *reinterpret_cast<const float4 *>(Ws + b * 4 * PLANE + kq * PLANE + r * PIT + 4 * f);
+        for (int j = 0; j < DEPTH; ++j) {
+            const int kc = kc0 + j;
+            if (kc < nkc) {
+                __builtin_amdgcn_wave_barrier();     // the previous chunk's fragment reads are done (single wavefront: program order)
+                park(j);
+                if (kc + DEPTH - 1 < nkc) gload(kc + DEPTH - 1, (j + DEPTH - 1) % DEPTH);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // the lane that feeds k = 4s + kq reads plane kq: steps s = 4f .. 4f+3 per ds_read_b128
+                const float *af = As + kq * PLANE + r * PIT;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[b].x, acc[b], 0, 0, 0);
+                for (int f = 0; f < 4; ++f) {
+                    const float4 a = *reinterpret_cast<const float4 *>(af + 4 * f);
+                    float4 w[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[b].y, acc[b], 0, 0, 0);
+                    for (int b = 0; b < NB; ++b) w[b] = *reinterpret_cast<const float4 *>(Ws + b * 4 * PLANE + kq * PLANE + r * PIT + 4 * f);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[b].z, acc[b], 0, 0, 0);
+                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[b].x, acc[b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[b].w, acc[b], 0, 0, 0);
+                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[b].y, acc[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[b].z, acc[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[b].w, acc[b], 0, 0, 0);
+                }
+            }
         }
     }
     // epilogue: C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + i
