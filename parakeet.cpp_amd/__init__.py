@@ -7,8 +7,8 @@ library csrc/ builds (libparakeet_amd.so) plus the header-only C++ facade in
 parakeet.cpp_amd/include/parakeet/ that mirrors the reference's
 parakeet::Transcriber API.
 """
-from .config import (ModelConfig, PRESETS, make_110m_config, make_rnnt_600m_config,  # noqa: F401
+from .config import (ModelConfig, PRESETS, make_110m_config, make_nemotron_600m_config, make_rnnt_600m_config,  # noqa: F401
                      make_tdt_600m_config, make_tiny_config)
 
 __all__ = ["ModelConfig", "PRESETS", "make_110m_config", "make_tdt_600m_config",
-           "make_rnnt_600m_config", "make_tiny_config"]
+           "make_rnnt_600m_config", "make_nemotron_600m_config", "make_tiny_config"]

@@ -3,4 +3,5 @@
 #include "config.hpp"
 #include "timestamp.hpp"
 #include "transcribe.hpp"
+#include "nemotron.hpp"
 #include "vocab.hpp"

@@ -46,3 +46,35 @@ def test_transcriber_on_a_wav_matches_oracle(tmp_path, orc):
         assert starts == sorted(starts)                      # monotonic word timestamps (tests/test_all.cpp:946-963)
     bad = subprocess.run([EXE, wp, str(tmp_path / "missing_vocab.txt"), ap], capture_output=True, text=True)
     assert bad.returncode == 1 and "Cannot open vocab file" in bad.stderr
+
+
+def test_nemotron_transcriber_streams_a_wav(tmp_path, orc):
+    """parakeet::NemotronTranscriber (reference include/parakeet/nemotron.hpp:54-133): transcribe_chunk / get_text /
+    get_timestamped_tokens on 160 ms chunks of a WAV == the oracle's Stream.push on the same chunks (2-layer cut of the
+    nemotron-600m architecture; blank id 1024 as the reference's transcribe_chunk decodes)."""
+    import dataclasses
+    exe = os.path.join(ROOT, "parakeet.cpp_amd", "examples", "stream_wav")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    cfg = dataclasses.replace(pk.make_nemotron_600m_config(), num_layers=2, name="nemotron-2L")
+    W = synth.synth_weights(cfg, seed=9)
+    wp, vp, ap = str(tmp_path / "model.safetensors"), str(tmp_path / "vocab.txt"), str(tmp_path / "clip.wav")
+    synth.save_weights(wp, W)
+    pieces = synth.synth_vocab(cfg.vocab_size - 1)
+    synth.save_vocab(vp, pieces)
+    pcm = synth.synth_pcm(1, 2560 * 40, seed=33)[0]
+    synth.write_wav_pcm16(ap, pcm)
+    q = (np.clip(pcm, -1, 1) * 32767.0).astype("<i2").astype(np.float32) / 32768.0
+    st = orc.Stream(orc.Model(cfg, W), 70, 1)
+    ids, frames = [], []
+    for i in range(40):
+        r = st.push(q[i * 2560:(i + 1) * 2560])
+        if r is not None:
+            ids += r["ids"].tolist(); frames += list(zip(r["start"].tolist(), r["end"].tolist()))
+    out = subprocess.run([exe, wp, vp, ap, "2", "2560", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout)
+    assert [t[0] for t in r["tokens"]] == ids and [(t[1], t[2]) for t in r["tokens"]] == frames
+    assert len(ids) > 0, "degenerate test: nothing decoded"
+    text = "".join(pieces[i] for i in ids).replace("▁", " ")
+    assert r["text"] == (text[1:] if text.startswith(" ") else text)
