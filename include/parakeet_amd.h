@@ -178,6 +178,11 @@ void pk_results_free(pk_result *results, int n_clips);
 /* read_audio (audio_io.cpp:453-483) restricted to RIFF/WAVE PCM16 / float32; mono-downmix; must be 16 kHz.
  * Returns a malloc'd buffer the caller frees with pk_free. */
 pk_status pk_read_wav(const char *path, float **pcm, int64_t *n_samples, int *sample_rate);
+/* read_audio(path, target_sample_rate) (audio_io.cpp:453-483) for RIFF/WAVE files: decode, mono downmix (sum * 1/channels,
+ * :198-214) and resampling to target_rate with the reference's Kaiser-windowed sinc interpolator (sinc_resample, :123-195; fp64,
+ * beta 7.857, 16-tap half width).  FLAC / MP3 / OGG are not decoded.  pk_resample: the resampler alone (resample(), :250-262). */
+pk_status pk_read_audio(const char *path, int target_rate, float **pcm, int64_t *n_samples, int *original_rate);
+pk_status pk_resample(const float *pcm, int64_t n, int src_rate, int dst_rate, float **out, int64_t *n_out);
 void pk_free(void *p);
 
 /* ---- streaming: NemotronTranscriber / StreamingTranscriber::transcribe_chunk (src/nemotron.cpp:24-52, src/eou.cpp:113-146) -------- */

@@ -161,6 +161,31 @@ def diag_math(fn, x):
     return y
 
 
+def resample(pcm, src_rate, dst_rate):
+    """pk_resample: the reference's Kaiser-windowed sinc resampler (src/audio_io.cpp:123-195)."""
+    pcm = _c(pcm)
+    L = lib()
+    L.pk_resample.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.POINTER(f32p), C.POINTER(C.c_int64)]
+    L.pk_free.argtypes = [C.c_void_p]
+    out, n = f32p(), C.c_int64(0)
+    check(L.pk_resample(_f(pcm), pcm.size, src_rate, dst_rate, C.byref(out), C.byref(n)))
+    r = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[: n.value].copy()
+    L.pk_free(out)
+    return r
+
+
+def read_audio(path, target_rate=16000):
+    """pk_read_audio: WAV -> mono -> resampled to target_rate; returns (pcm, original_rate)."""
+    L = lib()
+    L.pk_read_audio.argtypes = [C.c_char_p, C.c_int, C.POINTER(f32p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    L.pk_free.argtypes = [C.c_void_p]
+    out, n, sr = f32p(), C.c_int64(0), C.c_int(0)
+    check(L.pk_read_audio(path.encode(), target_rate, C.byref(out), C.byref(n), C.byref(sr)))
+    r = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[: n.value].copy()
+    L.pk_free(out)
+    return r, sr.value
+
+
 def diag_gemm(A, W, bias=None, epi="none", resid=None, alpha=1.0, bf16=False):
     A, W = _c(A), _c(W)
     M, K = A.shape

@@ -9,6 +9,7 @@
 namespace pk {
 const std::string &last_error();
 void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rate);
+void sinc_resample(const float *input, size_t input_len, int src_rate, int dst_rate, std::vector<float> &output);
 }
 
 using namespace pk;
@@ -588,6 +589,36 @@ pk_status pk_read_wav(const char *path, float **pcm, int64_t *n_samples, int *sa
         *pcm = p;
         *n_samples = (int64_t)mono.size();
         *sample_rate = sr;
+    });
+}
+/* read_audio(path, target_sample_rate) (audio_io.cpp:453-483) restricted to RIFF/WAVE: decode, mono downmix, resample to
+ * target_rate with the reference's Kaiser-windowed sinc (sinc_resample, :123-195). */
+pk_status pk_read_audio(const char *path, int target_rate, float **pcm, int64_t *n_samples, int *original_rate) {
+    return guard([&] {
+        need(path && pcm && n_samples && target_rate > 0, "path/pcm/n_samples/target_rate");
+        std::vector<float> mono, out;
+        int sr = 0;
+        read_wav(path, mono, sr);
+        if (original_rate) *original_rate = sr;
+        sinc_resample(mono.data(), mono.size(), sr, target_rate, out);
+        float *p = static_cast<float *>(malloc((out.size() ? out.size() : 1) * sizeof(float)));
+        if (!p) fail(PK_ERR_IO, "out of memory");
+        memcpy(p, out.data(), out.size() * sizeof(float));
+        *pcm = p;
+        *n_samples = (int64_t)out.size();
+    });
+}
+/* resample() / read_audio(const float *pcm, n, sample_rate, target) (audio_io.cpp:250-262,506-514). */
+pk_status pk_resample(const float *pcm, int64_t n, int src_rate, int dst_rate, float **out, int64_t *n_out) {
+    return guard([&] {
+        need(pcm && out && n_out && n >= 0 && src_rate > 0 && dst_rate > 0, "pcm/out/n/rates");
+        std::vector<float> r;
+        sinc_resample(pcm, (size_t)n, src_rate, dst_rate, r);
+        float *p = static_cast<float *>(malloc((r.size() ? r.size() : 1) * sizeof(float)));
+        if (!p) fail(PK_ERR_IO, "out of memory");
+        memcpy(p, r.data(), r.size() * sizeof(float));
+        *out = p;
+        *n_out = (int64_t)r.size();
     });
 }
 void pk_free(void *p) { free(p); }

@@ -1,7 +1,10 @@
-// parakeet.cpp_amd/csrc/wav.cpp -- minimal RIFF/WAVE reader (PCM16 / PCM24 / PCM32 / IEEE float32), mono downmix.
-// Stands in for the WAV branch of the reference's read_audio (src/audio_io.cpp:269-293,453-483: dr_wav ->
-// float32 in [-1,1] -> downmix_to_mono :198-214).  int16 -> float is /32768 as in the reference
-// (tests/test_all.cpp:483-721 "int16 -> f32 /32768").  Other containers / resampling are out of scope.
+// parakeet.cpp_amd/csrc/wav.cpp -- host-side audio ingestion: a RIFF/WAVE reader (PCM16 / PCM24 / PCM32 / IEEE float32), the
+// mono downmix and the Kaiser-windowed sinc resampler of the reference's read_audio (src/audio_io.cpp:269-293,453-483: dr_wav ->
+// float32 in [-1,1] -> downmix_to_mono :198-214 -> sinc_resample :123-195).  int16 -> float is /32768 as in the reference
+// (tests/test_all.cpp:483-721 "int16 -> f32 /32768").  Pinned against the reference's own object code
+// (oracle/_ref/libpk_ref_audio.so, tests/test_audio_vs_reference.py).  FLAC / MP3 / OGG containers are out of scope.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -61,7 +64,58 @@ void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rat
             else v = (float)((double)(int32_t)rd32(p) / 2147483648.0);
             acc += v;
         }
-        mono[i] = channels == 1 ? acc : acc / (float)channels;
+        mono[i] = channels == 1 ? acc : acc * (1.0f / (float)channels);       // downmix_to_mono: sum * inv_ch (:205-212)
+    }
+}
+
+// ---- sinc_resample (src/audio_io.cpp:100-195): Kaiser (beta 7.857, 16-tap half width) windowed sinc, fp64, normalised by the
+// sum of the weights; when downsampling the cutoff drops to dst/src and the window widens by src/dst.
+static double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 30; ++k) {
+        term *= (x * x) / (4.0 * k * k);
+        sum += term;
+        if (term < 1e-12 * sum) break;
+    }
+    return sum;
+}
+static double kaiser_window(double n, double N, double beta) {
+    const double arg = 2.0 * n / N - 1.0;
+    double val = 1.0 - arg * arg;
+    if (val < 0.0) val = 0.0;
+    return bessel_i0(beta * std::sqrt(val)) / bessel_i0(beta);
+}
+static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+void sinc_resample(const float *input, size_t input_len, int src_rate, int dst_rate, std::vector<float> &output) {
+    if (src_rate == dst_rate) { output.assign(input, input + input_len); return; }
+    const int g = gcd_int(src_rate, dst_rate), up = dst_rate / g, down = src_rate / g;
+    const size_t output_len = (size_t)(((int64_t)input_len * up + down - 1) / down);
+    output.resize(output_len);
+    constexpr int HALF_WIDTH = 16;
+    constexpr double BETA = 7.857;
+    const double ratio = (double)src_rate / dst_rate;
+    const double cutoff = std::min(1.0, 1.0 / std::max(ratio, 1.0));
+    const double filter_scale = cutoff;
+    const double sample_ratio = (double)dst_rate / src_rate;
+    const double width_factor = std::max(1.0, ratio);
+    for (size_t i = 0; i < output_len; ++i) {
+        const double src_pos = (double)i / sample_ratio;
+        const int center = (int)std::floor(src_pos);
+        double sum = 0.0, weight_sum = 0.0;
+        for (int j = center - HALF_WIDTH + 1; j <= center + HALF_WIDTH; ++j) {
+            if (j < 0 || j >= (int)input_len) continue;
+            const double dist = src_pos - j;
+            const double window_pos = dist / width_factor;
+            if (std::abs(window_pos) > HALF_WIDTH) continue;
+            const double w = kaiser_window(window_pos + HALF_WIDTH, 2.0 * HALF_WIDTH, BETA);
+            const double x = dist * cutoff * M_PI;
+            const double sinc_val = std::abs(x) < 1e-10 ? 1.0 : std::sin(x) / x;
+            const double weight = sinc_val * w * filter_scale;
+            sum += input[j] * weight;
+            weight_sum += weight;
+        }
+        output[i] = (weight_sum > 1e-10) ? (float)(sum / weight_sum) : 0.0f;
     }
 }
 

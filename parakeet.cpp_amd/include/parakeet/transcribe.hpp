@@ -6,7 +6,7 @@
 //  * the `const axiom::Tensor &samples` overloads become (const float *pcm, size_t n) / std::vector<float> -- the
 //    reference itself uses (const float*, size_t) for raw PCM in read_audio() and transcribe_chunk();
 //  * there is no CPU execution path: transcribe() places the model on GPU 0 on first use if to_gpu() was not called;
-//  * audio files: 16 kHz RIFF/WAVE only (no FLAC/MP3/OGG decoders, no resampler);
+//  * audio files: RIFF/WAVE only (any sample rate: resampled to 16 kHz with the reference's sinc resampler; no FLAC/MP3/OGG);
 //  * weights are loaded strictly (a missing / mis-shaped tensor throws instead of being ignored);
 //  * boost_phrases are accepted but ignored (phrase boosting is outside the accelerated path);
 //  * new: transcribe_batch() -- clips of equal length are decoded together (the reference is batch-1 only).
@@ -96,10 +96,8 @@ class Engine {   // owns one pk_model; shared by Transcriber and TDTTranscriber
         float *pcm = nullptr;
         int64_t n = 0;
         int sr = 0;
-        check(pk_read_wav(audio_path.c_str(), &pcm, &n, &sr));
+        check(pk_read_audio(audio_path.c_str(), 16000, &pcm, &n, &sr));   // read_audio(path): decode, downmix, resample to 16 kHz
         struct Free { float *p; ~Free() { pk_free(p); } } guard{pcm};
-        if (sr != 16000)   // preprocess_audio(AudioData): "Sample rate mismatch" (src/audio.cpp:161-165); no resampler here
-            throw std::runtime_error("Sample rate mismatch: audio=" + std::to_string(sr) + " expected=16000");
         return run({{pcm, (size_t)n}}, opts)[0];
     }
 
