@@ -75,7 +75,7 @@ typedef struct pk_config {
 } pk_config;
 
 /* make_110m_config / make_tdt_600m_config / make_rnnt_600m_config (config.hpp:77-135). name: "tdt-ctc-110m" | "tdt-600m" | "rnnt-600m" |
- * "nemotron-600m" (nemotron.hpp:31-52; streaming, see pk_stream_*). */
+ * "nemotron-600m" (nemotron.hpp:31-52) | "eou-120m" (eou.hpp:34-56) -- streaming models, see pk_stream_*. */
 pk_status pk_config_preset(const char *name, pk_config *out);
 
 typedef struct pk_model pk_model;

@@ -1007,6 +1007,112 @@ void orc_ctc_greedy(const float *logp, int B, int T, int V, int blank_id, int32_
 }
 
 /* ------------------------------------------------------------------------- */
+/* Phrase boosting -- ContextTrie (src/phrase_boost.cpp:9-66) and the boosted greedy decoders (:70-350)   */
+/* ------------------------------------------------------------------------- */
+struct orc_trie {
+    int n_nodes, cap;
+    int *first_child;      /* per node: head of its child list (-1 none) */
+    int *next_sibling;     /* per node: next child of the same parent */
+    int *token;            /* per node: the token on the edge from its parent */
+    int *depth;
+};
+orc_trie *orc_trie_new(void) {
+    orc_trie *t = (orc_trie *)calloc(1, sizeof(*t));
+    t->cap = 64;
+    t->first_child = (int *)xmalloc(sizeof(int) * t->cap); t->next_sibling = (int *)xmalloc(sizeof(int) * t->cap);
+    t->token = (int *)xmalloc(sizeof(int) * t->cap); t->depth = (int *)xmalloc(sizeof(int) * t->cap);
+    t->n_nodes = 1; t->first_child[0] = -1; t->next_sibling[0] = -1; t->token[0] = -1; t->depth[0] = 0;   /* root (:9) */
+    return t;
+}
+void orc_trie_free(orc_trie *t) { if (t) { free(t->first_child); free(t->next_sibling); free(t->token); free(t->depth); free(t); } }
+int orc_trie_size(const orc_trie *t) { return t->n_nodes; }
+static int trie_child(const orc_trie *t, int node, int tok) {
+    for (int c = t->first_child[node]; c >= 0; c = t->next_sibling[c])
+        if (t->token[c] == tok) return c;
+    return -1;
+}
+void orc_trie_insert(orc_trie *t, const int32_t *ids, int n) {                 /* :11-27 */
+    if (n <= 0) return;
+    int node = 0;
+    for (int i = 0; i < n; ++i) {
+        int c = trie_child(t, node, ids[i]);
+        if (c < 0) {
+            if (t->n_nodes == t->cap) {
+                t->cap *= 2;
+                t->first_child = (int *)realloc(t->first_child, sizeof(int) * t->cap); t->next_sibling = (int *)realloc(t->next_sibling, sizeof(int) * t->cap);
+                t->token = (int *)realloc(t->token, sizeof(int) * t->cap); t->depth = (int *)realloc(t->depth, sizeof(int) * t->cap);
+            }
+            c = t->n_nodes++;
+            t->first_child[c] = -1; t->token[c] = ids[i]; t->depth[c] = t->depth[node] + 1;
+            t->next_sibling[c] = t->first_child[node]; t->first_child[node] = c;
+        }
+        node = c;
+    }
+}
+/* the active-state set: root always in it after an advance (:52-66); at most one state per trie depth */
+typedef struct { int n; int s[256]; } trie_active;
+static void trie_mark(const orc_trie *t, const trie_active *a, unsigned char *flag, int V, int on) {   /* get_boosted_tokens :39-50 */
+    for (int i = 0; i < a->n; ++i)
+        for (int c = t->first_child[a->s[i]]; c >= 0; c = t->next_sibling[c])
+            if (t->token[c] >= 0 && t->token[c] < V) flag[t->token[c]] = (unsigned char)on;
+}
+static void trie_advance(const orc_trie *t, trie_active *a, int tok) {
+    trie_active nx;
+    nx.n = 1; nx.s[0] = 0;
+    for (int i = 0; i < a->n; ++i) {
+        const int c = trie_child(t, a->s[i], tok);
+        if (c >= 0 && nx.n < 256) {
+            int dup = 0;
+            for (int k = 0; k < nx.n; ++k) dup |= nx.s[k] == c;
+            if (!dup) nx.s[nx.n++] = c;
+        }
+    }
+    *a = nx;
+}
+static int argmax_boosted(const float *x, int n, const unsigned char *flag, float boost) {   /* strict '>' on value + boost (:88-97) */
+    int best = 0;
+    float bv = x[0] + (flag[0] ? boost : 0.0f);
+    for (int v = 1; v < n; ++v) {
+        const float val = x[v] + (flag[v] ? boost : 0.0f);
+        if (val > bv) { bv = val; best = v; }
+    }
+    return best;
+}
+
+/* ctc_greedy_decode(_with_timestamps)_boosted -- src/phrase_boost.cpp:70-171.  Same outputs as orc_ctc_greedy; the confidence
+ * is exp of the UNBOOSTED log-prob (:151-152). */
+void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
+                            int32_t *lens, int32_t *start, int32_t *end, float *conf) {
+    unsigned char *flag = (unsigned char *)calloc((size_t)V, 1);
+    for (int b = 0; b < B; ++b) {
+        int prev = -1, n = 0;
+        trie_active act;
+        act.n = 1; act.s[0] = 0;
+        for (int t = 0; t < T; ++t) {
+            const float *frame = logp + ((int64_t)b * T + t) * V;
+            trie_mark(trie, &act, flag, V, 1);
+            const int best = argmax_boosted(frame, V, flag, boost);
+            trie_mark(trie, &act, flag, V, 0);
+            if (best != prev) {
+                if (prev != -1 && prev != blank_id && n > 0 && end) end[(int64_t)b * T + n - 1] = t - 1;
+                if (best != blank_id) {
+                    ids[(int64_t)b * T + n] = best;
+                    if (start) start[(int64_t)b * T + n] = t;
+                    if (end) end[(int64_t)b * T + n] = t;
+                    if (conf) conf[(int64_t)b * T + n] = orc_expf(frame[best]);
+                    ++n;
+                    trie_advance(trie, &act, best);                                /* advance on actual emission :103-105 */
+                }
+            }
+            prev = best;
+        }
+        if (n > 0 && end) end[(int64_t)b * T + n - 1] = T - 1;
+        lens[b] = n;
+    }
+    free(flag);
+}
+
+/* ------------------------------------------------------------------------- */
 /* a11/a12/a13/a14: prediction net, joint, TDT / RNNT greedy                  */
 /* src/rnnt.cpp:22-28,37-44,56-111 ; src/lstm.cpp:11-49 ; src/tdt.cpp:15-24,36-201 */
 /* ------------------------------------------------------------------------- */
@@ -1100,7 +1206,8 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
                          int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps,
                          float *first_label_logp /* optional [B][V]: label log-probs of the first joint call */,
                          float *state_hc /* optional [B][2][L][Hp] carried LSTM state (in/out); NULL: zeros */,
-                         int32_t *state_token /* optional [B] carried last token (in/out); NULL: blank */, int clamp_end) {
+                         int32_t *state_token /* optional [B] carried last token (in/out); NULL: blank */, int clamp_end,
+                         const orc_trie *trie /* optional phrase-boost trie (src/phrase_boost.cpp:177-350) */, float boost) {
     const orc_config *c = &m->cfg;
     dec_weights w;
     if (dec_weights_get(m, &w, 0)) return -1;
@@ -1119,6 +1226,9 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
         float *scratch = (float *)xmalloc((size_t)(8 * Hp + J) * sizeof(float));
         float *lab = (float *)xmalloc((size_t)V * 2 * sizeof(float)), *lab_lp = lab + V;
         float dur[16], dur_lp[16];
+        unsigned char *flag = trie ? (unsigned char *)calloc((size_t)V, 1) : NULL;
+        trie_active act;
+        act.n = 1; act.s[0] = 0;
         int token = state_token ? state_token[b] : c->blank_id, t = 0, n = 0, nsteps = 0, bad = 0;
         while (t < T && !bad) {
             const float *ept = ep + ((int64_t)b * T + t) * J;
@@ -1135,7 +1245,14 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
                 log_softmax_row(dur, D, dur_lp);
                 if (nsteps == 0 && first_label_logp) memcpy(first_label_logp + (int64_t)b * V, lab_lp, (size_t)V * sizeof(float));
                 ++nsteps;
-                const int k = argmax_first(lab_lp, V);                     /* :78-82 */
+                int k;
+                if (trie) {                                                /* argmax of log-prob + boost for the trie's next tokens (phrase_boost.cpp:301-312) */
+                    trie_mark(trie, &act, flag, V, 1);
+                    k = argmax_boosted(lab_lp, V, flag, boost);
+                    trie_mark(trie, &act, flag, V, 0);
+                } else {
+                    k = argmax_first(lab_lp, V);                           /* :78-82 */
+                }
                 const int di = argmax_first(dur_lp, D);
                 const int skip = di < D ? c->durations[di] : 1;            /* :84-86 */
                 if (k == c->blank_id) {
@@ -1155,6 +1272,7 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
                 }
                 ++n;
                 token = k;
+                if (trie) trie_advance(trie, &act, k);                     /* phrase_boost.cpp:336 */
                 if (skip > 0) { t += skip; break; }
                 /* skip == 0: stay on this frame; if the for runs out t is NOT advanced (:66,99-105) */
             }
@@ -1164,6 +1282,7 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
         overflow |= bad;
         if (state_hc) memcpy(state_hc + (int64_t)b * 2 * w.L * Hp, h, (size_t)w.L * Hp * 2 * sizeof(float));
         if (state_token) state_token[b] = token;
+        free(flag);
         free(h); free(sh); free(pred); free(z); free(scratch); free(lab);
     }
     free(ep);
@@ -1171,7 +1290,12 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
 }
 int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, int32_t *ids,
                    int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps, float *first_label_logp) {
-    return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, first_label_logp, NULL, NULL, 1);
+    return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, first_label_logp, NULL, NULL, 1, NULL, 0.0f);
+}
+/* tdt_greedy_decode(_with_timestamps)_boosted -- src/phrase_boost.cpp:177-350 (confidence = exp of the unboosted log-prob, :313-315) */
+int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
+                           int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps) {
+    return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, NULL, NULL, NULL, 1, trie, boost);
 }
 
 /* rnnt_greedy_decode(+_with_timestamps): src/rnnt.cpp:56-111, :115-177 ; RNNTJoint::forward :37-44 */
@@ -1471,7 +1595,7 @@ int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc,
 int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf) {
     int32_t len = 0, steps = 0;
     const int cap = c * (s->m->cfg.max_symbols + 1) + 16;
-    const int r = tdt_greedy_ex(s->m, enc, 1, c, max_tokens, cap, ids, &len, start, end, conf, &steps, NULL, s->hc, &s->token, 0);
+    const int r = tdt_greedy_ex(s->m, enc, 1, c, max_tokens, cap, ids, &len, start, end, conf, &steps, NULL, s->hc, &s->token, 0, NULL, 0.0f);
     if (r || len < 0) return orc_fail("orc_stream_decode: decode cap hit");
     for (int i = 0; i < len; ++i) { if (start) start[i] += s->frame_offset; if (end) end[i] += s->frame_offset; }
     s->frame_offset += c;

@@ -7,6 +7,17 @@
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
+/* ---- phrase boosting: ContextTrie + boosted greedy decoders (src/phrase_boost.cpp) ---- */
+typedef struct orc_trie orc_trie;
+orc_trie *orc_trie_new(void);
+void orc_trie_free(orc_trie *t);
+void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
+int orc_trie_size(const orc_trie *t);
+void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
+                            int32_t *lens, int32_t *start, int32_t *end, float *conf);
+int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
+                           int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps);
+
 /* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
 typedef struct orc_stream orc_stream;
 orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);
@@ -85,6 +96,17 @@ int orc_rnnt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens
                     int32_t *start, float *conf);
 #ifdef __cplusplus
 }
+/* ---- phrase boosting: ContextTrie + boosted greedy decoders (src/phrase_boost.cpp) ---- */
+typedef struct orc_trie orc_trie;
+orc_trie *orc_trie_new(void);
+void orc_trie_free(orc_trie *t);
+void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
+int orc_trie_size(const orc_trie *t);
+void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
+                            int32_t *lens, int32_t *start, int32_t *end, float *conf);
+int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
+                           int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps);
+
 /* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
 typedef struct orc_stream orc_stream;
 orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);
@@ -94,6 +116,17 @@ int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc,
 int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
 
 #endif
+/* ---- phrase boosting: ContextTrie + boosted greedy decoders (src/phrase_boost.cpp) ---- */
+typedef struct orc_trie orc_trie;
+orc_trie *orc_trie_new(void);
+void orc_trie_free(orc_trie *t);
+void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
+int orc_trie_size(const orc_trie *t);
+void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
+                            int32_t *lens, int32_t *start, int32_t *end, float *conf);
+int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
+                           int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps);
+
 /* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
 typedef struct orc_stream orc_stream;
 orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);

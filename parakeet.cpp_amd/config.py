@@ -63,6 +63,10 @@ def make_nemotron_600m_config() -> ModelConfig:  # nemotron.hpp:31-52 (streaming
                        vocab_size=8193, num_lstm_layers=2, ctc_vocab_size=0, joint_prefix="joint_.", blank_id=1024)
 
 
+def make_eou_120m_config() -> ModelConfig:       # eou.hpp:34-56 (streaming; att_context 70 / 1); ParakeetEOU registers no CTC module
+    return ModelConfig(name="eou-120m", ctc_vocab_size=0, joint_prefix="joint_.")
+
+
 def make_tiny_config(**kw) -> ModelConfig:
     """Small model of the same architecture for fast parity tests (not a reference preset)."""
     cfg = ModelConfig(name="tiny", mel_bins=80, subsampling_channels=32, hidden_size=128, num_layers=2,
@@ -76,5 +80,6 @@ PRESETS = {
     "tdt-600m": make_tdt_600m_config,
     "rnnt-600m": make_rnnt_600m_config,
     "nemotron-600m": make_nemotron_600m_config,
+    "eou-120m": make_eou_120m_config,
     "tiny": make_tiny_config,
 }

@@ -82,6 +82,10 @@ pk_status pk_config_preset(const char *name, pk_config *out) {
             c.hidden_size = 1024; c.num_layers = 24; c.ffn_intermediate = 4096; c.vocab_size = 1025; c.num_lstm_layers = 2;
             c.num_durations = 0; c.ctc_vocab_size = 0; c.blank_id = 1024; c.rnnt_head = 1;
             snprintf(c.joint_prefix, sizeof c.joint_prefix, "joint_.");
+        } else if (n == "eou-120m") {           // make_eou_120m_config, eou.hpp:34-56 (streaming: use with pk_stream_*, context 70 / 1)
+            c.hidden_size = 512; c.num_layers = 17; c.ffn_intermediate = 2048; c.vocab_size = 1025; c.num_lstm_layers = 1;
+            c.num_durations = 5; c.ctc_vocab_size = 0; c.blank_id = 1024;
+            snprintf(c.joint_prefix, sizeof c.joint_prefix, "joint_.");
         } else if (n == "nemotron-600m") {      // make_nemotron_600m_config, nemotron.hpp:31-52 (streaming: use with pk_stream_*)
             c.hidden_size = 1024; c.num_layers = 24; c.ffn_intermediate = 4096; c.vocab_size = 8193; c.num_lstm_layers = 2;
             c.num_durations = 5; c.ctc_vocab_size = 0;

@@ -47,15 +47,39 @@ inline NemotronConfig make_nemotron_600m_config(int latency_frames = 0) {   // n
 
 using PartialResultCallback = std::function<void(const std::string &partial)>;
 
-class NemotronTranscriber {
+struct EOUConfig {                                 // include/parakeet/eou.hpp:25-32
+    StreamingEncoderConfig encoder;
+    PredictionConfig prediction;
+    JointConfig joint;
+    std::vector<int> durations = {0, 1, 2, 3, 4};
+    int eou_token_id = -1;
+    int ctc_vocab_size = 1025;
+};
+
+inline EOUConfig make_eou_120m_config() {          // eou.hpp:34-56
+    EOUConfig cfg;
+    detail::set_encoder(cfg.encoder, 80, 512, 17, 2048);
+    detail::set_decoder(cfg.prediction, cfg.joint, 512, 1025, 1);
+    cfg.encoder.att_context_left = 70;
+    cfg.encoder.att_context_right = 1;
+    cfg.encoder.chunk_size = 20;
+    cfg.eou_token_id = 1024;
+    return cfg;
+}
+
+namespace detail {
+
+/// One streaming session on pk_stream_* : the body shared by NemotronTranscriber and StreamingTranscriber (both are
+/// process_chunk -> forward_chunk -> rnnt_streaming_decode_chunk with the DEFAULT blank id 1024: nemotron.cpp:24-52, eou.cpp:113-146).
+class StreamSession {
   public:
-    NemotronTranscriber(const std::string &weights_path, const std::string &vocab_path, const NemotronConfig &config = make_nemotron_600m_config())
-        : config_(config),
-          eng_(weights_path, vocab_path,
-               detail::flatten(config.encoder, config.prediction, config.joint, config.durations, 0, "joint_.", false, /*blank_id=*/1024)) {}
-    ~NemotronTranscriber() { pk_stream_free(stream_); }
-    NemotronTranscriber(const NemotronTranscriber &) = delete;
-    NemotronTranscriber &operator=(const NemotronTranscriber &) = delete;
+    StreamSession(const std::string &weights_path, const std::string &vocab_path, const StreamingEncoderConfig &enc, const PredictionConfig &pred,
+                  const JointConfig &joint, const std::vector<int> &durations)
+        : left_(enc.att_context_left), right_(enc.att_context_right),
+          eng_(weights_path, vocab_path, flatten(enc, pred, joint, durations, 0, "joint_.", false, /*blank_id=*/1024)) {}
+    ~StreamSession() { pk_stream_free(stream_); }
+    StreamSession(const StreamSession &) = delete;
+    StreamSession &operator=(const StreamSession &) = delete;
 
     void to_gpu() { eng_.to_gpu(0); on_gpu_ = true; }
 
@@ -99,15 +123,38 @@ class NemotronTranscriber {
   private:
     void ensure_stream() {
         if (!on_gpu_) to_gpu();
-        if (!stream_) detail::check(pk_stream_create(eng_.handle(), 1, config_.encoder.att_context_left, config_.encoder.att_context_right, &stream_));
+        if (!stream_) detail::check(pk_stream_create(eng_.handle(), 1, left_, right_, &stream_));
     }
-    NemotronConfig config_;
+    int left_, right_;
     detail::Engine eng_;
     pk_stream *stream_ = nullptr;
     bool on_gpu_ = false;
     std::vector<int> tokens_;
     std::vector<TimestampedToken> timestamped_;
     PartialResultCallback partial_callback_;
+};
+
+}  // namespace detail
+
+/// parakeet::NemotronTranscriber (reference include/parakeet/nemotron.hpp:73-133)
+class NemotronTranscriber : public detail::StreamSession {
+  public:
+    NemotronTranscriber(const std::string &weights_path, const std::string &vocab_path, const NemotronConfig &config = make_nemotron_600m_config())
+        : detail::StreamSession(weights_path, vocab_path, config.encoder, config.prediction, config.joint, config.durations), config_(config) {}
+
+  private:
+    NemotronConfig config_;
+};
+
+/// parakeet::StreamingTranscriber (reference include/parakeet/eou.hpp:101-160): the EOU model's streaming session.  As in the
+/// reference's transcribe_chunk (src/eou.cpp:113-146) the end-of-utterance token id of the config takes no part in decoding.
+class StreamingTranscriber : public detail::StreamSession {
+  public:
+    StreamingTranscriber(const std::string &weights_path, const std::string &vocab_path, const EOUConfig &config = make_eou_120m_config())
+        : detail::StreamSession(weights_path, vocab_path, config.encoder, config.prediction, config.joint, config.durations), config_(config) {}
+
+  private:
+    EOUConfig config_;
 };
 
 }  // namespace parakeet
