@@ -152,9 +152,15 @@ typedef struct pk_kernel_stat {
 int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap);
 
 /* ---- one-call API: Transcriber::transcribe (transcribe.hpp:74-179) ---------------------------------------- */
-typedef struct pk_options {     /* TranscribeOptions (transcribe.hpp:38-43); boost phrases are out of scope */
+typedef struct pk_options {     /* TranscribeOptions (transcribe.hpp:38-43) */
     int32_t decoder;            /* PK_DECODER_* */
     int32_t timestamps;
+    /* boost_phrases / boost_score (transcribe.hpp:41-42): when n_boost_phrases > 0 the phrases are tokenised with the model's
+     * vocabulary (ContextTrie::build, src/phrase_boost.cpp:29-37) and this call decodes boosted; 0 phrases = the model-level
+     * setting of pk_set_boost_* (off by default).  boost_score is used as given (the reference's default is 5.0). */
+    const char *const *boost_phrases;
+    int32_t n_boost_phrases;
+    float boost_score;
 } pk_options;
 typedef struct pk_word {        /* WordTimestamp (timestamp.hpp:18-23) */
     const char *word;
@@ -237,6 +243,17 @@ int pk_vocab_size(const pk_model *m);
 int pk_detokenize(const pk_model *m, const int32_t *ids, int n, char *out, int cap);
 /* Tokenizer::encode (greedy longest match) -> number of ids (writes at most cap). */
 int pk_tokenize(const pk_model *m, const char *text, int32_t *ids, int cap);
+/* Phrase boosting (include/parakeet/phrase_boost.hpp:22-116, src/phrase_boost.cpp): a ContextTrie over token sequences biases
+ * the CTC / TDT greedy argmax by +boost_score towards tokens that continue a phrase.  The trie lives on the device with the
+ * model; once set, pk_ctc_decode, pk_tdt_decode, pk_batch_run and pk_transcribe_pcm decode boosted (confidences stay the
+ * unboosted probabilities).  n_phrases = 0 switches boosting off.  Phrases are limited to 63 tokens.  RNNT decode and streaming
+ * sessions have no boosted variant in the reference: PK_ERR_UNSUPPORTED while boosting is on.
+ * pk_set_boost_tokens: phrase i = ids[offsets[i] .. offsets[i+1])  (ContextTrie::insert, :11-27; empty phrases are ignored).
+ * pk_set_boost_phrases: ContextTrie::build (:29-37) -- Tokenizer::encode of each phrase; needs a vocabulary. */
+pk_status pk_set_boost_tokens(pk_model *m, const int32_t *ids, const int32_t *offsets, int n_phrases, float boost_score);
+pk_status pk_set_boost_phrases(pk_model *m, const char *const *phrases, int n_phrases, float boost_score);
+/* number of trie nodes (ContextTrie::size, 1 = root only), 0 when boosting is off */
+int pk_boost_trie_size(const pk_model *m);
 /* group_timestamps: words '\n'-joined into `words`; returns the word count. sentences!=0 -> TimestampMode::Sentences. */
 int pk_group_timestamps(const pk_model *m, const int32_t *ids, const int32_t *start, const int32_t *end, const float *conf,
                         int n, int sentences, char *words, int cap, float *wstart, float *wend, float *wconf, int wcap);

@@ -43,6 +43,9 @@ class OrcConfig(C.Structure):
                 ("joint_pred_bias", C.c_int), ("gemm_bf16", C.c_int), ("joint_prefix", C.c_char * 32)]
 
 
+f32p, i32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+
 def lib():
     global _LIB
     if _LIB is not None:
@@ -261,6 +264,20 @@ class Model:
             res["first_logp"] = fl
         return res
 
+    def tdt_greedy_boosted(self, enc, trie, boost=5.0, max_tokens=None, max_steps=0):
+        """tdt_greedy_decode(_with_timestamps)_boosted: src/phrase_boost.cpp:177-350."""
+        enc = _c(enc)
+        B, T, _ = enc.shape
+        mt = max_tokens or (T * self.cfg.max_symbols_per_step)
+        ids = np.zeros((B, mt), np.int32); st = np.zeros((B, mt), np.int32); en = np.zeros((B, mt), np.int32)
+        cf = np.zeros((B, mt), np.float32); lens = np.zeros(B, np.int32); steps = np.zeros(B, np.int32)
+        L = lib()
+        L.orc_tdt_greedy_boosted.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, i32p, i32p,
+                                             i32p, i32p, f32p, i32p]
+        r = self._chk(L.orc_tdt_greedy_boosted(self._h, _f(enc), B, T, mt, max_steps, trie._h, boost, _i(ids), _i(lens), _i(st),
+                                               _i(en), _f(cf), _i(steps)))
+        return dict(ids=ids, lens=lens, start=st, end=en, conf=cf, steps=steps, overflow=bool(r))
+
     def rnnt_greedy(self, enc, max_tokens=None):
         enc = _c(enc)
         B, T, _ = enc.shape
@@ -278,6 +295,65 @@ def ctc_greedy(logp, blank_id):
     ids = np.zeros((B, T), np.int32); st = np.zeros((B, T), np.int32); en = np.zeros((B, T), np.int32)
     cf = np.zeros((B, T), np.float32); lens = np.zeros(B, np.int32)
     lib().orc_ctc_greedy(_f(logp), B, T, V, blank_id, _i(ids), _i(lens), _i(st), _i(en), _f(cf))
+    return dict(ids=ids, lens=lens, start=st, end=en, conf=cf)
+
+
+class Trie:
+    """ContextTrie (include/parakeet/phrase_boost.hpp:22-57, src/phrase_boost.cpp:9-66)."""
+
+    def __init__(self, phrases=()):
+        L = lib()
+        L.orc_trie_new.restype = C.c_void_p
+        L.orc_trie_free.argtypes = [C.c_void_p]
+        L.orc_trie_insert.argtypes = [C.c_void_p, i32p, C.c_int]
+        L.orc_trie_size.argtypes = [C.c_void_p]
+        self._h = C.c_void_p(L.orc_trie_new())
+        for p in phrases:
+            self.insert(p)
+
+    def insert(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        lib().orc_trie_insert(self._h, _i(ids) if len(ids) else None, len(ids))
+
+    def size(self):
+        return lib().orc_trie_size(self._h)
+
+    def boosted_tokens(self, states, V=2048):
+        """get_boosted_tokens (src/phrase_boost.cpp:39-50) -> sorted token ids."""
+        st = np.ascontiguousarray(list(states), np.int32)
+        flag = np.zeros(V, np.uint8)
+        L = lib()
+        L.orc_trie_boosted_tokens.argtypes = [C.c_void_p, i32p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_trie_boosted_tokens(self._h, _i(st), len(st), flag.ctypes.data_as(C.c_void_p), V)
+        return set(np.nonzero(flag)[0].tolist())
+
+    def advance(self, states, tok):
+        """advance (src/phrase_boost.cpp:52-66) -> set of node ids (always holds the root)."""
+        st = np.ascontiguousarray(list(states), np.int32)
+        out = np.zeros(300, np.int32)
+        L = lib()
+        L.orc_trie_advance.argtypes = [C.c_void_p, i32p, C.c_int, C.c_int, i32p]
+        n = L.orc_trie_advance(self._h, _i(st), len(st), tok, _i(out))
+        return set(out[:n].tolist())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_trie_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def ctc_greedy_boosted(logp, blank_id, trie, boost=5.0):
+    """ctc_greedy_decode(_with_timestamps)_boosted: src/phrase_boost.cpp:70-171."""
+    logp = _c(logp)
+    B, T, V = logp.shape
+    ids = np.zeros((B, T), np.int32); st = np.zeros((B, T), np.int32); en = np.zeros((B, T), np.int32)
+    cf = np.zeros((B, T), np.float32); lens = np.zeros(B, np.int32)
+    L = lib()
+    L.orc_ctc_greedy_boosted.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, i32p, i32p, i32p, i32p, f32p]
+    L.orc_ctc_greedy_boosted(_f(logp), B, T, V, blank_id, trie._h, boost, _i(ids), _i(lens), _i(st), _i(en), _f(cf))
     return dict(ids=ids, lens=lens, start=st, end=en, conf=cf)
 
 

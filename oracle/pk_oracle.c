@@ -1069,6 +1069,27 @@ static void trie_advance(const orc_trie *t, trie_active *a, int tok) {
     }
     *a = nx;
 }
+/* test hooks for the reference's ContextTrie unit tests (tests/test_all.cpp:1280-1353) */
+int orc_trie_boosted_tokens(const orc_trie *t, const int32_t *states, int n, unsigned char *flag, int V) {
+    trie_active a;
+    a.n = 0;
+    for (int i = 0; i < n && a.n < 256; ++i)
+        if (states[i] >= 0 && states[i] < t->n_nodes) a.s[a.n++] = states[i];       /* out-of-range states are skipped (:43-44) */
+    memset(flag, 0, (size_t)V);
+    trie_mark(t, &a, flag, V, 1);
+    int c = 0;
+    for (int v = 0; v < V; ++v) c += flag[v];
+    return c;
+}
+int orc_trie_advance(const orc_trie *t, const int32_t *states, int n, int tok, int32_t *out) {
+    trie_active a;
+    a.n = 0;
+    for (int i = 0; i < n && a.n < 256; ++i)
+        if (states[i] >= 0 && states[i] < t->n_nodes) a.s[a.n++] = states[i];
+    trie_advance(t, &a, tok);
+    for (int i = 0; i < a.n; ++i) out[i] = a.s[i];
+    return a.n;
+}
 static int argmax_boosted(const float *x, int n, const unsigned char *flag, float boost) {   /* strict '>' on value + boost (:88-97) */
     int best = 0;
     float bv = x[0] + (flag[0] ? boost : 0.0f);

@@ -13,6 +13,8 @@ orc_trie *orc_trie_new(void);
 void orc_trie_free(orc_trie *t);
 void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
 int orc_trie_size(const orc_trie *t);
+int orc_trie_boosted_tokens(const orc_trie *t, const int32_t *states, int n, unsigned char *flag, int V);   /* -> count */
+int orc_trie_advance(const orc_trie *t, const int32_t *states, int n, int tok, int32_t *out);                /* -> count */
 void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
                             int32_t *lens, int32_t *start, int32_t *end, float *conf);
 int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
@@ -102,6 +104,8 @@ orc_trie *orc_trie_new(void);
 void orc_trie_free(orc_trie *t);
 void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
 int orc_trie_size(const orc_trie *t);
+int orc_trie_boosted_tokens(const orc_trie *t, const int32_t *states, int n, unsigned char *flag, int V);   /* -> count */
+int orc_trie_advance(const orc_trie *t, const int32_t *states, int n, int tok, int32_t *out);                /* -> count */
 void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
                             int32_t *lens, int32_t *start, int32_t *end, float *conf);
 int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
@@ -122,6 +126,8 @@ orc_trie *orc_trie_new(void);
 void orc_trie_free(orc_trie *t);
 void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
 int orc_trie_size(const orc_trie *t);
+int orc_trie_boosted_tokens(const orc_trie *t, const int32_t *states, int n, unsigned char *flag, int V);   /* -> count */
+int orc_trie_advance(const orc_trie *t, const int32_t *states, int n, int tok, int32_t *out);                /* -> count */
 void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
                             int32_t *lens, int32_t *start, int32_t *end, float *conf);
 int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,

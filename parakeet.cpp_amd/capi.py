@@ -41,7 +41,8 @@ class PkKernelStat(C.Structure):
 
 
 class PkOptions(C.Structure):
-    _fields_ = [("decoder", C.c_int32), ("timestamps", C.c_int32)]
+    _fields_ = [("decoder", C.c_int32), ("timestamps", C.c_int32), ("boost_phrases", C.POINTER(C.c_char_p)),
+                ("n_boost_phrases", C.c_int32), ("boost_score", C.c_float)]
 
 
 class PkWord(C.Structure):
@@ -122,6 +123,9 @@ _LATE_SIGNATURES = {
     "pk_vocab_size": [C.c_void_p],
     "pk_detokenize": [C.c_void_p, i32p, C.c_int, C.c_char_p, C.c_int],
     "pk_tokenize": [C.c_void_p, C.c_char_p, i32p, C.c_int],
+    "pk_set_boost_tokens": [C.c_void_p, i32p, i32p, C.c_int, C.c_float],
+    "pk_set_boost_phrases": [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_float],
+    "pk_boost_trie_size": [C.c_void_p],
     "pk_group_timestamps": [C.c_void_p, i32p, i32p, i32p, f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, f32p, f32p, f32p, C.c_int],
 }
 
@@ -296,6 +300,35 @@ def diag_sum64(x):
     return out
 
 
+class Batch:
+    """pk_batch: the resident pipeline (clips of one length stay in HBM; decode(k) overlaps encoder(k+1))."""
+
+    def __init__(self, model, max_clips, n_samples):
+        self._h = C.c_void_p()
+        self.n_clips = 0
+        check(lib().pk_batch_create(model._h, max_clips, n_samples, C.byref(self._h)))
+
+    def upload(self, pcm):
+        pcm = _c(pcm)
+        self.n_clips = pcm.shape[0]
+        check(lib().pk_batch_upload(self._h, _f(pcm), self.n_clips))
+
+    def run(self, decoder="tdt"):
+        check(lib().pk_batch_run(self._h, {"ctc": 0, "tdt": 1}[decoder]))
+
+    def results(self):
+        B, mt = self.n_clips, lib().pk_batch_max_tokens(self._h)
+        ids = np.zeros((B, mt), np.int32); st = np.zeros((B, mt), np.int32); en = np.zeros((B, mt), np.int32)
+        cf = np.zeros((B, mt), np.float32); lens = np.zeros(B, np.int32)
+        check(lib().pk_batch_results(self._h, _i(ids), _i(lens), _i(st), _i(en), _f(cf)))
+        return dict(ids=ids, lens=lens, start=st, end=en, conf=cf)
+
+    def close(self):
+        if self._h:
+            lib().pk_batch_free(self._h)
+            self._h = None
+
+
 # ---- model -------------------------------------------------------------------------------------------
 class Model:
     """Thin handle over pk_model (mirrors parakeet::Transcriber's ctor + to_gpu(), transcribe.hpp:59-71)."""
@@ -355,6 +388,55 @@ class Model:
         out = np.empty_like(x)
         n = self.cfg.num_layers - first_layer if n_layers is None else n_layers
         check(lib().pk_conformer_blocks(self._h, _f(x), B, T, first_layer, n, _f(out)))
+        return out
+
+    # phrase boosting (reference include/parakeet/phrase_boost.hpp) ------------------------------------------
+    def set_boost_tokens(self, phrases, boost_score=5.0):
+        """ContextTrie::insert of each token-id sequence; an empty list switches boosting off."""
+        flat = np.asarray([t for p in phrases for t in p], np.int32)
+        off = np.zeros(len(phrases) + 1, np.int32)
+        off[1:] = np.cumsum([len(p) for p in phrases])
+        check(lib().pk_set_boost_tokens(self._h, _i(flat) if len(flat) else _i(np.zeros(1, np.int32)), _i(off), len(phrases), boost_score))
+
+    def set_boost_phrases(self, phrases, boost_score=5.0):
+        """ContextTrie::build: Tokenizer::encode of each phrase (needs a vocabulary)."""
+        arr = (C.c_char_p * max(1, len(phrases)))(*[p.encode() for p in phrases])
+        check(lib().pk_set_boost_phrases(self._h, arr, len(phrases), boost_score))
+
+    def boost_trie_size(self):
+        return lib().pk_boost_trie_size(self._h)
+
+    def tokenize(self, text):
+        ids = np.zeros(4 * len(text.encode()) + 8, np.int32)
+        n = lib().pk_tokenize(self._h, text.encode(), _i(ids), len(ids))
+        return ids[:n].tolist()
+
+    def transcribe_pcm(self, clips, decoder="tdt", timestamps=False, boost_phrases=(), boost_score=5.0):
+        """pk_transcribe_pcm: Transcriber::transcribe (transcribe.hpp:91-180) on in-memory clips -> list of dicts."""
+        clips = [_c(c).ravel() for c in clips]
+        off = np.zeros(len(clips) + 1, np.int64)
+        off[1:] = np.cumsum([len(c) for c in clips])
+        pcm = np.concatenate(clips)
+        opt = PkOptions()
+        opt.decoder = {"ctc": 0, "tdt": 1}[decoder]
+        opt.timestamps = 1 if timestamps else 0
+        keep = (C.c_char_p * max(1, len(boost_phrases)))(*[p.encode() for p in boost_phrases])
+        opt.boost_phrases = keep
+        opt.n_boost_phrases = len(boost_phrases)
+        opt.boost_score = boost_score
+        res = C.POINTER(PkResult)()
+        check(lib().pk_transcribe_pcm(self._h, _f(pcm), off.ctypes.data_as(i64p), len(clips), C.byref(opt), C.byref(res)))
+        out = []
+        for i in range(len(clips)):
+            r = res[i]
+            d = dict(text=(r.text or b"").decode(), token_ids=[r.token_ids[k] for k in range(r.n_tokens)])
+            if timestamps:
+                d["start"] = [r.start_frame[k] for k in range(r.n_tokens)]
+                d["end"] = [r.end_frame[k] for k in range(r.n_tokens)]
+                d["conf"] = [r.confidence[k] for k in range(r.n_tokens)]
+                d["words"] = [(r.words[k].word.decode(), r.words[k].start, r.words[k].end, r.words[k].confidence) for k in range(r.n_words)]
+            out.append(d)
+        lib().pk_results_free(res, len(clips))
         return out
 
     def ctc_decode(self, enc, return_logp=False):

@@ -31,6 +31,19 @@ static void need(bool ok, const char *what) {
     if (!ok) fail(PK_ERR_INVALID, "invalid argument: %s", what);
 }
 
+// ContextTrie::build (src/phrase_boost.cpp:29-37): Tokenizer::encode of every phrase
+static std::vector<std::vector<int>> encode_phrases(Model &m, const char *const *phrases, int n) {
+    if (!m.tok.loaded()) fail(PK_ERR_INVALID, "boost phrases need a vocabulary (the model was loaded without one)");
+    std::vector<std::vector<int>> ph;
+    for (int i = 0; i < n; ++i) {
+        need(phrases[i] != nullptr, "phrases[i]");
+        auto v = m.tok.encode(phrases[i]);
+        if (!v.empty()) ph.push_back(std::move(v));               // ContextTrie::build skips phrases that encode to nothing
+    }
+    if (ph.empty() && n > 0) ph.emplace_back();                   // a root-only trie: boosting on, nothing boosted
+    return ph;
+}
+
 // Token arrays come back as whole [B][pitch] blocks; the device only writes the first lens[b] entries of a row.  Zero the rest
 // on the host so that a caller comparing / hashing whole arrays sees deterministic contents (never stale device memory).
 template <class T>
@@ -501,6 +514,17 @@ pk_status pk_transcribe_pcm(pk_model *h, const float *pcm, const int64_t *offset
         const int decoder = opt ? opt->decoder : PK_DECODER_TDT;
         const bool ts = opt && opt->timestamps;
         need(decoder == PK_DECODER_CTC || decoder == PK_DECODER_TDT, "options.decoder");
+        // per-call boost phrases (transcribe.hpp:110-115): the model-level setting comes back when the call ends
+        struct BoostScope {
+            Model &m; bool active = false; std::vector<std::vector<int>> saved; float saved_score = 0.0f;
+            ~BoostScope() { if (active) { try { m.set_boost(saved, saved_score); } catch (...) {} } }
+        } scope{m};
+        if (opt && opt->n_boost_phrases > 0) {
+            need(opt->boost_phrases != nullptr, "options.boost_phrases");
+            auto ph = encode_phrases(m, opt->boost_phrases, opt->n_boost_phrases);
+            scope.saved = m.boost_phrases; scope.saved_score = m.boost_score; scope.active = true;
+            m.set_boost(ph, opt->boost_score);
+        }
         auto store = std::make_unique<ResultStore>();
         ResultStore &R = *store;
         R.res.resize(n_clips + 1);            // one hidden trailing slot keeps the store pointer
@@ -648,6 +672,27 @@ int pk_tokenize(const pk_model *m, const char *text, int32_t *ids, int cap) {
     for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
     return (int)v.size();
 }
+
+pk_status pk_set_boost_tokens(pk_model *h, const int32_t *ids, const int32_t *offsets, int n_phrases, float boost_score) {
+    return guard([&] {
+        need(h && n_phrases >= 0 && (n_phrases == 0 || (ids && offsets)), "model/ids/offsets/n_phrases");
+        std::vector<std::vector<int>> ph;
+        for (int i = 0; i < n_phrases; ++i) {
+            need(offsets[i + 1] >= offsets[i], "offsets must be non-decreasing");
+            ph.emplace_back(ids + offsets[i], ids + offsets[i + 1]);
+        }
+        h->m->set_boost(ph, boost_score);
+    });
+}
+
+pk_status pk_set_boost_phrases(pk_model *h, const char *const *phrases, int n_phrases, float boost_score) {
+    return guard([&] {
+        need(h && n_phrases >= 0 && (n_phrases == 0 || phrases), "model/phrases/n_phrases");
+        h->m->set_boost(encode_phrases(*h->m, phrases, n_phrases), boost_score);
+    });
+}
+
+int pk_boost_trie_size(const pk_model *m) { return m && m->m->boost_on ? m->m->trie_nodes : 0; }
 
 int pk_group_timestamps(const pk_model *m, const int32_t *ids, const int32_t *start, const int32_t *end, const float *conf, int n,
                         int sentences, char *words, int cap, float *wstart, float *wend, float *wconf, int wcap) {

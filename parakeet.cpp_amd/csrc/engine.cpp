@@ -2,6 +2,7 @@
 #include "engine.hpp"
 
 #include <cmath>
+#include <map>
 #include <cstring>
 
 namespace pk {
@@ -480,15 +481,71 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
 }
 
 // CTCDecoder::forward + ctc_greedy_decode(_with_timestamps)  (src/ctc.cpp:12-25, :40-127)
+// ContextTrie::insert / build (src/phrase_boost.cpp:11-37) on the host, flattened to CSR for the decode kernels.
+void Model::set_boost(const std::vector<std::vector<int>> &phrases, float score) {
+    require_gpu();
+    boost_phrases = phrases;
+    boost_score = score;
+    boost_on = !phrases.empty();
+    trie_nodes = 0;
+    if (!boost_on) return;
+    std::vector<std::map<int, int>> kids(1);                       // node -> (token -> child), root = 0
+    for (const auto &ph : phrases) {
+        if ((int)ph.size() >= kTrieMaxActive)
+            fail(PK_ERR_INVALID, "boost phrase of %d tokens: at most %d are supported", (int)ph.size(), kTrieMaxActive - 1);
+        int node = 0;
+        for (int tk : ph) {
+            auto it = kids[node].find(tk);
+            if (it == kids[node].end()) {
+                const int next = (int)kids.size();
+                kids[node][tk] = next;
+                kids.emplace_back();
+                node = next;
+            } else {
+                node = it->second;
+            }
+        }
+    }
+    trie_nodes = (int)kids.size();
+    std::vector<int> off(kids.size() + 1, 0), tok, nd;
+    for (size_t i = 0; i < kids.size(); ++i) {
+        for (const auto &kv : kids[i]) { tok.push_back(kv.first); nd.push_back(kv.second); }
+        off[i + 1] = (int)tok.size();
+    }
+    if (tok.empty()) { tok.push_back(-1); nd.push_back(0); }       // root-only trie: keep the buffers non-empty
+    PK_HIP(hipStreamSynchronize(stream));                          // nothing in flight may still read the old trie
+    if (stream_dec) PK_HIP(hipStreamSynchronize(stream_dec));
+    trie_off.reserve(off.size() * 4); trie_tok.reserve(tok.size() * 4); trie_node.reserve(nd.size() * 4);
+    PK_HIP(hipMemcpy(trie_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    PK_HIP(hipMemcpy(trie_tok.p, tok.data(), tok.size() * 4, hipMemcpyHostToDevice));
+    PK_HIP(hipMemcpy(trie_node.p, nd.data(), nd.size() * 4, hipMemcpyHostToDevice));
+}
+TrieDev Model::trie_dev(Workspace &w, int B) {
+    TrieDev t{};
+    if (!boost_on) return t;
+    w.trie_act.reserve((size_t)B * (kTrieMaxActive + 1) * sizeof(int));
+    t.off = trie_off.as<int>(); t.tok = trie_tok.as<int>(); t.node = trie_node.as<int>();
+    t.n_nodes = trie_nodes; t.boost = boost_score;
+    t.act = w.trie_act.as<int>(); t.n_act = t.act + (size_t)B * kTrieMaxActive;
+    return t;
+}
+
 void Model::run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_logp, hipStream_t s) {
     if (cfg.ctc_vocab_size <= 0) fail(PK_ERR_UNSUPPORTED, "this model has no ctc_decoder_ head");
     const int V = cfg.ctc_vocab_size, d = cfg.hidden_size;
     const int64_t rows = (int64_t)B * T;
     gemm("ctc_head", d_enc, d, dec.ctc_w, d, dec.ctc_b, w.ctc_logits.as<float>(), V, (int)rows, V, d, EPI_NONE, nullptr, 0, 1.0f, s);
+    if (boost_on) want_logp = true;                                 // the boosted argmax needs the whole log-prob rows
     if (want_logp) w.ctc_lp.reserve((size_t)rows * V * 4);
     KL("logsoftmax_argmax", 0.0, (double)rows * V * 4,
        launch_logsoftmax_argmax(w.ctc_logits.as<float>(), rows, V, V, want_logp ? w.ctc_lp.as<float>() : nullptr, w.best_idx.as<int>(), w.best_lp.as<float>(), s));
     // CTC token arrays are [B][T]; they share the TDT output buffers (sized >= B*T)
+    if (boost_on) {
+        KL("ctc_boosted", 0.0, (double)rows * V * 4,
+           launch_ctc_boosted(w.ctc_lp.as<float>(), B, T, V, cfg.blank_id < V ? cfg.blank_id : V - 1, trie_dev(w, B), w.ids.as<int>(), w.lens.as<int>(),
+                              w.start.as<int>(), w.end.as<int>(), w.conf.as<float>(), s));
+        return;
+    }
     KL("ctc_collapse", 0.0, 0.0,
        launch_ctc_collapse(w.best_idx.as<int>(), w.best_lp.as<float>(), B, T, cfg.blank_id < V ? cfg.blank_id : V - 1, w.ids.as<int>(), w.lens.as<int>(),
                            w.start.as<int>(), w.end.as<int>(), w.conf.as<float>(), s));
@@ -504,6 +561,10 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
     st.B = B; st.T = T; st.V = V; st.D = D; st.L = L; st.Hp = Hp; st.blank = cfg.blank_id; st.max_symbols = cfg.max_symbols_per_step;
     st.max_tokens = max_tokens;
     st.keep_state = keep_state ? 1 : 0;
+    if (boost_on) {
+        if (cfg.rnnt_head || keep_state) fail(PK_ERR_UNSUPPORTED, "phrase boosting applies to the CTC and TDT greedy decoders only (src/phrase_boost.cpp)");
+        st.trie = trie_dev(w, B);
+    }
     st.max_steps = T * (cfg.max_symbols_per_step + 1) + 16;          // safety cap (the reference has none)
     for (int i = 0; i < D; ++i) st.durations[i] = cfg.durations[i];
     st.logits = w.logits.as<float>();

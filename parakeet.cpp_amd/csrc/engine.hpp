@@ -47,6 +47,7 @@ struct Workspace {
     DevBuf pcm, logmel, feats, a2, a3, a4, a5, flat, x, n, hbuf, qkv, ctx, g, dwb;
     DevBuf ctc_logits, ctc_lp, best_idx, best_lp;
     DevBuf ep, gh, gi, pp, z, logits, h, c, hn, cn, ints, ids, start, end, conf, lens;
+    DevBuf trie_act;            // phrase boosting: per-utterance active trie states [B][kTrieMaxActive] + counts [B]
     void size_for(const pk_config &cfg, int B, int64_t n_samples, int Tm);
 };
 
@@ -89,6 +90,17 @@ class Model {
     void run_layers(Workspace &w, int B, int first_layer, int stop_layer, int stop_stage, hipStream_t s);                 // w.x -> w.x
     void run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_logp, hipStream_t s);
     void run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s, bool keep_state = false);
+
+    // Phrase boosting (reference include/parakeet/phrase_boost.hpp:22-57, TranscribeOptions.boost_phrases transcribe.hpp:41-42):
+    // the ContextTrie of the tokenised phrases in CSR form on the device; CTC and TDT greedy decode then run boosted.
+    // phrases.empty() switches boosting off.  Not to be changed while a pipelined batch is in flight.
+    void set_boost(const std::vector<std::vector<int>> &phrases, float score);
+    bool boost_on = false;
+    float boost_score = 0.0f;
+    int trie_nodes = 0;
+    std::vector<std::vector<int>> boost_phrases;      // what the trie was built from (per-call overrides restore it)
+    DevBuf trie_off, trie_tok, trie_node;
+    TrieDev trie_dev(Workspace &w, int B);
 
     ProfileSink *prof = nullptr;
     void klaunch_begin(const char *name, double flops, double bytes, hipStream_t s);

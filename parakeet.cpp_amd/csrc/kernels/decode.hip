@@ -88,6 +88,103 @@ void launch_ctc_collapse(const int *best_idx, const float *best_lp, int B, int T
     hipLaunchKernelGGL(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, s, best_idx, best_lp, B, T, blank, ids, lens, start, end, conf);
 }
 
+// ctc_greedy_decode(_with_timestamps)_boosted (src/phrase_boost.cpp:70-171): the boosted argmax of frame t depends on the tokens
+// emitted before t (the trie's active states), so the frames of one utterance are walked in order by one 256-thread workgroup;
+// the utterances of the batch run side by side.  Outputs as ctc_collapse_kernel; confidence = exp(unboosted log-prob) (:151-152).
+__global__ __launch_bounds__(256) void ctc_boosted_kernel(const float *__restrict__ logp, int B, int T, int V, int blank, TrieDev trie,
+                                                          int *__restrict__ ids, int *__restrict__ lens, int *__restrict__ start,
+                                                          int *__restrict__ end, float *__restrict__ conf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned cb_sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int MW = (V + 31) >> 5;
+    unsigned *mask = cb_sm;                                         // [MW]
+    int *acts = reinterpret_cast<int *>(mask + MW);                 // [2][1 + kTrieMaxActive] (count first), double-buffered
+    float *red = reinterpret_cast<float *>(acts + 2 * (1 + kTrieMaxActive));   // [2][8]: best val, best idx per wavefront
+    int cur = 0;
+    if (tid == 0) { acts[0] = 1; acts[1] = 0; }
+    auto rebuild = [&](const int *set) {                            // mask = union of the children of the active states
+        for (int i = tid; i < MW; i += 256) mask[i] = 0u;
+        __syncthreads();
+        const int n = set[0];
+        for (int a = 0; a < n; ++a) {
+            const int sn = set[1 + a];
+            const int c1 = trie.off[sn + 1];
+            for (int c = trie.off[sn] + tid; c < c1; c += 256) {
+                const int tk = trie.tok[c];
+                if (tk >= 0 && tk < V) atomicOr(&mask[tk >> 5], 1u << (tk & 31));
+            }
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+    rebuild(acts);
+    int prev = -1, n = 0;
+    for (int t = 0; t < T; ++t) {
+        const float *frame = logp + ((int64_t)b * T + t) * V;
+        float best = -__builtin_huge_valf();
+        int bi = 0x7fffffff;
+        for (int i = tid; i < V; i += 256) {
+            const float v = frame[i] + (((mask[i >> 5] >> (i & 31)) & 1u) ? trie.boost : 0.0f);
+            if (bi == 0x7fffffff || v > best) { best = v; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        float *rd = red + 8 * (t & 1);                               // double-buffered: one barrier per frame
+        if (lane == 0) { rd[wave] = best; rd[4 + wave] = __int_as_float(bi); }
+        __syncthreads();
+        best = rd[0]; bi = __float_as_int(rd[4]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ob = rd[w];
+            const int oi = __float_as_int(rd[4 + w]);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (bi != prev) {                                            // block-uniform control flow
+            if (tid == 0 && prev != -1 && prev != blank && n > 0) end[(int64_t)b * T + n - 1] = t - 1;
+            if (bi != blank) {
+                if (tid == 0) {
+                    ids[(int64_t)b * T + n] = bi;
+                    start[(int64_t)b * T + n] = t;
+                    end[(int64_t)b * T + n] = t;
+                    conf[(int64_t)b * T + n] = dexpf(frame[bi]);
+                }
+                ++n;
+                int *src = acts + cur * (1 + kTrieMaxActive), *dst = acts + (cur ^ 1) * (1 + kTrieMaxActive);
+                if (tid == 0) { dst[0] = 1; dst[1] = 0; }
+                __syncthreads();
+                const int na = src[0];
+                for (int a = 0; a < na; ++a) {
+                    const int sn = src[1 + a];
+                    const int c1 = trie.off[sn + 1];
+                    for (int c = trie.off[sn] + tid; c < c1; c += 256)
+                        if (trie.tok[c] == bi) {
+                            const int slot = atomicAdd(&dst[0], 1);
+                            if (slot < kTrieMaxActive) dst[1 + slot] = trie.node[c];
+                        }
+                }
+                __syncthreads();
+                if (tid == 0 && dst[0] > kTrieMaxActive) dst[0] = kTrieMaxActive;
+                cur ^= 1;
+                rebuild(dst);
+            }
+        }
+        prev = bi;
+    }
+    if (tid == 0) {
+        if (n > 0) end[(int64_t)b * T + n - 1] = T - 1;
+        lens[b] = n;
+    }
+}
+void launch_ctc_boosted(const float *logp, int B, int T, int V, int blank, const TrieDev &trie, int *ids, int *lens, int *start, int *end,
+                        float *conf, hipStream_t s) {
+    const size_t lds = (size_t)((V + 31) / 32 + 2 * (1 + kTrieMaxActive) + 16) * sizeof(int);
+    hipLaunchKernelGGL(ctc_boosted_kernel, dim3(B), dim3(256), lds, s, logp, B, T, V, blank, trie, ids, lens, start, end, conf);
+}
+
 // ---- TDT / RNNT step kernels --------------------------------------------------------------------------
 // LSTMCell::forward (src/lstm.cpp:11-29), gate order i,f,g,o.  gi = W_ih x + b (layer 0: row `token` of the
 // precomputed table g1 = W_ih E + b), gh = W_hh h.  Writes CANDIDATE states hn/cn; tdt_decide commits them.
@@ -136,13 +233,27 @@ void launch_joint_act(const float *ep, const int *t, int T, int J, const float *
 // tdt_greedy_decode (src/tdt.cpp:62-106; timestamps :157-187) or rnnt_greedy_decode (src/rnnt.cpp:75-107).
 // The logits row is staged in LDS once; exp() is evaluated by all four wavefronts, the canonical sum64 by one
 // (the summation ORDER is part of the numerics contract; who evaluates the terms is not).
+// BOOST (phrase boosting, src/phrase_boost.cpp:177-350): the label argmax runs over log-prob + boost for the tokens that continue
+// an active trie state (a V-bit mask in LDS, rebuilt from the CSR children every step); the confidence stays the raw log-prob
+// and the active set advances on every emission.
+template <bool BOOST>
 __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];     // x[V+D], e[V+D], scratch[16]
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // x[V+D], e[V+D], scratch[16] (+ BOOST: mask, active sets)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (st.done[b]) return;
     const int VD = st.V + st.D;
     float *x = sm, *e = sm + VD;
     float *red = e + VD;                                           // [0..3] wave maxima, [4] lse, [8..11] best val, [12..15] best idx
+    const int MW = (st.V + 31) >> 5;
+    unsigned *mask = reinterpret_cast<unsigned *>(red + 16);       // [MW] boosted-token bits
+    int *acts = reinterpret_cast<int *>(mask + MW);                // [kTrieMaxActive] this step's active states
+    int *nx = acts + kTrieMaxActive;                               // [1 + kTrieMaxActive] next active set (count first)
+    int n_act = 0;
+    if constexpr (BOOST) {
+        n_act = st.trie.n_act[b];
+        if (tid < n_act) acts[tid] = st.trie.act[(int64_t)b * kTrieMaxActive + tid];
+        for (int i = tid; i < MW; i += 256) mask[i] = 0u;
+    }
     const float *lg = st.logits + (int64_t)b * VD;
     // issue every independent global load up front (state words, candidate LSTM state): each dependent round trip to
     // L2/HBM costs ~1-2 us in this latency-bound kernel
@@ -170,6 +281,16 @@ __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     for (int i = tid; i < st.V; i += 256) e[i] = dexpf(x[i] - m);
+    if constexpr (BOOST) {                                         // get_boosted_tokens: union of the children of the active states
+        for (int a = 0; a < n_act; ++a) {
+            const int sn = acts[a];
+            const int c1 = st.trie.off[sn + 1];
+            for (int c = st.trie.off[sn] + tid; c < c1; c += 256) {
+                const int tk = st.trie.tok[c];
+                if (tk >= 0 && tk < st.V) atomicOr(&mask[tk >> 5], 1u << (tk & 31));
+            }
+        }
+    }
     __syncthreads();
     if (wave == 0) {
         float p = 0.0f;
@@ -187,7 +308,8 @@ __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
     float best = -__builtin_huge_valf();
     int bi = 0x7fffffff;
     for (int i = tid; i < st.V; i += 256) {
-        const float l = (x[i] - m) - lse;
+        float l = (x[i] - m) - lse;
+        if constexpr (BOOST) l = l + (((mask[i >> 5] >> (i & 31)) & 1u) ? st.trie.boost : 0.0f);
         if (bi == 0x7fffffff || l > best) { best = l; bi = i; }
     }
 #pragma unroll
@@ -205,6 +327,7 @@ __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
         const int oi = __float_as_int(red[12 + w]);
         if (ob > lab.lp || (ob == lab.lp && oi < lab.idx)) { lab.lp = ob; lab.idx = oi; }
     }
+    if constexpr (BOOST) lab.lp = (x[lab.idx] - m) - lse;          // the confidence is the UNBOOSTED log-prob (phrase_boost.cpp:313-315)
     if (st.D > 0) skip = (int)red[5];
     const int lane0 = tid;                                         // thread 0 writes the scalar state
     // scalar control (wave-uniform values; lane 0 writes)
@@ -228,6 +351,23 @@ __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
                 st.conf[o] = dexpf(lab.lp);                                 // confidence = exp(max log-prob) :169
             }
             st.token[b] = lab.idx;
+        }
+        if constexpr (BOOST) {                        // ContextTrie::advance on the emitted token (phrase_boost.cpp:52-66, :336)
+            if (tid == 0) { nx[0] = 1; nx[1] = 0; }   // the root is always active
+            __syncthreads();
+            for (int a = 0; a < n_act; ++a) {
+                const int sn = acts[a];
+                const int c1 = st.trie.off[sn + 1];
+                for (int c = st.trie.off[sn] + tid; c < c1; c += 256)
+                    if (st.trie.tok[c] == lab.idx) {
+                        const int slot = atomicAdd(&nx[0], 1);
+                        if (slot < kTrieMaxActive) nx[1 + slot] = st.trie.node[c];
+                    }
+            }
+            __syncthreads();
+            const int nn = nx[0] < kTrieMaxActive ? nx[0] : kTrieMaxActive;
+            if (tid < nn) st.trie.act[(int64_t)b * kTrieMaxActive + tid] = nx[1 + tid];
+            if (tid == 0) st.trie.n_act[b] = nn;
         }
         ++n_out;
         if (st.D > 0) {
@@ -263,7 +403,12 @@ __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
 }
 void launch_tdt_decide(const TdtState &st, hipStream_t s) {
     const size_t lds = (size_t)(2 * (st.V + st.D) + 16) * sizeof(float);
-    hipLaunchKernelGGL(tdt_decide_kernel, dim3(st.B), dim3(256), lds, s, st);
+    if (st.trie.off) {
+        const size_t extra = (size_t)((st.V + 31) / 32 + 2 * kTrieMaxActive + 1) * sizeof(int);
+        hipLaunchKernelGGL(tdt_decide_kernel<true>, dim3(st.B), dim3(256), lds + extra, s, st);
+    } else {
+        hipLaunchKernelGGL(tdt_decide_kernel<false>, dim3(st.B), dim3(256), lds, s, st);
+    }
 }
 
 __global__ void tdt_init_kernel(TdtState st) {
@@ -277,6 +422,10 @@ __global__ void tdt_init_kernel(TdtState st) {
     st.steps[b] = 0;
     st.done[b] = 0;
     st.lens[b] = 0;
+    if (st.trie.off) {                                 // active_states = {root} (phrase_boost.cpp:258)
+        st.trie.n_act[b] = 1;
+        st.trie.act[(int64_t)b * kTrieMaxActive] = 0;
+    }
 }
 void launch_tdt_init(const TdtState &st, hipStream_t s) { hipLaunchKernelGGL(tdt_init_kernel, dim3((st.B + 63) / 64), dim3(64), 0, s, st); }
 

@@ -81,8 +81,21 @@ void launch_stream_dwconv(const float *g, const float *cache_in, int has_cache, 
 void launch_logsoftmax_argmax(const float *logits, int64_t rows, int ld, int n, float *lp_out, int *best_idx, float *best_lp, hipStream_t s);
 void launch_ctc_collapse(const int *best_idx, const float *best_lp, int B, int T, int blank, int *ids, int *lens, int *start, int *end,
                          float *conf, hipStream_t s);
+// ContextTrie of the phrase boosting (reference src/phrase_boost.cpp:9-66) in CSR form: the children of node i are the entries
+// [off[i], off[i+1]) of (tok, node).  Every utterance carries its active-state set (the root plus at most one node per trie
+// depth, so <= kTrieMaxActive for phrases of < kTrieMaxActive tokens).  off == nullptr: boosting is off.
+constexpr int kTrieMaxActive = 64;
+struct TrieDev {
+    const int *off, *tok, *node;
+    int n_nodes;
+    float boost;
+    int *act, *n_act;               // [B][kTrieMaxActive], [B]
+};
+void launch_ctc_boosted(const float *logp, int B, int T, int V, int blank, const TrieDev &trie, int *ids, int *lens, int *start, int *end,
+                        float *conf, hipStream_t s);
 struct TdtState {
     int B, T, V, D, L, Hp, blank, max_symbols, max_tokens, max_steps;
+    TrieDev trie;
     int keep_state;                 // streaming chunks (src/eou.cpp:17-98): the last token and h / c are carried in, end frames are not clamped
     int durations[8];
     const float *logits;            // [B][V+D]

@@ -8,7 +8,9 @@
 //  * there is no CPU execution path: transcribe() places the model on GPU 0 on first use if to_gpu() was not called;
 //  * audio files: RIFF/WAVE only (any sample rate: resampled to 16 kHz with the reference's sinc resampler; no FLAC/MP3/OGG);
 //  * weights are loaded strictly (a missing / mis-shaped tensor throws instead of being ignored);
-//  * boost_phrases are accepted but ignored (phrase boosting is outside the accelerated path);
+//  * boost_phrases / boost_score work as in the reference (the ContextTrie and the boosted argmax run on the GPU); the
+//    Tensor-level free functions of phrase_boost.hpp (ctc_greedy_decode_boosted(Tensor, ...)) have C-ABI counterparts instead:
+//    pk_set_boost_tokens / pk_set_boost_phrases + pk_ctc_decode / pk_tdt_decode;
 //  * new: transcribe_batch() -- clips of equal length are decoded together (the reference is batch-1 only).
 // Errors surface as std::runtime_error with the reference's trigger conditions (unreadable vocab / audio, ...).
 #pragma once
@@ -37,7 +39,7 @@ enum class Decoder { CTC, TDT };
 struct TranscribeOptions {
     Decoder decoder = Decoder::TDT;
     bool timestamps = false;
-    std::vector<std::string> boost_phrases;   // accepted, ignored (see header comment)
+    std::vector<std::string> boost_phrases;   // ContextTrie::build of these phrases biases the greedy argmax (phrase_boost.hpp)
     float boost_score = 5.0f;
 };
 
@@ -73,7 +75,14 @@ class Engine {   // owns one pk_model; shared by Transcriber and TDTTranscriber
             pcm.insert(pcm.end(), c.first, c.first + c.second);
             offsets.push_back((int64_t)pcm.size());
         }
-        pk_options o{opts.decoder == Decoder::CTC ? PK_DECODER_CTC : PK_DECODER_TDT, opts.timestamps ? 1 : 0};
+        pk_options o{};
+        o.decoder = opts.decoder == Decoder::CTC ? PK_DECODER_CTC : PK_DECODER_TDT;
+        o.timestamps = opts.timestamps ? 1 : 0;
+        std::vector<const char *> phrases;
+        for (auto &p : opts.boost_phrases) phrases.push_back(p.c_str());
+        o.boost_phrases = phrases.data();
+        o.n_boost_phrases = (int32_t)phrases.size();
+        o.boost_score = opts.boost_score;
         pk_result *res = nullptr;
         check(pk_transcribe_pcm(m_, pcm.data(), offsets.data(), (int)clips.size(), &o, &res));
         std::vector<TranscribeResult> out(clips.size());

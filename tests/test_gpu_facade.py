@@ -11,7 +11,7 @@ import pytest
 
 import gpu_common as G
 from conftest import ROOT, pk
-from parakeet_cpp_amd import synth
+from parakeet_cpp_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 EXE = os.path.join(ROOT, "parakeet.cpp_amd", "examples", "transcribe_wav")
@@ -44,6 +44,22 @@ def test_transcriber_on_a_wav_matches_oracle(tmp_path, orc):
         assert n > 3 and len(r["words"]) >= 1
         starts = [w[1] for w in r["words"]]
         assert starts == sorted(starts)                      # monotonic word timestamps (tests/test_all.cpp:946-963)
+    # TranscribeOptions.boost_phrases through the facade (transcribe.hpp:41-42; CLI --boost / --boost-score, src/main.cpp:23-25)
+    toks = want["tdt"]["ids"][0, :want["tdt"]["lens"][0]].tolist()
+    def text_of(ids):
+        t = "".join(pieces[i] for i in ids).replace("▁", " ")
+        return t[1:] if t.startswith(" ") else t
+    phrases = [text_of(toks[:2] + [77]), text_of([300, 301, 302])]
+    gm = capi.Model(wp, cfg, vocab_path=vp)                                   # host-only handle: the tokenizer
+    trie = orc.Trie([gm.tokenize(p) for p in phrases])
+    gm.close()
+    wb = om.tdt_greedy_boosted(enc, trie, 4.0)
+    out = subprocess.run([EXE, wp, vp, ap, "tdt", "--boost", phrases[0], "--boost", phrases[1], "--boost-score", "4"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout)["token_ids"]
+    assert got == wb["ids"][0, :wb["lens"][0]].tolist()
+    assert got != toks, "degenerate test: the boost changed nothing"
     bad = subprocess.run([EXE, wp, str(tmp_path / "missing_vocab.txt"), ap], capture_output=True, text=True)
     assert bad.returncode == 1 and "Cannot open vocab file" in bad.stderr
 
