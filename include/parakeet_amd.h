@@ -72,6 +72,10 @@ typedef struct pk_config {
                                       v_mfma_f32_32x32x16_bf16 -- the precision BASELINE configs[2] names for tdt-600m; the decode loop,
                                       attention scores, norms and depthwise convs stay fp32.  Needs every such K % 64 == 0. */
     char joint_prefix[32];         /* "tdt_joint_." (tdt_ctc.cpp:5-9) or "joint_." (tdt.cpp:28-32) */
+    /* encoder-only uses (Sortformer's NEST encoder, src/sortformer.cpp:41-47): vocab_size = 0 loads no prediction net / joint */
+    int32_t xscaling;              /* StreamingEncoderConfig::xscaling (streaming_encoder.cpp:402-406, :444-447): x *= sqrt(hidden) after subsampling */
+    int32_t mel_normalize_off;     /* AudioConfig::normalize = false (audio.cpp:140): features are the raw log-mel (Sortformer, main.cpp:516) */
+    char encoder_prefix[32];       /* module name of the encoder in the state dict; "" = "encoder_." ; Sortformer: "nest_encoder_." */
 } pk_config;
 
 /* make_110m_config / make_tdt_600m_config / make_rnnt_600m_config (config.hpp:77-135). name: "tdt-ctc-110m" | "tdt-600m" | "rnnt-600m" |
@@ -236,6 +240,27 @@ pk_status pk_transformer_load(const char *safetensors_path, const char *prefix, 
  * not supported: no caller on the ASR path passes one. */
 pk_status pk_transformer_forward(pk_transformer *t, const float *x, int B, int T, float *y);
 void pk_transformer_free(pk_transformer *t);
+
+/* ---- Sortformer speaker diarization (include/parakeet/sortformer.hpp:28-129, src/sortformer.cpp:41-121) ------------------------
+ * NEST FastConformer (offline Conformer path, xscaling, weights under "nest_encoder_.") -> projection_ -> TransformerEncoder
+ * ("transformer_.") -> relu -> first_hidden_ -> relu -> output_proj_ -> sigmoid.  One handle = weights on one device. */
+typedef struct pk_sortformer_config {   /* SortformerConfig (sortformer.hpp:28-41) */
+    pk_config nest;                     /* encoder fields only: vocab_size = ctc_vocab_size = 0, xscaling = 1, mel_normalize_off = 1 */
+    pk_transformer_config transformer;
+    int32_t max_speakers;               /* 4 */
+    float activity_threshold;           /* 0.5 */
+} pk_sortformer_config;
+typedef struct pk_sortformer pk_sortformer;
+void pk_sortformer_config_preset(pk_sortformer_config *out);              /* make_sortformer_117m_config (sortformer.hpp:43-76) */
+pk_status pk_sortformer_load(const char *safetensors_path, const pk_sortformer_config *cfg, int device, pk_sortformer **out);
+void pk_sortformer_free(pk_sortformer *s);
+/* Sortformer::forward (:50-69): feats[B][Tm][mel_bins] -> probs[B][T][max_speakers], T = pk_encoder_num_frames(Tm) (also in *T_out). */
+pk_status pk_sortformer_forward(pk_sortformer *s, const float *feats, int B, int Tm, float *probs, int *T_out);
+/* preprocess_audio with normalize = false (src/main.cpp:513-517, src/diarize.cpp:81-88) + forward, for n_clips clips of n_samples. */
+pk_status pk_sortformer_forward_pcm(pk_sortformer *s, const float *pcm, int n_clips, int64_t n_samples, float *probs, int *T_out);
+/* Sortformer::probs_to_segments (:71-113) on one utterance's probs[T][S]: runs of prob > threshold per speaker, seconds = frame * 0.08,
+ * sorted by start.  Writes at most cap segments, returns the number found. */
+int pk_sortformer_segments(const float *probs, int T, int S, float threshold, int32_t *speaker, float *start, float *end, int cap);
 
 /* ---- host-side text (src/vocab.cpp:29-117, src/timestamp.cpp:24-111) -------------------------------------- */
 int pk_vocab_size(const pk_model *m);

@@ -180,6 +180,10 @@ class Model:
         oc.gemm_bf16 = int(getattr(cfg, "gemm_bf16", False) if gemm_bf16 is None else gemm_bf16)
         oc.joint_prefix = cfg.joint_prefix.encode()
         self._h = lib().orc_model_new(C.byref(oc))
+        ep = getattr(cfg, "encoder_prefix", "encoder_.")
+        if ep != "encoder_." or getattr(cfg, "xscaling", False):
+            lib().orc_model_set_encoder.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+            lib().orc_model_set_encoder(self._h, ep.encode(), int(getattr(cfg, "xscaling", False)))
         self._keep = {}
         for k, v in weights.items():
             a = _c(v)
@@ -242,6 +246,18 @@ class Model:
                                                 _f(x), B, T, d))
         return x
 
+    def sortformer_forward(self, feats, sf):
+        """Sortformer::forward (src/sortformer.cpp:50-69): feats [B][Tm][mel] -> sigmoid speaker activities [B][T][S]."""
+        feats = _c(feats)
+        B, Tm, _ = feats.shape
+        T = subsampled_len(Tm)
+        probs = _out((B, T, sf.max_speakers), np.float32)
+        L = lib()
+        L.orc_sortformer_forward.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+        self._chk(L.orc_sortformer_forward(self._h, _f(feats), B, Tm, sf.transformer_layers, sf.transformer_heads, int(sf.pre_ln),
+                                           int(sf.has_final_norm), _f(probs)))
+        return probs
+
     def ctc_logprobs(self, enc):
         enc = _c(enc)
         B, T, _ = enc.shape
@@ -296,6 +312,18 @@ def ctc_greedy(logp, blank_id):
     cf = np.zeros((B, T), np.float32); lens = np.zeros(B, np.int32)
     lib().orc_ctc_greedy(_f(logp), B, T, V, blank_id, _i(ids), _i(lens), _i(st), _i(en), _f(cf))
     return dict(ids=ids, lens=lens, start=st, end=en, conf=cf)
+
+
+def probs_to_segments(probs, threshold=0.5):
+    """Sortformer::probs_to_segments (src/sortformer.cpp:71-113) on probs [T][S] -> list of (speaker, start_s, end_s)."""
+    probs = _c(probs)
+    T, S = probs.shape
+    cap = S * (T // 2 + 2)
+    spk = np.zeros(cap, np.int32); a = np.zeros(cap, np.float32); b = np.zeros(cap, np.float32)
+    L = lib()
+    L.orc_probs_to_segments.argtypes = [f32p, C.c_int, C.c_int, C.c_float, i32p, f32p, f32p]
+    n = L.orc_probs_to_segments(_f(probs), T, S, threshold, _i(spk), _f(a), _f(b))
+    return [(int(spk[i]), float(a[i]), float(b[i])) for i in range(n)]
 
 
 class Trie:

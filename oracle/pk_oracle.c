@@ -260,7 +260,13 @@ struct orc_model {
     orc_config cfg;
     orc_tensor *t;
     int nt, cap;
+    char enc_prefix[32];   /* module name of the FastConformer in the state dict: "encoder_." (default) or "nest_encoder_." (Sortformer) */
+    int xscaling;          /* StreamingEncoderConfig::xscaling (streaming_encoder.cpp:402-406): x *= sqrt(d_model) after subsampling */
 };
+void orc_model_set_encoder(orc_model *m, const char *prefix, int xscaling) {
+    snprintf(m->enc_prefix, sizeof m->enc_prefix, "%s", prefix ? prefix : "");
+    m->xscaling = xscaling;
+}
 
 orc_model *orc_model_new(const orc_config *cfg) {
     orc_model *m = (orc_model *)calloc(1, sizeof(orc_model));
@@ -293,11 +299,17 @@ static orc_tensor *find(const orc_model *m, const char *name) {
     return NULL;
 }
 static orc_tensor *getf(const orc_model *m, const char *fmt, ...) {
-    char name[192];
+    char name[256];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(name, sizeof(name), fmt, ap);
     va_end(ap);
+    if (m->enc_prefix[0] && strncmp(name, "encoder_.", 9) == 0) {
+        char alt[320];
+        snprintf(alt, sizeof alt, "%s%s", m->enc_prefix, name + 9);
+        memcpy(name, alt, sizeof name - 1);
+        name[sizeof name - 1] = 0;
+    }
     orc_tensor *t = find(m, name);
     if (!t) orc_fail("missing tensor '%s'", name);
     return t;
@@ -934,12 +946,77 @@ int orc_encoder(orc_model *m, const float *feats, int B, int Tm, float *out, flo
     float *pe = (float *)xmalloc((size_t)(2 * T - 1) * c->d_model * sizeof(float));
     orc_pos_emb(T, c->d_model, pe);
     const int64_t sz = (int64_t)B * T * c->d_model;
+    if (m->xscaling) {                                              /* streaming_encoder.cpp:402-406: x = x * sqrt(hidden) */
+        const float scale = sqrtf((float)c->d_model);
+        for (int64_t i = 0; i < sz; ++i) out[i] = out[i] * scale;
+    }
     for (int l = 0; l < c->n_layers; ++l) {
         if (orc_conformer_block(m, l, out, B, T, pe, 0)) { free(pe); return -1; }
         if (layer_taps) memcpy(layer_taps + (int64_t)l * sz, out, (size_t)sz * sizeof(float));
     }
     free(pe);
     return T;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Sortformer (src/sortformer.cpp:50-121): NEST FastConformer -> projection_ -> TransformerEncoder -> speaker head        */
+/* ------------------------------------------------------------------------- */
+/* Sortformer::forward (:50-69).  feats[B][Tm][mel] -> probs[B][T][S] (sigmoid speaker activities); returns T.
+ * Tensor names (AX_REGISTER_MODULES, :44-46): nest_encoder_.*, projection_, transformer_.*, first_hidden_, output_proj_
+ * (hidden_to_spks_ is registered but never used by forward). */
+int orc_sortformer_forward(orc_model *m, const float *feats, int B, int Tm, int n_tlayers, int n_theads, int pre_ln,
+                           int has_final_norm, float *probs) {
+    const orc_config *c = &m->cfg;
+    orc_tensor *pw = getf(m, "projection_.weight"), *pb = getf(m, "projection_.bias");
+    orc_tensor *fw = getf(m, "first_hidden_.weight"), *fb = getf(m, "first_hidden_.bias");
+    orc_tensor *ow = getf(m, "output_proj_.weight"), *ob = getf(m, "output_proj_.bias");
+    if (!pw || !pb || !fw || !fb || !ow || !ob) return -1;
+    const int d = c->d_model, dt = (int)pw->shape[0], S = (int)ow->shape[0];
+    const int T = orc_subsampled_len(Tm);
+    float *enc = (float *)xmalloc((size_t)B * T * d * sizeof(float));
+    if (orc_encoder(m, feats, B, Tm, enc, NULL) < 0) { free(enc); return -1; }          /* :52 nest_encoder_(features) */
+    const int64_t rows = (int64_t)B * T;
+    float *x = (float *)xmalloc((size_t)rows * dt * sizeof(float));
+    float *h = (float *)xmalloc((size_t)rows * dt * sizeof(float));
+    float *lg = (float *)xmalloc((size_t)rows * S * sizeof(float));
+    linear_t(0, pw, pb, (int)rows, enc, d, x, dt, 0);                                   /* :55 */
+    free(enc);
+    int r = orc_transformer_encoder(m, "transformer_.", n_tlayers, n_theads, pre_ln, has_final_norm, c->ln_eps, x, B, T, dt);   /* :58 */
+    if (r == 0) {
+        for (int64_t i = 0; i < rows * dt; ++i) x[i] = x[i] > 0.0f ? x[i] : 0.0f;       /* :62 relu */
+        linear_t(0, fw, fb, (int)rows, x, dt, h, dt, 0);                                /* :63 first_hidden_ */
+        for (int64_t i = 0; i < rows * dt; ++i) h[i] = h[i] > 0.0f ? h[i] : 0.0f;       /* :64 */
+        linear_t(0, ow, ob, (int)rows, h, dt, lg, S, 0);                                /* :65 output_proj_ */
+        for (int64_t i = 0; i < rows * S; ++i) probs[i] = orc_sigmoidf(lg[i]);          /* :68 */
+    }
+    free(x); free(h); free(lg);
+    return r == 0 ? T : -1;
+}
+
+/* Sortformer::probs_to_segments (:71-113): per speaker, contiguous runs of prob > threshold -> [start, end] in seconds
+ * (frame * 0.08), then sorted by start (std::sort; ties keep no particular order -- here: stable, by speaker).
+ * probs[T][S]; out arrays sized >= S * (T + 1) / 2 + S; returns the segment count. */
+int orc_probs_to_segments(const float *probs, int T, int S, float threshold, int32_t *spk, float *start, float *end) {
+    int n = 0;
+    for (int s = 0; s < S; ++s) {
+        int in_seg = 0, seg_start = 0;
+        for (int t = 0; t < T; ++t) {
+            const int active = probs[(int64_t)t * S + s] > threshold;
+            if (active && !in_seg) { seg_start = t; in_seg = 1; }
+            else if (!active && in_seg) {
+                spk[n] = s; start[n] = (float)seg_start * 0.08f; end[n] = (float)(t - 1) * 0.08f; ++n;
+                in_seg = 0;
+            }
+        }
+        if (in_seg) { spk[n] = s; start[n] = (float)seg_start * 0.08f; end[n] = (float)(T - 1) * 0.08f; ++n; }
+    }
+    for (int i = 1; i < n; ++i) {                                  /* insertion sort by start: stable */
+        const int32_t ks = spk[i]; const float a = start[i], b = end[i];
+        int j = i - 1;
+        while (j >= 0 && start[j] > a) { spk[j + 1] = spk[j]; start[j + 1] = start[j]; end[j + 1] = end[j]; --j; }
+        spk[j + 1] = ks; start[j + 1] = a; end[j + 1] = b;
+    }
+    return n;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1571,7 +1648,7 @@ static int stream_conv(orc_stream *s, int layer, float *x, int c) {
 
 /* StreamingFastConformerEncoder::forward_chunk -- src/streaming_encoder.cpp:430-472 (+ CausalConvSubsampling::forward_cached
  * :348-385, StreamingConformerBlock::forward_cached :289-301).  mel[n_frames][n_mels] -> enc[c][d]; returns c (0: cached).
- * xscaling (streaming_encoder.hpp:22, off in every shipped config) is not restated. */
+ * xscaling (:444-447; on only in the Sortformer NEST config) follows orc_model_set_encoder. */
 int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out) {
     orc_model *m = s->m;
     const orc_config *cf = &m->cfg;
@@ -1589,6 +1666,10 @@ int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc,
     if (c > max_out) { free(all); return orc_fail("orc_stream_encode: %d frames > max_out %d", c, max_out); }
     if (orc_subsampling(m, all, 1, consumable, enc, NULL, NULL) < 0) { free(all); return -1; }
     free(all);
+    if (m->xscaling) {
+        const float scale = sqrtf((float)d);
+        for (int64_t i = 0; i < (int64_t)c * d; ++i) enc[i] = enc[i] * scale;
+    }
     const int Tp = s->att_left + c, P = 2 * Tp - 1;                                  /* :452-454 */
     float *pe = (float *)xmalloc((size_t)P * d * sizeof(float));
     orc_pos_emb(Tp, d, pe);

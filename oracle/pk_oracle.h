@@ -7,6 +7,12 @@
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
+/* ---- Sortformer (src/sortformer.cpp) ---- */
+void orc_model_set_encoder(orc_model *m, const char *prefix, int xscaling);
+int orc_sortformer_forward(orc_model *m, const float *feats, int B, int Tm, int n_tlayers, int n_theads, int pre_ln,
+                           int has_final_norm, float *probs);
+int orc_probs_to_segments(const float *probs, int T, int S, float threshold, int32_t *spk, float *start, float *end);
+
 /* ---- phrase boosting: ContextTrie + boosted greedy decoders (src/phrase_boost.cpp) ---- */
 typedef struct orc_trie orc_trie;
 orc_trie *orc_trie_new(void);

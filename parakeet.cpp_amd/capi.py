@@ -27,12 +27,17 @@ class PkConfig(C.Structure):
                 ("num_lstm_layers", C.c_int32), ("joint_hidden", C.c_int32), ("num_durations", C.c_int32),
                 ("durations", C.c_int32 * 8), ("ctc_vocab_size", C.c_int32), ("blank_id", C.c_int32),
                 ("max_symbols_per_step", C.c_int32), ("joint_pred_bias", C.c_int32), ("rnnt_head", C.c_int32), ("stft_window_centered", C.c_int32), ("gemm_bf16", C.c_int32),
-                ("joint_prefix", C.c_char * 32)]
+                ("joint_prefix", C.c_char * 32), ("xscaling", C.c_int32), ("mel_normalize_off", C.c_int32),
+                ("encoder_prefix", C.c_char * 32)]
 
 
 class PkTransformerConfig(C.Structure):
     _fields_ = [("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("ffn_intermediate", C.c_int32),
                 ("pre_ln", C.c_int32), ("has_final_norm", C.c_int32), ("layer_norm_eps", C.c_float)]
+
+
+class PkSortformerConfig(C.Structure):
+    _fields_ = [("nest", PkConfig), ("transformer", PkTransformerConfig), ("max_speakers", C.c_int32), ("activity_threshold", C.c_float)]
 
 
 class PkKernelStat(C.Structure):
@@ -67,6 +72,10 @@ def to_pk_config(cfg: ModelConfig) -> PkConfig:
     c.stft_window_centered = int(getattr(cfg, "stft_window_centered", False))
     c.gemm_bf16 = int(getattr(cfg, "gemm_bf16", False))
     c.joint_prefix = cfg.joint_prefix.encode()
+    c.xscaling = int(getattr(cfg, "xscaling", False))
+    c.mel_normalize_off = int(not getattr(cfg, "mel_normalize", True))
+    ep = getattr(cfg, "encoder_prefix", "encoder_.")
+    c.encoder_prefix = b"" if ep == "encoder_." else ep.encode()
     return c
 
 
@@ -284,6 +293,63 @@ class Transformer:
         if self._h:
             lib().pk_transformer_free(self._h)
             self._h = None
+
+
+class Sortformer:
+    """pk_sortformer_*: Sortformer diarization (reference include/parakeet/sortformer.hpp:99-129) on the GPU."""
+
+    def __init__(self, weights_path, sf, device=0):
+        L = lib()
+        L.pk_sortformer_load.argtypes = [C.c_char_p, C.POINTER(PkSortformerConfig), C.c_int, C.POINTER(C.c_void_p)]
+        L.pk_sortformer_free.argtypes = [C.c_void_p]
+        L.pk_sortformer_free.restype = None
+        L.pk_sortformer_forward.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, f32p, C.POINTER(C.c_int)]
+        L.pk_sortformer_forward_pcm.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int64, f32p, C.POINTER(C.c_int)]
+        L.pk_sortformer_segments.argtypes = [f32p, C.c_int, C.c_int, C.c_float, i32p, f32p, f32p, C.c_int]
+        self.sf = sf
+        c = PkSortformerConfig()
+        c.nest = to_pk_config(sf.nest_encoder)
+        c.transformer = PkTransformerConfig(sf.transformer_hidden, sf.transformer_layers, sf.transformer_heads, sf.transformer_ffn,
+                                            int(sf.pre_ln), int(sf.has_final_norm), 1e-5)
+        c.max_speakers, c.activity_threshold = sf.max_speakers, sf.activity_threshold
+        self._h = C.c_void_p()
+        check(L.pk_sortformer_load(weights_path.encode(), C.byref(c), device, C.byref(self._h)))
+
+    def forward(self, feats):
+        """Sortformer::forward: feats [B][Tm][mel] -> probs [B][T][S]."""
+        feats = _c(feats)
+        B, Tm, _ = feats.shape
+        T = lib().pk_encoder_num_frames(Tm)
+        probs = np.zeros((B, T, self.sf.max_speakers), np.float32)
+        check(lib().pk_sortformer_forward(self._h, _f(feats), B, Tm, _f(probs), None))
+        return probs
+
+    def forward_pcm(self, pcm):
+        pcm = _c(pcm)
+        if pcm.ndim == 1:
+            pcm = pcm[None]
+        B, n = pcm.shape
+        T = lib().pk_encoder_num_frames(lib().pk_mel_num_frames(n))
+        probs = np.zeros((B, T, self.sf.max_speakers), np.float32)
+        check(lib().pk_sortformer_forward_pcm(self._h, _f(pcm), B, n, _f(probs), None))
+        return probs
+
+    def close(self):
+        if self._h:
+            lib().pk_sortformer_free(self._h)
+            self._h = None
+
+
+def sortformer_segments(probs, threshold=0.5):
+    """Sortformer::probs_to_segments on probs [T][S] -> list of (speaker, start_s, end_s)."""
+    L = lib()
+    L.pk_sortformer_segments.argtypes = [f32p, C.c_int, C.c_int, C.c_float, i32p, f32p, f32p, C.c_int]
+    probs = _c(probs)
+    T, S = probs.shape
+    cap = S * (T // 2 + 2)
+    spk = np.zeros(cap, np.int32); a = np.zeros(cap, np.float32); b = np.zeros(cap, np.float32)
+    n = L.pk_sortformer_segments(_f(probs), T, S, threshold, _i(spk), _f(a), _f(b), cap)
+    return [(int(spk[i]), float(a[i]), float(b[i])) for i in range(n)]
 
 
 def diag_layernorm(x, g, b, eps=1e-5):

@@ -34,6 +34,10 @@ class ModelConfig:
     stft_window_centered: bool = False
     # pk_config.gemm_bf16: encoder-side products on bf16 operands / fp32 accumulation (BASELINE configs[2] precision)
     gemm_bf16: bool = False
+    # encoder-only uses (Sortformer's NEST encoder): vocab_size = 0 -> no prediction net / joint
+    xscaling: bool = False          # StreamingEncoderConfig::xscaling (streaming_encoder.cpp:402-406)
+    mel_normalize: bool = True      # AudioConfig::normalize (audio.cpp:140); Sortformer runs on the raw log-mel (main.cpp:516)
+    encoder_prefix: str = "encoder_."   # module name of the FastConformer in the state dict ("nest_encoder_." in Sortformer)
 
     @property
     def head_dim(self):
@@ -65,6 +69,30 @@ def make_nemotron_600m_config() -> ModelConfig:  # nemotron.hpp:31-52 (streaming
 
 def make_eou_120m_config() -> ModelConfig:       # eou.hpp:34-56 (streaming; att_context 70 / 1); ParakeetEOU registers no CTC module
     return ModelConfig(name="eou-120m", ctc_vocab_size=0, joint_prefix="joint_.")
+
+
+@dataclass
+class SortformerConfig:              # include/parakeet/sortformer.hpp:28-41
+    nest_encoder: ModelConfig = None
+    transformer_hidden: int = 192
+    transformer_layers: int = 18
+    transformer_heads: int = 8
+    transformer_ffn: int = 768
+    pre_ln: bool = False             # NeMo sortformer: post-norm
+    has_final_norm: bool = False
+    max_speakers: int = 4
+    activity_threshold: float = 0.5
+
+
+def make_nest_encoder_config(**kw) -> ModelConfig:
+    """The encoder half of make_sortformer_117m_config (sortformer.hpp:45-58): 17-layer FastConformer, 128 mels, xscaling."""
+    cfg = ModelConfig(name="sortformer-nest", mel_bins=128, hidden_size=512, num_layers=17, num_heads=8, ffn_intermediate=2048,
+                      vocab_size=0, ctc_vocab_size=0, durations=[], xscaling=True, mel_normalize=False, encoder_prefix="nest_encoder_.")
+    return replace(cfg, **kw)
+
+
+def make_sortformer_117m_config() -> SortformerConfig:     # sortformer.hpp:43-76
+    return SortformerConfig(nest_encoder=make_nest_encoder_config())
 
 
 def make_tiny_config(**kw) -> ModelConfig:

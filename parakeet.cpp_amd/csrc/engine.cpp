@@ -27,7 +27,7 @@ Model::Model(const std::string &weights_path, const std::string &vocab_path, con
     if (256 % cfg.subsampling_channels) fail(PK_ERR_UNSUPPORTED, "subsampling_channels must divide 256");
     if (cfg.mel_bins > 128 || cfg.mel_bins % 8) fail(PK_ERR_UNSUPPORTED, "mel_bins must be a multiple of 8 and <= 128");
     if (cfg.conv_kernel_size != 9 && cfg.conv_kernel_size != 31) fail(PK_ERR_UNSUPPORTED, "conv_kernel_size must be 9 or 31");
-    if (cfg.num_lstm_layers < 1 || cfg.num_lstm_layers > 4) fail(PK_ERR_UNSUPPORTED, "num_lstm_layers must be 1..4");
+    if (cfg.vocab_size > 0 && (cfg.num_lstm_layers < 1 || cfg.num_lstm_layers > 4)) fail(PK_ERR_UNSUPPORTED, "num_lstm_layers must be 1..4");
     if (cfg.hidden_size > 1024) fail(PK_ERR_UNSUPPORTED, "hidden_size > 1024");
     if (cfg.num_lstm_layers * cfg.pred_hidden > 12 * 256) fail(PK_ERR_UNSUPPORTED, "num_lstm_layers * pred_hidden > 3072");
     if (cfg.pred_hidden % 64 || cfg.joint_hidden % 64) fail(PK_ERR_UNSUPPORTED, "pred_hidden / joint_hidden must be multiples of 64 (decode GEMV K chunk)");
@@ -174,7 +174,8 @@ void Model::upload_weights() {
             for (int k = 0; k < taps; ++k) w[(size_t)k * ch + c] = t.f32()[(size_t)c * taps + k];
         return upload(w.data(), w.size());
     };
-    const std::string sp = "encoder_.subsampling_.";
+    const std::string ep = cfg.encoder_prefix[0] ? std::string(cfg.encoder_prefix) : std::string("encoder_.");
+    const std::string sp = ep + "subsampling_.";
     sub.c1w = taps_last(sp + "conv1_.weight", C, 9);  sub.c1b = upload_tensor(sp + "conv1_.bias", {C});
     sub.d1w = taps_last(sp + "dw1_.weight", C, 9);    sub.d1b = upload_tensor(sp + "dw1_.bias", {C});
     sub.c2w = upload_gemm_tensor(sp + "conv2_.weight", {C, C}); sub.c2b = upload_tensor(sp + "conv2_.bias", {C});
@@ -185,7 +186,7 @@ void Model::upload_weights() {
     layers.resize(cfg.num_layers);
     for (int i = 0; i < cfg.num_layers; ++i) {
         LayerW &L = layers[i];
-        const std::string q = "encoder_.layers_." + std::to_string(i) + ".";
+        const std::string q = ep + "layers_." + std::to_string(i) + ".";
         L.ffn1_ng = upload_tensor(q + "ffn1_.norm_.weight", {d}); L.ffn1_nb = upload_tensor(q + "ffn1_.norm_.bias", {d});
         L.ffn1_w1 = upload_gemm_tensor(q + "ffn1_.fc1_.weight", {ffn, d}); L.ffn1_b1 = upload_tensor(q + "ffn1_.fc1_.bias", {ffn});
         L.ffn1_w2 = upload_gemm_tensor(q + "ffn1_.fc2_.weight", {d, ffn}); L.ffn1_b2 = upload_tensor(q + "ffn1_.fc2_.bias", {d});
@@ -233,6 +234,16 @@ void Model::upload_weights() {
             for (int k = 0; k < K; ++k) p[(size_t)r * K + sigma(k)] = w[(size_t)r * K + k];
         return upload(p.data(), p.size());
     };
+    if (cfg.ctc_vocab_size > 0) {
+        dec.ctc_w = upload_gemm_tensor("ctc_decoder_.proj_.weight", {cfg.ctc_vocab_size, d});
+        dec.ctc_b = upload_tensor("ctc_decoder_.proj_.bias", {cfg.ctc_vocab_size});
+    }
+    if (V <= 0) {                      // encoder-only model (Sortformer's NEST encoder): no prediction net, no joint
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipStreamSynchronize(stream));
+        st_.reset();
+        return;
+    }
     dec.embed = upload_tensor("prediction_.embed_.weight", {V, Hp});
     for (int l = 0; l < cfg.num_lstm_layers; ++l) {
         const std::string q = "prediction_.lstm_.cells_." + std::to_string(l) + ".";
@@ -259,10 +270,6 @@ void Model::upload_weights() {
         wld = upload(w.data(), w.size());
         bld = upload(b.data(), b.size());
         wld_s = upload_sigma(w.data(), V + D, J);
-    }
-    if (cfg.ctc_vocab_size > 0) {
-        dec.ctc_w = upload_gemm_tensor("ctc_decoder_.proj_.weight", {cfg.ctc_vocab_size, d});
-        dec.ctc_b = upload_tensor("ctc_decoder_.proj_.bias", {cfg.ctc_vocab_size});
     }
     // g1 = E W_ih0^T + b  ([V][4Hp]) on the MFMA GEMM: the same natural-k chains the per-step projection would run
     float *g1 = dev_alloc((size_t)V * 4 * Hp);
@@ -366,7 +373,7 @@ void Model::run_mel(const float *d_pcm, int B, int64_t n_samples, float *d_logme
     const int n_frames = (int)(1 + n_samples / 160);
     const double bytes_in = (double)B * n_samples * 4, bytes_lm = (double)B * cfg.mel_bins * n_frames * 4;
     KL("mel_logmel", 0.0, bytes_in + bytes_lm, launch_mel_logmel(d_pcm, B, n_samples, n_frames, mel, d_logmel, s));
-    KL("mel_normalize", 0.0, 2.0 * bytes_lm, launch_mel_normalize(d_logmel, B, cfg.mel_bins, n_frames, 1, d_feats, s));
+    KL("mel_normalize", 0.0, 2.0 * bytes_lm, launch_mel_normalize(d_logmel, B, cfg.mel_bins, n_frames, cfg.mel_normalize_off ? 0 : 1, d_feats, s));
 }
 
 // sinusoidal_position_embedding (src/encoder.cpp:9-30): float math on the host, exactly as the reference does,
@@ -416,6 +423,8 @@ void Model::run_subsample(Workspace &w, const float *d_feats, int B, int Tm, flo
     }
     // proj_  :240
     gemm("sub_proj", w.flat.as<float>(), (int64_t)C * W3, sub.pw, (int64_t)C * W3, sub.pb, d_x, d, B * H3, d, C * W3, EPI_NONE, nullptr, 0, 1.0f, s);
+    if (cfg.xscaling)                                               // streaming_encoder.cpp:402-406: x = x * sqrt(hidden_size)
+        KL("xscale", 0.0, 2.0 * B * H3 * d * 4, launch_scale(d_x, (int64_t)B * H3 * d, sqrtf((float)d), s));
     (void)W1; (void)H1;
 }
 
@@ -555,6 +564,7 @@ void Model::run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_lo
 void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s, bool keep_state) {
     const int d = cfg.hidden_size, Hp = cfg.pred_hidden, J = cfg.joint_hidden, V = cfg.vocab_size, D = cfg.rnnt_head ? 0 : cfg.num_durations;
     const int L = cfg.num_lstm_layers;
+    if (V <= 0) fail(PK_ERR_UNSUPPORTED, "this model has no prediction net / joint (encoder-only configuration)");
     // enc_proj_ hoisted out of the symbol loop: one GEMM over all frames (the reference recomputes it per symbol, src/tdt.cpp:17)
     gemm("joint_enc_proj", d_enc, d, dec.we, d, dec.be, w.ep.as<float>(), J, B * T, J, d, EPI_NONE, nullptr, 0, 1.0f, s);
     TdtState st{};

@@ -129,6 +129,7 @@ void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s);
 // ---- LayerNorm, canonical reductions, math diagnostics ------------------------------------------
 void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s);
 void launch_sum64_rows(const float *x, int rows, int n, float *out, hipStream_t s);
-void launch_math(int fn, const float *in, float *out, int64_t n, hipStream_t s);
+void launch_math(int fn, const float *in, float *out, int64_t n, hipStream_t s);   // 0 exp 1 log 2 tanh 3 sigmoid 4 silu 5 sqrt 6 recip 7 relu
+void launch_scale(float *x, int64_t n, float a, hipStream_t s);
 
 }  // namespace pk

@@ -74,6 +74,7 @@ __global__ void math_kernel(int fn, const float *__restrict__ in, float *__restr
         case 4: y = dsiluf(x); break;
         case 5: y = __builtin_sqrtf(x); break;
         case 6: y = 1.0f / x; break;
+        case 7: y = x > 0.0f ? x : 0.0f; break;
         default: y = x;
         }
         out[i] = y;
@@ -82,6 +83,14 @@ __global__ void math_kernel(int fn, const float *__restrict__ in, float *__restr
 void launch_math(int fn, const float *in, float *out, int64_t n, hipStream_t s) {
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(math_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, fn, in, out, n);
+}
+
+__global__ void scale_kernel(float *__restrict__ x, int64_t n, float a) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = x[i] * a;
+}
+void launch_scale(float *x, int64_t n, float a, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(scale_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, x, n, a);
 }
 
 }  // namespace pk

@@ -10,30 +10,9 @@
 #include <cmath>
 #include <cstring>
 
-#include "engine.hpp"
+#include "transformer.hpp"
 
 namespace pk {
-
-struct TransformerLayerW {
-    const float *n1g, *n1b, *n2g, *n2b, *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2;
-};
-
-class TransformerEncoder {
-  public:
-    TransformerEncoder(const std::string &weights_path, const std::string &prefix, const pk_transformer_config &c, int device);
-    ~TransformerEncoder();
-    void forward(const float *x_host, int B, int T, float *y_host);
-    pk_transformer_config cfg;
-
-  private:
-    int device_ = -1, hdp_ = 0, dp_ = 0;      // padded head dim / padded model width seen by the attention kernel
-    hipStream_t stream_ = nullptr;
-    std::vector<void *> allocs_;
-    std::vector<TransformerLayerW> layers_;
-    const float *fin_g_ = nullptr, *fin_b_ = nullptr;
-    DevBuf x_, n_, qkv_, ctx_, h_;
-    const float *upload(const float *h, size_t n);
-};
 
 const float *TransformerEncoder::upload(const float *h, size_t n) {
     void *p = nullptr;
@@ -109,14 +88,23 @@ TransformerEncoder::~TransformerEncoder() {
 
 void TransformerEncoder::forward(const float *x_host, int B, int T, float *y_host) {
     PK_HIP(hipSetDevice(device_));
+    const int64_t rows = (int64_t)B * T;
+    const int d = cfg.hidden_size;
+    x_.reserve(rows * d * 4);
+    PK_HIP(hipMemcpyAsync(x_.p, x_host, rows * d * 4, hipMemcpyHostToDevice, stream_));
+    forward_dev(x_.as<float>(), B, T, stream_);
+    PK_CHECK_LAUNCH();
+    PK_HIP(hipMemcpyAsync(y_host, x_.p, rows * d * 4, hipMemcpyDeviceToHost, stream_));
+    PK_HIP(hipStreamSynchronize(stream_));
+}
+
+void TransformerEncoder::forward_dev(float *x, int B, int T, hipStream_t s) {
     const int d = cfg.hidden_size, H = cfg.num_heads, f = cfg.ffn_intermediate, hd = d / H;
     const int64_t rows = (int64_t)B * T;
     const float eps = cfg.layer_norm_eps > 0.0f ? cfg.layer_norm_eps : 1e-5f;
     const float scale = 1.0f / sqrtf((float)hd);                              // src/transformer.cpp:27 (the REAL head dim)
-    x_.reserve(rows * d * 4); n_.reserve(rows * d * 4); qkv_.reserve(rows * 3 * dp_ * 4); ctx_.reserve(rows * dp_ * 4); h_.reserve(rows * f * 4);
-    float *x = x_.as<float>(), *n = n_.as<float>();
-    hipStream_t s = stream_;
-    PK_HIP(hipMemcpyAsync(x, x_host, rows * d * 4, hipMemcpyHostToDevice, s));
+    n_.reserve(rows * d * 4); qkv_.reserve(rows * 3 * dp_ * 4); ctx_.reserve(rows * dp_ * 4); h_.reserve(rows * f * 4);
+    float *n = n_.as<float>();
     for (const TransformerLayerW &L : layers_) {
         const float *in = x;
         if (cfg.pre_ln) { launch_layernorm(x, rows, d, L.n1g, L.n1b, eps, n, s); in = n; }        // :18
@@ -144,9 +132,6 @@ void TransformerEncoder::forward(const float *x_host, int B, int T, float *y_hos
         if (!cfg.pre_ln) launch_layernorm(x, rows, d, L.n2g, L.n2b, eps, x, s);
     }
     if (cfg.has_final_norm) launch_layernorm(x, rows, d, fin_g_, fin_b_, eps, x, s);              // :84-86
-    PK_CHECK_LAUNCH();
-    PK_HIP(hipMemcpyAsync(y_host, x, rows * d * 4, hipMemcpyDeviceToHost, s));
-    PK_HIP(hipStreamSynchronize(s));
 }
 
 }  // namespace pk

@@ -4,4 +4,6 @@
 #include "timestamp.hpp"
 #include "transcribe.hpp"
 #include "nemotron.hpp"
+#include "sortformer.hpp"
+#include "diarize.hpp"
 #include "vocab.hpp"

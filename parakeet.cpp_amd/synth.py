@@ -27,7 +27,8 @@ def synth_weights(cfg: ModelConfig, seed: int = 42) -> dict:
 
     C, d, F = cfg.subsampling_channels, cfg.hidden_size, cfg.mel_bins
     f3 = ((((F - 1) // 2 + 1) - 1) // 2 + 1 - 1) // 2 + 1
-    p = "encoder_.subsampling_."
+    ep = getattr(cfg, "encoder_prefix", "encoder_.")
+    p = ep + "subsampling_."
     for nm in ("conv1_", "dw1_", "dw2_"):
         W[p + nm + ".weight"] = (rng.standard_normal((C, 1, 3, 3)) / 3.0).astype(np.float32)
         W[p + nm + ".bias"] = (0.02 * rng.standard_normal(C)).astype(np.float32)
@@ -35,7 +36,7 @@ def synth_weights(cfg: ModelConfig, seed: int = 42) -> dict:
         lin(p + nm, C, C, extra_shape=(1, 1))
     lin(p + "proj_", d, C * f3)
     for i in range(cfg.num_layers):
-        q = f"encoder_.layers_.{i}."
+        q = f"{ep}layers_.{i}."
         for ff in ("ffn1_", "ffn2_"):
             norm(q + ff + ".norm_", d)
             lin(q + ff + ".fc1_", cfg.ffn_intermediate, d)
@@ -62,6 +63,8 @@ def synth_weights(cfg: ModelConfig, seed: int = 42) -> dict:
         lin(q + "conv_.pointwise_conv2_", d, d, extra_shape=(1,))
         norm(q + "final_norm_", d)
     V, Hp, J = cfg.vocab_size, cfg.pred_hidden, cfg.joint_hidden
+    if V <= 0:                                  # encoder-only (Sortformer's NEST encoder)
+        return W
     emb = rng.standard_normal((V, Hp)).astype(np.float32)
     emb[cfg.blank_id if cfg.blank_id < V else V - 1] = 0.0     # blank/SOS row is zero by training (tdt.cpp:56-57)
     W["prediction_.embed_.weight"] = emb
@@ -83,6 +86,32 @@ def synth_weights(cfg: ModelConfig, seed: int = 42) -> dict:
     if cfg.ctc_vocab_size:
         lin("ctc_decoder_.proj_", cfg.ctc_vocab_size, d, extra_shape=(1,))
         W["ctc_decoder_.proj_.bias"][cfg.ctc_vocab_size - 1] += 3.5
+    return W
+
+
+def synth_sortformer_weights(sf, seed: int = 42) -> dict:
+    """Sortformer state dict (AX_REGISTER_MODULES order, src/sortformer.cpp:41-47): nest_encoder_.*, projection_, transformer_.*,
+    output_proj_, first_hidden_, hidden_to_spks_ (registered, unused by forward)."""
+    W = synth_weights(sf.nest_encoder, seed)
+    rng = np.random.default_rng(seed + 1000)
+    d, dt, S, ffn = sf.nest_encoder.hidden_size, sf.transformer_hidden, sf.max_speakers, sf.transformer_ffn
+    lin = lambda o, i: (rng.standard_normal((o, i)) / np.sqrt(i)).astype(np.float32)
+    vec = lambda n, s=0.02: (s * rng.standard_normal(n)).astype(np.float32)
+    W["projection_.weight"], W["projection_.bias"] = lin(dt, d), vec(dt)
+    for l in range(sf.transformer_layers):
+        p = f"transformer_.layers_.{l}."
+        for n in ("norm1_", "norm2_"):
+            W[p + n + ".weight"] = (1 + vec(dt)).astype(np.float32); W[p + n + ".bias"] = vec(dt)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            W[p + "mha_." + n + ".weight"] = lin(dt, dt); W[p + "mha_." + n + ".bias"] = vec(dt)
+        W[p + "mha_.q_proj.weight"] *= np.float32(3.0)               # sharper attention: keeps frame-to-frame structure alive
+        W[p + "fc1_.weight"] = lin(ffn, dt); W[p + "fc1_.bias"] = vec(ffn)
+        W[p + "fc2_.weight"] = lin(dt, ffn); W[p + "fc2_.bias"] = vec(dt)
+    if sf.has_final_norm:
+        W["transformer_.final_norm_.weight"] = (1 + vec(dt)).astype(np.float32); W["transformer_.final_norm_.bias"] = vec(dt)
+    W["first_hidden_.weight"], W["first_hidden_.bias"] = lin(dt, dt), vec(dt)
+    W["output_proj_.weight"], W["output_proj_.bias"] = (4.0 * lin(S, dt)).astype(np.float32), vec(S)   # activities on both sides of 0.5
+    W["hidden_to_spks_.weight"], W["hidden_to_spks_.bias"] = lin(S, 2 * dt), vec(S)
     return W
 
 

@@ -94,3 +94,43 @@ def test_nemotron_transcriber_streams_a_wav(tmp_path, orc):
     assert len(ids) > 0, "degenerate test: nothing decoded"
     text = "".join(pieces[i] for i in ids).replace("▁", " ")
     assert r["text"] == (text[1:] if text.startswith(" ") else text)
+
+
+def test_diarized_transcriber_on_a_wav(tmp_path, orc):
+    """parakeet::Sortformer / DiarizedTranscriber (reference include/parakeet/diarize.hpp:55-78, src/diarize.cpp:10-106) through
+    examples/diarize_wav.cpp: segments == oracle Sortformer on the un-normalised 128-bin log-mel of the same WAV; every word gets the
+    speaker with the largest total overlap (recomputed here from the printed segments and the ASR word times)."""
+    exe = os.path.join(ROOT, "parakeet.cpp_amd", "examples", "diarize_wav")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    sf = pk.make_sortformer_117m_config()
+    Wsf = synth.synth_sortformer_weights(sf, seed=11)
+    cfg = pk.make_110m_config()
+    W = synth.synth_weights(cfg, seed=42)
+    sp, wp, vp, ap = (str(tmp_path / n) for n in ("sf.safetensors", "model.safetensors", "vocab.txt", "clip.wav"))
+    synth.save_weights(sp, Wsf)
+    synth.save_weights(wp, W)
+    synth.save_vocab(vp, synth.synth_vocab(1024))
+    pcm = synth.synth_pcm(1, 64000, seed=4)[0]
+    synth.write_wav_pcm16(ap, pcm)
+    q = (np.clip(pcm, -1, 1) * 32767.0).astype("<i2").astype(np.float32) / 32768.0
+    probs = orc.Model(sf.nest_encoder, Wsf).sortformer_forward(orc.mel(q, n_mels=128, normalize=False)[None], sf)[0]
+    want = orc.probs_to_segments(probs, 0.5)
+    assert len(want) > 0
+    out = subprocess.run([exe, sp, ap], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    segs = [(s[0], np.float32(s[1]), np.float32(s[2])) for s in json.loads(out.stdout)["segments"]]
+    assert segs == [(s, np.float32(a), np.float32(b)) for s, a, b in want]
+    out = subprocess.run([exe, sp, ap, wp, vp], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout)
+    assert [(s[0], np.float32(s[1]), np.float32(s[2])) for s in r["segments"]] == segs
+    assert len(r["words"]) > 0
+    for word, spk, a, b in r["words"]:
+        ov = {}
+        for s, sa, sb in segs:
+            o = min(np.float32(b), sb) - max(np.float32(a), sa)
+            if o > 0:
+                ov[s] = ov.get(s, np.float32(0)) + o
+        best = max(ov.values()) if ov else None
+        assert (spk == -1 and not ov) or (spk in ov and ov[spk] == best), (word, spk, ov)
