@@ -199,7 +199,7 @@ def main():
                     traffic = json.load(open(pmc)).get("ffn_fc1_silu_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": "gemm_pipe_kernel<2,4,2,1,32,EPI_SILU> (ffn_fc1_silu: 128x128 tile, 8 waves)", "achieved": round(ach, 2),
+            roof = {"bound": "mfma", "kernel": "gemm_pipe_kernel<4,2,1,2,32,EPI_SILU> (ffn_fc1_silu: 128x128 tile, 8 waves of 32x64)", "achieved": round(ach, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "flop_per_launch": per_launch_flop, "us_per_launch": round(per_launch_s * 1e6, 2),
                     "all_gemms": {"tflops": round(g_fl / max(g_ms, 1e-9), 2), "gflop": round(g_fl, 1), "ms": round(g_ms, 3)}}

@@ -35,30 +35,55 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
     const float4 rs = reinterpret_cast<const float4 *>(bn_rstd)[c4], ga = reinterpret_cast<const float4 *>(bn_g)[c4];
     const float4 be = reinterpret_cast<const float4 *>(bn_b)[c4];
     auto row = [&](int t) { return (t >= 0 && t < T) ? gp[(int64_t)t * d4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); };
-    float4 win[KC];                                                     // win[kk] = input row t + kk - HALF
-#pragma unroll
-    for (int kk = 0; kk < KC - 1; ++kk) win[kk + 1] = row(t0 + kk - HALF);
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-        const int t = t0 + tt;
-#pragma unroll
-        for (int kk = 0; kk < KC - 1; ++kk) win[kk] = win[kk + 1];
-        win[KC - 1] = row(t + HALF);
-        if (t >= T) break;
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-            acc.x = __builtin_fmaf(wt[kk].x, win[kk].x, acc.x);
-            acc.y = __builtin_fmaf(wt[kk].y, win[kk].y, acc.y);
-            acc.z = __builtin_fmaf(wt[kk].z, win[kk].z, acc.z);
-            acc.w = __builtin_fmaf(wt[kk].w, win[kk].w, acc.w);
-        }
+    auto bn_silu = [&](float4 acc) {
         float4 v;
         v.x = dsiluf(__builtin_fmaf(((acc.x + bi.x) - mu.x) * rs.x, ga.x, be.x));
         v.y = dsiluf(__builtin_fmaf(((acc.y + bi.y) - mu.y) * rs.y, ga.y, be.y));
         v.z = dsiluf(__builtin_fmaf(((acc.z + bi.z) - mu.z) * rs.z, ga.z, be.z));
         v.w = dsiluf(__builtin_fmaf(((acc.w + bi.w) - mu.w) * rs.w, ga.w, be.w));
-        op[(int64_t)t * d4] = v;
+        return v;
+    };
+    if constexpr (KC + TT - 1 <= 16) {
+        // every input row of the strip is requested before the first is used: KC + TT - 1 independent 16-byte loads in flight per
+        // thread (a load issued inside the frame loop stalled every frame for a full memory round trip: 34 us -> see DESIGN.md 8)
+        float4 win[KC + TT - 1];                                        // win[i] = input row t0 + i - HALF
+#pragma unroll
+        for (int i = 0; i < KC + TT - 1; ++i) win[i] = row(t0 + i - HALF);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int t = t0 + tt;
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                acc.x = __builtin_fmaf(wt[kk].x, win[tt + kk].x, acc.x);
+                acc.y = __builtin_fmaf(wt[kk].y, win[tt + kk].y, acc.y);
+                acc.z = __builtin_fmaf(wt[kk].z, win[tt + kk].z, acc.z);
+                acc.w = __builtin_fmaf(wt[kk].w, win[tt + kk].w, acc.w);
+            }
+            const float4 v = bn_silu(acc);
+            if (t < T) op[(int64_t)t * d4] = v;
+        }
+    } else {
+        float4 win[KC];                                                 // win[kk] = input row t + kk - HALF (sliding)
+#pragma unroll
+        for (int kk = 0; kk < KC - 1; ++kk) win[kk + 1] = row(t0 + kk - HALF);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int t = t0 + tt;
+#pragma unroll
+            for (int kk = 0; kk < KC - 1; ++kk) win[kk] = win[kk + 1];
+            win[KC - 1] = row(t + HALF);
+            if (t >= T) break;
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                acc.x = __builtin_fmaf(wt[kk].x, win[kk].x, acc.x);
+                acc.y = __builtin_fmaf(wt[kk].y, win[kk].y, acc.y);
+                acc.z = __builtin_fmaf(wt[kk].z, win[kk].z, acc.z);
+                acc.w = __builtin_fmaf(wt[kk].w, win[kk].w, acc.w);
+            }
+            op[(int64_t)t * d4] = bn_silu(acc);
+        }
     }
 }
 

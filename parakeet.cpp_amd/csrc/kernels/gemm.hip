@@ -198,8 +198,10 @@ static void launch_one(const GemmArgs &a, hipStream_t s) {
 template <int EPI>
 static void launch_epi(const GemmArgs &a, hipStream_t s) {
     if (a.K < 64) { launch_one<64, 64, EPI>(a, s); return; }           // pipelined kernels need >= 2 K tiles
-    if (a.M >= 1024 && a.N >= 2048) launch_gemm_pipe<2, 4, 2, 1, 32, EPI>(a, s);
-    else if (a.M >= 1024 && a.N >= 256 && (a.K >= 1024 || a.M >= 65536)) launch_gemm_pipe<2, 2, 2, 1, 32, EPI>(a, s);
+    // measured table: profiles/r01_gemm_sweep_v5.txt (128x128 tile on 8 waves of 32x64 wins for every wide output and for the
+    // 321k-row subsampling products; long-K / narrow-N products like fc2 of the 110M model take 128x64)
+    if (a.M >= 1024 && (a.N >= 1024 || (a.M >= 65536 && a.N >= 256))) launch_gemm_pipe<4, 2, 1, 2, 32, EPI>(a, s);
+    else if (a.M >= 1024 && a.N >= 256 && a.K >= 1024) launch_gemm_pipe<2, 2, 2, 1, 32, EPI>(a, s);
     else launch_gemm_pipe<2, 2, 1, 1, 32, EPI>(a, s);
 }
 

@@ -198,6 +198,34 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     auto epilogue_wide = [&](int m0, int n0) {
         constexpr int CP = BN + 4;                                  // C tile pitch (rows stay 16-byte aligned)
         static_assert((size_t)BM * CP <= 2 * (size_t)BUF, "C tile must fit in the staging buffers");
+        constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT, RSTEP = NT / C4;   // float4 chunks per output row / per thread; row stride
+        static_assert((BM * C4) % NT == 0 && NT % C4 == 0, "output tile must split evenly over the threads");
+        // A thread owns the SAME 4 output columns in all of its NCH chunks (rows rl0, rl0 + RSTEP, ...).  Everything the epilogue
+        // needs from global memory is requested FIRST -- bias once, the residual rows of all chunks -- so that the latency
+        // (1-2 us while the co-resident workgroup streams its tiles) overlaps the LDS transposition instead of being paid once
+        // per chunk: measured per-workgroup epilogue 15-28 us -> see profiles/r01_gemm_sweep_v5.txt.
+        const int c4 = tid % C4, rl0 = tid / C4;
+        const int col0 = n0 + 4 * c4;
+        const bool col_ok = col0 < g.N;
+        const bool sig = col0 < g.sigma_cols;
+        const int blk = (4 * c4) & ~15, sa = c4 & 3;                // sigma layout: position 16b + 4a + e holds natural column 16b + 4e + a
+        float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (g.bias && col_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bs[e] = g.bias[sig ? n0 + blk + 4 * e + sa : col0 + e];
+                if constexpr (EPI == EPI_GLU) bg[e] = g.bias[g.N + col0 + e];
+            }
+        }
+        float4 rs[NCH];
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                int row = m0 + rl0 + q * RSTEP;
+                row = row < g.M ? row : g.M - 1;
+                rs[q] = col_ok ? *reinterpret_cast<const float4 *>(g.resid + (int64_t)row * g.ldr + col0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
         __syncthreads();                                            // every wave is done reading its last fragments
         {
             const int lc = lane & 31, lr = 4 * (lane >> 5);
@@ -211,22 +239,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
         }
         __syncthreads();
         GP_STAMP(5);
-        constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT;           // float4 chunks per output row / per thread
-        static_assert((BM * C4) % NT == 0, "output tile must split evenly over the threads");
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            const int c = tid + NT * q, rl = c / C4, c4 = c % C4;
-            const int row = m0 + rl, col0 = n0 + 4 * c4;            // 4 consecutive output positions col0..col0+3
-            if (row >= g.M || col0 >= g.N) continue;
-            float v[4], gt[4], bs[4], bg[4];
-            if (col0 < g.sigma_cols) {
-                // sigma layout: position 16b + 4a + e holds natural column 16b + 4e + a
-                const int blk = (4 * c4) & ~15, a = c4 & 3;
+            const int rl = rl0 + q * RSTEP;
+            const int row = m0 + rl;
+            float v[4], gt[4];
+            if (sig) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = smem[rl * CP + blk + 4 * e + a];
-                    bs[e] = g.bias ? g.bias[n0 + blk + 4 * e + a] : 0.0f;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = smem[rl * CP + blk + 4 * e + sa];
             } else {
                 int vc = 4 * c4;                                    // virtual column of the value inside the C tile
                 if constexpr (EPI == EPI_GLU) vc = (vc / (WN / 2)) * WN + vc % (WN / 2);
@@ -236,15 +256,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
                     const float4 y = *reinterpret_cast<const float4 *>(smem + rl * CP + vc + WN / 2);
                     gt[0] = y.x; gt[1] = y.y; gt[2] = y.z; gt[3] = y.w;
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bs[e] = g.bias ? g.bias[col0 + e] : 0.0f;
-                    if constexpr (EPI == EPI_GLU) bg[e] = g.bias ? g.bias[g.N + col0 + e] : 0.0f;
-                }
             }
-            float4 rs = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if constexpr (EPI == EPI_RESID) rs = *reinterpret_cast<const float4 *>(g.resid + (int64_t)row * g.ldr + col0);
-            const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+            float rsv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (EPI == EPI_RESID) { rsv[0] = rs[q].x; rsv[1] = rs[q].y; rsv[2] = rs[q].z; rsv[3] = rs[q].w; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = v[e];
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
                 }
                 v[e] = x;
             }
-            *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
+            if (row < g.M && col_ok) *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
     const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);

@@ -10,7 +10,8 @@
 #include <vector>
 
 #define GP_CLOCKPROBE 1
-#include "../../parakeet.cpp_amd/csrc/kernels/gemm.hip"   // first-generation kernel + launch_gemm
+#include "../../parakeet.cpp_amd/csrc/kernels/gemm.hip"
+#include "../../parakeet.cpp_amd/csrc/kernels/gemm_smallm.hip"   // first-generation kernel + launch_gemm
 
 using namespace pk;
 
