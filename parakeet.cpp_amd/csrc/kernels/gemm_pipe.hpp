@@ -23,6 +23,9 @@ namespace pk {
 
 typedef float gp_f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef GP_EXP
+#define GP_EXP 0                    // micro-benchmark experiments only (tools/ubench): 1 = epilogue without global stores,
+#endif                              // 2 = epilogue without activation math, 4 = global loads three K tiles ahead
 #ifdef GP_CLOCKPROBE
 __device__ long long gp_clk[4];     // micro-benchmark builds only: shader / wall clock deltas of block 0
 __device__ long long *gp_trace;     // micro-benchmark builds only: [n_blocks][8] wall-clock stamps of wave 0 + hw id
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
                 if constexpr (EPI == EPI_RELU) {
                     x = x > 0.0f ? x : 0.0f;
                 } else if constexpr (EPI == EPI_SILU) {
-                    x = dsiluf(x);
+                    if (!(GP_EXP & 2)) x = dsiluf(x);
                 } else if constexpr (EPI == EPI_RESID) {
                     const float y = x * g.alpha;
                     x = rsv[e] + y;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
                 }
                 v[e] = x;
             }
-            if (row < g.M && col_ok) *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
+            if ((GP_EXP & 1) ? (row < 0) : (row < g.M && col_ok)) *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
     const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);

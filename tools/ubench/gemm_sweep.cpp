@@ -151,7 +151,7 @@ int main(int argc, char **argv) {
     if (argc > 2 && strcmp(argv[2], "trace") == 0) {   // per-workgroup timeline of one launch -> gpurun_out/gemm_trace_<name>.bin
         struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; int nblk; };
         const std::vector<KV> kv = {{"p128x128_512t", run_pipe<2, 4, 2, 1, 32>, 63 * 16}, {"p64x64", run_pipe<2, 2, 1, 1, 32>, 126 * 32},
-                                    {"p128x128_w64x64", run_pipe<2, 2, 2, 2, 32>, 63 * 16},};
+                                    {"p128x128_w64x64", run_pipe<2, 2, 2, 2, 32>, 63 * 16}, {"p128x128_w32x64_512t", run_pipe<4, 2, 1, 2, 32>, 63 * 16},};
         long long *dtrace;
         CK(hipMalloc(&dtrace, 8192 * 8 * 8));
         for (auto &v : kv) {
@@ -174,7 +174,7 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
-    if (argc > 2) {   // K scan: time = fixed + per-K cost
+    if (argc == 3) {   // K scan: time = fixed + per-K cost
         struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
         const std::vector<KV> kv = {{"old 128x128", run_old<128, 128>}, {"pipe 64x64 bk32", run_pipe<2, 2, 1, 1, 32>},
                                     {"pipe 128x128 w64x32 512t", run_pipe<2, 4, 2, 1, 32>}, {"pipe 128x128 w64x64", run_pipe<2, 2, 2, 2, 32>},};
@@ -199,8 +199,10 @@ int main(int argc, char **argv) {
             }
         return 0;
     }
+    const bool quick = argc > 3;                                    // gemm_sweep <reps> - quick : the two FFN shapes, 512-thread variants
     std::vector<unsigned> href, hout;
     for (auto &sh : shapes) {
+        if (quick && strncmp(sh.name, "fc", 2) != 0) continue;
         GemmArgs g{dA, sh.K, dW, sh.K, dB, dRef, sh.N, dR, sh.N, 0.5f, sh.M, sh.N, sh.K};
         const double flops = 2.0 * sh.M * (double)sh.N * sh.K * (sh.epi == EPI_GLU ? 2 : 1);
         const size_t no = (size_t)sh.M * sh.N;
@@ -213,6 +215,7 @@ int main(int argc, char **argv) {
         printf("== %s  %.2f GFLOP\n", sh.name, flops * 1e-9);
         for (auto &v : variants) {
             const bool is_old = strncmp(v.name, "old", 3) == 0;
+            if (quick && strstr(v.name, "512t") == nullptr && strstr(v.name, "128x64") == nullptr) continue;
             if (sh.epi == EPI_GLU) {
                 if (is_old && strstr(v.name, "128x128") == nullptr) continue;
                 if (strstr(v.name, "w64x32") || strstr(v.name, "w32x32")) continue;   // TN odd
