@@ -88,14 +88,17 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     }                                                                               \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (NCH > 0) {
-        // ring of three register sets: chunk c+2 is in flight while chunk c feeds the MFMA chain (>= 1280 cycles of cover)
-        float4 xs[3][CH], ws[3][CH];
-        SK_LOAD(xs[0], ws[0], 0)
-        if (NCH > 1) { SK_LOAD(xs[1], ws[1], 1) }
+        // two register sets, fully unrolled: chunk c+1 is in flight while chunk c feeds the MFMA chain (>= 640 cycles of cover).
+        // A third set hid more latency but pushed the kernel past 96 VGPRs, and then a decode wave no longer fits next to the
+        // four 104-VGPR waves per SIMD of the 128x128 GEMM of the NEXT batch's encoder (two-stream pipeline): every decode
+        // workgroup had to wait for a GEMM workgroup to retire and then held that slot -- 2.0 ms per 64-clip batch.
+        SK_LOAD(xa, wa, 0)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 2 < NCH) { SK_LOAD(xs[(c + 2) % 3], ws[(c + 2) % 3], c + 2) }
-            SK_MMA(xs[c % 3], ws[c % 3])
+        for (int c = 0; c < NCH; c += 2) {
+            if (c + 1 < NCH) { SK_LOAD(xb, wb, c + 1) }
+            SK_MMA(xa, wa)
+            if (c + 2 < NCH) { SK_LOAD(xa, wa, c + 2) }
+            if (c + 1 < NCH) { SK_MMA(xb, wb) }
         }
     } else {
         SK_LOAD(xa, wa, 0)
