@@ -133,11 +133,18 @@ void pk_batch_free(pk_batch *b);
 /* Host -> HBM copy of the PCM (outside bench's timed region). */
 pk_status pk_batch_upload(pk_batch *b, const float *pcm, int n_clips);
 /* mel -> encoder -> decode, enqueued on the batch's stream; returns without synchronising. */
+/* Streams of distinct batches: copy the NEXT batch into the second PCM buffer on a copy stream while the current encoder runs
+ * (no flush; the host buffer may be reused after the call returns for pageable memory, after the next call into the batch for
+ * pinned memory).  The next pk_batch_run consumes it. */
+pk_status pk_batch_upload_async(pk_batch *b, const float *pcm, int n_clips);
 pk_status pk_batch_run(pk_batch *b, int decoder);
 pk_status pk_batch_sync(pk_batch *b);
 /* Token ids etc. of the last run (synchronises).  Arrays [n_clips][max_tokens]; max_tokens = pk_batch_max_tokens. */
 int pk_batch_max_tokens(const pk_batch *b);
 pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
+/* Results of the newest batch whose decode has FINISHED -- run k's decode is driven inside pk_batch_run(k+1) -- without flushing the
+ * decode still pending: the consumer side of the pipeline (run(k+1); results_done -> batch k).  *n_clips = its clip count. */
+pk_status pk_batch_results_done(pk_batch *b, int *n_clips, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
 /* Stage timers of the last pk_batch_run_timed (ms): mel, encoder, decode, total (hipEvents on the batch stream). */
 pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]);
 /* Raw device pointers for zero-copy producers (e.g. torch tensors): PCM [max_clips][n_samples] f32. */

@@ -120,6 +120,8 @@ _LATE_SIGNATURES = {
     "pk_batch_free": [C.c_void_p],
     "pk_batch_upload": [C.c_void_p, f32p, C.c_int],
     "pk_batch_run": [C.c_void_p, C.c_int],
+    "pk_batch_upload_async": [C.c_void_p, f32p, C.c_int],
+    "pk_batch_results_done": [C.c_void_p, C.POINTER(C.c_int), i32p, i32p, i32p, i32p, f32p],
     "pk_batch_sync": [C.c_void_p],
     "pk_batch_max_tokens": [C.c_void_p],
     "pk_batch_results": [C.c_void_p, i32p, i32p, i32p, i32p, f32p],
@@ -372,6 +374,7 @@ class Batch:
     def __init__(self, model, max_clips, n_samples):
         self._h = C.c_void_p()
         self.n_clips = 0
+        self._cap = max_clips
         check(lib().pk_batch_create(model._h, max_clips, n_samples, C.byref(self._h)))
 
     def upload(self, pcm):
@@ -379,8 +382,28 @@ class Batch:
         self.n_clips = pcm.shape[0]
         check(lib().pk_batch_upload(self._h, _f(pcm), self.n_clips))
 
+    def upload_async(self, pcm):
+        """Stage the NEXT batch under the running encoder (double-buffered PCM, no flush)."""
+        pcm = _c(pcm)
+        self._staged = pcm                                   # keep the host array alive until the copy has been consumed
+        self._staged_clips = pcm.shape[0]
+        check(lib().pk_batch_upload_async(self._h, _f(pcm), pcm.shape[0]))
+
     def run(self, decoder="tdt"):
+        if getattr(self, "_staged_clips", 0):
+            self.n_clips, self._staged_clips = self._staged_clips, 0
         check(lib().pk_batch_run(self._h, {"ctc": 0, "tdt": 1}[decoder]))
+
+    def results_done(self):
+        """Results of the newest batch whose decode has finished (run k's decode completes inside run k+1); no flush."""
+        mt = lib().pk_batch_max_tokens(self._h)
+        cap = self._cap
+        ids = np.zeros((cap, mt), np.int32); st = np.zeros((cap, mt), np.int32); en = np.zeros((cap, mt), np.int32)
+        cf = np.zeros((cap, mt), np.float32); lens = np.zeros(cap, np.int32)
+        n = C.c_int(0)
+        check(lib().pk_batch_results_done(self._h, C.byref(n), _i(ids), _i(lens), _i(st), _i(en), _f(cf)))
+        B = n.value
+        return dict(ids=ids[:B], lens=lens[:B], start=st[:B], end=en[:B], conf=cf[:B])
 
     def results(self):
         B, mt = self.n_clips, lib().pk_batch_max_tokens(self._h)

@@ -272,9 +272,19 @@ pk_status pk_tdt_decode(pk_model *h, const float *enc, int B, int T, int max_tok
 // Two workspaces + two streams: the latency-bound decode loop of batch k (high-priority stream, a few small kernels
 // per step) runs concurrently with the MFMA-bound mel + encoder of batch k+1 (main stream).  pk_batch_run(k) enqueues
 // encoder(k) and then drives decode(k-1); pk_batch_sync / pk_batch_results flush the decode still pending.
+// A stream of DISTINCT batches keeps the overlap with pk_batch_upload_async (PCM double-buffered, copied on its own stream
+// under the running encoder) + pk_batch_results_done (the batch whose decode finished inside the last pk_batch_run; no flush).
 struct pk_batch {
     Model *m;
-    DevBuf pcm;                 // [max_clips][n_samples], shared by both slots (read-only during a run)
+    DevBuf pcm2[2];             // [max_clips][n_samples] x 2: the buffer being read by mel(k) and the one upload(k+1) fills
+    int cur = 0;                // buffer the next pk_batch_run reads
+    int staged = -1;            // buffer filled by pk_batch_upload_async and not yet consumed by a run
+    int staged_clips = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done[2], mel_done[2];
+    bool mel_used[2] = {false, false};
+    int slot_clips[2] = {0, 0}; // clips of the run that owns each workspace
+    int last_clips = 0;         // clips of the newest finished results
     Workspace ws[2];
     int n_clips = 0;
     int runs = 0;               // pk_batch_run calls so far
@@ -291,21 +301,32 @@ static void batch_encode(pk_batch *b, int slot) {
     Workspace &w = b->ws[slot];
     hipStream_t s = m.stream;
     if (b->used[slot]) PK_HIP(hipStreamWaitEvent(s, b->dec_done[slot], 0));   // decode(k-2) must be done with this slot
-    m.run_mel(b->pcm.as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
+    if (b->staged >= 0) {                                    // a batch uploaded under the previous run: switch buffers
+        b->cur = b->staged;
+        b->n_clips = b->staged_clips;
+        b->staged = -1;
+        PK_HIP(hipStreamWaitEvent(s, b->copy_done[b->cur], 0));
+    }
+    m.run_mel(b->pcm2[b->cur].as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
+    PK_HIP(hipEventRecord(b->mel_done[b->cur], s));         // the PCM buffer is free again once the mel kernels have read it
+    b->mel_used[b->cur] = true;
     m.run_encoder(w, w.feats.as<float>(), b->n_clips, w.Tm, -1, 0, s);
     PK_HIP(hipEventRecord(b->enc_done[slot], s));
     b->used[slot] = true;
+    b->slot_clips[slot] = b->n_clips;
 }
 
 static void batch_decode(pk_batch *b, int slot, int decoder, hipStream_t s) {
     Model &m = *b->m;
     Workspace &w = b->ws[slot];
     if (s != m.stream) PK_HIP(hipStreamWaitEvent(s, b->enc_done[slot], 0));
-    if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), b->n_clips, w.T, false, s);
-    else m.run_tdt(w, w.x.as<float>(), b->n_clips, w.T, w.max_tokens, s);
+    const int nc = b->slot_clips[slot] > 0 ? b->slot_clips[slot] : b->n_clips;
+    if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), nc, w.T, false, s);
+    else m.run_tdt(w, w.x.as<float>(), nc, w.T, w.max_tokens, s);
     PK_HIP(hipEventRecord(b->dec_done[slot], s));
     b->last_slot = slot;
     b->last_decoder = decoder;
+    b->last_clips = nc;
 }
 
 static void batch_flush(pk_batch *b) {
@@ -321,7 +342,7 @@ static void batch_flush(pk_batch *b) {
 static void batch_run(pk_batch *b, int decoder) {
     Model &m = *b->m;
     m.require_gpu();
-    need(b->n_clips > 0, "pk_batch_upload() first");
+    need(b->n_clips > 0 || b->staged >= 0, "pk_batch_upload() first");
     need(decoder == PK_DECODER_CTC || decoder == PK_DECODER_TDT, "decoder");
     const int slot = b->runs & 1;
     batch_encode(b, slot);                                   // encoder(k) is queued first ...
@@ -343,12 +364,15 @@ pk_status pk_batch_create(pk_model *h, int max_clips, int64_t n_samples, pk_batc
         m.require_gpu();
         auto b = std::make_unique<pk_batch>();
         b->m = &m;
-        b->pcm.reserve((size_t)max_clips * n_samples * 4);
+        for (auto &p : b->pcm2) p.reserve((size_t)max_clips * n_samples * 4);
         for (auto &w : b->ws) w.size_for(m.cfg, max_clips, -n_samples, pk_mel_num_frames(n_samples));
         for (auto &e : b->ev) PK_HIP(hipEventCreate(&e));
+        PK_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             PK_HIP(hipEventCreateWithFlags(&b->enc_done[i], hipEventDisableTiming));
             PK_HIP(hipEventCreateWithFlags(&b->dec_done[i], hipEventDisableTiming));
+            PK_HIP(hipEventCreateWithFlags(&b->copy_done[i], hipEventDisableTiming));
+            PK_HIP(hipEventCreateWithFlags(&b->mel_done[i], hipEventDisableTiming));
         }
         b->ev_ok = true;
         *out = b.release();
@@ -360,8 +384,13 @@ void pk_batch_free(pk_batch *b) {
     if (b->ev_ok) {
         (void)hipStreamSynchronize(b->m->stream_dec);
         (void)hipStreamSynchronize(b->m->stream);
+        (void)hipStreamSynchronize(b->copy_stream);
         for (auto &e : b->ev) (void)hipEventDestroy(e);
-        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(b->enc_done[i]); (void)hipEventDestroy(b->dec_done[i]); }
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(b->enc_done[i]); (void)hipEventDestroy(b->dec_done[i]);
+            (void)hipEventDestroy(b->copy_done[i]); (void)hipEventDestroy(b->mel_done[i]);
+        }
+        (void)hipStreamDestroy(b->copy_stream);
     }
     delete b;
 }
@@ -371,9 +400,25 @@ pk_status pk_batch_upload(pk_batch *b, const float *pcm, int n_clips) {
         need(b && pcm && n_clips > 0 && n_clips <= b->ws[0].B, "batch/pcm/n_clips");
         b->m->require_gpu();
         batch_flush(b);
-        PK_HIP(hipMemcpyAsync(b->pcm.p, pcm, (size_t)n_clips * b->ws[0].n_samples * 4, hipMemcpyHostToDevice, b->m->stream));
+        PK_HIP(hipStreamSynchronize(b->copy_stream));
+        b->staged = -1;
+        PK_HIP(hipMemcpyAsync(b->pcm2[b->cur].p, pcm, (size_t)n_clips * b->ws[0].n_samples * 4, hipMemcpyHostToDevice, b->m->stream));
         PK_HIP(hipStreamSynchronize(b->m->stream));
         b->n_clips = n_clips;
+    });
+}
+
+pk_status pk_batch_upload_async(pk_batch *b, const float *pcm, int n_clips) {
+    return guard([&] {
+        need(b && pcm && n_clips > 0 && n_clips <= b->ws[0].B, "batch/pcm/n_clips");
+        b->m->require_gpu();
+        const int nb = b->staged >= 0 ? b->staged : (b->cur ^ 1);      // re-staging before a run overwrites the staged batch
+        PK_HIP(hipStreamSynchronize(b->copy_stream));                  // at most one copy in flight; the previous host buffer is released here
+        if (b->mel_used[nb]) PK_HIP(hipStreamWaitEvent(b->copy_stream, b->mel_done[nb], 0));   // the last mel that read this buffer
+        PK_HIP(hipMemcpyAsync(b->pcm2[nb].p, pcm, (size_t)n_clips * b->ws[0].n_samples * 4, hipMemcpyHostToDevice, b->copy_stream));
+        PK_HIP(hipEventRecord(b->copy_done[nb], b->copy_stream));
+        b->staged = nb;
+        b->staged_clips = n_clips;
     });
 }
 
@@ -395,7 +440,7 @@ pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *st
         batch_flush(b);
         need(b->last_slot >= 0, "pk_batch_run() first");
         Workspace &w = b->ws[b->last_slot];
-        const int B = b->n_clips, mt = w.max_tokens;
+        const int B = b->last_clips > 0 ? b->last_clips : b->n_clips, mt = w.max_tokens;
         PK_HIP(hipMemcpy(lens, w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
         if (b->last_decoder == PK_DECODER_TDT) {
             const size_t n = (size_t)B * mt * 4;
@@ -417,6 +462,26 @@ pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *st
     });
 }
 
+pk_status pk_batch_results_done(pk_batch *b, int *n_clips, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
+    return guard([&] {
+        need(b && ids && lens, "batch/ids/lens");
+        Model &m = *b->m;
+        m.require_gpu();
+        need(b->last_slot >= 0, "no decoded batch yet: the decode of run k finishes inside pk_batch_run(k+1) (or pk_batch_sync)");
+        PK_HIP(hipEventSynchronize(b->dec_done[b->last_slot]));
+        Workspace &w = b->ws[b->last_slot];
+        const int B = b->last_clips, mt = w.max_tokens;
+        if (n_clips) *n_clips = B;
+        const size_t wid = (size_t)(b->last_decoder == PK_DECODER_TDT ? mt : w.T) * 4;
+        auto pitch = [&](void *dst, const void *src) {
+            if (dst) PK_HIP(hipMemcpy2D(dst, (size_t)mt * 4, src, wid, wid, B, hipMemcpyDeviceToHost));
+        };
+        PK_HIP(hipMemcpy(lens, w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+        pitch(ids, w.ids.p); pitch(start, w.start.p); pitch(end, w.end.p); pitch(conf, w.conf.p);
+        zero_tail(ids, lens, B, mt); zero_tail(start, lens, B, mt); zero_tail(end, lens, B, mt); zero_tail(conf, lens, B, mt);
+    });
+}
+
 // One un-pipelined run on the main stream with hipEvents between the stages (mel / encoder / decode / total, ms).
 pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]) {
     return guard([&] {
@@ -429,10 +494,11 @@ pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]) {
         Workspace &w = b->ws[0];
         hipStream_t s = m.stream;
         PK_HIP(hipEventRecord(b->ev[0], s));
-        m.run_mel(b->pcm.as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
+        m.run_mel(b->pcm2[b->cur].as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
         PK_HIP(hipEventRecord(b->ev[1], s));
         m.run_encoder(w, w.feats.as<float>(), b->n_clips, w.Tm, -1, 0, s);
         PK_HIP(hipEventRecord(b->ev[2], s));
+        b->slot_clips[0] = b->n_clips;
         batch_decode(b, 0, decoder, s);
         PK_HIP(hipEventRecord(b->ev[3], s));
         PK_CHECK_LAUNCH();
@@ -445,7 +511,7 @@ pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]) {
     });
 }
 
-void *pk_batch_dev_pcm(pk_batch *b) { return b ? b->pcm.p : nullptr; }
+void *pk_batch_dev_pcm(pk_batch *b) { return b ? b->pcm2[b->cur].p : nullptr; }
 void *pk_batch_stream(pk_batch *b) { return b ? (void *)b->m->stream : nullptr; }
 
 int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap) {
@@ -458,8 +524,9 @@ int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap) {
         batch_flush(b);
         try {
             Workspace &w = b->ws[0];
-            m.run_mel(b->pcm.as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), m.stream);
+            m.run_mel(b->pcm2[b->cur].as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), m.stream);
             m.run_encoder(w, w.feats.as<float>(), b->n_clips, w.Tm, -1, 0, m.stream);
+            b->slot_clips[0] = b->n_clips;
             batch_decode(b, 0, decoder, m.stream);
             PK_HIP(hipStreamSynchronize(m.stream));
             b->used[0] = true;

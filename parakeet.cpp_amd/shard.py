@@ -28,3 +28,42 @@ def gather_results(local: Sequence, local_idx: Sequence[int], n_items: int, worl
         for i, r in zip(idx, res):
             merged[i] = r
     return merged
+
+
+def gather_token_matrix(local_ids, local_lens, local_idx: Sequence[int], n_items: int, world: int, dist=None, device=None):
+    """Collective result exchange of the sharded run: every rank contributes a fixed-stride int32 matrix
+    [n_local_padded][1 + max_tokens] (column 0 = clip index or -1 for padding rows, column 1 = length, then the ids) and ONE
+    all_gather_into_tensor ('nccl' = RCCL over xGMI on MI355X; 'gloo' in the CPU tests) brings them to every rank; rows are put
+    back in clip order.  Returns (ids [n_items][max_tokens], lens [n_items]).  ~2 MB for 8192 clips: latency-bound, off the data path."""
+    import numpy as np
+    import torch
+    local_ids = np.asarray(local_ids, np.int32)
+    mt = local_ids.shape[1] if local_ids.ndim == 2 else 0
+    n_local = len(local_idx)
+    per_rank = (n_items + world - 1) // world if world > 1 else n_items
+    # ranks own different numbers of clips (round-robin over batches): pad to the largest shard
+    if world > 1 and dist is not None:
+        t = torch.tensor([n_local], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank = int(t.item())
+    mat = np.full((per_rank, 2 + mt), -1, np.int32)
+    mat[:n_local, 0] = np.asarray(local_idx, np.int32)
+    mat[:n_local, 1] = np.asarray(local_lens, np.int32)
+    if mt:
+        mat[:n_local, 2:] = local_ids
+    if world > 1 and dist is not None:
+        mine = torch.from_numpy(mat).to(device) if device is not None else torch.from_numpy(mat)
+        out = torch.empty((world * per_rank, 2 + mt), dtype=torch.int32, device=mine.device)
+        dist.all_gather_into_tensor(out, mine)
+        mat = out.cpu().numpy()
+    ids = np.zeros((n_items, mt), np.int32)
+    lens = np.zeros(n_items, np.int32)
+    seen = 0
+    for row in mat:
+        if row[0] >= 0:
+            ids[row[0]] = row[2:]
+            lens[row[0]] = row[1]
+            seen += 1
+    if seen != n_items:
+        raise RuntimeError(f"sharded gather: {seen} of {n_items} clips arrived")
+    return ids, lens

@@ -40,6 +40,15 @@ WORKER = textwrap.dedent("""
     local = [[i * 7 % 13, i] for i in idx]                    # stand-in for per-clip token ids
     merged = gather_results(local, idx, n, world, dist)
     assert merged == [[i * 7 % 13, i] for i in range(n)], "reassembly order"
+    import numpy as np
+    from parakeet_cpp_amd.shard import gather_token_matrix
+    lens = np.array([1 + i % 5 for i in idx], np.int32)
+    ids = np.zeros((len(idx), 6), np.int32)
+    for r, i in enumerate(idx):
+        ids[r, :lens[r]] = np.arange(lens[r]) + 10 * i
+    gi, gl = gather_token_matrix(ids, lens, idx, n, world, dist)          # fixed-stride all_gather_into_tensor (RCCL on the GPU box)
+    assert gl.tolist() == [1 + i % 5 for i in range(n)]
+    assert all(gi[i, :gl[i]].tolist() == (np.arange(gl[i]) + 10 * i).tolist() for i in range(n)), "token matrix order"
     import torch
     t = torch.tensor([float(len(idx))]); dist.all_reduce(t)
     assert int(t.item()) == n
