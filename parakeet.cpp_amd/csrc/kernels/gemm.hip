@@ -202,6 +202,7 @@ static void launch_epi(const GemmArgs &a, hipStream_t s) {
     // 321k-row subsampling products; long-K / narrow-N products like fc2 of the 110M model take 128x64)
     if (a.M >= 1024 && (a.N >= 1024 || (a.M >= 65536 && a.N >= 256))) launch_gemm_pipe<4, 2, 1, 2, 32, EPI>(a, s);
     else if (a.M >= 1024 && a.N >= 256 && a.K >= 1024) launch_gemm_pipe<2, 2, 2, 1, 32, EPI>(a, s);
+    else if (a.M >= 1024 && a.N >= 256) launch_gemm_pipe<2, 4, 1, 1, 32, EPI>(a, s);      // 64x128 on 8 waves of 32x32: out_proj / pw2 (-7 %)
     else launch_gemm_pipe<2, 2, 1, 1, 32, EPI>(a, s);
 }
 
