@@ -429,10 +429,11 @@ void Model::run_subsample(Workspace &w, const float *d_feats, int B, int Tm, flo
 }
 
 // FeedForward::forward (src/encoder.cpp:39-46): x += 0.5 * fc2(silu(fc1(LN(x))))
-void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s) {
+void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done) {
     const int d = cfg.hidden_size, f = cfg.ffn_intermediate;
     float *x = w.x.as<float>(), *n = w.n.as<float>(), *h = w.hbuf.as<float>();
-    KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, s));
+    if (!norm_done)    // (the first FFN's norm rides on the previous block's final_norm_ kernel, see run_layers)
+        KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, s));
     gemm("ffn_fc1_silu", n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, h, f, (int)rows, f, d, EPI_SILU, nullptr, 0, 1.0f, s);
     gemm("ffn_fc2_resid", h, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, (int)rows, d, f, EPI_RESID, x, d, 0.5f, s);
 }
@@ -452,11 +453,13 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
     if (stop_layer < 0 || stop_layer > cfg.num_layers) { stop_layer = cfg.num_layers; stop_stage = 0; }
     if (stop_layer == 0 && stop_stage == 0) return;
     ensure_pos_tables(T, s);
+    bool ffn1_norm_done = false;
     for (int l = first_layer; l < cfg.num_layers; ++l) {
         if (l > stop_layer || (l == stop_layer && stop_stage == 0)) break;
         const LayerW &L = layers[l];
         const int stage_cap = (l == stop_layer) ? stop_stage : 5;
-        ffn(w, L, false, rows, s);                                                   // ffn1_  :197
+        ffn(w, L, false, rows, s, ffn1_norm_done);                                   // ffn1_  :197
+        ffn1_norm_done = false;
         if (stage_cap == 1) break;
         // ConformerAttention::forward  :180-186
         KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, s));
@@ -485,7 +488,14 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
         if (stage_cap == 3) break;
         ffn(w, L, true, rows, s);                                                    // ffn2_  :201
         if (stage_cap == 4) break;
-        KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, s));   // final_norm_ :202
+        const bool next_runs = l + 1 < cfg.num_layers && !(l + 1 > stop_layer || (l + 1 == stop_layer && stop_stage == 0));
+        if (next_runs) {           // final_norm_ :202 and the next block's ffn1_ norm :40 in one pass over the rows
+            KL("layernorm", 0.0, 3.0 * rows * d * 4,
+               launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, layers[l + 1].ffn1_ng, layers[l + 1].ffn1_nb, 1e-5f, x, n, s));
+            ffn1_norm_done = true;
+        } else {
+            KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, s));   // final_norm_ :202
+        }
     }
 }
 

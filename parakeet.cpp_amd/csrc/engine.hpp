@@ -127,7 +127,7 @@ class Model {
     void upload_weights();
     void gemm(const char *name, const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *out, int64_t ldo,
               int M, int N, int K, int epi, const float *resid, int64_t ldr, float alpha, hipStream_t s);
-    void ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s);
+    void ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done = false);
 };
 
 // thread-local error slot of the C ABI

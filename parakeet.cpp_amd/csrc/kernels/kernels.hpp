@@ -128,6 +128,9 @@ void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s);
 
 // ---- LayerNorm, canonical reductions, math diagnostics ------------------------------------------
 void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s);
+// y1 = LN(x; g1, b1), y2 = LN(y1; g2, b2) in one pass (y1 may alias x)
+void launch_layernorm2(const float *x, int64_t rows, int d, const float *g1, const float *b1, const float *g2, const float *b2, float eps,
+                       float *y1, float *y2, hipStream_t s);
 void launch_sum64_rows(const float *x, int rows, int n, float *out, hipStream_t s);
 void launch_math(int fn, const float *in, float *out, int64_t n, hipStream_t s);   // 0 exp 1 log 2 tanh 3 sigmoid 4 silu 5 sqrt 6 recip 7 relu
 void launch_scale(float *x, int64_t n, float a, hipStream_t s);

@@ -44,6 +44,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     }
 }
 
+// Two LayerNorms back to back on the same row: y1 = LN(x; g1, b1) (a block's final_norm_, src/encoder.cpp:202) and
+// y2 = LN(y1; g2, b2) (the next block's ffn1_ norm, :40) -- the row stays in registers, one read of x instead of two, one launch
+// instead of two.  Every value goes through exactly the operations of two layernorm_kernel passes (same sum64 butterflies).
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float *__restrict__ x, int64_t rows, int d, const float *__restrict__ g1,
+                                                         const float *__restrict__ b1, const float *__restrict__ g2,
+                                                         const float *__restrict__ b2, float eps, float *__restrict__ y1,
+                                                         float *__restrict__ y2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * d;
+    float v[PER_LANE];
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = i < d ? xr[i] : 0.0f;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const float *g = pass ? g2 : g1, *b = pass ? b2 : b1;
+        float *yr = (pass ? y2 : y1) + row * d;
+        float p = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j)
+            if (lane + 64 * j < d) p = p + v[j];
+        const float mean = wave_sum64(p) / (float)d;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j)
+            if (lane + 64 * j < d) {
+                const float c = v[j] - mean;
+                q = q + c * c;
+            }
+        const float var = wave_sum64(q) / (float)d;
+        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j) {
+            const int i = lane + 64 * j;
+            if (i < d) {
+                v[j] = __builtin_fmaf((v[j] - mean) * rstd, g[i], b[i]);
+                yr[i] = v[j];
+            }
+        }
+    }
+}
+void launch_layernorm2(const float *x, int64_t rows, int d, const float *g1, const float *b1, const float *g2, const float *b2, float eps,
+                       float *y1, float *y2, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (d <= 128) hipLaunchKernelGGL(layernorm2_kernel<2>, grid, dim3(256), 0, s, x, rows, d, g1, b1, g2, b2, eps, y1, y2);
+    else if (d <= 512) hipLaunchKernelGGL(layernorm2_kernel<8>, grid, dim3(256), 0, s, x, rows, d, g1, b1, g2, b2, eps, y1, y2);
+    else hipLaunchKernelGGL(layernorm2_kernel<16>, grid, dim3(256), 0, s, x, rows, d, g1, b1, g2, b2, eps, y1, y2);
+}
+
 void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s) {
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (d <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y);
