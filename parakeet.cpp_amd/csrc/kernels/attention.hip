@@ -27,7 +27,7 @@ static constexpr int RB = 32;   // query rows per workgroup
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
 template <int HD, int VCH>
-__global__ __launch_bounds__(256, HD <= 64 ? 3 : 1) void relpos_attention_kernel(const float *__restrict__ qkv, int ldq, int d, int T,
+__global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel(const float *__restrict__ qkv, int ldq, int d, int T,
                                                                const float *__restrict__ pos /*[2T-1][d], sigma columns*/,
                                                                const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                float scale, float *__restrict__ ctx, int PITS, int n_rb, int n_bh) {
@@ -285,7 +285,7 @@ void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads,
     const int hd = d / n_heads;
     // V chunk rows: 64 keeps the footprint at ~39 KB for 10 s clips (4 workgroups per CU at hd = 64)
     if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
-    else if (hd == 128) launch_att<128, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
+    else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
     else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
     else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
 }
