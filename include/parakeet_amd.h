@@ -92,6 +92,9 @@ int pk_device_count(void);
 /* ---- model lifetime: Transcriber::Transcriber (transcribe.hpp:59-65), to_gpu() (:68-71) ------------------ */
 /* safetensors with the reference's tensor names (scripts/convert_nemo.py:98-310); vocab_path may be NULL. */
 pk_status pk_model_load(const char *safetensors_path, const char *vocab_path, const pk_config *cfg, pk_model **out);
+/* The same from a safetensors image in memory (copied): what a rank receives when rank 0 reads the file once and broadcasts it
+ * (RCCL) instead of every rank going to storage. */
+pk_status pk_model_load_buffer(const void *safetensors_image, size_t n_bytes, const char *vocab_path, const pk_config *cfg, pk_model **out);
 /* Upload (packed) weights to HBM on `device` and build the execution plan.  Idempotent per device. */
 pk_status pk_model_to_gpu(pk_model *m, int device);
 void pk_model_free(pk_model *m);

@@ -422,11 +422,19 @@ class Batch:
 class Model:
     """Thin handle over pk_model (mirrors parakeet::Transcriber's ctor + to_gpu(), transcribe.hpp:59-71)."""
 
-    def __init__(self, weights_path: str, cfg: ModelConfig, vocab_path: str = None, device: int = None):
+    def __init__(self, weights_path, cfg: ModelConfig, vocab_path: str = None, device: int = None):
+        """weights_path: a safetensors file, or its bytes (bytes / uint8 ndarray), e.g. as received from a broadcast."""
         self.cfg = cfg
         self._h = C.c_void_p()
         pc = to_pk_config(cfg)
-        check(lib().pk_model_load(weights_path.encode(), vocab_path.encode() if vocab_path else None, C.byref(pc), C.byref(self._h)))
+        vp = vocab_path.encode() if vocab_path else None
+        if isinstance(weights_path, str):
+            check(lib().pk_model_load(weights_path.encode(), vp, C.byref(pc), C.byref(self._h)))
+        else:
+            img = np.frombuffer(weights_path, np.uint8) if isinstance(weights_path, (bytes, bytearray)) else np.ascontiguousarray(weights_path, np.uint8)
+            L = lib()
+            L.pk_model_load_buffer.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.POINTER(PkConfig), C.POINTER(C.c_void_p)]
+            check(L.pk_model_load_buffer(img.ctypes.data_as(C.c_void_p), img.size, vp, C.byref(pc), C.byref(self._h)))
         if device is not None:
             self.to_gpu(device)
 

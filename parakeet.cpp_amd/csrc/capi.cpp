@@ -121,6 +121,15 @@ pk_status pk_model_load(const char *safetensors_path, const char *vocab_path, co
     });
 }
 
+pk_status pk_model_load_buffer(const void *safetensors_image, size_t n_bytes, const char *vocab_path, const pk_config *cfg, pk_model **out) {
+    return guard([&] {
+        need(safetensors_image && n_bytes > 0 && cfg && out, "image/n_bytes/cfg/out");
+        auto h = std::make_unique<pk_model>();
+        h->m = std::make_unique<Model>(safetensors_image, n_bytes, vocab_path ? vocab_path : "", *cfg);
+        *out = h.release();
+    });
+}
+
 pk_status pk_model_to_gpu(pk_model *m, int device) {
     return guard([&] { need(m, "model"); m->m->to_gpu(device); });
 }

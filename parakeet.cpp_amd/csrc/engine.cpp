@@ -19,6 +19,18 @@ ProfileSink::~ProfileSink() {
 }
 
 Model::Model(const std::string &weights_path, const std::string &vocab_path, const pk_config &c) : cfg(c) {
+    validate_config();
+    st_ = std::make_unique<SafeTensors>(weights_path);
+    if (!vocab_path.empty()) tok.load(vocab_path);
+}
+
+Model::Model(const void *weights, size_t n_bytes, const std::string &vocab_path, const pk_config &c) : cfg(c) {
+    validate_config();
+    st_ = std::make_unique<SafeTensors>(weights, n_bytes);
+    if (!vocab_path.empty()) tok.load(vocab_path);
+}
+
+void Model::validate_config() {
     if (cfg.hidden_size <= 0 || cfg.num_heads <= 0 || cfg.hidden_size % cfg.num_heads) fail(PK_ERR_INVALID, "bad hidden_size / num_heads");
     const int hd = cfg.hidden_size / cfg.num_heads;
     if (hd % 32) fail(PK_ERR_UNSUPPORTED, "head_dim must be a multiple of 32");
@@ -32,8 +44,6 @@ Model::Model(const std::string &weights_path, const std::string &vocab_path, con
     if (cfg.num_lstm_layers * cfg.pred_hidden > 12 * 256) fail(PK_ERR_UNSUPPORTED, "num_lstm_layers * pred_hidden > 3072");
     if (cfg.pred_hidden % 64 || cfg.joint_hidden % 64) fail(PK_ERR_UNSUPPORTED, "pred_hidden / joint_hidden must be multiples of 64 (decode GEMV K chunk)");
     if (cfg.num_durations < 0 || cfg.num_durations > 8) fail(PK_ERR_INVALID, "num_durations must be 0..8");
-    st_ = std::make_unique<SafeTensors>(weights_path);
-    if (!vocab_path.empty()) tok.load(vocab_path);
 }
 
 Model::~Model() {

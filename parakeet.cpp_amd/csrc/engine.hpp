@@ -56,6 +56,7 @@ class StreamBatch;
 class Model {
   public:
     Model(const std::string &weights_path, const std::string &vocab_path, const pk_config &cfg);
+    Model(const void *weights, size_t n_bytes, const std::string &vocab_path, const pk_config &cfg);   // safetensors image in memory
     ~Model();
     void to_gpu(int device);
     bool on_gpu() const { return device_ >= 0; }
@@ -123,6 +124,7 @@ class Model {
 
   private:
     std::unique_ptr<SafeTensors> st_;
+    void validate_config();
     void build_mel_tables();
     void upload_weights();
     void gemm(const char *name, const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *out, int64_t ldo,

@@ -81,7 +81,17 @@ SafeTensors::SafeTensors(const std::string &path) {
     map_ = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (map_ == MAP_FAILED) { map_ = nullptr; fail(PK_ERR_IO, "mmap failed: %s", path.c_str()); }
-    const uint8_t *base = static_cast<const uint8_t *>(map_);
+    parse(static_cast<const uint8_t *>(map_), map_len_);
+}
+
+SafeTensors::SafeTensors(const void *data, size_t len) {
+    if (!data || len < 8) fail(PK_ERR_WEIGHTS, "safetensors: buffer of %zu bytes is too short", len);
+    own_.assign(static_cast<const uint8_t *>(data), static_cast<const uint8_t *>(data) + len);
+    parse(own_.data(), own_.size());
+}
+
+void SafeTensors::parse(const uint8_t *base, size_t len) {
+    const size_t map_len_ = len;
     uint64_t hlen;
     memcpy(&hlen, base, 8);
     if (hlen > map_len_ - 8) fail(PK_ERR_WEIGHTS, "safetensors: header length %llu exceeds file", (unsigned long long)hlen);

@@ -24,6 +24,7 @@ struct HostTensor {
 class SafeTensors {
   public:
     explicit SafeTensors(const std::string &path);   // throws pk::Error(PK_ERR_IO / PK_ERR_WEIGHTS)
+    SafeTensors(const void *data, size_t len);       // the same container from memory (copied; e.g. received by a broadcast)
     ~SafeTensors();
     SafeTensors(const SafeTensors &) = delete;
     SafeTensors &operator=(const SafeTensors &) = delete;
@@ -31,8 +32,10 @@ class SafeTensors {
     const std::map<std::string, HostTensor> &tensors() const { return tensors_; }
 
   private:
+    void parse(const uint8_t *base, size_t len);
     void *map_ = nullptr;
     size_t map_len_ = 0;
+    std::vector<uint8_t> own_;
     std::map<std::string, HostTensor> tensors_;
 };
 

@@ -67,3 +67,25 @@ def gather_token_matrix(local_ids, local_lens, local_idx: Sequence[int], n_items
     if seen != n_items:
         raise RuntimeError(f"sharded gather: {seen} of {n_items} clips arrived")
     return ids, lens
+
+
+def broadcast_file(path: str, rank: int, world: int, dist=None, device=None):
+    """Weight distribution of the sharded run: rank 0 reads the safetensors file ONCE, its bytes travel in one
+    broadcast ('nccl' = RCCL over xGMI: 7 links x ~153 GB/s make 459 MB a matter of milliseconds; 'gloo' in the CPU tests) and every
+    rank builds its replica from memory (pk_model_load_buffer).  Returns the file image as a uint8 numpy array."""
+    import numpy as np
+    import torch
+    if world == 1 or dist is None:
+        return np.fromfile(path, np.uint8)
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    img = None
+    if rank == 0:
+        img = torch.from_numpy(np.fromfile(path, np.uint8))
+        n[0] = img.numel()
+    dist.broadcast(n, src=0)
+    if rank == 0:
+        buf = img.to(device) if device is not None else img
+    else:
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src=0)
+    return buf.cpu().numpy()

@@ -31,7 +31,7 @@ WORKER = textwrap.dedent("""
     import os, sys
     sys.path.insert(0, {root!r})
     import torch.distributed as dist
-    import pkload; pkload.load()
+    import pkload; pk = pkload.load()
     from parakeet_cpp_amd.shard import shard_indices, gather_results
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -49,6 +49,24 @@ WORKER = textwrap.dedent("""
     gi, gl = gather_token_matrix(ids, lens, idx, n, world, dist)          # fixed-stride all_gather_into_tensor (RCCL on the GPU box)
     assert gl.tolist() == [1 + i % 5 for i in range(n)]
     assert all(gi[i, :gl[i]].tolist() == (np.arange(gl[i]) + 10 * i).tolist() for i in range(n)), "token matrix order"
+    # weight distribution: rank 0 reads the file once, one broadcast, every rank builds its model from the memory image
+    from parakeet_cpp_amd.shard import broadcast_file
+    from parakeet_cpp_amd import capi, synth
+    cfg = pk.make_tiny_config()
+    wp = os.path.join({tmp!r}, "tiny.safetensors")
+    if rank == 0:
+        synth.save_weights(wp, synth.synth_weights(cfg, seed=42))
+    dist.barrier()
+    img = broadcast_file(wp if rank == 0 else "/nonexistent", rank, world, dist)
+    m = capi.Model(img, cfg)                                  # pk_model_load_buffer (host side only: no GPU in this test)
+    import ctypes as C
+    out = capi.PkConfig()
+    assert capi.lib().pk_model_config(m._h, C.byref(out)) == 0 and out.hidden_size == cfg.hidden_size
+    try:
+        capi.Model(img[: len(img) // 2], cfg)
+        raise SystemExit("a truncated image must be refused")
+    except RuntimeError as e:
+        assert "safetensors" in str(e)
     import torch
     t = torch.tensor([float(len(idx))]); dist.all_reduce(t)
     assert int(t.item()) == n
@@ -60,7 +78,7 @@ WORKER = textwrap.dedent("""
 
 def test_two_process_gloo_shard_and_gather(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.format(root=ROOT, tmp=str(tmp_path)))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

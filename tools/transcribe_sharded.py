@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(n_clips, batch, clip_samples, decoder, cfg_name="tdt-ctc-110m", layers=None, dist=None, rank=0, world=1, local_rank=0, barrier=None):
+def run(n_clips, batch, clip_samples, decoder, cfg_name="tdt-ctc-110m", layers=None, dist=None, rank=0, world=1, local_rank=0, barrier=None,
+        broadcast_weights=False):
     import dataclasses
     import numpy as np
     import pkload
@@ -35,7 +36,11 @@ def run(n_clips, batch, clip_samples, decoder, cfg_name="tdt-ctc-110m", layers=N
         os.replace(wpath + f".{os.getpid()}", wpath)
     if barrier:
         barrier()
-    model = capi.Model(wpath, cfg, device=local_rank)
+    if broadcast_weights:      # rank 0 reads the file once; one RCCL broadcast; replicas are built from memory
+        img = shard.broadcast_file(wpath, rank, world, dist, device=f"cuda:{local_rank}" if world > 1 else None)
+        model = capi.Model(img, cfg, device=local_rank)
+    else:
+        model = capi.Model(wpath, cfg, device=local_rank)
     idx = shard.shard_indices(n_clips, rank, world, batch)
     bt = capi.Batch(model, batch, clip_samples)
     mt = None
@@ -101,6 +106,7 @@ def main():
     ap.add_argument("--decoder", default="tdt", choices=["tdt", "ctc"])
     ap.add_argument("--config", default="tdt-ctc-110m")
     ap.add_argument("--layers", type=int, default=0, help="cut the encoder to this many layers (tests)")
+    ap.add_argument("--broadcast-weights", action="store_true", help="rank 0 reads the weights once and broadcasts the image (RCCL)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
@@ -117,7 +123,7 @@ def main():
 
     n = int(args.clip_seconds * 16000)
     ids, lens, elapsed = run(args.clips, args.batch, n, args.decoder, args.config, args.layers or None, dist if world > 1 else None, rank, world,
-                             local_rank, barrier)
+                             local_rank, barrier, args.broadcast_weights)
     if rank == 0:
         print(json.dumps({"workload": f"{args.config}: {args.clips} x {args.clip_seconds:g} s clips, batches of {args.batch}, {args.decoder.upper()} greedy",
                           "n_gpus": world, "clips_per_gpu": (args.clips + world - 1) // world, "wall_s": round(elapsed, 4),
