@@ -161,6 +161,19 @@ void Model::build_mel_tables() {
     mel.fb = upload(fb.data(), fb.size());
     mel.f_lo = reinterpret_cast<const int *>(upload(reinterpret_cast<const float *>(lo.data()), lo.size()));
     mel.f_hi = reinterpret_cast<const int *>(upload(reinterpret_cast<const float *>(hi.data()), hi.size()));
+    {   // packed bands for the LDS-staged dot products of the mel kernel
+        std::vector<int> off(cfg.mel_bins + 1, 0);
+        std::vector<float> packed;
+        for (int m = 0; m < cfg.mel_bins; ++m) {
+            for (int f = lo[m]; f <= hi[m]; ++f) packed.push_back(fb[(size_t)f * cfg.mel_bins + m]);
+            off[m + 1] = (int)packed.size();
+        }
+        if ((int)packed.size() > kMelMaxTaps) fail(PK_ERR_UNSUPPORTED, "mel filterbank has %d taps (> %d)", (int)packed.size(), kMelMaxTaps);
+        if (packed.empty()) packed.push_back(0.0f);
+        mel.fb_nnz = off[cfg.mel_bins];
+        mel.fbc = upload(packed.data(), packed.size());
+        mel.fb_off = reinterpret_cast<const int *>(upload(reinterpret_cast<const float *>(off.data()), off.size()));
+    }
     mel.n_mels = n_mels;
     mel.power_via_abs = 1;               // switch A2 default: abs() then square, as the reference writes it
 }

@@ -8,6 +8,7 @@
 namespace pk {
 
 // ---- mel front end (src/audio.cpp:100-158) ----------------------------------------------------
+constexpr int kMelMaxTaps = 1024;     // packed filterbank taps staged in LDS by the mel kernel (sum of the band widths; 80 / 128 bins: ~590)
 struct MelTables {
     const float *window;   // [512] symmetric Hann(400) zero-padded to n_fft, placed per switch A1 (pk_config.stft_window_centered)
     const float *window_left;  // [512] the same window left-aligned: the streaming preprocessor's frames (center=false)
@@ -16,6 +17,9 @@ struct MelTables {
     const float *fb;       // [257][n_mels] Slaney filterbank (src/audio.cpp:40-94)
     const int *f_lo;       // [n_mels] first / last non-zero fft bin of each filter
     const int *f_hi;
+    const float *fbc;      // the non-zero band of every filter, packed: fbc[fb_off[m] + f - f_lo[m]] = fb[f][m]
+    const int *fb_off;     // [n_mels + 1]
+    int fb_nnz;            // fb_off[n_mels] (<= kMelMaxTaps)
     int n_mels;
     int power_via_abs;     // switch A2
 };

@@ -25,12 +25,21 @@ static constexpr int kFramesPerBlock = 4;
 // STREAM = true: StreamingAudioPreprocessor::process_chunk's framing (src/audio.cpp:222-241): the buffer is ALREADY
 // pre-emphasised, center=false, frame t = samples [160 t, 160 t + 400) Hann-windowed and zero-padded on the right to the
 // 512-point FFT; output [B][n_frames][n_mels] (the layout of its result, no normalisation follows).
+// Every wavefront owns one frame and touches only its own LDS arrays, so the stages are ordered by wave-local fences (LDS
+// operations of one wave complete in order once the counter is drained) instead of workgroup barriers: four frames of a
+// workgroup no longer wait for each other ten times per FFT.
+#define PK_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <bool STREAM>
 __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict__ pcm, int64_t n_samples, int n_frames,
                                                          MelTables tb, float *__restrict__ logmel) {
     __shared__ float s_re[kFramesPerBlock][kNfft];
     __shared__ float s_im[kFramesPerBlock][kNfft];
     __shared__ float s_pw[kFramesPerBlock][260];
+    __shared__ float s_twr[kNfft / 2], s_twi[kNfft / 2];    // twiddles and the packed filterbank bands: read ~100 times per lane and
+    __shared__ float s_fb[kMelMaxTaps];                     // frame -- from LDS instead of dependent L1 / L2 round trips
+    for (int i = threadIdx.x; i < kNfft / 2; i += 256) { s_twr[i] = tb.tw_re[i]; s_twi[i] = tb.tw_im[i]; }
+    for (int i = threadIdx.x; i < tb.fb_nnz; i += 256) s_fb[i] = tb.fbc[i];
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
     const int t = blockIdx.x * kFramesPerBlock + wave;
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
             im[r] = 0.0f;
         }
     }
-    __syncthreads();
+    PK_WAVE_SYNC();
 #pragma unroll 1
     for (int lh = 0; lh < 9; ++lh) {
         const int h = 1 << lh;
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
                 const int j = q & (h - 1);
                 const int a = ((q >> lh) << (lh + 1)) + j;
                 const int bb = a + h;
-                const float cr = tb.tw_re[j << (8 - lh)], ci = tb.tw_im[j << (8 - lh)];
+                const float cr = s_twr[j << (8 - lh)], ci = s_twi[j << (8 - lh)];
                 const float br = re[bb], bi = im[bb];
                 const float tr = __builtin_fmaf(-ci, bi, cr * br);
                 const float ti = __builtin_fmaf(ci, br, cr * bi);
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
                 im[a] = ai + ti;
             }
         }
-        __syncthreads();
+        PK_WAVE_SYNC();
     }
     if (live) {
         for (int f = lane; f <= kNfft / 2; f += 64) {
@@ -96,18 +105,21 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
             }
         }
     }
-    __syncthreads();
+    PK_WAVE_SYNC();
     if (live) {
         for (int m = lane; m < tb.n_mels; m += 64) {
             float acc = 0.0f;
             const int lo = tb.f_lo[m], hi = tb.f_hi[m];           // zero weights contribute fma(0, p, acc) = acc exactly
-            for (int f = lo; f <= hi; ++f) acc = __builtin_fmaf(tb.fb[f * tb.n_mels + m], pw[f], acc);
+            const float *wm = s_fb + tb.fb_off[m] - lo;
+            for (int f = lo; f <= hi; ++f) acc = __builtin_fmaf(wm[f], pw[f], acc);
             const float lm = dlogf(acc + 5.96046448e-8f);
             if constexpr (STREAM) logmel[((int64_t)b * n_frames + t) * tb.n_mels + m] = lm;
             else logmel[((int64_t)b * tb.n_mels + m) * n_frames + t] = lm;
         }
     }
 }
+
+#undef PK_WAVE_SYNC
 
 __global__ __launch_bounds__(64) void mel_normalize_kernel(const float *__restrict__ logmel, int n_mels, int n_frames,
                                                            int normalize, float *__restrict__ feats) {
