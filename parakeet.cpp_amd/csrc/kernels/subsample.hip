@@ -146,8 +146,81 @@ void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const
     if (W2 <= 20 || W2 % 20 == 0) launch_c1d1<20>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
     else launch_c1d1<16>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
 }
+// Depthwise 3x3 stride-2 conv (dw2, src/encoder.cpp:230), channels-last.  One thread = 4 adjacent channels x XO adjacent output
+// pixels of one output row: the 2*XO+1 input pixels of each of the three input rows are loaded once as float4 and shared by the XO
+// outputs (the first version read every input pixel 2.25 times with 4-byte loads: 715 MB of HBM reads for a 329 MB tensor).  A
+// wavefront covers the 256 channels of one item (1 KB contiguous per pixel).  Items are numbered (b, yo, x chunk) and dealt to the
+// XCDs in contiguous ranges, so the rows two neighbouring output rows share are re-read from the same XCD's L2.
+// Per output the taps run ky-major, kx-minor from +0 and out-of-image taps are skipped: the reference's (and the oracle's) chain.
+template <int XO>
+__global__ __launch_bounds__(256) void sub_dw4_kernel(const float *__restrict__ in, int H, int W, int C,
+                                                      const float *__restrict__ wd /*[9][C]*/, const float *__restrict__ bd,
+                                                      int Ho, int Wo, int n_xc, int64_t n_items, int n_blocks, float *__restrict__ out) {
+    const int c4n = C >> 2;                                     // float4 lanes per item
+    const int ipb = 256 / c4n;                                  // items per block
+    const int per_xcd = (n_blocks + 7) >> 3;
+    const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lb >= n_blocks) return;
+    const int64_t item = (int64_t)lb * ipb + threadIdx.x / c4n;
+    if (item >= n_items) return;
+    const int c4 = threadIdx.x % c4n;
+    const int xc = (int)(item % n_xc);
+    const int yo = (int)((item / n_xc) % Ho);
+    const int b = (int)(item / ((int64_t)n_xc * Ho));
+    const int x0 = xc * XO;
+    const float4 *src = reinterpret_cast<const float4 *>(in + (int64_t)b * H * W * C) + c4;
+    float4 wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = reinterpret_cast<const float4 *>(wd + (int64_t)k * C)[c4];
+    const float4 bias = reinterpret_cast<const float4 *>(bd)[c4];
+    float4 acc[XO];
+#pragma unroll
+    for (int xl = 0; xl < XO; ++xl) acc[xl] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * yo + ky - 1;
+        if (iy < 0 || iy >= H) continue;                        // uniform over the wavefront
+        float4 px[2 * XO + 1];
+#pragma unroll
+        for (int i = 0; i < 2 * XO + 1; ++i) {
+            const int ix = 2 * x0 - 1 + i;
+            px[i] = (ix >= 0 && ix < W) ? src[((int64_t)iy * W + ix) * c4n] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int xl = 0; xl < XO; ++xl)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * (x0 + xl) + kx - 1;
+                if (ix < 0 || ix >= W) continue;                // skipped tap: the chain does not see it
+                const float4 w = wt[ky * 3 + kx], v = px[2 * xl + kx];
+                acc[xl].x = __builtin_fmaf(w.x, v.x, acc[xl].x);
+                acc[xl].y = __builtin_fmaf(w.y, v.y, acc[xl].y);
+                acc[xl].z = __builtin_fmaf(w.z, v.z, acc[xl].z);
+                acc[xl].w = __builtin_fmaf(w.w, v.w, acc[xl].w);
+            }
+    }
+    float4 *dst = reinterpret_cast<float4 *>(out + (((int64_t)b * Ho + yo) * Wo) * C) + c4;
+#pragma unroll
+    for (int xl = 0; xl < XO; ++xl)
+        if (x0 + xl < Wo) dst[(int64_t)(x0 + xl) * c4n] = make_float4(acc[xl].x + bias.x, acc[xl].y + bias.y, acc[xl].z + bias.z, acc[xl].w + bias.w);
+}
+
+template <int XO>
+static void launch_dw4(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, int Ho, int Wo, float *out, hipStream_t s) {
+    const int n_xc = (Wo + XO - 1) / XO;
+    const int64_t n_items = (int64_t)B * Ho * n_xc;
+    const int ipb = 256 / (C / 4);
+    const int n_blocks = (int)((n_items + ipb - 1) / ipb);
+    hipLaunchKernelGGL(sub_dw4_kernel<XO>, dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, in, H, W, C, wd, bd, Ho, Wo, n_xc, n_items, n_blocks, out);
+}
+
 void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, float *out, hipStream_t s) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (C % 4 == 0 && 256 % (C / 4) == 0 && C >= 16) {
+        if (Wo % 5 == 0) launch_dw4<5>(in, B, H, W, C, wd, bd, Ho, Wo, out, s);
+        else launch_dw4<4>(in, B, H, W, C, wd, bd, Ho, Wo, out, s);
+        return;
+    }
     const int64_t n_pix = (int64_t)B * Ho * Wo;
     const int ppb = 256 / C;
     hipLaunchKernelGGL(sub_dw_kernel, dim3((unsigned)((n_pix + ppb - 1) / ppb)), dim3(256), 0, s, in, H, W, C, wd, bd, Ho, Wo,
