@@ -121,26 +121,41 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
 
 #undef PK_WAVE_SYNC
 
-__global__ __launch_bounds__(64) void mel_normalize_kernel(const float *__restrict__ logmel, int n_mels, int n_frames,
-                                                           int normalize, float *__restrict__ feats) {
-    const int m = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    const float *row = logmel + ((int64_t)b * n_mels + m) * n_frames;
-    float *out = feats + (int64_t)b * n_frames * n_mels + m;
-    if (!normalize) {
-        for (int t = lane; t < n_frames; t += 64) out[(int64_t)t * n_mels] = row[t];
-        return;
+// Per-bin mean / unbiased variance normalisation + transpose to [B][n_frames][n_mels] (src/audio.cpp:140-156).  One wavefront per
+// (clip, mel bin) for the two canonical sum64 reductions over the frames; the 16 bins of a workgroup then go through a
+// [64 frames][16 bins] LDS tile so that the transposed store writes 64-byte runs (the first version stored 4 bytes per 320-byte
+// stride: 230 MB of write traffic for a 20 MB tensor, profiles/r01_pmc_hbm.json).
+__global__ __launch_bounds__(1024) void mel_normalize_kernel(const float *__restrict__ logmel, int n_mels, int n_frames,
+                                                             int normalize, float *__restrict__ feats) {
+    __shared__ float tile[64][17];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 16 + wave, b = blockIdx.y;
+    const bool live = m < n_mels;
+    const float *row = logmel + ((int64_t)b * n_mels + (live ? m : 0)) * n_frames;
+    float mean = 0.0f, den = 1.0f;
+    if (normalize && live) {
+        float p = 0.0f;
+        for (int t = lane; t < n_frames; t += 64) p = p + row[t];
+        mean = wave_sum64(p) / (float)n_frames;                    // src/audio.cpp:142
+        float q = 0.0f;
+        for (int t = lane; t < n_frames; t += 64) {
+            const float c = row[t] - mean;
+            q = q + c * c;
+        }
+        const float var = wave_sum64(q) / (float)(n_frames - 1);  // unbiased, :146-148
+        den = __builtin_sqrtf(var) + 1e-5f;                       // :149
     }
-    float p = 0.0f;
-    for (int t = lane; t < n_frames; t += 64) p = p + row[t];
-    const float mean = wave_sum64(p) / (float)n_frames;            // src/audio.cpp:142
-    float q = 0.0f;
-    for (int t = lane; t < n_frames; t += 64) {
-        const float c = row[t] - mean;
-        q = q + c * c;
+    const int of = threadIdx.x >> 4, ob = threadIdx.x & 15;        // store role: frame of the tile, bin of the group
+    float *out = feats + (int64_t)b * n_frames * n_mels + blockIdx.x * 16 + ob;
+    for (int t0 = 0; t0 < n_frames; t0 += 64) {
+        const int t = t0 + lane;
+        float v = 0.0f;
+        if (live && t < n_frames) v = normalize ? (row[t] - mean) / den : row[t];
+        tile[lane][wave] = v;
+        __syncthreads();
+        if (t0 + of < n_frames && blockIdx.x * 16 + ob < n_mels) out[(int64_t)(t0 + of) * n_mels] = tile[of][ob];
+        __syncthreads();
     }
-    const float var = wave_sum64(q) / (float)(n_frames - 1);      // unbiased, :146-148
-    const float den = __builtin_sqrtf(var) + 1e-5f;               // :149
-    for (int t = lane; t < n_frames; t += 64) out[(int64_t)t * n_mels] = (row[t] - mean) / den;
 }
 
 void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s) {
@@ -152,7 +167,7 @@ void launch_mel_stream(const float *pre, int B, int64_t n_samples, int n_frames,
     hipLaunchKernelGGL(mel_logmel_kernel<true>, grid, dim3(256), 0, s, pre, n_samples, n_frames, t, logmel_tf);
 }
 void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, int normalize, float *feats, hipStream_t s) {
-    hipLaunchKernelGGL(mel_normalize_kernel, dim3(n_mels, B), dim3(64), 0, s, logmel, n_mels, n_frames, normalize, feats);
+    hipLaunchKernelGGL(mel_normalize_kernel, dim3((n_mels + 15) / 16, B), dim3(1024), 0, s, logmel, n_mels, n_frames, normalize, feats);
 }
 
 }  // namespace pk
