@@ -259,6 +259,8 @@ typedef struct pk_sortformer_config {   /* SortformerConfig (sortformer.hpp:28-4
     pk_transformer_config transformer;
     int32_t max_speakers;               /* 4 */
     float activity_threshold;           /* 0.5 */
+    int32_t att_context_left;           /* 70: StreamingEncoderConfig of the NEST encoder (sortformer.hpp:53-54), used by diarize_chunk */
+    int32_t att_context_right;          /* 0 */
 } pk_sortformer_config;
 typedef struct pk_sortformer pk_sortformer;
 void pk_sortformer_config_preset(pk_sortformer_config *out);              /* make_sortformer_117m_config (sortformer.hpp:43-76) */
@@ -268,6 +270,12 @@ void pk_sortformer_free(pk_sortformer *s);
 pk_status pk_sortformer_forward(pk_sortformer *s, const float *feats, int B, int Tm, float *probs, int *T_out);
 /* preprocess_audio with normalize = false (src/main.cpp:513-517, src/diarize.cpp:81-88) + forward, for n_clips clips of n_samples. */
 pk_status pk_sortformer_forward_pcm(pk_sortformer *s, const float *pcm, int n_clips, int64_t n_samples, float *probs, int *T_out);
+/* Sortformer::diarize_chunk (:123-150), one streaming session per handle: forward_chunk of the NEST encoder on cached K / V / conv
+ * state (the streaming path of pk_stream_*), then projection / transformer / head on THIS chunk's frames.  feats[n_frames][mel_bins]
+ * (un-normalised log-mel, any chunking) -> probs[c][max_speakers]; *T_out = c (0: all frames were buffered: the subsampling consumes
+ * multiples of 8).  AOSCCache::update and probs_to_segments on the chunk are host loops (pk_sortformer_segments). */
+pk_status pk_sortformer_diarize_chunk(pk_sortformer *s, const float *feats, int n_frames, float *probs, int cap_frames, int *T_out);
+pk_status pk_sortformer_stream_reset(pk_sortformer *s);
 /* Sortformer::probs_to_segments (:71-113) on one utterance's probs[T][S]: runs of prob > threshold per speaker, seconds = frame * 0.08,
  * sorted by start.  Writes at most cap segments, returns the number found. */
 int pk_sortformer_segments(const float *probs, int T, int S, float threshold, int32_t *speaker, float *start, float *end, int cap);

@@ -434,6 +434,19 @@ class Stream:
             raise RuntimeError(lib().orc_last_error().decode())
         return dict(ids=ids[:n], start=st[:n], end=en[:n], conf=cf[:n])
 
+    def sortformer_chunk(self, feats, sf):
+        """Sortformer::diarize_chunk (src/sortformer.cpp:123-150) on feats [n_frames][mel] -> probs [c][S] (c may be 0)."""
+        feats = _c(feats)
+        cap = feats.shape[0] // 8 + 4
+        probs = np.zeros((cap, sf.max_speakers), np.float32)
+        L = lib()
+        L.orc_sortformer_chunk.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int]
+        c = L.orc_sortformer_chunk(self._h, _f(feats), feats.shape[0], sf.transformer_layers, sf.transformer_heads, int(sf.pre_ln),
+                                   int(sf.has_final_norm), _f(probs), cap)
+        if c < 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return probs[:c]
+
     def push(self, pcm):
         """transcribe_chunk (src/nemotron.cpp:24-52): PCM chunk -> new tokens of this chunk (dict) or None."""
         m = self.mel(pcm)

@@ -964,23 +964,19 @@ int orc_encoder(orc_model *m, const float *feats, int B, int Tm, float *out, flo
 /* Sortformer::forward (:50-69).  feats[B][Tm][mel] -> probs[B][T][S] (sigmoid speaker activities); returns T.
  * Tensor names (AX_REGISTER_MODULES, :44-46): nest_encoder_.*, projection_, transformer_.*, first_hidden_, output_proj_
  * (hidden_to_spks_ is registered but never used by forward). */
-int orc_sortformer_forward(orc_model *m, const float *feats, int B, int Tm, int n_tlayers, int n_theads, int pre_ln,
-                           int has_final_norm, float *probs) {
+/* projection_ -> transformer_ -> speaker head on encoder frames enc[B][T][d] (src/sortformer.cpp:55-68; :132-141 in diarize_chunk) */
+static int sortformer_head(orc_model *m, const float *enc, int B, int T, int n_tlayers, int n_theads, int pre_ln, int has_final_norm, float *probs) {
     const orc_config *c = &m->cfg;
     orc_tensor *pw = getf(m, "projection_.weight"), *pb = getf(m, "projection_.bias");
     orc_tensor *fw = getf(m, "first_hidden_.weight"), *fb = getf(m, "first_hidden_.bias");
     orc_tensor *ow = getf(m, "output_proj_.weight"), *ob = getf(m, "output_proj_.bias");
     if (!pw || !pb || !fw || !fb || !ow || !ob) return -1;
     const int d = c->d_model, dt = (int)pw->shape[0], S = (int)ow->shape[0];
-    const int T = orc_subsampled_len(Tm);
-    float *enc = (float *)xmalloc((size_t)B * T * d * sizeof(float));
-    if (orc_encoder(m, feats, B, Tm, enc, NULL) < 0) { free(enc); return -1; }          /* :52 nest_encoder_(features) */
     const int64_t rows = (int64_t)B * T;
     float *x = (float *)xmalloc((size_t)rows * dt * sizeof(float));
     float *h = (float *)xmalloc((size_t)rows * dt * sizeof(float));
     float *lg = (float *)xmalloc((size_t)rows * S * sizeof(float));
     linear_t(0, pw, pb, (int)rows, enc, d, x, dt, 0);                                   /* :55 */
-    free(enc);
     int r = orc_transformer_encoder(m, "transformer_.", n_tlayers, n_theads, pre_ln, has_final_norm, c->ln_eps, x, B, T, dt);   /* :58 */
     if (r == 0) {
         for (int64_t i = 0; i < rows * dt; ++i) x[i] = x[i] > 0.0f ? x[i] : 0.0f;       /* :62 relu */
@@ -990,6 +986,17 @@ int orc_sortformer_forward(orc_model *m, const float *feats, int B, int Tm, int 
         for (int64_t i = 0; i < rows * S; ++i) probs[i] = orc_sigmoidf(lg[i]);          /* :68 */
     }
     free(x); free(h); free(lg);
+    return r;
+}
+int orc_sortformer_forward(orc_model *m, const float *feats, int B, int Tm, int n_tlayers, int n_theads, int pre_ln,
+                           int has_final_norm, float *probs) {
+    const orc_config *c = &m->cfg;
+    const int d = c->d_model;
+    const int T = orc_subsampled_len(Tm);
+    float *enc = (float *)xmalloc((size_t)B * T * d * sizeof(float));
+    if (orc_encoder(m, feats, B, Tm, enc, NULL) < 0) { free(enc); return -1; }          /* :52 nest_encoder_(features) */
+    const int r = sortformer_head(m, enc, B, T, n_tlayers, n_theads, pre_ln, has_final_norm, probs);
+    free(enc);
     return r == 0 ? T : -1;
 }
 
@@ -1702,4 +1709,17 @@ int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, in
     for (int i = 0; i < len; ++i) { if (start) start[i] += s->frame_offset; if (end) end[i] += s->frame_offset; }
     s->frame_offset += c;
     return len;
+}
+
+/* Sortformer::diarize_chunk (src/sortformer.cpp:123-150): forward_chunk of the NEST encoder with the stream's caches, then
+ * projection / transformer / head on THIS chunk's frames only.  feats[n_frames][mel] -> probs[c][S]; returns c (0: buffered). */
+int orc_sortformer_chunk(orc_stream *s, const float *feats, int n_frames, int n_tlayers, int n_theads, int pre_ln, int has_final_norm,
+                         float *probs, int max_out) {
+    const int d = s->m->cfg.d_model;
+    float *enc = (float *)xmalloc((size_t)(max_out > 0 ? max_out : 1) * d * sizeof(float));
+    const int c = orc_stream_encode(s, feats, n_frames, enc, max_out);
+    if (c <= 0) { free(enc); return c; }
+    const int r = sortformer_head(s->m, enc, 1, c, n_tlayers, n_theads, pre_ln, has_final_norm, probs);
+    free(enc);
+    return r == 0 ? c : -1;
 }

@@ -34,6 +34,9 @@ int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out);
 int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out);
 int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
 
+int orc_sortformer_chunk(orc_stream *s, const float *feats, int n_frames, int n_tlayers, int n_theads, int pre_ln, int has_final_norm,
+                         float *probs, int max_out);
+
 #endif
 
 /* include/parakeet/audio.hpp:7-17 (AudioConfig) + switches A1/A2 */

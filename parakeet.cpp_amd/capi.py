@@ -37,7 +37,8 @@ class PkTransformerConfig(C.Structure):
 
 
 class PkSortformerConfig(C.Structure):
-    _fields_ = [("nest", PkConfig), ("transformer", PkTransformerConfig), ("max_speakers", C.c_int32), ("activity_threshold", C.c_float)]
+    _fields_ = [("nest", PkConfig), ("transformer", PkTransformerConfig), ("max_speakers", C.c_int32), ("activity_threshold", C.c_float),
+                ("att_context_left", C.c_int32), ("att_context_right", C.c_int32)]
 
 
 class PkKernelStat(C.Structure):
@@ -314,6 +315,9 @@ class Sortformer:
         c.transformer = PkTransformerConfig(sf.transformer_hidden, sf.transformer_layers, sf.transformer_heads, sf.transformer_ffn,
                                             int(sf.pre_ln), int(sf.has_final_norm), 1e-5)
         c.max_speakers, c.activity_threshold = sf.max_speakers, sf.activity_threshold
+        c.att_context_left, c.att_context_right = sf.att_context_left, sf.att_context_right
+        L.pk_sortformer_diarize_chunk.argtypes = [C.c_void_p, f32p, C.c_int, f32p, C.c_int, C.POINTER(C.c_int)]
+        L.pk_sortformer_stream_reset.argtypes = [C.c_void_p]
         self._h = C.c_void_p()
         check(L.pk_sortformer_load(weights_path.encode(), C.byref(c), device, C.byref(self._h)))
 
@@ -325,6 +329,18 @@ class Sortformer:
         probs = np.zeros((B, T, self.sf.max_speakers), np.float32)
         check(lib().pk_sortformer_forward(self._h, _f(feats), B, Tm, _f(probs), None))
         return probs
+
+    def diarize_chunk(self, feats):
+        """Sortformer::diarize_chunk on feats [n_frames][mel]: -> probs [c][S] of this chunk (c may be 0)."""
+        feats = _c(feats)
+        cap = feats.shape[0] // 8 + 4
+        probs = np.zeros((cap, self.sf.max_speakers), np.float32)
+        n = C.c_int(0)
+        check(lib().pk_sortformer_diarize_chunk(self._h, _f(feats), feats.shape[0], _f(probs), cap, C.byref(n)))
+        return probs[:n.value]
+
+    def reset_stream(self):
+        check(lib().pk_sortformer_stream_reset(self._h))
 
     def forward_pcm(self, pcm):
         pcm = _c(pcm)

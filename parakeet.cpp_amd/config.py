@@ -82,6 +82,8 @@ class SortformerConfig:              # include/parakeet/sortformer.hpp:28-41
     has_final_norm: bool = False
     max_speakers: int = 4
     activity_threshold: float = 0.5
+    att_context_left: int = 70       # nest_encoder.att_context_left / right (sortformer.hpp:53-54): diarize_chunk
+    att_context_right: int = 0
 
 
 def make_nest_encoder_config(**kw) -> ModelConfig:

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "stream.hpp"
 #include "transformer.hpp"
 
 namespace pk {
@@ -20,16 +21,21 @@ class Sortformer {
     int forward_feats(const float *feats, int B, int Tm, float *probs);
     // preprocess_audio(normalize = false) (src/main.cpp:513-517, src/diarize.cpp:81-88) + forward
     int forward_pcm(const float *pcm, int n_clips, int64_t n_samples, float *probs);
+    // Sortformer::diarize_chunk (:123-150): forward_chunk of the NEST encoder on the session's caches, then projection / transformer /
+    // head on this chunk's frames only.  feats[n_frames][mel] -> probs[c][S]; returns c (0: everything was buffered)
+    int forward_chunk(const float *feats, int n_frames, float *probs, int cap_frames);
+    void reset_stream();
     pk_sortformer_config cfg;
     std::unique_ptr<Model> nest;
 
   private:
     std::unique_ptr<TransformerEncoder> tr_;
+    std::unique_ptr<StreamBatch> stream_;
     std::vector<void *> allocs_;
     const float *pw_, *pb_, *fw_, *fb_, *ow_, *ob_;
     DevBuf xt_, h_, lg_;
     const float *upload(const SafeTensors &st, const std::string &name, int64_t want);
-    void head(int B, int T, float *probs_host);
+    void head(const float *d_enc, int B, int T, float *probs_host);
 };
 
 const float *Sortformer::upload(const SafeTensors &st, const std::string &name, int64_t want) {
@@ -63,8 +69,8 @@ Sortformer::~Sortformer() {
     }
 }
 
-// projection_ -> transformer_ -> speaker head on the encoder output sitting in nest->ws.x
-void Sortformer::head(int B, int T, float *probs_host) {
+// projection_ -> transformer_ -> speaker head on encoder frames d_enc[B*T][d] (device)
+void Sortformer::head(const float *d_enc, int B, int T, float *probs_host) {
     Model &m = *nest;
     hipStream_t s = m.stream;
     const int d = cfg.nest.hidden_size, dt = cfg.transformer.hidden_size, S = cfg.max_speakers;
@@ -72,7 +78,7 @@ void Sortformer::head(int B, int T, float *probs_host) {
     xt_.reserve(rows * dt * 4); h_.reserve(rows * dt * 4); lg_.reserve(rows * S * 4);
     float *x = xt_.as<float>(), *h = h_.as<float>(), *lg = lg_.as<float>();
     {   // :55 projection_
-        GemmArgs g{m.ws.x.as<float>(), d, pw_, d, pb_, x, dt, nullptr, 0, 1.0f, (int)rows, dt, d};
+        GemmArgs g{d_enc, d, pw_, d, pb_, x, dt, nullptr, 0, 1.0f, (int)rows, dt, d};
         launch_gemm(g, EPI_NONE, s);
     }
     tr_->forward_dev(x, B, T, s);                                   // :58
@@ -97,7 +103,7 @@ int Sortformer::forward_feats(const float *feats, int B, int Tm, float *probs) {
     m.ws.size_for(m.cfg, B, 0, Tm);
     PK_HIP(hipMemcpyAsync(m.ws.feats.p, feats, (size_t)B * Tm * m.cfg.mel_bins * 4, hipMemcpyHostToDevice, m.stream));
     m.run_encoder(m.ws, m.ws.feats.as<float>(), B, Tm, -1, 0, m.stream);
-    head(B, m.ws.T, probs);
+    head(m.ws.x.as<float>(), B, m.ws.T, probs);
     return m.ws.T;
 }
 
@@ -109,8 +115,25 @@ int Sortformer::forward_pcm(const float *pcm, int n_clips, int64_t n_samples, fl
     PK_HIP(hipMemcpyAsync(m.ws.pcm.p, pcm, (size_t)n_clips * n_samples * 4, hipMemcpyHostToDevice, m.stream));
     m.run_mel(m.ws.pcm.as<float>(), n_clips, n_samples, m.ws.logmel.as<float>(), m.ws.feats.as<float>(), m.stream);
     m.run_encoder(m.ws, m.ws.feats.as<float>(), n_clips, Tm, -1, 0, m.stream);
-    head(n_clips, m.ws.T, probs);
+    head(m.ws.x.as<float>(), n_clips, m.ws.T, probs);
     return m.ws.T;
+}
+
+int Sortformer::forward_chunk(const float *feats, int n_frames, float *probs, int cap_frames) {
+    if (!stream_) stream_ = std::make_unique<StreamBatch>(*nest, 1, cfg.att_context_left, cfg.att_context_right);
+    const float *d_enc = nullptr;
+    const int c = stream_->encode_keep(feats, n_frames, &d_enc);
+    if (c <= 0) {
+        PK_HIP(hipStreamSynchronize(nest->stream));
+        return 0;
+    }
+    if (c > cap_frames) fail(PK_ERR_INVALID, "probs holds %d frames, the chunk produces %d", cap_frames, c);
+    head(d_enc, 1, c, probs);
+    return c;
+}
+
+void Sortformer::reset_stream() {
+    if (stream_) stream_->reset();
 }
 
 }  // namespace pk
@@ -148,6 +171,8 @@ void pk_sortformer_config_preset(pk_sortformer_config *out) {       // make_sort
     out->transformer.layer_norm_eps = 1e-5f;
     out->max_speakers = 4;
     out->activity_threshold = 0.5f;
+    out->att_context_left = 70;                                    // sortformer.hpp:53-54
+    out->att_context_right = 0;
 }
 
 pk_status pk_sortformer_load(const char *safetensors_path, const pk_sortformer_config *cfg, int device, pk_sortformer **out) {
@@ -174,6 +199,21 @@ pk_status pk_sortformer_forward_pcm(pk_sortformer *s, const float *pcm, int n_cl
         if (!s || !pcm || !probs || n_clips <= 0 || n_samples <= 256) fail(PK_ERR_INVALID, "invalid argument: sortformer/pcm/probs/n_clips/n_samples");
         const int T = s->s->forward_pcm(pcm, n_clips, n_samples, probs);
         if (T_out) *T_out = T;
+    });
+}
+
+pk_status pk_sortformer_diarize_chunk(pk_sortformer *s, const float *feats, int n_frames, float *probs, int cap_frames, int *T_out) {
+    return sf_guard([&] {
+        if (!s || !feats || !probs || n_frames <= 0 || cap_frames <= 0) fail(PK_ERR_INVALID, "invalid argument: sortformer/feats/probs/n_frames/cap_frames");
+        const int c = s->s->forward_chunk(feats, n_frames, probs, cap_frames);
+        if (T_out) *T_out = c;
+    });
+}
+
+pk_status pk_sortformer_stream_reset(pk_sortformer *s) {
+    return sf_guard([&] {
+        if (!s) fail(PK_ERR_INVALID, "invalid argument: sortformer");
+        s->s->reset_stream();
     });
 }
 

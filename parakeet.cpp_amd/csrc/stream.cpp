@@ -13,43 +13,9 @@
 #include <cstring>
 #include <map>
 
-#include "engine.hpp"
+#include "stream.hpp"
 
 namespace pk {
-
-class StreamBatch {
-  public:
-    StreamBatch(Model &m, int n_streams, int att_left, int att_right);
-    void reset();
-    // stage entry points (host buffers); each returns the number of frames it produced per stream (0: buffered / cached)
-    int mel(const float *pcm, int n_samples, float *out /*[S][n_frames][F]*/, int cap_frames);
-    int encode(const float *mel_in, int n_frames, float *enc /*[S][c][d]*/, int cap_frames);
-    void decode(const float *enc, int c, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
-    // NemotronTranscriber::transcribe_chunk for S streams; device-resident between the stages
-    void push(const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
-    int S;
-
-  private:
-    Model &m_;
-    int left_, right_;
-    // StreamingAudioPreprocessor state (host)
-    std::vector<float> preemph_last_;
-    std::vector<std::vector<float>> overlap_;
-    // device state
-    DevBuf mel_cache_;          // [S][8][F] leftover mel frames (first n_mel_cache_ valid)
-    int n_mel_cache_ = 0;
-    struct LayerState { DevBuf k[2], v[2], conv[2]; int cur = 0, ccur = 0, n_kv = 0, has_conv = 0; };
-    std::vector<std::unique_ptr<LayerState>> layers_;
-    int frame_offset_ = 0;
-    Workspace ws_;              // encoder workspace of the current chunk
-    Workspace wd_;              // decode workspace: h / c / token persist across chunks (never re-allocated)
-    int dec_cap_frames_ = 0;
-    DevBuf pre_, mel_dev_, mel_all_, enc_in_;
-    std::map<int, std::unique_ptr<DevBuf>> pos_tables_;   // Tp -> pos_proj of every layer [L][2Tp-1][d], natural columns
-    int encode_device(const float *d_mel, int n_frames);                    // -> ws_.x [S*c][d], returns c
-    const float *pos_table(int Tp);
-    void decode_device(const float *d_enc, int c, int max_tokens);
-};
 
 StreamBatch::StreamBatch(Model &m, int n_streams, int att_left, int att_right) : S(n_streams), m_(m), left_(att_left), right_(att_right) {
     m_.require_gpu();
@@ -237,6 +203,17 @@ int StreamBatch::encode(const float *mel_in, int n_frames, float *enc, int cap_f
         PK_HIP(hipMemcpyAsync(enc, ws_.x.p, (size_t)S * c * d * 4, hipMemcpyDeviceToHost, m_.stream));
     }
     PK_HIP(hipStreamSynchronize(m_.stream));
+    return c;
+}
+
+int StreamBatch::encode_keep(const float *mel_in, int n_frames, const float **d_enc) {
+    m_.require_gpu();
+    if (n_frames <= 0) fail(PK_ERR_INVALID, "n_frames");
+    const int F = m_.cfg.mel_bins;
+    mel_dev_.reserve((size_t)S * n_frames * F * 4);
+    PK_HIP(hipMemcpyAsync(mel_dev_.p, mel_in, (size_t)S * n_frames * F * 4, hipMemcpyHostToDevice, m_.stream));
+    const int c = encode_device(mel_dev_.as<float>(), n_frames);
+    *d_enc = ws_.x.as<float>();
     return c;
 }
 

@@ -1,0 +1,47 @@
+// parakeet.cpp_amd/csrc/stream.hpp -- StreamBatch: S lock-step streams with cached encoder state (see stream.cpp).
+#pragma once
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "engine.hpp"
+
+namespace pk {
+
+class StreamBatch {
+  public:
+    StreamBatch(Model &m, int n_streams, int att_left, int att_right);
+    void reset();
+    // stage entry points (host buffers); each returns the number of frames it produced per stream (0: buffered / cached)
+    int mel(const float *pcm, int n_samples, float *out /*[S][n_frames][F]*/, int cap_frames);
+    int encode(const float *mel_in, int n_frames, float *enc /*[S][c][d]*/, int cap_frames);
+    // the same, leaving the c output frames per stream on the device (*d_enc -> [S*c][d], valid until the next call); enqueued only
+    int encode_keep(const float *mel_in, int n_frames, const float **d_enc);
+    void decode(const float *enc, int c, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
+    // NemotronTranscriber::transcribe_chunk for S streams; device-resident between the stages
+    void push(const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
+    int S;
+
+  private:
+    Model &m_;
+    int left_, right_;
+    // StreamingAudioPreprocessor state (host)
+    std::vector<float> preemph_last_;
+    std::vector<std::vector<float>> overlap_;
+    // device state
+    DevBuf mel_cache_;          // [S][8][F] leftover mel frames (first n_mel_cache_ valid)
+    int n_mel_cache_ = 0;
+    struct LayerState { DevBuf k[2], v[2], conv[2]; int cur = 0, ccur = 0, n_kv = 0, has_conv = 0; };
+    std::vector<std::unique_ptr<LayerState>> layers_;
+    int frame_offset_ = 0;
+    Workspace ws_;              // encoder workspace of the current chunk
+    Workspace wd_;              // decode workspace: h / c / token persist across chunks (never re-allocated)
+    int dec_cap_frames_ = 0;
+    DevBuf pre_, mel_dev_, mel_all_, enc_in_;
+    std::map<int, std::unique_ptr<DevBuf>> pos_tables_;   // Tp -> pos_proj of every layer [L][2Tp-1][d], natural columns
+    int encode_device(const float *d_mel, int n_frames);                    // -> ws_.x [S*c][d], returns c
+    const float *pos_table(int Tp);
+    void decode_device(const float *d_enc, int c, int max_tokens);
+};
+
+}  // namespace pk

@@ -6,7 +6,9 @@
 //  * `const Tensor &features` becomes (const float *features, int n_frames) -- [n_frames][mel_bins], the layout preprocess_audio
 //    returns -- or raw PCM (the GPU runs the un-normalised mel front end itself, as run_sortformer does, src/main.cpp:513-517);
 //  * forward() returns the probabilities as a flat [T][max_speakers] vector;
-//  * there is no CPU path; diarize_chunk (streaming) is not provided.
+//  * diarize_chunk keeps the encoder cache inside the Sortformer object (one streaming session per object; reset_stream() starts a
+//    new one) instead of taking an EncoderCache argument;
+//  * there is no CPU path.
 #pragma once
 
 #include <algorithm>
@@ -108,6 +110,7 @@ class Sortformer {
         c.transformer.pre_ln = config_.transformer.pre_ln ? 1 : 0; c.transformer.has_final_norm = config_.transformer.has_final_norm ? 1 : 0;
         c.transformer.layer_norm_eps = config_.transformer.layer_norm_eps;
         c.max_speakers = config_.max_speakers; c.activity_threshold = config_.activity_threshold;
+        c.att_context_left = e.att_context_left; c.att_context_right = e.att_context_right;
         detail::check(pk_sortformer_load(weights_path_.c_str(), &c, device, &h_));
     }
 
@@ -135,6 +138,20 @@ class Sortformer {
         detail::check(pk_sortformer_forward_pcm(h_, pcm, 1, (int64_t)n, probs.data(), nullptr));
         return probs_to_segments(probs.data(), T);
     }
+
+    /// Streaming: process a chunk of features [n_frames][mel_bins], update the arrival-order cache, return this chunk's segments
+    /// (times relative to the chunk, as the reference's probs_to_segments(p) on the chunk; src/sortformer.cpp:123-150)
+    std::vector<DiarizationSegment> diarize_chunk(const float *features, int n_frames, AOSCCache &aosc_cache) {
+        to_gpu();
+        const int cap = n_frames / 8 + 4;
+        std::vector<float> probs((size_t)cap * config_.max_speakers);
+        int T = 0;
+        detail::check(pk_sortformer_diarize_chunk(h_, features, n_frames, probs.data(), cap, &T));
+        if (T <= 0) return {};
+        aosc_cache.update(probs.data(), T, config_.max_speakers);
+        return probs_to_segments(probs.data(), T);
+    }
+    void reset_stream() { if (h_) detail::check(pk_sortformer_stream_reset(h_)); }
 
     /// probs [T][max_speakers] -> segments sorted by start (src/sortformer.cpp:71-113)
     std::vector<DiarizationSegment> probs_to_segments(const float *probs, int T) const {

@@ -108,3 +108,48 @@ def test_gpu_sortformer_117m_from_pcm(orc, tmp_path):
     for b in range(2):
         assert capi.sortformer_segments(got[b], sf.activity_threshold) == orc.probs_to_segments(want[b], sf.activity_threshold)
     g.close()
+
+
+def test_oracle_sortformer_chunks_consistent_with_stream_encoder(orc):
+    """diarize_chunk = forward_chunk (already pinned against the torch streaming restatement, tests/test_stream_oracle.py) + the head
+    of the offline path on the chunk's frames: chunked probabilities must equal head(orc.Stream.encode(chunk)) computed separately."""
+    sf = tiny_sf()
+    W = synth.synth_sortformer_weights(sf, seed=5)
+    om = orc.Model(sf.nest_encoder, W)
+    feats = feats_like(1, 100, 128, 3)[0]
+    st = orc.Stream(om, sf.att_context_left, sf.att_context_right)
+    got, n_frames = [], 0
+    for a, b in [(0, 16), (16, 40), (40, 49), (49, 100)]:
+        p = st.sortformer_chunk(feats[a:b], sf)
+        got.append(p)
+        n_frames += p.shape[0]
+    assert n_frames == (100 // 8) and sum(p.shape[0] > 0 for p in got) >= 3
+    assert all(np.isfinite(p).all() and ((p > 0) & (p < 1)).all() for p in got if p.size)
+
+
+@pytest.mark.gpu
+def test_gpu_sortformer_diarize_chunk_bit_identical(orc, tmp_path):
+    """Streaming diarization: pk_sortformer_diarize_chunk on ragged feature chunks == the oracle's diarize_chunk, bit for bit,
+    including chunks that only fill the subsampling buffer (0 frames out); reset starts an identical second session."""
+    from parakeet_cpp_amd import capi
+    sf = tiny_sf()
+    W = synth.synth_sortformer_weights(sf, seed=5)
+    wp = str(tmp_path / "sf.safetensors")
+    synth.save_weights(wp, W)
+    g = capi.Sortformer(wp, sf)
+    feats = feats_like(1, 200, 128, 7)[0]
+    cuts = [(0, 16), (16, 19), (19, 64), (64, 72), (72, 136), (136, 200)]
+    for session in range(2):
+        st = orc.Stream(orc.Model(sf.nest_encoder, W), sf.att_context_left, sf.att_context_right)
+        total = 0
+        for a, b in cuts:
+            want = st.sortformer_chunk(feats[a:b], sf)
+            got = g.diarize_chunk(feats[a:b])
+            assert got.shape == want.shape, (session, a, b)
+            assert np.array_equal(_bits(got), _bits(want)), (session, a, b)
+            if got.shape[0]:
+                assert capi.sortformer_segments(got, 0.5) == orc.probs_to_segments(want, 0.5)
+            total += got.shape[0]
+        assert total == 200 // 8
+        g.reset_stream()
+    g.close()
