@@ -78,7 +78,19 @@ def cpu_baseline(cfg, weights, n_clips, threads):
         t_mel += t1 - t0; t_enc += t2 - t1; t_tdt += t3 - t2
         done += n_clips; tokens += int(r["lens"].sum()); chunk += 1
     wall = t_mel + t_enc + t_tdt
+    # the reference's own sources are single-threaded: the same path on ONE thread, two clips
+    single = None
+    try:
+        oracle.set_threads(1)
+        t0 = time.time()
+        f1 = np.stack([oracle.mel(p) for p in pcm0[:2]])
+        r1 = om.tdt_greedy(om.encoder(f1))
+        w1 = time.time() - t0
+        single = {"value": round(2 * CLIP_SECONDS / w1, 3), "cores": 1, "sample": f"2 of the same clips, {w1:.1f} s", "tokens": int(r1["lens"].sum())}
+    finally:
+        oracle.set_threads(threads)
     return {
+        "single_thread": single,
         "value": round(done * CLIP_SECONDS / wall, 3), "unit": "RTFx (audio-s / wall-s)", "cores": threads, "kind": "port",
         "sample": f"{done} seeded 10 s clips in chunks of {n_clips} (the first chunk is the GPU run's batch prefix), mel+encoder+TDT, "
                   f"{wall:.1f} s of CPU work on oracle/libpk_oracle.so (AVX2 fp32, OpenMP over clips)",
