@@ -229,7 +229,7 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
 // bf16 operands / fp32 accumulate (a.W points to bf16 weights [N][K]); K % 64 == 0
 template <int EPI>
 static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
-    if (a.M >= 1024 && a.N >= 1024) launch_gemm_bf16_t<2, 2, 2, 2, EPI>(a, s);
+    if (a.M >= 1024 && a.N >= 1024) launch_gemm_bf16_t<4, 2, 1, 2, EPI>(a, s);      // 128x128 on 8 waves of 32x64
     else if (a.M >= 1024 && a.N >= 256) launch_gemm_bf16_t<2, 2, 2, 1, EPI>(a, s);
     else launch_gemm_bf16_t<2, 2, 1, 1, EPI>(a, s);
 }
@@ -239,7 +239,7 @@ void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s) {
     case EPI_RELU: launch_bf16_epi<EPI_RELU>(a, s); break;
     case EPI_SILU: launch_bf16_epi<EPI_SILU>(a, s); break;
     case EPI_RESID: launch_bf16_epi<EPI_RESID>(a, s); break;
-    case EPI_GLU: launch_gemm_bf16_t<2, 2, 2, 2, EPI_GLU>(a, s); break;
+    case EPI_GLU: launch_gemm_bf16_t<4, 2, 1, 2, EPI_GLU>(a, s); break;
     default: break;
     }
 }

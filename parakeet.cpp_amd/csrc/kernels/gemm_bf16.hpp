@@ -148,6 +148,42 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
     // ---- epilogue: accumulators -> LDS (row-major fp32 C tile) -> 4 consecutive columns per thread ------------------------------
     constexpr int CP = BN + 4;
     static_assert((size_t)BM * CP * 4 <= 2 * (size_t)BUF * 2, "C tile must fit in the staging buffers");
+    const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);
+    constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT, RSTEP = NT / C4;
+    static_assert((BM * C4) % NT == 0 && NT % C4 == 0, "output tile must split evenly over the threads");
+    // as in gemm_pipe.hpp: a thread owns the same 4 columns in all its chunks; bias and (wide) residual rows are requested before the
+    // LDS transposition so their latency overlaps it
+    const int c4 = tid % C4, rl0 = tid / C4;
+    const int col0 = n0 + 4 * c4;
+    const bool sig = col0 < g.sigma_cols;
+    int vcol[4], ncol[4];
+    float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (sig) {                                                   // sigma layout: position 16b + 4a + e holds natural column 16b + 4e + a
+            vcol[e] = ((4 * c4) & ~15) + 4 * e + (c4 & 3);
+            ncol[e] = n0 + vcol[e];
+        } else {
+            vcol[e] = 4 * c4 + e;
+            ncol[e] = col0 + e;
+            if constexpr (EPI == EPI_GLU) vcol[e] = (vcol[e] / (WN / 2)) * WN + vcol[e] % (WN / 2);
+        }
+        if (g.bias && ncol[e] < g.N) {
+            bs[e] = g.bias[ncol[e]];
+            if constexpr (EPI == EPI_GLU) bg[e] = g.bias[g.N + ncol[e]];
+        }
+    }
+    float4 rs[NCH];
+    if constexpr (EPI == EPI_RESID) {
+        if (wide && !sig) {
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                int row = m0 + rl0 + q * RSTEP;
+                row = row < g.M ? row : g.M - 1;
+                rs[q] = col0 < g.N ? *reinterpret_cast<const float4 *>(g.resid + (int64_t)row * g.ldr + col0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+    }
     __syncthreads();
     {
         const int lc = lane & 31, lr = 4 * (lane >> 5);
@@ -160,46 +196,39 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
                     smem_f[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + lr) * CP + wn * WN + j * 32 + lc] = acc[i][j][r];
     }
     __syncthreads();
-    const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);
-    constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT;
-    static_assert((BM * C4) % NT == 0, "output tile must split evenly over the threads");
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
-        const int c = tid + NT * q, rl = c / C4, c4 = c % C4;
-        const int row = m0 + rl, col0 = n0 + 4 * c4;
+        const int rl = rl0 + q * RSTEP;
+        const int row = m0 + rl;
         if (row >= g.M || col0 >= g.N) continue;
-        float v[4], gt[4] = {0.0f, 0.0f, 0.0f, 0.0f}, rsv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int ncol[4];                                                 // natural output column of each of the 4 results
-        const bool sig = col0 < g.sigma_cols;
+        float v[4], gt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            int vc;                                                  // virtual column inside the C tile
-            if (sig) {                                               // sigma layout: position 16b + 4a + e holds natural column 16b + 4e + a
-                vc = ((4 * c4) & ~15) + 4 * e + (c4 & 3);
-                ncol[e] = n0 + vc;
-            } else {
-                vc = 4 * c4 + e;
-                ncol[e] = col0 + e;
-                if constexpr (EPI == EPI_GLU) vc = (vc / (WN / 2)) * WN + vc % (WN / 2);
+            v[e] = smem_f[rl * CP + vcol[e]];
+            if constexpr (EPI == EPI_GLU) gt[e] = smem_f[rl * CP + vcol[e] + WN / 2];
+        }
+        float rsv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (EPI == EPI_RESID) {
+            if (wide && !sig) { rsv[0] = rs[q].x; rsv[1] = rs[q].y; rsv[2] = rs[q].z; rsv[3] = rs[q].w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rsv[e] = ncol[e] < g.N ? g.resid[(int64_t)row * g.ldr + ncol[e]] : 0.0f;
             }
-            v[e] = smem_f[rl * CP + vc];
-            if constexpr (EPI == EPI_GLU) gt[e] = smem_f[rl * CP + vc + WN / 2];
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (ncol[e] >= g.N) continue;
             float x = v[e];
-            if (g.bias) x = x + g.bias[ncol[e]];
+            if (g.bias) x = x + bs[e];
             if constexpr (EPI == EPI_RELU) {
                 x = x > 0.0f ? x : 0.0f;
             } else if constexpr (EPI == EPI_SILU) {
                 x = dsiluf(x);
             } else if constexpr (EPI == EPI_RESID) {
-                rsv[e] = g.resid[(int64_t)row * g.ldr + ncol[e]];
                 x = rsv[e] + x * g.alpha;
             } else if constexpr (EPI == EPI_GLU) {
                 float t2 = gt[e];
-                if (g.bias) t2 = t2 + g.bias[g.N + ncol[e]];
+                if (g.bias) t2 = t2 + bg[e];
                 x = x * dsigmoidf(t2);
             }
             v[e] = x;
