@@ -203,6 +203,11 @@ pk_status pk_read_wav(const char *path, float **pcm, int64_t *n_samples, int *sa
  * beta 7.857, 16-tap half width).  FLAC / MP3 / OGG are not decoded.  pk_resample: the resampler alone (resample(), :250-262). */
 pk_status pk_read_audio(const char *path, int target_rate, float **pcm, int64_t *n_samples, int *original_rate);
 pk_status pk_resample(const float *pcm, int64_t n, int src_rate, int dst_rate, float **out, int64_t *n_out);
+/* read_audio(const uint8_t *data, size_t len, target) (audio_io.hpp:27-28): an encoded RIFF/WAVE image in memory -> mono PCM at
+ * target_rate (malloc'd, pk_free). */
+pk_status pk_read_audio_memory(const void *data, size_t len, int target_rate, float **pcm, int64_t *n_samples, int *original_rate, int *n_channels);
+/* get_audio_duration (audio_io.hpp:39, audio_io.cpp:527-586): header walk, no decode.  duration = n_frames / sample_rate. */
+pk_status pk_audio_info(const char *path, int *sample_rate, int *n_channels, int64_t *n_frames);
 void pk_free(void *p);
 
 /* ---- streaming: NemotronTranscriber / StreamingTranscriber::transcribe_chunk (src/nemotron.cpp:24-52, src/eou.cpp:113-146) -------- */

@@ -370,6 +370,26 @@ def sortformer_segments(probs, threshold=0.5):
     return [(int(spk[i]), float(a[i]), float(b[i])) for i in range(n)]
 
 
+def read_audio_memory(data: bytes, target_rate=16000):
+    """read_audio(const uint8_t*, size_t, target) -> (mono pcm at target_rate, original rate, channels)."""
+    L = lib()
+    L.pk_read_audio_memory.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(f32p), i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    p = f32p(); n = C.c_int64(0); sr = C.c_int(0); ch = C.c_int(0)
+    check(L.pk_read_audio_memory(data, len(data), target_rate, C.byref(p), C.byref(n), C.byref(sr), C.byref(ch)))
+    out = np.ctypeslib.as_array(p, shape=(max(1, n.value),))[:n.value].copy()
+    L.pk_free(p)
+    return out, sr.value, ch.value
+
+
+def audio_info(path):
+    """get_audio_duration's header walk -> (sample_rate, channels, frames)."""
+    L = lib()
+    L.pk_audio_info.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), i64p]
+    sr = C.c_int(0); ch = C.c_int(0); n = C.c_int64(0)
+    check(L.pk_audio_info(path.encode(), C.byref(sr), C.byref(ch), C.byref(n)))
+    return sr.value, ch.value, n.value
+
+
 def diag_layernorm(x, g, b, eps=1e-5):
     x, g, b = _c(x), _c(g), _c(b)
     y = np.empty_like(x)

@@ -8,7 +8,9 @@
 
 namespace pk {
 const std::string &last_error();
-void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rate);
+void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rate, int *n_channels = nullptr);
+void parse_wav(const uint8_t *bytes, size_t n_bytes, const char *what, std::vector<float> &mono, int &sample_rate, int *n_channels, bool info_only, size_t file_len = 0);
+size_t wav_info_frames();
 void sinc_resample(const float *input, size_t input_len, int src_rate, int dst_rate, std::vector<float> &output);
 }
 
@@ -713,6 +715,48 @@ pk_status pk_read_audio(const char *path, int target_rate, float **pcm, int64_t 
     });
 }
 /* resample() / read_audio(const float *pcm, n, sample_rate, target) (audio_io.cpp:250-262,506-514). */
+static void hand_over(const std::vector<float> &v, float **pcm, int64_t *n) {
+    float *p = static_cast<float *>(malloc((v.size() ? v.size() : 1) * sizeof(float)));
+    if (!p) fail(PK_ERR_IO, "out of memory");
+    memcpy(p, v.data(), v.size() * sizeof(float));
+    *pcm = p;
+    *n = (int64_t)v.size();
+}
+/* read_audio(const uint8_t *data, size_t len, target) (audio_io.cpp:485-493), RIFF/WAVE images */
+pk_status pk_read_audio_memory(const void *data, size_t len, int target_rate, float **pcm, int64_t *n_samples, int *original_rate, int *n_channels) {
+    return guard([&] {
+        need(data && len > 0 && pcm && n_samples && target_rate > 0, "data/len/pcm/n_samples/target_rate");
+        std::vector<float> mono, out;
+        int sr = 0;
+        parse_wav(static_cast<const uint8_t *>(data), len, nullptr, mono, sr, n_channels, false);
+        if (original_rate) *original_rate = sr;
+        sinc_resample(mono.data(), mono.size(), sr, target_rate, out);
+        hand_over(out, pcm, n_samples);
+    });
+}
+/* get_audio_duration (audio_io.cpp:527-586): header walk only */
+pk_status pk_audio_info(const char *path, int *sample_rate, int *n_channels, int64_t *n_frames) {
+    return guard([&] {
+        need(path != nullptr, "path");
+        FILE *f = fopen(path, "rb");
+        if (!f) fail(PK_ERR_IO, "Failed to open audio file: %s", path);
+        std::vector<uint8_t> head(1 << 16);
+        fseek(f, 0, SEEK_END);
+        const long total = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        const size_t got = fread(head.data(), 1, head.size(), f);
+        fclose(f);
+        head.resize(got);
+        // only the head of the file is read; the data chunk's declared size (clamped to the file length) gives the frame count
+        std::vector<float> mono;
+        int sr = 0, ch = 0;
+        parse_wav(head.data(), head.size(), path, mono, sr, &ch, true, total > 0 ? (size_t)total : 0);
+        if (sample_rate) *sample_rate = sr;
+        if (n_channels) *n_channels = ch;
+        if (n_frames) *n_frames = (int64_t)wav_info_frames();
+    });
+}
+
 pk_status pk_resample(const float *pcm, int64_t n, int src_rate, int dst_rate, float **out, int64_t *n_out) {
     return guard([&] {
         need(pcm && out && n_out && n >= 0 && src_rate > 0 && dst_rate > 0, "pcm/out/n/rates");

@@ -17,16 +17,32 @@ namespace pk {
 static uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 static uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rate) {
+thread_local size_t info_frames_ = 0;      // frame count of the last info-only parse
+size_t wav_info_frames() { return info_frames_; }
+void parse_wav(const uint8_t *bytes, size_t n_bytes, const char *what, std::vector<float> &mono, int &sample_rate, int *n_channels, bool info_only, size_t file_len = 0);
+
+static void slurp(const std::string &path, std::vector<uint8_t> &buf) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) fail(PK_ERR_IO, "Failed to open audio file: %s", path.c_str());
-    std::vector<uint8_t> buf;
     fseek(f, 0, SEEK_END);
     const long len = ftell(f);
     fseek(f, 0, SEEK_SET);
     buf.resize(len > 0 ? (size_t)len : 0);
     if (len <= 0 || fread(buf.data(), 1, buf.size(), f) != buf.size()) { fclose(f); fail(PK_ERR_IO, "Failed to read audio file: %s", path.c_str()); }
     fclose(f);
+}
+
+void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rate, int *n_channels) {
+    std::vector<uint8_t> buf;
+    slurp(path, buf);
+    parse_wav(buf.data(), buf.size(), path.c_str(), mono, sample_rate, n_channels, false);
+}
+
+// read_audio(const uint8_t*, size_t) (src/audio_io.cpp:485-493): an encoded file image in memory.  info_only: header walk without
+// decoding (get_audio_duration, :527-586) -- mono is resized to the frame count but not filled.
+void parse_wav(const uint8_t *bytes, size_t n_bytes, const char *what, std::vector<float> &mono, int &sample_rate, int *n_channels, bool info_only, size_t file_len) {
+    struct View { const uint8_t *p; size_t n; size_t size() const { return n; } const uint8_t *data() const { return p; } const uint8_t &operator[](size_t i) const { return p[i]; } } buf{bytes, n_bytes};
+    const std::string path = what ? what : "<memory>";
     if (buf.size() < 12 || memcmp(buf.data(), "RIFF", 4) || memcmp(buf.data() + 8, "WAVE", 4))
         fail(PK_ERR_IO, "Unsupported audio format (only RIFF/WAVE is read natively): %s", path.c_str());
     int fmt = 0, channels = 0, bits = 0;
@@ -42,7 +58,8 @@ void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rat
             if (fmt == 0xFFFE && sz >= 26) fmt = rd16(body + 24);       // WAVE_FORMAT_EXTENSIBLE sub-format
         } else if (!memcmp(&buf[pos], "data", 4)) {
             data = body;
-            data_len = (pos + 8 + sz <= buf.size()) ? sz : buf.size() - pos - 8;
+            const size_t flen = file_len > buf.size() ? file_len : buf.size();   // info mode: only the head of the file is in memory
+            data_len = (pos + 8 + sz <= flen) ? sz : flen - pos - 8;
             break;
         }
         pos += 8 + sz + (sz & 1);
@@ -52,6 +69,8 @@ void read_wav(const std::string &path, std::vector<float> &mono, int &sample_rat
     if (!((fmt == 1 && (bits == 16 || bits == 24 || bits == 32)) || (fmt == 3 && bits == 32)))
         fail(PK_ERR_IO, "Unsupported WAV encoding (format %d, %d bits): %s", fmt, bits, path.c_str());
     const size_t frames = data_len / ((size_t)bps * channels);
+    if (n_channels) *n_channels = channels;
+    if (info_only) { mono.clear(); info_frames_ = frames; return; }
     mono.resize(frames);
     for (size_t i = 0; i < frames; ++i) {
         float acc = 0.0f;

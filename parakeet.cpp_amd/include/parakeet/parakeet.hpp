@@ -3,6 +3,7 @@
 #include "config.hpp"
 #include "timestamp.hpp"
 #include "transcribe.hpp"
+#include "audio_io.hpp"
 #include "nemotron.hpp"
 #include "sortformer.hpp"
 #include "diarize.hpp"
