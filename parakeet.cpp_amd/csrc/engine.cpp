@@ -475,6 +475,11 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
     float *x = w.x.as<float>(), *n = w.n.as<float>();
     if (stop_layer < 0 || stop_layer > cfg.num_layers) { stop_layer = cfg.num_layers; stop_stage = 0; }
     if (stop_layer == 0 && stop_stage == 0) return;
+    if (relpos_attention_lds_bytes(T, d / cfg.num_heads) > 160 * 1024) {
+        const int tmax = relpos_attention_max_frames(d / cfg.num_heads);
+        fail(PK_ERR_UNSUPPORTED, "utterance of %d encoder frames (%.1f s): the attention kernel keeps a [32][T] score block in LDS and takes at most %d frames (%.1f s) -- split the audio",
+             T, T * 0.08, tmax, tmax * 0.08);
+    }
     ensure_pos_tables(T, s);
     bool ffn1_norm_done = false;
     for (int l = first_layer; l < cfg.num_layers; ++l) {

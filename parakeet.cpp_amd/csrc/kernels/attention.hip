@@ -280,6 +280,22 @@ static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const
     hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits, n_rb, n_bh);
 }
 
+// LDS bytes one workgroup needs for T frames: the [32][T] score block (four k-planes) + one V chunk.  0: unsupported head size.
+size_t relpos_attention_lds_bytes(int T, int hd) {
+    if (hd != 32 && hd != 64 && hd != 96 && hd != 128) return 0;
+    int pits = (T + 3) / 4;
+    pits = (pits + 3) & ~3;
+    if (((pits / 4) & 1) == 0) pits += 4;
+    const int vch = hd == 128 ? 32 : 64;
+    return (size_t)(4 * (RB * pits + 8) + vch * (hd + 16)) * sizeof(float);
+}
+// longest sequence whose score block fits the 160 KB of LDS of a CU (hd 64: 1064 frames = 85 s of audio; hd 128: 1104)
+int relpos_attention_max_frames(int hd) {
+    int T = 0;
+    while (relpos_attention_lds_bytes(T + 8, hd) && relpos_attention_lds_bytes(T + 8, hd) <= 160 * 1024) T += 8;
+    return T;
+}
+
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
                              const float *bias_v, float *ctx, hipStream_t s, float scale) {
     const int hd = d / n_heads;

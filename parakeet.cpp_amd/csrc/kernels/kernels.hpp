@@ -60,6 +60,8 @@ void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd,
 // ---- conformer pieces ---------------------------------------------------------------------------------
 // qkv[B*T][3d]: q and k thirds in the sigma column layout.  pos == nullptr: plain multi-head attention (src/transformer.cpp:38),
 // no position term, bias_u / bias_v ignored.  scale <= 0: 1/sqrt(d / n_heads).
+size_t relpos_attention_lds_bytes(int T, int hd);     // 0: unsupported head size
+int relpos_attention_max_frames(int hd);              // longest sequence one workgroup's LDS score block can hold
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
                              const float *bias_v, float *ctx, hipStream_t s, float scale = 0.0f);
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,

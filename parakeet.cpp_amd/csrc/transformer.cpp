@@ -103,6 +103,8 @@ void TransformerEncoder::forward_dev(float *x, int B, int T, hipStream_t s) {
     const int64_t rows = (int64_t)B * T;
     const float eps = cfg.layer_norm_eps > 0.0f ? cfg.layer_norm_eps : 1e-5f;
     const float scale = 1.0f / sqrtf((float)hd);                              // src/transformer.cpp:27 (the REAL head dim)
+    if (relpos_attention_lds_bytes(T, hdp_) > 160 * 1024)
+        fail(PK_ERR_UNSUPPORTED, "sequence of %d frames exceeds the attention kernel's limit of %d", T, relpos_attention_max_frames(hdp_));
     n_.reserve(rows * d * 4); qkv_.reserve(rows * 3 * dp_ * 4); ctx_.reserve(rows * dp_ * 4); h_.reserve(rows * f * 4);
     float *n = n_.as<float>();
     for (const TransformerLayerW &L : layers_) {

@@ -86,3 +86,15 @@ def test_model_without_vocabulary(tmp_path, orc):
     assert gm.boost_trie_size() == 3
     gm.set_boost_tokens([])
     gm.close()
+
+
+def test_over_long_utterance_is_refused_with_a_clear_message(pair):
+    """The attention kernel holds a [32][T] score block in LDS: beyond ~85 s (hd = 64) the call fails loudly instead of launching."""
+    W, om, gm = pair
+    ok = synth.synth_pcm(1, 16000 * 80, seed=2)[0]                  # 80 s: T = 1001 frames, inside the limit
+    r = gm.transcribe_pcm([ok], "ctc")
+    assert len(r) == 1
+    too_long = np.zeros(16000 * 100, np.float32)                     # 100 s: T = 1251 frames
+    with pytest.raises(RuntimeError, match="split the audio"):
+        gm.transcribe_pcm([too_long], "ctc")
+    assert gm.transcribe_pcm([ok[:16000]], "ctc") is not None        # the model is still usable afterwards
