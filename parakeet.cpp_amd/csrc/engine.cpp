@@ -475,10 +475,15 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
     float *x = w.x.as<float>(), *n = w.n.as<float>();
     if (stop_layer < 0 || stop_layer > cfg.num_layers) { stop_layer = cfg.num_layers; stop_stage = 0; }
     if (stop_layer == 0 && stop_stage == 0) return;
+    float *att_scratch_p = nullptr;
     if (relpos_attention_lds_bytes(T, d / cfg.num_heads) > 160 * 1024) {
-        const int tmax = relpos_attention_max_frames(d / cfg.num_heads);
-        fail(PK_ERR_UNSUPPORTED, "utterance of %d encoder frames (%.1f s): the attention kernel keeps a [32][T] score block in LDS and takes at most %d frames (%.1f s) -- split the audio",
-             T, T * 0.08, tmax, tmax * 0.08);
+        // a [32][T] score block no longer fits LDS (> ~85 s of audio): the same kernel with its score blocks in global scratch
+        const size_t need = relpos_attention_scratch_bytes(B, T, cfg.num_heads, d / cfg.num_heads);
+        if (need == 0 || need > ((size_t)64 << 30))
+            fail(PK_ERR_UNSUPPORTED, "utterance of %d encoder frames (%.1f s) x %d clips: the attention scratch would need %.1f GB -- use fewer / shorter clips per call",
+                 T, T * 0.08, B, need / 1e9);
+        att_scratch.reserve(need);
+        att_scratch_p = att_scratch.as<float>();
     }
     ensure_pos_tables(T, s);
     bool ffn1_norm_done = false;
@@ -502,7 +507,7 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             const double fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);   // QK^T + QP^T(needed band) + AV
             KL("relpos_attention", fl, 0.0,
                launch_relpos_attention(w.qkv.as<float>(), B, T, d, cfg.num_heads, pos_proj.as<float>() + (size_t)l * P * d, L.pos_u, L.pos_v,
-                                       w.ctx.as<float>(), s));
+                                       w.ctx.as<float>(), s, 0.0f, att_scratch_p));
         }
         gemm("attn_out_resid", w.ctx.as<float>(), d, L.wo, d, L.bo, x, d, (int)rows, d, d, EPI_RESID, x, d, 1.0f, s);
         if (stage_cap == 2) break;

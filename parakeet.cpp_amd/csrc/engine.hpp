@@ -82,6 +82,7 @@ class Model {
     // per-layer pos_proj_(pe) [L][2T-1][d]; they depend on (T, weights) only, so they are rebuilt when T changes.
     int pos_T = 0;
     DevBuf pos_pe, pos_proj;
+    DevBuf att_scratch;         // score blocks of the attention kernel for sequences too long for LDS (grow-only)
     void ensure_pos_tables(int T, hipStream_t s);
 
     // stage drivers (device pointers, enqueue on `s`, never synchronise)

@@ -26,11 +26,15 @@ static constexpr int RB = 32;   // query rows per workgroup
 
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
-template <int HD, int VCH>
+// SG (long sequences, > ~85 s of audio): the score block of a workgroup lives in a global scratch area instead of LDS -- the same
+// code, indexing and barriers (a workgroup's own global writes are visible to it after __syncthreads()), so the same bits; slower,
+// but the length is then bounded by HBM, not by the 160 KB of LDS.
+template <int HD, int VCH, bool SG = false>
 __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel(const float *__restrict__ qkv, int ldq, int d, int T,
                                                                const float *__restrict__ pos /*[2T-1][d], sigma columns*/,
                                                                const float *__restrict__ bias_u, const float *__restrict__ bias_v,
-                                                               float scale, float *__restrict__ ctx, int PITS, int n_rb, int n_bh) {
+                                                               float scale, float *__restrict__ ctx, int PITS, int n_rb, int n_bh,
+                                                               float *__restrict__ s_scratch) {
     constexpr int KQ = HD / 4;
     constexpr int NQ4 = HD / 16;          // float4 fragments per lane for K = HD (one per block of 16 features)
     constexpr int VPIT = HD + 16;         // V rows, natural layout (pitch = 16 mod 32 banks)
@@ -39,8 +43,8 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel
     static_assert((VCH * KQ) % 256 == 0 && VCH % 4 == 0, "V chunk must split evenly over 256 threads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int SPLANE = RB * PITS + 8;     // +8: the four planes start 8 banks apart (conflict-free row sweeps)
-    float *S = smem;                      // [4][SPLANE] score planes
-    float *VS = smem + 4 * SPLANE;        // [VCH][VPIT] V chunk
+    float *S = SG ? s_scratch + (size_t)blockIdx.x * 4 * SPLANE : smem;     // [4][SPLANE] score planes
+    float *VS = SG ? smem : smem + 4 * SPLANE;                               // [VCH][VPIT] V chunk
     const int H = d / HD;
     // Block b runs on XCD b % 8 (observed dispatch rule).  The row blocks of one (utterance, head) share K, V and the P band:
     // give them consecutive slots on ONE XCD so the second..last read those rows from that XCD's L2 instead of HBM.
@@ -264,20 +268,29 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel
 
 template <int HD, int VCH>
 static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u, const float *bias_v,
-                       float *ctx, float scale_arg, hipStream_t s) {
+                       float *ctx, float scale_arg, hipStream_t s, float *scratch) {
     const float scale = scale_arg > 0.0f ? scale_arg : 1.0f / sqrtf((float)HD);   // src/encoder.cpp:126
     int pits = (T + 3) / 4;                                        // floats per score-plane row, padded so that pits/4 is odd
     pits = (pits + 3) & ~3;
     if (((pits / 4) & 1) == 0) pits += 4;
+    const int n_rb = (T + RB - 1) / RB, n_bh = B * n_heads;
+    dim3 grid(((n_bh + 7) / 8) * 8 * n_rb);                        // 8 XCD lanes x ceil(n_bh/8) pairs x n_rb row blocks
+    if (scratch) {
+        if constexpr (HD == 64 || HD == 128) {
+            const size_t lds = (size_t)VCH * (HD + 16) * sizeof(float);
+            hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, true>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits,
+                               n_rb, n_bh, scratch);
+        }
+        return;
+    }
     const size_t lds = (size_t)(4 * (RB * pits + 8) + VCH * (HD + 16)) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&relpos_attention_kernel<HD, VCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&relpos_attention_kernel<HD, VCH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
-    const int n_rb = (T + RB - 1) / RB, n_bh = B * n_heads;
-    dim3 grid(((n_bh + 7) / 8) * 8 * n_rb);                        // 8 XCD lanes x ceil(n_bh/8) pairs x n_rb row blocks
-    hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits, n_rb, n_bh);
+    hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, false>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits, n_rb, n_bh,
+                       (float *)nullptr);
 }
 
 // LDS bytes one workgroup needs for T frames: the [32][T] score block (four k-planes) + one V chunk.  0: unsupported head size.
@@ -290,6 +303,15 @@ size_t relpos_attention_lds_bytes(int T, int hd) {
     return (size_t)(4 * (RB * pits + 8) + vch * (hd + 16)) * sizeof(float);
 }
 // longest sequence whose score block fits the 160 KB of LDS of a CU (hd 64: 1064 frames = 85 s of audio; hd 128: 1104)
+// bytes of global scratch the long-sequence variant needs (hd 64 / 128 only; 0 otherwise)
+size_t relpos_attention_scratch_bytes(int B, int T, int n_heads, int hd) {
+    if (hd != 64 && hd != 128) return 0;
+    int pits = (T + 3) / 4;
+    pits = (pits + 3) & ~3;
+    if (((pits / 4) & 1) == 0) pits += 4;
+    const size_t n_rb = (T + RB - 1) / RB, n_bh = (size_t)B * n_heads;
+    return ((n_bh + 7) / 8) * 8 * n_rb * 4 * (size_t)(RB * pits + 8) * sizeof(float);
+}
 int relpos_attention_max_frames(int hd) {
     int T = 0;
     while (relpos_attention_lds_bytes(T + 8, hd) && relpos_attention_lds_bytes(T + 8, hd) <= 160 * 1024) T += 8;
@@ -297,13 +319,13 @@ int relpos_attention_max_frames(int hd) {
 }
 
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
-                             const float *bias_v, float *ctx, hipStream_t s, float scale) {
+                             const float *bias_v, float *ctx, hipStream_t s, float scale, float *scratch) {
     const int hd = d / n_heads;
     // V chunk rows: 64 keeps the footprint at ~39 KB for 10 s clips (4 workgroups per CU at hd = 64)
-    if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
-    else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
-    else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
-    else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s);
+    if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch);
+    else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch);
+    else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch);
+    else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch);
 }
 
 }  // namespace pk

@@ -62,8 +62,9 @@ void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd,
 // no position term, bias_u / bias_v ignored.  scale <= 0: 1/sqrt(d / n_heads).
 size_t relpos_attention_lds_bytes(int T, int hd);     // 0: unsupported head size
 int relpos_attention_max_frames(int hd);              // longest sequence one workgroup's LDS score block can hold
+size_t relpos_attention_scratch_bytes(int B, int T, int n_heads, int hd);   // long sequences: score blocks in global scratch (hd 64 / 128)
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
-                             const float *bias_v, float *ctx, hipStream_t s, float scale = 0.0f);
+                             const float *bias_v, float *ctx, hipStream_t s, float scale = 0.0f, float *scratch = nullptr);
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
                            const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s);
 

@@ -7,7 +7,6 @@
 //    reference itself uses (const float*, size_t) for raw PCM in read_audio() and transcribe_chunk();
 //  * there is no CPU execution path: transcribe() places the model on GPU 0 on first use if to_gpu() was not called;
 //  * audio files: RIFF/WAVE only (any sample rate: resampled to 16 kHz with the reference's sinc resampler; no FLAC/MP3/OGG);
-//  * one utterance may be at most 85 s long (hd = 64; the attention kernel's LDS score block) -- longer audio throws, split it;
 //  * weights are loaded strictly (a missing / mis-shaped tensor throws instead of being ignored);
 //  * boost_phrases / boost_score work as in the reference (the ContextTrie and the boosted argmax run on the GPU); the
 //    Tensor-level free functions of phrase_boost.hpp (ctc_greedy_decode_boosted(Tensor, ...)) have C-ABI counterparts instead:

@@ -88,13 +88,18 @@ def test_model_without_vocabulary(tmp_path, orc):
     gm.close()
 
 
-def test_over_long_utterance_is_refused_with_a_clear_message(pair):
-    """The attention kernel holds a [32][T] score block in LDS: beyond ~85 s (hd = 64) the call fails loudly instead of launching."""
+def test_long_utterance_uses_the_global_scratch_attention(pair, orc):
+    """Beyond ~85 s a [32][T] score block no longer fits LDS: the attention kernel then keeps its score blocks in global scratch
+    (same code, same bits).  A 100 s clip (T = 1251 frames) must decode exactly like the oracle; an 80 s clip (LDS path) too."""
     W, om, gm = pair
-    ok = synth.synth_pcm(1, 16000 * 80, seed=2)[0]                  # 80 s: T = 1001 frames, inside the limit
-    r = gm.transcribe_pcm([ok], "ctc")
-    assert len(r) == 1
-    too_long = np.zeros(16000 * 100, np.float32)                     # 100 s: T = 1251 frames
-    with pytest.raises(RuntimeError, match="split the audio"):
-        gm.transcribe_pcm([too_long], "ctc")
-    assert gm.transcribe_pcm([ok[:16000]], "ctc") is not None        # the model is still usable afterwards
+    for seconds in (80, 100):
+        pcm = synth.synth_pcm(1, 16000 * seconds, seed=seconds)[0]
+        enc = om.encoder(orc.mel(pcm)[None])
+        assert enc.shape[1] == (1001, 1251)[seconds == 100]
+        feats = gm.mel(pcm[None])
+        G.assert_bits_equal(gm.encode(feats), enc, f"{seconds} s encoder output")
+        t, c = om.tdt_greedy(enc), orc.ctc_greedy(om.ctc_logprobs(enc), om.cfg.ctc_vocab_size - 1)
+        r = gm.transcribe_pcm([pcm], "tdt")[0]
+        assert r["token_ids"] == t["ids"][0, :t["lens"][0]].tolist()
+        r = gm.transcribe_pcm([pcm], "ctc")[0]
+        assert r["token_ids"] == c["ids"][0, :c["lens"][0]].tolist() and len(r["token_ids"]) > 0
