@@ -276,7 +276,7 @@ static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const
     const int n_rb = (T + RB - 1) / RB, n_bh = B * n_heads;
     dim3 grid(((n_bh + 7) / 8) * 8 * n_rb);                        // 8 XCD lanes x ceil(n_bh/8) pairs x n_rb row blocks
     if (scratch) {
-        if constexpr (HD == 64 || HD == 128) {
+        {
             const size_t lds = (size_t)VCH * (HD + 16) * sizeof(float);
             hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, true>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits,
                                n_rb, n_bh, scratch);
@@ -303,9 +303,9 @@ size_t relpos_attention_lds_bytes(int T, int hd) {
     return (size_t)(4 * (RB * pits + 8) + vch * (hd + 16)) * sizeof(float);
 }
 // longest sequence whose score block fits the 160 KB of LDS of a CU (hd 64: 1064 frames = 85 s of audio; hd 128: 1104)
-// bytes of global scratch the long-sequence variant needs (hd 64 / 128 only; 0 otherwise)
+// bytes of global scratch the long-sequence variant needs (0: unsupported head size)
 size_t relpos_attention_scratch_bytes(int B, int T, int n_heads, int hd) {
-    if (hd != 64 && hd != 128) return 0;
+    if (hd != 32 && hd != 64 && hd != 96 && hd != 128) return 0;
     int pits = (T + 3) / 4;
     pits = (pits + 3) & ~3;
     if (((pits / 4) & 1) == 0) pits += 4;

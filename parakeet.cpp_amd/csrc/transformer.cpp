@@ -103,8 +103,13 @@ void TransformerEncoder::forward_dev(float *x, int B, int T, hipStream_t s) {
     const int64_t rows = (int64_t)B * T;
     const float eps = cfg.layer_norm_eps > 0.0f ? cfg.layer_norm_eps : 1e-5f;
     const float scale = 1.0f / sqrtf((float)hd);                              // src/transformer.cpp:27 (the REAL head dim)
-    if (relpos_attention_lds_bytes(T, hdp_) > 160 * 1024)
-        fail(PK_ERR_UNSUPPORTED, "sequence of %d frames exceeds the attention kernel's limit of %d", T, relpos_attention_max_frames(hdp_));
+    float *scratch = nullptr;
+    if (relpos_attention_lds_bytes(T, hdp_) > 160 * 1024) {          // long sequence: score blocks in global scratch (attention.hip)
+        const size_t need = relpos_attention_scratch_bytes(B, T, H, hdp_);
+        if (need == 0 || need > ((size_t)64 << 30)) fail(PK_ERR_UNSUPPORTED, "sequence of %d frames x %d: attention scratch of %.1f GB", T, B, need / 1e9);
+        att_scratch_.reserve(need);
+        scratch = att_scratch_.as<float>();
+    }
     n_.reserve(rows * d * 4); qkv_.reserve(rows * 3 * dp_ * 4); ctx_.reserve(rows * dp_ * 4); h_.reserve(rows * f * 4);
     float *n = n_.as<float>();
     for (const TransformerLayerW &L : layers_) {
@@ -115,7 +120,7 @@ void TransformerEncoder::forward_dev(float *x, int B, int T, hipStream_t s) {
             g.sigma_cols = 2 * dp_;
             launch_gemm(g, EPI_NONE, s);
         }
-        launch_relpos_attention(qkv_.as<float>(), B, T, dp_, H, nullptr, nullptr, nullptr, ctx_.as<float>(), s, scale);   // :38-45
+        launch_relpos_attention(qkv_.as<float>(), B, T, dp_, H, nullptr, nullptr, nullptr, ctx_.as<float>(), s, scale, scratch);   // :38-45
         {   // out_proj + residual (:49-51)
             GemmArgs g{ctx_.as<float>(), dp_, L.wo, dp_, L.bo, x, d, x, d, 1.0f, (int)rows, d, dp_};
             launch_gemm(g, EPI_RESID, s);

@@ -27,7 +27,7 @@ class TransformerEncoder {
     std::vector<void *> allocs_;
     std::vector<TransformerLayerW> layers_;
     const float *fin_g_ = nullptr, *fin_b_ = nullptr;
-    DevBuf x_, n_, qkv_, ctx_, h_;
+    DevBuf x_, n_, qkv_, ctx_, h_, att_scratch_;
     const float *upload(const float *h, size_t n);
 };
 
