@@ -256,6 +256,14 @@ pk_status pk_transformer_load(const char *safetensors_path, const char *prefix, 
 pk_status pk_transformer_forward(pk_transformer *t, const float *x, int B, int T, float *y);
 void pk_transformer_free(pk_transformer *t);
 
+/* ---- preprocess_audio on its own (include/parakeet/audio.hpp:7-30, src/audio.cpp:100-158): the mel front end without a model, for callers
+ * that hand features to pk_sortformer_forward / pk_encode themselves.  feats: [pk_mel_num_frames(n_samples)][n_mels]; normalize = 0 is
+ * AudioConfig::normalize = false (raw log-mel, what Sortformer takes); stft_window_centered: switch A1 of pk_config. */
+typedef struct pk_frontend pk_frontend;
+pk_status pk_frontend_create(int n_mels, int normalize, int stft_window_centered, int device, pk_frontend **out);
+pk_status pk_frontend_features(pk_frontend *f, const float *pcm, int64_t n_samples, float *feats, int *n_frames);
+void pk_frontend_free(pk_frontend *f);
+
 /* ---- Sortformer speaker diarization (include/parakeet/sortformer.hpp:28-129, src/sortformer.cpp:41-121) ------------------------
  * NEST FastConformer (offline Conformer path, xscaling, weights under "nest_encoder_.") -> projection_ -> TransformerEncoder
  * ("transformer_.") -> relu -> first_hidden_ -> relu -> output_proj_ -> sigmoid.  One handle = weights on one device. */

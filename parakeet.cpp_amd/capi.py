@@ -370,6 +370,32 @@ def sortformer_segments(probs, threshold=0.5):
     return [(int(spk[i]), float(a[i]), float(b[i])) for i in range(n)]
 
 
+class Frontend:
+    """pk_frontend_*: preprocess_audio without a model (reference src/audio.cpp:100-158)."""
+
+    def __init__(self, n_mels=80, normalize=True, window_centered=False, device=0):
+        L = lib()
+        L.pk_frontend_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pk_frontend_features.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.POINTER(C.c_int)]
+        L.pk_frontend_free.argtypes = [C.c_void_p]
+        L.pk_frontend_free.restype = None
+        self.n_mels = n_mels
+        self._h = C.c_void_p()
+        check(L.pk_frontend_create(n_mels, int(normalize), int(window_centered), device, C.byref(self._h)))
+
+    def features(self, pcm):
+        pcm = _c(pcm).ravel()
+        nf = lib().pk_mel_num_frames(pcm.size)
+        out = np.zeros((nf, self.n_mels), np.float32)
+        check(lib().pk_frontend_features(self._h, _f(pcm), pcm.size, _f(out), None))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().pk_frontend_free(self._h)
+            self._h = None
+
+
 def read_audio_memory(data: bytes, target_rate=16000):
     """read_audio(const uint8_t*, size_t, target) -> (mono pcm at target_rate, original rate, channels)."""
     L = lib()

@@ -2,6 +2,7 @@
 #include "engine.hpp"
 
 #include <cmath>
+#include <functional>
 #include <map>
 #include <cstring>
 
@@ -117,8 +118,11 @@ const float *Model::upload_tensor(const std::string &name, std::vector<int64_t> 
 
 // Slaney filterbank, fp64 build / fp32 store -- reference src/audio.cpp:24-94 (hz_to_mel_slaney, mel_to_hz_slaney,
 // build_mel_filterbank); Hann window (periodic=false) :117; FFT twiddles per the FFT-512 specification in DESIGN.md.
-void Model::build_mel_tables() {
-    const int n_fft = 512, win = 400, n_freqs = 257, n_mels = cfg.mel_bins;
+// Filterbank (src/audio.cpp:40-94), Hann window, FFT twiddles and the packed filter bands of the mel kernels; `upload` puts a host
+// array on the device and keeps ownership.  Shared by Model and the weight-free MelFrontend (preprocess_audio on its own).
+MelTables make_mel_tables(int n_mels, bool window_centered, const std::function<const float *(const float *, size_t)> &upload) {
+    MelTables mel{};
+    const int n_fft = 512, win = 400, n_freqs = 257;
     const double sr = 16000.0, f_min = 0.0, f_max = sr / 2.0;
     auto hz2mel = [](double f) { return f < 1000.0 ? f / (200.0 / 3.0) : 15.0 + std::log(f / 1000.0) / 0.06875177742094912; };
     auto mel2hz = [](double m) { return m < 15.0 ? m * (200.0 / 3.0) : 1000.0 * std::exp((m - 15.0) * 0.06875177742094912); };
@@ -143,7 +147,7 @@ void Model::build_mel_tables() {
     }
     std::vector<float> window(n_fft, 0.0f), twr(n_fft / 2), twi(n_fft / 2);
     // switch A1 (pk_config.stft_window_centered): left-aligned like the reference author's feature check, or centred (torch.stft)
-    const int off = cfg.stft_window_centered ? (n_fft - win) / 2 : 0;
+    const int off = window_centered ? (n_fft - win) / 2 : 0;
     for (int k = 0; k < win; ++k) window[off + k] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)k / (double)(win - 1)));
     for (int k = 0; k < n_fft / 2; ++k) {
         const double a = 2.0 * M_PI * (double)k / (double)n_fft;
@@ -162,20 +166,25 @@ void Model::build_mel_tables() {
     mel.f_lo = reinterpret_cast<const int *>(upload(reinterpret_cast<const float *>(lo.data()), lo.size()));
     mel.f_hi = reinterpret_cast<const int *>(upload(reinterpret_cast<const float *>(hi.data()), hi.size()));
     {   // packed bands for the LDS-staged dot products of the mel kernel
-        std::vector<int> off(cfg.mel_bins + 1, 0);
+        std::vector<int> off(n_mels + 1, 0);
         std::vector<float> packed;
-        for (int m = 0; m < cfg.mel_bins; ++m) {
-            for (int f = lo[m]; f <= hi[m]; ++f) packed.push_back(fb[(size_t)f * cfg.mel_bins + m]);
+        for (int m = 0; m < n_mels; ++m) {
+            for (int f = lo[m]; f <= hi[m]; ++f) packed.push_back(fb[(size_t)f * n_mels + m]);
             off[m + 1] = (int)packed.size();
         }
         if ((int)packed.size() > kMelMaxTaps) fail(PK_ERR_UNSUPPORTED, "mel filterbank has %d taps (> %d)", (int)packed.size(), kMelMaxTaps);
         if (packed.empty()) packed.push_back(0.0f);
-        mel.fb_nnz = off[cfg.mel_bins];
+        mel.fb_nnz = off[n_mels];
         mel.fbc = upload(packed.data(), packed.size());
         mel.fb_off = reinterpret_cast<const int *>(upload(reinterpret_cast<const float *>(off.data()), off.size()));
     }
     mel.n_mels = n_mels;
     mel.power_via_abs = 1;               // switch A2 default: abs() then square, as the reference writes it
+    return mel;
+}
+
+void Model::build_mel_tables() {
+    mel = make_mel_tables(cfg.mel_bins, cfg.stft_window_centered != 0, [this](const float *h, size_t n) { return upload(h, n); });
 }
 
 // Upload every tensor the hot path reads, under the reference's names (scripts/convert_nemo.py:98-310;

@@ -5,6 +5,7 @@
 // short, fixed sequence of hand-written kernels on one HIP stream.
 #pragma once
 #include <map>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -33,6 +34,8 @@ struct DecW {
     const float *we, *be, *wp, *bp, *wl, *bl, *wd, *bd;
     const float *ctc_w, *ctc_b;
 };
+
+MelTables make_mel_tables(int n_mels, bool window_centered, const std::function<const float *(const float *, size_t)> &upload);
 
 // Per-kernel hipEvent timing: when a sink is attached every launch is bracketed by two events.
 struct ProfileSink {

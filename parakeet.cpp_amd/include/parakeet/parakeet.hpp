@@ -4,6 +4,7 @@
 #include "timestamp.hpp"
 #include "transcribe.hpp"
 #include "audio_io.hpp"
+#include "audio.hpp"
 #include "nemotron.hpp"
 #include "sortformer.hpp"
 #include "diarize.hpp"

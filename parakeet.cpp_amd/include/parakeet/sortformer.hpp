@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "audio.hpp"
 #include "nemotron.hpp"
 
 namespace parakeet {
@@ -130,6 +131,8 @@ class Sortformer {
         const auto probs = forward(features, n_frames, &T);
         return probs_to_segments(probs.data(), T);
     }
+    /// From preprocess_audio(samples, {.normalize = false}) -- the reference README's usage
+    std::vector<DiarizationSegment> diarize(const Features &features) { return diarize(features.ptr(), features.n_frames); }
     /// From 16 kHz mono PCM: preprocess_audio(n_mels = mel_bins, normalize = false) + diarize (src/main.cpp:513-519)
     std::vector<DiarizationSegment> diarize_pcm(const float *pcm, size_t n) {
         to_gpu();

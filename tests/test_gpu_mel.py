@@ -3,6 +3,7 @@ bit-for-bit, at test sizes and at BASELINE's 10 s / 30 s clip lengths."""
 import numpy as np
 import pytest
 
+import gpu_common as G
 from conftest import pk
 from parakeet_cpp_amd import synth
 
@@ -58,3 +59,15 @@ def test_mel_centered_window_switch_bit_identical(tmp_path_factory, orc):
         assert np.array_equal(feats[b].view(np.uint32), want.view(np.uint32))
         assert not np.array_equal(want, orc.mel(pcm[b]))
     gm.close()
+
+
+@pytest.mark.parametrize("n_mels,normalize", [(80, True), (128, False)])
+def test_standalone_frontend_matches_oracle(orc, n_mels, normalize):
+    """pk_frontend_* = preprocess_audio without a model (the reference README's diarization usage feeds
+    preprocess_audio(samples, {.normalize = false}) to Sortformer::diarize): bit-identical to the oracle's mel."""
+    from parakeet_cpp_amd import capi
+    fe = capi.Frontend(n_mels=n_mels, normalize=normalize)
+    for n in (16000, 48123):
+        pcm = synth.synth_pcm(1, n, seed=n)[0]
+        G.assert_bits_equal(fe.features(pcm), orc.mel(pcm, n_mels=n_mels, normalize=normalize), f"frontend {n_mels} mels, normalize={normalize}")
+    fe.close()
