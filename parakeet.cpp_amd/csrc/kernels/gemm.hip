@@ -200,6 +200,10 @@ static void launch_epi(const GemmArgs &a, hipStream_t s) {
     if (a.K < 64) { launch_one<64, 64, EPI>(a, s); return; }           // pipelined kernels need >= 2 K tiles
     // measured table: profiles/r01_gemm_sweep_v5.txt (128x128 tile on 8 waves of 32x64 wins for every wide output and for the
     // 321k-row subsampling products; long-K / narrow-N products like fc2 of the 110M model take 128x64)
+    // long-K products whose 128x128 tiles fill the chip exactly once (fc2 / sub_proj of the 110M model: 252 tiles for 256 CUs): one
+    // 8-wave workgroup per CU with BK = 64 -- half the barriers per k, nothing to share the CU with (-6 % vs two 128x64 workgroups)
+    const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.M >= 1024 && a.N >= 256 && a.K >= 1024 && a.K % 64 == 0 && tiles128 <= 256) { launch_gemm_pipe<2, 4, 2, 1, 64, EPI>(a, s); return; }
     if (a.M >= 1024 && (a.N >= 1024 || (a.M >= 65536 && a.N >= 256))) launch_gemm_pipe<4, 2, 1, 2, 32, EPI>(a, s);
     else if (a.M >= 1024 && a.N >= 256 && a.K >= 1024) launch_gemm_pipe<2, 2, 2, 1, 32, EPI>(a, s);
     else if (a.M >= 1024 && a.N >= 256) launch_gemm_pipe<2, 4, 1, 1, 32, EPI>(a, s);      // 64x128 on 8 waves of 32x32: out_proj / pw2 (-7 %)
