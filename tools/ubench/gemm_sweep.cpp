@@ -131,6 +131,8 @@ int main(int argc, char **argv) {
         {"pipe 128x128 w32x64 bk32 512t", run_pipe<4, 2, 1, 2, 32>},
         {"pipe 128x128 w32x64 bk64 512t", run_pipe<4, 2, 1, 2, 64>},
         {"pipe 128x128 w64x32 bk64 512t", run_pipe<2, 4, 2, 1, 64>},
+        {"pipe 128x128 w32x64 bk64 512t", run_pipe<4, 2, 1, 2, 64>},
+        {"pipe 128x128 w64x32 bk64 512t", run_pipe<2, 4, 2, 1, 64>},
         {"pipe 128x64  w32x32 bk32 512t", run_pipe<4, 2, 1, 1, 32>},
         {"pipe 64x128  w32x32 bk32 512t", run_pipe<2, 4, 1, 1, 32>},
     };
