@@ -103,3 +103,20 @@ def test_long_utterance_uses_the_global_scratch_attention(pair, orc):
         assert r["token_ids"] == t["ids"][0, :t["lens"][0]].tolist()
         r = gm.transcribe_pcm([pcm], "ctc")[0]
         assert r["token_ids"] == c["ids"][0, :c["lens"][0]].tolist() and len(r["token_ids"]) > 0
+
+
+def test_strict_weights_at_upload(tmp_path):
+    """to_gpu() checks every tensor it uploads: a missing tensor, a wrong shape and a wrong dtype are named in the error (the reference
+    loads with strict = false and would run on uninitialised weights, transcribe.hpp:63)."""
+    cfg = G.tiny(name="tiny-strict")
+    W = synth.synth_weights(cfg, seed=42)
+    name = "encoder_.layers_.1.conv_.pointwise_conv2_.weight"
+    for what, mutate in (("missing", lambda d: d.pop(name)),
+                         ("shape", lambda d: d.__setitem__(name, np.zeros((3, 5), np.float32))),
+                         ("dtype", lambda d: d.__setitem__(name, d[name].astype(np.float16)))):
+        d = dict(W)
+        mutate(d)
+        p = str(tmp_path / f"{what}.safetensors")
+        synth.save_weights(p, d)
+        with pytest.raises(RuntimeError, match="pointwise_conv2_"):
+            capi.Model(p, cfg, device=0)
