@@ -7,37 +7,8 @@
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
-/* ---- Sortformer (src/sortformer.cpp) ---- */
-void orc_model_set_encoder(orc_model *m, const char *prefix, int xscaling);
-int orc_sortformer_forward(orc_model *m, const float *feats, int B, int Tm, int n_tlayers, int n_theads, int pre_ln,
-                           int has_final_norm, float *probs);
-int orc_probs_to_segments(const float *probs, int T, int S, float threshold, int32_t *spk, float *start, float *end);
-
-/* ---- phrase boosting: ContextTrie + boosted greedy decoders (src/phrase_boost.cpp) ---- */
-typedef struct orc_trie orc_trie;
-orc_trie *orc_trie_new(void);
-void orc_trie_free(orc_trie *t);
-void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
-int orc_trie_size(const orc_trie *t);
-int orc_trie_boosted_tokens(const orc_trie *t, const int32_t *states, int n, unsigned char *flag, int V);   /* -> count */
-int orc_trie_advance(const orc_trie *t, const int32_t *states, int n, int tok, int32_t *out);                /* -> count */
-void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
-                            int32_t *lens, int32_t *start, int32_t *end, float *conf);
-int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
-                           int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps);
-
-/* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
-typedef struct orc_stream orc_stream;
-orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);
-void orc_stream_free(orc_stream *s);
-int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out);
-int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out);
-int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
-
-int orc_sortformer_chunk(orc_stream *s, const float *feats, int n_frames, int n_tlayers, int n_theads, int pre_ln, int has_final_norm,
-                         float *probs, int max_out);
-
 #endif
+
 
 /* include/parakeet/audio.hpp:7-17 (AudioConfig) + switches A1/A2 */
 typedef struct {
@@ -105,49 +76,40 @@ int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens,
                    int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps, float *first_label_logp);
 int orc_rnnt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens, int32_t *ids, int32_t *lens,
                     int32_t *start, float *conf);
+
+/* ---- Sortformer (src/sortformer.cpp) ---- */
+void orc_model_set_encoder(orc_model *m, const char *prefix, int xscaling);
+int orc_sortformer_forward(orc_model *m, const float *feats, int B, int Tm, int n_tlayers, int n_theads, int pre_ln,
+                           int has_final_norm, float *probs);
+int orc_probs_to_segments(const float *probs, int T, int S, float threshold, int32_t *spk, float *start, float *end);
+
+/* ---- phrase boosting: ContextTrie + boosted greedy decoders (src/phrase_boost.cpp) ---- */
+typedef struct orc_trie orc_trie;
+orc_trie *orc_trie_new(void);
+void orc_trie_free(orc_trie *t);
+void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
+int orc_trie_size(const orc_trie *t);
+int orc_trie_boosted_tokens(const orc_trie *t, const int32_t *states, int n, unsigned char *flag, int V);   /* -> count */
+int orc_trie_advance(const orc_trie *t, const int32_t *states, int n, int tok, int32_t *out);                /* -> count */
+void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
+                            int32_t *lens, int32_t *start, int32_t *end, float *conf);
+int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
+                           int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps);
+
+/* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
+typedef struct orc_stream orc_stream;
+orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);
+void orc_stream_free(orc_stream *s);
+int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out);
+int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out);
+int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
+
+int orc_sortformer_chunk(orc_stream *s, const float *feats, int n_frames, int n_tlayers, int n_theads, int pre_ln, int has_final_norm,
+                         float *probs, int max_out);
+
+
 #ifdef __cplusplus
 }
-/* ---- phrase boosting: ContextTrie + boosted greedy decoders (src/phrase_boost.cpp) ---- */
-typedef struct orc_trie orc_trie;
-orc_trie *orc_trie_new(void);
-void orc_trie_free(orc_trie *t);
-void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
-int orc_trie_size(const orc_trie *t);
-int orc_trie_boosted_tokens(const orc_trie *t, const int32_t *states, int n, unsigned char *flag, int V);   /* -> count */
-int orc_trie_advance(const orc_trie *t, const int32_t *states, int n, int tok, int32_t *out);                /* -> count */
-void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
-                            int32_t *lens, int32_t *start, int32_t *end, float *conf);
-int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
-                           int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps);
-
-/* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
-typedef struct orc_stream orc_stream;
-orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);
-void orc_stream_free(orc_stream *s);
-int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out);
-int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out);
-int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
-
 #endif
-/* ---- phrase boosting: ContextTrie + boosted greedy decoders (src/phrase_boost.cpp) ---- */
-typedef struct orc_trie orc_trie;
-orc_trie *orc_trie_new(void);
-void orc_trie_free(orc_trie *t);
-void orc_trie_insert(orc_trie *t, const int32_t *ids, int n);
-int orc_trie_size(const orc_trie *t);
-int orc_trie_boosted_tokens(const orc_trie *t, const int32_t *states, int n, unsigned char *flag, int V);   /* -> count */
-int orc_trie_advance(const orc_trie *t, const int32_t *states, int n, int tok, int32_t *out);                /* -> count */
-void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
-                            int32_t *lens, int32_t *start, int32_t *end, float *conf);
-int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
-                           int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps);
 
-/* ---- streaming path (StreamingAudioPreprocessor, forward_chunk, rnnt_streaming_decode_chunk) -- one object per stream ---- */
-typedef struct orc_stream orc_stream;
-orc_stream *orc_stream_new(orc_model *m, int att_context_left, int att_context_right);
-void orc_stream_free(orc_stream *s);
-int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out);
-int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out);
-int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
-
-#endif
+#endif /* PK_ORACLE_H */
