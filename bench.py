@@ -25,6 +25,12 @@ CLIP_SAMPLES = 160000
 BATCH = 64
 ENCODER_FLOP_PER_CLIP = 28.23e9        # 14.11 GMAC per 10 s clip, tdt-ctc-110m
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+D_MODEL, FFN, ENC_FRAMES = 512, 2048, 126
+FC1_KERNEL = {False: "gemm_pipe_kernel<4,2,1,2,32,EPI_SILU> (ffn_fc1_silu: fp32 v_mfma_f32_32x32x2_f32, 128x128 tile, 8 waves of 32x64)",
+              True: "gemm_bf16_kernel<EPI_SILU> (ffn_fc1_silu: v_mfma_f32_32x32x16_bf16, 128x128 tile, 8 waves)"}
+# committed rocprofv3 --pmc summaries (HBM bytes per launch of the dominant kernel), newest first, per (config, bf16)
+PMC_FILES = {("tdt-ctc-110m", False): ("r02_pmc_hbm.json", "r01_pmc_hbm.json")}
 
 
 def log(*a):
@@ -48,26 +54,19 @@ def weights_file(cfg, seed=42):
     return path, None
 
 
-def cpu_baseline(cfg, weights, n_clips, threads):
-    """The CPU oracle (a C restatement of the reference algorithm: the reference itself cannot be built, its
-    arithmetic is the un-vendored axiom) timed on this host, on a bounded sample of the same workload."""
+def cpu_port(cfg, weights, pcm_all, threads, budget_s=10.0):
+    """The CPU oracle (oracle/libpk_oracle.so: a C restatement of the reference algorithm, AVX2 + OpenMP over clips) on ALL clips
+    of the timed batch: it is the parity checker of the timed configuration and the `port` CPU figure."""
     import numpy as np
     import oracle
-    from parakeet_cpp_amd import synth
-    if weights is None:
-        weights = synth.synth_weights(cfg, seed=42)
     oracle.set_threads(threads)
     om = oracle.Model(cfg, weights)
-    # warm the oracle's lazily built weight transposes / heap on one clip (untimed)
-    pcm0 = synth.synth_pcm(n_clips, CLIP_SAMPLES, seed=1234)
-    f0 = np.stack([oracle.mel(pcm0[0])])
-    om.tdt_greedy(om.encoder(f0))
-    # chunks of n_clips clips until ~12 s of CPU work have been timed (bounded sample; clip synthesis is outside the clock)
+    om.tdt_greedy(om.encoder(np.stack([oracle.mel(pcm_all[0])])))       # warm the lazily built weight transposes (untimed)
     t_mel = t_enc = t_tdt = 0.0
-    done = tokens = 0
-    chunk = 0
-    while (t_mel + t_enc + t_tdt) < 12.0 and done < 64 * n_clips:
-        pcm = pcm0 if chunk == 0 else synth.synth_pcm(n_clips, CLIP_SAMPLES, seed=1234 + chunk)
+    ids, n = [], len(pcm_all)
+    chunk = 16
+    for c0 in range(0, n, chunk):
+        pcm = pcm_all[c0:c0 + chunk]
         t0 = time.time()
         feats = np.stack([oracle.mel(p) for p in pcm])
         t1 = time.time()
@@ -76,27 +75,52 @@ def cpu_baseline(cfg, weights, n_clips, threads):
         r = om.tdt_greedy(enc)
         t3 = time.time()
         t_mel += t1 - t0; t_enc += t2 - t1; t_tdt += t3 - t2
-        done += n_clips; tokens += int(r["lens"].sum()); chunk += 1
+        ids += [r["ids"][b, :r["lens"][b]].tolist() for b in range(len(pcm))]
     wall = t_mel + t_enc + t_tdt
-    # the reference's own sources are single-threaded: the same path on ONE thread, two clips
     single = None
-    try:
+    try:                                   # the reference's own sources are single-threaded: same path, ONE thread, 2 clips
         oracle.set_threads(1)
         t0 = time.time()
-        f1 = np.stack([oracle.mel(p) for p in pcm0[:2]])
-        r1 = om.tdt_greedy(om.encoder(f1))
+        r1 = om.tdt_greedy(om.encoder(np.stack([oracle.mel(p) for p in pcm_all[:2]])))
         w1 = time.time() - t0
-        single = {"value": round(2 * CLIP_SECONDS / w1, 3), "cores": 1, "sample": f"2 of the same clips, {w1:.1f} s", "tokens": int(r1["lens"].sum())}
+        single = {"value": round(2 * CLIP_SECONDS / w1, 3), "cores": 1, "sample": f"2 of the same clips, {w1:.1f} s"}
     finally:
         oracle.set_threads(threads)
-    return {
-        "single_thread": single,
-        "value": round(done * CLIP_SECONDS / wall, 3), "unit": "RTFx (audio-s / wall-s)", "cores": threads, "kind": "port",
-        "sample": f"{done} seeded 10 s clips in chunks of {n_clips} (the first chunk is the GPU run's batch prefix), mel+encoder+TDT, "
-                  f"{wall:.1f} s of CPU work on oracle/libpk_oracle.so (AVX2 fp32, OpenMP over clips)",
-        "seconds": {"mel": round(t_mel, 3), "encoder": round(t_enc, 3), "tdt": round(t_tdt, 3)},
-        "tokens": tokens,
-    }
+    rep = {"value": round(n * CLIP_SECONDS / wall, 3), "unit": "RTFx (audio-s / wall-s)", "cores": threads, "kind": "port",
+           "sample": f"all {n} clips of rank 0's timed batch, mel+encoder+TDT, {wall:.1f} s of CPU work on oracle/libpk_oracle.so",
+           "seconds": {"mel": round(t_mel, 3), "encoder": round(t_enc, 3), "tdt": round(t_tdt, 3)}, "single_thread": single}
+    return rep, ids
+
+
+def cpu_reference(cfg, wpath, pcm_all, threads, budget_s=14.0):
+    """The REFERENCE'S OWN CODE on this host: parakeet::Transcriber::transcribe (include/parakeet/transcribe.hpp:99-179; mel, encoder,
+    TDT greedy, detokenise) from oracle/_ref/libpk_ref_model.so = the reference sources compiled where they lie on the CPU stand-in
+    for the un-vendored axiom tensor library (oracle/axiom_stub/: plain fp32 loops, OpenMP).  Bounded sample: clips of the timed
+    batch, one call per clip (the reference API is single-utterance), until ~budget_s seconds of CPU work."""
+    import refmodel
+    import oracle
+    from parakeet_cpp_amd import synth
+    if not refmodel.available():
+        return None, []
+    oracle.set_threads(threads)            # one libgomp: the same thread count applies to the stand-in's OpenMP loops
+    vpath = os.path.join(os.environ.get("PK_BENCH_CACHE", "/tmp"), f"pk_bench_{cfg.name}_vocab.txt")
+    if not os.path.exists(vpath):
+        synth.save_vocab(vpath, synth.synth_vocab(cfg.vocab_size - 1))
+    tr = refmodel.Transcriber(cfg, wpath, vpath)
+    tr.transcribe(pcm_all[0][:32000], "tdt")                            # first-touch of the weights, untimed
+    ids, wall = [], 0.0
+    for p in pcm_all:
+        t0 = time.time()
+        r = tr.transcribe(p, "tdt")
+        wall += time.time() - t0
+        ids.append(r["token_ids"].tolist())
+        if wall >= budget_s:
+            break
+    n = len(ids)
+    rep = {"value": round(n * CLIP_SECONDS / wall, 3), "unit": "RTFx (audio-s / wall-s)", "cores": threads, "kind": "reference",
+           "sample": f"the first {n} clips of rank 0's timed batch through parakeet::Transcriber::transcribe (TDT), one call per clip, "
+                     f"{wall:.1f} s of CPU work on oracle/_ref/libpk_ref_model.so (reference sources on the axiom CPU stand-in)"}
+    return rep, ids
 
 
 def main():
@@ -111,12 +135,13 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="pk_config.gemm_bf16: encoder products on bf16 operands / fp32 accumulation "
                     "(the precision BASELINE configs[2] names); the headline metric stays fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=16, help="clips per chunk of the CPU baseline sample (chunks run until ~12 s of CPU work)")
     args = ap.parse_args()
-    global CLIP_SECONDS, CLIP_SAMPLES, ENCODER_FLOP_PER_CLIP
+    global CLIP_SECONDS, CLIP_SAMPLES, ENCODER_FLOP_PER_CLIP, D_MODEL, FFN, ENC_FRAMES
+    exit_code = [0]
     big = args.config == "tdt-600m"
     if big:                                  # 470.9 GFLOP per 30 s clip
         CLIP_SECONDS, CLIP_SAMPLES, ENCODER_FLOP_PER_CLIP = 30.0, 480000, 470.9e9
+        D_MODEL, FFN, ENC_FRAMES = 1024, 4096, 376
         if args.batch == BATCH:
             args.batch = 32
         args.no_cpu_baseline = True          # the scalar oracle needs minutes per 30 s clip of the 24-layer model
@@ -208,28 +233,39 @@ def main():
     if rank == 0:
         audio_s = args.steps * args.batch * CLIP_SECONDS * n_gpus
         value = audio_s / elapsed
-        # roofline of the dominant kernel: the fp32-MFMA GEMM instantiation that runs ffn fc1 (+SiLU epilogue):
-        # algorithmic FLOP per launch = 2*M*N*K (M = batch*126 frames, N = 2048, K = 512; tdt-600m: M = batch*376, N = 4096, K = 1024)
+        # Roofline of the dominant kernel = the MFMA GEMM instantiation that runs ffn fc1 (+ SiLU epilogue).  Algorithmic FLOP per
+        # launch = 2*M*N*K (M = batch*126 frames, N = 2048, K = 512; tdt-600m: M = batch*376, N = 4096, K = 1024); duration = the HIP-event
+        # average over its launches measured above, in this run.  Peak by arithmetic type (MI355X_MICROARCH.md): fp32 MFMA 157.3 TF,
+        # dense bf16 MFMA 2500 TF.
+        peak = PEAK_BF16_MFMA_TFLOPS if args.bf16 else PEAK_F32_MFMA_TFLOPS
         dom = kernels.get("ffn_fc1_silu")
         roof = None
         if dom and dom["launches"]:
             per_launch_flop = dom["gflop"] * 1e9 / dom["launches"]
             per_launch_s = dom["ms"] * 1e-3 / dom["launches"]
             ach = per_launch_flop / per_launch_s / 1e12
-            gemm_names = [k for k, v in kernels.items() if v["gflop"] > 0 and k not in ("sub_conv1_dw1", "sub_dw2", "dwconv_bn_silu", "relpos_attention")]
-            g_fl = sum(kernels[k]["gflop"] for k in gemm_names)
-            g_ms = sum(kernels[k]["ms"] for k in gemm_names)
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("ffn_fc1_silu_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"bound": "mfma", "kernel": "gemm_pipe_kernel<4,2,1,2,32,EPI_SILU> (ffn_fc1_silu: 128x128 tile, 8 waves of 32x64)", "achieved": round(ach, 2),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            enc_gemms = ("sub_pw", "sub_proj", "ffn_fc1_silu", "ffn_fc2_resid", "attn_qkv", "attn_out_resid", "conv_pw1_glu", "conv_pw2_resid")
+            g_fl = sum(kernels[k]["gflop"] for k in enc_gemms if k in kernels)
+            g_ms = sum(kernels[k]["ms"] for k in enc_gemms if k in kernels)
+            # HBM traffic of that kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read inside this process):
+            # the committed summary of the same configuration, labelled with its source; null when there is none for this config.
+            traffic, traffic_src = None, None
+            for name in PMC_FILES.get((args.config, bool(args.bf16)), ()):
+                f = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(f):
+                    try:
+                        traffic = json.load(open(f)).get("ffn_fc1_silu_bytes_per_launch")
+                        traffic_src = "profiles/" + name + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    except Exception:
+                        traffic = None
+                    if traffic:
+                        break
+            roof = {"bound": "mfma", "kernel": FC1_KERNEL[bool(args.bf16)], "achieved": round(ach, 2),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": int(4 * (args.batch * ENC_FRAMES * (D_MODEL + FFN) + FFN * D_MODEL)),
                     "flop_per_launch": per_launch_flop, "us_per_launch": round(per_launch_s * 1e6, 2),
-                    "all_gemms": {"tflops": round(g_fl / max(g_ms, 1e-9), 2), "gflop": round(g_fl, 1), "ms": round(g_ms, 3)}}
+                    "encoder_gemms": {"tflops": round(g_fl / max(g_ms, 1e-9), 2), "gflop": round(g_fl, 1), "ms": round(g_ms, 3),
+                                      "frac_of_peak": round(g_fl / max(g_ms, 1e-9) / peak, 4)}}
         enc_ms = float(ms[1])
         out = {
             "metric": f"RTFx (audio-sec/wall-sec), mel+encoder+TDT decode, {args.config} {int(CLIP_SECONDS)}s@b{args.batch}",
@@ -242,22 +278,57 @@ def main():
             "encoder_ms_per_clip": round(enc_ms / args.batch, 4),
             "stage_ms": {"mel": round(float(ms[0]), 3), "encoder": round(enc_ms, 3), "decode": round(float(ms[2]), 3), "total": round(float(ms[3]), 3)},
             "encoder_tflops": round(ENCODER_FLOP_PER_CLIP * args.batch / (enc_ms * 1e-3) / 1e12, 2),
-            "encoder_frac_of_f32_mfma_peak": round(ENCODER_FLOP_PER_CLIP * args.batch / (enc_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "encoder_frac_of_mfma_peak": round(ENCODER_FLOP_PER_CLIP * args.batch / (enc_ms * 1e-3) / 1e12 / peak, 4),
             "decode_tokens_per_clip": round(float(lens.mean()), 1),
             "roofline": roof,
             "kernels": kernels,
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        # Parity of the TIMED configuration + CPU baselines, on this box's host cores (rank 0, N = 1 only).  The oracle decodes
+        # every clip of the timed batch (bit-exact contract: token ids must be identical); the reference's own Transcriber decodes a
+        # bounded prefix of it.  A mismatch against the oracle fails the run.
+        rc = 0
+        if n_gpus == 1 and not args.no_cpu_baseline and args.decoder == "tdt":
+            threads = min(8, os.cpu_count() or 1)
+            gpu_ids = [ids[b, :lens[b]].tolist() for b in range(args.batch)]
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, W, args.cpu_clips, min(8, os.cpu_count() or 1))
+                if W is None:
+                    W = synth.synth_weights(cfg, seed=42)
+                port, port_ids = cpu_port(cfg, W, pcm, threads)
+                bad = [b for b in range(args.batch) if gpu_ids[b] != port_ids[b]]
+                parity = {"clips": args.batch, "token_mismatches": len(bad), "tokens": int(lens.sum()),
+                          "checked_against": "oracle/libpk_oracle.so on every clip of the timed batch (token ids identical)"}
+                if bad:
+                    parity["mismatching_clips"] = bad[:8]
+                    rc = 3
+                ref, ref_ids = (None, [])
+                try:
+                    ref, ref_ids = cpu_reference(cfg, wpath, pcm, threads)
+                except Exception as e:
+                    ref = {"value": None, "kind": "reference", "error": repr(e)}
+                if ref_ids:
+                    rbad = [b for b in range(len(ref_ids)) if gpu_ids[b] != ref_ids[b]]
+                    parity["reference_clips"] = len(ref_ids)
+                    parity["reference_token_mismatches"] = len(rbad)
+                    parity["reference_checked_against"] = "parakeet::Transcriber::transcribe of oracle/_ref/libpk_ref_model.so (the reference's own sources) on the batch prefix"
+                out["parity"] = parity
+                # headline CPU figure: the reference's own code when the prebuilt library travelled, the port next to it
+                if ref and ref.get("value"):
+                    out["cpu_baseline"] = dict(ref, port=port)
+                else:
+                    out["cpu_baseline"] = dict(port, reference=ref)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
+        if rc:
+            log(f"[bench] PARITY FAILURE: GPU token ids differ from the oracle on clips {out['parity'].get('mismatching_clips')}")
+            exit_code[0] = rc
 
     L.pk_batch_free(batch)
     model.close()
     if world > 1:
         dist.destroy_process_group()
+    if exit_code[0]:
+        sys.exit(exit_code[0])
 
 
 if __name__ == "__main__":

@@ -80,12 +80,19 @@ def test_batch64_properties(full_pair, orc):
     c1 = run_batch(gm, pcm, 0)
     calone = run_batch(gm, pcm[17:18], 0)
     assert tok(calone, 0) == tok(c1, 17), "CTC batch invariance"
-    # oracle on a sample of the 64 (ids are [B][max_tokens] with timestamps always produced: the reference's
+    # oracle on all 64 (ids are [B][max_tokens] with timestamps always produced: the reference's
     # invariant 'ids equal with vs without timestamps' holds by construction -- same kernel, same argmax)
-    for b in (0, 63):
-        f = np.stack([orc.mel(pcm[b])])
-        o = om.tdt_greedy(om.encoder(f))
-        assert tok(r1, b) == tok(o, 0), f"clip {b} vs oracle"
+    # EVERY clip of the batch (this is bench.py's timed configuration: same seed, same 64 clips)
+    for c0 in range(0, 64, 16):
+        f = np.stack([orc.mel(p) for p in pcm[c0:c0 + 16]])
+        enc = om.encoder(f)
+        o = om.tdt_greedy(enc)
+        oc = orc.ctc_greedy(om.ctc_logprobs(enc), om.cfg.blank_id)
+        for i in range(16):
+            assert tok(r1, c0 + i) == tok(o, i), f"clip {c0 + i}: TDT ids vs oracle"
+            n = o["lens"][i]
+            assert np.array_equal(r1["start"][c0 + i, :n], o["start"][i, :n]) and np.array_equal(r1["end"][c0 + i, :n], o["end"][i, :n])
+            assert tok(c1, c0 + i) == tok(oc, i), f"clip {c0 + i}: CTC ids vs oracle"
     # monotone, in-range timestamps (tests/test_all.cpp:946-963 checks monotonic word timestamps)
     for b in range(64):
         n = r1["lens"][b]
