@@ -529,7 +529,10 @@ int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap) {
     int n_out = -1;
     pk_status st = guard([&] {
         need(b && out && cap > 0, "batch/out/cap");
+        need(decoder == 0 || decoder == 1, "decoder must be 0 (CTC) or 1 (TDT)");
+        need(b->n_clips > 0, "no clips uploaded");
         Model &m = *b->m;
+        m.require_gpu();
         ProfileSink sink;
         m.prof = &sink;
         batch_flush(b);
@@ -774,23 +777,33 @@ void pk_free(void *p) { free(p); }
 /* ---- host-side text ---------------------------------------------------------------------------------------- */
 int pk_vocab_size(const pk_model *m) { return m ? (int)m->m->tok.vocab_size() : 0; }
 
+// The text entry points return a count (>= 0) or -1; like every other entry point no C++ exception may cross the ABI, so the
+// bodies run under guard() and a failure (bad argument, std::bad_alloc) becomes -1 with pk_last_error() set.
 int pk_detokenize(const pk_model *m, const int32_t *ids, int n, char *out, int cap) {
-    if (!m || (!ids && n > 0) || n < 0) return -1;
-    std::vector<int> v(ids, ids + n);
-    const std::string s = m->m->tok.decode(v);
-    if (out && cap > 0) {
-        const int c = (int)s.size() < cap - 1 ? (int)s.size() : cap - 1;
-        memcpy(out, s.data(), c);
-        out[c] = 0;
-    }
-    return (int)s.size();
+    int ret = -1;
+    guard([&] {
+        need(m && n >= 0 && (ids || n == 0), "model/ids/n");
+        std::vector<int> v(ids, ids + n);
+        const std::string s = m->m->tok.decode(v);
+        if (out && cap > 0) {
+            const int c = (int)s.size() < cap - 1 ? (int)s.size() : cap - 1;
+            memcpy(out, s.data(), c);
+            out[c] = 0;
+        }
+        ret = (int)s.size();
+    });
+    return ret;
 }
 
 int pk_tokenize(const pk_model *m, const char *text, int32_t *ids, int cap) {
-    if (!m || !text) return -1;
-    const auto v = m->m->tok.encode(text);
-    for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
-    return (int)v.size();
+    int ret = -1;
+    guard([&] {
+        need(m && text && (ids || cap <= 0), "model/text/ids");
+        const auto v = m->m->tok.encode(text);
+        for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
+        ret = (int)v.size();
+    });
+    return ret;
 }
 
 pk_status pk_set_boost_tokens(pk_model *h, const int32_t *ids, const int32_t *offsets, int n_phrases, float boost_score) {
@@ -816,26 +829,30 @@ int pk_boost_trie_size(const pk_model *m) { return m && m->m->boost_on ? m->m->t
 
 int pk_group_timestamps(const pk_model *m, const int32_t *ids, const int32_t *start, const int32_t *end, const float *conf, int n,
                         int sentences, char *words, int cap, float *wstart, float *wend, float *wconf, int wcap) {
-    if (!m || n < 0) return -1;
-    std::vector<TimestampedToken> tt(n);
-    for (int i = 0; i < n; ++i) tt[i] = {ids[i], start[i], end[i], conf ? conf[i] : 1.0f};
-    const auto w = group_timestamps(tt, m->m->tok.pieces(), sentences != 0);
-    std::string joined;
-    for (size_t i = 0; i < w.size(); ++i) {
-        if (i) joined += '\n';
-        joined += w[i].word;
-        if ((int)i < wcap) {
-            if (wstart) wstart[i] = w[i].start;
-            if (wend) wend[i] = w[i].end;
-            if (wconf) wconf[i] = w[i].confidence;
+    int ret = -1;
+    guard([&] {
+        need(m && n >= 0 && (n == 0 || (ids && start && end)), "model/ids/start/end/n");
+        std::vector<TimestampedToken> tt(n);
+        for (int i = 0; i < n; ++i) tt[i] = {ids[i], start[i], end[i], conf ? conf[i] : 1.0f};
+        const auto w = group_timestamps(tt, m->m->tok.pieces(), sentences != 0);
+        std::string joined;
+        for (size_t i = 0; i < w.size(); ++i) {
+            if (i) joined += '\n';
+            joined += w[i].word;
+            if ((int)i < wcap) {
+                if (wstart) wstart[i] = w[i].start;
+                if (wend) wend[i] = w[i].end;
+                if (wconf) wconf[i] = w[i].confidence;
+            }
         }
-    }
-    if (words && cap > 0) {
-        const int c = (int)joined.size() < cap - 1 ? (int)joined.size() : cap - 1;
-        memcpy(words, joined.data(), c);
-        words[c] = 0;
-    }
-    return (int)w.size();
+        if (words && cap > 0) {
+            const int c = (int)joined.size() < cap - 1 ? (int)joined.size() : cap - 1;
+            memcpy(words, joined.data(), c);
+            words[c] = 0;
+        }
+        ret = (int)w.size();
+    });
+    return ret;
 }
 
 /* ---- diagnostics ---------------------------------------------------------------------------------- */

@@ -32,7 +32,15 @@ Model::Model(const void *weights, size_t n_bytes, const std::string &vocab_path,
 }
 
 void Model::validate_config() {
-    if (cfg.hidden_size <= 0 || cfg.num_heads <= 0 || cfg.hidden_size % cfg.num_heads) fail(PK_ERR_INVALID, "bad hidden_size / num_heads");
+    // every size that is later a divisor, a modulus or a vector length is checked for > 0 BEFORE any arithmetic on it
+    if (cfg.mel_bins <= 0 || cfg.subsampling_channels <= 0 || cfg.hidden_size <= 0 || cfg.num_heads <= 0 || cfg.num_layers < 0 ||
+        cfg.ffn_intermediate <= 0 || cfg.conv_kernel_size <= 0)
+        fail(PK_ERR_INVALID, "encoder sizes must be positive (mel_bins, subsampling_channels, hidden_size, num_heads, ffn_intermediate, conv_kernel_size; num_layers >= 0)");
+    if (cfg.vocab_size < 0 || cfg.ctc_vocab_size < 0) fail(PK_ERR_INVALID, "vocab_size / ctc_vocab_size must be >= 0");
+    if (cfg.vocab_size > 0 && (cfg.pred_hidden <= 0 || cfg.joint_hidden <= 0 || cfg.max_symbols_per_step <= 0 || cfg.blank_id < 0 || cfg.blank_id >= cfg.vocab_size))
+        fail(PK_ERR_INVALID, "decoder sizes must be positive (pred_hidden, joint_hidden, max_symbols_per_step) and 0 <= blank_id < vocab_size");
+    if (cfg.num_layers > 4096) fail(PK_ERR_INVALID, "num_layers out of range");
+    if (cfg.hidden_size % cfg.num_heads) fail(PK_ERR_INVALID, "bad hidden_size / num_heads");
     const int hd = cfg.hidden_size / cfg.num_heads;
     if (hd % 32) fail(PK_ERR_UNSUPPORTED, "head_dim must be a multiple of 32");
     if (cfg.hidden_size % 32 || cfg.ffn_intermediate % 32 || cfg.subsampling_channels % 32 || cfg.pred_hidden % 32 || cfg.joint_hidden % 32)
@@ -75,14 +83,21 @@ const float *Model::upload(const float *host, size_t n) {
     return d;
 }
 
-const HostTensor &Model::host_tensor(const std::string &name, int64_t want) {
+// Strict weight lookup: the tensor must exist, be F32, and have exactly the expected extents.  Extents of 1 are ignored on both
+// sides (a 1x1 conv weight [out][in][1][1] is the [out][in] matrix of the GEMM, a depthwise [C][1][k] is [C][k]); anything else
+// -- a transposed matrix with the same element count, a different rank, a negative extent -- is an error naming the tensor.
+const HostTensor &Model::host_tensor(const std::string &name, const std::vector<int64_t> &expect) {
     const HostTensor *t = st_->find(name);
     if (!t) fail(PK_ERR_WEIGHTS, "missing tensor '%s'", name.c_str());
     if (t->dtype != "F32") fail(PK_ERR_WEIGHTS, "tensor '%s' has dtype %s, expected F32", name.c_str(), t->dtype.c_str());
-    if (t->numel() != want) {
-        std::string got;
-        for (auto s : t->shape) got += std::to_string(s) + " ";
-        fail(PK_ERR_WEIGHTS, "tensor '%s' has shape [ %s], expected %lld elements", name.c_str(), got.c_str(), (long long)want);
+    std::vector<int64_t> a, b;
+    for (auto v : t->shape) if (v != 1) a.push_back(v);
+    for (auto v : expect) if (v != 1) b.push_back(v);
+    if (a != b) {
+        std::string got, want;
+        for (auto v : t->shape) got += std::to_string(v) + " ";
+        for (auto v : expect) want += std::to_string(v) + " ";
+        fail(PK_ERR_WEIGHTS, "tensor '%s' has shape [ %s], expected [ %s]", name.c_str(), got.c_str(), want.c_str());
     }
     return *t;
 }
@@ -107,13 +122,13 @@ const float *Model::upload_gemm_weight(const float *host, size_t n) {
 const float *Model::upload_gemm_tensor(const std::string &name, std::vector<int64_t> expect) {
     int64_t want = 1;
     for (auto e : expect) want *= e;
-    return upload_gemm_weight(host_tensor(name, want).f32(), (size_t)want);
+    return upload_gemm_weight(host_tensor(name, expect).f32(), (size_t)want);
 }
 
 const float *Model::upload_tensor(const std::string &name, std::vector<int64_t> expect) {
     int64_t want = 1;
     for (auto e : expect) want *= e;
-    return upload(host_tensor(name, want).f32(), (size_t)want);
+    return upload(host_tensor(name, expect).f32(), (size_t)want);
 }
 
 // Slaney filterbank, fp64 build / fp32 store -- reference src/audio.cpp:24-94 (hz_to_mel_slaney, mel_to_hz_slaney,
@@ -199,8 +214,8 @@ void Model::upload_weights() {
     const int H = cfg.num_heads, hd = d / H;
     int f3 = F;
     for (int i = 0; i < 3; ++i) f3 = (f3 - 1) / 2 + 1;
-    auto taps_last = [&](const std::string &name, int ch, int taps) {   // [ch][1][taps...] -> [taps][ch]
-        const HostTensor &t = host_tensor(name, (int64_t)ch * taps);
+    auto taps_last = [&](const std::string &name, int ch, int taps, bool two_d) {   // [ch][1][3][3] / [ch][1][taps] -> [taps][ch]
+        const HostTensor &t = host_tensor(name, two_d ? std::vector<int64_t>{ch, 3, 3} : std::vector<int64_t>{ch, taps});
         std::vector<float> w((size_t)ch * taps);
         for (int c = 0; c < ch; ++c)
             for (int k = 0; k < taps; ++k) w[(size_t)k * ch + c] = t.f32()[(size_t)c * taps + k];
@@ -208,10 +223,10 @@ void Model::upload_weights() {
     };
     const std::string ep = cfg.encoder_prefix[0] ? std::string(cfg.encoder_prefix) : std::string("encoder_.");
     const std::string sp = ep + "subsampling_.";
-    sub.c1w = taps_last(sp + "conv1_.weight", C, 9);  sub.c1b = upload_tensor(sp + "conv1_.bias", {C});
-    sub.d1w = taps_last(sp + "dw1_.weight", C, 9);    sub.d1b = upload_tensor(sp + "dw1_.bias", {C});
+    sub.c1w = taps_last(sp + "conv1_.weight", C, 9, true);  sub.c1b = upload_tensor(sp + "conv1_.bias", {C});
+    sub.d1w = taps_last(sp + "dw1_.weight", C, 9, true);    sub.d1b = upload_tensor(sp + "dw1_.bias", {C});
     sub.c2w = upload_gemm_tensor(sp + "conv2_.weight", {C, C}); sub.c2b = upload_tensor(sp + "conv2_.bias", {C});
-    sub.d2w = taps_last(sp + "dw2_.weight", C, 9);    sub.d2b = upload_tensor(sp + "dw2_.bias", {C});
+    sub.d2w = taps_last(sp + "dw2_.weight", C, 9, true);    sub.d2b = upload_tensor(sp + "dw2_.bias", {C});
     sub.c3w = upload_gemm_tensor(sp + "conv3_.weight", {C, C}); sub.c3b = upload_tensor(sp + "conv3_.bias", {C});
     sub.pw = upload_gemm_tensor(sp + "proj_.weight", {d, (int64_t)C * f3}); sub.pb = upload_tensor(sp + "proj_.bias", {d});
 
@@ -230,8 +245,8 @@ void Model::upload_weights() {
             std::vector<float> w((size_t)3 * d * d), b((size_t)3 * d);
             const char *nm[3] = {"q_proj", "k_proj", "v_proj"};
             for (int j = 0; j < 3; ++j) {
-                const HostTensor &tw = host_tensor(q + "attn_.mha_." + nm[j] + ".weight", (int64_t)d * d);
-                const HostTensor &tb = host_tensor(q + "attn_.mha_." + nm[j] + ".bias", d);
+                const HostTensor &tw = host_tensor(q + "attn_.mha_." + nm[j] + ".weight", {d, d});
+                const HostTensor &tb = host_tensor(q + "attn_.mha_." + nm[j] + ".bias", {d});
                 memcpy(w.data() + (size_t)j * d * d, tw.f32(), (size_t)d * d * 4);
                 memcpy(b.data() + (size_t)j * d, tb.f32(), (size_t)d * 4);
             }
@@ -243,11 +258,11 @@ void Model::upload_weights() {
         L.pos_u = upload_tensor(q + "attn_.pos_bias_u_", {H, hd}); L.pos_v = upload_tensor(q + "attn_.pos_bias_v_", {H, hd});
         L.cv_ng = upload_tensor(q + "conv_.norm_.weight", {d}); L.cv_nb = upload_tensor(q + "conv_.norm_.bias", {d});
         L.pw1_w = upload_gemm_tensor(q + "conv_.pointwise_conv1_.weight", {2 * d, d}); L.pw1_b = upload_tensor(q + "conv_.pointwise_conv1_.bias", {2 * d});
-        L.dw_w = taps_last(q + "conv_.depthwise_conv_.weight", d, K); L.dw_b = upload_tensor(q + "conv_.depthwise_conv_.bias", {d});
+        L.dw_w = taps_last(q + "conv_.depthwise_conv_.weight", d, K, false); L.dw_b = upload_tensor(q + "conv_.depthwise_conv_.bias", {d});
         L.bn_g = upload_tensor(q + "conv_.batch_norm_.weight", {d}); L.bn_b = upload_tensor(q + "conv_.batch_norm_.bias", {d});
         L.bn_mean = upload_tensor(q + "conv_.batch_norm_.running_mean", {d});
         {
-            const HostTensor &tv = host_tensor(q + "conv_.batch_norm_.running_var", d);
+            const HostTensor &tv = host_tensor(q + "conv_.batch_norm_.running_var", {d});
             std::vector<float> r(d);
             for (int c = 0; c < d; ++c) r[c] = 1.0f / sqrtf(tv.f32()[c] + 1e-5f);   // BatchNorm1d default eps (switch A3)
             L.bn_rstd = upload(r.data(), r.size());
@@ -282,22 +297,22 @@ void Model::upload_weights() {
         dec.wih[l] = upload_tensor(q + "input_proj_.weight", {4 * Hp, Hp});
         dec.bih[l] = upload_tensor(q + "input_proj_.bias", {4 * Hp});       // = b_ih + b_hh (convert_nemo.py:409-417)
         dec.whh[l] = upload_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp});
-        dec_whh_s[l] = upload_sigma(host_tensor(q + "hidden_proj_.weight", (int64_t)4 * Hp * Hp).f32(), 4 * Hp, Hp);
-        dec_wih_s[l] = l ? upload_sigma(host_tensor(q + "input_proj_.weight", (int64_t)4 * Hp * Hp).f32(), 4 * Hp, Hp) : nullptr;
+        dec_whh_s[l] = upload_sigma(host_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp}).f32(), 4 * Hp, Hp);
+        dec_wih_s[l] = l ? upload_sigma(host_tensor(q + "input_proj_.weight", {4 * Hp, Hp}).f32(), 4 * Hp, Hp) : nullptr;
     }
     const std::string jp = cfg.joint_prefix;
     dec.we = upload_gemm_tensor(jp + "enc_proj_.weight", {J, d}); dec.be = upload_tensor(jp + "enc_proj_.bias", {J});
     dec.wp = upload_tensor(jp + "pred_proj_.weight", {J, Hp});
-    dec_wp_s = upload_sigma(host_tensor(jp + "pred_proj_.weight", (int64_t)J * Hp).f32(), J, Hp);
+    dec_wp_s = upload_sigma(host_tensor(jp + "pred_proj_.weight", {J, Hp}).f32(), J, Hp);
     dec.bp = (cfg.joint_pred_bias && st_->find(jp + "pred_proj_.bias")) ? upload_tensor(jp + "pred_proj_.bias", {J}) : nullptr;
     {
         std::vector<float> w((size_t)(V + D) * J), b((size_t)(V + D));
         const std::string ln = cfg.rnnt_head ? "out_proj_" : "label_proj_";
-        memcpy(w.data(), host_tensor(jp + ln + ".weight", (int64_t)V * J).f32(), (size_t)V * J * 4);
-        memcpy(b.data(), host_tensor(jp + ln + ".bias", V).f32(), (size_t)V * 4);
+        memcpy(w.data(), host_tensor(jp + ln + ".weight", {V, J}).f32(), (size_t)V * J * 4);
+        memcpy(b.data(), host_tensor(jp + ln + ".bias", {V}).f32(), (size_t)V * 4);
         if (D > 0) {
-            memcpy(w.data() + (size_t)V * J, host_tensor(jp + "duration_proj_.weight", (int64_t)D * J).f32(), (size_t)D * J * 4);
-            memcpy(b.data() + V, host_tensor(jp + "duration_proj_.bias", D).f32(), (size_t)D * 4);
+            memcpy(w.data() + (size_t)V * J, host_tensor(jp + "duration_proj_.weight", {D, J}).f32(), (size_t)D * J * 4);
+            memcpy(b.data() + V, host_tensor(jp + "duration_proj_.bias", {D}).f32(), (size_t)D * 4);
         }
         wld = upload(w.data(), w.size());
         bld = upload(b.data(), b.size());
@@ -333,9 +348,22 @@ void Model::to_gpu(int device) {
         PK_HIP(hipStreamCreateWithPriority(&stream_dec, hipStreamNonBlocking, hi));
     }
     PK_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_done), sizeof(int), hipHostMallocDefault));
-    device_ = device;
-    build_mel_tables();
-    upload_weights();
+    // The model counts as resident only when EVERY weight made it: a failed upload (missing / mis-shaped / non-F32 tensor, HIP
+    // out of memory) rolls everything back, so that a second to_gpu() reports the error again instead of returning PK_OK on a
+    // half-initialised model.
+    device_ = device;                       // dev_alloc / require_gpu inside the uploads need it
+    try {
+        build_mel_tables();
+        upload_weights();
+    } catch (...) {
+        for (void *q : allocs_) (void)hipFree(q);
+        allocs_.clear();
+        if (h_done) { (void)hipHostFree(h_done); h_done = nullptr; }
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (stream_dec) { (void)hipStreamDestroy(stream_dec); stream_dec = nullptr; }
+        device_ = -1;
+        throw;
+    }
 }
 
 // ---- profiling hooks ----------------------------------------------------------------------------------------

@@ -121,7 +121,7 @@ class Model {
     const float *upload_gemm_weight(const float *host, size_t n);                                   // fp32, or bf16 when cfg.gemm_bf16
     const float *upload_gemm_tensor(const std::string &name, std::vector<int64_t> expect_shape);
     void run_gemm(const char *name, const GemmArgs &g, int epi, hipStream_t s, bool fp32_weight = false);
-    const HostTensor &host_tensor(const std::string &name, int64_t expect_numel);
+    const HostTensor &host_tensor(const std::string &name, const std::vector<int64_t> &expect_shape);
     float *dev_alloc(size_t n_floats);
 
     friend class StreamBatch;

@@ -25,7 +25,8 @@ typedef float gp_f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef GP_EXP
 #define GP_EXP 0                    // micro-benchmark experiments only (tools/ubench): 1 = epilogue without global stores,
-#endif                              // 2 = epilogue without activation math, 4 = global loads three K tiles ahead
+#endif                              // 2 = epilogue without activation math; main loop without 8 = barrier, 16 = LDS stores,
+                                    // 32 = global loads, 64 = fragment reads, 128 = MFMAs
 #ifdef GP_CLOCKPROBE
 __device__ long long gp_clk[4];     // micro-benchmark builds only: shader / wall clock deltas of block 0
 __device__ long long *gp_trace;     // micro-benchmark builds only: [n_blocks][8] wall-clock stamps of wave 0 + hw id
@@ -34,8 +35,9 @@ __device__ long long *gp_trace;     // micro-benchmark builds only: [n_blocks][8
 #define GP_STAMP(i) do { } while (0)
 #endif
 
-template <int WGM, int WGN, int TM, int TN, int BK, int EPI>
+template <int WGM, int WGN, int TM, int TN, int BK, int EPI, int NBUF = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, int tiles_n, int n_tiles) {
+    static_assert(NBUF == 1 || NBUF == 2, "LDS staging buffers");
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
     constexpr int PITCH = BK + 4, BUF = (BM + BN) * PITCH, NSUB = BK / 8, C4R = BK / 4;   // C4R float4 chunks per tile row
@@ -103,25 +105,41 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     };
 
     float4 ra[A_CH], rw[W_CH];
-    auto gload = [&](int kt) {
+    auto gload_to = [&](int kt, float4 (&sa)[A_CH], float4 (&sw)[W_CH]) {
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
+        for (int i = 0; i < A_CH; ++i) sa[i] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
 #pragma unroll
-        for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const float4 *>(w_src[i] + kt * BK);
+        for (int i = 0; i < W_CH; ++i) sw[i] = *reinterpret_cast<const float4 *>(w_src[i] + kt * BK);
     };
-    auto lstore = [&](int buf) {
+    auto lstore_from = [&](int buf, float4 (&sa)[A_CH], float4 (&sw)[W_CH]) {
         float *base = smem + buf * BUF;
+        if constexpr ((GP_EXP & 4096) != 0) {                      // experiment: linear, conflict-free 16-byte stores (WRONG layout)
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4 *>(base + (tid + NT * i) * 4) = sa[i];
+#pragma unroll
+            for (int i = 0; i < W_CH; ++i) *reinterpret_cast<float4 *>(base + (tid + NT * (A_CH + i)) * 4) = sw[i];
+            return;
+        }
+        if constexpr ((GP_EXP & 256) != 0) {                       // experiment: 16-byte stores (WRONG layout, timing only)
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4 *>(base + a_dst[i] + 2 * ((tid + NT * i) % C4R)) = sa[i];
+#pragma unroll
+            for (int i = 0; i < W_CH; ++i) *reinterpret_cast<float4 *>(base + w_dst[i] + 2 * ((tid + NT * i) % C4R)) = sw[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-            *reinterpret_cast<float2 *>(base + a_dst[i]) = make_float2(ra[i].x, ra[i].z);             // k = 4c, 4c+2
-            *reinterpret_cast<float2 *>(base + a_dst[i] + BK / 2) = make_float2(ra[i].y, ra[i].w);    // k = 4c+1, 4c+3
+            *reinterpret_cast<float2 *>(base + a_dst[i]) = make_float2(sa[i].x, sa[i].z);             // k = 4c, 4c+2
+            *reinterpret_cast<float2 *>(base + a_dst[i] + BK / 2) = make_float2(sa[i].y, sa[i].w);    // k = 4c+1, 4c+3
         }
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) {
-            *reinterpret_cast<float2 *>(base + w_dst[i]) = make_float2(rw[i].x, rw[i].z);
-            *reinterpret_cast<float2 *>(base + w_dst[i] + BK / 2) = make_float2(rw[i].y, rw[i].w);
+            *reinterpret_cast<float2 *>(base + w_dst[i]) = make_float2(sw[i].x, sw[i].z);
+            *reinterpret_cast<float2 *>(base + w_dst[i] + BK / 2) = make_float2(sw[i].y, sw[i].w);
         }
     };
+    auto gload = [&](int kt) { gload_to(kt, ra, rw); };
+    auto lstore = [&](int buf) { lstore_from(buf, ra, rw); };
 
     gp_f32x16 acc[TM][TN];
     auto zero_acc = [&]() {
@@ -200,9 +218,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     // wave writes whole 256-512 B row segments instead of 32 x 128 B slivers, the residual arrives as float4 too.
     auto epilogue_wide = [&](int m0, int n0) {
         constexpr int CP = BN + 4;                                  // C tile pitch (rows stay 16-byte aligned)
-        static_assert((size_t)BM * CP <= 2 * (size_t)BUF, "C tile must fit in the staging buffers");
+        // the C tile goes through the staging buffers; when it does not fit (single-buffered variant) in NPASS row bands
+        constexpr size_t CAP = (size_t)NBUF * BUF;
+        constexpr int NPASS = ((size_t)BM * CP <= CAP) ? 1 : ((size_t)BM / 2 * CP <= CAP) ? 2 : ((size_t)BM / 4 * CP <= CAP) ? 4 : 8, PR = BM / NPASS;
+        static_assert((size_t)PR * CP <= (size_t)NBUF * BUF, "C tile band must fit in the staging buffers");
+        static_assert(PR % 32 == 0, "row bands are whole MFMA tiles");
         constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT, RSTEP = NT / C4;   // float4 chunks per output row / per thread; row stride
         static_assert((BM * C4) % NT == 0 && NT % C4 == 0, "output tile must split evenly over the threads");
+        static_assert(NPASS == 1 || PR % RSTEP == 0, "row bands must split evenly over the threads' row stride");
         // A thread owns the SAME 4 output columns in all of its NCH chunks (rows rl0, rl0 + RSTEP, ...).  Everything the epilogue
         // needs from global memory is requested FIRST -- bias once, the residual rows of all chunks -- so that the latency
         // (1-2 us while the co-resident workgroup streams its tiles) overlaps the LDS transposition instead of being paid once
@@ -229,34 +252,41 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
                 rs[q] = col_ok ? *reinterpret_cast<const float4 *>(g.resid + (int64_t)row * g.ldr + col0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
         }
-        __syncthreads();                                            // every wave is done reading its last fragments
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+        __syncthreads();                                            // every wave is done reading its last fragments / the previous band
         {
             const int lc = lane & 31, lr = 4 * (lane >> 5);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                const int rb = wm * WM + i * 32;                    // first tile row of this accumulator block
+                if (rb / PR != pass) continue;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        smem[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + lr) * CP + wn * WN + j * 32 + lc] = acc[i][j][r];
+                        smem[(rb - pass * PR + (r & 3) + 8 * (r >> 2) + lr) * CP + wn * WN + j * 32 + lc] = acc[i][j][r];
+            }
         }
         __syncthreads();
         GP_STAMP(5);
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
+            if ((q * RSTEP) / PR != pass) continue;
             const int rl = rl0 + q * RSTEP;
             const int row = m0 + rl;
+            const int rs_ = rl - pass * PR;                        // row inside the LDS band
             float v[4], gt[4];
             if (sig) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = smem[rl * CP + blk + 4 * e + sa];
+                for (int e = 0; e < 4; ++e) v[e] = smem[rs_ * CP + blk + 4 * e + sa];
             } else {
                 int vc = 4 * c4;                                    // virtual column of the value inside the C tile
                 if constexpr (EPI == EPI_GLU) vc = (vc / (WN / 2)) * WN + vc % (WN / 2);
-                const float4 x = *reinterpret_cast<const float4 *>(smem + rl * CP + vc);
+                const float4 x = *reinterpret_cast<const float4 *>(smem + rs_ * CP + vc);
                 v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
                 if constexpr (EPI == EPI_GLU) {
-                    const float4 y = *reinterpret_cast<const float4 *>(smem + rl * CP + vc + WN / 2);
+                    const float4 y = *reinterpret_cast<const float4 *>(smem + rs_ * CP + vc + WN / 2);
                     gt[0] = y.x; gt[1] = y.y; gt[2] = y.z; gt[3] = y.w;
                 }
             }
@@ -282,6 +312,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             }
             if ((GP_EXP & 1) ? (row < 0) : (row < g.M && col_ok)) *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
         }
+        }
     };
     const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);
     auto epilogue = [&](int m0, int n0) {
@@ -304,19 +335,116 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     fragload(0, 0, 0);
     int cur = 0;
     zero_acc();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    // (GP_EXP bits 8..128 switch main-loop components off in micro-benchmark builds: results are wrong, only the time is read;
+    //  512 = LDS stores after the third sub-step's MFMAs, 1024 = global loads two K tiles ahead in a second register set,
+    //  2048 = staging stores / global loads issued one chunk at a time between the MFMAs)
+    // one staging chunk q of a K tile: q < A_CH -> A rows, else W rows
+    auto gload_one = [&](int kt, int q, float4 (&sa)[A_CH], float4 (&sw)[W_CH]) {
+        if (q < A_CH) sa[q] = *reinterpret_cast<const float4 *>(a_src[q] + kt * BK);
+        else sw[q - A_CH] = *reinterpret_cast<const float4 *>(w_src[q - A_CH] + kt * BK);
+    };
+    auto lstore_one = [&](int buf, int q, float4 (&sa)[A_CH], float4 (&sw)[W_CH]) {
+        float *base = smem + buf * BUF;
+        const float4 v = q < A_CH ? sa[q] : sw[q - A_CH];
+        const int d = q < A_CH ? a_dst[q] : w_dst[q - A_CH];
+        *reinterpret_cast<float2 *>(base + d) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2 *>(base + d + BK / 2) = make_float2(v.y, v.w);
+    };
+    // the MFMAs [lo, hi) of a sub-step, in the same (e, i, j) order as mma()
+    auto mma_range = [&](int slot, int lo, int hi) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int idx = (e * TM + i) * TN + j;
+                    if (idx < lo || idx >= hi) continue;
+                    const float a = e == 0 ? fa[slot][i].x : e == 1 ? fa[slot][i].y : e == 2 ? fa[slot][i].z : fa[slot][i].w;
+                    const float b = e == 0 ? fb[slot][j].x : e == 1 ? fb[slot][j].y : e == 2 ? fb[slot][j].z : fb[slot][j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                }
+    };
+    constexpr int NMMA = 4 * TM * TN, NCH_ST = A_CH + W_CH;
+    auto iter = [&](int kt, float4 (&sa)[A_CH], float4 (&sw)[W_CH], int ahead) {
+        const bool more1 = kt + 1 < nk, moreA = kt + ahead < nk;
 #pragma unroll
         for (int s = 0; s < NSUB - 1; ++s) {
-            fragload(cur, s + 1, (s + 1) & 1);
-            if (s == NSUB - 2 && more1) lstore(cur ^ 1);
-            GP_SB(); mma(s & 1); GP_SB();
+            if (!(GP_EXP & 64)) fragload(cur, s + 1, (s + 1) & 1);
+            if constexpr ((GP_EXP & 2048) != 0) {                  // staging stores spread over the sub-step's MFMAs, one chunk at a time
+                if (s == NSUB - 2 && more1) {
+#pragma unroll
+                    for (int q = 0; q < NCH_ST; ++q) {
+                        lstore_one(cur ^ 1, q, sa, sw);
+                        GP_SB(); mma_range(s & 1, q * NMMA / NCH_ST, (q + 1) * NMMA / NCH_ST); GP_SB();
+                    }
+                } else {
+                    GP_SB(); mma(s & 1); GP_SB();
+                }
+            } else {
+                if (!(GP_EXP & (16 | 8192)) && !(GP_EXP & 512) && s == NSUB - 2 && more1) lstore_from(cur ^ 1, sa, sw);
+                GP_SB(); if (!(GP_EXP & 128)) mma(s & 1); GP_SB();
+                if (!(GP_EXP & 16) && (GP_EXP & 512) && s == NSUB - 2 && more1) lstore_from(cur ^ 1, sa, sw);
+            }
         }
-        __syncthreads();
-        if (more1) fragload(cur ^ 1, 0, 0);
-        if (more2) gload(kt + 2);
-        GP_SB(); mma((NSUB - 1) & 1); GP_SB();
+        if constexpr ((GP_EXP & 8192) != 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's direct-to-LDS loads landed
+        if (!(GP_EXP & 8)) __syncthreads();
+        if (!(GP_EXP & 64) && more1) fragload(cur ^ 1, 0, 0);
+        if constexpr ((GP_EXP & 8192) != 0) {                      // experiment: K tile kt+2 straight from global memory into the LDS buffer
+            if (moreA) {                                           // that was just released (linear layout: WRONG for the fragment reads)
+                const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+                for (int q = 0; q < NCH_ST; ++q) {
+                    const float *src = (q < A_CH ? a_src[q] : w_src[q - A_CH]) + (kt + ahead) * BK;
+                    float *dst = smem + cur * BUF + (wv * 64 + NT * q) * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                }
+            }
+            GP_SB(); mma((NSUB - 1) & 1); GP_SB();
+        } else if constexpr ((GP_EXP & 2048) != 0) {                      // ... and the global loads over the last sub-step's MFMAs
+            if (moreA) {
+#pragma unroll
+                for (int q = 0; q < NCH_ST; ++q) {
+                    gload_one(kt + ahead, q, sa, sw);
+                    GP_SB(); mma_range((NSUB - 1) & 1, q * NMMA / NCH_ST, (q + 1) * NMMA / NCH_ST); GP_SB();
+                }
+            } else {
+                GP_SB(); mma((NSUB - 1) & 1); GP_SB();
+            }
+        } else {
+            if (!(GP_EXP & 32) && moreA) gload_to(kt + ahead, sa, sw);
+            GP_SB(); if (!(GP_EXP & 128)) mma((NSUB - 1) & 1); GP_SB();
+        }
         cur ^= 1;
+    };
+    if constexpr (NBUF == 1) {
+        // Single staging buffer (half the LDS: twice the resident workgroups, so a workgroup's prologue / epilogue / barriers are
+        // covered by its neighbours' MFMAs).  Two barriers per K tile: one when every wave has its last fragments in registers
+        // (the buffer may be overwritten), one when the next tile is stored; the last sub-step's MFMAs run between them.
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+#pragma unroll
+            for (int s = 0; s < NSUB - 1; ++s) {
+                fragload(0, s + 1, (s + 1) & 1);
+                GP_SB(); mma(s & 1); GP_SB();
+            }
+            __syncthreads();
+            if (more1) lstore(0);
+            if (more2) gload(kt + 2);
+            GP_SB(); mma((NSUB - 1) & 1); GP_SB();
+            __syncthreads();
+            if (more1) fragload(0, 0, 0);
+        }
+    } else if constexpr ((GP_EXP & 1024) != 0) {
+        float4 ra2[A_CH], rw2[W_CH];
+        if (nk > 2) gload_to(2, ra2, rw2);
+        for (int kt = 0; kt < nk; kt += 2) {
+            iter(kt, ra, rw, 3);
+            if (kt + 1 < nk) iter(kt + 1, ra2, rw2, 3);
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) iter(kt, ra, rw, 2);
     }
     GP_STAMP(2);
     epilogue(m0, n0);
@@ -334,14 +462,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
 #endif
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, int EPI>
+template <int WGM, int WGN, int TM, int TN, int BK, int EPI, int NBUF = 2>
 static void launch_gemm_pipe(const GemmArgs &a, hipStream_t s) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
     const int n_tiles = tiles_m * tiles_n;
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = &gemm_pipe_kernel<WGM, WGN, TM, TN, BK, EPI>;
+    constexpr size_t lds = NBUF * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    auto kern = &gemm_pipe_kernel<WGM, WGN, TM, TN, BK, EPI, NBUF>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

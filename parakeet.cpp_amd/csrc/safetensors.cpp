@@ -30,7 +30,9 @@ struct Json {  // just enough JSON for the header: objects, arrays, strings, int
                 switch (*p) {
                 case 'n': s += '\n'; break;
                 case 't': s += '\t'; break;
-                case 'u': s += '?'; p += 4; break;
+                case 'u':
+                    if (end - p < 5) fail(PK_ERR_WEIGHTS, "safetensors header: truncated \\u escape");
+                    s += '?'; p += 4; break;
                 default: s += *p;
                 }
                 ++p;
@@ -48,10 +50,15 @@ struct Json {  // just enough JSON for the header: objects, arrays, strings, int
         if (p < end && *p == '-') { neg = true; ++p; }
         if (p >= end || *p < '0' || *p > '9') fail(PK_ERR_WEIGHTS, "safetensors header: expected integer");
         int64_t v = 0;
-        while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+        int digits = 0;
+        while (p < end && *p >= '0' && *p <= '9') {
+            if (++digits > 18) fail(PK_ERR_WEIGHTS, "safetensors header: integer too long");
+            v = v * 10 + (*p++ - '0');
+        }
         return neg ? -v : v;
     }
-    void skip() {  // skip any value
+    void skip(int depth = 0) {  // skip any value
+        if (depth > 64) fail(PK_ERR_WEIGHTS, "safetensors header: nesting too deep");
         ws();
         if (p >= end) return;
         if (*p == '"') { (void)str(); return; }
@@ -61,7 +68,7 @@ struct Json {  // just enough JSON for the header: objects, arrays, strings, int
             if (eat(close)) return;
             do {
                 if (open == '{') { (void)str(); need(':'); }
-                skip();
+                skip(depth + 1);
             } while (eat(','));
             need(close);
             return;
@@ -114,7 +121,14 @@ void SafeTensors::parse(const uint8_t *base, size_t len) {
                     t.dtype = j.str();
                 } else if (key == "shape") {
                     j.need('[');
-                    if (!j.eat(']')) { do t.shape.push_back(j.integer()); while (j.eat(',')); j.need(']'); }
+                    if (!j.eat(']')) {
+                        do {
+                            const int64_t dim = j.integer();
+                            if (dim < 0) fail(PK_ERR_WEIGHTS, "safetensors: negative extent in the shape of %s", name.c_str());
+                            t.shape.push_back(dim);
+                        } while (j.eat(','));
+                        j.need(']');
+                    }
                 } else if (key == "data_offsets") {
                     j.need('[');
                     off0 = j.integer();
@@ -129,7 +143,19 @@ void SafeTensors::parse(const uint8_t *base, size_t len) {
             if (off0 < 0 || off1 < off0 || (size_t)off1 > payload_len) fail(PK_ERR_WEIGHTS, "safetensors: bad offsets for %s", name.c_str());
             t.data = payload + off0;
             t.nbytes = (size_t)(off1 - off0);
-            if (t.dtype == "F32" && (size_t)t.numel() * 4 != t.nbytes) fail(PK_ERR_WEIGHTS, "safetensors: %s size/shape mismatch", name.c_str());
+            {   // element count without overflow: no tensor can hold more elements than the payload has bytes
+                uint64_t prod = 1;
+                for (auto dim : t.shape) {
+                    if (dim != 0 && prod > (uint64_t)payload_len / (uint64_t)dim) fail(PK_ERR_WEIGHTS, "safetensors: shape of %s exceeds the file", name.c_str());
+                    prod *= (uint64_t)dim;
+                }
+            }
+            {   // size / shape consistency for every dtype with a known element size (unknown dtypes are never read)
+                static const struct { const char *n; size_t b; } sizes[] = {{"F64", 8}, {"F32", 4}, {"F16", 2}, {"BF16", 2}, {"I64", 8}, {"I32", 4}, {"I16", 2},
+                                                                          {"I8", 1}, {"U8", 1}, {"BOOL", 1}, {"U16", 2}, {"U32", 4}, {"U64", 8}, {"F8_E4M3", 1}, {"F8_E5M2", 1}};
+                for (const auto &e : sizes)
+                    if (t.dtype == e.n && (size_t)t.numel() * e.b != t.nbytes) fail(PK_ERR_WEIGHTS, "safetensors: %s size/shape mismatch", name.c_str());
+            }
             tensors_.emplace(name, std::move(t));
         } while (j.eat(','));
         j.need('}');

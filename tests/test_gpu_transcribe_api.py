@@ -120,3 +120,28 @@ def test_strict_weights_at_upload(tmp_path):
         synth.save_weights(p, d)
         with pytest.raises(RuntimeError, match="pointwise_conv2_"):
             capi.Model(p, cfg, device=0)
+    # a TRANSPOSED matrix has the right element count and the wrong extents: refused by name (fc1 [ffn][d] vs fc2 [d][ffn])
+    fc1 = "encoder_.layers_.0.ffn1_.fc1_.weight"
+    d = dict(W)
+    d[fc1] = np.ascontiguousarray(W[fc1].T)
+    p = str(tmp_path / "transposed.safetensors")
+    synth.save_weights(p, d)
+    with pytest.raises(RuntimeError, match="fc1_.weight"):
+        capi.Model(p, cfg, device=0)
+
+
+def test_failed_to_gpu_is_not_sticky(tmp_path):
+    """A failed upload must not leave the model marked resident: the second to_gpu() reports the same error again (it used to return
+    PK_OK on a half-initialised model) and compute entry points keep answering PK_ERR_NO_DEVICE."""
+    cfg = G.tiny(name="tiny-sticky")
+    W = synth.synth_weights(cfg, seed=42)
+    W.pop("encoder_.layers_.1.ffn2_.fc2_.bias")
+    p = str(tmp_path / "broken.safetensors")
+    synth.save_weights(p, W)
+    m = capi.Model(p, cfg)                                # host-side load succeeds: tensors are checked when they are uploaded
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="fc2_.bias"):
+            m.to_gpu(0)
+    with pytest.raises(RuntimeError, match="not on a GPU"):
+        m.mel(synth.synth_pcm(1, 16000, seed=1))
+    m.close()

@@ -59,7 +59,8 @@ def test_wrong_shape_dtype_and_missing_tensor(image, tmp_path):
     m = capi.Model(rebuild(h), cfg)                       # parses (same element count); the shape check happens at upload time on a GPU
     m.close()
     h = json.loads(json.dumps(hdr)); h[name]["dtype"] = "F16"
-    m = capi.Model(rebuild(h), cfg); m.close()            # dtype is checked when the tensor is uploaded (to_gpu): see the GPU tests
+    with pytest.raises(RuntimeError, match="size/shape"):  # the byte count no longer matches the element size of the declared dtype
+        capi.Model(rebuild(h), cfg)
     h = json.loads(json.dumps(hdr)); h[name]["data_offsets"] = [0, 10 ** 12]
     with pytest.raises(RuntimeError, match="offsets"):
         capi.Model(rebuild(h), cfg)
@@ -74,3 +75,53 @@ def test_unreadable_vocab(image, tmp_path):
     img.tofile(p)
     with pytest.raises(RuntimeError, match="vocab"):
         capi.Model(p, cfg, vocab_path=str(tmp_path / "nope.txt"))
+
+
+def test_hostile_headers_are_refused_not_crashed(image):
+    """Stack-deep __metadata__ nesting, an integer with hundreds of digits, a \\u escape cut off by the end of the header, negative
+    and overflowing extents: all answered with an error."""
+    cfg, img = image
+    hlen = struct.unpack("<Q", img[:8].tobytes())[0]
+    hdr = img[8:8 + hlen].tobytes().decode()
+    body = img[8 + hlen:].tobytes()
+
+    def with_header(text):
+        hb = text.encode()
+        return np.frombuffer(struct.pack("<Q", len(hb)) + hb + body, np.uint8)
+
+    deep = '{"__metadata__":' + "[" * 200000 + "]" * 200000 + "," + hdr[1:]
+    with pytest.raises(RuntimeError, match="nesting"):
+        capi.Model(with_header(deep), cfg)
+    name = "encoder_.layers_.0.ffn1_.fc1_.weight"
+    h = json.loads(hdr)
+    long_int = json.dumps(h).replace('"shape": [256, 128]', '"shape": [' + "9" * 400 + ", 128]", 1)
+    assert "9" * 400 in long_int
+    with pytest.raises(RuntimeError, match="integer too long"):
+        capi.Model(with_header(long_int), cfg)
+    with pytest.raises(RuntimeError):
+        capi.Model(with_header('{"a\\u12'), cfg)
+    h2 = json.loads(hdr); h2[name]["shape"] = [-256, -128]
+    with pytest.raises(RuntimeError, match="negative"):
+        capi.Model(with_header(json.dumps(h2)), cfg)
+    h3 = json.loads(hdr); h3[name]["shape"] = [2 ** 40, 2 ** 40]
+    with pytest.raises(RuntimeError, match="exceeds"):
+        capi.Model(with_header(json.dumps(h3)), cfg)
+
+
+def test_config_bounds_are_checked_before_use(image):
+    """Non-positive sizes used to reach a modulo / a vector resize (SIGFPE, bad_alloc); now PK_ERR_INVALID."""
+    import dataclasses
+    cfg, img = image
+    for field, val in (("subsampling_channels", 0), ("mel_bins", 0), ("num_layers", -3), ("ffn_intermediate", 0), ("vocab_size", -5),
+                       ("max_symbols_per_step", 0), ("hidden_size", 0), ("num_heads", 0)):
+        with pytest.raises(RuntimeError):
+            capi.Model(img, dataclasses.replace(cfg, **{field: val}))
+
+
+def test_text_entry_points_refuse_null_arguments():
+    import ctypes as C
+    L = capi.lib()
+    assert L.pk_detokenize(None, None, 0, None, 0) == -1
+    assert L.pk_tokenize(None, b"x", None, 0) == -1
+    L.pk_group_timestamps.restype = C.c_int
+    assert L.pk_group_timestamps(None, None, None, None, None, 0, 0, None, 0, None, None, None, 0) == -1

@@ -62,6 +62,16 @@ static void run_pipe(const GemmArgs &a, int epi, hipStream_t s) {
     case EPI_GLU: if constexpr (TN % 2 == 0) launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_GLU>(a, s); break;
     }
 }
+template <int WGM, int WGN, int TM, int TN, int BK>
+static void run_sb(const GemmArgs &a, int epi, hipStream_t s) {       // single LDS staging buffer
+    switch (epi) {
+    case EPI_NONE: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_NONE, 1>(a, s); break;
+    case EPI_RELU: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_RELU, 1>(a, s); break;
+    case EPI_SILU: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_SILU, 1>(a, s); break;
+    case EPI_RESID: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_RESID, 1>(a, s); break;
+    case EPI_GLU: if constexpr (TN % 2 == 0) launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_GLU, 1>(a, s); break;
+    }
+}
 template <int BM, int BN>
 static void run_old(const GemmArgs &a, int epi, hipStream_t s) {
     switch (epi) {
@@ -133,6 +143,14 @@ int main(int argc, char **argv) {
         {"pipe 128x128 w64x32 bk64 512t", run_pipe<2, 4, 2, 1, 64>},
         {"pipe 128x128 w32x64 bk64 512t", run_pipe<4, 2, 1, 2, 64>},
         {"pipe 128x128 w64x32 bk64 512t", run_pipe<2, 4, 2, 1, 64>},
+        {"sb   128x128 w64x64 bk32 256t 512t-class", run_sb<2, 2, 2, 2, 32>},
+        {"sb   64x128  w32x64 bk32 256t 512t-class", run_sb<2, 2, 1, 2, 32>},
+        {"sb   128x128 w32x64 bk32 512t", run_sb<4, 2, 1, 2, 32>},
+        {"sb   128x128 w64x32 bk32 512t", run_sb<2, 4, 2, 1, 32>},
+        {"sb   256x128 w64x64 bk32 512t", run_sb<4, 2, 2, 2, 32>},
+        {"sb   128x256 w64x64 bk32 512t", run_sb<2, 4, 2, 2, 32>},
+        {"sb   64x128  w32x32 bk32 512t", run_sb<2, 4, 1, 1, 32>},
+        {"sb   128x64  w32x32 bk32 512t", run_sb<4, 2, 1, 1, 32>},
         {"pipe 128x64  w32x32 bk32 512t", run_pipe<4, 2, 1, 1, 32>},
         {"pipe 64x128  w32x32 bk32 512t", run_pipe<2, 4, 1, 1, 32>},
     };
@@ -153,6 +171,11 @@ int main(int argc, char **argv) {
             CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
         };
         fill(dA, maxA, 1.0f); fill(dW, maxW, 0.05f); fill(dB, 16384, 0.1f); fill(dR, maxO, 1.0f);
+    }
+    {   // clocks ramp for tens of milliseconds after idle: 0.3 s of GEMMs before anything is timed
+        GemmArgs g{dA, 512, dW, 512, dB, dO, 2048, dR, 2048, 0.5f, 8064, 2048, 512};
+        for (int i = 0; i < 1500; ++i) run_pipe<4, 2, 1, 2, 32>(g, EPI_NONE, s);
+        CK(hipStreamSynchronize(s));
     }
     if (argc > 2 && strcmp(argv[2], "trace") == 0) {   // per-workgroup timeline of one launch -> gpurun_out/gemm_trace_<name>.bin
         struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; int nblk; };
@@ -177,6 +200,34 @@ int main(int argc, char **argv) {
             fwrite(h.data(), 8, h.size(), f);
             fclose(f);
             printf("wrote %s (%d blocks)\n", fn.c_str(), v.nblk);
+        }
+        return 0;
+    }
+    if (argc > 2 && strcmp(argv[2], "ml") == 0) {   // main-loop experiments (GP_EXP builds): production tiles, no epilogue math, two K
+        struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
+        const std::vector<KV> kv = {{"pipe 128x128 w32x64 512t", run_pipe<4, 2, 1, 2, 32>}, {"pipe 128x128 w64x64 256t", run_pipe<2, 2, 2, 2, 32>},
+                                    {"pipe 64x64 w32x32 256t", run_pipe<2, 2, 1, 1, 32>}, {"sb 128x128 w64x64 256t", run_sb<2, 2, 2, 2, 32>},
+                                    {"sb 64x128 w32x64 256t", run_sb<2, 2, 1, 2, 32>}, {"sb 128x128 w32x64 512t", run_sb<4, 2, 1, 2, 32>}};
+        for (int epi : {(int)EPI_NONE, (int)EPI_SILU, (int)EPI_RESID})
+        for (auto &v : kv) {
+            printf("ml GP_EXP=%d epi=%d %-28s:", GP_EXP, epi, v.name);
+            float t[2];
+            int i2 = 0;
+            for (int K : {512, 2048}) {
+                GemmArgs g{dA, K, dW, K, dB, dO, 2048, dR, 2048, 0.5f, 8064, 2048, K};
+                for (int i = 0; i < 2; ++i) v.run(g, epi, s);
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < reps; ++i) v.run(g, epi, s);
+                CK(hipEventRecord(e1, s));
+                CK(hipStreamSynchronize(s));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                t[i2++] = ms / reps * 1e3f;
+                printf("  K=%d %.1fus", K, ms / reps * 1e3);
+            }
+            const double slope = (t[1] - t[0]) / 1536.0;                      // us per k
+            printf("  | main loop %.1f TF, fixed %.1f us\n", 2.0 * 8064 * 2048 / slope * 1e-6, t[0] - slope * 512);
+            if (argc > 3 && epi != EPI_NONE) continue;
         }
         return 0;
     }
@@ -208,7 +259,7 @@ int main(int argc, char **argv) {
     const bool quick = argc > 3;                                    // gemm_sweep <reps> - quick : the two FFN shapes, 512-thread variants
     std::vector<unsigned> href, hout;
     for (auto &sh : shapes) {
-        if (quick && strncmp(sh.name, "fc", 2) != 0) continue;
+        if (quick && strncmp(sh.name, "B ", 2) == 0) continue;
         GemmArgs g{dA, sh.K, dW, sh.K, dB, dRef, sh.N, dR, sh.N, 0.5f, sh.M, sh.N, sh.K};
         const double flops = 2.0 * sh.M * (double)sh.N * sh.K * (sh.epi == EPI_GLU ? 2 : 1);
         const size_t no = (size_t)sh.M * sh.N;
@@ -221,7 +272,7 @@ int main(int argc, char **argv) {
         printf("== %s  %.2f GFLOP\n", sh.name, flops * 1e-9);
         for (auto &v : variants) {
             const bool is_old = strncmp(v.name, "old", 3) == 0;
-            if (quick && strstr(v.name, "512t") == nullptr && strstr(v.name, "128x64") == nullptr) continue;
+            if (quick && strstr(v.name, "512t") == nullptr) continue;
             if (sh.epi == EPI_GLU) {
                 if (is_old && strstr(v.name, "128x128") == nullptr) continue;
                 if (strstr(v.name, "w64x32") || strstr(v.name, "w32x32")) continue;   // TN odd
