@@ -195,6 +195,26 @@ typedef struct pk_result {      /* TranscribeResult (transcribe.hpp:23-30) + Tim
 pk_status pk_transcribe_pcm(pk_model *m, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt,
                             pk_result **results);
 void pk_results_free(pk_result *results, int n_clips);
+/* ---- one node, several GPUs: utterance shards (the reference has no multi-device path, README.md:513) ----------
+ * A pk_group is one model REPLICA per device of this process: the safetensors image is read once, sent to every device with one
+ * RCCL broadcast (xGMI) and each replica is built from its copy.  pk_group_transcribe_pcm partitions the clips into batches of
+ * equal-length clips (<= 64) and deals the batches round-robin to the devices (rank r takes batches r, r+G, ...: utterances share
+ * nothing, so there is NO collective on the data path); one host thread drives each device.  Afterwards the fixed-stride token
+ * matrix [clips_per_rank][2 + max_tokens] of every rank is all-gathered (ncclAllGather) and the wall times are max-reduced
+ * (ncclAllReduce); the token ids of the results are taken from the gathered matrix.  With one device the communicator has one
+ * rank and the same collectives run.  devices = NULL / n_devices <= 0: every visible device.
+ * Same result contract as pk_transcribe_pcm (which is what a group of one device computes, clip for clip). */
+typedef struct pk_group pk_group;
+pk_status pk_group_create(const char *safetensors_path, const char *vocab_path_or_null, const pk_config *cfg, const int *devices,
+                          int n_devices, pk_group **out);
+void pk_group_free(pk_group *g);
+int pk_group_size(const pk_group *g);
+pk_status pk_group_transcribe_pcm(pk_group *g, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt,
+                                  pk_result **results);
+/* figures of the last pk_group_transcribe_pcm: max-over-ranks wall time of the compute phase (the all-reduced value), total audio
+ * seconds, clips handled by each rank (clips_per_rank[pk_group_size]); any pointer may be NULL */
+pk_status pk_group_last_stats(const pk_group *g, double *wall_ms_max, double *audio_seconds, int32_t *clips_per_rank);
+
 /* read_audio (audio_io.cpp:453-483) restricted to RIFF/WAVE PCM16 / float32; mono-downmix; must be 16 kHz.
  * Returns a malloc'd buffer the caller frees with pk_free. */
 pk_status pk_read_wav(const char *path, float **pcm, int64_t *n_samples, int *sample_rate);

@@ -139,6 +139,11 @@ _LATE_SIGNATURES = {
     "pk_set_boost_phrases": [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_float],
     "pk_boost_trie_size": [C.c_void_p],
     "pk_group_timestamps": [C.c_void_p, i32p, i32p, i32p, f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, f32p, f32p, f32p, C.c_int],
+    "pk_group_create": [C.c_char_p, C.c_char_p, C.POINTER(PkConfig), i32p, C.c_int, C.POINTER(C.c_void_p)],
+    "pk_group_free": [C.c_void_p],
+    "pk_group_size": [C.c_void_p],
+    "pk_group_transcribe_pcm": [C.c_void_p, f32p, i64p, C.c_int, C.POINTER(PkOptions), C.POINTER(C.POINTER(PkResult))],
+    "pk_group_last_stats": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), i32p],
 }
 
 
@@ -481,6 +486,70 @@ class Batch:
 
 
 # ---- model -------------------------------------------------------------------------------------------
+def _transcribe(fn, handle, clips, decoder, timestamps, boost_phrases, boost_score):
+    clips = [_c(c).ravel() for c in clips]
+    off = np.zeros(len(clips) + 1, np.int64)
+    off[1:] = np.cumsum([len(c) for c in clips])
+    pcm = np.concatenate(clips)
+    opt = PkOptions()
+    opt.decoder = {"ctc": 0, "tdt": 1}[decoder]
+    opt.timestamps = 1 if timestamps else 0
+    keep = (C.c_char_p * max(1, len(boost_phrases)))(*[p.encode() for p in boost_phrases])
+    opt.boost_phrases = keep
+    opt.n_boost_phrases = len(boost_phrases)
+    opt.boost_score = boost_score
+    res = C.POINTER(PkResult)()
+    check(fn(handle, _f(pcm), off.ctypes.data_as(i64p), len(clips), C.byref(opt), C.byref(res)))
+    out = []
+    for i in range(len(clips)):
+        r = res[i]
+        d = dict(text=(r.text or b"").decode(), token_ids=[r.token_ids[k] for k in range(r.n_tokens)])
+        if timestamps:
+            d["start"] = [r.start_frame[k] for k in range(r.n_tokens)]
+            d["end"] = [r.end_frame[k] for k in range(r.n_tokens)]
+            d["conf"] = [r.confidence[k] for k in range(r.n_tokens)]
+            d["words"] = [(r.words[k].word.decode(), r.words[k].start, r.words[k].end, r.words[k].confidence) for k in range(r.n_words)]
+        out.append(d)
+    lib().pk_results_free(res, len(clips))
+    return out
+
+
+class Group:
+    """pk_group: one model replica per GPU of this process, utterance batches dealt round-robin, weights broadcast and results gathered
+    over RCCL (include/parakeet_amd.h, "one node, several GPUs")."""
+
+    def __init__(self, weights_path, cfg: ModelConfig, vocab_path: str = None, devices=None):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        pc = to_pk_config(cfg)
+        dev = np.ascontiguousarray(devices, np.int32) if devices is not None else None
+        check(lib().pk_group_create(weights_path.encode(), vocab_path.encode() if vocab_path else None, C.byref(pc),
+                                    _i(dev) if dev is not None else None, len(dev) if dev is not None else 0, C.byref(self._h)))
+
+    def size(self):
+        return lib().pk_group_size(self._h)
+
+    def transcribe_pcm(self, clips, decoder="tdt", timestamps=False, boost_phrases=(), boost_score=5.0):
+        return _transcribe(lib().pk_group_transcribe_pcm, self._h, clips, decoder, timestamps, boost_phrases, boost_score)
+
+    def last_stats(self):
+        wall, audio = C.c_double(0), C.c_double(0)
+        per = np.zeros(self.size(), np.int32)
+        check(lib().pk_group_last_stats(self._h, C.byref(wall), C.byref(audio), _i(per)))
+        return dict(wall_ms_max=wall.value, audio_seconds=audio.value, clips_per_rank=per.tolist())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pk_group_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Model:
     """Thin handle over pk_model (mirrors parakeet::Transcriber's ctor + to_gpu(), transcribe.hpp:59-71)."""
 
@@ -572,31 +641,7 @@ class Model:
 
     def transcribe_pcm(self, clips, decoder="tdt", timestamps=False, boost_phrases=(), boost_score=5.0):
         """pk_transcribe_pcm: Transcriber::transcribe (transcribe.hpp:91-180) on in-memory clips -> list of dicts."""
-        clips = [_c(c).ravel() for c in clips]
-        off = np.zeros(len(clips) + 1, np.int64)
-        off[1:] = np.cumsum([len(c) for c in clips])
-        pcm = np.concatenate(clips)
-        opt = PkOptions()
-        opt.decoder = {"ctc": 0, "tdt": 1}[decoder]
-        opt.timestamps = 1 if timestamps else 0
-        keep = (C.c_char_p * max(1, len(boost_phrases)))(*[p.encode() for p in boost_phrases])
-        opt.boost_phrases = keep
-        opt.n_boost_phrases = len(boost_phrases)
-        opt.boost_score = boost_score
-        res = C.POINTER(PkResult)()
-        check(lib().pk_transcribe_pcm(self._h, _f(pcm), off.ctypes.data_as(i64p), len(clips), C.byref(opt), C.byref(res)))
-        out = []
-        for i in range(len(clips)):
-            r = res[i]
-            d = dict(text=(r.text or b"").decode(), token_ids=[r.token_ids[k] for k in range(r.n_tokens)])
-            if timestamps:
-                d["start"] = [r.start_frame[k] for k in range(r.n_tokens)]
-                d["end"] = [r.end_frame[k] for k in range(r.n_tokens)]
-                d["conf"] = [r.confidence[k] for k in range(r.n_tokens)]
-                d["words"] = [(r.words[k].word.decode(), r.words[k].start, r.words[k].end, r.words[k].confidence) for k in range(r.n_words)]
-            out.append(d)
-        lib().pk_results_free(res, len(clips))
-        return out
+        return _transcribe(lib().pk_transcribe_pcm, self._h, clips, decoder, timestamps, boost_phrases, boost_score)
 
     def ctc_decode(self, enc, return_logp=False):
         enc = _c(enc)

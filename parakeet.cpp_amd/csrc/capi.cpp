@@ -1,8 +1,13 @@
 // parakeet.cpp_amd/csrc/capi.cpp -- the extern "C" boundary declared in include/parakeet_amd.h.
 // Every entry point translates pk::Error / std::exception into a status code + thread-local message.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <exception>
 #include <functional>
+#include <thread>
+
+#include <rccl/rccl.h>
 
 #include "engine.hpp"
 
@@ -586,98 +591,335 @@ struct ResultStore {          // owns everything a pk_result array points into
 };
 }  // namespace
 
+// Transcriber::transcribe (transcribe.hpp:99-179) of the clips listed in `clips` (global indices into offsets), results into the slots
+// of the same indices of R.  One model, one device; called by pk_transcribe_pcm (all clips) and by every rank of a pk_group.
+static void transcribe_clips(Model &m, const float *pcm, const int64_t *offsets, const std::vector<int> &clips, const pk_options *opt,
+                             ResultStore &R) {
+    m.require_gpu();
+    const int decoder = opt ? opt->decoder : PK_DECODER_TDT;
+    const bool ts = opt && opt->timestamps;
+    need(decoder == PK_DECODER_CTC || decoder == PK_DECODER_TDT, "options.decoder");
+    // per-call boost phrases (transcribe.hpp:110-115): the model-level setting comes back when the call ends
+    struct BoostScope {
+        Model &m; bool active = false; std::vector<std::vector<int>> saved; float saved_score = 0.0f;
+        ~BoostScope() { if (active) { try { m.set_boost(saved, saved_score); } catch (...) {} } }
+    } scope{m};
+    if (opt && opt->n_boost_phrases > 0) {
+        need(opt->boost_phrases != nullptr, "options.boost_phrases");
+        auto ph = encode_phrases(m, opt->boost_phrases, opt->n_boost_phrases);
+        scope.saved = m.boost_phrases; scope.saved_score = m.boost_score; scope.active = true;
+        m.set_boost(ph, opt->boost_score);
+    }
+    // group clips of equal length into batches (the reference has no padding semantics: no masks offline, encoder.cpp:163)
+    std::vector<int> order(clips);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offsets[a + 1] - offsets[a] < offsets[b + 1] - offsets[b]; });
+    const int n_clips = (int)order.size();
+    const int kMaxBatch = 64;
+    for (int g0 = 0; g0 < n_clips;) {
+        const int64_t len = offsets[order[g0] + 1] - offsets[order[g0]];
+        need(len > 256, "every clip needs more than 256 samples");
+        int g1 = g0;
+        while (g1 < n_clips && g1 - g0 < kMaxBatch && offsets[order[g1] + 1] - offsets[order[g1]] == len) ++g1;
+        const int B = g1 - g0;
+        Workspace &w = m.ws;
+        w.size_for(m.cfg, B, len, pk_mel_num_frames(len));
+        for (int i = 0; i < B; ++i)
+            PK_HIP(hipMemcpyAsync(w.pcm.as<float>() + (size_t)i * len, pcm + offsets[order[g0 + i]], (size_t)len * 4, hipMemcpyHostToDevice, m.stream));
+        m.run_mel(w.pcm.as<float>(), B, len, w.logmel.as<float>(), w.feats.as<float>(), m.stream);
+        m.run_encoder(w, w.feats.as<float>(), B, w.Tm, -1, 0, m.stream);
+        const int pitch = decoder == PK_DECODER_CTC ? w.T : w.max_tokens;
+        if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), B, w.T, false, m.stream);
+        else m.run_tdt(w, w.x.as<float>(), B, w.T, w.max_tokens, m.stream);
+        PK_CHECK_LAUNCH();
+        std::vector<int32_t> ids((size_t)B * pitch), st((size_t)B * pitch), en((size_t)B * pitch), lens(B);
+        std::vector<float> cf((size_t)B * pitch);
+        PK_HIP(hipStreamSynchronize(m.stream));
+        PK_HIP(hipMemcpy(lens.data(), w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(ids.data(), w.ids.p, ids.size() * 4, hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(st.data(), w.start.p, st.size() * 4, hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(en.data(), w.end.p, en.size() * 4, hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(cf.data(), w.conf.p, cf.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < B; ++i) {
+            const int c = order[g0 + i];
+            if (lens[i] < 0) fail(PK_ERR_DECODE_CAP, "TDT decode hit the safety cap on clip %d", c);
+            const int n = lens[i];
+            R.ids[c].assign(ids.begin() + (size_t)i * pitch, ids.begin() + (size_t)i * pitch + n);
+            std::vector<int> iv(R.ids[c].begin(), R.ids[c].end());
+            if (m.tok.loaded()) R.text[c] = m.tok.decode(iv);                    // transcribe.hpp:149,172
+            if (ts) {
+                R.start[c].assign(st.begin() + (size_t)i * pitch, st.begin() + (size_t)i * pitch + n);
+                R.end[c].assign(en.begin() + (size_t)i * pitch, en.begin() + (size_t)i * pitch + n);
+                R.conf[c].assign(cf.begin() + (size_t)i * pitch, cf.begin() + (size_t)i * pitch + n);
+                if (m.tok.loaded()) {                                            // group_timestamps, transcribe.hpp:150-152
+                    std::vector<TimestampedToken> tt(n);
+                    for (int k = 0; k < n; ++k) tt[k] = {R.ids[c][k], R.start[c][k], R.end[c][k], R.conf[c][k]};
+                    auto words = group_timestamps(tt, m.tok.pieces(), false);
+                    for (auto &wd : words) R.word_text[c].push_back(wd.word);
+                    for (size_t k = 0; k < words.size(); ++k)
+                        R.words[c].push_back({R.word_text[c][k].c_str(), words[k].start, words[k].end, words[k].confidence});
+                }
+            }
+        }
+        g0 = g1;
+    }
+}
+
+static std::unique_ptr<ResultStore> new_store(int n_clips) {
+    auto store = std::make_unique<ResultStore>();
+    ResultStore &R = *store;
+    R.res.resize(n_clips + 1);            // one hidden trailing slot keeps the store pointer
+    R.text.resize(n_clips); R.ids.resize(n_clips); R.start.resize(n_clips); R.end.resize(n_clips); R.conf.resize(n_clips);
+    R.word_text.resize(n_clips); R.words.resize(n_clips);
+    return store;
+}
+// hands the store over to the caller as a pk_result array (freed by pk_results_free)
+static pk_result *publish_store(std::unique_ptr<ResultStore> store, int n_clips, bool ts) {
+    ResultStore &R = *store;
+    for (int c = 0; c < n_clips; ++c) {
+        pk_result &r = R.res[c];
+        r.text = R.text[c].c_str();
+        r.n_tokens = (int32_t)R.ids[c].size();
+        r.token_ids = R.ids[c].data();
+        r.start_frame = ts ? R.start[c].data() : nullptr;
+        r.end_frame = ts ? R.end[c].data() : nullptr;
+        r.confidence = ts ? R.conf[c].data() : nullptr;
+        r.n_words = (int32_t)R.words[c].size();
+        r.words = R.words[c].data();
+    }
+    memset(&R.res[n_clips], 0, sizeof(pk_result));
+    R.res[n_clips].text = reinterpret_cast<const char *>(store.get());   // back-pointer for pk_results_free
+    pk_result *out = R.res.data();
+    store.release();
+    return out;
+}
+
 pk_status pk_transcribe_pcm(pk_model *h, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt,
                             pk_result **results) {
     return guard([&] {
         need(h && pcm && offsets && results && n_clips > 0, "model/pcm/offsets/results/n_clips");
-        Model &m = *h->m;
-        m.require_gpu();
-        const int decoder = opt ? opt->decoder : PK_DECODER_TDT;
-        const bool ts = opt && opt->timestamps;
-        need(decoder == PK_DECODER_CTC || decoder == PK_DECODER_TDT, "options.decoder");
-        // per-call boost phrases (transcribe.hpp:110-115): the model-level setting comes back when the call ends
-        struct BoostScope {
-            Model &m; bool active = false; std::vector<std::vector<int>> saved; float saved_score = 0.0f;
-            ~BoostScope() { if (active) { try { m.set_boost(saved, saved_score); } catch (...) {} } }
-        } scope{m};
-        if (opt && opt->n_boost_phrases > 0) {
-            need(opt->boost_phrases != nullptr, "options.boost_phrases");
-            auto ph = encode_phrases(m, opt->boost_phrases, opt->n_boost_phrases);
-            scope.saved = m.boost_phrases; scope.saved_score = m.boost_score; scope.active = true;
-            m.set_boost(ph, opt->boost_score);
+        auto store = new_store(n_clips);
+        std::vector<int> all(n_clips);
+        for (int i = 0; i < n_clips; ++i) all[i] = i;
+        transcribe_clips(*h->m, pcm, offsets, all, opt, *store);
+        *results = publish_store(std::move(store), n_clips, opt && opt->timestamps);
+    });
+}
+
+/* ---- one node, several GPUs ------------------------------------------------------------------------------------------------ */
+struct pk_group {
+    std::vector<int> devices;
+    std::vector<std::unique_ptr<Model>> models;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;          // one stream per device for the collectives
+    double wall_ms_max = 0.0, audio_s = 0.0;
+    std::vector<int32_t> clips_per_rank;
+    ~pk_group() {
+        for (size_t r = 0; r < devices.size(); ++r) {
+            (void)hipSetDevice(devices[r]);
+            if (r < streams.size() && streams[r]) (void)hipStreamDestroy(streams[r]);
         }
-        auto store = std::make_unique<ResultStore>();
-        ResultStore &R = *store;
-        R.res.resize(n_clips + 1);            // one hidden trailing slot keeps the store pointer
-        R.text.resize(n_clips); R.ids.resize(n_clips); R.start.resize(n_clips); R.end.resize(n_clips); R.conf.resize(n_clips);
-        R.word_text.resize(n_clips); R.words.resize(n_clips);
-        // group clips of equal length into batches (the reference has no padding semantics: no masks offline, encoder.cpp:163)
+        models.clear();
+        for (auto c : comms) if (c) (void)ncclCommDestroy(c);
+    }
+};
+#define PK_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) fail(PK_ERR_HIP, "RCCL: %s (%s)", ncclGetErrorString(r_), #call); } while (0)
+
+// runs fn(rank) on one host thread per device; the first exception of any rank is rethrown on the calling thread
+static void for_each_rank(int n, const std::function<void(int)> &fn) {
+    std::vector<std::exception_ptr> err(n);
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; ++r)
+        th.emplace_back([&, r] {
+            try { fn(r); } catch (...) { err[r] = std::current_exception(); }
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+pk_status pk_group_create(const char *weights, const char *vocab, const pk_config *cfg, const int *devices, int n_devices, pk_group **out) {
+    return guard([&] {
+        need(weights && cfg && out, "weights/cfg/out");
+        int visible = 0;
+        if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) fail(PK_ERR_NO_DEVICE, "no HIP device available (this engine has no CPU path)");
+        auto g = std::make_unique<pk_group>();
+        if (!devices || n_devices <= 0) {
+            for (int d = 0; d < visible; ++d) g->devices.push_back(d);
+        } else {
+            for (int i = 0; i < n_devices; ++i) {
+                need(devices[i] >= 0 && devices[i] < visible, "devices[i] out of range");
+                g->devices.push_back(devices[i]);
+            }
+        }
+        const int G = (int)g->devices.size();
+        // 1. ONE disk read: the safetensors image
+        std::vector<uint8_t> image;
+        {
+            FILE *f = fopen(weights, "rb");
+            if (!f) fail(PK_ERR_IO, "Cannot open weights file: %s", weights);
+            fseek(f, 0, SEEK_END);
+            const long len = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            if (len < 8) { fclose(f); fail(PK_ERR_WEIGHTS, "weights file %s is too short", weights); }
+            image.resize((size_t)len);
+            const size_t got = fread(image.data(), 1, image.size(), f);
+            fclose(f);
+            if (got != image.size()) fail(PK_ERR_IO, "short read on %s", weights);
+        }
+        // 2. communicators (single process, one rank per device) and the broadcast of the image over xGMI
+        g->comms.assign(G, nullptr);
+        PK_NCCL(ncclCommInitAll(g->comms.data(), G, g->devices.data()));
+        g->streams.assign(G, nullptr);
+        std::vector<void *> dimg(G, nullptr);
+        struct Guard { std::vector<void *> &p; std::vector<int> &dev; ~Guard() { for (size_t r = 0; r < p.size(); ++r) if (p[r]) { (void)hipSetDevice(dev[r]); (void)hipFree(p[r]); } } } free_imgs{dimg, g->devices};
+        for (int r = 0; r < G; ++r) {
+            PK_HIP(hipSetDevice(g->devices[r]));
+            PK_HIP(hipStreamCreateWithFlags(&g->streams[r], hipStreamNonBlocking));
+            PK_HIP(hipMalloc(&dimg[r], image.size()));
+        }
+        PK_HIP(hipSetDevice(g->devices[0]));
+        PK_HIP(hipMemcpyAsync(dimg[0], image.data(), image.size(), hipMemcpyHostToDevice, g->streams[0]));
+        PK_NCCL(ncclGroupStart());
+        for (int r = 0; r < G; ++r) {
+            PK_HIP(hipSetDevice(g->devices[r]));
+            PK_NCCL(ncclBroadcast(dimg[r], dimg[r], image.size(), ncclUint8, 0, g->comms[r], g->streams[r]));
+        }
+        PK_NCCL(ncclGroupEnd());
+        // 3. every rank builds its replica from ITS copy of the image (checked against the original) and uploads the weights
+        g->models.resize(G);
+        const std::string vp = vocab ? vocab : "";
+        for_each_rank(G, [&](int r) {
+            PK_HIP(hipSetDevice(g->devices[r]));
+            PK_HIP(hipStreamSynchronize(g->streams[r]));
+            std::vector<uint8_t> mine(image.size());
+            PK_HIP(hipMemcpy(mine.data(), dimg[r], mine.size(), hipMemcpyDeviceToHost));
+            if (memcmp(mine.data(), image.data(), mine.size()) != 0) fail(PK_ERR_WEIGHTS, "rank %d received a different weight image from the broadcast", r);
+            g->models[r] = std::make_unique<Model>(mine.data(), mine.size(), vp, *cfg);
+            g->models[r]->to_gpu(g->devices[r]);
+        });
+        g->clips_per_rank.assign(G, 0);
+        *out = g.release();
+    });
+}
+
+void pk_group_free(pk_group *g) { delete g; }
+int pk_group_size(const pk_group *g) { return g ? (int)g->devices.size() : 0; }
+
+pk_status pk_group_transcribe_pcm(pk_group *g, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt, pk_result **results) {
+    return guard([&] {
+        need(g && pcm && offsets && results && n_clips > 0, "group/pcm/offsets/results/n_clips");
+        const int G = (int)g->devices.size();
+        // partition: equal-length batches of <= 64 clips, dealt round-robin (rank r takes batches r, r+G, ...)
         std::vector<int> order(n_clips);
         for (int i = 0; i < n_clips; ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offsets[a + 1] - offsets[a] < offsets[b + 1] - offsets[b]; });
-        const int kMaxBatch = 64;
-        for (int g0 = 0; g0 < n_clips;) {
+        std::vector<std::vector<int>> shard(G);
+        int batch = 0;
+        double audio = 0.0;
+        for (int g0 = 0; g0 < n_clips; ++batch) {
             const int64_t len = offsets[order[g0] + 1] - offsets[order[g0]];
-            need(len > 256, "every clip needs more than 256 samples");
             int g1 = g0;
-            while (g1 < n_clips && g1 - g0 < kMaxBatch && offsets[order[g1] + 1] - offsets[order[g1]] == len) ++g1;
-            const int B = g1 - g0;
-            Workspace &w = m.ws;
-            w.size_for(m.cfg, B, len, pk_mel_num_frames(len));
-            for (int i = 0; i < B; ++i)
-                PK_HIP(hipMemcpyAsync(w.pcm.as<float>() + (size_t)i * len, pcm + offsets[order[g0 + i]], (size_t)len * 4, hipMemcpyHostToDevice, m.stream));
-            m.run_mel(w.pcm.as<float>(), B, len, w.logmel.as<float>(), w.feats.as<float>(), m.stream);
-            m.run_encoder(w, w.feats.as<float>(), B, w.Tm, -1, 0, m.stream);
-            const int pitch = decoder == PK_DECODER_CTC ? w.T : w.max_tokens;
-            if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), B, w.T, false, m.stream);
-            else m.run_tdt(w, w.x.as<float>(), B, w.T, w.max_tokens, m.stream);
-            PK_CHECK_LAUNCH();
-            std::vector<int32_t> ids((size_t)B * pitch), st((size_t)B * pitch), en((size_t)B * pitch), lens(B);
-            std::vector<float> cf((size_t)B * pitch);
-            PK_HIP(hipStreamSynchronize(m.stream));
-            PK_HIP(hipMemcpy(lens.data(), w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
-            PK_HIP(hipMemcpy(ids.data(), w.ids.p, ids.size() * 4, hipMemcpyDeviceToHost));
-            PK_HIP(hipMemcpy(st.data(), w.start.p, st.size() * 4, hipMemcpyDeviceToHost));
-            PK_HIP(hipMemcpy(en.data(), w.end.p, en.size() * 4, hipMemcpyDeviceToHost));
-            PK_HIP(hipMemcpy(cf.data(), w.conf.p, cf.size() * 4, hipMemcpyDeviceToHost));
-            for (int i = 0; i < B; ++i) {
-                const int c = order[g0 + i];
-                if (lens[i] < 0) fail(PK_ERR_DECODE_CAP, "TDT decode hit the safety cap on clip %d", c);
-                const int n = lens[i];
-                R.ids[c].assign(ids.begin() + (size_t)i * pitch, ids.begin() + (size_t)i * pitch + n);
-                std::vector<int> iv(R.ids[c].begin(), R.ids[c].end());
-                if (m.tok.loaded()) R.text[c] = m.tok.decode(iv);                    // transcribe.hpp:149,172
-                if (ts) {
-                    R.start[c].assign(st.begin() + (size_t)i * pitch, st.begin() + (size_t)i * pitch + n);
-                    R.end[c].assign(en.begin() + (size_t)i * pitch, en.begin() + (size_t)i * pitch + n);
-                    R.conf[c].assign(cf.begin() + (size_t)i * pitch, cf.begin() + (size_t)i * pitch + n);
-                    if (m.tok.loaded()) {                                            // group_timestamps, transcribe.hpp:150-152
-                        std::vector<TimestampedToken> tt(n);
-                        for (int k = 0; k < n; ++k) tt[k] = {R.ids[c][k], R.start[c][k], R.end[c][k], R.conf[c][k]};
-                        auto words = group_timestamps(tt, m.tok.pieces(), false);
-                        for (auto &wd : words) R.word_text[c].push_back(wd.word);
-                        for (size_t k = 0; k < words.size(); ++k)
-                            R.words[c].push_back({R.word_text[c][k].c_str(), words[k].start, words[k].end, words[k].confidence});
-                    }
-                }
-            }
+            while (g1 < n_clips && g1 - g0 < 64 && offsets[order[g1] + 1] - offsets[order[g1]] == len) ++g1;
+            for (int i = g0; i < g1; ++i) shard[batch % G].push_back(order[i]);
+            audio += (double)(g1 - g0) * (double)len / 16000.0;
             g0 = g1;
         }
-        for (int c = 0; c < n_clips; ++c) {
-            pk_result &r = R.res[c];
-            r.text = R.text[c].c_str();
-            r.n_tokens = (int32_t)R.ids[c].size();
-            r.token_ids = R.ids[c].data();
-            r.start_frame = ts ? R.start[c].data() : nullptr;
-            r.end_frame = ts ? R.end[c].data() : nullptr;
-            r.confidence = ts ? R.conf[c].data() : nullptr;
-            r.n_words = (int32_t)R.words[c].size();
-            r.words = R.words[c].data();
+        auto store = new_store(n_clips);
+        ResultStore &R = *store;
+        std::vector<double> wall_ms(G, 0.0);
+        for_each_rank(G, [&](int r) {                    // compute phase: no collective, ranks never wait for each other
+            if (shard[r].empty()) return;
+            const auto t0 = std::chrono::steady_clock::now();
+            transcribe_clips(*g->models[r], pcm, offsets, shard[r], opt, R);
+            wall_ms[r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
+        // result exchange over RCCL: max token count + max wall time (all-reduce), then the fixed-stride token matrix (all-gather)
+        int local_max = 0;
+        size_t cap = 0;
+        for (int r = 0; r < G; ++r) cap = std::max(cap, shard[r].size());
+        for (int c = 0; c < n_clips; ++c) local_max = std::max(local_max, (int)R.ids[c].size());
+        std::vector<std::vector<int>> rank_max(G, std::vector<int>(2, 0));
+        for (int r = 0; r < G; ++r) {
+            for (int c : shard[r]) rank_max[r][0] = std::max(rank_max[r][0], (int)R.ids[c].size());
+            rank_max[r][1] = (int)std::min(wall_ms[r] * 1000.0, 2.0e9);                    // microseconds
         }
-        memset(&R.res[n_clips], 0, sizeof(pk_result));
-        R.res[n_clips].text = reinterpret_cast<const char *>(store.get());   // back-pointer for pk_results_free
-        *results = R.res.data();
-        store.release();
+        std::vector<int *> dmax(G, nullptr);
+        std::vector<int32_t *> dmat(G, nullptr), dall(G, nullptr);
+        struct Guard {
+            std::vector<int *> &a; std::vector<int32_t *> &b, &c; std::vector<int> &dev;
+            ~Guard() { for (size_t r = 0; r < dev.size(); ++r) { (void)hipSetDevice(dev[r]); if (a[r]) (void)hipFree(a[r]); if (b[r]) (void)hipFree(b[r]); if (c[r]) (void)hipFree(c[r]); } }
+        } free_all{dmax, dmat, dall, g->devices};
+        for (int r = 0; r < G; ++r) {
+            PK_HIP(hipSetDevice(g->devices[r]));
+            PK_HIP(hipMalloc(reinterpret_cast<void **>(&dmax[r]), 2 * sizeof(int)));
+            PK_HIP(hipMemcpyAsync(dmax[r], rank_max[r].data(), 2 * sizeof(int), hipMemcpyHostToDevice, g->streams[r]));
+        }
+        PK_NCCL(ncclGroupStart());
+        for (int r = 0; r < G; ++r) {
+            PK_HIP(hipSetDevice(g->devices[r]));
+            PK_NCCL(ncclAllReduce(dmax[r], dmax[r], 2, ncclInt32, ncclMax, g->comms[r], g->streams[r]));
+        }
+        PK_NCCL(ncclGroupEnd());
+        int reduced[2] = {0, 0};
+        PK_HIP(hipSetDevice(g->devices[0]));
+        PK_HIP(hipMemcpyAsync(reduced, dmax[0], sizeof(reduced), hipMemcpyDeviceToHost, g->streams[0]));
+        PK_HIP(hipStreamSynchronize(g->streams[0]));
+        const int max_tok = reduced[0];
+        if (max_tok != local_max) fail(PK_ERR_HIP, "RCCL all-reduce(max) returned %d tokens, the ranks hold %d", max_tok, local_max);
+        const size_t stride = 2 + (size_t)max_tok, per_rank = std::max<size_t>(cap, 1) * stride;
+        std::vector<std::vector<int32_t>> hmat(G);
+        for (int r = 0; r < G; ++r) {                      // row = [global clip index, n_tokens, ids...] ; unused rows: index -1
+            hmat[r].assign(per_rank, 0);
+            for (size_t i = 0; i < std::max<size_t>(cap, 1); ++i) hmat[r][i * stride] = -1;
+            for (size_t i = 0; i < shard[r].size(); ++i) {
+                const int c = shard[r][i];
+                int32_t *row = hmat[r].data() + i * stride;
+                row[0] = c;
+                row[1] = (int32_t)R.ids[c].size();
+                std::copy(R.ids[c].begin(), R.ids[c].end(), row + 2);
+            }
+            PK_HIP(hipSetDevice(g->devices[r]));
+            PK_HIP(hipMalloc(reinterpret_cast<void **>(&dmat[r]), per_rank * 4));
+            PK_HIP(hipMalloc(reinterpret_cast<void **>(&dall[r]), per_rank * 4 * G));
+            PK_HIP(hipMemcpyAsync(dmat[r], hmat[r].data(), per_rank * 4, hipMemcpyHostToDevice, g->streams[r]));
+        }
+        PK_NCCL(ncclGroupStart());
+        for (int r = 0; r < G; ++r) {
+            PK_HIP(hipSetDevice(g->devices[r]));
+            PK_NCCL(ncclAllGather(dmat[r], dall[r], per_rank, ncclInt32, g->comms[r], g->streams[r]));
+        }
+        PK_NCCL(ncclGroupEnd());
+        std::vector<int32_t> all(per_rank * G);
+        PK_HIP(hipSetDevice(g->devices[0]));
+        PK_HIP(hipMemcpyAsync(all.data(), dall[0], all.size() * 4, hipMemcpyDeviceToHost, g->streams[0]));
+        for (int r = 0; r < G; ++r) {
+            PK_HIP(hipSetDevice(g->devices[r]));
+            PK_HIP(hipStreamSynchronize(g->streams[r]));
+        }
+        // the token ids of the results are the GATHERED ones (rank 0's copy of the matrix)
+        int seen = 0;
+        for (size_t row = 0; row < (size_t)G * std::max<size_t>(cap, 1); ++row) {
+            const int32_t *p = all.data() + row * stride;
+            if (p[0] < 0) continue;
+            need(p[0] < n_clips && p[1] >= 0 && p[1] <= max_tok, "gathered token matrix row");
+            if ((int)R.ids[p[0]].size() != p[1] || !std::equal(p + 2, p + 2 + p[1], R.ids[p[0]].begin()))
+                fail(PK_ERR_HIP, "RCCL all-gather returned different token ids for clip %d", p[0]);
+            R.ids[p[0]].assign(p + 2, p + 2 + p[1]);
+            ++seen;
+        }
+        if (seen != n_clips) fail(PK_ERR_HIP, "RCCL all-gather returned %d of %d clips", seen, n_clips);
+        g->wall_ms_max = reduced[1] / 1000.0;
+        g->audio_s = audio;
+        for (int r = 0; r < G; ++r) g->clips_per_rank[r] = (int32_t)shard[r].size();
+        *results = publish_store(std::move(store), n_clips, opt && opt->timestamps);
+    });
+}
+
+pk_status pk_group_last_stats(const pk_group *g, double *wall_ms_max, double *audio_seconds, int32_t *clips_per_rank) {
+    return guard([&] {
+        need(g, "group");
+        if (wall_ms_max) *wall_ms_max = g->wall_ms_max;
+        if (audio_seconds) *audio_seconds = g->audio_s;
+        if (clips_per_rank) std::copy(g->clips_per_rank.begin(), g->clips_per_rank.end(), clips_per_rank);
     });
 }
 

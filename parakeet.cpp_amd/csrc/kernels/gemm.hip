@@ -204,6 +204,9 @@ static void launch_epi(const GemmArgs &a, hipStream_t s) {
     // 8-wave workgroup per CU with BK = 64 -- half the barriers per k, nothing to share the CU with (-6 % vs two 128x64 workgroups)
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (a.M >= 1024 && a.N >= 256 && a.K >= 1024 && a.K % 64 == 0 && tiles128 <= 256) { launch_gemm_pipe<2, 4, 2, 1, 64, EPI>(a, s); return; }
+    // round 2: the SINGLE-buffered variant of the same tiles (template parameter NBUF = 1: half the LDS, two barriers per K tile) was
+    // 2-3 % ahead in the micro-benchmark (profiles/r02_gemm_sweep_sb.txt) and exactly level in the engine (fc1 163 us either way,
+    // profiles/r02_bench_v2_sb.json): not used.
     if (a.M >= 1024 && (a.N >= 1024 || (a.M >= 65536 && a.N >= 256))) launch_gemm_pipe<4, 2, 1, 2, 32, EPI>(a, s);
     else if (a.M >= 1024 && a.N >= 256 && a.K >= 1024) launch_gemm_pipe<2, 2, 2, 1, 32, EPI>(a, s);
     else if (a.M >= 1024 && a.N >= 256) launch_gemm_pipe<2, 4, 1, 1, 32, EPI>(a, s);      // 64x128 on 8 waves of 32x32: out_proj / pw2 (-7 %)

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
                     GP_SB(); mma(s & 1); GP_SB();
                 }
             } else {
-                if (!(GP_EXP & (16 | 8192)) && !(GP_EXP & 512) && s == NSUB - 2 && more1) lstore_from(cur ^ 1, sa, sw);
+                if (!(GP_EXP & (16 | 8192)) && !(GP_EXP & 512) && s == ((GP_EXP & 16384) ? 0 : NSUB - 2) && more1) lstore_from(cur ^ 1, sa, sw);
                 GP_SB(); if (!(GP_EXP & 128)) mma(s & 1); GP_SB();
                 if (!(GP_EXP & 16) && (GP_EXP & 512) && s == NSUB - 2 && more1) lstore_from(cur ^ 1, sa, sw);
             }

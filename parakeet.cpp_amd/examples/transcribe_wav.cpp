@@ -1,6 +1,6 @@
 // examples/transcribe_wav.cpp -- the reference README's three-line usage, unchanged, on the MI355X engine:
 //     parakeet::Transcriber t("model.safetensors", "vocab.txt");  t.to_gpu();  auto r = t.transcribe("audio.wav");
-// usage: transcribe_wav <model.safetensors> <vocab.txt> <audio.wav> [ctc|tdt] [--timestamps] [--boost PHRASE]... [--boost-score N]
+// usage: transcribe_wav <model.safetensors> <vocab.txt> <audio.wav> [ctc|tdt] [--timestamps] [--boost PHRASE]... [--boost-score N] [--all-gpus]
 // (--boost / --boost-score as the reference CLI, src/main.cpp:23-25)
 // Prints one JSON object (text, token ids, optional word timestamps) -- tests/test_gpu_facade.py parses it.
 #include <cstdio>
@@ -17,14 +17,17 @@ int main(int argc, char **argv) {
     }
     try {
         parakeet::TranscribeOptions opts;
+        bool all_gpus = false;
         for (int i = 4; i < argc; ++i) {
+            if (!std::strcmp(argv[i], "--all-gpus")) all_gpus = true;      // new: a replica on every GPU of the node (pk_group, RCCL)
             if (!std::strcmp(argv[i], "ctc")) opts.decoder = parakeet::Decoder::CTC;
             if (!std::strcmp(argv[i], "--timestamps")) opts.timestamps = true;
             if (!std::strcmp(argv[i], "--boost") && i + 1 < argc) opts.boost_phrases.push_back(argv[++i]);
             else if (!std::strcmp(argv[i], "--boost-score") && i + 1 < argc) opts.boost_score = std::strtof(argv[++i], nullptr);
         }
         parakeet::Transcriber t(argv[1], argv[2]);
-        t.to_gpu();
+        if (all_gpus) t.to_all_gpus();
+        else t.to_gpu();
         const auto r = t.transcribe(std::string(argv[3]), opts);
         std::printf("{\"text\": \"");
         for (char c : r.text) { if (c == '"' || c == '\\') std::putchar('\\'); std::putchar(c); }

@@ -54,11 +54,15 @@ inline void check(pk_status st) {
 
 class Engine {   // owns one pk_model; shared by Transcriber and TDTTranscriber
   public:
-    Engine(const std::string &weights_path, const std::string &vocab_path, const pk_config &cfg) {
+    Engine(const std::string &weights_path, const std::string &vocab_path, const pk_config &cfg)
+        : weights_path_(weights_path), vocab_path_(vocab_path), cfg_(cfg) {
         check(pk_model_load(weights_path.c_str(), vocab_path.empty() ? nullptr : vocab_path.c_str(), &cfg, &m_));
         tok_ = Tokenizer(m_);
     }
-    ~Engine() { pk_model_free(m_); }
+    ~Engine() {
+        pk_group_free(g_);
+        pk_model_free(m_);
+    }
     Engine(const Engine &) = delete;
     Engine &operator=(const Engine &) = delete;
 
@@ -67,8 +71,18 @@ class Engine {   // owns one pk_model; shared by Transcriber and TDTTranscriber
         on_gpu_ = true;
     }
 
+    // New (the reference is single-device, README.md:513): one replica per GPU of this node, clips dealt to the devices in batches
+    // (pk_group: weights broadcast and results gathered over RCCL).  Empty list = every visible device.
+    void to_all_gpus(const std::vector<int> &devices = {}) {
+        pk_group_free(g_);
+        g_ = nullptr;
+        check(pk_group_create(weights_path_.c_str(), vocab_path_.empty() ? nullptr : vocab_path_.c_str(), &cfg_,
+                              devices.empty() ? nullptr : devices.data(), (int)devices.size(), &g_));
+    }
+    int num_gpus() const { return g_ ? pk_group_size(g_) : (on_gpu_ ? 1 : 0); }
+
     std::vector<TranscribeResult> run(const std::vector<std::pair<const float *, size_t>> &clips, const TranscribeOptions &opts) {
-        if (!on_gpu_) to_gpu(0);
+        if (!g_ && !on_gpu_) to_gpu(0);
         std::vector<float> pcm;
         std::vector<int64_t> offsets{0};
         for (auto &c : clips) {
@@ -84,7 +98,8 @@ class Engine {   // owns one pk_model; shared by Transcriber and TDTTranscriber
         o.n_boost_phrases = (int32_t)phrases.size();
         o.boost_score = opts.boost_score;
         pk_result *res = nullptr;
-        check(pk_transcribe_pcm(m_, pcm.data(), offsets.data(), (int)clips.size(), &o, &res));
+        if (g_) check(pk_group_transcribe_pcm(g_, pcm.data(), offsets.data(), (int)clips.size(), &o, &res));
+        else check(pk_transcribe_pcm(m_, pcm.data(), offsets.data(), (int)clips.size(), &o, &res));
         std::vector<TranscribeResult> out(clips.size());
         for (size_t i = 0; i < clips.size(); ++i) {
             const pk_result &r = res[i];
@@ -114,7 +129,10 @@ class Engine {   // owns one pk_model; shared by Transcriber and TDTTranscriber
     pk_model *handle() { return m_; }
 
   private:
+    std::string weights_path_, vocab_path_;
+    pk_config cfg_;
     pk_model *m_ = nullptr;
+    pk_group *g_ = nullptr;
     Tokenizer tok_;
     bool on_gpu_ = false;
 };
@@ -132,6 +150,9 @@ class Transcriber {
 
     void to_gpu() { eng_.to_gpu(0); }
     void to_gpu(int device) { eng_.to_gpu(device); }
+    /// New: a replica on every GPU of the node (or on `devices`); transcribe_batch() then shards its clips over them.
+    void to_all_gpus(const std::vector<int> &devices = {}) { eng_.to_all_gpus(devices); }
+    int num_gpus() const { return eng_.num_gpus(); }
 
     TranscribeResult transcribe(const std::string &audio_path, Decoder decoder = Decoder::TDT, bool timestamps = false) {
         return eng_.run_file(audio_path, options(decoder, timestamps));
@@ -180,6 +201,8 @@ class TDTTranscriber {
 
     void to_gpu() { eng_.to_gpu(0); }
     void to_gpu(int device) { eng_.to_gpu(device); }
+    void to_all_gpus(const std::vector<int> &devices = {}) { eng_.to_all_gpus(devices); }
+    int num_gpus() const { return eng_.num_gpus(); }
 
     TranscribeResult transcribe(const std::string &audio_path, bool timestamps = false) { return eng_.run_file(audio_path, options(timestamps)); }
     TranscribeResult transcribe(const std::string &audio_path, const TranscribeOptions &opts) { return eng_.run_file(audio_path, tdt(opts)); }

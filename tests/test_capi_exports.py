@@ -71,6 +71,9 @@ def test_no_gpu_is_a_loud_error(tmp_path):
     assert e.value.code == -4
     with pytest.raises(capi.PkError):
         capi.diag_math("exp", [0.0])
+    with pytest.raises(capi.PkError) as e:             # the multi-GPU entry point as well
+        capi.Group(str(wp), cfg)
+    assert e.value.code == -4
 
 
 def test_strict_weight_loading_errors(tmp_path):

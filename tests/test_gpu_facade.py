@@ -44,6 +44,11 @@ def test_transcriber_on_a_wav_matches_oracle(tmp_path, orc):
         assert n > 3 and len(r["words"]) >= 1
         starts = [w[1] for w in r["words"]]
         assert starts == sorted(starts)                      # monotonic word timestamps (tests/test_all.cpp:946-963)
+    # Transcriber::to_all_gpus() (new, additive): replicas over RCCL, same answer
+    out = subprocess.run([EXE, wp, vp, ap, "tdt", "--all-gpus"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    last = out.stdout.strip().splitlines()[-1]               # RCCL prints a version banner on stdout when its first communicator is made
+    assert json.loads(last)["token_ids"] == want["tdt"]["ids"][0, :want["tdt"]["lens"][0]].tolist()
     # TranscribeOptions.boost_phrases through the facade (transcribe.hpp:41-42; CLI --boost / --boost-score, src/main.cpp:23-25)
     toks = want["tdt"]["ids"][0, :want["tdt"]["lens"][0]].tolist()
     def text_of(ids):
