@@ -35,147 +35,16 @@ __device__ long long *gp_trace;     // micro-benchmark builds only: [n_blocks][8
 #define GP_STAMP(i) do { } while (0)
 #endif
 
-template <int WGM, int WGN, int TM, int TN, int BK, int EPI, int NBUF = 2>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, int tiles_n, int n_tiles) {
-    static_assert(NBUF == 1 || NBUF == 2, "LDS staging buffers");
+// Epilogue shared by the GEMM kernels of this directory (bias, ReLU, SiLU, residual + alpha*y, GLU, sigma column layout) on the
+// accumulators of a WGM x WGN grid of waves, each holding TM x TN 32x32 tiles.  `smem` is the kernel's staging memory (free by now),
+// CAP its size in floats: the wide path turns the C tile row-major through it (in row bands when it does not fit).
+template <int WGM, int WGN, int TM, int TN, int EPI, int CAP_FLOATS>
+__device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[TM][TN], float *smem, int m0, int n0) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
-    constexpr int PITCH = BK + 4, BUF = (BM + BN) * PITCH, NSUB = BK / 8, C4R = BK / 4;   // C4R float4 chunks per tile row
-    constexpr int A_CH = BM * C4R / NT, W_CH = BN * C4R / NT;                              // staging chunks per thread per K tile
-    static_assert(BK == 32 || BK == 64, "BK");
-    static_assert((BM * C4R) % NT == 0 && (BN * C4R) % NT == 0, "tile rows must split evenly over the threads");
-    constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;      // output columns per block
-    static_assert(EPI != EPI_GLU || (TN % 2 == 0), "GLU needs an even number of column tiles per wave");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
+    constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int nk = g.K / BK;
-
-    // staging chunk c -> (tile row, float4 column); rows are interleaved in groups of 8 (0,4,1,5,2,6,3,7) so the two
-    // rows a 16-lane ds_write_b64 group touches sit 16 banks apart
-    auto chunk_row = [](int c) { const int rr = c / C4R; return (rr & ~7) | ((rr & 1) << 2) | ((rr >> 1) & 3); };
-    const float *a_src[A_CH];
-    const float *w_src[W_CH];
-    int a_dst[A_CH], w_dst[W_CH];
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        const int c = tid + NT * i;
-        a_dst[i] = chunk_row(c) * PITCH + 2 * (c % C4R);
-    }
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) {
-        const int c = tid + NT * i;
-        w_dst[i] = (BM + chunk_row(c)) * PITCH + 2 * (c % C4R);
-    }
-    // XCD-aware bijective remap (block b runs on XCD b % 8): XCD x gets a contiguous range of tiles.
-    auto remap = [&](int b) {
-        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = b & 7, idx = b >> 3;
-        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    };
-    auto set_tile = [&](int t, int &m0, int &n0) {
-        const int bid = remap(t);
-        m0 = (bid / tiles_n) * BM;
-        n0 = (bid % tiles_n) * NOUT;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int c = tid + NT * i;
-            int gr = m0 + chunk_row(c);
-            gr = gr < g.M ? gr : g.M - 1;
-            a_src[i] = g.A + (int64_t)gr * g.lda + (c % C4R) * 4;
-        }
-#pragma unroll
-        for (int i = 0; i < W_CH; ++i) {
-            const int c = tid + NT * i, v = chunk_row(c);
-            int wr;
-            if constexpr (EPI == EPI_GLU) {
-                // virtual column v -> (wave column, tile, lane column); tiles [0,TN/2) are the value half, tiles
-                // [TN/2,TN) the gate half of the SAME output columns, so one lane holds both.
-                constexpr int HT = TN / 2;
-                const int vw = v / WN, rem = v % WN, tn = rem >> 5, cc = rem & 31;
-                int col = n0 + vw * (WN / 2) + (tn % HT) * 32 + cc;
-                col = col < g.N ? col : g.N - 1;
-                wr = (tn / HT) * g.N + col;
-            } else {
-                wr = n0 + v;
-                wr = wr < g.N ? wr : g.N - 1;
-            }
-            w_src[i] = g.W + (int64_t)wr * g.ldw + (c % C4R) * 4;
-        }
-    };
-
-    float4 ra[A_CH], rw[W_CH];
-    auto gload_to = [&](int kt, float4 (&sa)[A_CH], float4 (&sw)[W_CH]) {
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) sa[i] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
-#pragma unroll
-        for (int i = 0; i < W_CH; ++i) sw[i] = *reinterpret_cast<const float4 *>(w_src[i] + kt * BK);
-    };
-    auto lstore_from = [&](int buf, float4 (&sa)[A_CH], float4 (&sw)[W_CH]) {
-        float *base = smem + buf * BUF;
-        if constexpr ((GP_EXP & 4096) != 0) {                      // experiment: linear, conflict-free 16-byte stores (WRONG layout)
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4 *>(base + (tid + NT * i) * 4) = sa[i];
-#pragma unroll
-            for (int i = 0; i < W_CH; ++i) *reinterpret_cast<float4 *>(base + (tid + NT * (A_CH + i)) * 4) = sw[i];
-            return;
-        }
-        if constexpr ((GP_EXP & 256) != 0) {                       // experiment: 16-byte stores (WRONG layout, timing only)
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4 *>(base + a_dst[i] + 2 * ((tid + NT * i) % C4R)) = sa[i];
-#pragma unroll
-            for (int i = 0; i < W_CH; ++i) *reinterpret_cast<float4 *>(base + w_dst[i] + 2 * ((tid + NT * i) % C4R)) = sw[i];
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            *reinterpret_cast<float2 *>(base + a_dst[i]) = make_float2(sa[i].x, sa[i].z);             // k = 4c, 4c+2
-            *reinterpret_cast<float2 *>(base + a_dst[i] + BK / 2) = make_float2(sa[i].y, sa[i].w);    // k = 4c+1, 4c+3
-        }
-#pragma unroll
-        for (int i = 0; i < W_CH; ++i) {
-            *reinterpret_cast<float2 *>(base + w_dst[i]) = make_float2(sw[i].x, sw[i].z);
-            *reinterpret_cast<float2 *>(base + w_dst[i] + BK / 2) = make_float2(sw[i].y, sw[i].w);
-        }
-    };
-    auto gload = [&](int kt) { gload_to(kt, ra, rw); };
-    auto lstore = [&](int buf) { lstore_from(buf, ra, rw); };
-
-    gp_f32x16 acc[TM][TN];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    };
-
-    // fragment base of this lane: row (lane & 31) of the wave's sub-tile, half h = lane >> 5
-    const int fa_off = (wm * WM + (lane & 31)) * PITCH + (BK / 2) * (lane >> 5);
-    const int fb_off = (BM + wn * WN + (lane & 31)) * PITCH + (BK / 2) * (lane >> 5);
-    float4 fa[2][TM], fb[2][TN];
-    auto fragload = [&](int buf, int s, int slot) {
-        const float *base = smem + buf * BUF + 4 * s;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const float4 *>(base + fa_off + i * 32 * PITCH);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4 *>(base + fb_off + j * 32 * PITCH);
-    };
-    auto mma = [&](int slot) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float a = e == 0 ? fa[slot][i].x : e == 1 ? fa[slot][i].y : e == 2 ? fa[slot][i].z : fa[slot][i].w;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float b = e == 0 ? fb[slot][j].x : e == 1 ? fb[slot][j].y : e == 2 ? fb[slot][j].z : fb[slot][j].w;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
-                }
-            }
-        }
-    };
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     auto epilogue_scalar = [&](int m0, int n0) {
         const int lc = lane & 31, lr = 4 * (lane >> 5);
@@ -219,9 +88,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     auto epilogue_wide = [&](int m0, int n0) {
         constexpr int CP = BN + 4;                                  // C tile pitch (rows stay 16-byte aligned)
         // the C tile goes through the staging buffers; when it does not fit (single-buffered variant) in NPASS row bands
-        constexpr size_t CAP = (size_t)NBUF * BUF;
+        constexpr size_t CAP = (size_t)CAP_FLOATS;
         constexpr int NPASS = ((size_t)BM * CP <= CAP) ? 1 : ((size_t)BM / 2 * CP <= CAP) ? 2 : ((size_t)BM / 4 * CP <= CAP) ? 4 : 8, PR = BM / NPASS;
-        static_assert((size_t)PR * CP <= (size_t)NBUF * BUF, "C tile band must fit in the staging buffers");
+        static_assert((size_t)PR * CP <= CAP, "C tile band must fit in the staging buffers");
         static_assert(PR % 32 == 0, "row bands are whole MFMA tiles");
         constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT, RSTEP = NT / C4;   // float4 chunks per output row / per thread; row stride
         static_assert((BM * C4) % NT == 0 && NT % C4 == 0, "output tile must split evenly over the threads");
@@ -315,10 +184,136 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
         }
     };
     const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);
-    auto epilogue = [&](int m0, int n0) {
-        if (wide) epilogue_wide(m0, n0);
-        else epilogue_scalar(m0, n0);
+    if (wide) epilogue_wide(m0, n0);
+    else epilogue_scalar(m0, n0);
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK, int EPI, int NBUF = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, int tiles_n, int n_tiles) {
+    static_assert(NBUF == 1 || NBUF == 2, "LDS staging buffers");
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
+    constexpr int PITCH = BK + 4, BUF = (BM + BN) * PITCH, NSUB = BK / 8, C4R = BK / 4;   // C4R float4 chunks per tile row
+    constexpr int A_CH = BM * C4R / NT, W_CH = BN * C4R / NT;                              // staging chunks per thread per K tile
+    static_assert(BK == 32 || BK == 64, "BK");
+    static_assert((BM * C4R) % NT == 0 && (BN * C4R) % NT == 0, "tile rows must split evenly over the threads");
+    constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;      // output columns per block
+    static_assert(EPI != EPI_GLU || (TN % 2 == 0), "GLU needs an even number of column tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nk = g.K / BK;
+
+    // staging chunk c -> (tile row, float4 column); rows are interleaved in groups of 8 (0,4,1,5,2,6,3,7) so the two
+    // rows a 16-lane ds_write_b64 group touches sit 16 banks apart
+    auto chunk_row = [](int c) { const int rr = c / C4R; return (rr & ~7) | ((rr & 1) << 2) | ((rr >> 1) & 3); };
+    const float *a_src[A_CH];
+    const float *w_src[W_CH];
+    int a_dst[A_CH], w_dst[W_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int c = tid + NT * i;
+        a_dst[i] = chunk_row(c) * PITCH + 2 * (c % C4R);
+    }
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) {
+        const int c = tid + NT * i;
+        w_dst[i] = (BM + chunk_row(c)) * PITCH + 2 * (c % C4R);
+    }
+    // XCD-aware bijective remap (block b runs on XCD b % 8): XCD x gets a contiguous range of tiles.
+    auto remap = [&](int b) {
+        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = b & 7, idx = b >> 3;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     };
+    auto set_tile = [&](int t, int &m0, int &n0) {
+        const int bid = remap(t);
+        m0 = (bid / tiles_n) * BM;
+        n0 = (bid % tiles_n) * NOUT;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int c = tid + NT * i;
+            int gr = m0 + chunk_row(c);
+            gr = gr < g.M ? gr : g.M - 1;
+            a_src[i] = g.A + (int64_t)gr * g.lda + (c % C4R) * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) {
+            const int c = tid + NT * i, v = chunk_row(c);
+            int wr;
+            if constexpr (EPI == EPI_GLU) {
+                // virtual column v -> (wave column, tile, lane column); tiles [0,TN/2) are the value half, tiles
+                // [TN/2,TN) the gate half of the SAME output columns, so one lane holds both.
+                constexpr int HT = TN / 2;
+                const int vw = v / WN, rem = v % WN, tn = rem >> 5, cc = rem & 31;
+                int col = n0 + vw * (WN / 2) + (tn % HT) * 32 + cc;
+                col = col < g.N ? col : g.N - 1;
+                wr = (tn / HT) * g.N + col;
+            } else {
+                wr = n0 + v;
+                wr = wr < g.N ? wr : g.N - 1;
+            }
+            w_src[i] = g.W + (int64_t)wr * g.ldw + (c % C4R) * 4;
+        }
+    };
+
+    float4 ra[A_CH], rw[W_CH];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const float4 *>(w_src[i] + kt * BK);
+    };
+    auto lstore = [&](int buf) {
+        float *base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            *reinterpret_cast<float2 *>(base + a_dst[i]) = make_float2(ra[i].x, ra[i].z);             // k = 4c, 4c+2
+            *reinterpret_cast<float2 *>(base + a_dst[i] + BK / 2) = make_float2(ra[i].y, ra[i].w);    // k = 4c+1, 4c+3
+        }
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) {
+            *reinterpret_cast<float2 *>(base + w_dst[i]) = make_float2(rw[i].x, rw[i].z);
+            *reinterpret_cast<float2 *>(base + w_dst[i] + BK / 2) = make_float2(rw[i].y, rw[i].w);
+        }
+    };
+
+    gp_f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    };
+
+    // fragment base of this lane: row (lane & 31) of the wave's sub-tile, half h = lane >> 5
+    const int fa_off = (wm * WM + (lane & 31)) * PITCH + (BK / 2) * (lane >> 5);
+    const int fb_off = (BM + wn * WN + (lane & 31)) * PITCH + (BK / 2) * (lane >> 5);
+    float4 fa[2][TM], fb[2][TN];
+    auto fragload = [&](int buf, int s, int slot) {
+        const float *base = smem + buf * BUF + 4 * s;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const float4 *>(base + fa_off + i * 32 * PITCH);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4 *>(base + fb_off + j * 32 * PITCH);
+    };
+    auto mma = [&](int slot) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float a = e == 0 ? fa[slot][i].x : e == 1 ? fa[slot][i].y : e == 2 ? fa[slot][i].z : fa[slot][i].w;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float b = e == 0 ? fb[slot][j].x : e == 1 ? fb[slot][j].y : e == 2 ? fb[slot][j].z : fb[slot][j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto epilogue = [&](int m0, int n0) { gp_epilogue<WGM, WGN, TM, TN, EPI, NBUF * BUF>(g, acc, smem, m0, n0); };
 #define GP_SB() __builtin_amdgcn_sched_barrier(0)
 
 #ifdef GP_CLOCKPROBE
@@ -335,93 +330,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     fragload(0, 0, 0);
     int cur = 0;
     zero_acc();
-    // (GP_EXP bits 8..128 switch main-loop components off in micro-benchmark builds: results are wrong, only the time is read;
-    //  512 = LDS stores after the third sub-step's MFMAs, 1024 = global loads two K tiles ahead in a second register set,
-    //  2048 = staging stores / global loads issued one chunk at a time between the MFMAs)
-    // one staging chunk q of a K tile: q < A_CH -> A rows, else W rows
-    auto gload_one = [&](int kt, int q, float4 (&sa)[A_CH], float4 (&sw)[W_CH]) {
-        if (q < A_CH) sa[q] = *reinterpret_cast<const float4 *>(a_src[q] + kt * BK);
-        else sw[q - A_CH] = *reinterpret_cast<const float4 *>(w_src[q - A_CH] + kt * BK);
-    };
-    auto lstore_one = [&](int buf, int q, float4 (&sa)[A_CH], float4 (&sw)[W_CH]) {
-        float *base = smem + buf * BUF;
-        const float4 v = q < A_CH ? sa[q] : sw[q - A_CH];
-        const int d = q < A_CH ? a_dst[q] : w_dst[q - A_CH];
-        *reinterpret_cast<float2 *>(base + d) = make_float2(v.x, v.z);
-        *reinterpret_cast<float2 *>(base + d + BK / 2) = make_float2(v.y, v.w);
-    };
-    // the MFMAs [lo, hi) of a sub-step, in the same (e, i, j) order as mma()
-    auto mma_range = [&](int slot, int lo, int hi) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int idx = (e * TM + i) * TN + j;
-                    if (idx < lo || idx >= hi) continue;
-                    const float a = e == 0 ? fa[slot][i].x : e == 1 ? fa[slot][i].y : e == 2 ? fa[slot][i].z : fa[slot][i].w;
-                    const float b = e == 0 ? fb[slot][j].x : e == 1 ? fb[slot][j].y : e == 2 ? fb[slot][j].z : fb[slot][j].w;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
-                }
-    };
-    constexpr int NMMA = 4 * TM * TN, NCH_ST = A_CH + W_CH;
-    auto iter = [&](int kt, float4 (&sa)[A_CH], float4 (&sw)[W_CH], int ahead) {
-        const bool more1 = kt + 1 < nk, moreA = kt + ahead < nk;
-#pragma unroll
-        for (int s = 0; s < NSUB - 1; ++s) {
-            if (!(GP_EXP & 64)) fragload(cur, s + 1, (s + 1) & 1);
-            if constexpr ((GP_EXP & 2048) != 0) {                  // staging stores spread over the sub-step's MFMAs, one chunk at a time
-                if (s == NSUB - 2 && more1) {
-#pragma unroll
-                    for (int q = 0; q < NCH_ST; ++q) {
-                        lstore_one(cur ^ 1, q, sa, sw);
-                        GP_SB(); mma_range(s & 1, q * NMMA / NCH_ST, (q + 1) * NMMA / NCH_ST); GP_SB();
-                    }
-                } else {
-                    GP_SB(); mma(s & 1); GP_SB();
-                }
-            } else {
-                if (!(GP_EXP & (16 | 8192)) && !(GP_EXP & 512) && s == ((GP_EXP & 16384) ? 0 : NSUB - 2) && more1) lstore_from(cur ^ 1, sa, sw);
-                GP_SB(); if (!(GP_EXP & 128)) mma(s & 1); GP_SB();
-                if (!(GP_EXP & 16) && (GP_EXP & 512) && s == NSUB - 2 && more1) lstore_from(cur ^ 1, sa, sw);
-            }
-        }
-        if constexpr ((GP_EXP & 8192) != 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's direct-to-LDS loads landed
-        if (!(GP_EXP & 8)) __syncthreads();
-        if (!(GP_EXP & 64) && more1) fragload(cur ^ 1, 0, 0);
-        if constexpr ((GP_EXP & 8192) != 0) {                      // experiment: K tile kt+2 straight from global memory into the LDS buffer
-            if (moreA) {                                           // that was just released (linear layout: WRONG for the fragment reads)
-                const int wv = __builtin_amdgcn_readfirstlane(wave);
-#pragma unroll
-                for (int q = 0; q < NCH_ST; ++q) {
-                    const float *src = (q < A_CH ? a_src[q] : w_src[q - A_CH]) + (kt + ahead) * BK;
-                    float *dst = smem + cur * BUF + (wv * 64 + NT * q) * 4;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-                }
-            }
-            GP_SB(); mma((NSUB - 1) & 1); GP_SB();
-        } else if constexpr ((GP_EXP & 2048) != 0) {                      // ... and the global loads over the last sub-step's MFMAs
-            if (moreA) {
-#pragma unroll
-                for (int q = 0; q < NCH_ST; ++q) {
-                    gload_one(kt + ahead, q, sa, sw);
-                    GP_SB(); mma_range((NSUB - 1) & 1, q * NMMA / NCH_ST, (q + 1) * NMMA / NCH_ST); GP_SB();
-                }
-            } else {
-                GP_SB(); mma((NSUB - 1) & 1); GP_SB();
-            }
-        } else {
-            if (!(GP_EXP & 32) && moreA) gload_to(kt + ahead, sa, sw);
-            GP_SB(); if (!(GP_EXP & 128)) mma((NSUB - 1) & 1); GP_SB();
-        }
-        cur ^= 1;
-    };
+    // GP_EXP bits 8..128 (micro-benchmark builds only; results are wrong, only the time is read) switch main-loop components off:
+    // 8 = barrier, 16 = LDS stores, 32 = global loads, 64 = fragment reads, 128 = MFMAs  (profiles/r02_gemm_mainloop_ablation.txt)
     if constexpr (NBUF == 1) {
-        // Single staging buffer (half the LDS: twice the resident workgroups, so a workgroup's prologue / epilogue / barriers are
-        // covered by its neighbours' MFMAs).  Two barriers per K tile: one when every wave has its last fragments in registers
-        // (the buffer may be overwritten), one when the next tile is stored; the last sub-step's MFMAs run between them.
+        // Single staging buffer (half the LDS, two barriers per K tile: one when every wave has its last fragments in registers, one
+        // when the next tile is stored; the last sub-step's MFMAs run between them).  Level with the double-buffered loop in the
+        // engine (profiles/r02_bench_v2_sb.json); kept as a variant of the sweep.
         for (int kt = 0; kt < nk; ++kt) {
             const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
 #pragma unroll
@@ -436,15 +350,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             __syncthreads();
             if (more1) fragload(0, 0, 0);
         }
-    } else if constexpr ((GP_EXP & 1024) != 0) {
-        float4 ra2[A_CH], rw2[W_CH];
-        if (nk > 2) gload_to(2, ra2, rw2);
-        for (int kt = 0; kt < nk; kt += 2) {
-            iter(kt, ra, rw, 3);
-            if (kt + 1 < nk) iter(kt + 1, ra2, rw2, 3);
-        }
     } else {
-        for (int kt = 0; kt < nk; ++kt) iter(kt, ra, rw, 2);
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+#pragma unroll
+            for (int s = 0; s < NSUB - 1; ++s) {
+                if (!(GP_EXP & 64)) fragload(cur, s + 1, (s + 1) & 1);
+                if (!(GP_EXP & 16) && s == NSUB - 2 && more1) lstore(cur ^ 1);
+                GP_SB(); if (!(GP_EXP & 128)) mma(s & 1); GP_SB();
+            }
+            if (!(GP_EXP & 8)) __syncthreads();
+            if (!(GP_EXP & 64) && more1) fragload(cur ^ 1, 0, 0);
+            if (!(GP_EXP & 32) && more2) gload(kt + 2);
+            GP_SB(); if (!(GP_EXP & 128)) mma((NSUB - 1) & 1); GP_SB();
+            cur ^= 1;
+        }
     }
     GP_STAMP(2);
     epilogue(m0, n0);

@@ -11,6 +11,7 @@
 
 #define GP_CLOCKPROBE 1
 #include "../../parakeet.cpp_amd/csrc/kernels/gemm.hip"
+#include "gemm_dma.hpp"
 #include "../../parakeet.cpp_amd/csrc/kernels/gemm_smallm.hip"   // first-generation kernel + launch_gemm
 
 using namespace pk;
@@ -70,6 +71,16 @@ static void run_sb(const GemmArgs &a, int epi, hipStream_t s) {       // single 
     case EPI_SILU: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_SILU, 1>(a, s); break;
     case EPI_RESID: launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_RESID, 1>(a, s); break;
     case EPI_GLU: if constexpr (TN % 2 == 0) launch_gemm_pipe<WGM, WGN, TM, TN, BK, EPI_GLU, 1>(a, s); break;
+    }
+}
+template <int WGM, int WGN, int TM, int TN>
+static void run_dma(const GemmArgs &a, int epi, hipStream_t s) {      // direct-to-LDS staging
+    switch (epi) {
+    case EPI_NONE: launch_gemm_dma<WGM, WGN, TM, TN, EPI_NONE>(a, s); break;
+    case EPI_RELU: launch_gemm_dma<WGM, WGN, TM, TN, EPI_RELU>(a, s); break;
+    case EPI_SILU: launch_gemm_dma<WGM, WGN, TM, TN, EPI_SILU>(a, s); break;
+    case EPI_RESID: launch_gemm_dma<WGM, WGN, TM, TN, EPI_RESID>(a, s); break;
+    case EPI_GLU: if constexpr (TN % 2 == 0) launch_gemm_dma<WGM, WGN, TM, TN, EPI_GLU>(a, s); break;
     }
 }
 template <int BM, int BN>
@@ -143,6 +154,13 @@ int main(int argc, char **argv) {
         {"pipe 128x128 w64x32 bk64 512t", run_pipe<2, 4, 2, 1, 64>},
         {"pipe 128x128 w32x64 bk64 512t", run_pipe<4, 2, 1, 2, 64>},
         {"pipe 128x128 w64x32 bk64 512t", run_pipe<2, 4, 2, 1, 64>},
+        {"dma  128x128 w64x64 256t 512t-class", run_dma<2, 2, 2, 2>},
+        {"dma  128x128 w32x64 512t", run_dma<4, 2, 1, 2>},
+        {"dma  128x128 w64x32 512t", run_dma<2, 4, 2, 1>},
+        {"dma  64x128  w32x64 256t 512t-class", run_dma<2, 2, 1, 2>},
+        {"dma  128x64  w64x32 256t 512t-class", run_dma<2, 2, 2, 1>},
+        {"dma  64x128  w32x32 512t", run_dma<2, 4, 1, 1>},
+        {"dma  64x64   w32x32 256t 512t-class", run_dma<2, 2, 1, 1>},
         {"sb   128x128 w64x64 bk32 256t 512t-class", run_sb<2, 2, 2, 2, 32>},
         {"sb   64x128  w32x64 bk32 256t 512t-class", run_sb<2, 2, 1, 2, 32>},
         {"sb   128x128 w32x64 bk32 512t", run_sb<4, 2, 1, 2, 32>},
@@ -207,7 +225,9 @@ int main(int argc, char **argv) {
         struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
         const std::vector<KV> kv = {{"pipe 128x128 w32x64 512t", run_pipe<4, 2, 1, 2, 32>}, {"pipe 128x128 w64x64 256t", run_pipe<2, 2, 2, 2, 32>},
                                     {"pipe 64x64 w32x32 256t", run_pipe<2, 2, 1, 1, 32>}, {"sb 128x128 w64x64 256t", run_sb<2, 2, 2, 2, 32>},
-                                    {"sb 64x128 w32x64 256t", run_sb<2, 2, 1, 2, 32>}, {"sb 128x128 w32x64 512t", run_sb<4, 2, 1, 2, 32>}};
+                                    {"sb 64x128 w32x64 256t", run_sb<2, 2, 1, 2, 32>}, {"sb 128x128 w32x64 512t", run_sb<4, 2, 1, 2, 32>},
+                                    {"dma 128x128 w64x64 256t", run_dma<2, 2, 2, 2>}, {"dma 128x128 w32x64 512t", run_dma<4, 2, 1, 2>},
+                                    {"dma 64x128 w32x64 256t", run_dma<2, 2, 1, 2>}};
         for (int epi : {(int)EPI_NONE, (int)EPI_SILU, (int)EPI_RESID})
         for (auto &v : kv) {
             printf("ml GP_EXP=%d epi=%d %-28s:", GP_EXP, epi, v.name);
