@@ -8,7 +8,7 @@ import numpy as np
 from .config import ModelConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libparakeet_amd.so")
+LIB_PATH = os.environ.get("PK_LIB") or os.path.join(_HERE, "libparakeet_amd.so")   # PK_LIB: experiment builds of the same library
 _LIB = None
 
 f32p, i32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)

@@ -345,7 +345,12 @@ void Model::to_gpu(int device) {
     {
         int lo = 0, hi = 0;
         PK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // numerically lowest = highest priority
-        PK_HIP(hipStreamCreateWithPriority(&stream_dec, hipStreamNonBlocking, hi));
+        int prio = hi;                                        // default: the decode loop of batch k-1 runs at the highest priority
+        if (const char *e = getenv("PK_DEC_PRIORITY")) {      // experiment knob (tools/): "normal" / "low"
+            if (!strcmp(e, "normal")) prio = 0;
+            else if (!strcmp(e, "low")) prio = lo;
+        }
+        PK_HIP(hipStreamCreateWithPriority(&stream_dec, hipStreamNonBlocking, prio));
     }
     PK_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_done), sizeof(int), hipHostMallocDefault));
     // The model counts as resident only when EVERY weight made it: a failed upload (missing / mis-shaped / non-F32 tensor, HIP
@@ -672,35 +677,60 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
     // Per step: [cell GEMV per LSTM layer] -> joint-activation GEMV -> heads GEMV -> decide.  h / h' / z live in the sigma
     // K layout (they are only ever GEMV operands); c, the g1 table, enc_proj and the logits are in natural order.
     const double f_hh = 2.0 * B * 4 * Hp * Hp, f_pp = 2.0 * B * J * Hp, f_hd = 2.0 * B * (V + D) * J;
+    // the step-invariant arguments of every phase
+    TdtPersist P{};
+    P.st = st;
+    P.L = L;
+    for (int l = 0; l < L; ++l) {
+        float *hl = w.h.as<float>() + (size_t)l * B * Hp, *cl = w.c.as<float>() + (size_t)l * B * Hp;
+        float *hnl = w.hn.as<float>() + (size_t)l * B * Hp, *cnl = w.cn.as<float>() + (size_t)l * B * Hp;
+        SkinnyArgs &a = P.cell[l];
+        a.X = hl; a.W = dec_whh_s[l]; a.B = B; a.N = 4 * Hp; a.K = Hp; a.out = hnl; a.c = cl; a.cn = cnl; a.Hp = Hp;
+        if (l == 0) {
+            a.gi = dec.g1; a.gi_ld = 4 * Hp; a.gi_row = st.token;
+        } else {
+            SkinnyArgs &g = P.ih[l];
+            g.X = w.hn.as<float>() + (size_t)(l - 1) * B * Hp; g.W = dec_wih_s[l]; g.B = B; g.N = 4 * Hp; g.K = Hp;
+            g.bias = dec.bih[l]; g.out = w.gi.as<float>(); g.ldo = 4 * Hp;
+            a.gi = w.gi.as<float>(); a.gi_ld = 4 * Hp; a.gi_row = nullptr;
+        }
+    }
+    {
+        SkinnyArgs &a = P.act;
+        a.X = w.hn.as<float>() + (size_t)(L - 1) * B * Hp; a.W = dec_wp_s; a.B = B; a.N = J; a.K = Hp; a.bias = dec.bp;
+        a.out = w.z.as<float>(); a.ep = w.ep.as<float>(); a.t = st.t; a.T = T;
+    }
+    {
+        SkinnyArgs &a = P.heads;
+        a.X = w.z.as<float>(); a.W = wld_s; a.B = B; a.N = V + D; a.K = J; a.bias = bld; a.out = w.logits.as<float>(); a.ldo = V + D;
+    }
+    // ONE launch for the whole loop (kernels/decode_persist.hip): implemented, bit-identical to the per-phase loop (tests/test_gpu_decode.py),
+    // and NOT faster on this hardware -- OPT-IN with PK_DEC_PERSISTENT=1.  Measured in round 2 (profiles/r02_decode_persistent.md): the
+    // grid barrier between the four all-to-all phases of a step costs ~20 us with a single system-scope arrival counter (160 arrivals
+    // serialise at the memory side), 98 us per step against 46 us for four launches; next to the encoder of the following batch the
+    // resident part of the grid spins while the rest waits for CU slots.  Eligible when the decide scratch is small enough for a
+    // workgroup to sit beside the encoder's GEMM workgroups, at most two LSTM layers, no phrase boosting, no carried streaming state.
+    {
+        const char *e = getenv("PK_DEC_PERSISTENT");
+        const bool want = e && e[0] == '1';
+        const int G = Hp / 4;
+        if (want && !boost_on && !keep_state && Hp % 4 == 0 && G >= 1 && G <= 200 && L <= 2 && tdt_persistent_lds_bytes(st) <= 12 * 1024) {
+            P.bar = reinterpret_cast<unsigned *>(st.done_count + 1);           // two spare words behind the per-utterance state
+            P.abort = st.done_count + 2;
+            P.timeout_ticks = 200000000LL;                                     // 2 s of the 100 MHz wall clock
+            PK_HIP(hipMemsetAsync(P.bar, 0, 2 * sizeof(int), s));
+            KL("tdt_persistent", (f_hh * L + f_pp + f_hd) * (T + 8), 0.0, launch_tdt_persistent(P, s));
+            return;
+        }
+    }
     const int chunk = 16;
     for (int step = 0; step < st.max_steps; ++step) {
         for (int l = 0; l < L; ++l) {
-            float *hl = w.h.as<float>() + (size_t)l * B * Hp, *cl = w.c.as<float>() + (size_t)l * B * Hp;
-            float *hnl = w.hn.as<float>() + (size_t)l * B * Hp, *cnl = w.cn.as<float>() + (size_t)l * B * Hp;
-            SkinnyArgs a{};
-            a.X = hl; a.W = dec_whh_s[l]; a.B = B; a.N = 4 * Hp; a.K = Hp; a.out = hnl; a.c = cl; a.cn = cnl; a.Hp = Hp;
-            if (l == 0) {
-                a.gi = dec.g1; a.gi_ld = 4 * Hp; a.gi_row = st.token;
-            } else {
-                SkinnyArgs g{};
-                g.X = w.hn.as<float>() + (size_t)(l - 1) * B * Hp; g.W = dec_wih_s[l]; g.B = B; g.N = 4 * Hp; g.K = Hp;
-                g.bias = dec.bih[l]; g.out = w.gi.as<float>(); g.ldo = 4 * Hp;
-                KL("lstm_ih_gemv", f_hh, 0.0, launch_skinny_gemm(g, SK_BIAS, s));
-                a.gi = w.gi.as<float>(); a.gi_ld = 4 * Hp; a.gi_row = nullptr;
-            }
-            KL("lstm_hh_cell", f_hh, 0.0, launch_skinny_gemm(a, SK_CELL, s));
+            if (l > 0) KL("lstm_ih_gemv", f_hh, 0.0, launch_skinny_gemm(P.ih[l], SK_BIAS, s));
+            KL("lstm_hh_cell", f_hh, 0.0, launch_skinny_gemm(P.cell[l], SK_CELL, s));
         }
-        {
-            SkinnyArgs a{};
-            a.X = w.hn.as<float>() + (size_t)(L - 1) * B * Hp; a.W = dec_wp_s; a.B = B; a.N = J; a.K = Hp; a.bias = dec.bp;
-            a.out = w.z.as<float>(); a.ep = w.ep.as<float>(); a.t = st.t; a.T = T;
-            KL("joint_pred_act", f_pp, 0.0, launch_skinny_gemm(a, SK_ACT, s));
-        }
-        {
-            SkinnyArgs a{};
-            a.X = w.z.as<float>(); a.W = wld_s; a.B = B; a.N = V + D; a.K = J; a.bias = bld; a.out = w.logits.as<float>(); a.ldo = V + D;
-            KL("joint_heads_gemv", f_hd, 0.0, launch_skinny_gemm(a, SK_BIAS, s));
-        }
+        KL("joint_pred_act", f_pp, 0.0, launch_skinny_gemm(P.act, SK_ACT, s));
+        KL("joint_heads_gemv", f_hd, 0.0, launch_skinny_gemm(P.heads, SK_BIAS, s));
         KL("tdt_decide", 0.0, 0.0, launch_tdt_decide(st, s));
         if ((step + 1) % chunk == 0) {                                 // poll "all finished" once per chunk of steps
             PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));

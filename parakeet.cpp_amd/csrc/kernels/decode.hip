@@ -9,40 +9,12 @@
 //        gemm  PP = h' W_pred^T         (MFMA)           -> joint_act   z = relu(enc_proj[t_b] + PP)
 //        gemm  LOG = z [W_label;W_dur]^T + b (MFMA)      -> tdt_decide  log-softmax, argmax, control,
 //                                                                        commit / revert of the LSTM state
-#include "../pk_devmath.h"
-#include "kernels.hpp"
+#include "decode_dev.hpp"
 
 namespace pk {
 
 // ---- row log-softmax + first-max argmax (one wavefront per row) ---------------------------------------
 // lsm = (x - max) - log(sum64(exp(x - max))).  argmax over lsm with strict '>' (lowest index wins ties).
-struct BestLP {
-    float lp;
-    int idx;
-};
-__device__ __forceinline__ BestLP wave_logsoftmax_argmax(const float *__restrict__ x, int n, float *__restrict__ lp_out, int lane) {
-    float m = -__builtin_huge_valf();
-    for (int i = lane; i < n; i += 64) m = fmaxf(m, x[i]);
-    m = wave_max64(m);
-    float p = 0.0f;
-    for (int i = lane; i < n; i += 64) p = p + dexpf(x[i] - m);
-    const float lse = dlogf(wave_sum64(p));
-    float best = -__builtin_huge_valf();
-    int bi = 0x7fffffff;
-    for (int i = lane; i < n; i += 64) {
-        const float l = (x[i] - m) - lse;
-        if (lp_out) lp_out[i] = l;
-        if (bi == 0x7fffffff || l > best) { best = l; bi = i; }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    return {best, bi};
-}
-
 __global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(const float *__restrict__ logits, int64_t rows, int ld, int n,
                                                                 float *__restrict__ lp_out, int *__restrict__ best_idx,
                                                                 float *__restrict__ best_lp) {
@@ -239,167 +211,7 @@ void launch_joint_act(const float *ep, const int *t, int T, int J, const float *
 template <bool BOOST>
 __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // x[V+D], e[V+D], scratch[16] (+ BOOST: mask, active sets)
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (st.done[b]) return;
-    const int VD = st.V + st.D;
-    float *x = sm, *e = sm + VD;
-    float *red = e + VD;                                           // [0..3] wave maxima, [4] lse, [8..11] best val, [12..15] best idx
-    const int MW = (st.V + 31) >> 5;
-    unsigned *mask = reinterpret_cast<unsigned *>(red + 16);       // [MW] boosted-token bits
-    int *acts = reinterpret_cast<int *>(mask + MW);                // [kTrieMaxActive] this step's active states
-    int *nx = acts + kTrieMaxActive;                               // [1 + kTrieMaxActive] next active set (count first)
-    int n_act = 0;
-    if constexpr (BOOST) {
-        n_act = st.trie.n_act[b];
-        if (tid < n_act) acts[tid] = st.trie.act[(int64_t)b * kTrieMaxActive + tid];
-        for (int i = tid; i < MW; i += 256) mask[i] = 0u;
-    }
-    const float *lg = st.logits + (int64_t)b * VD;
-    // issue every independent global load up front (state words, candidate LSTM state): each dependent round trip to
-    // L2/HBM costs ~1-2 us in this latency-bound kernel
-    const int t_in = st.t[b], steps_in = st.steps[b], n_out_in = st.n_out[b], nsym_in = st.nsym[b];
-    constexpr int kMaxCarry = 12;                                  // L * Hp <= 12 * 256
-    float hcar[kMaxCarry], ccar[kMaxCarry];
-    const int n_state = st.L * st.Hp;
-#pragma unroll
-    for (int q = 0; q < kMaxCarry; ++q) {
-        const int i = tid + 256 * q;
-        if (i < n_state) {
-            const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
-            hcar[q] = st.hn[o];
-            ccar[q] = st.cn[o];
-        }
-    }
-    float m = -__builtin_huge_valf();
-    for (int i = tid; i < VD; i += 256) {
-        const float v = lg[i];
-        x[i] = v;
-        if (i < st.V) m = fmaxf(m, v);
-    }
-    m = wave_max64(m);
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    for (int i = tid; i < st.V; i += 256) e[i] = dexpf(x[i] - m);
-    if constexpr (BOOST) {                                         // get_boosted_tokens: union of the children of the active states
-        for (int a = 0; a < n_act; ++a) {
-            const int sn = acts[a];
-            const int c1 = st.trie.off[sn + 1];
-            for (int c = st.trie.off[sn] + tid; c < c1; c += 256) {
-                const int tk = st.trie.tok[c];
-                if (tk >= 0 && tk < st.V) atomicOr(&mask[tk >> 5], 1u << (tk & 31));
-            }
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float p = 0.0f;
-        for (int i = lane; i < st.V; i += 64) p = p + e[i];
-        const float lse = dlogf(wave_sum64(p));
-        if (lane == 0) red[4] = lse;
-    }
-    int skip = 1;
-    if (wave == 1 && st.D > 0) {                                   // duration head: a few values, one wavefront
-        const BestLP dur = wave_logsoftmax_argmax(x + st.V, st.D, nullptr, lane);
-        if (lane == 0) red[5] = (float)(dur.idx < st.D ? st.durations[dur.idx] : 1);
-    }
-    __syncthreads();
-    const float lse = red[4];
-    float best = -__builtin_huge_valf();
-    int bi = 0x7fffffff;
-    for (int i = tid; i < st.V; i += 256) {
-        float l = (x[i] - m) - lse;
-        if constexpr (BOOST) l = l + (((mask[i >> 5] >> (i & 31)) & 1u) ? st.trie.boost : 0.0f);
-        if (bi == 0x7fffffff || l > best) { best = l; bi = i; }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    if (lane == 0) { red[8 + wave] = best; red[12 + wave] = __int_as_float(bi); }
-    __syncthreads();
-    BestLP lab{red[8], __float_as_int(red[12])};
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        const float ob = red[8 + w];
-        const int oi = __float_as_int(red[12 + w]);
-        if (ob > lab.lp || (ob == lab.lp && oi < lab.idx)) { lab.lp = ob; lab.idx = oi; }
-    }
-    if constexpr (BOOST) lab.lp = (x[lab.idx] - m) - lse;          // the confidence is the UNBOOSTED log-prob (phrase_boost.cpp:313-315)
-    if (st.D > 0) skip = (int)red[5];
-    const int lane0 = tid;                                         // thread 0 writes the scalar state
-    // scalar control (wave-uniform values; lane 0 writes)
-    int t = t_in;
-    const int nsteps = steps_in + 1;
-    int n_out = n_out_in;
-    int nsym = nsym_in;
-    const bool commit = lab.idx != st.blank;
-    if (!commit) {
-        // blank: the LSTM state reverts -- the candidates hn/cn are simply not committed (src/tdt.cpp:88-93)
-        t += (st.D > 0) ? (skip > 1 ? skip : 1) : 1;
-        nsym = 0;
-    } else {
-        if (lane0 == 0) {
-            if (n_out < st.max_tokens) {
-                const int64_t o = (int64_t)b * st.max_tokens + n_out;
-                st.ids[o] = lab.idx;
-                st.start[o] = t;
-                int e = st.D > 0 ? t + (skip > 1 ? skip : 1) - 1 : t;     // src/tdt.cpp:184-187 ; rnnt.cpp:170 (end = t)
-                st.end[o] = (st.keep_state || e < st.T) ? e : st.T - 1;
-                st.conf[o] = dexpf(lab.lp);                                 // confidence = exp(max log-prob) :169
-            }
-            st.token[b] = lab.idx;
-        }
-        if constexpr (BOOST) {                        // ContextTrie::advance on the emitted token (phrase_boost.cpp:52-66, :336)
-            if (tid == 0) { nx[0] = 1; nx[1] = 0; }   // the root is always active
-            __syncthreads();
-            for (int a = 0; a < n_act; ++a) {
-                const int sn = acts[a];
-                const int c1 = st.trie.off[sn + 1];
-                for (int c = st.trie.off[sn] + tid; c < c1; c += 256)
-                    if (st.trie.tok[c] == lab.idx) {
-                        const int slot = atomicAdd(&nx[0], 1);
-                        if (slot < kTrieMaxActive) nx[1 + slot] = st.trie.node[c];
-                    }
-            }
-            __syncthreads();
-            const int nn = nx[0] < kTrieMaxActive ? nx[0] : kTrieMaxActive;
-            if (tid < nn) st.trie.act[(int64_t)b * kTrieMaxActive + tid] = nx[1 + tid];
-            if (tid == 0) st.trie.n_act[b] = nn;
-        }
-        ++n_out;
-        if (st.D > 0) {
-            if (skip > 0) t += skip;                  // duration 0: emit another symbol on the same frame (:99-105)
-        } else if (++nsym >= st.max_symbols) {        // RNNT: the inner for runs out -> next frame (rnnt.cpp:82-107)
-            t += 1;
-            nsym = 0;
-        }
-#pragma unroll
-        for (int q = 0; q < kMaxCarry; ++q) {         // commit the candidate LSTM state, [L][B][Hp]
-            const int i = tid + 256 * q;
-            if (i < n_state) {
-                const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
-                st.h[o] = hcar[q];
-                st.c[o] = ccar[q];
-            }
-        }
-    }
-    if (lane0 == 0) {
-        bool finished = t >= st.T;
-        int len = n_out < st.max_tokens ? n_out : st.max_tokens;
-        if (!finished && st.max_steps > 0 && nsteps >= st.max_steps) { finished = true; len = -1; }   // safety cap
-        st.t[b] = t;
-        st.steps[b] = nsteps;
-        st.n_out[b] = n_out;
-        st.nsym[b] = nsym;
-        if (finished) {
-            st.lens[b] = len;
-            st.done[b] = 1;
-            atomicAdd(st.done_count, 1);
-        }
-    }
+    tdt_decide_one<BOOST, false>(st, blockIdx.x, sm);
 }
 void launch_tdt_decide(const TdtState &st, hipStream_t s) {
     const size_t lds = (size_t)(2 * (st.V + st.D) + 16) * sizeof(float);

@@ -1,0 +1,388 @@
+// parakeet.cpp_amd/csrc/kernels/decode_dev.hpp -- device code of the TDT / RNNT decode step shared by the per-phase kernels
+// (decode_gemv.hip, decode.hip) and the persistent single-launch kernel (decode_persist.hip).
+#pragma once
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+
+namespace pk {
+
+// accesses to data exchanged between workgroups inside one launch: system scope (sc0 sc1) relaxed atomics, which the compiler
+// neither caches nor serialises (a volatile access would be followed by s_waitcnt vmcnt(0)); plain accesses otherwise
+template <bool COH> __device__ __forceinline__ float dd_ldf(const float *p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else return *p;
+}
+template <bool COH> __device__ __forceinline__ int dd_ldi(const int *p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else return *p;
+}
+template <bool COH> __device__ __forceinline__ float4 dd_ld4(const float4 *p) {
+    if constexpr (COH) {
+        const float *f = reinterpret_cast<const float *>(p);
+        return make_float4(dd_ldf<true>(f), dd_ldf<true>(f + 1), dd_ldf<true>(f + 2), dd_ldf<true>(f + 3));
+    } else {
+        return *p;
+    }
+}
+template <bool COH> __device__ __forceinline__ void dd_stf(float *p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *p = v;
+}
+template <bool COH> __device__ __forceinline__ void dd_sti(int *p, int v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *p = v;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int sigma16(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
+
+// NCH: compile-time number of 64-wide K chunks (10 for K = 640: fully unrolled, counted vmcnt waits keep the next
+// chunk's loads in flight under the MFMA chain); 0 = runtime trip count (any K % 64 == 0).
+// COH = the operands other workgroups of the SAME kernel produced (X, c, the token / frame words, gi of the upper LSTM layers) are
+// read, and the outputs written, with system-scope accesses (sc0 sc1: no cache between the workgroups) -- the persistent decode
+// kernel (decode_persist.hip) runs every phase of a step inside one launch.
+template <int EPI, int NCH, bool COH>
+__device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgroup, float (*tile)[16][17]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int m0 = (mgroup * 4 + wave) * 16;
+    if (m0 >= a.B) return;                                       // whole wave out of range (uniform)
+    int wrow;
+    if (EPI == SK_CELL) wrow = (col >> 2) * a.Hp + 4 * nt + (col & 3);   // tile columns = (gate, unit): rows g*Hp + j
+    else { wrow = 16 * nt + col; wrow = wrow < a.N ? wrow : a.N - 1; }
+    int xrow = m0 + col;
+    xrow = xrow < a.B ? xrow : a.B - 1;
+    const float4 *xp = reinterpret_cast<const float4 *>(a.X + (int64_t)xrow * a.K) + kq;
+    const float4 *wp = reinterpret_cast<const float4 *>(a.W + (int64_t)wrow * a.K) + kq;
+    // Epilogue operands are fetched FIRST (token -> g1 row, c, enc_proj[t_b], bias): in this latency-bound loop every
+    // dependent round trip to L2 / HBM that can hide under the 160-MFMA chain is ~1-2 us saved per launch.
+    float e_gi[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_c = 0.0f;          // SK_CELL: lane -> (utterance lane>>2, unit lane&3)
+    float e_ep[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_bias = 0.0f;       // SK_ACT / SK_BIAS: lane -> column `col`, utterances 4*kq+r
+    if (EPI == SK_CELL) {
+        const int b = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
+        if (b < a.B) {
+            const float *gir = a.gi + (int64_t)(a.gi_row ? dd_ldi<COH>(a.gi_row + b) : b) * a.gi_ld;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_gi[g] = a.gi_row ? gir[g * a.Hp + j] : dd_ldf<COH>(gir + g * a.Hp + j);   // layer 0: the constant g1 table
+            e_c = dd_ldf<COH>(a.c + (int64_t)b * a.Hp + j);
+        }
+    } else {
+        const int n = 16 * nt + col;
+        if (n < a.N) {
+            if (a.bias) e_bias = a.bias[n];
+            if (EPI == SK_ACT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = m0 + 4 * kq + r;
+                    if (b < a.B) {
+                        int tt = dd_ldi<COH>(a.t + b);
+                        tt = tt < a.T ? tt : a.T - 1;
+                        e_ep[r] = a.ep[((int64_t)b * a.T + tt) * a.N + n];
+                    }
+                }
+            }
+        }
+    }
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    // software pipeline: chunks of 4 float4 pairs (16 MFMAs, ~640 cycles) with the next chunk's loads in flight
+    constexpr int CH = 4;
+    const int nchunks = a.K / (16 * CH);
+    float4 xa[CH], wa[CH], xb[CH], wb[CH];
+#define SK_LOAD(X_, W_, c_)                                                         \
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                               \
+        X_[i] = dd_ld4<COH>(xp + 4 * ((c_) * CH + i));                                            \
+        W_[i] = wp[4 * ((c_) * CH + i)];                                 \
+    }                                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+#define SK_MMA(X_, W_)                                                              \
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                               \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X_[i].x, W_[i].x, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X_[i].y, W_[i].y, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X_[i].z, W_[i].z, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X_[i].w, W_[i].w, acc, 0, 0, 0); \
+    }                                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NCH > 0) {
+        // two register sets, fully unrolled: chunk c+1 is in flight while chunk c feeds the MFMA chain (>= 640 cycles of cover).
+        // A third set hid more latency but pushed the kernel past 96 VGPRs, and then a decode wave no longer fits next to the
+        // four 104-VGPR waves per SIMD of the 128x128 GEMM of the NEXT batch's encoder (two-stream pipeline): every decode
+        // workgroup had to wait for a GEMM workgroup to retire and then held that slot -- 2.0 ms per 64-clip batch.
+        SK_LOAD(xa, wa, 0)
+#pragma unroll
+        for (int c = 0; c < NCH; c += 2) {
+            if (c + 1 < NCH) { SK_LOAD(xb, wb, c + 1) }
+            SK_MMA(xa, wa)
+            if (c + 2 < NCH) { SK_LOAD(xa, wa, c + 2) }
+            if (c + 1 < NCH) { SK_MMA(xb, wb) }
+        }
+    } else {
+        SK_LOAD(xa, wa, 0)
+        for (int c = 0; c < nchunks; c += 2) {
+            if (c + 1 < nchunks) { SK_LOAD(xb, wb, c + 1) }
+            SK_MMA(xa, wa)
+            if (c + 2 < nchunks) { SK_LOAD(xa, wa, c + 2) }
+            if (c + 1 < nchunks) { SK_MMA(xb, wb) }
+        }
+    }
+#undef SK_LOAD
+#undef SK_MMA
+    // C/D layout of 16x16x4: column = lane & 15, row (utterance) = 4 * (lane >> 4) + r
+    if (EPI == SK_BIAS) {
+        const int n = 16 * nt + col;
+        if (n < a.N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = m0 + 4 * kq + r;
+                if (b < a.B) dd_stf<COH>(a.out + (int64_t)b * a.ldo + n, a.bias ? acc[r] + e_bias : acc[r]);
+            }
+        }
+    } else if (EPI == SK_ACT) {
+        // z = relu(enc_proj(enc_t) + pred_proj(pred) [+ bp])   src/tdt.cpp:17-18 ; written in sigma layout
+        const int n = 16 * nt + col;
+        if (n < a.N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = m0 + 4 * kq + r;
+                if (b >= a.B) continue;
+                float p = acc[r];
+                if (a.bias) p = p + e_bias;
+                const float s = e_ep[r] + p;
+                dd_stf<COH>(a.out + (int64_t)b * a.N + sigma16(n), s > 0.0f ? s : 0.0f);
+            }
+        }
+    } else {
+        // LSTMCell::forward: gates = (W_ih x + b) + W_hh h ; i,f,g,o ; c' = f*c + i*g ; h' = o*tanh(c')
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][col] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int ul = lane >> 2, jj = lane & 3;
+        const int b = m0 + ul, j = 4 * nt + jj;
+        if (b < a.B) {
+            const float gi_ = e_gi[0] + tile[wave][ul][jj];
+            const float gf_ = e_gi[1] + tile[wave][ul][4 + jj];
+            const float gg_ = e_gi[2] + tile[wave][ul][8 + jj];
+            const float go_ = e_gi[3] + tile[wave][ul][12 + jj];
+            const float ig = dsigmoidf(gi_), fg = dsigmoidf(gf_), gg = dtanhf(gg_), og = dsigmoidf(go_);
+            const float t1 = fg * e_c;
+            const float t2 = ig * gg;
+            const float cnew = t1 + t2;
+            dd_stf<COH>(a.cn + (int64_t)b * a.Hp + j, cnew);
+            dd_stf<COH>(a.out + (int64_t)b * a.Hp + sigma16(j), og * dtanhf(cnew));   // h' in sigma layout (it is only ever a GEMV operand)
+        }
+    }
+}
+
+
+// ---- greedy decision of one utterance (src/tdt.cpp:76-105, src/rnnt.cpp:82-107, src/phrase_boost.cpp:177-350) --------------------
+struct BestLP {
+    float lp;
+    int idx;
+};
+__device__ __forceinline__ BestLP wave_logsoftmax_argmax(const float *__restrict__ x, int n, float *__restrict__ lp_out, int lane) {
+    float m = -__builtin_huge_valf();
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, x[i]);
+    m = wave_max64(m);
+    float p = 0.0f;
+    for (int i = lane; i < n; i += 64) p = p + dexpf(x[i] - m);
+    const float lse = dlogf(wave_sum64(p));
+    float best = -__builtin_huge_valf();
+    int bi = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const float l = (x[i] - m) - lse;
+        if (lp_out) lp_out[i] = l;
+        if (bi == 0x7fffffff || l > best) { best = l; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    return {best, bi};
+}
+
+
+// One utterance's decision of a lock-step decode step, by one 256-thread workgroup; sm = x[V+D], e[V+D], scratch[16] (+ BOOST: mask,
+// active sets).  COH: the words other workgroups of the same launch wrote / will read go through system-scope accesses.
+template <bool BOOST, bool COH>
+__device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float *sm) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (dd_ldi<COH>(st.done + b)) return;
+    const int VD = st.V + st.D;
+    float *x = sm, *e = sm + VD;
+    float *red = e + VD;                                           // [0..3] wave maxima, [4] lse, [8..11] best val, [12..15] best idx
+    const int MW = (st.V + 31) >> 5;
+    unsigned *mask = reinterpret_cast<unsigned *>(red + 16);       // [MW] boosted-token bits
+    int *acts = reinterpret_cast<int *>(mask + MW);                // [kTrieMaxActive] this step's active states
+    int *nx = acts + kTrieMaxActive;                               // [1 + kTrieMaxActive] next active set (count first)
+    int n_act = 0;
+    if constexpr (BOOST) {
+        n_act = st.trie.n_act[b];
+        if (tid < n_act) acts[tid] = st.trie.act[(int64_t)b * kTrieMaxActive + tid];
+        for (int i = tid; i < MW; i += 256) mask[i] = 0u;
+    }
+    const float *lg = st.logits + (int64_t)b * VD;
+    // issue every independent global load up front (state words, candidate LSTM state): each dependent round trip to
+    // L2/HBM costs ~1-2 us in this latency-bound kernel
+    const int t_in = dd_ldi<COH>(st.t + b), steps_in = dd_ldi<COH>(st.steps + b), n_out_in = dd_ldi<COH>(st.n_out + b), nsym_in = dd_ldi<COH>(st.nsym + b);
+    constexpr int kMaxCarry = 12;                                  // L * Hp <= 12 * 256
+    float hcar[kMaxCarry], ccar[kMaxCarry];
+    const int n_state = st.L * st.Hp;
+    if constexpr (!COH) {                                          // (persistent kernel: copied at commit time instead -- 24 fewer live
+#pragma unroll                                                     //  registers, it has to fit beside the encoder's GEMM waves)
+        for (int q = 0; q < kMaxCarry; ++q) {
+            const int i = tid + 256 * q;
+            if (i < n_state) {
+                const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
+                hcar[q] = st.hn[o];
+                ccar[q] = st.cn[o];
+            }
+        }
+    }
+    float m = -__builtin_huge_valf();
+    for (int i = tid; i < VD; i += 256) {
+        const float v = dd_ldf<COH>(lg + i);
+        x[i] = v;
+        if (i < st.V) m = fmaxf(m, v);
+    }
+    m = wave_max64(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int i = tid; i < st.V; i += 256) e[i] = dexpf(x[i] - m);
+    if constexpr (BOOST) {                                         // get_boosted_tokens: union of the children of the active states
+        for (int a = 0; a < n_act; ++a) {
+            const int sn = acts[a];
+            const int c1 = st.trie.off[sn + 1];
+            for (int c = st.trie.off[sn] + tid; c < c1; c += 256) {
+                const int tk = st.trie.tok[c];
+                if (tk >= 0 && tk < st.V) atomicOr(&mask[tk >> 5], 1u << (tk & 31));
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float p = 0.0f;
+        for (int i = lane; i < st.V; i += 64) p = p + e[i];
+        const float lse = dlogf(wave_sum64(p));
+        if (lane == 0) red[4] = lse;
+    }
+    int skip = 1;
+    if (wave == 1 && st.D > 0) {                                   // duration head: a few values, one wavefront
+        const BestLP dur = wave_logsoftmax_argmax(x + st.V, st.D, nullptr, lane);
+        if (lane == 0) red[5] = (float)(dur.idx < st.D ? st.durations[dur.idx] : 1);
+    }
+    __syncthreads();
+    const float lse = red[4];
+    float best = -__builtin_huge_valf();
+    int bi = 0x7fffffff;
+    for (int i = tid; i < st.V; i += 256) {
+        float l = (x[i] - m) - lse;
+        if constexpr (BOOST) l = l + (((mask[i >> 5] >> (i & 31)) & 1u) ? st.trie.boost : 0.0f);
+        if (bi == 0x7fffffff || l > best) { best = l; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { red[8 + wave] = best; red[12 + wave] = __int_as_float(bi); }
+    __syncthreads();
+    BestLP lab{red[8], __float_as_int(red[12])};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float ob = red[8 + w];
+        const int oi = __float_as_int(red[12 + w]);
+        if (ob > lab.lp || (ob == lab.lp && oi < lab.idx)) { lab.lp = ob; lab.idx = oi; }
+    }
+    if constexpr (BOOST) lab.lp = (x[lab.idx] - m) - lse;          // the confidence is the UNBOOSTED log-prob (phrase_boost.cpp:313-315)
+    if (st.D > 0) skip = (int)red[5];
+    const int lane0 = tid;                                         // thread 0 writes the scalar state
+    // scalar control (wave-uniform values; lane 0 writes)
+    int t = t_in;
+    const int nsteps = steps_in + 1;
+    int n_out = n_out_in;
+    int nsym = nsym_in;
+    const bool commit = lab.idx != st.blank;
+    if (!commit) {
+        // blank: the LSTM state reverts -- the candidates hn/cn are simply not committed (src/tdt.cpp:88-93)
+        t += (st.D > 0) ? (skip > 1 ? skip : 1) : 1;
+        nsym = 0;
+    } else {
+        if (lane0 == 0) {
+            if (n_out < st.max_tokens) {
+                const int64_t o = (int64_t)b * st.max_tokens + n_out;
+                st.ids[o] = lab.idx;
+                st.start[o] = t;
+                int e = st.D > 0 ? t + (skip > 1 ? skip : 1) - 1 : t;     // src/tdt.cpp:184-187 ; rnnt.cpp:170 (end = t)
+                st.end[o] = (st.keep_state || e < st.T) ? e : st.T - 1;
+                st.conf[o] = dexpf(lab.lp);                                 // confidence = exp(max log-prob) :169
+            }
+            dd_sti<COH>(st.token + b, lab.idx);
+        }
+        if constexpr (BOOST) {                        // ContextTrie::advance on the emitted token (phrase_boost.cpp:52-66, :336)
+            if (tid == 0) { nx[0] = 1; nx[1] = 0; }   // the root is always active
+            __syncthreads();
+            for (int a = 0; a < n_act; ++a) {
+                const int sn = acts[a];
+                const int c1 = st.trie.off[sn + 1];
+                for (int c = st.trie.off[sn] + tid; c < c1; c += 256)
+                    if (st.trie.tok[c] == lab.idx) {
+                        const int slot = atomicAdd(&nx[0], 1);
+                        if (slot < kTrieMaxActive) nx[1 + slot] = st.trie.node[c];
+                    }
+            }
+            __syncthreads();
+            const int nn = nx[0] < kTrieMaxActive ? nx[0] : kTrieMaxActive;
+            if (tid < nn) st.trie.act[(int64_t)b * kTrieMaxActive + tid] = nx[1 + tid];
+            if (tid == 0) st.trie.n_act[b] = nn;
+        }
+        ++n_out;
+        if (st.D > 0) {
+            if (skip > 0) t += skip;                  // duration 0: emit another symbol on the same frame (:99-105)
+        } else if (++nsym >= st.max_symbols) {        // RNNT: the inner for runs out -> next frame (rnnt.cpp:82-107)
+            t += 1;
+            nsym = 0;
+        }
+        if constexpr (COH) {                          // commit the candidate LSTM state, [L][B][Hp]
+            for (int l = 0; l < st.L; ++l) {
+                const int64_t base = ((int64_t)l * st.B + b) * st.Hp;
+#pragma unroll 2
+                for (int j = tid; j < st.Hp; j += 256) {
+                    dd_stf<true>(st.h + base + j, dd_ldf<true>(st.hn + base + j));
+                    dd_stf<true>(st.c + base + j, dd_ldf<true>(st.cn + base + j));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kMaxCarry; ++q) {
+                const int i = tid + 256 * q;
+                if (i < n_state) {
+                    const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
+                    st.h[o] = hcar[q];
+                    st.c[o] = ccar[q];
+                }
+            }
+        }
+    }
+    if (lane0 == 0) {
+        bool finished = t >= st.T;
+        int len = n_out < st.max_tokens ? n_out : st.max_tokens;
+        if (!finished && st.max_steps > 0 && nsteps >= st.max_steps) { finished = true; len = -1; }   // safety cap
+        dd_sti<COH>(st.t + b, t);
+        dd_sti<COH>(st.steps + b, nsteps);
+        dd_sti<COH>(st.n_out + b, n_out);
+        dd_sti<COH>(st.nsym + b, nsym);
+        if (finished) {
+            st.lens[b] = len;
+            dd_sti<COH>(st.done + b, 1);
+            if constexpr (COH) __hip_atomic_fetch_add(st.done_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else atomicAdd(st.done_count, 1);
+        }
+    }
+}
+
+}  // namespace pk

@@ -133,6 +133,19 @@ struct SkinnyArgs {
 };
 void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s);
 
+// the whole greedy loop of a batch in one launch (kernels/decode_persist.hip): the step-invariant arguments of every phase
+struct TdtPersist {
+    TdtState st;
+    int L;
+    SkinnyArgs cell[4], ih[4];      // per LSTM layer: W_hh product + cell ; (l > 0) W_ih product of the layer below's h'
+    SkinnyArgs act, heads;          // joint activation ; label (+ duration) heads
+    unsigned *bar;                  // grid-barrier arrival counter (zeroed before the launch)
+    int *abort;                     // set by a workgroup whose barrier wait timed out
+    long long timeout_ticks;        // wall_clock64 ticks (100 MHz)
+};
+size_t tdt_persistent_lds_bytes(const TdtState &st);
+void launch_tdt_persistent(const TdtPersist &p, hipStream_t s);
+
 // ---- LayerNorm, canonical reductions, math diagnostics ------------------------------------------
 void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s);
 // y1 = LN(x; g1, b1), y2 = LN(y1; g2, b2) in one pass (y1 may alias x)

@@ -83,3 +83,35 @@ def test_rnnt_head(tmp_path_factory):
         assert np.array_equal(g["ids"][b, :n], o["ids"][b, :n])
         assert np.array_equal(g["start"][b, :n], o["start"][b, :n])
     assert o["lens"].sum() > 0
+
+
+@pytest.mark.parametrize("B", [1, 5, 64, 70])
+def test_persistent_loop_equals_per_phase_loop(tiny_pair, B, monkeypatch):
+    """The single-launch decode loop (kernels/decode_persist.hip: grid barriers, system-scope exchange) against the per-phase launches
+    of the same device code (PK_DEC_PERSISTENT=0) and against the oracle: every output word identical."""
+    W, om, gm = tiny_pair
+    enc = enc_like(B, 57, om.cfg.hidden_size, 100 + B)
+    monkeypatch.setenv("PK_DEC_PERSISTENT", "0")
+    a = gm.tdt_decode(enc)
+    monkeypatch.setenv("PK_DEC_PERSISTENT", "1")
+    b = gm.tdt_decode(enc)
+    for k in ("lens", "steps", "ids", "start", "end"):
+        assert np.array_equal(a[k], b[k]), k
+    G.assert_bits_equal(a["conf"], b["conf"], "confidence")
+    o = check_tdt(gm, om, enc)
+    assert o["lens"].sum() > 0
+
+
+def test_persistent_loop_110m_heads_and_two_layers(tmp_path_factory, monkeypatch):
+    for cfg in (dataclasses.replace(pk.make_110m_config(), num_layers=1, name="110m-1L-persist"),
+                G.tiny(name="tiny-2lstm-persist", num_lstm_layers=2)):
+        W, om, gm = G.make_pair(tmp_path_factory.mktemp("persist"), cfg, seed=9)
+        enc = enc_like(16 if cfg.hidden_size == 512 else 7, 126, cfg.hidden_size, 3)
+        monkeypatch.setenv("PK_DEC_PERSISTENT", "0")
+        a = gm.tdt_decode(enc)
+        monkeypatch.setenv("PK_DEC_PERSISTENT", "1")
+        b = gm.tdt_decode(enc)
+        for k in ("lens", "steps", "ids", "start", "end"):
+            assert np.array_equal(a[k], b[k]), (cfg.name, k)
+        G.assert_bits_equal(a["conf"], b["conf"], "confidence")
+        check_tdt(gm, om, enc)
