@@ -723,7 +723,7 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
             return;
         }
     }
-    const int chunk = 16;
+    const int chunk = 16;            // host polls "all finished" every 16 steps (4 / 64 / 128 measured: no difference, profiles/r02_decode_persistent.md)
     for (int step = 0; step < st.max_steps; ++step) {
         for (int l = 0; l < L; ++l) {
             if (l > 0) KL("lstm_ih_gemv", f_hh, 0.0, launch_skinny_gemm(P.ih[l], SK_BIAS, s));

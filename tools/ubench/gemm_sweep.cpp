@@ -221,6 +221,37 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (argc > 2 && strcmp(argv[2], "bf16") == 0) {   // bf16-operand kernels on the tdt-600m shapes (timing only: W bits are reinterpreted)
+        struct KV { const char *name; std::function<void(const GemmArgs &, hipStream_t)> silu, resid; };
+        const std::vector<KV> kv = {
+            {"bf16 128x128 8w 32x64", launch_gemm_bf16_t<4, 2, 1, 2, EPI_SILU>, launch_gemm_bf16_t<4, 2, 1, 2, EPI_RESID>},
+            {"bf16 128x128 8w 64x32", launch_gemm_bf16_t<2, 4, 2, 1, EPI_SILU>, launch_gemm_bf16_t<2, 4, 2, 1, EPI_RESID>},
+            {"bf16 128x128 4w 64x64", launch_gemm_bf16_t<2, 2, 2, 2, EPI_SILU>, launch_gemm_bf16_t<2, 2, 2, 2, EPI_RESID>},
+            {"bf16 128x64  4w 64x32", launch_gemm_bf16_t<2, 2, 2, 1, EPI_SILU>, launch_gemm_bf16_t<2, 2, 2, 1, EPI_RESID>},
+            {"bf16 64x128  4w 32x64", launch_gemm_bf16_t<2, 2, 1, 2, EPI_SILU>, launch_gemm_bf16_t<2, 2, 1, 2, EPI_RESID>},
+        };
+        struct SH { const char *name; int M, N, K; bool resid; };
+        const std::vector<SH> shs = {{"B fc1 12032x4096x1024 silu", 12032, 4096, 1024, false}, {"B fc2 12032x1024x4096 resid", 12032, 1024, 4096, true},
+                                     {"B qkv 12032x3072x1024", 12032, 3072, 1024, false}, {"B out 12032x1024x1024 resid", 12032, 1024, 1024, true},
+                                     {"A fc1 8064x2048x512 silu", 8064, 2048, 512, false}};
+        for (auto &sh : shs) {
+            printf("== %s  %.1f GFLOP\n", sh.name, 2.0 * sh.M * sh.N * sh.K * 1e-9);
+            for (auto &v : kv) {
+                GemmArgs g{dA, sh.K, dW, sh.K, dB, dO, sh.N, dR, sh.N, 0.5f, sh.M, sh.N, sh.K};
+                auto &run = sh.resid ? v.resid : v.silu;
+                for (int i = 0; i < 3; ++i) run(g, s);
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < reps; ++i) run(g, s);
+                CK(hipEventRecord(e1, s));
+                CK(hipStreamSynchronize(s));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                ms /= reps;
+                printf("   %-28s %8.1f us  %7.1f TF\n", v.name, ms * 1e3, 2.0 * sh.M * sh.N * sh.K / ms * 1e-9);
+            }
+        }
+        return 0;
+    }
     if (argc > 2 && strcmp(argv[2], "ml") == 0) {   // main-loop experiments (GP_EXP builds): production tiles, no epilogue math, two K
         struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
         const std::vector<KV> kv = {{"pipe 128x128 w32x64 512t", run_pipe<4, 2, 1, 2, 32>}, {"pipe 128x128 w64x64 256t", run_pipe<2, 2, 2, 2, 32>},
