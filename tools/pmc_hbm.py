@@ -39,8 +39,8 @@ def main():
     for k in sorted(fetch, key=lambda k: -(fetch[k] * 2 + write.get(k, 0))):
         rd, wr = 2.0 * fetch[k] * 1024.0, write.get(k, 0.0) * 1024.0
         out["kernels"][k] = {"launches_seen": nf[k], "read_bytes": round(rd), "write_bytes": round(wr), "hbm_bytes": round(rd + wr)}
-    fc1 = "gemm_pipe_kernel<4, 2, 1, 2, 32, 2>"
-    if fc1 in out["kernels"]:
+    fc1 = next((k for k in out["kernels"] if k.startswith("gemm_pipe_kernel<4, 2, 1, 2, 32, 2")), None)   # ffn fc1 + SiLU (EPI_SILU = 2)
+    if fc1:
         out["ffn_fc1_silu_bytes_per_launch"] = out["kernels"][fc1]["hbm_bytes"]
         out["ffn_fc1_silu_write_check"] = {"counter_bytes": out["kernels"][fc1]["write_bytes"], "algorithmic_bytes": 8064 * 2048 * 4}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
