@@ -689,10 +689,9 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
         if (l == 0) {
             a.gi = dec.g1; a.gi_ld = 4 * Hp; a.gi_row = st.token;
         } else {
-            SkinnyArgs &g = P.ih[l];
-            g.X = w.hn.as<float>() + (size_t)(l - 1) * B * Hp; g.W = dec_wih_s[l]; g.B = B; g.N = 4 * Hp; g.K = Hp;
-            g.bias = dec.bih[l]; g.out = w.gi.as<float>(); g.ldo = 4 * Hp;
-            a.gi = w.gi.as<float>(); a.gi_ld = 4 * Hp; a.gi_row = nullptr;
+            // upper layer: the input projection W_ih h'(l-1) + b_ih runs inside the cell kernel (second chain of the same tile)
+            a.X2 = w.hn.as<float>() + (size_t)(l - 1) * B * Hp; a.W2 = dec_wih_s[l]; a.bias2 = dec.bih[l];
+            a.gi = nullptr; a.gi_ld = 4 * Hp; a.gi_row = nullptr;
         }
     }
     {
@@ -726,8 +725,7 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
     const int chunk = 16;            // host polls "all finished" every 16 steps (4 / 64 / 128 measured: no difference, profiles/r02_decode_persistent.md)
     for (int step = 0; step < st.max_steps; ++step) {
         for (int l = 0; l < L; ++l) {
-            if (l > 0) KL("lstm_ih_gemv", f_hh, 0.0, launch_skinny_gemm(P.ih[l], SK_BIAS, s));
-            KL("lstm_hh_cell", f_hh, 0.0, launch_skinny_gemm(P.cell[l], SK_CELL, s));
+            KL("lstm_hh_cell", l ? 2.0 * f_hh : f_hh, 0.0, launch_skinny_gemm(P.cell[l], SK_CELL, s));
         }
         KL("joint_pred_act", f_pp, 0.0, launch_skinny_gemm(P.act, SK_ACT, s));
         KL("joint_heads_gemv", f_hd, 0.0, launch_skinny_gemm(P.heads, SK_BIAS, s));

@@ -61,12 +61,12 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
     float e_ep[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_bias = 0.0f;       // SK_ACT / SK_BIAS: lane -> column `col`, utterances 4*kq+r
     if (EPI == SK_CELL) {
         const int b = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
-        if (b < a.B) {
+        if (b < a.B && !a.W2) {
             const float *gir = a.gi + (int64_t)(a.gi_row ? dd_ldi<COH>(a.gi_row + b) : b) * a.gi_ld;
 #pragma unroll
             for (int g = 0; g < 4; ++g) e_gi[g] = a.gi_row ? gir[g * a.Hp + j] : dd_ldf<COH>(gir + g * a.Hp + j);   // layer 0: the constant g1 table
-            e_c = dd_ldf<COH>(a.c + (int64_t)b * a.Hp + j);
         }
+        if (b < a.B) e_c = dd_ldf<COH>(a.c + (int64_t)b * a.Hp + j);
     } else {
         const int n = 16 * nt + col;
         if (n < a.N) {
@@ -84,15 +84,14 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
             }
         }
     }
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     // software pipeline: chunks of 4 float4 pairs (16 MFMAs, ~640 cycles) with the next chunk's loads in flight
     constexpr int CH = 4;
     const int nchunks = a.K / (16 * CH);
     float4 xa[CH], wa[CH], xb[CH], wb[CH];
 #define SK_LOAD(X_, W_, c_)                                                         \
     _Pragma("unroll") for (int i = 0; i < CH; ++i) {                               \
-        X_[i] = dd_ld4<COH>(xp + 4 * ((c_) * CH + i));                                            \
-        W_[i] = wp[4 * ((c_) * CH + i)];                                 \
+        X_[i] = dd_ld4<COH>(xq + 4 * ((c_) * CH + i));                              \
+        W_[i] = wq[4 * ((c_) * CH + i)];                                            \
     }                                                                               \
     __builtin_amdgcn_sched_barrier(0);
 #define SK_MMA(X_, W_)                                                              \
@@ -103,28 +102,44 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(X_[i].w, W_[i].w, acc, 0, 0, 0); \
     }                                                                               \
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NCH > 0) {
-        // two register sets, fully unrolled: chunk c+1 is in flight while chunk c feeds the MFMA chain (>= 640 cycles of cover).
-        // A third set hid more latency but pushed the kernel past 96 VGPRs, and then a decode wave no longer fits next to the
-        // four 104-VGPR waves per SIMD of the 128x128 GEMM of the NEXT batch's encoder (two-stream pipeline): every decode
-        // workgroup had to wait for a GEMM workgroup to retire and then held that slot -- 2.0 ms per 64-clip batch.
-        SK_LOAD(xa, wa, 0)
+    // one single-chain product acc = X W^T over K (natural k order) through the two-set prefetch ring
+    auto chain = [&](const float4 *xq, const float4 *wq) -> f32x4 {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (NCH > 0) {
+            // two register sets, fully unrolled: chunk c+1 is in flight while chunk c feeds the MFMA chain (>= 640 cycles of cover).
+            // A third set hid more latency but pushed the kernel past 96 VGPRs, and then a decode wave no longer fits next to the
+            // four 104-VGPR waves per SIMD of the 128x128 GEMM of the NEXT batch's encoder (two-stream pipeline): every decode
+            // workgroup had to wait for a GEMM workgroup to retire and then held that slot -- 2.0 ms per 64-clip batch.
+            SK_LOAD(xa, wa, 0)
 #pragma unroll
-        for (int c = 0; c < NCH; c += 2) {
-            if (c + 1 < NCH) { SK_LOAD(xb, wb, c + 1) }
-            SK_MMA(xa, wa)
-            if (c + 2 < NCH) { SK_LOAD(xa, wa, c + 2) }
-            if (c + 1 < NCH) { SK_MMA(xb, wb) }
+            for (int c = 0; c < NCH; c += 2) {
+                if (c + 1 < NCH) { SK_LOAD(xb, wb, c + 1) }
+                SK_MMA(xa, wa)
+                if (c + 2 < NCH) { SK_LOAD(xa, wa, c + 2) }
+                if (c + 1 < NCH) { SK_MMA(xb, wb) }
+            }
+        } else {
+            SK_LOAD(xa, wa, 0)
+            for (int c = 0; c < nchunks; c += 2) {
+                if (c + 1 < nchunks) { SK_LOAD(xb, wb, c + 1) }
+                SK_MMA(xa, wa)
+                if (c + 2 < nchunks) { SK_LOAD(xa, wa, c + 2) }
+                if (c + 1 < nchunks) { SK_MMA(xb, wb) }
+            }
         }
-    } else {
-        SK_LOAD(xa, wa, 0)
-        for (int c = 0; c < nchunks; c += 2) {
-            if (c + 1 < nchunks) { SK_LOAD(xb, wb, c + 1) }
-            SK_MMA(xa, wa)
-            if (c + 2 < nchunks) { SK_LOAD(xa, wa, c + 2) }
-            if (c + 1 < nchunks) { SK_MMA(xb, wb) }
-        }
+        return acc;
+    };
+    // SK_CELL of an upper LSTM layer (a.W2 set): the layer's input projection W_ih x + b_ih (x = the h' of the layer below) is the
+    // same kind of chain over the same 16 gate columns -- computed here, before the W_hh chain, instead of in a launch of its own
+    // (one launch and one round trip of gi through memory less per step; the two chains and their sum are the per-phase kernels' own:
+    // gi = chain_ih + b_ih, gates = gi + chain_hh, src/lstm.cpp:15)
+    f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (EPI == SK_CELL && a.W2) {
+        int x2row = m0 + col;
+        x2row = x2row < a.B ? x2row : a.B - 1;
+        acc2 = chain(reinterpret_cast<const float4 *>(a.X2 + (int64_t)x2row * a.K) + kq, reinterpret_cast<const float4 *>(a.W2 + (int64_t)wrow * a.K) + kq);
     }
+    const f32x4 acc = chain(xp, wp);
 #undef SK_LOAD
 #undef SK_MMA
     // C/D layout of 16x16x4: column = lane & 15, row (utterance) = 4 * (lane >> 4) + r
@@ -153,12 +168,24 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
         }
     } else {
         // LSTMCell::forward: gates = (W_ih x + b) + W_hh h ; i,f,g,o ; c' = f*c + i*g ; h' = o*tanh(c')
+        const int ul = lane >> 2, jj = lane & 3;
+        const int b = m0 + ul, j = 4 * nt + jj;
+        if (a.W2) {                                   // upper layer: gi = chain_ih + b_ih, through the same LDS transposition
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][col] = acc2[r];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (b < a.B) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) e_gi[g] = tile[wave][ul][4 * g + jj] + a.bias2[g * a.Hp + j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][col] = acc[r];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int ul = lane >> 2, jj = lane & 3;
-        const int b = m0 + ul, j = 4 * nt + jj;
         if (b < a.B) {
             const float gi_ = e_gi[0] + tile[wave][ul][jj];
             const float gf_ = e_gi[1] + tile[wave][ul][4 + jj];

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
         for (int l = 0; l < 2; ++l) {                     // the launcher admits at most two LSTM layers
             if (l >= p.L || aborted) break;
-            if (l > 0) {
+            if (l > 0 && !p.cell[l].W2) {                 // (input projection not fused into the cell: its own phase)
                 const int n_t = (p.ih[l].N + 15) / 16;
                 for (int nt = wg; nt < n_t; nt += G)
                     for (int mg = 0; mg < n_mg; ++mg) skinny_tile<SK_BIAS, NCH, true>(p.ih[l], nt, mg, tile);
@@ -118,7 +118,7 @@ size_t tdt_persistent_lds_bytes(const TdtState &st) {
 void launch_tdt_persistent(const TdtPersist &p, hipStream_t s) {
     const int G = p.cell[0].Hp / 4;
     const size_t lds = tdt_persistent_lds_bytes(p.st);
-    const bool k640 = p.cell[0].K == 640 && p.act.K == 640 && p.heads.K == 640 && (p.L == 1 || p.ih[1].K == 640);
+    const bool k640 = p.cell[0].K == 640 && p.act.K == 640 && p.heads.K == 640;
     if (k640) hipLaunchKernelGGL(tdt_persistent_kernel<10>, dim3(G), dim3(256), lds, s, p);
     else hipLaunchKernelGGL(tdt_persistent_kernel<0>, dim3(G), dim3(256), lds, s, p);
 }

@@ -130,6 +130,8 @@ struct SkinnyArgs {
     const float *ep; const int *t; int T;
     // SK_CELL (N = 4*Hp)
     const float *gi; int gi_ld; const int *gi_row; const float *c; float *cn; int Hp;
+    // SK_CELL of an upper LSTM layer with the input projection fused in: gi = X2 W2^T + bias2 (X2 [B][K] sigma, W2 [4Hp][K] sigma); W2 null: gi is read
+    const float *X2 = nullptr, *W2 = nullptr, *bias2 = nullptr;
 };
 void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s);
 
