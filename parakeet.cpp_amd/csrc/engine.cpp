@@ -723,13 +723,40 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
         }
     }
     const int chunk = 16;            // host polls "all finished" every 16 steps (4 / 64 / 128 measured: no difference, profiles/r02_decode_persistent.md)
-    for (int step = 0; step < st.max_steps; ++step) {
+    auto enqueue_step = [&]() {
         for (int l = 0; l < L; ++l) {
             KL("lstm_hh_cell", l ? 2.0 * f_hh : f_hh, 0.0, launch_skinny_gemm(P.cell[l], SK_CELL, s));
         }
         KL("joint_pred_act", f_pp, 0.0, launch_skinny_gemm(P.act, SK_ACT, s));
         KL("joint_heads_gemv", f_hd, 0.0, launch_skinny_gemm(P.heads, SK_BIAS, s));
         KL("tdt_decide", 0.0, 0.0, launch_tdt_decide(st, s));
+    };
+    // PK_DEC_GRAPH=1: the chunk of 16 steps is captured once into a hipGraph (every argument is step-invariant) and replayed.
+    static const bool want_graph = [] { const char *e = getenv("PK_DEC_GRAPH"); return e && e[0] == '1'; }();
+    if (want_graph && !prof) {
+        std::vector<unsigned char> key(sizeof(TdtPersist) + sizeof(hipStream_t));
+        memcpy(key.data(), &P, sizeof(TdtPersist));
+        memcpy(key.data() + sizeof(TdtPersist), &s, sizeof(hipStream_t));
+        if (!w.dec_graph || key != w.dec_graph_key) {
+            if (w.dec_graph) { (void)hipGraphExecDestroy(w.dec_graph); w.dec_graph = nullptr; }
+            hipGraph_t graph = nullptr;
+            PK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < chunk; ++i) enqueue_step();
+            PK_HIP(hipStreamEndCapture(s, &graph));
+            PK_HIP(hipGraphInstantiate(&w.dec_graph, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            w.dec_graph_key = key;
+        }
+        for (int step = 0; step < st.max_steps; step += chunk) {
+            PK_HIP(hipGraphLaunch(w.dec_graph, s));
+            PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));
+            PK_HIP(hipStreamSynchronize(s));
+            if (*h_done >= B) break;
+        }
+        return;
+    }
+    for (int step = 0; step < st.max_steps; ++step) {
+        enqueue_step();
         if ((step + 1) % chunk == 0) {                                 // poll "all finished" once per chunk of steps
             PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));
             PK_HIP(hipStreamSynchronize(s));

@@ -51,6 +51,13 @@ struct Workspace {
     DevBuf ctc_logits, ctc_lp, best_idx, best_lp;
     DevBuf ep, gh, gi, pp, z, logits, h, c, hn, cn, ints, ids, start, end, conf, lens;
     DevBuf trie_act;            // phrase boosting: per-utterance active trie states [B][kTrieMaxActive] + counts [B]
+    // captured chunk of decode steps (Model::run_tdt): replayed while the step-invariant kernel arguments stay the same
+    hipGraphExec_t dec_graph = nullptr;
+    std::vector<unsigned char> dec_graph_key;
+    ~Workspace() { if (dec_graph) (void)hipGraphExecDestroy(dec_graph); }
+    Workspace() = default;
+    Workspace(const Workspace &) = delete;
+    Workspace &operator=(const Workspace &) = delete;
     void size_for(const pk_config &cfg, int B, int64_t n_samples, int Tm);
 };
 

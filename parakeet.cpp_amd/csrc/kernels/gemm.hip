@@ -22,6 +22,7 @@
 //    no separate elementwise passes over HBM.
 #include "../pk_devmath.h"
 #include "kernels.hpp"
+#include <cstdlib>
 #include "gemm_pipe.hpp"
 #include "gemm_bf16.hpp"
 
@@ -195,21 +196,42 @@ static void launch_one(const GemmArgs &a, hipStream_t s) {
 // Tile choice, from tools/ubench/gemm_sweep on MI355X (profiles/r01_gemm_sweep.txt): the pipelined kernels win where
 // the K loop is short (most of the encoder is K = 512); wide outputs like 128x128 tiles on 8 waves, long-K / narrow-N
 // products 128x64, everything else 64x64 (more resident workgroups to overlap one tile's epilogue with another's MFMAs).
+// PK_GEMM_VARIANT: A/B switch between the double-buffered ("pipe", NBUF = 2) and single-buffered ("sb", NBUF = 1) staging of the same
+// tiles (tools/experiments/gemm_variant_ab.sh).  Bits: 1 = long-K single-round products (fc2, sub_proj) on sb 128x128 / 8 waves of 32x64 /
+// BK 64; 2 = wide outputs (fc1, qkv, sub_pw) on sb; 4 = out_proj / pw2 on sb 64x128 / 4 waves; 8 = GLU on sb; 16 = wide outputs on sb BK 64.
+// Default 11 = what the engine measurement of round 2 picked (profiles/r02_gemm_variant_ab.txt: step 20.44 -> 19.73 ms; bit 4 is level).
+static int gemm_variant_mask() {
+    static const int m = [] { const char *e = getenv("PK_GEMM_VARIANT"); return e ? atoi(e) : 11; }();
+    return m;
+}
+
 template <int EPI>
 static void launch_epi(const GemmArgs &a, hipStream_t s) {
     if (a.K < 64) { launch_one<64, 64, EPI>(a, s); return; }           // pipelined kernels need >= 2 K tiles
+    const int vm = gemm_variant_mask();
     // measured table: profiles/r01_gemm_sweep_v5.txt (128x128 tile on 8 waves of 32x64 wins for every wide output and for the
     // 321k-row subsampling products; long-K / narrow-N products like fc2 of the 110M model take 128x64)
     // long-K products whose 128x128 tiles fill the chip exactly once (fc2 / sub_proj of the 110M model: 252 tiles for 256 CUs): one
     // 8-wave workgroup per CU with BK = 64 -- half the barriers per k, nothing to share the CU with (-6 % vs two 128x64 workgroups)
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (a.M >= 1024 && a.N >= 256 && a.K >= 1024 && a.K % 64 == 0 && tiles128 <= 256) { launch_gemm_pipe<2, 4, 2, 1, 64, EPI>(a, s); return; }
-    // round 2: the SINGLE-buffered variant of the same tiles (template parameter NBUF = 1: half the LDS, two barriers per K tile) was
-    // 2-3 % ahead in the micro-benchmark (profiles/r02_gemm_sweep_sb.txt) and exactly level in the engine (fc1 163 us either way,
-    // profiles/r02_bench_v2_sb.json): not used.
-    if (a.M >= 1024 && (a.N >= 1024 || (a.M >= 65536 && a.N >= 256))) launch_gemm_pipe<4, 2, 1, 2, 32, EPI>(a, s);
+    if (a.M >= 1024 && a.N >= 256 && a.K >= 1024 && a.K % 64 == 0 && tiles128 <= 256) {
+        if (vm & 1) launch_gemm_pipe<4, 2, 1, 2, 64, EPI, 1>(a, s);
+        else launch_gemm_pipe<2, 4, 2, 1, 64, EPI>(a, s);
+        return;
+    }
+    // round 2: the SINGLE-buffered loop (template parameter NBUF = 1: half the LDS, two barriers per K tile) is ahead of the double-buffered
+    // one on every large shape, in the micro-benchmark (tools/ubench/gemm_sweep ml: main loop 130-135 vs 118-125 TF) and, by less, in the
+    // engine (fc2 -8 %, fc1 -3.6 %, qkv -5 %, GLU -3 %): gemm_variant_mask().
+    if (a.M >= 1024 && (a.N >= 1024 || (a.M >= 65536 && a.N >= 256))) {
+        if ((vm & 16) && a.K % 64 == 0 && a.K >= 128) launch_gemm_pipe<4, 2, 1, 2, 64, EPI, 1>(a, s);
+        else if (vm & 2) launch_gemm_pipe<4, 2, 1, 2, 32, EPI, 1>(a, s);
+        else launch_gemm_pipe<4, 2, 1, 2, 32, EPI>(a, s);
+    }
     else if (a.M >= 1024 && a.N >= 256 && a.K >= 1024) launch_gemm_pipe<2, 2, 2, 1, 32, EPI>(a, s);
-    else if (a.M >= 1024 && a.N >= 256) launch_gemm_pipe<2, 4, 1, 1, 32, EPI>(a, s);      // 64x128 on 8 waves of 32x32: out_proj / pw2 (-7 %)
+    else if (a.M >= 1024 && a.N >= 256) {
+        if (vm & 4) launch_gemm_pipe<2, 2, 1, 2, 32, EPI, 1>(a, s);
+        else launch_gemm_pipe<2, 4, 1, 1, 32, EPI>(a, s);      // 64x128 on 8 waves of 32x32: out_proj / pw2 (-7 %)
+    }
     else launch_gemm_pipe<2, 2, 1, 1, 32, EPI>(a, s);
 }
 
@@ -227,6 +249,7 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
     case EPI_RESID: launch_epi<EPI_RESID>(a, s); break;
     case EPI_GLU:
         if (a.K < 64) launch_one<128, 128, EPI_GLU>(a, s);
+        else if (gemm_variant_mask() & 8) launch_gemm_pipe<4, 2, 1, 2, 32, EPI_GLU, 1>(a, s);
         else launch_gemm_pipe<4, 2, 1, 2, 32, EPI_GLU>(a, s);
         break;
     default: break;

@@ -31,6 +31,8 @@ typedef float gp_f32x16 __attribute__((ext_vector_type(16)));
 __device__ long long gp_clk[4];     // micro-benchmark builds only: shader / wall clock deltas of block 0
 __device__ long long *gp_trace;     // micro-benchmark builds only: [n_blocks][8] wall-clock stamps of wave 0 + hw id
 #define GP_STAMP(i) do { if (gp_trace && tid == 0) gp_trace[(long long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+__device__ long long *gp_tr2;       // micro-benchmark builds only: [n_blocks][16 waves][GP_TR2_IT][2] shader-clock stamps around the K-loop barrier
+#define GP_TR2_IT 24
 #else
 #define GP_STAMP(i) do { } while (0)
 #endif
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     };
 
     gp_f32x16 acc[TM][TN];
+    if (GP_EXP & 256) { float d_; asm volatile("; keep AGPRs allocatable %0" : "=a"(d_)); }
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -320,6 +323,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     const long long c0_ = clock64(), w0_ = wall_clock64();
 #endif
     int m0, n0;
+#ifdef GP_DELAY_TICKS
+    // experiment: the second workgroup of every CU (blocks 256..511 of the first round) starts GP_DELAY_TICKS x 10 ns late, so that the
+    // two co-resident workgroups do not reach their epilogues together
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+        const long long t0_ = wall_clock64();
+        while (wall_clock64() - t0_ < GP_DELAY_TICKS) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     GP_STAMP(0);
     set_tile(blockIdx.x, m0, n0);
     gload(0);
@@ -359,7 +370,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
                 if (!(GP_EXP & 16) && s == NSUB - 2 && more1) lstore(cur ^ 1);
                 GP_SB(); if (!(GP_EXP & 128)) mma(s & 1); GP_SB();
             }
+#ifdef GP_CLOCKPROBE
+            unsigned long long tA_ = 0, tB_ = 0;
+            if (gp_tr2) asm volatile("s_memtime %0" : "=s"(tA_));
+#endif
             if (!(GP_EXP & 8)) __syncthreads();
+#ifdef GP_CLOCKPROBE
+            if (gp_tr2) {
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB_));
+                if (lane == 0 && kt < GP_TR2_IT) {
+                    long long *d = gp_tr2 + (((long long)blockIdx.x * 16 + wave) * (GP_TR2_IT + 1) + kt) * 2;
+                    d[0] = (long long)tA_;
+                    d[1] = (long long)tB_;
+                }
+            }
+#endif
             if (!(GP_EXP & 64) && more1) fragload(cur ^ 1, 0, 0);
             if (!(GP_EXP & 32) && more2) gload(kt + 2);
             GP_SB(); if (!(GP_EXP & 128)) mma((NSUB - 1) & 1); GP_SB();
@@ -372,6 +397,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
 #undef GP_SB
 #ifdef GP_CLOCKPROBE
     if (blockIdx.x == 0 && tid == 0) { gp_clk[0] = clock64() - c0_; gp_clk[1] = wall_clock64() - w0_; }
+    if (gp_tr2 && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        gp_tr2[(((long long)blockIdx.x * 16 + wave) * (GP_TR2_IT + 1) + GP_TR2_IT) * 2] = (long long)hw | ((long long)(xcc & 0xf) << 32);
+    }
     if (gp_trace && tid == 0) {
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void mfma_clock_kernel(long long *out, int ite
     if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)s; }
 }
 
+__global__ void stamp_kernel(long long *out) { out[0] = wall_clock64(); }
+
 struct Shape { const char *name; int M, N, K, epi; };
 struct Variant { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
 
@@ -198,7 +200,8 @@ int main(int argc, char **argv) {
     if (argc > 2 && strcmp(argv[2], "trace") == 0) {   // per-workgroup timeline of one launch -> gpurun_out/gemm_trace_<name>.bin
         struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; int nblk; };
         const std::vector<KV> kv = {{"p128x128_512t", run_pipe<2, 4, 2, 1, 32>, 63 * 16}, {"p64x64", run_pipe<2, 2, 1, 1, 32>, 126 * 32},
-                                    {"p128x128_w64x64", run_pipe<2, 2, 2, 2, 32>, 63 * 16}, {"p128x128_w32x64_512t", run_pipe<4, 2, 1, 2, 32>, 63 * 16},};
+                                    {"p128x128_w64x64", run_pipe<2, 2, 2, 2, 32>, 63 * 16}, {"p128x128_w32x64_512t", run_pipe<4, 2, 1, 2, 32>, 63 * 16},
+                                    {"sb128x128_w32x64_512t", run_sb<4, 2, 1, 2, 32>, 63 * 16}, {"sb256x256_512t", run_sb<2, 4, 4, 2, 32>, 32 * 8}};
         long long *dtrace;
         CK(hipMalloc(&dtrace, 8192 * 8 * 8));
         for (auto &v : kv) {
@@ -209,15 +212,78 @@ int main(int argc, char **argv) {
             CK(hipStreamSynchronize(s));
             CK(hipMemset(dtrace, 0, 8192 * 8 * 8));
             CK(hipMemcpyToSymbol(HIP_SYMBOL(gp_trace), &dtrace, 8));
+            v.run(g, EPI_SILU, s);                                               // (warm: the symbol copy above idled the queue)
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, dtrace + 8192 * 8 - 8);
             v.run(g, EPI_SILU, s);
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, dtrace + 8192 * 8 - 7);
             CK(hipStreamSynchronize(s));
-            std::vector<long long> h((size_t)v.nblk * 8);
-            CK(hipMemcpy(h.data(), dtrace, h.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<long long> h((size_t)v.nblk * 8 + 2);
+            CK(hipMemcpy(h.data(), dtrace, (size_t)v.nblk * 8 * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h.data() + (size_t)v.nblk * 8, dtrace + 8192 * 8 - 8, 16, hipMemcpyDeviceToHost));
             std::string fn = std::string("gpurun_out/gemm_trace_") + v.name + ".bin";
             FILE *f = fopen(fn.c_str(), "wb");
             fwrite(h.data(), 8, h.size(), f);
             fclose(f);
             printf("wrote %s (%d blocks)\n", fn.c_str(), v.nblk);
+        }
+        return 0;
+    }
+    if (argc > 2 && strcmp(argv[2], "cold") == 0) {   // weights hot (same W every launch) vs cold (a different 4 MB W of a 512 MB pool per launch)
+        float *pool;
+        const size_t wfl = (size_t)2048 * 512, NPOOL = 128;
+        CK(hipMalloc(&pool, wfl * 4 * NPOOL));
+        for (size_t i = 0; i < NPOOL; ++i) CK(hipMemcpy(pool + i * wfl, dW, wfl * 4, hipMemcpyDeviceToDevice));
+        struct SH { const char *name; int N, K, epi; std::function<void(const GemmArgs &, int, hipStream_t)> run; };
+        const std::vector<SH> shs = {{"fc1 sb 128x128 w32x64", 2048, 512, EPI_SILU, run_sb<4, 2, 1, 2, 32>}, {"fc1 pipe 128x128 w32x64", 2048, 512, EPI_SILU, run_pipe<4, 2, 1, 2, 32>},
+                                     {"fc2 sb 128x128 w32x64 bk64", 512, 2048, EPI_RESID, run_sb<4, 2, 1, 2, 64>}, {"fc2 pipe 128x128 w64x32 bk64", 512, 2048, EPI_RESID, run_pipe<2, 4, 2, 1, 64>},
+                                     {"qkv sb 128x128 w32x64", 1536, 512, EPI_NONE, run_sb<4, 2, 1, 2, 32>}};
+        for (auto &sh : shs)
+            for (int cold = 0; cold < 3; ++cold) {      // 0 hot, 1 cold W, 2 cold W + the A operand overwritten (device memset = L2/MALL churn) before every launch
+                float tot = 0;
+                for (int i = 0; i < reps + 2; ++i) {
+                    GemmArgs g{dA, sh.K, cold ? pool + (size_t)(i % NPOOL) * wfl : dW, sh.K, dB, dO, sh.N, dR, sh.N, 0.5f, 8064, sh.N, sh.K};
+                    if (cold == 2) CK(hipMemsetAsync(dRef, 0, (size_t)64 << 20, s));
+                    CK(hipEventRecord(e0, s));
+                    sh.run(g, sh.epi, s);
+                    CK(hipEventRecord(e1, s));
+                    CK(hipStreamSynchronize(s));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (i >= 2) tot += ms;
+                }
+                printf("%-32s %s : %.1f us\n", sh.name, cold == 0 ? "hot W        " : cold == 1 ? "cold W       " : "cold W + churn", tot / reps * 1e3);
+            }
+        return 0;
+    }
+    if (argc > 2 && strcmp(argv[2], "trace2") == 0) {   // per-wave shader-clock stamps around the K-loop barrier -> gpurun_out/gemm_tr2_<name>.bin
+        struct KV { const char *name; std::function<void(const GemmArgs &, int, hipStream_t)> run; int nblk; };
+        const std::vector<KV> kv = {{"w32x64_512t", run_pipe<4, 2, 1, 2, 32>, 63 * 16}, {"w64x64_256t", run_pipe<2, 2, 2, 2, 32>, 63 * 16}};
+        long long *dtr, *dtrace;
+        const size_t n2 = (size_t)1008 * 16 * (GP_TR2_IT + 1) * 2;
+        CK(hipMalloc(&dtr, n2 * 8));
+        CK(hipMalloc(&dtrace, 8192 * 8 * 8));
+        for (auto &v : kv) {
+            GemmArgs g{dA, 2048, dW, 2048, dB, dO, 2048, dR, 2048, 0.5f, 8064, 2048, 2048};
+            for (int i = 0; i < 3; ++i) v.run(g, EPI_NONE, s);
+            CK(hipStreamSynchronize(s));
+            CK(hipMemset(dtr, 0, n2 * 8));
+            CK(hipMemset(dtrace, 0, 8192 * 8 * 8));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(gp_tr2), &dtr, 8));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(gp_trace), &dtrace, 8));
+            v.run(g, EPI_NONE, s);
+            CK(hipStreamSynchronize(s));
+            long long *null = nullptr;
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(gp_tr2), &null, 8));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(gp_trace), &null, 8));
+            std::vector<long long> h(n2), h1((size_t)v.nblk * 8);
+            CK(hipMemcpy(h.data(), dtr, n2 * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h1.data(), dtrace, h1.size() * 8, hipMemcpyDeviceToHost));
+            std::string fn = std::string("gpurun_out/gemm_tr2_") + v.name + ".bin";
+            FILE *f = fopen(fn.c_str(), "wb");
+            fwrite(h.data(), 8, h.size(), f);
+            fwrite(h1.data(), 8, h1.size(), f);
+            fclose(f);
+            printf("wrote %s\n", fn.c_str());
         }
         return 0;
     }
@@ -257,15 +323,31 @@ int main(int argc, char **argv) {
         const std::vector<KV> kv = {{"pipe 128x128 w32x64 512t", run_pipe<4, 2, 1, 2, 32>}, {"pipe 128x128 w64x64 256t", run_pipe<2, 2, 2, 2, 32>},
                                     {"pipe 64x64 w32x32 256t", run_pipe<2, 2, 1, 1, 32>}, {"sb 128x128 w64x64 256t", run_sb<2, 2, 2, 2, 32>},
                                     {"sb 64x128 w32x64 256t", run_sb<2, 2, 1, 2, 32>}, {"sb 128x128 w32x64 512t", run_sb<4, 2, 1, 2, 32>},
+                                    {"pipe 128x256 w64x128 256t", run_pipe<2, 2, 2, 4, 32>}, {"pipe 256x128 w128x64 256t", run_pipe<2, 2, 4, 2, 32>},
+                                    {"pipe 128x256 w64x64 512t", run_pipe<2, 4, 2, 2, 32>}, {"pipe 256x256 w128x64 512t", run_pipe<2, 4, 4, 2, 32>},
+                                    {"sb 256x256 w128x64 512t", run_sb<2, 4, 4, 2, 32>}, {"sb 128x256 w64x128 256t", run_sb<2, 2, 2, 4, 32>},
                                     {"dma 128x128 w64x64 256t", run_dma<2, 2, 2, 2>}, {"dma 128x128 w32x64 512t", run_dma<4, 2, 1, 2>},
                                     {"dma 64x128 w32x64 256t", run_dma<2, 2, 1, 2>}};
+        const int mlN = argc > 4 ? atoi(argv[4]) : 2048, Klo = argc > 5 ? atoi(argv[5]) : 512, Khi = argc > 6 ? atoi(argv[6]) : 2048;
+        std::vector<KV> kv2 = kv;
+        if (argc > 4) {
+            kv2 = {{"pipe 128x128 w64x32 512t bk64", run_pipe<2, 4, 2, 1, 64>}, {"sb 128x128 w64x32 512t bk64", run_sb<2, 4, 2, 1, 64>},
+                   {"pipe 128x128 w32x64 512t", run_pipe<4, 2, 1, 2, 32>}, {"sb 128x128 w32x64 512t", run_sb<4, 2, 1, 2, 32>},
+                   {"sb 128x128 w32x64 512t bk64", run_sb<4, 2, 1, 2, 64>},
+                   {"pipe 128x128 w64x64 256t", run_pipe<2, 2, 2, 2, 32>}, {"sb 128x128 w64x64 256t", run_sb<2, 2, 2, 2, 32>},
+                   {"sb 128x128 w64x64 256t bk64", run_sb<2, 2, 2, 2, 64>},
+                   {"pipe 64x128 w32x32 512t", run_pipe<2, 4, 1, 1, 32>}, {"sb 64x128 w32x64 256t", run_sb<2, 2, 1, 2, 32>},
+                   {"pipe 128x64 w64x32 256t", run_pipe<2, 2, 2, 1, 32>}, {"sb 128x64 w64x32 256t", run_sb<2, 2, 2, 1, 32>},
+                   {"sb 256x256 w128x64 512t", run_sb<2, 4, 4, 2, 32>}, {"sb 256x128 w128x32 512t", run_sb<2, 4, 4, 1, 32>},
+                   {"sb 256x128 w64x64 512t", run_sb<4, 2, 2, 2, 32>}, {"sb 128x256 w64x64 512t", run_sb<2, 4, 2, 2, 32>}};
+        }
         for (int epi : {(int)EPI_NONE, (int)EPI_SILU, (int)EPI_RESID})
-        for (auto &v : kv) {
-            printf("ml GP_EXP=%d epi=%d %-28s:", GP_EXP, epi, v.name);
+        for (auto &v : kv2) {
+            printf("ml GP_EXP=%d N=%d epi=%d %-30s:", GP_EXP, mlN, epi, v.name);
             float t[2];
             int i2 = 0;
-            for (int K : {512, 2048}) {
-                GemmArgs g{dA, K, dW, K, dB, dO, 2048, dR, 2048, 0.5f, 8064, 2048, K};
+            for (int K : {Klo, Khi}) {
+                GemmArgs g{dA, K, dW, K, dB, dO, mlN, dR, mlN, 0.5f, 8064, mlN, K};
                 for (int i = 0; i < 2; ++i) v.run(g, epi, s);
                 CK(hipEventRecord(e0, s));
                 for (int i = 0; i < reps; ++i) v.run(g, epi, s);
@@ -274,11 +356,11 @@ int main(int argc, char **argv) {
                 float ms;
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 t[i2++] = ms / reps * 1e3f;
-                printf("  K=%d %.1fus", K, ms / reps * 1e3);
+                printf("  K=%d %.1fus (%.1f TF)", K, ms / reps * 1e3, 2.0 * 8064 * mlN * K / (ms / reps) * 1e-9);
             }
-            const double slope = (t[1] - t[0]) / 1536.0;                      // us per k
-            printf("  | main loop %.1f TF, fixed %.1f us\n", 2.0 * 8064 * 2048 / slope * 1e-6, t[0] - slope * 512);
-            if (argc > 3 && epi != EPI_NONE) continue;
+            const double slope = (t[1] - t[0]) / (double)(Khi - Klo);                      // us per k
+            printf("  | main loop %.1f TF, fixed %.1f us\n", 2.0 * 8064 * mlN / slope * 1e-6, t[0] - slope * Klo);
+            if (argc > 3 && argv[3][0] == 'x' && epi != EPI_NONE) continue;
         }
         return 0;
     }
