@@ -12,6 +12,7 @@
 #define GP_CLOCKPROBE 1
 #include "../../parakeet.cpp_amd/csrc/kernels/gemm.hip"
 #include "gemm_dma.hpp"
+#include "gemm_pd.hpp"
 #include "../../parakeet.cpp_amd/csrc/kernels/gemm_smallm.hip"   // first-generation kernel + launch_gemm
 
 using namespace pk;
@@ -84,6 +85,17 @@ static void run_dma(const GemmArgs &a, int epi, hipStream_t s) {      // direct-
     case EPI_RESID: launch_gemm_dma<WGM, WGN, TM, TN, EPI_RESID>(a, s); break;
     case EPI_GLU: if constexpr (TN % 2 == 0) launch_gemm_dma<WGM, WGN, TM, TN, EPI_GLU>(a, s); break;
     }
+}
+static void run_pd(const GemmArgs &a, int epi, hipStream_t s) {       // persistent workgroups, direct epilogue (gemm_pd.hpp); falls back to sb
+    bool ok = false;
+    switch (epi) {
+    case EPI_NONE: ok = launch_gemm_pd<EPI_NONE>(a, s); break;
+    case EPI_RELU: ok = launch_gemm_pd<EPI_RELU>(a, s); break;
+    case EPI_SILU: ok = launch_gemm_pd<EPI_SILU>(a, s); break;
+    case EPI_RESID: ok = launch_gemm_pd<EPI_RESID>(a, s); break;
+    default: break;
+    }
+    if (!ok) run_sb<4, 2, 1, 2, 32>(a, epi, s);
 }
 template <int BM, int BN>
 static void run_old(const GemmArgs &a, int epi, hipStream_t s) {
@@ -166,6 +178,7 @@ int main(int argc, char **argv) {
         {"sb   128x128 w64x64 bk32 256t 512t-class", run_sb<2, 2, 2, 2, 32>},
         {"sb   64x128  w32x64 bk32 256t 512t-class", run_sb<2, 2, 1, 2, 32>},
         {"sb   128x128 w32x64 bk32 512t", run_sb<4, 2, 1, 2, 32>},
+        {"pd   128x128 w32x64 bk32 512t persistent", run_pd},
         {"sb   128x128 w64x32 bk32 512t", run_sb<2, 4, 2, 1, 32>},
         {"sb   256x128 w64x64 bk32 512t", run_sb<4, 2, 2, 2, 32>},
         {"sb   128x256 w64x64 bk32 512t", run_sb<2, 4, 2, 2, 32>},
@@ -331,7 +344,7 @@ int main(int argc, char **argv) {
         const int mlN = argc > 4 ? atoi(argv[4]) : 2048, Klo = argc > 5 ? atoi(argv[5]) : 512, Khi = argc > 6 ? atoi(argv[6]) : 2048;
         std::vector<KV> kv2 = kv;
         if (argc > 4) {
-            kv2 = {{"pipe 128x128 w64x32 512t bk64", run_pipe<2, 4, 2, 1, 64>}, {"sb 128x128 w64x32 512t bk64", run_sb<2, 4, 2, 1, 64>},
+            kv2 = {{"pd 128x128 w32x64 512t persistent", run_pd}, {"pipe 128x128 w64x32 512t bk64", run_pipe<2, 4, 2, 1, 64>}, {"sb 128x128 w64x32 512t bk64", run_sb<2, 4, 2, 1, 64>},
                    {"pipe 128x128 w32x64 512t", run_pipe<4, 2, 1, 2, 32>}, {"sb 128x128 w32x64 512t", run_sb<4, 2, 1, 2, 32>},
                    {"sb 128x128 w32x64 512t bk64", run_sb<4, 2, 1, 2, 64>},
                    {"pipe 128x128 w64x64 256t", run_pipe<2, 2, 2, 2, 32>}, {"sb 128x128 w64x64 256t", run_sb<2, 2, 2, 2, 32>},
