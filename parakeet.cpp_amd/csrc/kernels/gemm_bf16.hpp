@@ -7,13 +7,14 @@
 // operand rounding plus the summation order inside v_mfma_f32_32x32x16_bf16 (not a sequential chain): results are
 // compared with the oracle's bf16 mode within a stated tolerance, not bit for bit (tests/test_gpu_bf16.py).
 //
-// Structure = gemm_pipe.hpp (register-double-buffered fragments, LDS double buffer, one barrier per K tile, epilogue
+// Structure = gemm_pipe.hpp (register-double-buffered fragments, LDS double buffer, one barrier per K tile, its epilogue
 // through LDS with 16-byte stores), with BK = 64: a tile row is 64 bf16 = 128 B (+16 B pad: the same 144-byte pitch, so
 // the conflict-free ds_read_b128 analysis carries over); lane (row, h) reads the 8 consecutive k = 16s + 8h .. +7 of
 // MFMA step s with one ds_read_b128 -- bf16 needs no K permutation.
 #pragma once
 #include "../pk_devmath.h"
 #include "kernels.hpp"
+#include "gemm_pipe.hpp"
 
 namespace pk {
 
@@ -145,106 +146,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
     }
 #undef BG_SB
 
-    // ---- epilogue: accumulators -> LDS (row-major fp32 C tile) -> 4 consecutive columns per thread ------------------------------
-    constexpr int CP = BN + 4;
-    static_assert((size_t)BM * CP * 4 <= 2 * (size_t)BUF * 2, "C tile must fit in the staging buffers");
-    const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);
-    constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT, RSTEP = NT / C4;
-    static_assert((BM * C4) % NT == 0 && NT % C4 == 0, "output tile must split evenly over the threads");
-    // as in gemm_pipe.hpp: a thread owns the same 4 columns in all its chunks; bias and (wide) residual rows are requested before the
-    // LDS transposition so their latency overlaps it
-    const int c4 = tid % C4, rl0 = tid / C4;
-    const int col0 = n0 + 4 * c4;
-    const bool sig = col0 < g.sigma_cols;
-    int vcol[4], ncol[4];
-    float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (sig) {                                                   // sigma layout: position 16b + 4a + e holds natural column 16b + 4e + a
-            vcol[e] = ((4 * c4) & ~15) + 4 * e + (c4 & 3);
-            ncol[e] = n0 + vcol[e];
-        } else {
-            vcol[e] = 4 * c4 + e;
-            ncol[e] = col0 + e;
-            if constexpr (EPI == EPI_GLU) vcol[e] = (vcol[e] / (WN / 2)) * WN + vcol[e] % (WN / 2);
-        }
-        if (g.bias && ncol[e] < g.N) {
-            bs[e] = g.bias[ncol[e]];
-            if constexpr (EPI == EPI_GLU) bg[e] = g.bias[g.N + ncol[e]];
-        }
-    }
-    float4 rs[NCH];
-    if constexpr (EPI == EPI_RESID) {
-        if (wide && !sig) {
-#pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                int row = m0 + rl0 + q * RSTEP;
-                row = row < g.M ? row : g.M - 1;
-                rs[q] = col0 < g.N ? *reinterpret_cast<const float4 *>(g.resid + (int64_t)row * g.ldr + col0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        }
-    }
-    __syncthreads();
-    {
-        const int lc = lane & 31, lr = 4 * (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    smem_f[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + lr) * CP + wn * WN + j * 32 + lc] = acc[i][j][r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-        const int rl = rl0 + q * RSTEP;
-        const int row = m0 + rl;
-        if (row >= g.M || col0 >= g.N) continue;
-        float v[4], gt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = smem_f[rl * CP + vcol[e]];
-            if constexpr (EPI == EPI_GLU) gt[e] = smem_f[rl * CP + vcol[e] + WN / 2];
-        }
-        float rsv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if constexpr (EPI == EPI_RESID) {
-            if (wide && !sig) { rsv[0] = rs[q].x; rsv[1] = rs[q].y; rsv[2] = rs[q].z; rsv[3] = rs[q].w; }
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rsv[e] = ncol[e] < g.N ? g.resid[(int64_t)row * g.ldr + ncol[e]] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (ncol[e] >= g.N) continue;
-            float x = v[e];
-            if (g.bias) x = x + bs[e];
-            if constexpr (EPI == EPI_RELU) {
-                x = x > 0.0f ? x : 0.0f;
-            } else if constexpr (EPI == EPI_SILU) {
-                x = dsiluf(x);
-            } else if constexpr (EPI == EPI_RESID) {
-                x = rsv[e] + x * g.alpha;
-            } else if constexpr (EPI == EPI_GLU) {
-                float t2 = gt[e];
-                if (g.bias) t2 = t2 + bg[e];
-                x = x * dsigmoidf(t2);
-            }
-            v[e] = x;
-        }
-        if (wide) {
-            *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int col = col0 + e;
-                if (col >= g.N) continue;
-                if (g.remap_rows) g.out[(int64_t)(row / g.remap_rows) * g.remap_gs + (int64_t)(row % g.remap_rows) * g.remap_rs + (int64_t)col * g.remap_cs] = v[e];
-                else g.out[(int64_t)row * g.ldo + col] = v[e];
-            }
-        }
-    }
+    // epilogue shared with the fp32 kernels (gemm_pipe.hpp): accumulators -> LDS -> 4 consecutive columns per thread, in row bands when the
+    // C tile is larger than the staging buffers
+    gp_epilogue<WGM, WGN, TM, TN, EPI, BUF>(g, acc, smem_f, m0, n0);     // 2 buffers x BUF bf16 = BUF floats
 }
 
 template <int WGM, int WGN, int TM, int TN, int EPI>

@@ -308,6 +308,12 @@ int main(int argc, char **argv) {
             {"bf16 128x128 4w 64x64", launch_gemm_bf16_t<2, 2, 2, 2, EPI_SILU>, launch_gemm_bf16_t<2, 2, 2, 2, EPI_RESID>},
             {"bf16 128x64  4w 64x32", launch_gemm_bf16_t<2, 2, 2, 1, EPI_SILU>, launch_gemm_bf16_t<2, 2, 2, 1, EPI_RESID>},
             {"bf16 64x128  4w 32x64", launch_gemm_bf16_t<2, 2, 1, 2, EPI_SILU>, launch_gemm_bf16_t<2, 2, 1, 2, EPI_RESID>},
+            {"bf16 256x256 8w 128x64", launch_gemm_bf16_t<2, 4, 4, 2, EPI_SILU>, launch_gemm_bf16_t<2, 4, 4, 2, EPI_RESID>},
+            {"bf16 256x256 8w 64x128", launch_gemm_bf16_t<4, 2, 2, 4, EPI_SILU>, launch_gemm_bf16_t<4, 2, 2, 4, EPI_RESID>},
+            {"bf16 128x256 4w 64x128", launch_gemm_bf16_t<2, 2, 2, 4, EPI_SILU>, launch_gemm_bf16_t<2, 2, 2, 4, EPI_RESID>},
+            {"bf16 256x128 4w 128x64", launch_gemm_bf16_t<2, 2, 4, 2, EPI_SILU>, launch_gemm_bf16_t<2, 2, 4, 2, EPI_RESID>},
+            {"bf16 128x256 8w 64x64", launch_gemm_bf16_t<2, 4, 2, 2, EPI_SILU>, launch_gemm_bf16_t<2, 4, 2, 2, EPI_RESID>},
+            {"bf16 256x128 8w 64x64", launch_gemm_bf16_t<4, 2, 2, 2, EPI_SILU>, launch_gemm_bf16_t<4, 2, 2, 2, EPI_RESID>},
         };
         struct SH { const char *name; int M, N, K; bool resid; };
         const std::vector<SH> shs = {{"B fc1 12032x4096x1024 silu", 12032, 4096, 1024, false}, {"B fc2 12032x1024x4096 resid", 12032, 1024, 4096, true},
