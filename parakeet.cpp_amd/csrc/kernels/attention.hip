@@ -23,6 +23,16 @@ namespace pk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int RB = 32;   // query rows per workgroup
+#ifndef ATT_OCC
+#define ATT_OCC 3                 // workgroups per CU the hd <= 64 kernel is compiled for (register budget 168 / 128 VGPRs for 3 / 4)
+#endif
+
+#ifdef ATT_TRACE
+__device__ long long *att_trace;    // micro-benchmark builds only (tools/ubench/attn_bench): [workgroup][wave][8] shader-clock stamps
+#define ATT_STAMP(i) do { if (att_trace && lane == 0) att_trace[((long long)blockIdx.x * 4 + wave) * 8 + (i)] = clock64(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
@@ -30,7 +40,7 @@ __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v
 // code, indexing and barriers (a workgroup's own global writes are visible to it after __syncthreads()), so the same bits; slower,
 // but the length is then bounded by HBM, not by the 160 KB of LDS.
 template <int HD, int VCH, bool SG = false>
-__global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel(const float *__restrict__ qkv, int ldq, int d, int T,
+__global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_kernel(const float *__restrict__ qkv, int ldq, int d, int T,
                                                                const float *__restrict__ pos /*[2T-1][d], sigma columns*/,
                                                                const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                float scale, float *__restrict__ ctx, int PITS, int n_rb, int n_bh,
@@ -106,6 +116,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel
     };
 
     // ---- phase 0: V chunk 0 and the Q fragments (q+u), (q+v) of this wave's 16 rows --------------------------------------
+    ATT_STAMP(0);
     v_issue(0);
     float4 qu[NQ4], qv[NQ4];
     {
@@ -129,6 +140,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel
     float4 bA0[NQ4], bA1[NQ4], bB0[NQ4], bB1[NQ4];                  // two operand-tile pairs: one computing, one in flight
 
     // ---- phase 1: content scores (q+u) K^T -> S; this wave's column tiles are t = cp, cp+2, ... (pairs, one pair ahead) ----
+    ATT_STAMP(1);
     {
         const int nct = (T + 15) / 16;
         auto store = [&](int t, const f32x4 &a0, const f32x4 &a1) {
@@ -154,6 +166,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel
             }
         }
     }
+    ATT_STAMP(2);
     v_commit();
     // ---- phase 2: position scores (q+v) P^T, shifted, combined and scaled.  This wave's 16 query rows need
     //      p = j - i + T - 1 in [wpmin, wpmax] (T+15 rows): its own tile grid starts at wpmin, tiles t = cp, cp+2, ... ------
@@ -162,6 +175,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel
     const int npt = (pos && w_lo < T) ? (wpmax - wpmin) / 16 + 1 : 0;
     if (cp < npt) { load_tile(pb, d, wpmin + cp * 16, P, bA0); load_tile(pb, d, wpmin + (cp + 2) * 16, P, bA1); }   // in flight across the barrier
     __syncthreads();                                              // content scores complete; V chunk 0 visible
+    ATT_STAMP(3);
     {
         auto rmw = [&](int t, const f32x4 &a0, const f32x4 &a1) {
 #pragma unroll
@@ -191,7 +205,9 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel
             }
         }
     }
+    ATT_STAMP(4);
     __syncthreads();
+    ATT_STAMP(5);
     // ---- phase 3: softmax, one wavefront per row ----------------------------------------------------------------------------
     // Each wave owns rows wave, wave+4, ...: all NSR of them go through the three sweeps TOGETHER, so the 2 x 6 dependent
     // cross-lane butterfly stages and the exp / divide chains of different rows overlap instead of queueing up.
@@ -229,6 +245,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel
                 S[a] = S[a] / sm[k];
             }
     }
+    ATT_STAMP(6);
     __syncthreads();
     // ---- phase 4: ctx = softmax(S) V  (k = key index, natural order; NDV independent 16-column tiles per wave) ---------------
     f32x4 acc[NDV];
@@ -264,6 +281,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? 3 : 2) void relpos_attention_kernel
             const int il = il_base + r;
             if (il < rows) ctx[((int64_t)b * T + i0 + il) * d + h * HD + (cp + 2 * m) * 16 + l15] = acc[m][r];
         }
+    ATT_STAMP(7);
 }
 
 template <int HD, int VCH>
