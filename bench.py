@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="pk_config.gemm_bf16: encoder products on bf16 operands / fp32 accumulation "
                     "(the precision BASELINE configs[2] names); the headline metric stays fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-group", type=int, default=int(os.environ.get("PK_BENCH_DECODE_GROUP", "4")),
+                    help="pk_batch_set_decode_group: TDT loops of this many consecutive steps decoded as one lock-step batch (1 = per step)")
     args = ap.parse_args()
     global CLIP_SECONDS, CLIP_SAMPLES, ENCODER_FLOP_PER_CLIP, D_MODEL, FFN, ENC_FRAMES
     exit_code = [0]
@@ -193,6 +195,9 @@ def main():
     pcm = synth.synth_pcm(args.batch, CLIP_SAMPLES, seed=1234 + rank)
     capi.check(L.pk_batch_upload(batch, pcm.ctypes.data_as(capi.f32p), args.batch))
     dec = 1 if args.decoder == "tdt" else 0
+    group = max(1, args.decode_group) if dec == 1 else 1
+    if group > 1:
+        capi.check(L.pk_batch_set_decode_group(batch, group))
 
     for _ in range(args.warmup):
         capi.check(L.pk_batch_run(batch, dec))
@@ -204,6 +209,16 @@ def main():
     capi.check(L.pk_batch_sync(batch))
     barrier()
     elapsed = time.perf_counter() - t0
+    # the token ids the TIMED steps produced (the runs of the last decode group), before the untimed profiling passes below
+    timed_ids = []
+    if dec == 1:
+        mt_ = L.pk_batch_max_tokens(batch)
+        for back in range(L.pk_batch_results_available(batch)):
+            ids_ = np.zeros((args.batch, mt_), np.int32); lens_ = np.zeros(args.batch, np.int32); n_ = C.c_int(0)
+            capi.check(L.pk_batch_results_back(batch, back, C.byref(n_), ids_.ctypes.data_as(capi.i32p), lens_.ctypes.data_as(capi.i32p), None, None, None))
+            timed_ids.append([ids_[b, :lens_[b]].tolist() for b in range(n_.value)])
+        if group > 1:
+            capi.check(L.pk_batch_set_decode_group(batch, 1))        # the stage / kernel timers below run one un-pipelined step at a time
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -272,9 +287,10 @@ def main():
             "value": round(value, 1), "unit": "x real-time", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}, batch={args.batch}x{int(CLIP_SECONDS)}s clips per GPU, {args.decoder.upper()} greedy decode, {'bf16 GEMM operands / fp32 accumulate' if args.bf16 else 'fp32'} "
+            "config": {"workload": f"{args.config}, batch={args.batch}x{int(CLIP_SECONDS)}s clips per GPU, {args.decoder.upper()} greedy decode{' (the loops of %d consecutive steps driven as one lock-step batch)' % group if group > 1 else ''}, {'bf16 GEMM operands / fp32 accumulate' if args.bf16 else 'fp32'} "
                                    f"(BASELINE configs[{2 if big else 1}]{' shapes; BASELINE names bf16, this run is fp32' if (big and not args.bf16) else ''})",
-                       "clips_per_step_per_gpu": args.batch, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{n_gpus} (utterance shards, no data-path collective)"},
+                       "clips_per_step_per_gpu": args.batch, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{n_gpus} (utterance shards, no data-path collective)",
+                       "decode_group": group},
             "encoder_ms_per_clip": round(enc_ms / args.batch, 4),
             "stage_ms": {"mel": round(float(ms[0]), 3), "encoder": round(enc_ms, 3), "decode": round(float(ms[2]), 3), "total": round(float(ms[3]), 3)},
             "encoder_tflops": round(ENCODER_FLOP_PER_CLIP * args.batch / (enc_ms * 1e-3) / 1e12, 2),
@@ -297,7 +313,11 @@ def main():
                 bad = [b for b in range(args.batch) if gpu_ids[b] != port_ids[b]]
                 parity = {"clips": args.batch, "token_mismatches": len(bad), "tokens": int(lens.sum()),
                           "checked_against": "oracle/libpk_oracle.so on every clip of the timed batch (token ids identical)"}
-                if bad:
+                # the runs of the timed region itself (decoded in groups) against the same oracle ids
+                bad_t = sum(1 for run_ids in timed_ids for b in range(len(run_ids)) if run_ids[b] != port_ids[b])
+                parity["timed_runs_checked"] = len(timed_ids)
+                parity["timed_runs_token_mismatches"] = bad_t
+                if bad or bad_t:
                     parity["mismatching_clips"] = bad[:8]
                     rc = 3
                 ref, ref_ids = (None, [])

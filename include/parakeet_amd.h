@@ -148,6 +148,16 @@ pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *st
 /* Results of the newest batch whose decode has FINISHED -- run k's decode is driven inside pk_batch_run(k+1) -- without flushing the
  * decode still pending: the consumer side of the pipeline (run(k+1); results_done -> batch k).  *n_clips = its clip count. */
 pk_status pk_batch_results_done(pk_batch *b, int *n_clips, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
+/* Decode groups (throughput mode of the pipeline; default 1 = decode(k) under encoder(k+1)).  With group = G the TDT / RNNT greedy loops of
+ * G consecutive pk_batch_run calls are driven as ONE lock-step batch of G * n_clips utterances under the encoder of the run after them:
+ * the loop of tdt_greedy_decode (src/tdt.cpp:62-106) is launch-bound -- four launches per symbol step whatever the batch -- so G runs
+ * share them.  Token ids, frames and confidences of every run are unchanged (the utterances are independent); what changes is WHEN they
+ * are available: after the G-th run of the group (+1), or at pk_batch_sync / pk_batch_results.  1 <= G <= 8; flushes the pipeline. */
+pk_status pk_batch_set_decode_group(pk_batch *b, int group);
+/* Results of the (back+1)-th newest run whose decode has finished (back = 0: the newest, = pk_batch_results_done); the runs of the newest
+ * decoded group are kept: 0 <= back < pk_batch_results_available(). */
+pk_status pk_batch_results_back(pk_batch *b, int back, int *n_clips, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
+int pk_batch_results_available(const pk_batch *b);
 /* Stage timers of the last pk_batch_run_timed (ms): mel, encoder, decode, total (hipEvents on the batch stream). */
 pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]);
 /* Raw device pointers for zero-copy producers (e.g. torch tensors): PCM [max_clips][n_samples] f32. */

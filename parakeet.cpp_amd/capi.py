@@ -123,6 +123,9 @@ _LATE_SIGNATURES = {
     "pk_batch_run": [C.c_void_p, C.c_int],
     "pk_batch_upload_async": [C.c_void_p, f32p, C.c_int],
     "pk_batch_results_done": [C.c_void_p, C.POINTER(C.c_int), i32p, i32p, i32p, i32p, f32p],
+    "pk_batch_results_back": [C.c_void_p, C.c_int, C.POINTER(C.c_int), i32p, i32p, i32p, i32p, f32p],
+    "pk_batch_results_available": [C.c_void_p],
+    "pk_batch_set_decode_group": [C.c_void_p, C.c_int],
     "pk_batch_sync": [C.c_void_p],
     "pk_batch_max_tokens": [C.c_void_p],
     "pk_batch_results": [C.c_void_p, i32p, i32p, i32p, i32p, f32p],
@@ -460,6 +463,27 @@ class Batch:
         if getattr(self, "_staged_clips", 0):
             self.n_clips, self._staged_clips = self._staged_clips, 0
         check(lib().pk_batch_run(self._h, {"ctc": 0, "tdt": 1}[decoder]))
+
+    def set_decode_group(self, group):
+        """Throughput mode: the TDT loops of `group` consecutive runs are decoded as one lock-step batch (results unchanged, later)."""
+        check(lib().pk_batch_set_decode_group(self._h, int(group)))
+
+    def sync(self):
+        check(lib().pk_batch_sync(self._h))
+
+    def results_available(self):
+        return int(lib().pk_batch_results_available(self._h))
+
+    def results_back(self, back=0):
+        """Results of the (back+1)-th newest run whose decode has finished; no flush."""
+        mt = lib().pk_batch_max_tokens(self._h)
+        cap = self._cap
+        ids = np.zeros((cap, mt), np.int32); st = np.zeros((cap, mt), np.int32); en = np.zeros((cap, mt), np.int32)
+        cf = np.zeros((cap, mt), np.float32); lens = np.zeros(cap, np.int32)
+        n = C.c_int(0)
+        check(lib().pk_batch_results_back(self._h, int(back), C.byref(n), _i(ids), _i(lens), _i(st), _i(en), _f(cf)))
+        B = n.value
+        return dict(ids=ids[:B], lens=lens[:B], start=st[:B], end=en[:B], conf=cf[:B])
 
     def results_done(self):
         """Results of the newest batch whose decode has finished (run k's decode completes inside run k+1); no flush."""

@@ -310,6 +310,25 @@ struct pk_batch {
     hipEvent_t enc_done[2], dec_done[2];
     bool used[2] = {false, false};
     bool ev_ok = false;
+    // Decode groups (pk_batch_set_decode_group): the TDT loops of `group` consecutive runs are driven as ONE lock-step batch.  The loop is
+    // launch-bound (4 launches per symbol step whatever the batch), and every launch on the decode stream costs the encoder of the
+    // following run ~2 us (profiles/r02_decode_persistent.md): a group of G cuts that by G.  enc_proj of run k goes into its rows of
+    // grp[fill].ep on the ENCODER stream right after encoder(k) (the encoder workspaces are then free again); a full group is decoded
+    // under the encoder of the run after it.  Results of run k are available once its group is decoded (pk_batch_results_back).
+    int group = 1;
+    struct Member { int clips, row0; };
+    struct Group {
+        Workspace w;                    // decode state of group * max_clips utterances
+        std::vector<Member> mem;        // runs in this group, oldest first
+        int rows = 0;                   // utterances so far
+        hipEvent_t ep_done = nullptr, dec_done = nullptr;
+        bool decoded = false, used = false;
+    } grp[2];
+    struct Loc { Workspace *w; int row0, clips, decoder; hipEvent_t ev; };
+    std::vector<Loc> done;              // finished (decode driven) runs, newest last; the last max(group, 1) stay readable
+    int fill = 0;                       // group collecting runs
+    int ready = -1;                     // full group whose decode has not been driven yet
+    int last_grp = -1;                  // group holding the newest finished results (-1: they live in ws[last_slot])
 };
 
 static void batch_encode(pk_batch *b, int slot) {
@@ -343,6 +362,33 @@ static void batch_decode(pk_batch *b, int slot, int decoder, hipStream_t s) {
     b->last_slot = slot;
     b->last_decoder = decoder;
     b->last_clips = nc;
+    b->done.clear();                                          // single-run decode: only the newest run is kept
+    b->done.push_back({&w, 0, nc, decoder, b->dec_done[slot]});
+}
+
+// host-driven TDT loop of a whole decode group on the decode stream
+static void group_drive(pk_batch *b, int gi) {
+    Model &m = *b->m;
+    auto &G = b->grp[gi];
+    hipStream_t s = m.stream_dec;
+    PK_HIP(hipStreamWaitEvent(s, G.ep_done, 0));
+    m.run_tdt_loop(G.w, G.rows, G.w.T, G.w.max_tokens, s);
+    PK_HIP(hipEventRecord(G.dec_done, s));
+    G.decoded = true;
+    b->done.clear();
+    for (auto &mm : G.mem) b->done.push_back({&G.w, mm.row0, mm.clips, PK_DECODER_TDT, G.dec_done});
+    b->last_slot = 0;                                         // (a result exists)
+    b->last_decoder = PK_DECODER_TDT;
+    b->last_clips = G.mem.back().clips;
+}
+
+// closes the group being filled (full, or partial at a flush) and makes the other buffer the one to fill
+static void group_close(pk_batch *b) {
+    auto &G = b->grp[b->fill];
+    PK_HIP(hipEventRecord(G.ep_done, b->m->stream));
+    b->ready = b->fill;
+    b->fill ^= 1;
+    b->grp[b->fill].mem.clear();
 }
 
 static void batch_flush(pk_batch *b) {
@@ -350,6 +396,13 @@ static void batch_flush(pk_batch *b) {
         const int slot = b->pending_slot, dec = b->pending_decoder;
         b->pending_slot = -1;
         batch_decode(b, slot, dec, b->m->stream_dec);
+    }
+    if (b->ready >= 0) { const int r = b->ready; b->ready = -1; group_drive(b, r); }
+    if (b->group > 1 && !b->grp[b->fill].mem.empty()) {      // a partial group: decode what there is
+        group_close(b);
+        const int r = b->ready;
+        b->ready = -1;
+        group_drive(b, r);
     }
     PK_HIP(hipStreamSynchronize(b->m->stream_dec));
     PK_HIP(hipStreamSynchronize(b->m->stream));
@@ -361,14 +414,38 @@ static void batch_run(pk_batch *b, int decoder) {
     need(b->n_clips > 0 || b->staged >= 0, "pk_batch_upload() first");
     need(decoder == PK_DECODER_CTC || decoder == PK_DECODER_TDT, "decoder");
     const int slot = b->runs & 1;
+    const bool grouped = b->group > 1 && decoder == PK_DECODER_TDT;
+    if (!grouped && b->group > 1 && (b->ready >= 0 || !b->grp[b->fill].mem.empty())) batch_flush(b);   // decoder switch inside a group
     batch_encode(b, slot);                                   // encoder(k) is queued first ...
     if (b->pending_slot >= 0) {                              // ... then the host drives decode(k-1) while it runs
         const int ps = b->pending_slot, pd = b->pending_decoder;
         b->pending_slot = -1;
         batch_decode(b, ps, pd, m.stream_dec);
     }
-    b->pending_slot = slot;
-    b->pending_decoder = decoder;
+    if (grouped) {
+        auto &G = b->grp[b->fill];
+        Workspace &w = b->ws[slot];
+        if (G.mem.empty()) {                                 // first run of a group: the buffer's previous decode must be done with it
+            if (G.used) PK_HIP(hipStreamWaitEvent(m.stream, G.dec_done, 0));
+            G.rows = 0;
+            G.decoded = false;
+        }
+        const int nc = b->slot_clips[slot];
+        m.run_enc_proj(w.x.as<float>(), (int64_t)nc * w.T, G.w.ep.as<float>() + (size_t)G.rows * w.T * m.cfg.joint_hidden, m.stream);
+        G.mem.push_back({nc, G.rows});
+        G.rows += nc;
+        G.used = true;
+        const bool full = (int)G.mem.size() == b->group;
+        if (b->ready >= 0) {                                 // the group completed by an earlier run: decode it under this encoder
+            const int r = b->ready;
+            b->ready = -1;
+            group_drive(b, r);
+        }
+        if (full) group_close(b);
+    } else {
+        b->pending_slot = slot;
+        b->pending_decoder = decoder;
+    }
     b->runs += 1;
     PK_CHECK_LAUNCH();
 }
@@ -407,6 +484,10 @@ void pk_batch_free(pk_batch *b) {
             (void)hipEventDestroy(b->copy_done[i]); (void)hipEventDestroy(b->mel_done[i]);
         }
         (void)hipStreamDestroy(b->copy_stream);
+        for (auto &G : b->grp) {
+            if (G.ep_done) (void)hipEventDestroy(G.ep_done);
+            if (G.dec_done) (void)hipEventDestroy(G.dec_done);
+        }
     }
     delete b;
 }
@@ -448,53 +529,69 @@ pk_status pk_batch_sync(pk_batch *b) {
 
 int pk_batch_max_tokens(const pk_batch *b) { return b ? b->ws[0].max_tokens : 0; }
 
+// copies the results of one finished run: rows [row0, row0 + clips) of its workspace, presented as [clips][max_tokens]
+static void copy_results(const pk_batch::Loc &L, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
+    Workspace &w = *L.w;
+    const int B = L.clips, mt = w.max_tokens;
+    const size_t src_w = (size_t)(L.decoder == PK_DECODER_TDT ? mt : w.T);        // CTC arrays are [B][T] on the device
+    auto pitch = [&](void *dst, const void *src) {
+        if (dst) PK_HIP(hipMemcpy2D(dst, (size_t)mt * 4, static_cast<const char *>(src) + (size_t)L.row0 * src_w * 4, src_w * 4, src_w * 4, B, hipMemcpyDeviceToHost));
+    };
+    PK_HIP(hipMemcpy(lens, w.lens.as<int>() + L.row0, (size_t)B * 4, hipMemcpyDeviceToHost));
+    pitch(ids, w.ids.p); pitch(start, w.start.p); pitch(end, w.end.p); pitch(conf, w.conf.p);
+    zero_tail(ids, lens, B, mt); zero_tail(start, lens, B, mt); zero_tail(end, lens, B, mt); zero_tail(conf, lens, B, mt);
+}
+
 pk_status pk_batch_results(pk_batch *b, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
     return guard([&] {
         need(b && ids && lens, "batch/ids/lens");
-        Model &m = *b->m;
-        m.require_gpu();
+        b->m->require_gpu();
         batch_flush(b);
-        need(b->last_slot >= 0, "pk_batch_run() first");
-        Workspace &w = b->ws[b->last_slot];
-        const int B = b->last_clips > 0 ? b->last_clips : b->n_clips, mt = w.max_tokens;
-        PK_HIP(hipMemcpy(lens, w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
-        if (b->last_decoder == PK_DECODER_TDT) {
-            const size_t n = (size_t)B * mt * 4;
-            PK_HIP(hipMemcpy(ids, w.ids.p, n, hipMemcpyDeviceToHost));
-            if (start) PK_HIP(hipMemcpy(start, w.start.p, n, hipMemcpyDeviceToHost));
-            if (end) PK_HIP(hipMemcpy(end, w.end.p, n, hipMemcpyDeviceToHost));
-            if (conf) PK_HIP(hipMemcpy(conf, w.conf.p, n, hipMemcpyDeviceToHost));
-        } else {   // CTC arrays are [B][T] on the device; present them with the same [B][max_tokens] pitch
-            const size_t wid = (size_t)w.T * 4;
-            auto pitch = [&](void *dst, const void *src) {
-                PK_HIP(hipMemcpy2D(dst, (size_t)mt * 4, src, wid, wid, B, hipMemcpyDeviceToHost));
-            };
-            pitch(ids, w.ids.p);
-            if (start) pitch(start, w.start.p);
-            if (end) pitch(end, w.end.p);
-            if (conf) pitch(conf, w.conf.p);
-        }
-        zero_tail(ids, lens, B, mt); zero_tail(start, lens, B, mt); zero_tail(end, lens, B, mt); zero_tail(conf, lens, B, mt);
+        need(!b->done.empty(), "pk_batch_run() first");
+        copy_results(b->done.back(), ids, lens, start, end, conf);
+    });
+}
+
+pk_status pk_batch_results_back(pk_batch *b, int back, int *n_clips, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
+    return guard([&] {
+        need(b && ids && lens, "batch/ids/lens");
+        b->m->require_gpu();
+        need(!b->done.empty(), "no decoded batch yet: the decode of run k finishes inside a later pk_batch_run (or pk_batch_sync)");
+        need(back >= 0 && back < (int)b->done.size(), "back: only the runs of the newest decoded group are kept");
+        const pk_batch::Loc &L = b->done[b->done.size() - 1 - (size_t)back];
+        PK_HIP(hipEventSynchronize(L.ev));
+        if (n_clips) *n_clips = L.clips;
+        copy_results(L, ids, lens, start, end, conf);
     });
 }
 
 pk_status pk_batch_results_done(pk_batch *b, int *n_clips, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
+    return pk_batch_results_back(b, 0, n_clips, ids, lens, start, end, conf);
+}
+
+int pk_batch_results_available(const pk_batch *b) { return b ? (int)b->done.size() : 0; }
+
+pk_status pk_batch_set_decode_group(pk_batch *b, int group) {
     return guard([&] {
-        need(b && ids && lens, "batch/ids/lens");
+        need(b, "batch");
+        need(group >= 1 && group <= 8, "decode group: 1 .. 8 runs");
         Model &m = *b->m;
         m.require_gpu();
-        need(b->last_slot >= 0, "no decoded batch yet: the decode of run k finishes inside pk_batch_run(k+1) (or pk_batch_sync)");
-        PK_HIP(hipEventSynchronize(b->dec_done[b->last_slot]));
-        Workspace &w = b->ws[b->last_slot];
-        const int B = b->last_clips, mt = w.max_tokens;
-        if (n_clips) *n_clips = B;
-        const size_t wid = (size_t)(b->last_decoder == PK_DECODER_TDT ? mt : w.T) * 4;
-        auto pitch = [&](void *dst, const void *src) {
-            if (dst) PK_HIP(hipMemcpy2D(dst, (size_t)mt * 4, src, wid, wid, B, hipMemcpyDeviceToHost));
-        };
-        PK_HIP(hipMemcpy(lens, w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
-        pitch(ids, w.ids.p); pitch(start, w.start.p); pitch(end, w.end.p); pitch(conf, w.conf.p);
-        zero_tail(ids, lens, B, mt); zero_tail(start, lens, B, mt); zero_tail(end, lens, B, mt); zero_tail(conf, lens, B, mt);
+        batch_flush(b);
+        if (group > 1) {
+            need(m.cfg.vocab_size > 0, "decode groups apply to the TDT / RNNT decoder; this model has none");
+            for (auto &G : b->grp) {
+                G.w.size_decode(m.cfg, group * b->ws[0].B, b->ws[0].T);
+                if (!G.ep_done) PK_HIP(hipEventCreateWithFlags(&G.ep_done, hipEventDisableTiming));
+                if (!G.dec_done) PK_HIP(hipEventCreateWithFlags(&G.dec_done, hipEventDisableTiming));
+                G.mem.clear();
+                G.rows = 0;
+                G.used = G.decoded = false;
+            }
+        }
+        b->fill = 0;
+        b->ready = -1;
+        b->group = group;
     });
 }
 

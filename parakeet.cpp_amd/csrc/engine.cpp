@@ -422,6 +422,12 @@ void Workspace::size_for(const pk_config &c, int B_, int64_t n_samples_, int Tm_
     ctx.reserve(M * d * f); g.reserve(M * d * f); dwb.reserve(M * d * f);
     if (c.ctc_vocab_size > 0) { ctc_logits.reserve(M * c.ctc_vocab_size * f); }
     best_idx.reserve(M * sizeof(int)); best_lp.reserve(M * f);
+    reserve_decode(c);
+}
+
+// the TDT / RNNT decode state of B utterances of T frames (B, T set by the caller)
+void Workspace::reserve_decode(const pk_config &c) {
+    const size_t M = (size_t)B * T, f = sizeof(float);
     max_tokens = T * (c.max_symbols_per_step > 0 ? c.max_symbols_per_step : 10);
     const int Hp = c.pred_hidden, J = c.joint_hidden, L = c.num_lstm_layers, VD = c.vocab_size + c.num_durations;
     ep.reserve(M * J * f); gh.reserve((size_t)B * 4 * Hp * f); gi.reserve((size_t)B * 4 * Hp * f); pp.reserve((size_t)B * J * f);
@@ -431,6 +437,12 @@ void Workspace::size_for(const pk_config &c, int B_, int64_t n_samples_, int Tm_
     const size_t tok = (size_t)B * max_tokens;
     ids.reserve(tok * sizeof(int)); start.reserve(tok * sizeof(int)); end.reserve(tok * sizeof(int)); conf.reserve(tok * f);
     lens.reserve((size_t)B * sizeof(int));
+}
+
+// decode-only workspace (no encoder buffers): the lock-step TDT state of a GROUP of pipelined batches (capi.cpp)
+void Workspace::size_decode(const pk_config &c, int B_, int T_) {
+    B = B_; T = T_;
+    reserve_decode(c);
 }
 
 // ---- stages ---------------------------------------------------------------------------------------------------
@@ -646,12 +658,24 @@ void Model::run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_lo
 }
 
 // tdt_greedy_decode(_with_timestamps) / rnnt_greedy_decode  (src/tdt.cpp:36-201, src/rnnt.cpp:56-177)
+// enc_proj_ hoisted out of the symbol loop: one GEMM over all frames (the reference recomputes it per symbol, src/tdt.cpp:17)
+void Model::run_enc_proj(const float *d_enc, int64_t rows, float *ep_out, hipStream_t s) {
+    const int d = cfg.hidden_size, J = cfg.joint_hidden;
+    if (cfg.vocab_size <= 0) fail(PK_ERR_UNSUPPORTED, "this model has no prediction net / joint (encoder-only configuration)");
+    gemm("joint_enc_proj", d_enc, d, dec.we, d, dec.be, ep_out, J, (int)rows, J, d, EPI_NONE, nullptr, 0, 1.0f, s);
+}
+
 void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s, bool keep_state) {
-    const int d = cfg.hidden_size, Hp = cfg.pred_hidden, J = cfg.joint_hidden, V = cfg.vocab_size, D = cfg.rnnt_head ? 0 : cfg.num_durations;
+    run_enc_proj(d_enc, (int64_t)B * T, w.ep.as<float>(), s);
+    run_tdt_loop(w, B, T, max_tokens, s, keep_state);
+}
+
+// The greedy loop over w.ep = enc_proj of B utterances of T frames (rows b*T + t).  B may span several batches of the pipelined path
+// (capi.cpp: decode groups): the utterances are independent, a lock-step batch of 2B costs the same number of launches as one of B.
+void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t s, bool keep_state) {
+    const int Hp = cfg.pred_hidden, J = cfg.joint_hidden, V = cfg.vocab_size, D = cfg.rnnt_head ? 0 : cfg.num_durations;
     const int L = cfg.num_lstm_layers;
     if (V <= 0) fail(PK_ERR_UNSUPPORTED, "this model has no prediction net / joint (encoder-only configuration)");
-    // enc_proj_ hoisted out of the symbol loop: one GEMM over all frames (the reference recomputes it per symbol, src/tdt.cpp:17)
-    gemm("joint_enc_proj", d_enc, d, dec.we, d, dec.be, w.ep.as<float>(), J, B * T, J, d, EPI_NONE, nullptr, 0, 1.0f, s);
     TdtState st{};
     st.B = B; st.T = T; st.V = V; st.D = D; st.L = L; st.Hp = Hp; st.blank = cfg.blank_id; st.max_symbols = cfg.max_symbols_per_step;
     st.max_tokens = max_tokens;

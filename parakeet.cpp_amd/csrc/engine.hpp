@@ -59,6 +59,8 @@ struct Workspace {
     Workspace(const Workspace &) = delete;
     Workspace &operator=(const Workspace &) = delete;
     void size_for(const pk_config &cfg, int B, int64_t n_samples, int Tm);
+    void size_decode(const pk_config &cfg, int B, int T);     // TDT / RNNT decode state only
+    void reserve_decode(const pk_config &cfg);
 };
 
 class StreamBatch;
@@ -102,6 +104,8 @@ class Model {
     void run_layers(Workspace &w, int B, int first_layer, int stop_layer, int stop_stage, hipStream_t s);                 // w.x -> w.x
     void run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_logp, hipStream_t s);
     void run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s, bool keep_state = false);
+    void run_enc_proj(const float *d_enc, int64_t rows, float *ep_out, hipStream_t s);                    // joint enc_proj_ of all frames
+    void run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t s, bool keep_state = false);  // greedy loop over w.ep
 
     // Phrase boosting (reference include/parakeet/phrase_boost.hpp:22-57, TranscribeOptions.boost_phrases transcribe.hpp:41-42):
     // the ContextTrie of the tokenised phrases in CSR form on the device; CTC and TDT greedy decode then run boosted.

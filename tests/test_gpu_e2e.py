@@ -145,6 +145,72 @@ def test_streaming_batch_api_matches_sequential(tmp_path, orc):
         assert tok(g, b) == tok(o, b)
 
 
+def test_decode_groups_keep_every_result(tmp_path):
+    """pk_batch_set_decode_group: the TDT loops of G consecutive runs are driven as one lock-step batch.  Every run's token ids, frames
+    and confidences must equal those of the run decoded on its own -- full groups, a partial group at the flush, runs of different
+    clip counts, a CTC run in between, and a switch back to group 1."""
+    import dataclasses
+    cfg = dataclasses.replace(pk.make_110m_config(), num_layers=1, name="110m-1L-groups")
+    W, om, gm = G.make_pair(tmp_path, cfg)
+    n = 32000
+    batches = [synth.synth_pcm(4, n, seed=60), synth.synth_pcm(3, n, seed=61), synth.synth_pcm(4, n, seed=62), synth.synth_pcm(2, n, seed=63),
+               synth.synth_pcm(4, n, seed=64), synth.synth_pcm(4, n, seed=65), synth.synth_pcm(1, n, seed=66)]
+    want = []
+    bt = capi.Batch(gm, 4, n)
+    for p in batches:
+        bt.upload(p); bt.run("tdt")
+        want.append(bt.results())
+    bt.close()
+
+    def same(g, w, what):
+        B = w["lens"].shape[0]
+        assert g["lens"].shape[0] == B and np.array_equal(g["lens"], w["lens"]), what
+        for key in ("ids", "start", "end"):
+            assert np.array_equal(g[key], w[key]), (what, key)
+        G.assert_bits_equal(g["conf"], w["conf"], "confidence")
+
+    for grp in (2, 3, 4):
+        bt = capi.Batch(gm, 4, n)
+        bt.set_decode_group(grp)
+        got = {}
+        bt.upload_async(batches[0])
+        for k in range(len(batches)):
+            bt.run("tdt")
+            if k + 1 < len(batches):
+                bt.upload_async(batches[k + 1])
+            # the group completed by run j is decoded inside run j+1: after run k the newest decoded group ends at run k-1
+            if k >= grp and (k % grp) == 0:
+                assert bt.results_available() == grp
+                for back in range(grp):
+                    got[k - 1 - back] = bt.results_back(back)
+        bt.sync()                                            # the partial (or last full) group
+        last = len(batches) - 1
+        for back in range(bt.results_available()):
+            got[last - back] = bt.results_back(back)
+        assert sorted(got) == list(range(len(batches))), (grp, sorted(got))
+        for k in range(len(batches)):
+            same(got[k], want[k], (grp, k))
+        # results() = the last run, after a flush; a CTC run inside the pipeline flushes the open group and is decoded on its own
+        bt.upload_async(batches[1]); bt.run("tdt")
+        bt.upload_async(batches[2]); bt.run("ctc")
+        r = bt.results()
+        assert r["lens"].shape[0] == batches[2].shape[0]
+        same(bt_single(gm, batches[2], n, "ctc"), r, (grp, "ctc after tdt"))
+        bt.set_decode_group(1)
+        bt.upload_async(batches[3]); bt.run("tdt")
+        same(bt.results(), want[3], (grp, "back to group 1"))
+        bt.close()
+    assert sum(int(w["lens"].sum()) for w in want) > 0
+
+
+def bt_single(gm, pcm, n, dec):
+    bt = capi.Batch(gm, 4, n)
+    bt.upload(pcm); bt.run(dec)
+    r = bt.results()
+    bt.close()
+    return r
+
+
 def test_sharded_driver_single_rank(tmp_path):
     """tools/transcribe_sharded.py (BASELINE configs[3] driver) at world size 1: 150 clips = 2 full batches + a short one through
     the streaming pipeline == each batch decoded on its own; clip order preserved by the fixed-stride gather."""
