@@ -16,6 +16,9 @@
 //     softmax(S) V: one ds_read_b128 feeds four MFMA steps.
 //   * V streams through LDS in chunks of VCH rows (coalesced 16-byte loads, natural rows, pitch = 16 mod 32 banks).
 // Softmax is one wavefront per row with the canonical max / sum64 butterflies.  3 barriers per workgroup (+2 per extra V chunk).
+// (Round 2 also tried V as a straight-from-L2 B operand -- one dword per lane per MFMA step, a register block of 8 steps ahead: bit-equal,
+// no V copy in LDS and no chunk barriers, but the gathers are slower than the LDS copy: AV phase 10 k -> 23 k clocks per wave at T = 126,
+// 52 k -> 112 k at T = 376 / hd = 128.  Not kept.)
 #include "../pk_devmath.h"
 #include "kernels.hpp"
 
@@ -24,7 +27,7 @@ namespace pk {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int RB = 32;   // query rows per workgroup
 #ifndef ATT_OCC
-#define ATT_OCC 3                 // workgroups per CU the hd <= 64 kernel is compiled for (register budget 168 / 128 VGPRs for 3 / 4)
+#define ATT_OCC 4                 // workgroups per CU the hd <= 64 kernel is compiled for (register budget 168 / 128 VGPRs for 3 / 4)
 #endif
 
 #ifdef ATT_TRACE
@@ -115,26 +118,22 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
             }
     };
 
-    // ---- phase 0: V chunk 0 and the Q fragments (q+u), (q+v) of this wave's 16 rows --------------------------------------
+    // ---- phase 0: the Q fragments of this wave's 16 rows.  Only ONE biased copy is live at a time -- (q+u) for the content scores, then
+    //      q is fetched again (L2) and (q+v) formed for the position scores -- and the first V chunk is requested after the score phases:
+    //      the register budget of four workgroups per CU (128 VGPRs) has no room for both copies plus the V prefetch beside the four
+    //      operand tiles of the score loops (round 2: 168 -> 134 VGPRs, 86.9 -> 82.3 us per layer at T = 126).
     ATT_STAMP(0);
-    v_issue(0);
-    float4 qu[NQ4], qv[NQ4];
-    {
-        float4 q[NQ4];
-        load_tile(qb, ldq, i0 + rt * 16, T, q);
+    float4 qx[NQ4];                                                 // (q+u), later (q+v); element e of fragment f <-> k = 16f + 4e + kq
+    auto load_q_biased = [&](const float *bias) {                   // as the reference forms them (src/encoder.cpp:141-142)
+        load_tile(qb, ldq, i0 + rt * 16, T, qx);
         if (pos) {
-            const float *ur = bias_u + h * HD + kq, *vr = bias_v + h * HD + kq;
+            const float *br = bias + h * HD + kq;
 #pragma unroll
-            for (int f = 0; f < NQ4; ++f) {
-                // element e <-> k = 16f + 4e + kq ; (q+u), (q+v) as the reference forms them (src/encoder.cpp:141-142)
-                qu[f] = make_float4(q[f].x + ur[16 * f], q[f].y + ur[16 * f + 4], q[f].z + ur[16 * f + 8], q[f].w + ur[16 * f + 12]);
-                qv[f] = make_float4(q[f].x + vr[16 * f], q[f].y + vr[16 * f + 4], q[f].z + vr[16 * f + 8], q[f].w + vr[16 * f + 12]);
-            }
-        } else {                                                    // plain multi-head attention (src/transformer.cpp:38): no position term
-#pragma unroll
-            for (int f = 0; f < NQ4; ++f) qu[f] = qv[f] = q[f];
+            for (int f = 0; f < NQ4; ++f)
+                qx[f] = make_float4(qx[f].x + br[16 * f], qx[f].y + br[16 * f + 4], qx[f].z + br[16 * f + 8], qx[f].w + br[16 * f + 12]);
         }
-    }
+    };
+    load_q_biased(bias_u);
     const int il_base = rt * 16 + 4 * kq;                           // C layout: column = lane & 15, row = 4*(lane>>4) + r
     const int Tpad4 = (T + 3) & ~3;
     float4 bA0[NQ4], bA1[NQ4], bB0[NQ4], bB1[NQ4];                  // two operand-tile pairs: one computing, one in flight
@@ -157,24 +156,24 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
         for (int t = cp; t < nct; t += 8) {
             f32x4 a0, a1;
             if (t + 4 < nct) { load_tile(kb, ldq, (t + 4) * 16, T, bB0); load_tile(kb, ldq, (t + 6) * 16, T, bB1); }
-            mma_pair(qu, bA0, bA1, a0, a1);
+            mma_pair(qx, bA0, bA1, a0, a1);
             store(t, a0, a1);
             if (t + 4 < nct) {
                 if (t + 8 < nct) { load_tile(kb, ldq, (t + 8) * 16, T, bA0); load_tile(kb, ldq, (t + 10) * 16, T, bA1); }
-                mma_pair(qu, bB0, bB1, a0, a1);
+                mma_pair(qx, bB0, bB1, a0, a1);
                 store(t + 4, a0, a1);
             }
         }
     }
     ATT_STAMP(2);
-    v_commit();
+    if (pos) load_q_biased(bias_v);
     // ---- phase 2: position scores (q+v) P^T, shifted, combined and scaled.  This wave's 16 query rows need
     //      p = j - i + T - 1 in [wpmin, wpmax] (T+15 rows): its own tile grid starts at wpmin, tiles t = cp, cp+2, ... ------
     const int w_lo = i0 + rt * 16, w_hi = (w_lo + 15) < (T - 1) ? (w_lo + 15) : (T - 1);
     const int wpmin = T - 1 - w_hi, wpmax = 2 * T - 2 - w_lo;
     const int npt = (pos && w_lo < T) ? (wpmax - wpmin) / 16 + 1 : 0;
     if (cp < npt) { load_tile(pb, d, wpmin + cp * 16, P, bA0); load_tile(pb, d, wpmin + (cp + 2) * 16, P, bA1); }   // in flight across the barrier
-    __syncthreads();                                              // content scores complete; V chunk 0 visible
+    __syncthreads();                                              // content scores complete
     ATT_STAMP(3);
     {
         auto rmw = [&](int t, const f32x4 &a0, const f32x4 &a1) {
@@ -196,16 +195,17 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
         for (int t = cp; t < npt; t += 8) {
             f32x4 a0, a1;
             if (t + 4 < npt) { load_tile(pb, d, wpmin + (t + 4) * 16, P, bB0); load_tile(pb, d, wpmin + (t + 6) * 16, P, bB1); }
-            mma_pair(qv, bA0, bA1, a0, a1);
+            mma_pair(qx, bA0, bA1, a0, a1);
             rmw(t, a0, a1);
             if (t + 4 < npt) {
                 if (t + 8 < npt) { load_tile(pb, d, wpmin + (t + 8) * 16, P, bA0); load_tile(pb, d, wpmin + (t + 10) * 16, P, bA1); }
-                mma_pair(qv, bB0, bB1, a0, a1);
+                mma_pair(qx, bB0, bB1, a0, a1);
                 rmw(t + 4, a0, a1);
             }
         }
     }
     ATT_STAMP(4);
+    v_issue(0);                                                   // first V chunk: in flight across the softmax
     __syncthreads();
     ATT_STAMP(5);
     // ---- phase 3: softmax, one wavefront per row ----------------------------------------------------------------------------
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
 #pragma unroll
             for (int k = 0; k < NSR; ++k) {
                 const int a = sidx(wave + 4 * k, j);
-                const float e = dexpf(S[a] - mx[k]);
+                const float e = dexpf_nonpos(S[a] - mx[k]);       // S <= row maximum
                 S[a] = e;
                 sm[k] = sm[k] + e;
             }
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
             }
     }
     ATT_STAMP(6);
+    v_commit();
     __syncthreads();
     // ---- phase 4: ctx = softmax(S) V  (k = key index, natural order; NDV independent 16-column tiles per wave) ---------------
     f32x4 acc[NDV];

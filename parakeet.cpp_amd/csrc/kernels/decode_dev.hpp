@@ -212,7 +212,7 @@ __device__ __forceinline__ BestLP wave_logsoftmax_argmax(const float *__restrict
     for (int i = lane; i < n; i += 64) m = fmaxf(m, x[i]);
     m = wave_max64(m);
     float p = 0.0f;
-    for (int i = lane; i < n; i += 64) p = p + dexpf(x[i] - m);
+    for (int i = lane; i < n; i += 64) p = p + dexpf_nonpos(x[i] - m);
     const float lse = dlogf(wave_sum64(p));
     float best = -__builtin_huge_valf();
     int bi = 0x7fffffff;
@@ -278,7 +278,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    for (int i = tid; i < st.V; i += 256) e[i] = dexpf(x[i] - m);
+    for (int i = tid; i < st.V; i += 256) e[i] = dexpf_nonpos(x[i] - m);
     if constexpr (BOOST) {                                         // get_boosted_tokens: union of the children of the active states
         for (int a = 0; a < n_act; ++a) {
             const int sn = acts[a];

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
     m = wave_max64(m);
     float p = 0.0f;
     for (int j = lane; j < kv; j += 64) {
-        const float e = dexpf(pr[j] - m);
+        const float e = dexpf_nonpos(pr[j] - m);
         pr[j] = e;
         p = p + e;
     }

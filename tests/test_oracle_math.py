@@ -57,3 +57,15 @@ def test_vector_gemm_equals_scalar_fma_chain(orc):
     for k in range(a.size):
         acc = np.float32(a[k] * w[k] + np.float64(acc))   # products of two f32 are exact in f64; one rounding
     assert orc.linear(A[:1], W[:1])[0, 0] == acc
+
+
+def test_exp_nonpos_is_exp(tmp_path):
+    """pk_devmath.h: dexpf_nonpos (softmax / log-softmax arguments) returns dexpf's bits for x <= 0 -- host restatement of both, strided
+    sweep over all non-positive floats (tools/verify_exp_nonpos.c; stride 1 = exhaustive, ~80 s)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "verify_exp_nonpos")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "verify_exp_nonpos.c"), "-lm"])
+    out = subprocess.run([exe, "997"], capture_output=True, text=True)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout
