@@ -259,11 +259,11 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
 // bf16 operands / fp32 accumulate (a.W points to bf16 weights [N][K]); K % 64 == 0
 template <int EPI>
 static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
-    // round 2 (profiles/r02_gemm_bf16_tiles.txt): at 32 MFMA clocks per 16 k the 128x128 tile is bound by its LDS fragment traffic
-    // (1.5 KB per MFMA); 256x256 on 8 waves of 64x128 halves it: tdt-600m fc1 329 -> 464 TF, fc2 304 -> 390, qkv 340 -> 366, out 319 -> 342
-    const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    if (a.M >= 1024 && a.N >= 1024 && tiles256 >= 160) launch_gemm_bf16_t<4, 2, 2, 4, EPI>(a, s);
-    else if (a.M >= 1024 && a.N >= 1024) launch_gemm_bf16_t<4, 2, 1, 2, EPI>(a, s);      // 128x128 on 8 waves of 32x64
+    // round 2: the staging stores decide the rate of this kernel.  As 16-byte ds_write_b128 the 128x128 tile ran at 320-340 TF and 256x256
+    // macro tiles were the way to 450 (profiles/r02_gemm_bf16_tiles.txt); the SAME 16 bytes written as a ds_write2_b64 pair
+    // (gemm_bf16.hpp, lstore) take the 128x128 tile to 580 TF in the sweep and 510-600 TF in the engine (profiles/r02_gemm_bf16_ablation.txt)
+    // -- the 16-byte LDS store is pathologically slow next to fragment reads on gfx950, as the fp32 kernel had already shown.
+    if (a.M >= 1024 && a.N >= 1024) launch_gemm_bf16_t<4, 2, 1, 2, EPI>(a, s);      // 128x128 on 8 waves of 32x64
     else if (a.M >= 1024 && a.N >= 256) launch_gemm_bf16_t<2, 2, 2, 1, EPI>(a, s);
     else launch_gemm_bf16_t<2, 2, 1, 1, EPI>(a, s);
 }
@@ -273,10 +273,7 @@ void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s) {
     case EPI_RELU: launch_bf16_epi<EPI_RELU>(a, s); break;
     case EPI_SILU: launch_bf16_epi<EPI_SILU>(a, s); break;
     case EPI_RESID: launch_bf16_epi<EPI_RESID>(a, s); break;
-    case EPI_GLU:
-        if (a.M >= 1024 && (int64_t)((a.M + 255) / 256) * ((a.N + 127) / 128) >= 160) launch_gemm_bf16_t<4, 2, 2, 4, EPI_GLU>(a, s);
-        else launch_gemm_bf16_t<4, 2, 1, 2, EPI_GLU>(a, s);
-        break;
+    case EPI_GLU: launch_gemm_bf16_t<4, 2, 1, 2, EPI_GLU>(a, s); break;
     default: break;
     }
 }

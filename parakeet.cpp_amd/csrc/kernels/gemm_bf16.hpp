@@ -16,6 +16,10 @@
 #include "kernels.hpp"
 #include "gemm_pipe.hpp"
 
+#ifndef BG_EXP
+#define BG_EXP 0                    // micro-benchmark experiments only (tools/ubench, results wrong, timing only): main loop without
+#endif                              // 16 = LDS stores, 32 = global loads, 64 = fragment reads; 512 = staging stores as ds_write_b128 instead of ds_write2_b64 pairs
+
 namespace pk {
 
 typedef float bg_f32x16 __attribute__((ext_vector_type(16)));
@@ -93,10 +97,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
             bg_bf16x8 v;
             v[0] = (__bf16)ra[i][0].x; v[1] = (__bf16)ra[i][0].y; v[2] = (__bf16)ra[i][0].z; v[3] = (__bf16)ra[i][0].w;
             v[4] = (__bf16)ra[i][1].x; v[5] = (__bf16)ra[i][1].y; v[6] = (__bf16)ra[i][1].z; v[7] = (__bf16)ra[i][1].w;
-            *reinterpret_cast<bg_bf16x8 *>(base + a_dst[i]) = v;
+            if (!(BG_EXP & 512)) {
+                typedef float v2f_ __attribute__((ext_vector_type(2)));
+                const float4 q = *reinterpret_cast<const float4 *>(&v);
+                const unsigned addr = (unsigned)(size_t)(base + a_dst[i]);
+                asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" ::"v"(addr), "v"(v2f_{q.x, q.y}), "v"(v2f_{q.z, q.w}) : "memory");
+            } else {
+                *reinterpret_cast<bg_bf16x8 *>(base + a_dst[i]) = v;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < W_CH; ++i) *reinterpret_cast<uint4 *>(base + w_dst[i]) = rw[i];
+        for (int i = 0; i < W_CH; ++i) {
+            if (!(BG_EXP & 512)) {
+                typedef float v2f_ __attribute__((ext_vector_type(2)));
+                const float4 q = *reinterpret_cast<const float4 *>(&rw[i]);
+                const unsigned addr = (unsigned)(size_t)(base + w_dst[i]);
+                asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" ::"v"(addr), "v"(v2f_{q.x, q.y}), "v"(v2f_{q.z, q.w}) : "memory");
+            } else {
+                *reinterpret_cast<uint4 *>(base + w_dst[i]) = rw[i];
+            }
+        }
     };
 
     bg_f32x16 acc[TM][TN];
@@ -134,13 +154,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
         const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
 #pragma unroll
         for (int s = 0; s < NSUB - 1; ++s) {
-            fragload(cur, s + 1, (s + 1) & 1);
-            if (s == NSUB - 2 && more1) lstore(cur ^ 1);
+            if (!(BG_EXP & 64)) fragload(cur, s + 1, (s + 1) & 1);
+            if (!(BG_EXP & 16) && s == NSUB - 2 && more1) lstore(cur ^ 1);
             BG_SB(); mma(s & 1); BG_SB();
         }
         __syncthreads();
-        if (more1) fragload(cur ^ 1, 0, 0);
-        if (more2) gload(kt + 2);
+        if (!(BG_EXP & 64) && more1) fragload(cur ^ 1, 0, 0);
+        if (!(BG_EXP & 32) && more2) gload(kt + 2);
         BG_SB(); mma((NSUB - 1) & 1); BG_SB();
         cur ^= 1;
     }
