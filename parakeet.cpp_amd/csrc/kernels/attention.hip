@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
 #pragma unroll
         for (int i = 0; i < NLV; ++i) {
             const int e = tid + 256 * i;
-            *reinterpret_cast<float4 *>(VS + (e / KQ) * VPIT + 4 * (e % KQ)) = vf[i];
+            lds_store16(VS + (e / KQ) * VPIT + 4 * (e % KQ), vf[i]);
         }
     };
     // one 16-row operand tile straight from global: lane (row l15, quarter kq) takes float4 #kq of every 16-feature block
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
     }
     ATT_STAMP(6);
     v_commit();
+    lds_store_fence();
     __syncthreads();
     // ---- phase 4: ctx = softmax(S) V  (k = key index, natural order; NDV independent 16-column tiles per wave) ---------------
     f32x4 acc[NDV];
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
         if (more) {
             __syncthreads();
             v_commit();
+            lds_store_fence();
             __syncthreads();
         }
     }

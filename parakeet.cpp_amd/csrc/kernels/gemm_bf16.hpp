@@ -2,7 +2,7 @@
 // BASELINE configs[2] (tdt-600m) names.
 //
 // out[M][N] = epi(bf16(A)[M][K] * W16[N][K]^T + bias): the activations stay fp32 in HBM and are rounded to bf16 (RNE,
-// v_cvt_pk_bf16_f32) while they are staged into LDS; the weights are rounded once at upload and live in HBM as bf16.
+// v_cvt_pk_bf16_f32) while they are staged into LDS (as ds_write2_b64 pairs: 16-byte ds_write_b128 stores halve the kernel's rate); the weights are rounded once at upload and live in HBM as bf16.
 // Products of two bf16 are exact in fp32 and the accumulator is fp32, so the only difference to the fp32 path is the
 // operand rounding plus the summation order inside v_mfma_f32_32x32x16_bf16 (not a sequential chain): results are
 // compared with the oracle's bf16 mode within a stated tolerance, not bit for bit (tests/test_gpu_bf16.py).
@@ -98,10 +98,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
             v[0] = (__bf16)ra[i][0].x; v[1] = (__bf16)ra[i][0].y; v[2] = (__bf16)ra[i][0].z; v[3] = (__bf16)ra[i][0].w;
             v[4] = (__bf16)ra[i][1].x; v[5] = (__bf16)ra[i][1].y; v[6] = (__bf16)ra[i][1].z; v[7] = (__bf16)ra[i][1].w;
             if (!(BG_EXP & 512)) {
-                typedef float v2f_ __attribute__((ext_vector_type(2)));
-                const float4 q = *reinterpret_cast<const float4 *>(&v);
-                const unsigned addr = (unsigned)(size_t)(base + a_dst[i]);
-                asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" ::"v"(addr), "v"(v2f_{q.x, q.y}), "v"(v2f_{q.z, q.w}) : "memory");
+                lds_store16(base + a_dst[i], *reinterpret_cast<const float4 *>(&v));
             } else {
                 *reinterpret_cast<bg_bf16x8 *>(base + a_dst[i]) = v;
             }
@@ -109,10 +106,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) {
             if (!(BG_EXP & 512)) {
-                typedef float v2f_ __attribute__((ext_vector_type(2)));
-                const float4 q = *reinterpret_cast<const float4 *>(&rw[i]);
-                const unsigned addr = (unsigned)(size_t)(base + w_dst[i]);
-                asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" ::"v"(addr), "v"(v2f_{q.x, q.y}), "v"(v2f_{q.z, q.w}) : "memory");
+                lds_store16(base + w_dst[i], *reinterpret_cast<const float4 *>(&rw[i]));
             } else {
                 *reinterpret_cast<uint4 *>(base + w_dst[i]) = rw[i];
             }
@@ -146,6 +140,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
 #define BG_SB() __builtin_amdgcn_sched_barrier(0)
     gload(0);
     lstore(0);
+    lds_store_fence();
     __syncthreads();
     if (nk > 1) gload(1);
     fragload(0, 0, 0);
@@ -158,6 +153,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
             if (!(BG_EXP & 16) && s == NSUB - 2 && more1) lstore(cur ^ 1);
             BG_SB(); mma(s & 1); BG_SB();
         }
+        lds_store_fence();                                          // the staging stores are inline ds_write2_b64 (lds_store16)
         __syncthreads();
         if (!(BG_EXP & 64) && more1) fragload(cur ^ 1, 0, 0);
         if (!(BG_EXP & 32) && more2) gload(kt + 2);
