@@ -391,15 +391,20 @@ void Model::klaunch_end(hipStream_t s) {
 void Model::run_gemm(const char *name, const GemmArgs &g, int epi, hipStream_t s, bool fp32_weight) {
     if (cfg.gemm_bf16 && !fp32_weight) {
         if (g.K % 64) fail(PK_ERR_UNSUPPORTED, "gemm_bf16 needs K %% 64 == 0 (%s has K = %d)", name, g.K);
+        if (g.out_bf16 && (g.remap_rows != 0 || (g.ldo & 3) != 0 || (g.N & 3) != 0 || g.sigma_cols != 0 || epi == EPI_RESID || epi == EPI_GLU))
+            fail(PK_ERR_INVALID, "%s: a bf16 output needs the row-major wide epilogue", name);
         KL(name, gemm_flops(g, epi), 0.0, launch_gemm_bf16(g, epi, s));
     } else {
+        if (g.a_bf16 || g.out_bf16) fail(PK_ERR_INVALID, "%s: bf16 activations outside the bf16 GEMM path", name);
         KL(name, gemm_flops(g, epi), 0.0, launch_gemm(g, epi, s));
     }
 }
 
 void Model::gemm(const char *name, const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *out, int64_t ldo,
-                 int M, int N, int K, int epi, const float *resid, int64_t ldr, float alpha, hipStream_t s) {
+                 int M, int N, int K, int epi, const float *resid, int64_t ldr, float alpha, hipStream_t s, int a_bf16, int out_bf16) {
     GemmArgs g{A, lda, W, ldw, bias, out, ldo, resid, ldr, alpha, M, N, K};
+    g.a_bf16 = a_bf16;
+    g.out_bf16 = out_bf16;
     run_gemm(name, g, epi, s);
 }
 
@@ -509,10 +514,14 @@ void Model::run_subsample(Workspace &w, const float *d_feats, int B, int Tm, flo
 void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done) {
     const int d = cfg.hidden_size, f = cfg.ffn_intermediate;
     float *x = w.x.as<float>(), *n = w.n.as<float>(), *h = w.hbuf.as<float>();
+    // bf16 mode: the normalised rows and the fc1 activations exist only as GEMM operands -- their producers round them to bf16 (RNE, the
+    // rounding the GEMM's staging path would apply: same operand values) and store HALF the bytes in the same buffers.
+    const int a16 = cfg.gemm_bf16 ? 1 : 0;
     if (!norm_done)    // (the first FFN's norm rides on the previous block's final_norm_ kernel, see run_layers)
-        KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, s));
-    gemm("ffn_fc1_silu", n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, h, f, (int)rows, f, d, EPI_SILU, nullptr, 0, 1.0f, s);
-    gemm("ffn_fc2_resid", h, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, (int)rows, d, f, EPI_RESID, x, d, 0.5f, s);
+        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4,
+           launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, s, a16));
+    gemm("ffn_fc1_silu", n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, h, f, (int)rows, f, d, EPI_SILU, nullptr, 0, 1.0f, s, a16, a16);
+    gemm("ffn_fc2_resid", h, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, (int)rows, d, f, EPI_RESID, x, d, 0.5f, s, a16, 0);
 }
 
 // FastConformerEncoder::forward (src/encoder.cpp:253-271) -> w.x [B][T][d]
@@ -540,6 +549,7 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
         att_scratch_p = att_scratch.as<float>();
     }
     ensure_pos_tables(T, s);
+    const int a16 = cfg.gemm_bf16 ? 1 : 0;                           // bf16 mode: LayerNorm outputs stored as bf16 GEMM operands (ffn())
     bool ffn1_norm_done = false;
     for (int l = first_layer; l < cfg.num_layers; ++l) {
         if (l > stop_layer || (l == stop_layer && stop_stage == 0)) break;
@@ -549,11 +559,12 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
         ffn1_norm_done = false;
         if (stage_cap == 1) break;
         // ConformerAttention::forward  :180-186
-        KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, s));
+        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, s, a16));
         {
             // q and k columns in the sigma layout (MFMA operands of the attention kernel), v natural
             GemmArgs g{n, d, L.wqkv, d, L.bqkv, w.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
             g.sigma_cols = 2 * d;
+            g.a_bf16 = a16;
             run_gemm("attn_qkv", g, EPI_NONE, s);
         }
         {
@@ -561,24 +572,24 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             const double fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);   // QK^T + QP^T(needed band) + AV
             KL("relpos_attention", fl, 0.0,
                launch_relpos_attention(w.qkv.as<float>(), B, T, d, cfg.num_heads, pos_proj.as<float>() + (size_t)l * P * d, L.pos_u, L.pos_v,
-                                       w.ctx.as<float>(), s, 0.0f, att_scratch_p));
+                                       w.ctx.as<float>(), s, 0.0f, att_scratch_p, a16));
         }
-        gemm("attn_out_resid", w.ctx.as<float>(), d, L.wo, d, L.bo, x, d, (int)rows, d, d, EPI_RESID, x, d, 1.0f, s);
+        gemm("attn_out_resid", w.ctx.as<float>(), d, L.wo, d, L.bo, x, d, (int)rows, d, d, EPI_RESID, x, d, 1.0f, s, a16, 0);
         if (stage_cap == 2) break;
         // ConformerConvModule::forward  :59-75
-        KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.cv_ng, L.cv_nb, 1e-5f, n, s));
-        gemm("conv_pw1_glu", n, d, L.pw1_w, d, L.pw1_b, w.g.as<float>(), d, (int)rows, d, d, EPI_GLU, nullptr, 0, 1.0f, s);
+        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, L.cv_ng, L.cv_nb, 1e-5f, n, s, a16));
+        gemm("conv_pw1_glu", n, d, L.pw1_w, d, L.pw1_b, w.g.as<float>(), d, (int)rows, d, d, EPI_GLU, nullptr, 0, 1.0f, s, a16, 0);
         KL("dwconv_bn_silu", (double)rows * d * cfg.conv_kernel_size * 2.0, 2.0 * rows * d * 4,
            launch_dwconv_bn_silu(w.g.as<float>(), B, T, d, cfg.conv_kernel_size, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
-                                 w.dwb.as<float>(), s));
-        gemm("conv_pw2_resid", w.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, (int)rows, d, d, EPI_RESID, x, d, 1.0f, s);
+                                 w.dwb.as<float>(), s, a16));
+        gemm("conv_pw2_resid", w.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, (int)rows, d, d, EPI_RESID, x, d, 1.0f, s, a16, 0);
         if (stage_cap == 3) break;
         ffn(w, L, true, rows, s);                                                    // ffn2_  :201
         if (stage_cap == 4) break;
         const bool next_runs = l + 1 < cfg.num_layers && !(l + 1 > stop_layer || (l + 1 == stop_layer && stop_stage == 0));
         if (next_runs) {           // final_norm_ :202 and the next block's ffn1_ norm :40 in one pass over the rows
             KL("layernorm", 0.0, 3.0 * rows * d * 4,
-               launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, layers[l + 1].ffn1_ng, layers[l + 1].ffn1_nb, 1e-5f, x, n, s));
+               launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, layers[l + 1].ffn1_ng, layers[l + 1].ffn1_nb, 1e-5f, x, n, s, a16));
             ffn1_norm_done = true;
         } else {
             KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, s));   // final_norm_ :202

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
                                                                const float *__restrict__ pos /*[2T-1][d], sigma columns*/,
                                                                const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                float scale, float *__restrict__ ctx, int PITS, int n_rb, int n_bh,
-                                                               float *__restrict__ s_scratch) {
+                                                               float *__restrict__ s_scratch, int ctx_bf16) {
     constexpr int KQ = HD / 4;
     constexpr int NQ4 = HD / 16;          // float4 fragments per lane for K = HD (one per block of 16 features)
     constexpr int VPIT = HD + 16;         // V rows, natural layout (pitch = 16 mod 32 banks)
@@ -282,14 +282,18 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int il = il_base + r;
-            if (il < rows) ctx[((int64_t)b * T + i0 + il) * d + h * HD + (cp + 2 * m) * 16 + l15] = acc[m][r];
+            if (il < rows) {
+                const int64_t o = ((int64_t)b * T + i0 + il) * d + h * HD + (cp + 2 * m) * 16 + l15;
+                if (ctx_bf16) reinterpret_cast<__bf16 *>(ctx)[o] = (__bf16)acc[m][r];      // bf16 mode: out_proj's operand, rounded here (RNE)
+                else ctx[o] = acc[m][r];
+            }
         }
     ATT_STAMP(7);
 }
 
 template <int HD, int VCH>
 static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u, const float *bias_v,
-                       float *ctx, float scale_arg, hipStream_t s, float *scratch) {
+                       float *ctx, float scale_arg, hipStream_t s, float *scratch, int ctx_bf16) {
     const float scale = scale_arg > 0.0f ? scale_arg : 1.0f / sqrtf((float)HD);   // src/encoder.cpp:126
     int pits = (T + 3) / 4;                                        // floats per score-plane row, padded so that pits/4 is odd
     pits = (pits + 3) & ~3;
@@ -300,7 +304,7 @@ static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const
         {
             const size_t lds = (size_t)VCH * (HD + 16) * sizeof(float);
             hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, true>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits,
-                               n_rb, n_bh, scratch);
+                               n_rb, n_bh, scratch, ctx_bf16);
         }
         return;
     }
@@ -311,7 +315,7 @@ static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const
         attr = lds;
     }
     hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, false>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits, n_rb, n_bh,
-                       (float *)nullptr);
+                       (float *)nullptr, ctx_bf16);
 }
 
 // LDS bytes one workgroup needs for T frames: the [32][T] score block (four k-planes) + one V chunk.  0: unsupported head size.
@@ -340,13 +344,13 @@ int relpos_attention_max_frames(int hd) {
 }
 
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
-                             const float *bias_v, float *ctx, hipStream_t s, float scale, float *scratch) {
+                             const float *bias_v, float *ctx, hipStream_t s, float scale, float *scratch, int ctx_bf16) {
     const int hd = d / n_heads;
     // V chunk rows: 64 keeps the footprint at ~39 KB for 10 s clips (4 workgroups per CU at hd = 64)
-    if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch);
-    else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch);
-    else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch);
-    else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch);
+    if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16);
+    else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16);
+    else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16);
+    else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16);
 }
 
 }  // namespace pk

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
                                                              const float *__restrict__ w /*[KC][d]*/, const float *__restrict__ bias,
                                                              const float *__restrict__ bn_mean, const float *__restrict__ bn_rstd,
                                                              const float *__restrict__ bn_g, const float *__restrict__ bn_b,
-                                                             int64_t n_items, float *__restrict__ out) {
+                                                             int64_t n_items, float *__restrict__ out, int out_bf16) {
     constexpr int HALF = (KC - 1) / 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_items) return;
@@ -28,6 +28,12 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
     const int t0 = strip * TT;
     const float4 *gp = reinterpret_cast<const float4 *>(g + (int64_t)b * T * d) + c4;       // row t at gp[t * d4]
     float4 *op = reinterpret_cast<float4 *>(out + (int64_t)b * T * d) + c4;
+    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+    bf16x4_ *oph = reinterpret_cast<bf16x4_ *>(reinterpret_cast<__bf16 *>(out) + (int64_t)b * T * d) + c4;   // bf16 mode: the pw2 GEMM's operand (RNE)
+    auto put = [&](int t, const float4 &v) {
+        if (out_bf16) oph[(int64_t)t * d4] = bf16x4_{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        else op[(int64_t)t * d4] = v;
+    };
     float4 wt[KC];
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) wt[kk] = reinterpret_cast<const float4 *>(w + (int64_t)kk * d)[c4];
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
                 acc.w = __builtin_fmaf(wt[kk].w, win[tt + kk].w, acc.w);
             }
             const float4 v = bn_silu(acc);
-            if (t < T) op[(int64_t)t * d4] = v;
+            if (t < T) put(t, v);
         }
     } else {
         float4 win[KC];                                                 // win[kk] = input row t + kk - HALF (sliding)
@@ -82,19 +88,19 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
                 acc.z = __builtin_fmaf(wt[kk].z, win[kk].z, acc.z);
                 acc.w = __builtin_fmaf(wt[kk].w, win[kk].w, acc.w);
             }
-            op[(int64_t)t * d4] = bn_silu(acc);
+            put(t, bn_silu(acc));
         }
     }
 }
 
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
-                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s) {
+                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16) {
     constexpr int TT = 8;
     const int n_strips = (T + TT - 1) / TT;
     const int64_t n_items = (int64_t)B * n_strips * (d / 4);          // d % 4 == 0 (hidden sizes are multiples of 32)
     const dim3 grid((unsigned)((n_items + 255) / 256));
-    if (kc == 9) hipLaunchKernelGGL((dwconv_bn_silu_kernel<9, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out);
-    else if (kc == 31) hipLaunchKernelGGL((dwconv_bn_silu_kernel<31, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out);
+    if (kc == 9) hipLaunchKernelGGL((dwconv_bn_silu_kernel<9, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out, out_bf16);
+    else if (kc == 31) hipLaunchKernelGGL((dwconv_bn_silu_kernel<31, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out, out_bf16);
 }
 
 }  // namespace pk

@@ -257,25 +257,35 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
 }
 
 // bf16 operands / fp32 accumulate (a.W points to bf16 weights [N][K]); K % 64 == 0
-template <int EPI>
+template <int EPI, bool A16>
 static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
     // round 2: the staging stores decide the rate of this kernel.  As 16-byte ds_write_b128 the 128x128 tile ran at 320-340 TF and 256x256
     // macro tiles were the way to 450 (profiles/r02_gemm_bf16_tiles.txt); the SAME 16 bytes written as a ds_write2_b64 pair
     // (gemm_bf16.hpp, lstore) take the 128x128 tile to 580 TF in the sweep and 510-600 TF in the engine (profiles/r02_gemm_bf16_ablation.txt)
     // -- the 16-byte LDS store is pathologically slow next to fragment reads on gfx950, as the fp32 kernel had already shown.
-    if (a.M >= 1024 && a.N >= 1024) launch_gemm_bf16_t<4, 2, 1, 2, EPI>(a, s);      // 128x128 on 8 waves of 32x64
-    else if (a.M >= 1024 && a.N >= 256) launch_gemm_bf16_t<2, 2, 2, 1, EPI>(a, s);
-    else launch_gemm_bf16_t<2, 2, 1, 1, EPI>(a, s);
+    if constexpr (EPI == EPI_GLU) {
+        launch_gemm_bf16_t<4, 2, 1, 2, EPI_GLU, A16>(a, s);
+    } else {
+        if (a.M >= 1024 && a.N >= 1024) launch_gemm_bf16_t<4, 2, 1, 2, EPI, A16>(a, s);      // 128x128 on 8 waves of 32x64
+        else if (a.M >= 1024 && a.N >= 256) launch_gemm_bf16_t<2, 2, 2, 1, EPI, A16>(a, s);
+        else launch_gemm_bf16_t<2, 2, 1, 1, EPI, A16>(a, s);
+    }
 }
-void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s) {
+template <bool A16>
+static void launch_gemm_bf16_a(const GemmArgs &a, int epi, hipStream_t s) {
     switch (epi) {
-    case EPI_NONE: launch_bf16_epi<EPI_NONE>(a, s); break;
-    case EPI_RELU: launch_bf16_epi<EPI_RELU>(a, s); break;
-    case EPI_SILU: launch_bf16_epi<EPI_SILU>(a, s); break;
-    case EPI_RESID: launch_bf16_epi<EPI_RESID>(a, s); break;
-    case EPI_GLU: launch_gemm_bf16_t<4, 2, 1, 2, EPI_GLU>(a, s); break;
+    case EPI_NONE: launch_bf16_epi<EPI_NONE, A16>(a, s); break;
+    case EPI_RELU: launch_bf16_epi<EPI_RELU, A16>(a, s); break;
+    case EPI_SILU: launch_bf16_epi<EPI_SILU, A16>(a, s); break;
+    case EPI_RESID: launch_bf16_epi<EPI_RESID, A16>(a, s); break;
+    case EPI_GLU: launch_bf16_epi<EPI_GLU, A16>(a, s); break;
     default: break;
     }
+}
+void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s) {
+    // (a bf16 output goes through the wide epilogue only -- row-major, 4-column groups: Model::run_gemm checks)
+    if (a.a_bf16) launch_gemm_bf16_a<true>(a, epi, s);
+    else launch_gemm_bf16_a<false>(a, epi, s);
 }
 
 double gemm_flops(const GemmArgs &a, int epi) {

@@ -18,14 +18,14 @@
 
 #ifndef BG_EXP
 #define BG_EXP 0                    // micro-benchmark experiments only (tools/ubench, results wrong, timing only): main loop without
-#endif                              // 16 = LDS stores, 32 = global loads, 64 = fragment reads; 512 = staging stores as ds_write_b128 instead of ds_write2_b64 pairs
+#endif                              // 16 = LDS stores, 32 = global loads, 64 = fragment reads; 512 = staging stores as ds_write_b128 instead of ds_write2_b64 pairs, 1024 = as two separate ds_write_b64
 
 namespace pk {
 
 typedef float bg_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bg_bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int WGM, int WGN, int TM, int TN, int EPI>
+template <int WGM, int WGN, int TM, int TN, int EPI, bool A16 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, int tiles_n, int n_tiles) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
@@ -50,15 +50,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
     }
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * NOUT;
 
-    const float *a_src[A_CH];
+    const float *a_src[A_CH];                                       // A16: bf16 rows (g.A reinterpreted, lda in elements)
     const __bf16 *w_src[W_CH];
+    const __bf16 *A16p = reinterpret_cast<const __bf16 *>(g.A);
     int a_dst[A_CH], w_dst[W_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         const int c = tid + NT * i, row = c >> 3, c8 = c & 7;
         int gr = m0 + row;
         gr = gr < g.M ? gr : g.M - 1;
-        a_src[i] = g.A + (int64_t)gr * g.lda + c8 * 8;
+        a_src[i] = A16 ? reinterpret_cast<const float *>(A16p + (int64_t)gr * g.lda + c8 * 8) : g.A + (int64_t)gr * g.lda + c8 * 8;
         a_dst[i] = row * PITCH + c8 * 8;
     }
 #pragma unroll
@@ -81,11 +82,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
 
     float4 ra[A_CH][2];
     uint4 rw[W_CH];
+    int opaque0 = 0;
+    if (BG_EXP & 1024) asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-            ra[i][0] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
-            ra[i][1] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK + 4);
+            if constexpr (A16) {
+                ra[i][0] = *reinterpret_cast<const float4 *>(a_src[i] + kt * (BK / 2));      // 8 bf16 = 16 bytes, already rounded by the producer
+            } else {
+                ra[i][0] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
+                ra[i][1] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK + 4);
+            }
         }
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const uint4 *>(w_src[i] + kt * BK);
@@ -94,10 +101,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
         __bf16 *base = smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
+            if constexpr (A16) {
+                lds_store16(base + a_dst[i], ra[i][0]);
+                continue;
+            }
             bg_bf16x8 v;
             v[0] = (__bf16)ra[i][0].x; v[1] = (__bf16)ra[i][0].y; v[2] = (__bf16)ra[i][0].z; v[3] = (__bf16)ra[i][0].w;
             v[4] = (__bf16)ra[i][1].x; v[5] = (__bf16)ra[i][1].y; v[6] = (__bf16)ra[i][1].z; v[7] = (__bf16)ra[i][1].w;
-            if (!(BG_EXP & 512)) {
+            if (BG_EXP & 1024) {                                   // two separate 8-byte stores the compiler cannot merge (opaque zero offset)
+                const float4 q = *reinterpret_cast<const float4 *>(&v);
+                *reinterpret_cast<float2 *>(base + a_dst[i]) = make_float2(q.x, q.y);
+                *reinterpret_cast<float2 *>(base + a_dst[i] + 4 + opaque0) = make_float2(q.z, q.w);
+            } else if (!(BG_EXP & 512)) {
                 lds_store16(base + a_dst[i], *reinterpret_cast<const float4 *>(&v));
             } else {
                 *reinterpret_cast<bg_bf16x8 *>(base + a_dst[i]) = v;
@@ -105,7 +120,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
         }
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) {
-            if (!(BG_EXP & 512)) {
+            if (BG_EXP & 1024) {
+                const float4 q = *reinterpret_cast<const float4 *>(&rw[i]);
+                *reinterpret_cast<float2 *>(base + w_dst[i]) = make_float2(q.x, q.y);
+                *reinterpret_cast<float2 *>(base + w_dst[i] + 4 + opaque0) = make_float2(q.z, q.w);
+            } else if (!(BG_EXP & 512)) {
                 lds_store16(base + w_dst[i], *reinterpret_cast<const float4 *>(&rw[i]));
             } else {
                 *reinterpret_cast<uint4 *>(base + w_dst[i]) = rw[i];
@@ -167,14 +186,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
     gp_epilogue<WGM, WGN, TM, TN, EPI, BUF>(g, acc, smem_f, m0, n0);     // 2 buffers x BUF bf16 = BUF floats
 }
 
-template <int WGM, int WGN, int TM, int TN, int EPI>
+template <int WGM, int WGN, int TM, int TN, int EPI, bool A16 = false>
 static void launch_gemm_bf16_t(const GemmArgs &a, hipStream_t s) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
     const int n_tiles = tiles_m * tiles_n;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * (64 + 8) * 2;
-    auto kern = &gemm_bf16_kernel<WGM, WGN, TM, TN, EPI>;
+    auto kern = &gemm_bf16_kernel<WGM, WGN, TM, TN, EPI, A16>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -181,11 +181,19 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
                 }
                 v[e] = x;
             }
-            if ((GP_EXP & 1) ? (row < 0) : (row < g.M && col_ok)) *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
+            if ((GP_EXP & 1) ? (row < 0) : (row < g.M && col_ok)) {
+                if (g.out_bf16) {                                   // bf16 activations (gemm_bf16.hpp): 4 results = 8 bytes
+                    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                    const bf16x4_ o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4_ *>(reinterpret_cast<__bf16 *>(g.out) + (int64_t)row * g.ldo + col0) = o;
+                } else {
+                    *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
         }
         }
     };
-    const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);
+    const bool wide = g.remap_rows == 0 && (g.ldo & 3) == 0 && (g.N & 3) == 0 && (EPI != EPI_RESID || (g.ldr & 3) == 0);   // (out_bf16 requires it: launcher)
     if (wide) epilogue_wide(m0, n0);
     else epilogue_scalar(m0, n0);
 }

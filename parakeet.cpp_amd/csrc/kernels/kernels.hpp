@@ -45,6 +45,10 @@ struct GemmArgs {
     // 4x4 index matrix is transposed (col -> (col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)).  The attention kernel reads
     // Q, K and the projected position table that way: a lane's float4 then holds its operands of 4 consecutive MFMA steps.
     int sigma_cols = 0;
+    // bf16 mode (launch_gemm_bf16 / gemm_bf16.hpp) only: A points to bf16 activations [M][lda] the producer already rounded (RNE, the
+    // rounding the staging path would apply -- same operand values, half the bytes); out points to a bf16 buffer [M][ldo] (the next
+    // product's A operand; row-major wide outputs only).
+    int a_bf16 = 0, out_bf16 = 0;
 };
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
 // same contract with bf16 operands and fp32 accumulation: a.W points to bf16 weights [N][K] (rounded once at upload), A is
@@ -64,9 +68,9 @@ size_t relpos_attention_lds_bytes(int T, int hd);     // 0: unsupported head siz
 int relpos_attention_max_frames(int hd);              // longest sequence one workgroup's LDS score block can hold
 size_t relpos_attention_scratch_bytes(int B, int T, int n_heads, int hd);   // long sequences: score blocks in global scratch (hd 64 / 128)
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
-                             const float *bias_v, float *ctx, hipStream_t s, float scale = 0.0f, float *scratch = nullptr);
+                             const float *bias_v, float *ctx, hipStream_t s, float scale = 0.0f, float *scratch = nullptr, int ctx_bf16 = 0);
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
-                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s);
+                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16 = 0);
 
 // ---- streaming encoder pieces (src/streaming_encoder.cpp) -----------------------------------------------------------------------
 // StreamingConformerAttention::forward_cached (:162-272) core for S streams x c query rows: keys / values = nc cached rows
@@ -149,10 +153,10 @@ size_t tdt_persistent_lds_bytes(const TdtState &st);
 void launch_tdt_persistent(const TdtPersist &p, hipStream_t s);
 
 // ---- LayerNorm, canonical reductions, math diagnostics ------------------------------------------
-void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s);
+void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s, int y_bf16 = 0);   // y_bf16: y is a bf16 buffer (RNE)
 // y1 = LN(x; g1, b1), y2 = LN(y1; g2, b2) in one pass (y1 may alias x)
 void launch_layernorm2(const float *x, int64_t rows, int d, const float *g1, const float *b1, const float *g2, const float *b2, float eps,
-                       float *y1, float *y2, hipStream_t s);
+                       float *y1, float *y2, hipStream_t s, int y2_bf16 = 0);
 void launch_sum64_rows(const float *x, int rows, int n, float *out, hipStream_t s);
 void launch_math(int fn, const float *in, float *out, int64_t n, hipStream_t s);   // 0 exp 1 log 2 tanh 3 sigmoid 4 silu 5 sqrt 6 recip 7 relu
 void launch_scale(float *x, int64_t n, float a, hipStream_t s);

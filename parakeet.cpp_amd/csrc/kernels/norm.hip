@@ -11,7 +11,7 @@ namespace pk {
 template <int PER_LANE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int64_t rows, int d,
                                                         const float *__restrict__ g, const float *__restrict__ b,
-                                                        float eps, float *__restrict__ y) {
+                                                        float eps, float *__restrict__ y, int y_bf16) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -37,10 +37,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     const float var = wave_sum64(q) / (float)d;
     const float rstd = 1.0f / __builtin_sqrtf(var + eps);
     float *yr = y + row * d;
+    __bf16 *yh = reinterpret_cast<__bf16 *>(y) + row * d;          // bf16 mode: the consuming GEMM's operand, rounded here instead of there
 #pragma unroll
     for (int j = 0; j < PER_LANE; ++j) {
         const int i = lane + 64 * j;
-        if (i < d) yr[i] = __builtin_fmaf((v[j] - mean) * rstd, g[i], b[i]);
+        if (i < d) {
+            const float o = __builtin_fmaf((v[j] - mean) * rstd, g[i], b[i]);
+            if (y_bf16) yh[i] = (__bf16)o;
+            else yr[i] = o;
+        }
     }
 }
 
@@ -51,7 +56,7 @@ template <int PER_LANE>
 __global__ __launch_bounds__(256) void layernorm2_kernel(const float *__restrict__ x, int64_t rows, int d, const float *__restrict__ g1,
                                                          const float *__restrict__ b1, const float *__restrict__ g2,
                                                          const float *__restrict__ b2, float eps, float *__restrict__ y1,
-                                                         float *__restrict__ y2) {
+                                                         float *__restrict__ y2, int y2_bf16) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -85,24 +90,25 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float *__restrict
             const int i = lane + 64 * j;
             if (i < d) {
                 v[j] = __builtin_fmaf((v[j] - mean) * rstd, g[i], b[i]);
-                yr[i] = v[j];
+                if (pass && y2_bf16) (reinterpret_cast<__bf16 *>(y2) + row * d)[i] = (__bf16)v[j];
+                else yr[i] = v[j];
             }
         }
     }
 }
 void launch_layernorm2(const float *x, int64_t rows, int d, const float *g1, const float *b1, const float *g2, const float *b2, float eps,
-                       float *y1, float *y2, hipStream_t s) {
+                       float *y1, float *y2, hipStream_t s, int y2_bf16) {
     const dim3 grid((unsigned)((rows + 3) / 4));
-    if (d <= 128) hipLaunchKernelGGL(layernorm2_kernel<2>, grid, dim3(256), 0, s, x, rows, d, g1, b1, g2, b2, eps, y1, y2);
-    else if (d <= 512) hipLaunchKernelGGL(layernorm2_kernel<8>, grid, dim3(256), 0, s, x, rows, d, g1, b1, g2, b2, eps, y1, y2);
-    else hipLaunchKernelGGL(layernorm2_kernel<16>, grid, dim3(256), 0, s, x, rows, d, g1, b1, g2, b2, eps, y1, y2);
+    if (d <= 128) hipLaunchKernelGGL(layernorm2_kernel<2>, grid, dim3(256), 0, s, x, rows, d, g1, b1, g2, b2, eps, y1, y2, y2_bf16);
+    else if (d <= 512) hipLaunchKernelGGL(layernorm2_kernel<8>, grid, dim3(256), 0, s, x, rows, d, g1, b1, g2, b2, eps, y1, y2, y2_bf16);
+    else hipLaunchKernelGGL(layernorm2_kernel<16>, grid, dim3(256), 0, s, x, rows, d, g1, b1, g2, b2, eps, y1, y2, y2_bf16);
 }
 
-void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s) {
+void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s, int y_bf16) {
     const dim3 grid((unsigned)((rows + 3) / 4));
-    if (d <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y);
-    else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y);
-    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y);
+    if (d <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
+    else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
+    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
 }
 
 __global__ __launch_bounds__(64) void sum64_rows_kernel(const float *__restrict__ x, int n, float *__restrict__ out) {
