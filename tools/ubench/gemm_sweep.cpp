@@ -315,6 +315,25 @@ int main(int argc, char **argv) {
             {"bf16 128x256 8w 64x64", launch_gemm_bf16_t<2, 4, 2, 2, EPI_SILU>, launch_gemm_bf16_t<2, 4, 2, 2, EPI_RESID>},
             {"bf16 256x128 8w 64x64", launch_gemm_bf16_t<4, 2, 2, 2, EPI_SILU>, launch_gemm_bf16_t<4, 2, 2, 2, EPI_RESID>},
         };
+        // bf16 copy of A for the variants whose A operand is already bf16 in HBM (GemmArgs::a_bf16)
+        __bf16 *dA16;
+        {
+            const size_t n = (size_t)12032 * 4096;
+            std::vector<float> hf(n);
+            CK(hipMemcpy(hf.data(), dA, n * 4, hipMemcpyDeviceToHost));
+            std::vector<unsigned short> hb(n);
+            for (size_t i = 0; i < n; ++i) { unsigned u; memcpy(&u, &hf[i], 4); hb[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+            CK(hipMalloc(&dA16, n * 2));
+            CK(hipMemcpy(dA16, hb.data(), n * 2, hipMemcpyHostToDevice));
+        }
+        const std::vector<KV> kv16 = {
+            {"bf16A 128x128 8w 32x64", launch_gemm_bf16_t<4, 2, 1, 2, EPI_SILU, true>, launch_gemm_bf16_t<4, 2, 1, 2, EPI_RESID, true>},
+            {"bf16A 256x128 8w 64x64", launch_gemm_bf16_t<4, 2, 2, 2, EPI_SILU, true>, launch_gemm_bf16_t<4, 2, 2, 2, EPI_RESID, true>},
+            {"bf16A 128x256 8w 64x64", launch_gemm_bf16_t<2, 4, 2, 2, EPI_SILU, true>, launch_gemm_bf16_t<2, 4, 2, 2, EPI_RESID, true>},
+            {"bf16A 256x256 8w 64x128", launch_gemm_bf16_t<4, 2, 2, 4, EPI_SILU, true>, launch_gemm_bf16_t<4, 2, 2, 4, EPI_RESID, true>},
+            {"bf16A 256x256 8w 128x64", launch_gemm_bf16_t<2, 4, 4, 2, EPI_SILU, true>, launch_gemm_bf16_t<2, 4, 4, 2, EPI_RESID, true>},
+            {"bf16A 128x128 4w 64x64", launch_gemm_bf16_t<2, 2, 2, 2, EPI_SILU, true>, launch_gemm_bf16_t<2, 2, 2, 2, EPI_RESID, true>},
+        };
         struct SH { const char *name; int M, N, K; bool resid; };
         const std::vector<SH> shs = {{"B fc1 12032x4096x1024 silu", 12032, 4096, 1024, false}, {"B fc2 12032x1024x4096 resid", 12032, 1024, 4096, true},
                                      {"B qkv 12032x3072x1024", 12032, 3072, 1024, false}, {"B out 12032x1024x1024 resid", 12032, 1024, 1024, true},
@@ -323,6 +342,20 @@ int main(int argc, char **argv) {
             printf("== %s  %.1f GFLOP\n", sh.name, 2.0 * sh.M * sh.N * sh.K * 1e-9);
             for (auto &v : kv) {
                 GemmArgs g{dA, sh.K, dW, sh.K, dB, dO, sh.N, dR, sh.N, 0.5f, sh.M, sh.N, sh.K};
+                auto &run = sh.resid ? v.resid : v.silu;
+                for (int i = 0; i < 3; ++i) run(g, s);
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < reps; ++i) run(g, s);
+                CK(hipEventRecord(e1, s));
+                CK(hipStreamSynchronize(s));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                ms /= reps;
+                printf("   %-28s %8.1f us  %7.1f TF\n", v.name, ms * 1e3, 2.0 * sh.M * sh.N * sh.K / ms * 1e-9);
+            }
+            for (auto &v : kv16) {
+                GemmArgs g{reinterpret_cast<const float *>(dA16), sh.K, dW, sh.K, dB, dO, sh.N, dR, sh.N, 0.5f, sh.M, sh.N, sh.K};
+                g.a_bf16 = 1;
                 auto &run = sh.resid ? v.resid : v.silu;
                 for (int i = 0; i < 3; ++i) run(g, s);
                 CK(hipEventRecord(e0, s));
