@@ -26,7 +26,7 @@ typedef float gp_f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GP_EXP
 #define GP_EXP 0                    // micro-benchmark experiments only (tools/ubench): 1 = epilogue without global stores,
 #endif                              // 2 = epilogue without activation math; main loop without 8 = barrier, 16 = LDS stores,
-                                    // 32 = global loads, 64 = fragment reads, 128 = MFMAs
+                                    // 32 = global loads, 64 = fragment reads, 128 = MFMAs; 1024 = staging stores as ds_write2_b64 pairs instead of four ds_write_b32
 #ifdef GP_CLOCKPROBE
 __device__ long long gp_clk[4];     // micro-benchmark builds only: shader / wall clock deltas of block 0
 __device__ long long *gp_trace;     // micro-benchmark builds only: [n_blocks][8] wall-clock stamps of wave 0 + hw id
@@ -274,18 +274,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const float4 *>(w_src[i] + kt * BK);
     };
+    // Staging stores: {a, b} at p, {c, d} at p + BK/2 floats.  FOUR 4-byte stores, not one ds_write2_b64: on gfx950 the finer the LDS store
+    // next to the fragment reads, the less it costs the loop -- 16-byte stores 98 TF, 8-byte pairs 134, 4-byte stores 141 TF of the 145 TF
+    // MFMA rate on the single-buffered 128x128 kernel (profiles/r02_gemm_lds_store_width.txt).  Inline, because the compiler would pair
+    // them again; the barrier that publishes them is preceded by lds_store_fence().
+    auto st2 = [&](float *p, float a, float b, float c, float d) {
+        // The products without an epilogue function (qkv: 756 tiles = 1.48 rounds of workgroups) keep the 8-byte pair form: there the 4-byte
+        // stores shift the round structure the wrong way (115.6 vs 107.3 us in the sweep, +19 % in the engine).
+        if ((GP_EXP & 1024) || EPI == EPI_NONE) {
+            *reinterpret_cast<float2 *>(p) = make_float2(a, b);
+            *reinterpret_cast<float2 *>(p + BK / 2) = make_float2(c, d);
+        } else {
+            const unsigned addr = (unsigned)(size_t)p;              // low 32 bits of a flat LDS address = the LDS offset
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:%5\n\tds_write_b32 %0, %4 offset:%6"
+                         ::"v"(addr), "v"(a), "v"(b), "v"(c), "v"(d), "n"(BK / 2 * 4), "n"(BK / 2 * 4 + 4) : "memory");
+        }
+    };
     auto lstore = [&](int buf) {
         float *base = smem + buf * BUF;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            *reinterpret_cast<float2 *>(base + a_dst[i]) = make_float2(ra[i].x, ra[i].z);             // k = 4c, 4c+2
-            *reinterpret_cast<float2 *>(base + a_dst[i] + BK / 2) = make_float2(ra[i].y, ra[i].w);    // k = 4c+1, 4c+3
-        }
+        for (int i = 0; i < A_CH; ++i) st2(base + a_dst[i], ra[i].x, ra[i].z, ra[i].y, ra[i].w);       // k = 4c, 4c+2 | k = 4c+1, 4c+3
 #pragma unroll
-        for (int i = 0; i < W_CH; ++i) {
-            *reinterpret_cast<float2 *>(base + w_dst[i]) = make_float2(rw[i].x, rw[i].z);
-            *reinterpret_cast<float2 *>(base + w_dst[i] + BK / 2) = make_float2(rw[i].y, rw[i].w);
-        }
+        for (int i = 0; i < W_CH; ++i) st2(base + w_dst[i], rw[i].x, rw[i].z, rw[i].y, rw[i].w);
     };
 
     gp_f32x16 acc[TM][TN];
@@ -343,6 +353,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     set_tile(blockIdx.x, m0, n0);
     gload(0);
     lstore(0);
+    lds_store_fence();
     __syncthreads();
     GP_STAMP(1);
     gload(1);                      // nk >= 2 (K >= 2*BK, checked by the launcher)
@@ -366,6 +377,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             if (more1) lstore(0);
             if (more2) gload(kt + 2);
             GP_SB(); mma((NSUB - 1) & 1); GP_SB();
+            lds_store_fence();                                      // the staging stores are inline (st2)
             __syncthreads();
             if (more1) fragload(0, 0, 0);
         }
@@ -382,6 +394,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             unsigned long long tA_ = 0, tB_ = 0;
             if (gp_tr2) asm volatile("s_memtime %0" : "=s"(tA_));
 #endif
+            lds_store_fence();
             if (!(GP_EXP & 8)) __syncthreads();
 #ifdef GP_CLOCKPROBE
             if (gp_tr2) {
