@@ -18,7 +18,7 @@
 
 #ifndef BG_EXP
 #define BG_EXP 0                    // micro-benchmark experiments only (tools/ubench, results wrong, timing only): main loop without
-#endif                              // 16 = LDS stores, 32 = global loads, 64 = fragment reads; 512 = staging stores as ds_write_b128 instead of ds_write2_b64 pairs, 1024 = as two separate ds_write_b64
+#endif                              // 16 = LDS stores, 32 = global loads, 64 = fragment reads; 512 = staging stores as ds_write_b128 instead of ds_write2_b64 pairs, 1024 = as two separate ds_write_b64, 2048 = as four ds_write_b32
 
 namespace pk {
 
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             if constexpr (A16) {
-                lds_store16(base + a_dst[i], ra[i][0]);
+                if (BG_EXP & 2048) lds_store16_b32(base + a_dst[i], ra[i][0]);
+                else lds_store16(base + a_dst[i], ra[i][0]);
                 continue;
             }
             bg_bf16x8 v;
@@ -112,6 +113,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
                 const float4 q = *reinterpret_cast<const float4 *>(&v);
                 *reinterpret_cast<float2 *>(base + a_dst[i]) = make_float2(q.x, q.y);
                 *reinterpret_cast<float2 *>(base + a_dst[i] + 4 + opaque0) = make_float2(q.z, q.w);
+            } else if (BG_EXP & 2048) {
+                lds_store16_b32(base + a_dst[i], *reinterpret_cast<const float4 *>(&v));
             } else if (!(BG_EXP & 512)) {
                 lds_store16(base + a_dst[i], *reinterpret_cast<const float4 *>(&v));
             } else {
@@ -124,6 +127,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
                 const float4 q = *reinterpret_cast<const float4 *>(&rw[i]);
                 *reinterpret_cast<float2 *>(base + w_dst[i]) = make_float2(q.x, q.y);
                 *reinterpret_cast<float2 *>(base + w_dst[i] + 4 + opaque0) = make_float2(q.z, q.w);
+            } else if (BG_EXP & 2048) {
+                lds_store16_b32(base + w_dst[i], *reinterpret_cast<const float4 *>(&rw[i]));
             } else if (!(BG_EXP & 512)) {
                 lds_store16(base + w_dst[i], *reinterpret_cast<const float4 *>(&rw[i]));
             } else {

@@ -127,6 +127,11 @@ __device__ __forceinline__ void lds_store16(void *lds_ptr, const float4 &v) {
     const unsigned addr = (unsigned)(size_t)lds_ptr;                 // low 32 bits of a flat LDS address = the LDS offset
     asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" ::"v"(addr), "v"(v2f_{v.x, v.y}), "v"(v2f_{v.z, v.w}) : "memory");
 }
+__device__ __forceinline__ void lds_store16_b32(void *lds_ptr, const float4 &v) {      // the same 16 bytes as four 4-byte stores
+    const unsigned addr = (unsigned)(size_t)lds_ptr;
+    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:8\n\tds_write_b32 %0, %4 offset:12"
+                 ::"v"(addr), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
+}
 __device__ __forceinline__ void lds_store_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Butterfly stage of the canonical 64-lane sum ("sum64"): p += p(lane ^ off), off = 32,16,...,1.
