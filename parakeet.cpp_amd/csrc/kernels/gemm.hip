@@ -198,10 +198,11 @@ static void launch_one(const GemmArgs &a, hipStream_t s) {
 // products 128x64, everything else 64x64 (more resident workgroups to overlap one tile's epilogue with another's MFMAs).
 // PK_GEMM_VARIANT: A/B switch between the double-buffered ("pipe", NBUF = 2) and single-buffered ("sb", NBUF = 1) staging of the same
 // tiles (tools/experiments/gemm_variant_ab.sh).  Bits: 1 = long-K single-round products (fc2, sub_proj) on sb 128x128 / 8 waves of 32x64 /
-// BK 64; 2 = wide outputs (fc1, qkv, sub_pw) on sb; 4 = out_proj / pw2 on sb 64x128 / 4 waves; 8 = GLU on sb; 16 = wide outputs on sb BK 64.
-// Default 11 = what the engine measurement of round 2 picked (profiles/r02_gemm_variant_ab.txt: step 20.44 -> 19.73 ms; bit 4 is level).
+// BK 64; 2 = wide outputs (fc1, qkv, sub_pw) on sb; 4 = out_proj / pw2 on sb 64x128 / 4 waves; 8 = GLU on sb; 16 = wide outputs on sb BK 64; 64 = out_proj / pw2 on sb 128x128 / 8 waves.
+// Default 75 = what the engine measurements of round 2 picked (profiles/r02_gemm_variant_ab.txt: step 20.44 -> 19.73 ms with 11; bit 4 is
+// level; bit 64 takes out_proj / pw2 from 0.81 to 0.77 ms per step).
 static int gemm_variant_mask() {
-    static const int m = [] { const char *e = getenv("PK_GEMM_VARIANT"); return e ? atoi(e) : 11; }();
+    static const int m = [] { const char *e = getenv("PK_GEMM_VARIANT"); return e ? atoi(e) : 75; }();
     return m;
 }
 
@@ -229,7 +230,8 @@ static void launch_epi(const GemmArgs &a, hipStream_t s) {
     }
     else if (a.M >= 1024 && a.N >= 256 && a.K >= 1024) launch_gemm_pipe<2, 2, 2, 1, 32, EPI>(a, s);
     else if (a.M >= 1024 && a.N >= 256) {
-        if (vm & 4) launch_gemm_pipe<2, 2, 1, 2, 32, EPI, 1>(a, s);
+        if (vm & 64) launch_gemm_pipe<4, 2, 1, 2, 32, EPI, 1>(a, s);
+        else if (vm & 4) launch_gemm_pipe<2, 2, 1, 2, 32, EPI, 1>(a, s);
         else launch_gemm_pipe<2, 4, 1, 1, 32, EPI>(a, s);      // 64x128 on 8 waves of 32x32: out_proj / pw2 (-7 %)
     }
     else launch_gemm_pipe<2, 2, 1, 1, 32, EPI>(a, s);
