@@ -13,6 +13,7 @@
 #include "../../parakeet.cpp_amd/csrc/kernels/gemm.hip"
 #include "gemm_dma.hpp"
 #include "gemm_pd.hpp"
+#include "gemm_bf16p.hpp"
 #include "../../parakeet.cpp_amd/csrc/kernels/gemm_smallm.hip"   // first-generation kernel + launch_gemm
 
 using namespace pk;
@@ -333,6 +334,13 @@ int main(int argc, char **argv) {
             {"bf16A 256x256 8w 64x128", launch_gemm_bf16_t<4, 2, 2, 4, EPI_SILU, true>, launch_gemm_bf16_t<4, 2, 2, 4, EPI_RESID, true>},
             {"bf16A 256x256 8w 128x64", launch_gemm_bf16_t<2, 4, 4, 2, EPI_SILU, true>, launch_gemm_bf16_t<2, 4, 4, 2, EPI_RESID, true>},
             {"bf16A 128x128 4w 64x64", launch_gemm_bf16_t<2, 2, 2, 2, EPI_SILU, true>, launch_gemm_bf16_t<2, 2, 2, 2, EPI_RESID, true>},
+            {"bf16P 128x128 8w 32x64 pf3", launch_gemm_bf16p_t<4, 2, 1, 2, EPI_SILU, 3>, launch_gemm_bf16p_t<4, 2, 1, 2, EPI_RESID, 3>},
+            {"bf16P 256x128 8w 64x64 pf2", launch_gemm_bf16p_t<4, 2, 2, 2, EPI_SILU, 2>, launch_gemm_bf16p_t<4, 2, 2, 2, EPI_RESID, 2>},
+            {"bf16P 256x128 8w 64x64 pf3", launch_gemm_bf16p_t<4, 2, 2, 2, EPI_SILU, 3>, launch_gemm_bf16p_t<4, 2, 2, 2, EPI_RESID, 3>},
+            {"bf16P 256x128 8w 64x64 pf4", launch_gemm_bf16p_t<4, 2, 2, 2, EPI_SILU, 4>, launch_gemm_bf16p_t<4, 2, 2, 2, EPI_RESID, 4>},
+            {"bf16P 128x256 8w 64x64 pf3", launch_gemm_bf16p_t<2, 4, 2, 2, EPI_SILU, 3>, launch_gemm_bf16p_t<2, 4, 2, 2, EPI_RESID, 3>},
+            {"bf16P 256x256 8w 64x128 pf2", launch_gemm_bf16p_t<4, 2, 2, 4, EPI_SILU, 2>, launch_gemm_bf16p_t<4, 2, 2, 4, EPI_RESID, 2>},
+            {"bf16P 256x256 8w 64x128 pf3", launch_gemm_bf16p_t<4, 2, 2, 4, EPI_SILU, 3>, launch_gemm_bf16p_t<4, 2, 2, 4, EPI_RESID, 3>},
         };
         struct SH { const char *name; int M, N, K; bool resid; };
         const std::vector<SH> shs = {{"B fc1 12032x4096x1024 silu", 12032, 4096, 1024, false}, {"B fc2 12032x1024x4096 resid", 12032, 1024, 4096, true},
