@@ -13,9 +13,9 @@ namespace pk {
 // e^x.  n = rne(x*log2e) by the 1.5*2^23 trick; r = x - n*ln2 in two parts; e^r = 1 + (r + r^2 E(r));
 // result scaled by 2^n in two exact steps (n/2 floor, remainder).  > 88.7228 -> +inf, < -87.3365 -> 0.
 __device__ __forceinline__ float dexpf(float x) {
-    if (x != x) return x;
-    if (x > 88.72283935546875f) return __builtin_huge_valf();
-    if (x < -87.33654022216797f) return 0.0f;
+    // Branch-free: the range cases are SELECTS on the finished arithmetic (same values as the early returns of the specification; a lane
+    // outside the range computes garbage that is discarded).  With early returns the compiler emitted three nested exec-mask branches per
+    // element, which also kept it from interleaving the independent chains of an epilogue's four outputs.
     const float t = __builtin_fmaf(x, 1.44269502162933349609375f, 12582912.0f);
     const float n = t - 12582912.0f;
     float r = __builtin_fmaf(n, -0.693145751953125f, x);
@@ -27,12 +27,16 @@ __device__ __forceinline__ float dexpf(float x) {
     e = __builtin_fmaf(e, r, 0.5f);
     const float q = __builtin_fmaf(r * r, e, r);
     const float p = q + 1.0f;
-    const int ni = (int)n;
-    const int n1 = ni >> 1;
+    const int ni = (int)__builtin_amdgcn_fmed3f(n, -160.0f, 160.0f);   // in range: n itself; outside: any finite value (a float -> int
+    const int n1 = ni >> 1;                                            // conversion out of range would be undefined behaviour)
     const int n2 = ni - n1;
     const float s1 = __int_as_float((n1 + 127) << 23);
     const float s2 = __int_as_float((n2 + 127) << 23);
-    return (p * s1) * s2;
+    float y = (p * s1) * s2;
+    y = x < -87.33654022216797f ? 0.0f : y;
+    y = x > 88.72283935546875f ? __builtin_huge_valf() : y;
+    y = x != x ? x : y;
+    return y;
 }
 
 // e^x for x <= 0 (softmax / log-softmax arguments: value minus the row maximum).  The SAME value as dexpf(x), bit for bit, for every
@@ -40,7 +44,6 @@ __device__ __forceinline__ float dexpf(float x) {
 // propagates through the arithmetic, and because n >= -126 the scale 2^n is a normal number, so one multiplication rounds exactly
 // like dexpf's two exact-then-rounded steps.  9 VALU operations fewer per element.
 __device__ __forceinline__ float dexpf_nonpos(float x) {
-    if (x < -87.33654022216797f) return 0.0f;
     const float t = __builtin_fmaf(x, 1.44269502162933349609375f, 12582912.0f);
     const float n = t - 12582912.0f;
     float r = __builtin_fmaf(n, -0.693145751953125f, x);
@@ -52,7 +55,8 @@ __device__ __forceinline__ float dexpf_nonpos(float x) {
     e = __builtin_fmaf(e, r, 0.5f);
     const float q = __builtin_fmaf(r * r, e, r);
     const float p = q + 1.0f;
-    return p * __int_as_float(((int)n + 127) << 23);
+    const float y = p * __int_as_float(((int)__builtin_amdgcn_fmed3f(n, -160.0f, 160.0f) + 127) << 23);
+    return x < -87.33654022216797f ? 0.0f : y;                      // (a select, not a branch: see dexpf)
 }
 
 // ln x.  x = m 2^e with m in [sqrt(1/2), sqrt(2)); f = m - 1; ln(1+f) = f - f^2/2 + f^3 L(f); + e ln2 in two parts.
