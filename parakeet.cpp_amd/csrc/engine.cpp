@@ -405,6 +405,7 @@ void Model::gemm(const char *name, const float *A, int64_t lda, const float *W, 
     GemmArgs g{A, lda, W, ldw, bias, out, ldo, resid, ldr, alpha, M, N, K};
     g.a_bf16 = a_bf16;
     g.out_bf16 = out_bf16;
+    g.fast_act = (cfg.gemm_bf16 && (epi == EPI_SILU || epi == EPI_GLU)) ? 1 : 0;     // bf16 mode: tolerance-class activations (kernels.hpp)
     run_gemm(name, g, epi, s);
 }
 

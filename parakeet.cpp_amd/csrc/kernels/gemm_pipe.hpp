@@ -69,14 +69,14 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
                     if constexpr (EPI == EPI_RELU) {
                         v = v > 0.0f ? v : 0.0f;
                     } else if constexpr (EPI == EPI_SILU) {
-                        v = dsiluf(v);
+                        v = g.fast_act ? fast_siluf(v) : dsiluf(v);
                     } else if constexpr (EPI == EPI_RESID) {
                         const float y = v * g.alpha;
                         v = g.resid[(int64_t)row * g.ldr + col] + y;
                     } else if constexpr (EPI == EPI_GLU) {
                         float gt = acc[i][j + TN / 2][r];
                         if (g.bias) gt = gt + bias_g;
-                        v = v * dsigmoidf(gt);
+                        v = v * (g.fast_act ? fast_sigmoidf(gt) : dsigmoidf(gt));
                     }
                     if (g.remap_rows) g.out[(int64_t)(row / g.remap_rows) * g.remap_gs + (int64_t)(row % g.remap_rows) * g.remap_rs + (int64_t)col * g.remap_cs] = v;
                     else g.out[(int64_t)row * g.ldo + (col < g.sigma_cols ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = v;
@@ -170,14 +170,14 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
                 if constexpr (EPI == EPI_RELU) {
                     x = x > 0.0f ? x : 0.0f;
                 } else if constexpr (EPI == EPI_SILU) {
-                    if (!(GP_EXP & 2)) x = dsiluf(x);
+                    if (!(GP_EXP & 2)) x = g.fast_act ? fast_siluf(x) : dsiluf(x);
                 } else if constexpr (EPI == EPI_RESID) {
                     const float y = x * g.alpha;
                     x = rsv[e] + y;
                 } else if constexpr (EPI == EPI_GLU) {
                     float t2 = gt[e];
                     if (g.bias) t2 = t2 + bg[e];
-                    x = x * dsigmoidf(t2);
+                    x = x * (g.fast_act ? fast_sigmoidf(t2) : dsigmoidf(t2));
                 }
                 v[e] = x;
             }

@@ -49,6 +49,10 @@ struct GemmArgs {
     // rounding the staging path would apply -- same operand values, half the bytes); out points to a bf16 buffer [M][ldo] (the next
     // product's A operand; row-major wide outputs only).
     int a_bf16 = 0, out_bf16 = 0;
+    // bf16 mode only: SiLU / sigmoid of the epilogue on the hardware exp2 / rcp (1 ulp) instead of the fixed polynomial + IEEE division of the
+    // numerics contract -- that mode is compared with the oracle within a bf16-epsilon-class tolerance, not bit for bit, and at bf16 MFMA rates
+    // the 38-operation SiLU is as expensive as the product itself (fc1 of tdt-600m: ~48 us of VALU against 40 us of MFMA).
+    int fast_act = 0;
 };
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
 // same contract with bf16 operands and fp32 accumulation: a.W points to bf16 weights [N][K] (rounded once at upload), A is

@@ -121,6 +121,9 @@ __device__ __forceinline__ float dtanhf(float x) {
 }
 
 __device__ __forceinline__ float dsigmoidf(float x) { return 1.0f / (1.0f + dexpf(-x)); }
+// bf16 mode only (GemmArgs::fast_act): hardware v_exp_f32 / v_rcp_f32, ~1 ulp each -- NOT part of the bit-exact contract
+__device__ __forceinline__ float fast_sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f)); }
+__device__ __forceinline__ float fast_siluf(float x) { return x * fast_sigmoidf(x); }
 __device__ __forceinline__ float dsiluf(float x) { return x / (1.0f + dexpf(-x)); }
 
 // 16 bytes to LDS as a ds_write2_b64 pair.  On gfx950 a 16-byte ds_write_b128 next to fragment reads is several times slower than the
