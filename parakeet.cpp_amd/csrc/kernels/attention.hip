@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
 #pragma unroll
             for (int k = 0; k < NSR; ++k) {
                 const int a = sidx(wave + 4 * k, j);
-                const float e = dexpf_nonpos(S[a] - mx[k]);       // S <= row maximum
+                // bf16 mode (ctx_bf16: tolerance-class, see GemmArgs::fast_act): hardware exp2 instead of the fixed polynomial
+                const float e = ctx_bf16 ? __builtin_amdgcn_exp2f((S[a] - mx[k]) * 1.44269502162933349609375f) : dexpf_nonpos(S[a] - mx[k]);   // S <= row maximum
                 S[a] = e;
                 sm[k] = sm[k] + e;
             }
@@ -238,12 +239,23 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
         for (int off = 32; off >= 1; off >>= 1)                      // the canonical sum64 butterfly, NSR rows side by side
 #pragma unroll
             for (int k = 0; k < NSR; ++k) sm[k] = sm[k] + __shfl_xor(sm[k], off, 64);
-        for (int j = lane; j < T; j += 64)
+        if (ctx_bf16) {                                              // bf16 mode: one hardware reciprocal per row, a multiplication per element
 #pragma unroll
-            for (int k = 0; k < NSR; ++k) {
-                const int a = sidx(wave + 4 * k, j);
-                S[a] = S[a] / sm[k];
-            }
+            for (int k = 0; k < NSR; ++k) sm[k] = __builtin_amdgcn_rcpf(sm[k]);
+            for (int j = lane; j < T; j += 64)
+#pragma unroll
+                for (int k = 0; k < NSR; ++k) {
+                    const int a = sidx(wave + 4 * k, j);
+                    S[a] = S[a] * sm[k];
+                }
+        } else {
+            for (int j = lane; j < T; j += 64)
+#pragma unroll
+                for (int k = 0; k < NSR; ++k) {
+                    const int a = sidx(wave + 4 * k, j);
+                    S[a] = S[a] / sm[k];
+                }
+        }
     }
     ATT_STAMP(6);
     v_commit();

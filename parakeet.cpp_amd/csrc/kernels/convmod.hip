@@ -43,10 +43,15 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
     auto row = [&](int t) { return (t >= 0 && t < T) ? gp[(int64_t)t * d4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); };
     auto bn_silu = [&](float4 acc) {
         float4 v;
-        v.x = dsiluf(__builtin_fmaf(((acc.x + bi.x) - mu.x) * rs.x, ga.x, be.x));
-        v.y = dsiluf(__builtin_fmaf(((acc.y + bi.y) - mu.y) * rs.y, ga.y, be.y));
-        v.z = dsiluf(__builtin_fmaf(((acc.z + bi.z) - mu.z) * rs.z, ga.z, be.z));
-        v.w = dsiluf(__builtin_fmaf(((acc.w + bi.w) - mu.w) * rs.w, ga.w, be.w));
+        v.x = __builtin_fmaf(((acc.x + bi.x) - mu.x) * rs.x, ga.x, be.x);
+        v.y = __builtin_fmaf(((acc.y + bi.y) - mu.y) * rs.y, ga.y, be.y);
+        v.z = __builtin_fmaf(((acc.z + bi.z) - mu.z) * rs.z, ga.z, be.z);
+        v.w = __builtin_fmaf(((acc.w + bi.w) - mu.w) * rs.w, ga.w, be.w);
+        if (out_bf16) {                                                 // bf16 mode: tolerance-class activation (GemmArgs::fast_act)
+            v.x = fast_siluf(v.x); v.y = fast_siluf(v.y); v.z = fast_siluf(v.z); v.w = fast_siluf(v.w);
+        } else {
+            v.x = dsiluf(v.x); v.y = dsiluf(v.y); v.z = dsiluf(v.z); v.w = dsiluf(v.w);
+        }
         return v;
     };
     if constexpr (KC + TT - 1 <= 16) {
