@@ -6,7 +6,9 @@ bit for bit; this one cannot be (the MFMA does not sum a 16-wide product group a
    a 1-ulp fp32 difference in an activation can flip its bf16 rounding (2^-8 relative) in one implementation and not the
    other, so two correct bf16 implementations agree only to bf16-epsilon class: encoder output within 2e-2 * max|x| (and a
    mean deviation below 2e-3 * max|x|, i.e. well under the bf16-vs-fp32 gap itself), token agreement (1 - edit distance / length) >= 95 %
-   asserted (observed: identical on the tiny model, one differing token in 66 on the 600M cut) so that a legitimate near-tie flip does not fail the suite."""
+   asserted (observed: identical on the tiny model, one differing token in 66 on the 600M cut) so that a legitimate near-tie flip does not fail the suite.
+   Since round 2 the mode also stores GEMM-only activations as bf16 (same rounded operand values) and evaluates SiLU / sigmoid / the attention
+   softmax on the hardware exp2 / rcp (1 ulp fp32, far below bf16 epsilon): same tolerances."""
 import dataclasses
 
 import numpy as np
