@@ -268,7 +268,7 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
     if constexpr (EPI == EPI_GLU) {
         launch_gemm_bf16_t<4, 2, 1, 2, EPI_GLU, A16>(a, s);
     } else {
-        if (a.M >= 1024 && a.N >= 1024) launch_gemm_bf16_t<4, 2, 1, 2, EPI, A16>(a, s);      // 128x128 on 8 waves of 32x64
+        if (a.M >= 1024 && (a.N >= 1024 || (a.M >= 65536 && a.N >= 256))) launch_gemm_bf16_t<4, 2, 1, 2, EPI, A16>(a, s);      // 128x128 on 8 waves of 32x64 (also the 1.4 M-row subsampling products)
         else if (a.M >= 1024 && a.N >= 256) launch_gemm_bf16_t<2, 2, 2, 1, EPI, A16>(a, s);
         else launch_gemm_bf16_t<2, 2, 1, 1, EPI, A16>(a, s);
     }
