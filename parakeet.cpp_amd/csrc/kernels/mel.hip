@@ -35,9 +35,17 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
     __shared__ float s_re[kFramesPerBlock][kNfft];
     __shared__ float s_im[kFramesPerBlock][kNfft];
     __shared__ float s_pw[kFramesPerBlock][260];
-    __shared__ float s_twr[kNfft / 2], s_twi[kNfft / 2];    // twiddles and the packed filterbank bands: read ~100 times per lane and
-    __shared__ float s_fb[kMelMaxTaps];                     // frame -- from LDS instead of dependent L1 / L2 round trips
-    for (int i = threadIdx.x; i < kNfft / 2; i += 256) { s_twr[i] = tb.tw_re[i]; s_twi[i] = tb.tw_im[i]; }
+    // twiddles and the packed filterbank bands: read ~100 times per lane and frame -- from LDS instead of dependent L1 / L2 round trips.
+    // The twiddles are laid out PER STAGE (stage lh uses w^(j << (8 - lh)), j < 2^lh, stored at 2^lh - 1 + j): the lanes of a butterfly
+    // stage then read consecutive words (or broadcast) instead of a 2^(8-lh)-word stride that put 8 lanes on one bank in stages 3-6
+    // (round 1: 8.5e7 LDS bank-conflict cycles per dispatch).
+    __shared__ float s_twr[kNfft], s_twi[kNfft];
+    __shared__ float s_fb[kMelMaxTaps];
+    for (int i = threadIdx.x; i < kNfft - 1; i += 256) {
+        const int lh = 31 - __builtin_clz(i + 1), j = i + 1 - (1 << lh);   // i = 2^lh - 1 + j
+        s_twr[i] = tb.tw_re[j << (8 - lh)];
+        s_twi[i] = tb.tw_im[j << (8 - lh)];
+    }
     for (int i = threadIdx.x; i < tb.fb_nnz; i += 256) s_fb[i] = tb.fbc[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
                 const int j = q & (h - 1);
                 const int a = ((q >> lh) << (lh + 1)) + j;
                 const int bb = a + h;
-                const float cr = s_twr[j << (8 - lh)], ci = s_twi[j << (8 - lh)];
+                const float cr = s_twr[h - 1 + j], ci = s_twi[h - 1 + j];
                 const float br = re[bb], bi = im[bb];
                 const float tr = __builtin_fmaf(-ci, bi, cr * br);
                 const float ti = __builtin_fmaf(ci, br, cr * bi);
