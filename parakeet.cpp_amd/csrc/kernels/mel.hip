@@ -28,12 +28,15 @@ static constexpr int kFramesPerBlock = 4;
 // Every wavefront owns one frame and touches only its own LDS arrays, so the stages are ordered by wave-local fences (LDS
 // operations of one wave complete in order once the counter is drained) instead of workgroup barriers: four frames of a
 // workgroup no longer wait for each other ten times per FFT.
+#define PK_FP(i) ((i) + ((i) >> 5))
 #define PK_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <bool STREAM>
 __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict__ pcm, int64_t n_samples, int n_frames,
                                                          MelTables tb, float *__restrict__ logmel) {
-    __shared__ float s_re[kFramesPerBlock][kNfft];
-    __shared__ float s_im[kFramesPerBlock][kNfft];
+    // FFT arrays with one pad word per 32 (element i at i + (i >> 5)): the butterfly strides 2^lh of the in-place radix-2 stages would
+    // otherwise put two to eight lanes on one LDS bank
+    __shared__ float s_re[kFramesPerBlock][kNfft + kNfft / 32];
+    __shared__ float s_im[kFramesPerBlock][kNfft + kNfft / 32];
     __shared__ float s_pw[kFramesPerBlock][260];
     // twiddles and the packed filterbank bands: read ~100 times per lane and frame -- from LDS instead of dependent L1 / L2 round trips.
     // The twiddles are laid out PER STAGE (stage lh uses w^(j << (8 - lh)), j < 2^lh, stored at 2^lh - 1 + j): the lanes of a butterfly
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
             const int n = lane + 64 * i;
             const int r = (int)(__brev((unsigned)n) >> 23);       // 9-bit reversal
             if constexpr (STREAM) {
-                re[r] = n < 400 ? x[(int64_t)t * kHop + n] * tb.window_left[n] : 0.0f;
+                re[PK_FP(r)] = n < 400 ? x[(int64_t)t * kHop + n] * tb.window_left[n] : 0.0f;
             } else {
                 int64_t idx = (int64_t)t * kHop + n - kNfft / 2;  // center=true
                 if (idx < 0) idx = -idx;                          // pad_mode="reflect"
@@ -73,9 +76,9 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
                     const float p = 0.97f * x[idx - 1];
                     v = x[idx] - p;
                 }
-                re[r] = v * tb.window[n];
+                re[PK_FP(r)] = v * tb.window[n];
             }
-            im[r] = 0.0f;
+            im[PK_FP(r)] = 0.0f;
         }
     }
     PK_WAVE_SYNC();
@@ -90,21 +93,22 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
                 const int a = ((q >> lh) << (lh + 1)) + j;
                 const int bb = a + h;
                 const float cr = s_twr[h - 1 + j], ci = s_twi[h - 1 + j];
-                const float br = re[bb], bi = im[bb];
+                const int pa = PK_FP(a), pb = PK_FP(bb);
+                const float br = re[pb], bi = im[pb];
                 const float tr = __builtin_fmaf(-ci, bi, cr * br);
                 const float ti = __builtin_fmaf(ci, br, cr * bi);
-                const float ar = re[a], ai = im[a];
-                re[bb] = ar - tr;
-                im[bb] = ai - ti;
-                re[a] = ar + tr;
-                im[a] = ai + ti;
+                const float ar = re[pa], ai = im[pa];
+                re[pb] = ar - tr;
+                im[pb] = ai - ti;
+                re[pa] = ar + tr;
+                im[pa] = ai + ti;
             }
         }
         PK_WAVE_SYNC();
     }
     if (live) {
         for (int f = lane; f <= kNfft / 2; f += 64) {
-            const float s = __builtin_fmaf(re[f], re[f], im[f] * im[f]);
+            const float s = __builtin_fmaf(re[PK_FP(f)], re[PK_FP(f)], im[PK_FP(f)] * im[PK_FP(f)]);
             if (tb.power_via_abs) {                               // abs() then square, src/audio.cpp:123-124
                 const float mag = __builtin_sqrtf(s);
                 pw[f] = mag * mag;
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
 }
 
 #undef PK_WAVE_SYNC
+#undef PK_FP
 
 // Per-bin mean / unbiased variance normalisation + transpose to [B][n_frames][n_mels] (src/audio.cpp:140-156).  One wavefront per
 // (clip, mel bin) for the two canonical sum64 reductions over the frames; the 16 bins of a workgroup then go through a
