@@ -28,11 +28,10 @@ __device__ __forceinline__ float dexpf(float x) {
     const float q = __builtin_fmaf(r * r, e, r);
     const float p = q + 1.0f;
     const int ni = (int)__builtin_amdgcn_fmed3f(n, -160.0f, 160.0f);   // in range: n itself; outside: any finite value (a float -> int
-    const int n1 = ni >> 1;                                            // conversion out of range would be undefined behaviour)
-    const int n2 = ni - n1;
-    const float s1 = __int_as_float((n1 + 127) << 23);
-    const float s2 = __int_as_float((n2 + 127) << 23);
-    float y = (p * s1) * s2;
+                                                                       // conversion out of range would be undefined behaviour)
+    // p 2^n with ONE rounding: v_ldexp_f32.  The specification's two exact-then-rounded multiplications (2^(n>>1), then the rest) give
+    // the same float for every x of the arithmetic range (all 2 237 668 969 of them compared on the host, tools/verify_exp_nonpos.c).
+    float y = __builtin_ldexpf(p, ni);
     y = x < -87.33654022216797f ? 0.0f : y;
     y = x > 88.72283935546875f ? __builtin_huge_valf() : y;
     y = x != x ? x : y;
@@ -55,7 +54,7 @@ __device__ __forceinline__ float dexpf_nonpos(float x) {
     e = __builtin_fmaf(e, r, 0.5f);
     const float q = __builtin_fmaf(r * r, e, r);
     const float p = q + 1.0f;
-    const float y = p * __int_as_float(((int)__builtin_amdgcn_fmed3f(n, -160.0f, 160.0f) + 127) << 23);
+    const float y = __builtin_ldexpf(p, (int)__builtin_amdgcn_fmed3f(n, -160.0f, 160.0f));
     return x < -87.33654022216797f ? 0.0f : y;                      // (a select, not a branch: see dexpf)
 }
 
