@@ -30,7 +30,7 @@ D_MODEL, FFN, ENC_FRAMES = 512, 2048, 126
 FC1_KERNEL = {False: "gemm_pipe_kernel<4,2,1,2,32,EPI_SILU,1> (ffn_fc1_silu: fp32 v_mfma_f32_32x32x2_f32, 128x128 tile, 8 waves of 32x64, 1 LDS staging buffer, 4-byte staging stores)",
               True: "gemm_bf16_kernel<4,2,1,2,EPI_SILU> (ffn_fc1_silu: v_mfma_f32_32x32x16_bf16, 128x128 tile, 8 waves of 32x64, ds_write2_b64 staging)"}
 # committed rocprofv3 --pmc summaries (HBM bytes per launch of the dominant kernel), newest first, per (config, bf16)
-PMC_FILES = {("tdt-ctc-110m", False): ("r02_pmc_hbm_v3.json", "r02_pmc_hbm_v2.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json")}
+PMC_FILES = {("tdt-ctc-110m", False): ("r02_pmc_hbm_v4.json", "r02_pmc_hbm_v3.json", "r02_pmc_hbm_v2.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json")}
 
 
 def log(*a):
