@@ -210,6 +210,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;      // output columns per block
     static_assert(EPI != EPI_GLU || (TN % 2 == 0), "GLU needs an even number of column tiles per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // Wave priority 3: the encoder's GEMM waves win instruction arbitration against the decode-loop waves of the previous batch that share
+    // the SIMD (default priority 0, latency-tolerant: their stream has 3-7x slack).  rocprofv3 trace of round 2: a GEMM launch that overlaps
+    // decode kernels ran 8-27 % longer (fc2, one workgroup per CU and a single round, the most).
+    __builtin_amdgcn_s_setprio(3);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
