@@ -70,7 +70,10 @@ typedef struct pk_config {
     int32_t gemm_bf16;             /* 0: every product is an fp32 fma chain (bit-identical to the CPU oracle).  1: the encoder-side Linear /
                                       1x1-conv products (and the CTC / enc_proj heads) take bf16 operands with fp32 accumulation on
                                       v_mfma_f32_32x32x16_bf16 -- the precision BASELINE configs[2] names for tdt-600m; the decode loop,
-                                      attention scores, norms and depthwise convs stay fp32.  Needs every such K % 64 == 0. */
+                                      attention scores, norms and depthwise convs stay fp32.  Needs every such K % 64 == 0.  This mode is
+                                      compared with the oracle within a tolerance, never bit for bit; since round 2 it also stores the
+                                      activations that exist only as GEMM operands as bf16 (the same rounded values) and evaluates SiLU /
+                                      sigmoid / the attention softmax on the hardware exp2 / rcp (1 ulp fp32). */
     char joint_prefix[32];         /* "tdt_joint_." (tdt_ctc.cpp:5-9) or "joint_." (tdt.cpp:28-32) */
     /* encoder-only uses (Sortformer's NEST encoder, src/sortformer.cpp:41-47): vocab_size = 0 loads no prediction net / joint */
     int32_t xscaling;              /* StreamingEncoderConfig::xscaling (streaming_encoder.cpp:402-406, :444-447): x *= sqrt(hidden) after subsampling */
