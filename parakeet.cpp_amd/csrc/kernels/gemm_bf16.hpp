@@ -16,6 +16,9 @@
 #include "kernels.hpp"
 #include "gemm_pipe.hpp"
 
+#ifndef BG_GROUPM
+#define BG_GROUPM 8                 // tile rows per group of the grouped tile order (1 = row-major)
+#endif
 #ifndef BG_EXP
 #define BG_EXP 0                    // micro-benchmark experiments only (tools/ubench, results wrong, timing only): main loop without
 #endif                              // 16 = LDS stores, 32 = global loads, 64 = fragment reads; 512 = staging stores as ds_write_b128 instead of ds_write2_b64 pairs, 1024 = as two separate ds_write_b64, 2048 = as four ds_write_b32
@@ -48,7 +51,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
         const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * NOUT;
+    // Grouped order: BG_GROUPM tile rows down before the next tile column, so that the ~64 tiles an XCD works on at one time form a squarer
+    // block of the output.  At bf16 rates this kernel lives on its L2 hit rate: in plain row-major order the tdt-600m fc1 product pulled
+    // 711 MB per launch through the L2 miss path (21x its operands, 4.8 TB/s: profiles/r02_pmc_hbm_600m_bf16.json) -- every pair of tile
+    // rows streamed the whole 8.4 MB weight matrix again.
+    int m0, n0;
+    {
+        const int tiles_m = n_tiles / tiles_n, per_group = BG_GROUPM * tiles_n;
+        const int grp = bid / per_group, first_m = grp * BG_GROUPM;
+        const int gsz = (tiles_m - first_m) < BG_GROUPM ? (tiles_m - first_m) : BG_GROUPM;
+        const int in = bid - grp * per_group;
+        m0 = (first_m + in % gsz) * BM;
+        n0 = (in / gsz) * NOUT;
+    }
 
     const float *a_src[A_CH];                                       // A16: bf16 rows (g.A reinterpreted, lda in elements)
     const __bf16 *w_src[W_CH];
