@@ -30,7 +30,8 @@ D_MODEL, FFN, ENC_FRAMES = 512, 2048, 126
 FC1_KERNEL = {False: "gemm_pipe_kernel<4,2,1,2,32,EPI_SILU,1> (ffn_fc1_silu: fp32 v_mfma_f32_32x32x2_f32, 128x128 tile, 8 waves of 32x64, 1 LDS staging buffer, 4-byte staging stores)",
               True: "gemm_bf16_kernel<4,2,1,2,EPI_SILU> (ffn_fc1_silu: v_mfma_f32_32x32x16_bf16, 128x128 tile, 8 waves of 32x64, ds_write2_b64 staging)"}
 # committed rocprofv3 --pmc summaries (HBM bytes per launch of the dominant kernel), newest first, per (config, bf16)
-PMC_FILES = {("tdt-ctc-110m", False): ("r02_pmc_hbm_v4.json", "r02_pmc_hbm_v3.json", "r02_pmc_hbm_v2.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json")}
+PMC_FILES = {("tdt-600m", True): ("r02_pmc_hbm_600m_bf16.json",),
+             ("tdt-ctc-110m", False): ("r02_pmc_hbm_v4.json", "r02_pmc_hbm_v3.json", "r02_pmc_hbm_v2.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json")}
 
 
 def log(*a):
@@ -277,7 +278,7 @@ def main():
                         break
             roof = {"bound": "mfma", "kernel": FC1_KERNEL[bool(args.bf16)], "achieved": round(ach, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": int(4 * (args.batch * ENC_FRAMES * (D_MODEL + FFN) + FFN * D_MODEL)),
+                    "algorithmic_bytes_per_launch": int((2 if args.bf16 else 4) * (args.batch * ENC_FRAMES * (D_MODEL + FFN) + FFN * D_MODEL)),   # bf16 mode: A, W and the fc1 output are bf16
                     "flop_per_launch": per_launch_flop, "us_per_launch": round(per_launch_s * 1e6, 2),
                     "encoder_gemms": {"tflops": round(g_fl / max(g_ms, 1e-9), 2), "gflop": round(g_fl, 1), "ms": round(g_ms, 3),
                                       "frac_of_peak": round(g_fl / max(g_ms, 1e-9) / peak, 4)}}
