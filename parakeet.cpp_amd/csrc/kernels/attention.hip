@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
                                                                const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                float scale, float *__restrict__ ctx, int PITS, int n_rb, int n_bh,
                                                                float *__restrict__ s_scratch, int ctx_bf16) {
+    __builtin_amdgcn_s_setprio(3);        // ahead of the overlapped decode-loop waves in the SIMD's arbitration (gemm_pipe.hpp)
     constexpr int KQ = HD / 4;
     constexpr int NQ4 = HD / 16;          // float4 fragments per lane for K = HD (one per block of 16 features)
     constexpr int VPIT = HD + 16;         // V rows, natural layout (pitch = 16 mod 32 banks)

@@ -12,6 +12,7 @@ template <int PER_LANE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int64_t rows, int d,
                                                         const float *__restrict__ g, const float *__restrict__ b,
                                                         float eps, float *__restrict__ y, int y_bf16) {
+    __builtin_amdgcn_s_setprio(3);                                  // (see gemm_pipe.hpp)
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float *__restrict
                                                          const float *__restrict__ b1, const float *__restrict__ g2,
                                                          const float *__restrict__ b2, float eps, float *__restrict__ y1,
                                                          float *__restrict__ y2, int y2_bf16) {
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
