@@ -157,8 +157,11 @@ pk_status pk_batch_results_done(pk_batch *b, int *n_clips, int32_t *ids, int32_t
  * share them.  Token ids, frames and confidences of every run are unchanged (the utterances are independent); what changes is WHEN they
  * are available: after the G-th run of the group (+1), or at pk_batch_sync / pk_batch_results.  1 <= G <= 8; flushes the pipeline. */
 pk_status pk_batch_set_decode_group(pk_batch *b, int group);
-/* Results of the (back+1)-th newest run whose decode has finished (back = 0: the newest, = pk_batch_results_done); the runs of the newest
- * decoded group are kept: 0 <= back < pk_batch_results_available(). */
+/* Results of the (back+1)-th newest run whose decode has finished (back = 0: the newest, = pk_batch_results_done), 0 <= back <
+ * pk_batch_results_available().  A finished run stays readable until its buffers are recycled: without groups until the run after next is
+ * issued, with groups of G until the first run of the group after next -- so the G runs of the newest decoded group are always there, and a
+ * pk_batch_sync that decodes a full group and the partial group behind it keeps the runs of both.  pk_batch_set_decode_group drops the
+ * runs held in group buffers: read them first. */
 pk_status pk_batch_results_back(pk_batch *b, int back, int *n_clips, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
 int pk_batch_results_available(const pk_batch *b);
 /* Stage timers of the last pk_batch_run_timed (ms): mel, encoder, decode, total (hipEvents on the batch stream). */
@@ -209,13 +212,15 @@ pk_status pk_transcribe_pcm(pk_model *m, const float *pcm, const int64_t *offset
                             pk_result **results);
 void pk_results_free(pk_result *results, int n_clips);
 /* ---- one node, several GPUs: utterance shards (the reference has no multi-device path, README.md:513) ----------
- * A pk_group is one model REPLICA per device of this process: the safetensors image is read once, sent to every device with one
- * RCCL broadcast (xGMI) and each replica is built from its copy.  pk_group_transcribe_pcm partitions the clips into batches of
- * equal-length clips (<= 64) and deals the batches round-robin to the devices (rank r takes batches r, r+G, ...: utterances share
- * nothing, so there is NO collective on the data path); one host thread drives each device.  Afterwards the fixed-stride token
- * matrix [clips_per_rank][2 + max_tokens] of every rank is all-gathered (ncclAllGather) and the wall times are max-reduced
- * (ncclAllReduce); the token ids of the results are taken from the gathered matrix.  With one device the communicator has one
- * rank and the same collectives run.  devices = NULL / n_devices <= 0: every visible device.
+ * A pk_group is one model REPLICA per device of this process: the safetensors file is mapped once and every replica is built from that
+ * one host image by its own host thread (each device uploads over its own PCIe link).  pk_group_transcribe_pcm partitions the clips into
+ * batches of equal-length clips (<= 64) and deals the batches round-robin to the devices (rank r takes batches r, r+G, ...); one host
+ * thread drives each device through the SAME two-stream pipeline pk_transcribe_pcm uses (PCM of batch k+1 staged and decode(k) driven
+ * under encoder(k+1); from four batches per rank on, decode groups of four).  Utterances share nothing, so there is NO collective: not on
+ * the data path and -- one process, one address space -- not for the results either; the ranks never wait for each other.  The library has
+ * no link-time dependency on RCCL.  (The multi-PROCESS deployment -- one process per GPU under torch.distributed, bench.py --gpus N,
+ * tools/transcribe_sharded.py -- ends with one RCCL all-gather of the token matrix; pk_group_verify_exchange below runs that exchange
+ * in-process as a check.)  devices = NULL / n_devices <= 0: every visible device.
  * Same result contract as pk_transcribe_pcm (which is what a group of one device computes, clip for clip). */
 typedef struct pk_group pk_group;
 pk_status pk_group_create(const char *safetensors_path, const char *vocab_path_or_null, const pk_config *cfg, const int *devices,
@@ -224,9 +229,15 @@ void pk_group_free(pk_group *g);
 int pk_group_size(const pk_group *g);
 pk_status pk_group_transcribe_pcm(pk_group *g, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt,
                                   pk_result **results);
-/* figures of the last pk_group_transcribe_pcm: max-over-ranks wall time of the compute phase (the all-reduced value), total audio
- * seconds, clips handled by each rank (clips_per_rank[pk_group_size]); any pointer may be NULL */
+/* figures of the last pk_group_transcribe_pcm: max-over-ranks wall time of the compute phase, total audio seconds, clips handled by
+ * each rank (clips_per_rank[pk_group_size]); any pointer may be NULL */
 pk_status pk_group_last_stats(const pk_group *g, double *wall_ms_max, double *audio_seconds, int32_t *clips_per_rank);
+/* Debug check of the result exchange a multi-process deployment performs, run in-process over RCCL (loaded with dlopen on first use;
+ * PK_ERR_UNSUPPORTED with the loader's message when librccl is not installed): the token ids of `results` (those of the LAST
+ * pk_group_transcribe_pcm) go rank by rank through device memory, one ncclAllReduce(max) of (token maximum, wall time) and one fixed-stride
+ * ncclAllGather of the [clips_per_rank][2 + max_tokens] int32 matrix; every rank's gathered copy must reproduce `results`.
+ * *rccl_ranks (optional) = ncclCommCount of the communicator. */
+pk_status pk_group_verify_exchange(pk_group *g, const pk_result *results, int n_clips, int *rccl_ranks);
 
 /* read_audio (audio_io.cpp:453-483) restricted to RIFF/WAVE PCM16 / float32; mono-downmix; must be 16 kHz.
  * Returns a malloc'd buffer the caller frees with pk_free. */

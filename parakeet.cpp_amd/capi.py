@@ -147,6 +147,7 @@ _LATE_SIGNATURES = {
     "pk_group_size": [C.c_void_p],
     "pk_group_transcribe_pcm": [C.c_void_p, f32p, i64p, C.c_int, C.POINTER(PkOptions), C.POINTER(C.POINTER(PkResult))],
     "pk_group_last_stats": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), i32p],
+    "pk_group_verify_exchange": [C.c_void_p, C.POINTER(PkResult), C.c_int, C.POINTER(C.c_int)],
 }
 
 
@@ -510,7 +511,7 @@ class Batch:
 
 
 # ---- model -------------------------------------------------------------------------------------------
-def _transcribe(fn, handle, clips, decoder, timestamps, boost_phrases, boost_score):
+def _transcribe(fn, handle, clips, decoder, timestamps, boost_phrases, boost_score, with_raw=None):
     clips = [_c(c).ravel() for c in clips]
     off = np.zeros(len(clips) + 1, np.int64)
     off[1:] = np.cumsum([len(c) for c in clips])
@@ -534,13 +535,15 @@ def _transcribe(fn, handle, clips, decoder, timestamps, boost_phrases, boost_sco
             d["conf"] = [r.confidence[k] for k in range(r.n_tokens)]
             d["words"] = [(r.words[k].word.decode(), r.words[k].start, r.words[k].end, r.words[k].confidence) for k in range(r.n_words)]
         out.append(d)
+    if with_raw is not None:
+        with_raw(res, len(clips))                            # e.g. pk_group_verify_exchange on the pk_result array itself
     lib().pk_results_free(res, len(clips))
     return out
 
 
 class Group:
-    """pk_group: one model replica per GPU of this process, utterance batches dealt round-robin, weights broadcast and results gathered
-    over RCCL (include/parakeet_amd.h, "one node, several GPUs")."""
+    """pk_group: one model replica per GPU of this process, utterance batches dealt round-robin, one host thread and one two-stream
+    pipeline per device, no collective (include/parakeet_amd.h, "one node, several GPUs")."""
 
     def __init__(self, weights_path, cfg: ModelConfig, vocab_path: str = None, devices=None):
         self.cfg = cfg
@@ -553,8 +556,16 @@ class Group:
     def size(self):
         return lib().pk_group_size(self._h)
 
-    def transcribe_pcm(self, clips, decoder="tdt", timestamps=False, boost_phrases=(), boost_score=5.0):
-        return _transcribe(lib().pk_group_transcribe_pcm, self._h, clips, decoder, timestamps, boost_phrases, boost_score)
+    def transcribe_pcm(self, clips, decoder="tdt", timestamps=False, boost_phrases=(), boost_score=5.0, verify_exchange=False):
+        """verify_exchange: also run pk_group_verify_exchange (the RCCL all-reduce + all-gather of the token matrix) on the results;
+        self.rccl_ranks then holds the communicator's rank count."""
+        raw = None
+        if verify_exchange:
+            def raw(res, n):
+                ranks = C.c_int(0)
+                check(lib().pk_group_verify_exchange(self._h, res, n, C.byref(ranks)))
+                self.rccl_ranks = ranks.value
+        return _transcribe(lib().pk_group_transcribe_pcm, self._h, clips, decoder, timestamps, boost_phrases, boost_score, with_raw=raw)
 
     def last_stats(self):
         wall, audio = C.c_double(0), C.c_double(0)

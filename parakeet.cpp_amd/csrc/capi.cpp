@@ -7,9 +7,8 @@
 #include <functional>
 #include <thread>
 
-#include <rccl/rccl.h>
-
 #include "engine.hpp"
+#include "rccl_dyn.hpp"
 
 namespace pk {
 const std::string &last_error();
@@ -316,7 +315,7 @@ struct pk_batch {
     // grp[fill].ep on the ENCODER stream right after encoder(k) (the encoder workspaces are then free again); a full group is decoded
     // under the encoder of the run after it.  Results of run k are available once its group is decoded (pk_batch_results_back).
     int group = 1;
-    struct Member { int clips, row0; };
+    struct Member { int clips, row0; int64_t seq; };
     struct Group {
         Workspace w;                    // decode state of group * max_clips utterances
         std::vector<Member> mem;        // runs in this group, oldest first
@@ -324,17 +323,25 @@ struct pk_batch {
         hipEvent_t ep_done = nullptr, dec_done = nullptr;
         bool decoded = false, used = false;
     } grp[2];
-    struct Loc { Workspace *w; int row0, clips, decoder; hipEvent_t ev; };
-    std::vector<Loc> done;              // finished (decode driven) runs, newest last; the last max(group, 1) stay readable
+    struct Loc { Workspace *w; int row0, clips, decoder; hipEvent_t ev; int64_t seq; };
+    // Finished (decode driven) runs, oldest first.  An entry stays readable until the buffers it points into are recycled: a pipeline
+    // slot when run k+2 is encoded into it, a group buffer when the group after next starts to fill it.  Nothing else removes entries, so a
+    // flush that drives a full group AND the partial group behind it keeps the runs of both (round-2 advisor finding).
+    std::vector<Loc> done;
+    int64_t slot_seq[2] = {-1, -1};     // run index that owns each pipeline slot
+    void forget(const Workspace *w) {   // the buffers of `w` are about to be overwritten
+        done.erase(std::remove_if(done.begin(), done.end(), [w](const Loc &l) { return l.w == w; }), done.end());
+    }
     int fill = 0;                       // group collecting runs
     int ready = -1;                     // full group whose decode has not been driven yet
-    int last_grp = -1;                  // group holding the newest finished results (-1: they live in ws[last_slot])
 };
 
 static void batch_encode(pk_batch *b, int slot) {
     Model &m = *b->m;
     Workspace &w = b->ws[slot];
     hipStream_t s = m.stream;
+    b->forget(&w);                                           // the results of run k-2 live in this slot: no longer readable
+    b->slot_seq[slot] = b->runs;
     if (b->used[slot]) PK_HIP(hipStreamWaitEvent(s, b->dec_done[slot], 0));   // decode(k-2) must be done with this slot
     if (b->staged >= 0) {                                    // a batch uploaded under the previous run: switch buffers
         b->cur = b->staged;
@@ -362,8 +369,8 @@ static void batch_decode(pk_batch *b, int slot, int decoder, hipStream_t s) {
     b->last_slot = slot;
     b->last_decoder = decoder;
     b->last_clips = nc;
-    b->done.clear();                                          // single-run decode: only the newest run is kept
-    b->done.push_back({&w, 0, nc, decoder, b->dec_done[slot]});
+    b->forget(&w);                                            // (the timed / profiled single-slot paths decode into a slot they did not encode)
+    b->done.push_back({&w, 0, nc, decoder, b->dec_done[slot], b->slot_seq[slot]});
 }
 
 // host-driven TDT loop of a whole decode group on the decode stream
@@ -375,8 +382,7 @@ static void group_drive(pk_batch *b, int gi) {
     m.run_tdt_loop(G.w, G.rows, G.w.T, G.w.max_tokens, s);
     PK_HIP(hipEventRecord(G.dec_done, s));
     G.decoded = true;
-    b->done.clear();
-    for (auto &mm : G.mem) b->done.push_back({&G.w, mm.row0, mm.clips, PK_DECODER_TDT, G.dec_done});
+    for (auto &mm : G.mem) b->done.push_back({&G.w, mm.row0, mm.clips, PK_DECODER_TDT, G.dec_done, mm.seq});
     b->last_slot = 0;                                         // (a result exists)
     b->last_decoder = PK_DECODER_TDT;
     b->last_clips = G.mem.back().clips;
@@ -427,12 +433,13 @@ static void batch_run(pk_batch *b, int decoder) {
         Workspace &w = b->ws[slot];
         if (G.mem.empty()) {                                 // first run of a group: the buffer's previous decode must be done with it
             if (G.used) PK_HIP(hipStreamWaitEvent(m.stream, G.dec_done, 0));
+            b->forget(&G.w);                                 // the runs of the group decoded two groups ago are overwritten from here on
             G.rows = 0;
             G.decoded = false;
         }
         const int nc = b->slot_clips[slot];
         m.run_enc_proj(w.x.as<float>(), (int64_t)nc * w.T, G.w.ep.as<float>() + (size_t)G.rows * w.T * m.cfg.joint_hidden, m.stream);
-        G.mem.push_back({nc, G.rows});
+        G.mem.push_back({nc, G.rows, b->slot_seq[slot]});
         G.rows += nc;
         G.used = true;
         const bool full = (int)G.mem.size() == b->group;
@@ -450,25 +457,34 @@ static void batch_run(pk_batch *b, int decoder) {
     PK_CHECK_LAUNCH();
 }
 
+// (re)sizes the two pipeline slots for batches of up to max_clips clips of n_samples samples; buffers only ever grow
+static void batch_size(pk_batch *b, int max_clips, int64_t n_samples) {
+    Model &m = *b->m;
+    for (auto &p : b->pcm2) p.reserve((size_t)max_clips * n_samples * 4);
+    for (auto &w : b->ws) w.size_for(m.cfg, max_clips, -n_samples, pk_mel_num_frames(n_samples));
+}
+
+static std::unique_ptr<pk_batch> batch_new(Model &m, int max_clips, int64_t n_samples) {
+    m.require_gpu();
+    auto b = std::make_unique<pk_batch>();
+    b->m = &m;
+    batch_size(b.get(), max_clips, n_samples);
+    for (auto &e : b->ev) PK_HIP(hipEventCreate(&e));
+    PK_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        PK_HIP(hipEventCreateWithFlags(&b->enc_done[i], hipEventDisableTiming));
+        PK_HIP(hipEventCreateWithFlags(&b->dec_done[i], hipEventDisableTiming));
+        PK_HIP(hipEventCreateWithFlags(&b->copy_done[i], hipEventDisableTiming));
+        PK_HIP(hipEventCreateWithFlags(&b->mel_done[i], hipEventDisableTiming));
+    }
+    b->ev_ok = true;
+    return b;
+}
+
 pk_status pk_batch_create(pk_model *h, int max_clips, int64_t n_samples, pk_batch **out) {
     return guard([&] {
         need(h && out && max_clips > 0 && n_samples > 256, "model/out/max_clips/n_samples");
-        Model &m = *h->m;
-        m.require_gpu();
-        auto b = std::make_unique<pk_batch>();
-        b->m = &m;
-        for (auto &p : b->pcm2) p.reserve((size_t)max_clips * n_samples * 4);
-        for (auto &w : b->ws) w.size_for(m.cfg, max_clips, -n_samples, pk_mel_num_frames(n_samples));
-        for (auto &e : b->ev) PK_HIP(hipEventCreate(&e));
-        PK_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            PK_HIP(hipEventCreateWithFlags(&b->enc_done[i], hipEventDisableTiming));
-            PK_HIP(hipEventCreateWithFlags(&b->dec_done[i], hipEventDisableTiming));
-            PK_HIP(hipEventCreateWithFlags(&b->copy_done[i], hipEventDisableTiming));
-            PK_HIP(hipEventCreateWithFlags(&b->mel_done[i], hipEventDisableTiming));
-        }
-        b->ev_ok = true;
-        *out = b.release();
+        *out = batch_new(*h->m, max_clips, n_samples).release();
     });
 }
 
@@ -505,17 +521,30 @@ pk_status pk_batch_upload(pk_batch *b, const float *pcm, int n_clips) {
     });
 }
 
+// stages the NEXT batch into the PCM buffer the running encoder does not read, on the copy stream.  clip(i) = host pointer of clip i;
+// clips that follow each other in host memory go as one copy.
+static void batch_stage(pk_batch *b, int n_clips, const std::function<const float *(int)> &clip) {
+    b->m->require_gpu();
+    const int64_t n = b->ws[0].n_samples;
+    const int nb = b->staged >= 0 ? b->staged : (b->cur ^ 1);      // re-staging before a run overwrites the staged batch
+    PK_HIP(hipStreamSynchronize(b->copy_stream));                  // at most one copy in flight; the previous host buffer is released here
+    if (b->mel_used[nb]) PK_HIP(hipStreamWaitEvent(b->copy_stream, b->mel_done[nb], 0));   // the last mel that read this buffer
+    for (int i = 0; i < n_clips;) {
+        int j = i + 1;
+        while (j < n_clips && clip(j) == clip(j - 1) + n) ++j;
+        PK_HIP(hipMemcpyAsync(b->pcm2[nb].as<float>() + (size_t)i * n, clip(i), (size_t)(j - i) * n * 4, hipMemcpyHostToDevice, b->copy_stream));
+        i = j;
+    }
+    PK_HIP(hipEventRecord(b->copy_done[nb], b->copy_stream));
+    b->staged = nb;
+    b->staged_clips = n_clips;
+}
+
 pk_status pk_batch_upload_async(pk_batch *b, const float *pcm, int n_clips) {
     return guard([&] {
         need(b && pcm && n_clips > 0 && n_clips <= b->ws[0].B, "batch/pcm/n_clips");
-        b->m->require_gpu();
-        const int nb = b->staged >= 0 ? b->staged : (b->cur ^ 1);      // re-staging before a run overwrites the staged batch
-        PK_HIP(hipStreamSynchronize(b->copy_stream));                  // at most one copy in flight; the previous host buffer is released here
-        if (b->mel_used[nb]) PK_HIP(hipStreamWaitEvent(b->copy_stream, b->mel_done[nb], 0));   // the last mel that read this buffer
-        PK_HIP(hipMemcpyAsync(b->pcm2[nb].p, pcm, (size_t)n_clips * b->ws[0].n_samples * 4, hipMemcpyHostToDevice, b->copy_stream));
-        PK_HIP(hipEventRecord(b->copy_done[nb], b->copy_stream));
-        b->staged = nb;
-        b->staged_clips = n_clips;
+        const int64_t n = b->ws[0].n_samples;
+        batch_stage(b, n_clips, [&](int i) { return pcm + (size_t)i * n; });
     });
 }
 
@@ -571,28 +600,30 @@ pk_status pk_batch_results_done(pk_batch *b, int *n_clips, int32_t *ids, int32_t
 
 int pk_batch_results_available(const pk_batch *b) { return b ? (int)b->done.size() : 0; }
 
-pk_status pk_batch_set_decode_group(pk_batch *b, int group) {
-    return guard([&] {
-        need(b, "batch");
-        need(group >= 1 && group <= 8, "decode group: 1 .. 8 runs");
-        Model &m = *b->m;
-        m.require_gpu();
-        batch_flush(b);
-        if (group > 1) {
-            need(m.cfg.vocab_size > 0, "decode groups apply to the TDT / RNNT decoder; this model has none");
-            for (auto &G : b->grp) {
-                G.w.size_decode(m.cfg, group * b->ws[0].B, b->ws[0].T);
-                if (!G.ep_done) PK_HIP(hipEventCreateWithFlags(&G.ep_done, hipEventDisableTiming));
-                if (!G.dec_done) PK_HIP(hipEventCreateWithFlags(&G.dec_done, hipEventDisableTiming));
-                G.mem.clear();
-                G.rows = 0;
-                G.used = G.decoded = false;
-            }
+static void batch_set_group(pk_batch *b, int group) {
+    need(group >= 1 && group <= 8, "decode group: 1 .. 8 runs");
+    Model &m = *b->m;
+    m.require_gpu();
+    batch_flush(b);
+    for (auto &G : b->grp) b->forget(&G.w);              // their buffers may be reallocated below: read results BEFORE changing the group size
+    if (group > 1) {
+        need(m.cfg.vocab_size > 0, "decode groups apply to the TDT / RNNT decoder; this model has none");
+        for (auto &G : b->grp) {
+            G.w.size_decode(m.cfg, group * b->ws[0].B, b->ws[0].T);
+            if (!G.ep_done) PK_HIP(hipEventCreateWithFlags(&G.ep_done, hipEventDisableTiming));
+            if (!G.dec_done) PK_HIP(hipEventCreateWithFlags(&G.dec_done, hipEventDisableTiming));
+            G.mem.clear();
+            G.rows = 0;
+            G.used = G.decoded = false;
         }
-        b->fill = 0;
-        b->ready = -1;
-        b->group = group;
-    });
+    }
+    b->fill = 0;
+    b->ready = -1;
+    b->group = group;
+}
+
+pk_status pk_batch_set_decode_group(pk_batch *b, int group) {
+    return guard([&] { need(b, "batch"); batch_set_group(b, group); });
 }
 
 // One un-pipelined run on the main stream with hipEvents between the stages (mel / encoder / decode / total, ms).
@@ -675,6 +706,39 @@ int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap) {
     return st == PK_OK ? n_out : (int)st;
 }
 
+// Brings a pipeline back to a defined idle state after an error inside a run (nothing pending, nothing readable).
+static void batch_reset(pk_batch *b) {
+    (void)hipStreamSynchronize(b->m->stream_dec);
+    (void)hipStreamSynchronize(b->m->stream);
+    (void)hipStreamSynchronize(b->copy_stream);
+    (void)hipGetLastError();
+    b->pending_slot = b->pending_decoder = -1;
+    b->ready = -1;
+    b->staged = -1;
+    b->n_clips = 0;
+    for (auto &G : b->grp) { G.mem.clear(); G.rows = 0; }
+    b->done.clear();
+}
+
+// The pipeline a Model keeps for the one-call API (pk_transcribe_pcm, every rank of a pk_group): created on first use, re-sized per
+// length class (buffers only grow), freed with the model.
+static pk_batch *model_pipeline(Model &m, int max_clips, int64_t n_samples) {
+    m.require_gpu();
+    if (!m.pipe) {
+        m.pipe = batch_new(m, max_clips, n_samples).release();
+        m.pipe_free = [](void *p) { pk_batch_free(static_cast<pk_batch *>(p)); };
+        return static_cast<pk_batch *>(m.pipe);
+    }
+    pk_batch *b = static_cast<pk_batch *>(m.pipe);
+    batch_flush(b);
+    PK_HIP(hipStreamSynchronize(b->copy_stream));
+    b->done.clear();
+    b->staged = -1;
+    b->n_clips = 0;
+    batch_size(b, max_clips, n_samples);
+    return b;
+}
+
 /* ---- one-call API ------------------------------------------------------------------------------------------ */
 
 namespace {
@@ -707,55 +771,78 @@ static void transcribe_clips(Model &m, const float *pcm, const int64_t *offsets,
         scope.saved = m.boost_phrases; scope.saved_score = m.boost_score; scope.active = true;
         m.set_boost(ph, opt->boost_score);
     }
-    // group clips of equal length into batches (the reference has no padding semantics: no masks offline, encoder.cpp:163)
+    // Clips of equal length form batches of <= 64 (the reference has no padding semantics: no masks offline, encoder.cpp:163).  The batches of
+    // a length class go through the model's two-stream pipeline (struct pk_batch): PCM of batch k+1 is staged on the copy stream and
+    // decode(k) -- or, from four batches on, the decode loops of four batches as one lock-step group -- runs under encoder(k+1).
     std::vector<int> order(clips);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offsets[a + 1] - offsets[a] < offsets[b + 1] - offsets[b]; });
     const int n_clips = (int)order.size();
     const int kMaxBatch = 64;
+    for (int i = 0; i < n_clips; ++i) need(offsets[order[i] + 1] - offsets[order[i]] > 256, "every clip needs more than 256 samples");
+    std::vector<int32_t> ids, st, en, lens;
+    std::vector<float> cf;
     for (int g0 = 0; g0 < n_clips;) {
         const int64_t len = offsets[order[g0] + 1] - offsets[order[g0]];
-        need(len > 256, "every clip needs more than 256 samples");
         int g1 = g0;
-        while (g1 < n_clips && g1 - g0 < kMaxBatch && offsets[order[g1] + 1] - offsets[order[g1]] == len) ++g1;
-        const int B = g1 - g0;
-        Workspace &w = m.ws;
-        w.size_for(m.cfg, B, len, pk_mel_num_frames(len));
-        for (int i = 0; i < B; ++i)
-            PK_HIP(hipMemcpyAsync(w.pcm.as<float>() + (size_t)i * len, pcm + offsets[order[g0 + i]], (size_t)len * 4, hipMemcpyHostToDevice, m.stream));
-        m.run_mel(w.pcm.as<float>(), B, len, w.logmel.as<float>(), w.feats.as<float>(), m.stream);
-        m.run_encoder(w, w.feats.as<float>(), B, w.Tm, -1, 0, m.stream);
-        const int pitch = decoder == PK_DECODER_CTC ? w.T : w.max_tokens;
-        if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), B, w.T, false, m.stream);
-        else m.run_tdt(w, w.x.as<float>(), B, w.T, w.max_tokens, m.stream);
-        PK_CHECK_LAUNCH();
-        std::vector<int32_t> ids((size_t)B * pitch), st((size_t)B * pitch), en((size_t)B * pitch), lens(B);
-        std::vector<float> cf((size_t)B * pitch);
-        PK_HIP(hipStreamSynchronize(m.stream));
-        PK_HIP(hipMemcpy(lens.data(), w.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost));
-        PK_HIP(hipMemcpy(ids.data(), w.ids.p, ids.size() * 4, hipMemcpyDeviceToHost));
-        PK_HIP(hipMemcpy(st.data(), w.start.p, st.size() * 4, hipMemcpyDeviceToHost));
-        PK_HIP(hipMemcpy(en.data(), w.end.p, en.size() * 4, hipMemcpyDeviceToHost));
-        PK_HIP(hipMemcpy(cf.data(), w.conf.p, cf.size() * 4, hipMemcpyDeviceToHost));
-        for (int i = 0; i < B; ++i) {
-            const int c = order[g0 + i];
-            if (lens[i] < 0) fail(PK_ERR_DECODE_CAP, "TDT decode hit the safety cap on clip %d", c);
-            const int n = lens[i];
-            R.ids[c].assign(ids.begin() + (size_t)i * pitch, ids.begin() + (size_t)i * pitch + n);
-            std::vector<int> iv(R.ids[c].begin(), R.ids[c].end());
-            if (m.tok.loaded()) R.text[c] = m.tok.decode(iv);                    // transcribe.hpp:149,172
-            if (ts) {
-                R.start[c].assign(st.begin() + (size_t)i * pitch, st.begin() + (size_t)i * pitch + n);
-                R.end[c].assign(en.begin() + (size_t)i * pitch, en.begin() + (size_t)i * pitch + n);
-                R.conf[c].assign(cf.begin() + (size_t)i * pitch, cf.begin() + (size_t)i * pitch + n);
-                if (m.tok.loaded()) {                                            // group_timestamps, transcribe.hpp:150-152
-                    std::vector<TimestampedToken> tt(n);
-                    for (int k = 0; k < n; ++k) tt[k] = {R.ids[c][k], R.start[c][k], R.end[c][k], R.conf[c][k]};
-                    auto words = group_timestamps(tt, m.tok.pieces(), false);
-                    for (auto &wd : words) R.word_text[c].push_back(wd.word);
-                    for (size_t k = 0; k < words.size(); ++k)
-                        R.words[c].push_back({R.word_text[c][k].c_str(), words[k].start, words[k].end, words[k].confidence});
+        while (g1 < n_clips && offsets[order[g1] + 1] - offsets[order[g1]] == len) ++g1;
+        const int count = g1 - g0, nb = (count + kMaxBatch - 1) / kMaxBatch;
+        pk_batch *b = model_pipeline(m, std::min(count, kMaxBatch), len);
+        try {
+            batch_set_group(b, (decoder == PK_DECODER_TDT && nb >= 4) ? 4 : 1);
+            const int64_t first_seq = b->runs;
+            const int mt = b->ws[0].max_tokens;
+            std::vector<char> taken(nb, 0);
+            auto clips_of = [&](int k) { return std::min(kMaxBatch, count - k * kMaxBatch); };
+            auto stage = [&](int k) {
+                batch_stage(b, clips_of(k), [&](int i) { return pcm + offsets[order[g0 + k * kMaxBatch + i]]; });
+            };
+            auto drain = [&]() {                                  // every finished run of this class that has not been handed out yet
+                for (const auto &L : b->done) {
+                    const int64_t k = L.seq - first_seq;
+                    if (k < 0 || k >= nb || taken[k]) continue;
+                    taken[k] = 1;
+                    const int B = L.clips;
+                    const size_t tok = (size_t)B * mt;
+                    ids.resize(tok); lens.resize(B);
+                    if (ts) { st.resize(tok); en.resize(tok); cf.resize(tok); }
+                    PK_HIP(hipEventSynchronize(L.ev));
+                    copy_results(L, ids.data(), lens.data(), ts ? st.data() : nullptr, ts ? en.data() : nullptr, ts ? cf.data() : nullptr);
+                    for (int i = 0; i < B; ++i) {
+                        const int c = order[g0 + (int)k * kMaxBatch + i];
+                        if (lens[i] < 0) fail(PK_ERR_DECODE_CAP, "TDT decode hit the safety cap on clip %d", c);
+                        const int n = lens[i];
+                        R.ids[c].assign(ids.begin() + (size_t)i * mt, ids.begin() + (size_t)i * mt + n);
+                        std::vector<int> iv(R.ids[c].begin(), R.ids[c].end());
+                        if (m.tok.loaded()) R.text[c] = m.tok.decode(iv);                    // transcribe.hpp:149,172
+                        if (ts) {
+                            R.start[c].assign(st.begin() + (size_t)i * mt, st.begin() + (size_t)i * mt + n);
+                            R.end[c].assign(en.begin() + (size_t)i * mt, en.begin() + (size_t)i * mt + n);
+                            R.conf[c].assign(cf.begin() + (size_t)i * mt, cf.begin() + (size_t)i * mt + n);
+                            if (m.tok.loaded()) {                                            // group_timestamps, transcribe.hpp:150-152
+                                std::vector<TimestampedToken> tt(n);
+                                for (int q = 0; q < n; ++q) tt[q] = {R.ids[c][q], R.start[c][q], R.end[c][q], R.conf[c][q]};
+                                auto words = group_timestamps(tt, m.tok.pieces(), false);
+                                for (auto &wd : words) R.word_text[c].push_back(wd.word);
+                                for (size_t q = 0; q < words.size(); ++q)
+                                    R.words[c].push_back({R.word_text[c][q].c_str(), words[q].start, words[q].end, words[q].confidence});
+                            }
+                        }
+                    }
                 }
+            };
+            stage(0);
+            for (int k = 0; k < nb; ++k) {
+                batch_run(b, decoder);                               // encoder(k) queued, then decode(k-1) / the finished group driven under it
+                if (k + 1 < nb) stage(k + 1);
+                drain();
             }
+            batch_flush(b);
+            drain();
+            for (int k = 0; k < nb; ++k)
+                if (!taken[k]) fail(PK_ERR_HIP, "internal: batch %d of the pipeline produced no result", k);
+        } catch (...) {
+            batch_reset(b);
+            throw;
         }
         g0 = g1;
     }
@@ -806,23 +893,28 @@ pk_status pk_transcribe_pcm(pk_model *h, const float *pcm, const int64_t *offset
 struct pk_group {
     std::vector<int> devices;
     std::vector<std::unique_ptr<Model>> models;
-    std::vector<ncclComm_t> comms;
-    std::vector<hipStream_t> streams;          // one stream per device for the collectives
     double wall_ms_max = 0.0, audio_s = 0.0;
     std::vector<int32_t> clips_per_rank;
+    std::vector<double> wall_ms;
+    std::vector<std::vector<int>> last_shard;  // clip indices each rank handled in the last call (pk_group_verify_exchange)
+    // RCCL is only touched by pk_group_verify_exchange: communicators and streams are created on its first call
+    const RcclApi *rccl = nullptr;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;
     ~pk_group() {
-        for (size_t r = 0; r < devices.size(); ++r) {
+        for (size_t r = 0; r < streams.size(); ++r) {
             (void)hipSetDevice(devices[r]);
-            if (r < streams.size() && streams[r]) (void)hipStreamDestroy(streams[r]);
+            if (streams[r]) (void)hipStreamDestroy(streams[r]);
         }
         models.clear();
-        for (auto c : comms) if (c) (void)ncclCommDestroy(c);
+        if (rccl) for (auto c : comms) if (c) (void)rccl->CommDestroy(c);
     }
 };
-#define PK_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) fail(PK_ERR_HIP, "RCCL: %s (%s)", ncclGetErrorString(r_), #call); } while (0)
+#define PK_NCCL(api, call) do { ncclResult_t r_ = (api)->call; if (r_ != ncclSuccess) fail(PK_ERR_HIP, "RCCL: %s (%s)", (api)->GetErrorString(r_), #call); } while (0)
 
 // runs fn(rank) on one host thread per device; the first exception of any rank is rethrown on the calling thread
 static void for_each_rank(int n, const std::function<void(int)> &fn) {
+    if (n == 1) { fn(0); return; }
     std::vector<std::exception_ptr> err(n);
     std::vector<std::thread> th;
     for (int r = 0; r < n; ++r)
@@ -848,52 +940,20 @@ pk_status pk_group_create(const char *weights, const char *vocab, const pk_confi
             }
         }
         const int G = (int)g->devices.size();
-        // 1. ONE disk read: the safetensors image
-        std::vector<uint8_t> image;
-        {
-            FILE *f = fopen(weights, "rb");
-            if (!f) fail(PK_ERR_IO, "Cannot open weights file: %s", weights);
-            fseek(f, 0, SEEK_END);
-            const long len = ftell(f);
-            fseek(f, 0, SEEK_SET);
-            if (len < 8) { fclose(f); fail(PK_ERR_WEIGHTS, "weights file %s is too short", weights); }
-            image.resize((size_t)len);
-            const size_t got = fread(image.data(), 1, image.size(), f);
-            fclose(f);
-            if (got != image.size()) fail(PK_ERR_IO, "short read on %s", weights);
-        }
-        // 2. communicators (single process, one rank per device) and the broadcast of the image over xGMI
-        g->comms.assign(G, nullptr);
-        PK_NCCL(ncclCommInitAll(g->comms.data(), G, g->devices.data()));
-        g->streams.assign(G, nullptr);
-        std::vector<void *> dimg(G, nullptr);
-        struct Guard { std::vector<void *> &p; std::vector<int> &dev; ~Guard() { for (size_t r = 0; r < p.size(); ++r) if (p[r]) { (void)hipSetDevice(dev[r]); (void)hipFree(p[r]); } } } free_imgs{dimg, g->devices};
-        for (int r = 0; r < G; ++r) {
-            PK_HIP(hipSetDevice(g->devices[r]));
-            PK_HIP(hipStreamCreateWithFlags(&g->streams[r], hipStreamNonBlocking));
-            PK_HIP(hipMalloc(&dimg[r], image.size()));
-        }
-        PK_HIP(hipSetDevice(g->devices[0]));
-        PK_HIP(hipMemcpyAsync(dimg[0], image.data(), image.size(), hipMemcpyHostToDevice, g->streams[0]));
-        PK_NCCL(ncclGroupStart());
-        for (int r = 0; r < G; ++r) {
-            PK_HIP(hipSetDevice(g->devices[r]));
-            PK_NCCL(ncclBroadcast(dimg[r], dimg[r], image.size(), ncclUint8, 0, g->comms[r], g->streams[r]));
-        }
-        PK_NCCL(ncclGroupEnd());
-        // 3. every rank builds its replica from ITS copy of the image (checked against the original) and uploads the weights
+        // ONE disk read (mmap) shared by every rank: each replica is built from the same host image by its own host thread -- the per-tensor
+        // layout transforms and uploads of the G devices run concurrently, each device over its own PCIe link; no copy of the image is made.
+        SafeTensors image(weights);
+        const void *base = image.image_base();
+        const size_t len = image.image_bytes();
         g->models.resize(G);
         const std::string vp = vocab ? vocab : "";
         for_each_rank(G, [&](int r) {
-            PK_HIP(hipSetDevice(g->devices[r]));
-            PK_HIP(hipStreamSynchronize(g->streams[r]));
-            std::vector<uint8_t> mine(image.size());
-            PK_HIP(hipMemcpy(mine.data(), dimg[r], mine.size(), hipMemcpyDeviceToHost));
-            if (memcmp(mine.data(), image.data(), mine.size()) != 0) fail(PK_ERR_WEIGHTS, "rank %d received a different weight image from the broadcast", r);
-            g->models[r] = std::make_unique<Model>(mine.data(), mine.size(), vp, *cfg);
+            g->models[r] = std::make_unique<Model>(base, len, vp, *cfg, /*borrow=*/true);
             g->models[r]->to_gpu(g->devices[r]);
         });
         g->clips_per_rank.assign(G, 0);
+        g->wall_ms.assign(G, 0.0);
+        g->last_shard.assign(G, {});
         *out = g.release();
     });
 }
@@ -923,21 +983,66 @@ pk_status pk_group_transcribe_pcm(pk_group *g, const float *pcm, const int64_t *
         auto store = new_store(n_clips);
         ResultStore &R = *store;
         std::vector<double> wall_ms(G, 0.0);
-        for_each_rank(G, [&](int r) {                    // compute phase: no collective, ranks never wait for each other
+        // No collective anywhere: utterances share nothing, every rank writes the result slots of its own clips, and the ranks never wait
+        // for each other.  Each rank runs its batches through its replica's two-stream pipeline (transcribe_clips).
+        for_each_rank(G, [&](int r) {
             if (shard[r].empty()) return;
             const auto t0 = std::chrono::steady_clock::now();
             transcribe_clips(*g->models[r], pcm, offsets, shard[r], opt, R);
             wall_ms[r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         });
-        // result exchange over RCCL: max token count + max wall time (all-reduce), then the fixed-stride token matrix (all-gather)
+        g->wall_ms = wall_ms;
+        g->wall_ms_max = *std::max_element(wall_ms.begin(), wall_ms.end());
+        g->audio_s = audio;
+        for (int r = 0; r < G; ++r) g->clips_per_rank[r] = (int32_t)shard[r].size();
+        g->last_shard = shard;
+        *results = publish_store(std::move(store), n_clips, opt && opt->timestamps);
+    });
+}
+
+pk_status pk_group_last_stats(const pk_group *g, double *wall_ms_max, double *audio_seconds, int32_t *clips_per_rank) {
+    return guard([&] {
+        need(g, "group");
+        if (wall_ms_max) *wall_ms_max = g->wall_ms_max;
+        if (audio_seconds) *audio_seconds = g->audio_s;
+        if (clips_per_rank) std::copy(g->clips_per_rank.begin(), g->clips_per_rank.end(), clips_per_rank);
+    });
+}
+
+// Debug check, never part of a transcription: the token ids of the last pk_group_transcribe_pcm go rank by rank through device memory and
+// ONE fixed-stride ncclAllGather ([clips_per_rank][2 + max_tokens] int32 -- the exchange a multi-PROCESS deployment ends with,
+// parakeet.cpp_amd/shard.py) plus an ncclAllReduce(max) of the per-rank token maxima and wall times; every rank's copy of the gathered
+// matrix must reproduce `results`.  RCCL is loaded here, on first use (rccl_dyn.hpp); without it: PK_ERR_UNSUPPORTED.
+pk_status pk_group_verify_exchange(pk_group *g, const pk_result *results, int n_clips, int *rccl_ranks) {
+    return guard([&] {
+        need(g && results && n_clips > 0, "group/results/n_clips");
+        const int G = (int)g->devices.size();
+        size_t total = 0;
+        for (auto &sh : g->last_shard) total += sh.size();
+        need((int)total == n_clips, "results are not those of the last pk_group_transcribe_pcm");
+        if (!g->rccl) {
+            std::string why;
+            g->rccl = rccl_api(&why);
+            if (!g->rccl) fail(PK_ERR_UNSUPPORTED, "RCCL is not available on this host (%s)", why.c_str());
+            g->comms.assign(G, nullptr);
+            PK_NCCL(g->rccl, CommInitAll(g->comms.data(), G, g->devices.data()));
+            g->streams.assign(G, nullptr);
+            for (int r = 0; r < G; ++r) {
+                PK_HIP(hipSetDevice(g->devices[r]));
+                PK_HIP(hipStreamCreateWithFlags(&g->streams[r], hipStreamNonBlocking));
+            }
+        }
+        const RcclApi *N = g->rccl;
+        if (rccl_ranks) PK_NCCL(N, CommCount(g->comms[0], rccl_ranks));
+        const auto &shard = g->last_shard;
+        size_t cap = 1;
         int local_max = 0;
-        size_t cap = 0;
-        for (int r = 0; r < G; ++r) cap = std::max(cap, shard[r].size());
-        for (int c = 0; c < n_clips; ++c) local_max = std::max(local_max, (int)R.ids[c].size());
         std::vector<std::vector<int>> rank_max(G, std::vector<int>(2, 0));
         for (int r = 0; r < G; ++r) {
-            for (int c : shard[r]) rank_max[r][0] = std::max(rank_max[r][0], (int)R.ids[c].size());
-            rank_max[r][1] = (int)std::min(wall_ms[r] * 1000.0, 2.0e9);                    // microseconds
+            cap = std::max(cap, shard[r].size());
+            for (int c : shard[r]) rank_max[r][0] = std::max(rank_max[r][0], (int)results[c].n_tokens);
+            rank_max[r][1] = (int)std::min(g->wall_ms[r] * 1000.0, 2.0e9);                    // microseconds
+            local_max = std::max(local_max, rank_max[r][0]);
         }
         std::vector<int *> dmax(G, nullptr);
         std::vector<int32_t *> dmat(G, nullptr), dall(G, nullptr);
@@ -950,73 +1055,58 @@ pk_status pk_group_transcribe_pcm(pk_group *g, const float *pcm, const int64_t *
             PK_HIP(hipMalloc(reinterpret_cast<void **>(&dmax[r]), 2 * sizeof(int)));
             PK_HIP(hipMemcpyAsync(dmax[r], rank_max[r].data(), 2 * sizeof(int), hipMemcpyHostToDevice, g->streams[r]));
         }
-        PK_NCCL(ncclGroupStart());
+        PK_NCCL(N, GroupStart());
         for (int r = 0; r < G; ++r) {
             PK_HIP(hipSetDevice(g->devices[r]));
-            PK_NCCL(ncclAllReduce(dmax[r], dmax[r], 2, ncclInt32, ncclMax, g->comms[r], g->streams[r]));
+            PK_NCCL(N, AllReduce(dmax[r], dmax[r], 2, ncclInt32, ncclMax, g->comms[r], g->streams[r]));
         }
-        PK_NCCL(ncclGroupEnd());
+        PK_NCCL(N, GroupEnd());
         int reduced[2] = {0, 0};
         PK_HIP(hipSetDevice(g->devices[0]));
         PK_HIP(hipMemcpyAsync(reduced, dmax[0], sizeof(reduced), hipMemcpyDeviceToHost, g->streams[0]));
         PK_HIP(hipStreamSynchronize(g->streams[0]));
         const int max_tok = reduced[0];
         if (max_tok != local_max) fail(PK_ERR_HIP, "RCCL all-reduce(max) returned %d tokens, the ranks hold %d", max_tok, local_max);
-        const size_t stride = 2 + (size_t)max_tok, per_rank = std::max<size_t>(cap, 1) * stride;
+        if (std::abs(reduced[1] / 1000.0 - g->wall_ms_max) > 1.0) fail(PK_ERR_HIP, "RCCL all-reduce(max) of the wall times returned %d us", reduced[1]);
+        const size_t stride = 2 + (size_t)max_tok, per_rank = cap * stride;
         std::vector<std::vector<int32_t>> hmat(G);
         for (int r = 0; r < G; ++r) {                      // row = [global clip index, n_tokens, ids...] ; unused rows: index -1
             hmat[r].assign(per_rank, 0);
-            for (size_t i = 0; i < std::max<size_t>(cap, 1); ++i) hmat[r][i * stride] = -1;
+            for (size_t i = 0; i < cap; ++i) hmat[r][i * stride] = -1;
             for (size_t i = 0; i < shard[r].size(); ++i) {
                 const int c = shard[r][i];
                 int32_t *row = hmat[r].data() + i * stride;
                 row[0] = c;
-                row[1] = (int32_t)R.ids[c].size();
-                std::copy(R.ids[c].begin(), R.ids[c].end(), row + 2);
+                row[1] = results[c].n_tokens;
+                std::copy(results[c].token_ids, results[c].token_ids + results[c].n_tokens, row + 2);
             }
             PK_HIP(hipSetDevice(g->devices[r]));
             PK_HIP(hipMalloc(reinterpret_cast<void **>(&dmat[r]), per_rank * 4));
             PK_HIP(hipMalloc(reinterpret_cast<void **>(&dall[r]), per_rank * 4 * G));
             PK_HIP(hipMemcpyAsync(dmat[r], hmat[r].data(), per_rank * 4, hipMemcpyHostToDevice, g->streams[r]));
         }
-        PK_NCCL(ncclGroupStart());
+        PK_NCCL(N, GroupStart());
         for (int r = 0; r < G; ++r) {
             PK_HIP(hipSetDevice(g->devices[r]));
-            PK_NCCL(ncclAllGather(dmat[r], dall[r], per_rank, ncclInt32, g->comms[r], g->streams[r]));
+            PK_NCCL(N, AllGather(dmat[r], dall[r], per_rank, ncclInt32, g->comms[r], g->streams[r]));
         }
-        PK_NCCL(ncclGroupEnd());
+        PK_NCCL(N, GroupEnd());
         std::vector<int32_t> all(per_rank * G);
-        PK_HIP(hipSetDevice(g->devices[0]));
-        PK_HIP(hipMemcpyAsync(all.data(), dall[0], all.size() * 4, hipMemcpyDeviceToHost, g->streams[0]));
-        for (int r = 0; r < G; ++r) {
+        for (int r = 0; r < G; ++r) {                      // EVERY rank's copy of the gathered matrix is checked
             PK_HIP(hipSetDevice(g->devices[r]));
+            PK_HIP(hipMemcpyAsync(all.data(), dall[r], all.size() * 4, hipMemcpyDeviceToHost, g->streams[r]));
             PK_HIP(hipStreamSynchronize(g->streams[r]));
+            int seen = 0;
+            for (size_t row = 0; row < (size_t)G * cap; ++row) {
+                const int32_t *p = all.data() + row * stride;
+                if (p[0] < 0) continue;
+                need(p[0] < n_clips && p[1] >= 0 && p[1] <= max_tok, "gathered token matrix row");
+                if (results[p[0]].n_tokens != p[1] || !std::equal(p + 2, p + 2 + p[1], results[p[0]].token_ids))
+                    fail(PK_ERR_HIP, "RCCL all-gather: rank %d holds different token ids for clip %d", r, p[0]);
+                ++seen;
+            }
+            if (seen != n_clips) fail(PK_ERR_HIP, "RCCL all-gather: rank %d holds %d of %d clips", r, seen, n_clips);
         }
-        // the token ids of the results are the GATHERED ones (rank 0's copy of the matrix)
-        int seen = 0;
-        for (size_t row = 0; row < (size_t)G * std::max<size_t>(cap, 1); ++row) {
-            const int32_t *p = all.data() + row * stride;
-            if (p[0] < 0) continue;
-            need(p[0] < n_clips && p[1] >= 0 && p[1] <= max_tok, "gathered token matrix row");
-            if ((int)R.ids[p[0]].size() != p[1] || !std::equal(p + 2, p + 2 + p[1], R.ids[p[0]].begin()))
-                fail(PK_ERR_HIP, "RCCL all-gather returned different token ids for clip %d", p[0]);
-            R.ids[p[0]].assign(p + 2, p + 2 + p[1]);
-            ++seen;
-        }
-        if (seen != n_clips) fail(PK_ERR_HIP, "RCCL all-gather returned %d of %d clips", seen, n_clips);
-        g->wall_ms_max = reduced[1] / 1000.0;
-        g->audio_s = audio;
-        for (int r = 0; r < G; ++r) g->clips_per_rank[r] = (int32_t)shard[r].size();
-        *results = publish_store(std::move(store), n_clips, opt && opt->timestamps);
-    });
-}
-
-pk_status pk_group_last_stats(const pk_group *g, double *wall_ms_max, double *audio_seconds, int32_t *clips_per_rank) {
-    return guard([&] {
-        need(g, "group");
-        if (wall_ms_max) *wall_ms_max = g->wall_ms_max;
-        if (audio_seconds) *audio_seconds = g->audio_s;
-        if (clips_per_rank) std::copy(g->clips_per_rank.begin(), g->clips_per_rank.end(), clips_per_rank);
     });
 }
 

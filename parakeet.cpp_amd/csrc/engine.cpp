@@ -25,9 +25,9 @@ Model::Model(const std::string &weights_path, const std::string &vocab_path, con
     if (!vocab_path.empty()) tok.load(vocab_path);
 }
 
-Model::Model(const void *weights, size_t n_bytes, const std::string &vocab_path, const pk_config &c) : cfg(c) {
+Model::Model(const void *weights, size_t n_bytes, const std::string &vocab_path, const pk_config &c, bool borrow) : cfg(c) {
     validate_config();
-    st_ = std::make_unique<SafeTensors>(weights, n_bytes);
+    st_ = std::make_unique<SafeTensors>(weights, n_bytes, borrow);
     if (!vocab_path.empty()) tok.load(vocab_path);
 }
 
@@ -58,6 +58,7 @@ void Model::validate_config() {
 Model::~Model() {
     if (device_ >= 0) {
         (void)hipSetDevice(device_);
+        if (pipe && pipe_free) pipe_free(pipe);           // uses the streams below
         for (void *p : allocs_) (void)hipFree(p);
         if (h_done) (void)hipHostFree(h_done);
         if (stream) (void)hipStreamDestroy(stream);

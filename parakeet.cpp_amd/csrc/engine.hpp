@@ -68,7 +68,8 @@ class StreamBatch;
 class Model {
   public:
     Model(const std::string &weights_path, const std::string &vocab_path, const pk_config &cfg);
-    Model(const void *weights, size_t n_bytes, const std::string &vocab_path, const pk_config &cfg);   // safetensors image in memory
+    // safetensors image in memory; borrow: no copy, the image must stay alive until to_gpu() has returned
+    Model(const void *weights, size_t n_bytes, const std::string &vocab_path, const pk_config &cfg, bool borrow = false);
     ~Model();
     void to_gpu(int device);
     bool on_gpu() const { return device_ >= 0; }
@@ -126,6 +127,9 @@ class Model {
     DevBuf io_in, io_out, io_tmp;
     Workspace ws;       // workspace of the host-buffer stage entry points
     int *h_done = nullptr;   // pinned host word for the decode loop's "all utterances finished" poll
+    // the two-stream batch pipeline of the one-call API (struct pk_batch, capi.cpp), owned by the model; freed first in ~Model
+    void *pipe = nullptr;
+    void (*pipe_free)(void *) = nullptr;
 
     const float *upload(const float *host, size_t n);
     const float *upload_tensor(const std::string &name, std::vector<int64_t> expect_shape);

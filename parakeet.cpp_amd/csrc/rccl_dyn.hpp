@@ -1,0 +1,63 @@
+// parakeet.cpp_amd/csrc/rccl_dyn.hpp -- RCCL resolved at run time (dlopen), so that libparakeet_amd.so has NO link-time dependency on
+// librccl: a single-GPU user never loads it, and a host without RCCL gets a clear error only from the one entry point that needs it
+// (pk_group_verify_exchange).  The declarations come from <rccl/rccl.h> (types and enums only; no symbol of it is referenced).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <string>
+
+namespace pk {
+
+struct RcclApi {
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string path;
+};
+
+// nullptr (and *why filled) when librccl cannot be loaded.  Search order: PK_RCCL_LIB, the loader's default path, $ROCM_PATH/lib, /opt/rocm/lib.
+inline const RcclApi *rccl_api(std::string *why) {
+    static RcclApi api;
+    static bool tried = false, ok = false;
+    static std::string err;
+    if (!tried) {
+        tried = true;
+        std::string cand[6];
+        int n = 0;
+        if (const char *e = getenv("PK_RCCL_LIB")) cand[n++] = e;
+        cand[n++] = "librccl.so.1";
+        cand[n++] = "librccl.so";
+        if (const char *r = getenv("ROCM_PATH")) cand[n++] = std::string(r) + "/lib/librccl.so.1";
+        cand[n++] = "/opt/rocm/lib/librccl.so.1";
+        void *h = nullptr;
+        for (int i = 0; i < n && !h; ++i) {
+            h = dlopen(cand[i].c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (h) api.path = cand[i];
+            else err += std::string(err.empty() ? "" : "; ") + (dlerror() ? dlerror() : cand[i].c_str());
+        }
+        if (h) {
+            bool all = true;
+            auto sym = [&](const char *name) { void *p = dlsym(h, name); if (!p) { all = false; err = std::string("librccl lacks ") + name; } return p; };
+            api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+            api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+            api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+            api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+            api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+            ok = all;
+        }
+    }
+    if (!ok && why) *why = err;
+    return ok ? &api : nullptr;
+}
+
+}  // namespace pk

@@ -91,8 +91,12 @@ SafeTensors::SafeTensors(const std::string &path) {
     parse(static_cast<const uint8_t *>(map_), map_len_);
 }
 
-SafeTensors::SafeTensors(const void *data, size_t len) {
+SafeTensors::SafeTensors(const void *data, size_t len, bool borrow) {
     if (!data || len < 8) fail(PK_ERR_WEIGHTS, "safetensors: buffer of %zu bytes is too short", len);
+    if (borrow) {                       // the caller keeps the image alive for the lifetime of this view (pk_group_create)
+        parse(static_cast<const uint8_t *>(data), len);
+        return;
+    }
     own_.assign(static_cast<const uint8_t *>(data), static_cast<const uint8_t *>(data) + len);
     parse(own_.data(), own_.size());
 }

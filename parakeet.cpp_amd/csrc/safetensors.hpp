@@ -24,12 +24,16 @@ struct HostTensor {
 class SafeTensors {
   public:
     explicit SafeTensors(const std::string &path);   // throws pk::Error(PK_ERR_IO / PK_ERR_WEIGHTS)
-    SafeTensors(const void *data, size_t len);       // the same container from memory (copied; e.g. received by a broadcast)
+    // the same container from memory: copied (e.g. an image received by a broadcast), or -- borrow -- a view of an image the caller keeps alive
+    SafeTensors(const void *data, size_t len, bool borrow = false);
     ~SafeTensors();
     SafeTensors(const SafeTensors &) = delete;
     SafeTensors &operator=(const SafeTensors &) = delete;
     const HostTensor *find(const std::string &name) const;
     const std::map<std::string, HostTensor> &tensors() const { return tensors_; }
+    // the whole container as it lies in memory (the file mapping or the owned copy): lets several views share one image
+    const void *image_base() const { return map_ ? map_ : (own_.empty() ? nullptr : own_.data()); }
+    size_t image_bytes() const { return map_ ? map_len_ : own_.size(); }
 
   private:
     void parse(const uint8_t *base, size_t len);

@@ -200,6 +200,23 @@ def test_decode_groups_keep_every_result(tmp_path):
         bt.upload_async(batches[3]); bt.run("tdt")
         same(bt.results(), want[3], (grp, "back to group 1"))
         bt.close()
+    # A caller that reads ONLY after pk_batch_sync (round-2 advisor finding): 6 runs in groups of 4 -- the full group is decoded inside
+    # run 4, the partial group (runs 4, 5) by the sync; the runs of BOTH must still be readable, newest first.
+    bt = capi.Batch(gm, 4, n)
+    bt.set_decode_group(4)
+    bt.upload_async(batches[0])
+    for k in range(6):
+        bt.run("tdt")
+        if k + 1 < 6:
+            bt.upload_async(batches[k + 1])
+    bt.sync()
+    assert bt.results_available() == 6
+    for back in range(6):
+        same(bt.results_back(back), want[5 - back], ("read after sync", back))
+    # changing the group size drops the runs held in group buffers instead of leaving stale pointers behind
+    bt.set_decode_group(2)
+    assert bt.results_available() == 0
+    bt.close()
     assert sum(int(w["lens"].sum()) for w in want) > 0
 
 

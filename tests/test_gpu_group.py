@@ -1,7 +1,8 @@
-"""pk_group -- the library's multi-GPU entry: one replica per device, utterance batches dealt round-robin, the weight
-image broadcast and the token matrix all-gathered over RCCL.  The GPU box of the test run exposes ONE device, so the communicator has
-one rank -- the collectives (ncclBroadcast, ncclAllReduce(max), ncclAllGather) still execute, which is exactly the point: the same
-code path runs unchanged on 8 devices.  Results must equal pk_transcribe_pcm on a single model, clip for clip."""
+"""pk_group -- the library's multi-GPU entry: one replica per device built from ONE mapped weight image, utterance batches
+dealt round-robin, one host thread + one two-stream pipeline per device, no collective.  Results must equal pk_transcribe_pcm on a
+single model, clip for clip.  pk_group_verify_exchange runs the multi-process deployment's result exchange (RCCL all-reduce + fixed-stride
+all-gather of the token matrix) in-process as a check: the GPU box of the test run exposes ONE device, so the communicator has one rank --
+the collectives still execute, and the same code runs unchanged on 8 devices."""
 import numpy as np
 import pytest
 
@@ -26,7 +27,8 @@ def test_group_matches_single_model(tmp_path):
     assert grp.size() == capi.device_count() >= 1
     for dec, ts in (("tdt", True), ("ctc", False)):
         want = single.transcribe_pcm(clips, decoder=dec, timestamps=ts)
-        got = grp.transcribe_pcm(clips, decoder=dec, timestamps=ts)
+        got = grp.transcribe_pcm(clips, decoder=dec, timestamps=ts, verify_exchange=True)
+        assert grp.rccl_ranks == grp.size()
         assert len(got) == len(want) == 70
         for i, (g, w) in enumerate(zip(got, want)):
             assert g["token_ids"] == w["token_ids"] and g["text"] == w["text"], i
@@ -53,3 +55,46 @@ def test_group_explicit_device_list_and_errors(tmp_path):
         capi.Group(wp, cfg, devices=[99])
     with pytest.raises(RuntimeError, match="Cannot open"):
         capi.Group(str(tmp_path / "nope.safetensors"), cfg)
+
+
+def test_group_pipeline_keeps_up_with_resident_batches(tmp_path):
+    """Row (e) of the scope table: the in-library multi-GPU entry must run the PIPELINED path.  One rank of a pk_group (host PCM in, results
+    out, uploads inside the clock) against the resident pk_batch pipeline bench.py times, same clips, same decode group: >= 0.95x, and
+    identical token ids.  tdt-ctc-110m at the BASELINE batch shape (64 x 10 s)."""
+    import time
+    import dataclasses
+    from conftest import pk
+    cfg = dataclasses.replace(pk.make_110m_config(), name="110m-grp")
+    wp = str(tmp_path / "g17.safetensors")
+    synth.save_weights(wp, synth.synth_weights(cfg, seed=42))
+    n, B, steps = 160000, 64, 8
+    base = synth.synth_pcm(B, n, seed=1234)
+    clips = [base[i % B] for i in range(B * steps)]
+    grp = capi.Group(wp, cfg, devices=[0])
+    grp.transcribe_pcm(clips[: 4 * B], decoder="tdt")                       # warm-up: pipeline buffers, position tables
+    t_best = 1e9
+    for _ in range(2):
+        got = grp.transcribe_pcm(clips, decoder="tdt")
+        t_best = min(t_best, grp.last_stats()["wall_ms_max"])
+    grp.close()
+    gm = capi.Model(wp, cfg, device=0)
+    bt = capi.Batch(gm, B, n)
+    bt.upload(base)
+    bt.set_decode_group(4)
+    for _ in range(4):
+        bt.run("tdt")
+    bt.sync()
+    b_best = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bt.run("tdt")
+        bt.sync()
+        b_best = min(b_best, (time.perf_counter() - t0) * 1e3)
+    r = bt.results_back(0)
+    bt.close(); gm.close()
+    for b in range(B):
+        assert got[(steps - 1) * B + b]["token_ids"] == r["ids"][b, : r["lens"][b]].tolist()
+    ratio = b_best / t_best
+    print(f"pk_group 1 rank: {t_best / steps:.2f} ms/batch incl. uploads; resident pk_batch: {b_best / steps:.2f} ms/batch; ratio {ratio:.3f}")
+    assert ratio >= 0.95, (t_best, b_best)
