@@ -102,6 +102,13 @@ pk_status pk_model_load_buffer(const void *safetensors_image, size_t n_bytes, co
 pk_status pk_model_to_gpu(pk_model *m, int device);
 void pk_model_free(pk_model *m);
 pk_status pk_model_config(const pk_model *m, pk_config *out);
+/* How the TDT / RNNT greedy loop (src/tdt.cpp:62-106) is issued.  Every mode runs the SAME device functions and gives identical results
+ * (tests/test_gpu_decode.py); they differ in launch structure only.  PHASES (default): one launch per phase of a symbol step (LSTM cells,
+ * joint activation, heads, decision), the host polls a done-counter every 16 steps.  PERSISTENT: the whole loop in one launch, phases
+ * separated by a grid barrier (needs <= 2 LSTM layers, no phrase boosting, no carried streaming state; otherwise PHASES is used).
+ * GRAPH: the 16-step chunk of PHASES captured once as a hipGraph and replayed. */
+enum { PK_DECODE_LOOP_PHASES = 0, PK_DECODE_LOOP_PERSISTENT = 1, PK_DECODE_LOOP_GRAPH = 2 };
+pk_status pk_model_set_decode_loop(pk_model *m, int mode);
 
 /* ---- stage entry points (host buffers; used by the parity tests and the C++ facade) ----------------------- */
 /* preprocess_audio (src/audio.cpp:100-158): n_clips clips of n_samples each -> feats[n_clips][n_frames][mel_bins],

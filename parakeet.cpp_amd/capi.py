@@ -117,6 +117,7 @@ _LATE_SIGNATURES = {
     "pk_subsample": [C.c_void_p, f32p, C.c_int, C.c_int, f32p],
     "pk_ctc_decode": [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, f32p],
     "pk_tdt_decode": [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, i32p],
+    "pk_model_set_decode_loop": [C.c_void_p, C.c_int],
     "pk_batch_create": [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_void_p)],
     "pk_batch_free": [C.c_void_p],
     "pk_batch_upload": [C.c_void_p, f32p, C.c_int],
@@ -607,6 +608,10 @@ class Model:
     def to_gpu(self, device: int = 0):
         check(lib().pk_model_to_gpu(self._h, device))
         return self
+
+    def set_decode_loop(self, mode):
+        """pk_model_set_decode_loop: "phases" (default) | "persistent" | "graph" -- same results, different launch structure."""
+        check(lib().pk_model_set_decode_loop(self._h, {"phases": 0, "persistent": 1, "graph": 2}[mode]))
 
     def close(self):
         if getattr(self, "_h", None):

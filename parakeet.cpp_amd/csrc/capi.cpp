@@ -142,6 +142,14 @@ pk_status pk_model_to_gpu(pk_model *m, int device) {
 
 void pk_model_free(pk_model *m) { delete m; }
 
+pk_status pk_model_set_decode_loop(pk_model *m, int mode) {
+    return guard([&] {
+        need(m, "model");
+        need(mode == PK_DECODE_LOOP_PHASES || mode == PK_DECODE_LOOP_PERSISTENT || mode == PK_DECODE_LOOP_GRAPH, "mode");
+        m->m->decode_loop = mode;
+    });
+}
+
 pk_status pk_model_config(const pk_model *m, pk_config *out) {
     return guard([&] { need(m && out, "model/out"); *out = m->m->cfg; });
 }

@@ -346,11 +346,14 @@ void Model::to_gpu(int device) {
     {
         int lo = 0, hi = 0;
         PK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // numerically lowest = highest priority
-        int prio = hi;                                        // default: the decode loop of batch k-1 runs at the highest priority
-        if (const char *e = getenv("PK_DEC_PRIORITY")) {      // experiment knob (tools/): "normal" / "low"
+        int prio = hi;                                        // the decode loop of batch k-1 runs at the highest priority
+#ifdef PK_EXPERIMENTAL
+        if (const char *e = getenv("PK_DEC_PRIORITY")) {      // experiment builds only (tools/): "normal" / "low"
             if (!strcmp(e, "normal")) prio = 0;
             else if (!strcmp(e, "low")) prio = lo;
         }
+#endif
+        (void)lo;
         PK_HIP(hipStreamCreateWithPriority(&stream_dec, hipStreamNonBlocking, prio));
     }
     PK_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_done), sizeof(int), hipHostMallocDefault));
@@ -741,14 +744,13 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         a.X = w.z.as<float>(); a.W = wld_s; a.B = B; a.N = V + D; a.K = J; a.bias = bld; a.out = w.logits.as<float>(); a.ldo = V + D;
     }
     // ONE launch for the whole loop (kernels/decode_persist.hip): implemented, bit-identical to the per-phase loop (tests/test_gpu_decode.py),
-    // and NOT faster on this hardware -- OPT-IN with PK_DEC_PERSISTENT=1.  Measured in round 2 (profiles/r02_decode_persistent.md): the
+    // and NOT faster on this hardware -- opt-in: pk_model_set_decode_loop(m, PK_DECODE_LOOP_PERSISTENT).  Measured in round 2 (profiles/r02_decode_persistent.md): the
     // grid barrier between the four all-to-all phases of a step costs ~20 us with a single system-scope arrival counter (160 arrivals
     // serialise at the memory side), 98 us per step against 46 us for four launches; next to the encoder of the following batch the
     // resident part of the grid spins while the rest waits for CU slots.  Eligible when the decide scratch is small enough for a
     // workgroup to sit beside the encoder's GEMM workgroups, at most two LSTM layers, no phrase boosting, no carried streaming state.
     {
-        const char *e = getenv("PK_DEC_PERSISTENT");
-        const bool want = e && e[0] == '1';
+        const bool want = decode_loop == PK_DECODE_LOOP_PERSISTENT;
         const int G = Hp / 4;
         if (want && !boost_on && !keep_state && Hp % 4 == 0 && G >= 1 && G <= 200 && L <= 2 && tdt_persistent_lds_bytes(st) <= 12 * 1024) {
             P.bar = reinterpret_cast<unsigned *>(st.done_count + 1);           // two spare words behind the per-utterance state
@@ -768,12 +770,17 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         KL("joint_heads_gemv", f_hd, 0.0, launch_skinny_gemm(P.heads, SK_BIAS, s));
         KL("tdt_decide", 0.0, 0.0, launch_tdt_decide(st, s));
     };
-    // PK_DEC_GRAPH=1: the chunk of 16 steps is captured once into a hipGraph (every argument is step-invariant) and replayed.
-    static const bool want_graph = [] { const char *e = getenv("PK_DEC_GRAPH"); return e && e[0] == '1'; }();
+    // PK_DECODE_LOOP_GRAPH: the chunk of 16 steps is captured once into a hipGraph (every argument is step-invariant) and replayed.
+    const bool want_graph = decode_loop == PK_DECODE_LOOP_GRAPH;
     if (want_graph && !prof) {
-        std::vector<unsigned char> key(sizeof(TdtPersist) + sizeof(hipStream_t));
-        memcpy(key.data(), &P, sizeof(TdtPersist));
-        memcpy(key.data() + sizeof(TdtPersist), &s, sizeof(hipStream_t));
+        // key = the pointer / size arguments the captured launches carry, field by field (no struct padding in the comparison) + the model's
+        // weight generation (a graph never outlives the weights it was captured against: the workspace is keyed by model + stream)
+        std::vector<unsigned char> key;
+        auto put = [&key](const void *p, size_t n) { const unsigned char *c = static_cast<const unsigned char *>(p); key.insert(key.end(), c, c + n); };
+        const void *ptrs[] = {this, s, st.logits, st.h, st.c, st.hn, st.cn, st.token, st.lens, st.ids, st.start, st.end, st.conf, P.act.ep, P.heads.W, P.act.W, P.cell[0].W, P.cell[0].gi};
+        const int ints[] = {B, T, V, D, L, Hp, J, max_tokens, st.blank, st.max_symbols, st.max_steps, st.keep_state, boost_on ? 1 : 0};
+        put(ptrs, sizeof ptrs);
+        put(ints, sizeof ints);
         if (!w.dec_graph || key != w.dec_graph_key) {
             if (w.dec_graph) { (void)hipGraphExecDestroy(w.dec_graph); w.dec_graph = nullptr; }
             hipGraph_t graph = nullptr;

@@ -126,6 +126,7 @@ class Model {
     // grow-only scratch shared by the host-buffer entry points
     DevBuf io_in, io_out, io_tmp;
     Workspace ws;       // workspace of the host-buffer stage entry points
+    int decode_loop = PK_DECODE_LOOP_PHASES;   // pk_model_set_decode_loop: how run_tdt_loop issues the greedy loop
     int *h_done = nullptr;   // pinned host word for the decode loop's "all utterances finished" poll
     // the two-stream batch pipeline of the one-call API (struct pk_batch, capi.cpp), owned by the model; freed first in ~Model
     void *pipe = nullptr;

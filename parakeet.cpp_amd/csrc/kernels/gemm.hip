@@ -184,26 +184,27 @@ static void launch_one(const GemmArgs &a, hipStream_t s) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
     const int n_tiles = tiles_m * tiles_n;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * LDP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_kernel<BM, BN, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static DynLdsSlots slots;
+    ensure_dyn_lds(slots, reinterpret_cast<const void *>(&gemm_nt_kernel<BM, BN, EPI>), lds);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI>), dim3(n_tiles), dim3(256), lds, s, a, tiles_n, n_tiles);
 }
 
 // Tile choice, from tools/ubench/gemm_sweep on MI355X (profiles/r01_gemm_sweep.txt): the pipelined kernels win where
 // the K loop is short (most of the encoder is K = 512); wide outputs like 128x128 tiles on 8 waves, long-K / narrow-N
 // products 128x64, everything else 64x64 (more resident workgroups to overlap one tile's epilogue with another's MFMAs).
-// PK_GEMM_VARIANT: A/B switch between the double-buffered ("pipe", NBUF = 2) and single-buffered ("sb", NBUF = 1) staging of the same
-// tiles (tools/experiments/gemm_variant_ab.sh).  Bits: 1 = long-K single-round products (fc2, sub_proj) on sb 128x128 / 8 waves of 32x64 /
-// BK 64; 2 = wide outputs (fc1, qkv, sub_pw) on sb; 4 = out_proj / pw2 on sb 64x128 / 4 waves; 8 = GLU on sb; 16 = wide outputs on sb BK 64; 64 = out_proj / pw2 on sb 128x128 / 8 waves.
-// Default 75 = what the engine measurements of round 2 picked (profiles/r02_gemm_variant_ab.txt: step 20.44 -> 19.73 ms with 11; bit 4 is
-// level; bit 64 takes out_proj / pw2 from 0.81 to 0.77 ms per step).
+// Variant mask of the tile table.  Bits: 1 = long-K single-round products (fc2, sub_proj) on the single-buffered 128x128 / 8 waves of 32x64 /
+// BK 64 tile; 2 = wide outputs (fc1, qkv, sub_pw) single-buffered; 4 = out_proj / pw2 on sb 64x128 / 4 waves; 8 = GLU on sb; 16 = wide outputs
+// on sb BK 64; 64 = out_proj / pw2 on sb 128x128 / 8 waves.  75 = what the engine measurements of round 2 picked
+// (profiles/r02_gemm_variant_ab.txt: step 20.44 -> 19.73 ms with 11; bit 4 is level; bit 64 takes out_proj / pw2 from 0.81 to 0.77 ms per step).
+// A production build has NO run-time switch: the mask is a constant.  Experiment builds (make EXPERIMENTAL=1 -> -DPK_EXPERIMENTAL) read
+// PK_GEMM_VARIANT for the interleaved A/B runs of tools/experiments/gemm_variant_ab.sh.
 static int gemm_variant_mask() {
+#ifdef PK_EXPERIMENTAL
     static const int m = [] { const char *e = getenv("PK_GEMM_VARIANT"); return e ? atoi(e) : 75; }();
     return m;
+#else
+    return 75;
+#endif
 }
 
 template <int EPI>

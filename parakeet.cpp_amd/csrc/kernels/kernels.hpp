@@ -3,9 +3,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 
 namespace pk {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting and the launchers run on one host thread per device in a
+// pk_group: the largest size set so far is kept per (launcher, device).  `slots` is the launcher's own static array.
+constexpr int kMaxDevices = 16;
+struct DynLdsSlots { std::atomic<size_t> set[kMaxDevices]; };
+inline void ensure_dyn_lds(DynLdsSlots &slots, const void *kernel, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t> &cur = slots.set[dev >= 0 && dev < kMaxDevices ? dev : 0];
+    if (bytes > cur.load(std::memory_order_acquire) || dev >= kMaxDevices) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        cur.store(bytes, std::memory_order_release);
+    }
+}
 
 // ---- mel front end (src/audio.cpp:100-158) ----------------------------------------------------
 constexpr int kMelMaxTaps = 1024;     // packed filterbank taps staged in LDS by the mel kernel (sum of the band widths; 80 / 128 bins: ~590)

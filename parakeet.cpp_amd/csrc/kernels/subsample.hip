@@ -131,11 +131,8 @@ static void launch_c1d1(const float *feats, int B, int Tm, int F, int C, const f
     const int spb = 256 / C, n_ys = (H2 + 7) / 8, n_xc = (W2 + XC - 1) / XC;
     const int64_t n_strips = (int64_t)B * n_ys * n_xc;
     const size_t lds = (size_t)spb * WR * PW * sizeof(float);
-    static size_t attr = 0;
-    if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sub_conv1_dw1_kernel<XC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    static DynLdsSlots slots;
+    ensure_dyn_lds(slots, reinterpret_cast<const void *>(&sub_conv1_dw1_kernel<XC>), lds);
     hipLaunchKernelGGL(sub_conv1_dw1_kernel<XC>, dim3((unsigned)((n_strips + spb - 1) / spb)), dim3(256), lds, s, feats, Tm, F, C, w1, b1,
                        wd, bd, H1, W1, H2, W2, n_xc, n_ys, n_strips, out);
 }

@@ -264,6 +264,13 @@ void StreamBatch::decode(const float *enc, int c, int max_tokens, int32_t *ids, 
 }
 
 void StreamBatch::push(const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
+    // Validate BEFORE any carried state (pre-emphasis carry, overlap samples, caches) is touched: a rejected push must leave the streams
+    // exactly where they were.  Bound on the encoder frames this push can produce: < 8 leftover mel frames + (559 overlap + n_samples) / 160 + 1
+    // new ones, / 8, + 1 -- at most dec_cap_frames_ when n_samples <= (dec_cap_frames_ - 2) * 8 hops.
+    if (max_tokens <= 0 || max_tokens > wd_.max_tokens) fail(PK_ERR_INVALID, "max_tokens %d: 1 .. %d", max_tokens, wd_.max_tokens);
+    if ((int64_t)n_samples > (int64_t)(dec_cap_frames_ - 2) * 8 * 160)
+        fail(PK_ERR_UNSUPPORTED, "a push of %d samples exceeds the stream's decode workspace (%d encoder frames per chunk: at most %d samples)",
+             n_samples, dec_cap_frames_, (dec_cap_frames_ - 2) * 8 * 160);
     for (int s = 0; s < S; ++s) lens[s] = 0;
     const int n_frames = mel(pcm, n_samples, nullptr, 0);
     if (n_frames == 0) return;

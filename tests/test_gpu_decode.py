@@ -86,31 +86,38 @@ def test_rnnt_head(tmp_path_factory):
 
 
 @pytest.mark.parametrize("B", [1, 5, 64, 70])
-def test_persistent_loop_equals_per_phase_loop(tiny_pair, B, monkeypatch):
-    """The single-launch decode loop (kernels/decode_persist.hip: grid barriers, system-scope exchange) against the per-phase launches
-    of the same device code (PK_DEC_PERSISTENT=0) and against the oracle: every output word identical."""
+def test_persistent_loop_equals_per_phase_loop(tiny_pair, B):
+    """The single-launch decode loop (kernels/decode_persist.hip: grid barriers, system-scope exchange) and the hipGraph replay against the
+    per-phase launches of the same device code (pk_model_set_decode_loop) and against the oracle: every output word identical."""
     W, om, gm = tiny_pair
     enc = enc_like(B, 57, om.cfg.hidden_size, 100 + B)
-    monkeypatch.setenv("PK_DEC_PERSISTENT", "0")
+    gm.set_decode_loop("phases")
     a = gm.tdt_decode(enc)
-    monkeypatch.setenv("PK_DEC_PERSISTENT", "1")
-    b = gm.tdt_decode(enc)
-    for k in ("lens", "steps", "ids", "start", "end"):
-        assert np.array_equal(a[k], b[k]), k
-    G.assert_bits_equal(a["conf"], b["conf"], "confidence")
+    try:
+        for mode in ("persistent", "graph"):
+            gm.set_decode_loop(mode)
+            b = gm.tdt_decode(enc)
+            for k in ("lens", "steps", "ids", "start", "end"):
+                assert np.array_equal(a[k], b[k]), (mode, k)
+            G.assert_bits_equal(a["conf"], b["conf"], "confidence")
+    finally:
+        gm.set_decode_loop("phases")
     o = check_tdt(gm, om, enc)
     assert o["lens"].sum() > 0
 
 
-def test_persistent_loop_110m_heads_and_two_layers(tmp_path_factory, monkeypatch):
+def test_persistent_loop_110m_heads_and_two_layers(tmp_path_factory):
     for cfg in (dataclasses.replace(pk.make_110m_config(), num_layers=1, name="110m-1L-persist"),
                 G.tiny(name="tiny-2lstm-persist", num_lstm_layers=2)):
         W, om, gm = G.make_pair(tmp_path_factory.mktemp("persist"), cfg, seed=9)
         enc = enc_like(16 if cfg.hidden_size == 512 else 7, 126, cfg.hidden_size, 3)
-        monkeypatch.setenv("PK_DEC_PERSISTENT", "0")
+        gm.set_decode_loop("phases")
         a = gm.tdt_decode(enc)
-        monkeypatch.setenv("PK_DEC_PERSISTENT", "1")
-        b = gm.tdt_decode(enc)
+        gm.set_decode_loop("persistent")
+        try:
+            b = gm.tdt_decode(enc)
+        finally:
+            gm.set_decode_loop("phases")
         for k in ("lens", "steps", "ids", "start", "end"):
             assert np.array_equal(a[k], b[k]), (cfg.name, k)
         G.assert_bits_equal(a["conf"], b["conf"], "confidence")

@@ -1,3 +1,5 @@
+// tools/ubench/attention_trace.hip -- INSTRUMENTED copy of parakeet.cpp_amd/csrc/kernels/attention.hip for tools/ubench/attn_bench only
+// (ATT_TRACE shader-clock stamps per phase).  The product kernel carries no such scaffolding; keep the arithmetic in step with it.
 // parakeet.cpp_amd/csrc/kernels/attention.hip -- relative-position multi-head attention core
 // (reference ConformerAttention::rel_position_attention, src/encoder.cpp:135-171, with rel_shift
 // :85-109 applied in closed form):
@@ -19,8 +21,8 @@
 // (Round 2 also tried V as a straight-from-L2 B operand -- one dword per lane per MFMA step, a register block of 8 steps ahead: bit-equal,
 // no V copy in LDS and no chunk barriers, but the gathers are slower than the LDS copy: AV phase 10 k -> 23 k clocks per wave at T = 126,
 // 52 k -> 112 k at T = 376 / hd = 128.  Not kept.)
-#include "../pk_devmath.h"
-#include "kernels.hpp"
+#include "../../parakeet.cpp_amd/csrc/pk_devmath.h"
+#include "../../parakeet.cpp_amd/csrc/kernels/kernels.hpp"
 
 namespace pk {
 
@@ -28,6 +30,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int RB = 32;   // query rows per workgroup
 #ifndef ATT_OCC
 #define ATT_OCC 4                 // workgroups per CU the hd <= 64 kernel is compiled for (register budget 168 / 128 VGPRs for 3 / 4)
+#endif
+
+#ifdef ATT_TRACE
+__device__ long long *att_trace;    // micro-benchmark builds only (tools/ubench/attn_bench): [workgroup][wave][8] shader-clock stamps
+#define ATT_STAMP(i) do { if (att_trace && lane == 0) att_trace[((long long)blockIdx.x * 4 + wave) * 8 + (i)] = clock64(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
@@ -116,6 +125,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
     //      q is fetched again (L2) and (q+v) formed for the position scores -- and the first V chunk is requested after the score phases:
     //      the register budget of four workgroups per CU (128 VGPRs) has no room for both copies plus the V prefetch beside the four
     //      operand tiles of the score loops (round 2: 168 -> 134 VGPRs, 86.9 -> 82.3 us per layer at T = 126).
+    ATT_STAMP(0);
     float4 qx[NQ4];                                                 // (q+u), later (q+v); element e of fragment f <-> k = 16f + 4e + kq
     auto load_q_biased = [&](const float *bias) {                   // as the reference forms them (src/encoder.cpp:141-142)
         load_tile(qb, ldq, i0 + rt * 16, T, qx);
@@ -132,6 +142,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
     float4 bA0[NQ4], bA1[NQ4], bB0[NQ4], bB1[NQ4];                  // two operand-tile pairs: one computing, one in flight
 
     // ---- phase 1: content scores (q+u) K^T -> S; this wave's column tiles are t = cp, cp+2, ... (pairs, one pair ahead) ----
+    ATT_STAMP(1);
     {
         const int nct = (T + 15) / 16;
         auto store = [&](int t, const f32x4 &a0, const f32x4 &a1) {
@@ -157,6 +168,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
             }
         }
     }
+    ATT_STAMP(2);
     if (pos) load_q_biased(bias_v);
     // ---- phase 2: position scores (q+v) P^T, shifted, combined and scaled.  This wave's 16 query rows need
     //      p = j - i + T - 1 in [wpmin, wpmax] (T+15 rows): its own tile grid starts at wpmin, tiles t = cp, cp+2, ... ------
@@ -165,6 +177,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
     const int npt = (pos && w_lo < T) ? (wpmax - wpmin) / 16 + 1 : 0;
     if (cp < npt) { load_tile(pb, d, wpmin + cp * 16, P, bA0); load_tile(pb, d, wpmin + (cp + 2) * 16, P, bA1); }   // in flight across the barrier
     __syncthreads();                                              // content scores complete
+    ATT_STAMP(3);
     {
         auto rmw = [&](int t, const f32x4 &a0, const f32x4 &a1) {
 #pragma unroll
@@ -194,8 +207,10 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
             }
         }
     }
+    ATT_STAMP(4);
     v_issue(0);                                                   // first V chunk: in flight across the softmax
     __syncthreads();
+    ATT_STAMP(5);
     // ---- phase 3: softmax, one wavefront per row ----------------------------------------------------------------------------
     // Each wave owns rows wave, wave+4, ...: all NSR of them go through the three sweeps TOGETHER, so the 2 x 6 dependent
     // cross-lane butterfly stages and the exp / divide chains of different rows overlap instead of queueing up.
@@ -245,6 +260,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
                 }
         }
     }
+    ATT_STAMP(6);
     v_commit();
     lds_store_fence();
     __syncthreads();
@@ -287,6 +303,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
                 else ctx[o] = acc[m][r];
             }
         }
+    ATT_STAMP(7);
 }
 
 template <int HD, int VCH>

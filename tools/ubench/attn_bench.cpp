@@ -8,7 +8,7 @@
 #include <vector>
 
 #define ATT_TRACE 1
-#include "../../parakeet.cpp_amd/csrc/kernels/attention.hip"
+#include "attention_trace.hip"
 
 using namespace pk;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)

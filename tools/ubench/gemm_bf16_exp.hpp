@@ -1,3 +1,5 @@
+// tools/ubench/gemm_bf16_exp.hpp -- INSTRUMENTED copy of parakeet.cpp_amd/csrc/kernels/gemm_bf16.hpp (BG_EXP component switches) for the
+// micro-benchmarks; defines the product header's include guard so that including it first shadows the product version.
 // parakeet.cpp_amd/csrc/kernels/gemm_bf16.hpp -- bf16-input / fp32-accumulate MFMA GEMM (gfx950), the precision
 // BASELINE configs[2] (tdt-600m) names.
 //
@@ -13,13 +15,14 @@
 // MFMA step s with one ds_read_b128 -- bf16 needs no K permutation.
 #ifndef PK_GEMM_BF16_HPP
 #define PK_GEMM_BF16_HPP
-#include "../pk_devmath.h"
-#include "kernels.hpp"
-#include "gemm_pipe.hpp"
+#include "gemm_pipe_exp.hpp"
 
 #ifndef BG_GROUPM
 #define BG_GROUPM 8                 // tile rows per group of the grouped tile order (1 = row-major)
 #endif
+#ifndef BG_EXP
+#define BG_EXP 0                    // micro-benchmark experiments only (tools/ubench, results wrong, timing only): main loop without
+#endif                              // 16 = LDS stores, 32 = global loads, 64 = fragment reads; 512 = staging stores as ds_write_b128 instead of ds_write2_b64 pairs, 1024 = as two separate ds_write_b64, 2048 = as four ds_write_b32
 
 namespace pk {
 
@@ -95,6 +98,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
 
     float4 ra[A_CH][2];
     uint4 rw[W_CH];
+    int opaque0 = 0;
+    if (BG_EXP & 1024) asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
@@ -113,16 +118,39 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             if constexpr (A16) {
-                lds_store16(base + a_dst[i], ra[i][0]);
+                if (BG_EXP & 2048) lds_store16_b32(base + a_dst[i], ra[i][0]);
+                else lds_store16(base + a_dst[i], ra[i][0]);
                 continue;
             }
             bg_bf16x8 v;
             v[0] = (__bf16)ra[i][0].x; v[1] = (__bf16)ra[i][0].y; v[2] = (__bf16)ra[i][0].z; v[3] = (__bf16)ra[i][0].w;
             v[4] = (__bf16)ra[i][1].x; v[5] = (__bf16)ra[i][1].y; v[6] = (__bf16)ra[i][1].z; v[7] = (__bf16)ra[i][1].w;
-            lds_store16(base + a_dst[i], *reinterpret_cast<const float4 *>(&v));
+            if (BG_EXP & 1024) {                                   // two separate 8-byte stores the compiler cannot merge (opaque zero offset)
+                const float4 q = *reinterpret_cast<const float4 *>(&v);
+                *reinterpret_cast<float2 *>(base + a_dst[i]) = make_float2(q.x, q.y);
+                *reinterpret_cast<float2 *>(base + a_dst[i] + 4 + opaque0) = make_float2(q.z, q.w);
+            } else if (BG_EXP & 2048) {
+                lds_store16_b32(base + a_dst[i], *reinterpret_cast<const float4 *>(&v));
+            } else if (!(BG_EXP & 512)) {
+                lds_store16(base + a_dst[i], *reinterpret_cast<const float4 *>(&v));
+            } else {
+                *reinterpret_cast<bg_bf16x8 *>(base + a_dst[i]) = v;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < W_CH; ++i) lds_store16(base + w_dst[i], *reinterpret_cast<const float4 *>(&rw[i]));
+        for (int i = 0; i < W_CH; ++i) {
+            if (BG_EXP & 1024) {
+                const float4 q = *reinterpret_cast<const float4 *>(&rw[i]);
+                *reinterpret_cast<float2 *>(base + w_dst[i]) = make_float2(q.x, q.y);
+                *reinterpret_cast<float2 *>(base + w_dst[i] + 4 + opaque0) = make_float2(q.z, q.w);
+            } else if (BG_EXP & 2048) {
+                lds_store16_b32(base + w_dst[i], *reinterpret_cast<const float4 *>(&rw[i]));
+            } else if (!(BG_EXP & 512)) {
+                lds_store16(base + w_dst[i], *reinterpret_cast<const float4 *>(&rw[i]));
+            } else {
+                *reinterpret_cast<uint4 *>(base + w_dst[i]) = rw[i];
+            }
+        }
     };
 
     bg_f32x16 acc[TM][TN];
@@ -161,14 +189,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs g, i
         const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
 #pragma unroll
         for (int s = 0; s < NSUB - 1; ++s) {
-            fragload(cur, s + 1, (s + 1) & 1);
-            if (s == NSUB - 2 && more1) lstore(cur ^ 1);
+            if (!(BG_EXP & 64)) fragload(cur, s + 1, (s + 1) & 1);
+            if (!(BG_EXP & 16) && s == NSUB - 2 && more1) lstore(cur ^ 1);
             BG_SB(); mma(s & 1); BG_SB();
         }
         lds_store_fence();                                          // the staging stores are inline ds_write2_b64 (lds_store16)
         __syncthreads();
-        if (more1) fragload(cur ^ 1, 0, 0);
-        if (more2) gload(kt + 2);
+        if (!(BG_EXP & 64) && more1) fragload(cur ^ 1, 0, 0);
+        if (!(BG_EXP & 32) && more2) gload(kt + 2);
         BG_SB(); mma((NSUB - 1) & 1); BG_SB();
         cur ^= 1;
     }

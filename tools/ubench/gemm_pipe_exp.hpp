@@ -1,4 +1,9 @@
-// parakeet.cpp_amd/csrc/kernels/gemm_pipe.hpp -- software-pipelined fp32 MFMA GEMM (gfx950).
+// tools/ubench/gemm_pipe_exp.hpp -- the INSTRUMENTED copy of parakeet.cpp_amd/csrc/kernels/gemm_pipe.hpp used by the micro-benchmarks only
+// (component switches GP_EXP, clock stamps GP_CLOCKPROBE, late-start GP_DELAY_TICKS).  It defines the product header's include guard, so a
+// benchmark that includes it BEFORE kernels/gemm.hip gets this version; the product header carries none of this scaffolding.
+// Keep the arithmetic in step with the product header (tools/ubench/gemm_sweep checks both against the same reference).
+//
+// software-pipelined fp32 MFMA GEMM (gfx950).
 //
 // out[M][N] = epi(A[M][K] * W[N][K]^T + bias), natural-k fma chains (bit-identical to the oracle's scalar chain).
 // Same arithmetic as the first-generation kernel (gemm.hip), rebuilt around the LDS pipe and the per-tile fixed costs:
@@ -17,12 +22,26 @@
 //    MFMA rate; what is left is the write burst of the output tile (all workgroups of a round finish together).
 #ifndef PK_GEMM_PIPE_HPP
 #define PK_GEMM_PIPE_HPP
-#include "../pk_devmath.h"
-#include "kernels.hpp"
+#include "../../parakeet.cpp_amd/csrc/pk_devmath.h"
+#include "../../parakeet.cpp_amd/csrc/kernels/kernels.hpp"
 
 namespace pk {
 
 typedef float gp_f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef GP_EXP
+#define GP_EXP 0                    // micro-benchmark experiments only (tools/ubench): 1 = epilogue without global stores,
+#endif                              // 2 = epilogue without activation math; main loop without 8 = barrier, 16 = LDS stores,
+                                    // 32 = global loads, 64 = fragment reads, 128 = MFMAs; 1024 = staging stores as ds_write2_b64 pairs instead of four ds_write_b32
+#ifdef GP_CLOCKPROBE
+__device__ long long gp_clk[4];     // micro-benchmark builds only: shader / wall clock deltas of block 0
+__device__ long long *gp_trace;     // micro-benchmark builds only: [n_blocks][8] wall-clock stamps of wave 0 + hw id
+#define GP_STAMP(i) do { if (gp_trace && tid == 0) gp_trace[(long long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+__device__ long long *gp_tr2;       // micro-benchmark builds only: [n_blocks][16 waves][GP_TR2_IT][2] shader-clock stamps around the K-loop barrier
+#define GP_TR2_IT 24
+#else
+#define GP_STAMP(i) do { } while (0)
+#endif
 
 // Epilogue shared by the GEMM kernels of this directory (bias, ReLU, SiLU, residual + alpha*y, GLU, sigma column layout) on the
 // accumulators of a WGM x WGN grid of waves, each holding TM x TN 32x32 tiles.  `smem` is the kernel's staging memory (free by now),
@@ -127,6 +146,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
             }
         }
         __syncthreads();
+        GP_STAMP(5);
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             if ((q * RSTEP) / PR != pass) continue;
@@ -156,7 +176,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
                 if constexpr (EPI == EPI_RELU) {
                     x = x > 0.0f ? x : 0.0f;
                 } else if constexpr (EPI == EPI_SILU) {
-                    x = g.fast_act ? fast_siluf(x) : dsiluf(x);
+                    if (!(GP_EXP & 2)) x = g.fast_act ? fast_siluf(x) : dsiluf(x);
                 } else if constexpr (EPI == EPI_RESID) {
                     const float y = x * g.alpha;
                     x = rsv[e] + y;
@@ -167,7 +187,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
                 }
                 v[e] = x;
             }
-            if (row < g.M && col_ok) {
+            if ((GP_EXP & 1) ? (row < 0) : (row < g.M && col_ok)) {
                 if (g.out_bf16) {                                   // bf16 activations (gemm_bf16.hpp): 4 results = 8 bytes
                     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
                     const bf16x4_ o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     auto st2 = [&](float *p, float a, float b, float c, float d) {
         // The products without an epilogue function (qkv: 756 tiles = 1.48 rounds of workgroups) keep the 8-byte pair form: there the 4-byte
         // stores shift the round structure the wrong way (115.6 vs 107.3 us in the sweep, +19 % in the engine).
-        if (EPI == EPI_NONE) {
+        if ((GP_EXP & 1024) || EPI == EPI_NONE) {
             *reinterpret_cast<float2 *>(p) = make_float2(a, b);
             *reinterpret_cast<float2 *>(p + BK / 2) = make_float2(c, d);
         } else {
@@ -289,6 +309,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     };
 
     gp_f32x16 acc[TM][TN];
+    if (GP_EXP & 256) { float d_; asm volatile("; keep AGPRs allocatable %0" : "=a"(d_)); }
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -326,16 +347,31 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     auto epilogue = [&](int m0, int n0) { gp_epilogue<WGM, WGN, TM, TN, EPI, NBUF * BUF>(g, acc, smem, m0, n0); };
 #define GP_SB() __builtin_amdgcn_sched_barrier(0)
 
+#ifdef GP_CLOCKPROBE
+    const long long c0_ = clock64(), w0_ = wall_clock64();
+#endif
     int m0, n0;
+#ifdef GP_DELAY_TICKS
+    // experiment: the second workgroup of every CU (blocks 256..511 of the first round) starts GP_DELAY_TICKS x 10 ns late, so that the
+    // two co-resident workgroups do not reach their epilogues together
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+        const long long t0_ = wall_clock64();
+        while (wall_clock64() - t0_ < GP_DELAY_TICKS) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+    GP_STAMP(0);
     set_tile(blockIdx.x, m0, n0);
     gload(0);
     lstore(0);
     lds_store_fence();
     __syncthreads();
+    GP_STAMP(1);
     gload(1);                      // nk >= 2 (K >= 2*BK, checked by the launcher)
     fragload(0, 0, 0);
     int cur = 0;
     zero_acc();
+    // GP_EXP bits 8..128 (micro-benchmark builds only; results are wrong, only the time is read) switch main-loop components off:
+    // 8 = barrier, 16 = LDS stores, 32 = global loads, 64 = fragment reads, 128 = MFMAs  (profiles/r02_gemm_mainloop_ablation.txt)
     if constexpr (NBUF == 1) {
         // Single staging buffer (half the LDS, two barriers per K tile: one when every wave has its last fragments in registers, one
         // when the next tile is stored; the last sub-step's MFMAs run between them).  Level with the double-buffered loop in the
@@ -360,20 +396,52 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
 #pragma unroll
             for (int s = 0; s < NSUB - 1; ++s) {
-                fragload(cur, s + 1, (s + 1) & 1);
-                if (s == NSUB - 2 && more1) lstore(cur ^ 1);
-                GP_SB(); mma(s & 1); GP_SB();
+                if (!(GP_EXP & 64)) fragload(cur, s + 1, (s + 1) & 1);
+                if (!(GP_EXP & 16) && s == NSUB - 2 && more1) lstore(cur ^ 1);
+                GP_SB(); if (!(GP_EXP & 128)) mma(s & 1); GP_SB();
             }
+#ifdef GP_CLOCKPROBE
+            unsigned long long tA_ = 0, tB_ = 0;
+            if (gp_tr2) asm volatile("s_memtime %0" : "=s"(tA_));
+#endif
             lds_store_fence();
-            __syncthreads();
-            if (more1) fragload(cur ^ 1, 0, 0);
-            if (more2) gload(kt + 2);
-            GP_SB(); mma((NSUB - 1) & 1); GP_SB();
+            if (!(GP_EXP & 8)) __syncthreads();
+#ifdef GP_CLOCKPROBE
+            if (gp_tr2) {
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tB_));
+                if (lane == 0 && kt < GP_TR2_IT) {
+                    long long *d = gp_tr2 + (((long long)blockIdx.x * 16 + wave) * (GP_TR2_IT + 1) + kt) * 2;
+                    d[0] = (long long)tA_;
+                    d[1] = (long long)tB_;
+                }
+            }
+#endif
+            if (!(GP_EXP & 64) && more1) fragload(cur ^ 1, 0, 0);
+            if (!(GP_EXP & 32) && more2) gload(kt + 2);
+            GP_SB(); if (!(GP_EXP & 128)) mma((NSUB - 1) & 1); GP_SB();
             cur ^= 1;
         }
     }
+    GP_STAMP(2);
     epilogue(m0, n0);
+    GP_STAMP(3);
 #undef GP_SB
+#ifdef GP_CLOCKPROBE
+    if (blockIdx.x == 0 && tid == 0) { gp_clk[0] = clock64() - c0_; gp_clk[1] = wall_clock64() - w0_; }
+    if (gp_tr2 && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        gp_tr2[(((long long)blockIdx.x * 16 + wave) * (GP_TR2_IT + 1) + GP_TR2_IT) * 2] = (long long)hw | ((long long)(xcc & 0xf) << 32);
+    }
+    if (gp_trace && tid == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        gp_trace[(long long)blockIdx.x * 8 + 4] = (long long)hw | ((long long)(xcc & 0xf) << 32);
+    }
+#endif
 }
 
 template <int WGM, int WGN, int TM, int TN, int BK, int EPI, int NBUF = 2>

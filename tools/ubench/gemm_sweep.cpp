@@ -10,6 +10,8 @@
 #include <vector>
 
 #define GP_CLOCKPROBE 1
+#include "gemm_pipe_exp.hpp"      // instrumented copies; they shadow the product headers through their include guards
+#include "gemm_bf16_exp.hpp"
 #include "../../parakeet.cpp_amd/csrc/kernels/gemm.hip"
 #include "gemm_dma.hpp"
 #include "gemm_pd.hpp"
