@@ -137,6 +137,12 @@ pk_status pk_ctc_decode(pk_model *m, const float *enc, int B, int T, int32_t *id
 pk_status pk_tdt_decode(pk_model *m, const float *enc, int B, int T, int max_tokens, int32_t *ids, int32_t *lens,
                         int32_t *start, int32_t *end, float *conf, int32_t *steps);
 
+/* Early warning of the tolerance-class (bf16) mode, SURVEY.md 8(c): per utterance of the LAST pk_tdt_decode on this model, the smallest
+ * (top-1 minus top-2) label log-prob over all of its greedy decisions (tdt.cpp:78-82 takes the argmax; this is how close it came to
+ * another token).  A margin below the mode's numerical error marks a token that may differ from the reference.  Not produced for
+ * boosted or streaming decodes. */
+pk_status pk_decode_margins(pk_model *m, float *min_margin, int B);
+
 /* ---- resident batch pipeline (device buffers; what bench.py times) ---------------------------------------- */
 typedef struct pk_batch pk_batch;
 enum { PK_DECODER_CTC = 0, PK_DECODER_TDT = 1 }; /* enum class Decoder (transcribe.hpp:34) */
@@ -171,6 +177,8 @@ pk_status pk_batch_set_decode_group(pk_batch *b, int group);
  * runs held in group buffers: read them first. */
 pk_status pk_batch_results_back(pk_batch *b, int back, int *n_clips, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
 int pk_batch_results_available(const pk_batch *b);
+/* pk_decode_margins for the (back+1)-th newest finished run of the pipeline: min_margin[n_clips of that run]. */
+pk_status pk_batch_margins(pk_batch *b, int back, float *min_margin);
 /* Stage timers of the last pk_batch_run_timed (ms): mel, encoder, decode, total (hipEvents on the batch stream). */
 pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]);
 /* Raw device pointers for zero-copy producers (e.g. torch tensors): PCM [max_clips][n_samples] f32. */

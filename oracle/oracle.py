@@ -266,12 +266,23 @@ class Model:
         self._chk(lib().orc_ctc_logprobs(self._h, _f(enc), B, T, _f(lp)))
         return lp
 
-    def tdt_greedy(self, enc, max_tokens=None, max_steps=0, first_logp=False):
+    def tdt_greedy(self, enc, max_tokens=None, max_steps=0, first_logp=False, margin=False):
         enc = _c(enc)
         B, T, _ = enc.shape
         mt = max_tokens or (T * self.cfg.max_symbols_per_step)
         ids = np.zeros((B, mt), np.int32); st = np.zeros((B, mt), np.int32); en = np.zeros((B, mt), np.int32)
         cf = np.zeros((B, mt), np.float32); lens = np.zeros(B, np.int32); steps = np.zeros(B, np.int32)
+        if margin:                              # per-utterance smallest top-1 / top-2 label log-prob margin
+            L = lib()
+            L.orc_tdt_greedy_margin.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, i32p, f32p,
+                                                f32p, i32p, C.c_int]
+            mg = np.zeros(B, np.float32)
+            cap = T * (self.cfg.max_symbols_per_step + 1) + 16
+            smg = np.zeros((B, cap), np.float32); slab = np.full((B, cap), -1, np.int32)
+            r = self._chk(L.orc_tdt_greedy_margin(self._h, _f(enc), B, T, mt, max_steps, _i(ids), _i(lens), _i(st), _i(en), _f(cf), _i(steps), _f(mg),
+                                                  _f(smg), _i(slab), cap))
+            return dict(ids=ids, lens=lens, start=st, end=en, conf=cf, steps=steps, overflow=bool(r), min_margin=mg, step_margin=smg,
+                        step_label=slab)
         fl = np.zeros((B, self.cfg.vocab_size), np.float32) if first_logp else None
         r = self._chk(lib().orc_tdt_greedy(self._h, _f(enc), B, T, mt, max_steps, _i(ids), _i(lens), _i(st), _i(en),
                                            _f(cf), _i(steps), _f(fl) if first_logp else None))

@@ -1312,7 +1312,10 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
                          float *first_label_logp /* optional [B][V]: label log-probs of the first joint call */,
                          float *state_hc /* optional [B][2][L][Hp] carried LSTM state (in/out); NULL: zeros */,
                          int32_t *state_token /* optional [B] carried last token (in/out); NULL: blank */, int clamp_end,
-                         const orc_trie *trie /* optional phrase-boost trie (src/phrase_boost.cpp:177-350) */, float boost) {
+                         const orc_trie *trie /* optional phrase-boost trie (src/phrase_boost.cpp:177-350) */, float boost,
+                         float *min_margin /* optional [B]: smallest top-1 minus top-2 label log-prob over the utterance's decisions */,
+                         float *step_margin /* optional [B][step_cap]: that margin of EVERY decision (joint evaluation), in order */,
+                         int32_t *step_label /* optional [B][step_cap]: the label each decision chose (blank included) */, int step_cap) {
     const orc_config *c = &m->cfg;
     dec_weights w;
     if (dec_weights_get(m, &w, 0)) return -1;
@@ -1335,6 +1338,7 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
         trie_active act;
         act.n = 1; act.s[0] = 0;
         int token = state_token ? state_token[b] : c->blank_id, t = 0, n = 0, nsteps = 0, bad = 0;
+        float margin = HUGE_VALF;
         while (t < T && !bad) {
             const float *ept = ep + ((int64_t)b * T + t) * J;
             for (int sym = 0; sym < c->max_symbols; ++sym) {
@@ -1357,6 +1361,14 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
                     trie_mark(trie, &act, flag, V, 0);
                 } else {
                     k = argmax_first(lab_lp, V);                           /* :78-82 */
+                    if (min_margin) {                                      /* how close the decision was to flipping */
+                        float second = -HUGE_VALF;
+                        for (int i = 0; i < V; ++i) if (i != k && lab_lp[i] > second) second = lab_lp[i];
+                        const float mg = lab_lp[k] - second;
+                        if (mg < margin) margin = mg;
+                        if (step_margin && nsteps - 1 < step_cap) step_margin[(int64_t)b * step_cap + nsteps - 1] = mg;
+                        if (step_label && nsteps - 1 < step_cap) step_label[(int64_t)b * step_cap + nsteps - 1] = k;
+                    }
                 }
                 const int di = argmax_first(dur_lp, D);
                 const int skip = di < D ? c->durations[di] : 1;            /* :84-86 */
@@ -1384,6 +1396,7 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
         }
         lens[b] = bad ? -1 : (n < max_tokens ? n : max_tokens);
         if (steps) steps[b] = nsteps;
+        if (min_margin) min_margin[b] = margin;
         overflow |= bad;
         if (state_hc) memcpy(state_hc + (int64_t)b * 2 * w.L * Hp, h, (size_t)w.L * Hp * 2 * sizeof(float));
         if (state_token) state_token[b] = token;
@@ -1395,12 +1408,19 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
 }
 int orc_tdt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, int32_t *ids,
                    int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps, float *first_label_logp) {
-    return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, first_label_logp, NULL, NULL, 1, NULL, 0.0f);
+    return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, first_label_logp, NULL, NULL, 1, NULL, 0.0f, NULL, NULL, NULL, 0);
+}
+/* the same decode, also reporting per utterance the smallest top-1 / top-2 label log-prob margin of its decisions */
+int orc_tdt_greedy_margin(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, int32_t *ids,
+                          int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps, float *min_margin,
+                          float *step_margin, int32_t *step_label, int step_cap) {
+    return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, NULL, NULL, NULL, 1, NULL, 0.0f, min_margin,
+                         step_margin, step_label, step_cap);
 }
 /* tdt_greedy_decode(_with_timestamps)_boosted -- src/phrase_boost.cpp:177-350 (confidence = exp of the unboosted log-prob, :313-315) */
 int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
                            int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps) {
-    return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, NULL, NULL, NULL, 1, trie, boost);
+    return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, NULL, NULL, NULL, 1, trie, boost, NULL, NULL, NULL, 0);
 }
 
 /* rnnt_greedy_decode(+_with_timestamps): src/rnnt.cpp:56-111, :115-177 ; RNNTJoint::forward :37-44 */
@@ -1704,7 +1724,7 @@ int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc,
 int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf) {
     int32_t len = 0, steps = 0;
     const int cap = c * (s->m->cfg.max_symbols + 1) + 16;
-    const int r = tdt_greedy_ex(s->m, enc, 1, c, max_tokens, cap, ids, &len, start, end, conf, &steps, NULL, s->hc, &s->token, 0, NULL, 0.0f);
+    const int r = tdt_greedy_ex(s->m, enc, 1, c, max_tokens, cap, ids, &len, start, end, conf, &steps, NULL, s->hc, &s->token, 0, NULL, 0.0f, NULL, NULL, NULL, 0);
     if (r || len < 0) return orc_fail("orc_stream_decode: decode cap hit");
     for (int i = 0; i < len; ++i) { if (start) start[i] += s->frame_offset; if (end) end[i] += s->frame_offset; }
     s->frame_offset += c;

@@ -93,6 +93,12 @@ int orc_trie_boosted_tokens(const orc_trie *t, const int32_t *states, int n, uns
 int orc_trie_advance(const orc_trie *t, const int32_t *states, int n, int tok, int32_t *out);                /* -> count */
 void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id, const orc_trie *trie, float boost, int32_t *ids,
                             int32_t *lens, int32_t *start, int32_t *end, float *conf);
+/* orc_tdt_greedy + per utterance the smallest (top-1 minus top-2) label log-prob over all of its decisions: the early warning of the
+ * tolerance-class (bf16) mode -- a margin below the mode's error is a token that may flip */
+int orc_tdt_greedy_margin(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, int32_t *ids,
+                          int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps, float *min_margin,
+                          float *step_margin /* optional [B][step_cap]: the margin of every decision in order */,
+                          int32_t *step_label /* optional [B][step_cap]: the label every decision chose, blank included */, int step_cap);
 int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
                            int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps);
 

@@ -1,0 +1,35 @@
+"""TEST INFRASTRUCTURE (like everything under oracle/): the token-level statement of the tolerance-class (bf16) mode.
+
+A greedy TDT decode is a chain of argmax decisions; under a numerical error of size eps a decision whose top-1 / top-2 margin is below eps may
+legitimately go the other way, and everything after it follows a different path.  So two correct implementations of the tolerance-class
+mode satisfy:  walking the reference decode's decisions in order, the other decode's tokens leave it only at a decision whose margin is
+within the mode's error -- every token before the first such near-tie is identical.  first_divergence() evaluates that against the
+per-decision labels and margins the oracle records (oracle.Model.tdt_greedy(margin=True); tests/golden/tdt600m_depth24_seed42.npz)."""
+import numpy as np
+
+
+def first_divergence(got, oracle_labels, oracle_margins, blank):
+    """got: the token ids under test.  oracle_labels / oracle_margins: label chosen (blank included, -1 = unused slot) and top-1 / top-2
+    log-prob margin of every decision of the oracle's decode, in order.  Returns (None, None) when the token sequences are identical, else
+    (index of the first differing token, smallest oracle margin among the decisions after the last agreed token up to and including the
+    oracle's next token -- the decisions at which the two decodes can have parted)."""
+    want = [int(k) for k in oracle_labels if k >= 0 and k != blank]
+    got = [int(k) for k in got]
+    n_same = 0
+    while n_same < min(len(got), len(want)) and got[n_same] == want[n_same]:
+        n_same += 1
+    if n_same == len(got) == len(want):
+        return None, None
+    seen, lo, hi = 0, 0, len(oracle_labels)
+    for s, k in enumerate(oracle_labels):
+        if k < 0:
+            hi = s
+            break
+        if k != blank:
+            seen += 1
+            if seen == n_same:
+                lo = s + 1
+            if seen == n_same + 1:
+                hi = s + 1
+                break
+    return n_same, (float(np.min(oracle_margins[lo:hi])) if hi > lo else float("inf"))

@@ -128,6 +128,8 @@ _LATE_SIGNATURES = {
     "pk_batch_results_available": [C.c_void_p],
     "pk_batch_set_decode_group": [C.c_void_p, C.c_int],
     "pk_batch_sync": [C.c_void_p],
+    "pk_batch_margins": [C.c_void_p, C.c_int, f32p],
+    "pk_decode_margins": [C.c_void_p, f32p, C.c_int],
     "pk_batch_max_tokens": [C.c_void_p],
     "pk_batch_results": [C.c_void_p, i32p, i32p, i32p, i32p, f32p],
     "pk_batch_run_timed": [C.c_void_p, C.c_int, f32p],
@@ -487,6 +489,12 @@ class Batch:
         B = n.value
         return dict(ids=ids[:B], lens=lens[:B], start=st[:B], end=en[:B], conf=cf[:B])
 
+    def margins(self, back=0, n_clips=None):
+        """pk_batch_margins: smallest top-1 / top-2 label log-prob margin of every clip of the (back+1)-th newest finished run."""
+        mg = np.zeros(self._cap, np.float32)
+        check(lib().pk_batch_margins(self._h, int(back), _f(mg)))
+        return mg[: (n_clips if n_clips is not None else self._cap)]
+
     def results_done(self):
         """Results of the newest batch whose decode has finished (run k's decode completes inside run k+1); no flush."""
         mt = lib().pk_batch_max_tokens(self._h)
@@ -702,4 +710,9 @@ class Model:
         ids = np.zeros((B, mt), np.int32); st = np.zeros((B, mt), np.int32); en = np.zeros((B, mt), np.int32)
         cf = np.zeros((B, mt), np.float32); lens = np.zeros(B, np.int32); steps = np.zeros(B, np.int32)
         check(lib().pk_tdt_decode(self._h, _f(enc), B, T, mt, _i(ids), _i(lens), _i(st), _i(en), _f(cf), _i(steps)))
-        return dict(ids=ids, lens=lens, start=st, end=en, conf=cf, steps=steps)
+        r = dict(ids=ids, lens=lens, start=st, end=en, conf=cf, steps=steps)
+        if not getattr(self, "_boosted", False):
+            mg = np.zeros(B, np.float32)
+            if lib().pk_decode_margins(self._h, _f(mg), B) == 0:
+                r["min_margin"] = mg                         # smallest top-1 / top-2 label log-prob margin per utterance
+        return r

@@ -291,6 +291,17 @@ pk_status pk_tdt_decode(pk_model *h, const float *enc, int B, int T, int max_tok
 }
 
 
+pk_status pk_decode_margins(pk_model *h, float *min_margin, int B) {
+    return guard([&] {
+        need(h && min_margin && B > 0, "model/min_margin/B");
+        Model &m = *h->m;
+        m.require_gpu();
+        need(B <= m.ws.B && m.ws.margin.p, "B exceeds the last pk_tdt_decode call");
+        need(!m.boost_on, "margins are reported for unboosted decodes");
+        PK_HIP(hipMemcpy(min_margin, m.ws.margin.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 /* ---- resident batch pipeline ---------------------------------------------------------------------------- */
 // Two workspaces + two streams: the latency-bound decode loop of batch k (high-priority stream, a few small kernels
 // per step) runs concurrently with the MFMA-bound mel + encoder of batch k+1 (main stream).  pk_batch_run(k) enqueues
@@ -599,6 +610,18 @@ pk_status pk_batch_results_back(pk_batch *b, int back, int *n_clips, int32_t *id
         PK_HIP(hipEventSynchronize(L.ev));
         if (n_clips) *n_clips = L.clips;
         copy_results(L, ids, lens, start, end, conf);
+    });
+}
+
+pk_status pk_batch_margins(pk_batch *b, int back, float *min_margin) {
+    return guard([&] {
+        need(b && min_margin, "batch/min_margin");
+        b->m->require_gpu();
+        need(back >= 0 && back < (int)b->done.size(), "back: 0 <= back < pk_batch_results_available()");
+        const pk_batch::Loc &L = b->done[b->done.size() - 1 - (size_t)back];
+        need(L.decoder == PK_DECODER_TDT && !b->m->boost_on, "margins are reported for unboosted TDT / RNNT decodes");
+        PK_HIP(hipEventSynchronize(L.ev));
+        PK_HIP(hipMemcpy(min_margin, L.w->margin.as<float>() + L.row0, (size_t)L.clips * 4, hipMemcpyDeviceToHost));
     });
 }
 

@@ -447,6 +447,7 @@ void Workspace::reserve_decode(const pk_config &c) {
     const size_t tok = (size_t)B * max_tokens;
     ids.reserve(tok * sizeof(int)); start.reserve(tok * sizeof(int)); end.reserve(tok * sizeof(int)); conf.reserve(tok * f);
     lens.reserve((size_t)B * sizeof(int));
+    margin.reserve((size_t)B * f);
 }
 
 // decode-only workspace (no encoder buffers): the lock-step TDT state of a GROUP of pipelined batches (capi.cpp)
@@ -709,6 +710,7 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     st.done_count = ib + 6 * B;
     st.lens = w.lens.as<int>();
     st.ids = w.ids.as<int>(); st.start = w.start.as<int>(); st.end = w.end.as<int>(); st.conf = w.conf.as<float>();
+    st.margin = (boost_on || keep_state) ? nullptr : w.margin.as<float>();
     if (!keep_state) {                                               // a streaming chunk continues from the carried LSTM state
         PK_HIP(hipMemsetAsync(w.h.p, 0, (size_t)L * B * Hp * 4, s));
         PK_HIP(hipMemsetAsync(w.c.p, 0, (size_t)L * B * Hp * 4, s));

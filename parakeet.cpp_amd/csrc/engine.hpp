@@ -49,7 +49,7 @@ struct Workspace {
     int B = 0; int64_t n_samples = 0; int Tm = 0, T = 0, max_tokens = 0;
     DevBuf pcm, logmel, feats, a2, a3, a4, a5, flat, x, n, hbuf, qkv, ctx, g, dwb;
     DevBuf ctc_logits, ctc_lp, best_idx, best_lp;
-    DevBuf ep, gh, gi, pp, z, logits, h, c, hn, cn, ints, ids, start, end, conf, lens;
+    DevBuf ep, gh, gi, pp, z, logits, h, c, hn, cn, ints, ids, start, end, conf, lens, margin;
     DevBuf trie_act;            // phrase boosting: per-utterance active trie states [B][kTrieMaxActive] + counts [B]
     // captured chunk of decode steps (Model::run_tdt): replayed while the step-invariant kernel arguments stay the same
     hipGraphExec_t dec_graph = nullptr;

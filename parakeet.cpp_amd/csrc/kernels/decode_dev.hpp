@@ -304,26 +304,43 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     __syncthreads();
     const float lse = red[4];
     float best = -__builtin_huge_valf();
+    // `second` = the largest label log-prob that is NOT the winner's (ties with the winner count: margin 0).  It only feeds the optional
+    // top-1 / top-2 margin report (st.margin); the decision itself is the first-maximum argmax exactly as before.
+    float second = -__builtin_huge_valf();
     int bi = 0x7fffffff;
     for (int i = tid; i < st.V; i += 256) {
         float l = (x[i] - m) - lse;
         if constexpr (BOOST) l = l + (((mask[i >> 5] >> (i & 31)) & 1u) ? st.trie.boost : 0.0f);
-        if (bi == 0x7fffffff || l > best) { best = l; bi = i; }
+        if (bi == 0x7fffffff || l > best) { second = best; best = l; bi = i; }
+        else second = fmaxf(second, l);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const float ob = __shfl_xor(best, off, 64);
         const int oi = __shfl_xor(bi, off, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        const float os = __shfl_xor(second, off, 64);
+        const bool take = ob > best || (ob == best && oi < bi);
+        second = fmaxf(fmaxf(second, os), (oi == bi) ? -__builtin_huge_valf() : (take ? best : ob));   // the loser's maximum joins the rest
+        if (take) { best = ob; bi = oi; }
     }
-    if (lane == 0) { red[8 + wave] = best; red[12 + wave] = __int_as_float(bi); }
+    if (lane == 0) { red[8 + wave] = best; red[12 + wave] = __int_as_float(bi); red[wave] = second; }   // (red[0..3]: the wave maxima were consumed two barriers ago)
     __syncthreads();
     BestLP lab{red[8], __float_as_int(red[12])};
+    float sec = red[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
         const float ob = red[8 + w];
         const int oi = __float_as_int(red[12 + w]);
-        if (ob > lab.lp || (ob == lab.lp && oi < lab.idx)) { lab.lp = ob; lab.idx = oi; }
+        const bool take = ob > lab.lp || (ob == lab.lp && oi < lab.idx);
+        sec = fmaxf(fmaxf(sec, red[w]), (oi == lab.idx) ? -__builtin_huge_valf() : (take ? lab.lp : ob));
+        if (take) { lab.lp = ob; lab.idx = oi; }
+    }
+    if constexpr (!BOOST) {
+        if (st.margin && tid == 0) {                               // running minimum over the utterance's decisions (SURVEY 8c early warning)
+            const float mg = lab.lp - sec;
+            const float old = dd_ldf<COH>(st.margin + b);
+            dd_stf<COH>(st.margin + b, mg < old ? mg : old);
+        }
     }
     if constexpr (BOOST) lab.lp = (x[lab.idx] - m) - lse;          // the confidence is the UNBOOSTED log-prob (phrase_boost.cpp:313-315)
     if (st.D > 0) skip = (int)red[5];

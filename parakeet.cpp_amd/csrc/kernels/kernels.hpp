@@ -134,6 +134,7 @@ struct TdtState {
     int *token, *t, *nsym, *n_out, *steps, *done, *lens, *done_count;
     int *ids, *start, *end;         // [B][max_tokens]
     float *conf;
+    float *margin;                  // [B] or null: running min over the utterance's decisions of (top-1 - top-2) label log-prob
 };
 void launch_tdt_init(const TdtState &st, hipStream_t s);
 void launch_lstm_cell(const float *gi, int gi_ld, const int *gi_row, const float *gh, const float *c, int B, int Hp, float *hn,
