@@ -1056,6 +1056,11 @@ pk_status pk_group_verify_exchange(pk_group *g, const pk_result *results, int n_
             g->rccl = rccl_api(&why);
             if (!g->rccl) fail(PK_ERR_UNSUPPORTED, "RCCL is not available on this host (%s)", why.c_str());
             g->comms.assign(G, nullptr);
+            for (int r = 0; r < G; ++r) {                  // RCCL's init turns ANY pending HIP error into a failure: start from a clean slate on every device
+                PK_HIP(hipSetDevice(g->devices[r]));
+                PK_HIP(hipDeviceSynchronize());
+                (void)hipGetLastError();
+            }
             PK_NCCL(g->rccl, CommInitAll(g->comms.data(), G, g->devices.data()));
             g->streams.assign(G, nullptr);
             for (int r = 0; r < G; ++r) {

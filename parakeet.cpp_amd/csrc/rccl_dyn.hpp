@@ -22,20 +22,34 @@ struct RcclApi {
     std::string path;
 };
 
-// nullptr (and *why filled) when librccl cannot be loaded.  Search order: PK_RCCL_LIB, the loader's default path, $ROCM_PATH/lib, /opt/rocm/lib.
+// nullptr (and *why filled) when librccl cannot be loaded.  Search order: PK_RCCL_LIB; the librccl that sits NEXT TO the HIP runtime this
+// library is actually running on (dladdr of a HIP entry point) -- a process may hold several ROCm stacks (PyTorch wheels bundle their own
+// libamdhip64 / librccl), and an RCCL from another stack than the HIP runtime in use fails in ncclCommInitAll ("no ROCm-capable device");
+// a bare soname would resolve to whichever copy happens to be loaded already; then $ROCM_PATH/lib, /opt/rocm/lib, and the soname last.
 inline const RcclApi *rccl_api(std::string *why) {
     static RcclApi api;
     static bool tried = false, ok = false;
     static std::string err;
     if (!tried) {
         tried = true;
-        std::string cand[6];
+        std::string cand[8];
         int n = 0;
         if (const char *e = getenv("PK_RCCL_LIB")) cand[n++] = e;
-        cand[n++] = "librccl.so.1";
-        cand[n++] = "librccl.so";
+        {
+            Dl_info info;
+            if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+                const std::string hip = info.dli_fname;
+                const size_t slash = hip.rfind('/');
+                if (slash != std::string::npos) {
+                    cand[n++] = hip.substr(0, slash) + "/librccl.so.1";
+                    cand[n++] = hip.substr(0, slash) + "/librccl.so";
+                }
+            }
+        }
         if (const char *r = getenv("ROCM_PATH")) cand[n++] = std::string(r) + "/lib/librccl.so.1";
         cand[n++] = "/opt/rocm/lib/librccl.so.1";
+        cand[n++] = "librccl.so.1";
+        cand[n++] = "librccl.so";
         void *h = nullptr;
         for (int i = 0; i < n && !h; ++i) {
             h = dlopen(cand[i].c_str(), RTLD_NOW | RTLD_LOCAL);
