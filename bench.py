@@ -129,10 +129,11 @@ def cpu_reference(cfg, wpath, pcm_all, threads, budget_s=14.0):
     return rep, ids
 
 
+DEFAULT_OVERLAP = {}            # (config, bf16) -> pk_batch_set_decode_overlap default; filled from the measurements in DESIGN.md section 5
 MARGIN_TOL_BF16 = 2e-2          # label log-prob error class of the bf16 mode at depth 24 (tests/test_gpu_600m_depth.py states the same bound)
 
 
-def fixture_parity(args, cfg, pcm, gpu_ids):
+def fixture_parity(args, cfg, pcm, gpu_ids, gpu_frames=None):
     """Parity of a tdt-600m run against the committed full-depth fixture.  fp32: token ids identical.  bf16: the tolerance statement for
     a greedy decode -- the GPU's tokens may leave the bf16 oracle's only at a decision whose top-1 / top-2 margin is within the mode's error
     (oracle/tolerance.py).  Returns (report, failed)."""
@@ -154,7 +155,9 @@ def fixture_parity(args, cfg, pcm, gpu_ids):
         return rep, bool(bad)
     per, failed = [], False
     for b in range(n):
-        at, mg = first_divergence(gpu_ids[b], g["bf16_step_label"][b], g["bf16_step_margin"][b], cfg.blank_id)
+        at, mg = first_divergence(gpu_ids[b], g["bf16_step_label"][b], g["bf16_step_margin"][b], cfg.blank_id,
+                                  got_frames=(gpu_frames[0][b], gpu_frames[1][b]) if gpu_frames else None,
+                                  oracle_frames=(g["bf16_start"][b], g["bf16_end"][b]))
         per.append({"clip": b, "gpu_tokens": len(gpu_ids[b]), "oracle_tokens": int(g["bf16_lens"][b]), "first_differing_token": at,
                     "oracle_margin_there": (None if mg is None else round(mg, 6))})
         if at is not None and mg > MARGIN_TOL_BF16:
@@ -227,10 +230,14 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="pk_config.gemm_bf16: encoder products on bf16 operands / fp32 accumulation "
                     "(the precision BASELINE configs[2] names); the headline metric stays fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decode-group", type=int, default=int(os.environ.get("PK_BENCH_DECODE_GROUP", "4")),
-                    help="pk_batch_set_decode_group: TDT loops of this many consecutive steps decoded as one lock-step batch (1 = per step)")
+    ap.add_argument("--decode-group", type=int, default=int(os.environ.get("PK_BENCH_DECODE_GROUP", "-1")),
+                    help="pk_batch_set_decode_group: TDT loops of this many consecutive steps decoded as one lock-step batch (1 = per step); "
+                         "-1 = the configuration's default (4 for tdt-ctc-110m, 16 for tdt-600m: profiles/r03_decode_overlap_ab.txt)")
     ap.add_argument("--decode-loop", default="phases", choices=["phases", "persistent", "graph"],
                     help="pk_model_set_decode_loop: launch structure of the greedy loop (identical results)")
+    ap.add_argument("--decode-overlap", type=int, default=-1, choices=[-1, 0, 1],
+                    help="pk_batch_set_decode_overlap: 1 = decode under the next encoder on a second stream, 0 = on the encoder's stream after it; "
+                         "-1 = the configuration's default (1 for tdt-ctc-110m)")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="after the timed K steps: keep stepping in windows of K for about this long and report the median window (0 = skip)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launcher + collective plumbing over gloo without a GPU (CPU test hook)")
@@ -297,9 +304,13 @@ def main():
     pcm = synth.synth_pcm(args.batch, CLIP_SAMPLES, seed=1234 + rank)
     capi.check(L.pk_batch_upload(batch, pcm.ctypes.data_as(capi.f32p), args.batch))
     dec = 1 if args.decoder == "tdt" else 0
+    if args.decode_group < 0:
+        args.decode_group = 16 if big else 4
     group = max(1, args.decode_group) if dec == 1 else 1
     if group > 1:
         capi.check(L.pk_batch_set_decode_group(batch, group))
+    overlap = DEFAULT_OVERLAP.get((args.config, bool(args.bf16)), 1) if args.decode_overlap < 0 else args.decode_overlap
+    capi.check(L.pk_batch_set_decode_overlap(batch, overlap))
 
     for _ in range(args.warmup):
         capi.check(L.pk_batch_run(batch, dec))
@@ -382,7 +393,9 @@ def main():
     mt = L.pk_batch_max_tokens(batch)
     ids = np.zeros((args.batch, mt), np.int32)
     lens = np.zeros(args.batch, np.int32)
-    capi.check(L.pk_batch_results(batch, ids.ctypes.data_as(capi.i32p), lens.ctypes.data_as(capi.i32p), None, None, None))
+    st_fr = np.zeros((args.batch, mt), np.int32); en_fr = np.zeros((args.batch, mt), np.int32)
+    capi.check(L.pk_batch_results(batch, ids.ctypes.data_as(capi.i32p), lens.ctypes.data_as(capi.i32p), st_fr.ctypes.data_as(capi.i32p),
+                                  en_fr.ctypes.data_as(capi.i32p), None))
 
     if rank == 0:
         audio_s = args.steps * args.batch * CLIP_SECONDS * n_gpus
@@ -429,7 +442,7 @@ def main():
             "config": {"workload": f"{args.config}, batch={args.batch}x{int(CLIP_SECONDS)}s clips per GPU, {args.decoder.upper()} greedy decode{' (the loops of %d consecutive steps driven as one lock-step batch)' % group if group > 1 else ''}, {'bf16 GEMM operands / fp32 accumulate' if args.bf16 else 'fp32'} "
                                    f"(BASELINE configs[{2 if big else 1}]{' shapes; BASELINE names bf16, this run is fp32' if (big and not args.bf16) else ''})",
                        "clips_per_step_per_gpu": args.batch, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{n_gpus} (utterance shards, no data-path collective)",
-                       "decode_group": group, "decode_loop": args.decode_loop},
+                       "decode_group": group, "decode_loop": args.decode_loop, "decode_overlap": overlap},
             "ms_per_step_per_rank": [round(x / args.steps * 1e3, 3) for x in per_rank_s],
             "collective_ranks": (dist.get_world_size() if world > 1 else 1), "collective_backend": ("nccl (RCCL)" if world > 1 else None),
             "sustained": sustained,
@@ -455,7 +468,7 @@ def main():
             # fixture (tests/golden/tdt600m_depth24_seed42.npz = the oracle's and the reference code's outputs for the FIRST clips of exactly
             # this batch, tools/make_golden_600m.py) and the CPU baseline is the fp32 oracle timed live on ONE clip (~10 s of CPU work).
             try:
-                out["parity"], bad = fixture_parity(args, cfg, pcm, gpu_ids)
+                out["parity"], bad = fixture_parity(args, cfg, pcm, gpu_ids, (st_fr, en_fr))
                 if bad:
                     rc = 3
                 if W is None:

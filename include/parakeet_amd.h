@@ -138,8 +138,8 @@ pk_status pk_tdt_decode(pk_model *m, const float *enc, int B, int T, int max_tok
                         int32_t *start, int32_t *end, float *conf, int32_t *steps);
 
 /* Early warning of the tolerance-class (bf16) mode, SURVEY.md 8(c): per utterance of the LAST pk_tdt_decode on this model, the smallest
- * (top-1 minus top-2) label log-prob over all of its greedy decisions (tdt.cpp:78-82 takes the argmax; this is how close it came to
- * another token).  A margin below the mode's numerical error marks a token that may differ from the reference.  Not produced for
+ * (top-1 minus top-2) log-prob over all of its greedy decisions -- the label argmax (tdt.cpp:78-82) and, for TDT heads, the duration argmax
+ * (:84-86: a flip there moves the frame pointer and every later token with it): how close the decode came to a different path.  A margin below the mode's numerical error marks a token that may differ from the reference.  Not produced for
  * boosted or streaming decodes. */
 pk_status pk_decode_margins(pk_model *m, float *min_margin, int B);
 
@@ -168,8 +168,14 @@ pk_status pk_batch_results_done(pk_batch *b, int *n_clips, int32_t *ids, int32_t
  * G consecutive pk_batch_run calls are driven as ONE lock-step batch of G * n_clips utterances under the encoder of the run after them:
  * the loop of tdt_greedy_decode (src/tdt.cpp:62-106) is launch-bound -- four launches per symbol step whatever the batch -- so G runs
  * share them.  Token ids, frames and confidences of every run are unchanged (the utterances are independent); what changes is WHEN they
- * are available: after the G-th run of the group (+1), or at pk_batch_sync / pk_batch_results.  1 <= G <= 8; flushes the pipeline. */
+ * are available: after the G-th run of the group (+1), or at pk_batch_sync / pk_batch_results.  1 <= G <= 16; flushes the pipeline. */
 pk_status pk_batch_set_decode_group(pk_batch *b, int group);
+/* on (default): the decode loop of run k / of a finished group runs on a second, high-priority stream UNDER the encoder of the following run.
+ * off: it runs on the encoder's stream, after the encoder -- no concurrency on the device.  The decode GEMVs stream the prediction-net and
+ * joint weights through L2 once per symbol step (13 MB for tdt-ctc-110m, 42 MB for tdt-600m); for the large heads that traffic costs the
+ * concurrently running encoder GEMMs more than the loop's own duration, so serial issue can be the faster schedule.
+ * Results are identical either way.  Flushes the pipeline. */
+pk_status pk_batch_set_decode_overlap(pk_batch *b, int on);
 /* Results of the (back+1)-th newest run whose decode has finished (back = 0: the newest, = pk_batch_results_done), 0 <= back <
  * pk_batch_results_available().  A finished run stays readable until its buffers are recycled: without groups until the run after next is
  * issued, with groups of G until the first run of the group after next -- so the G runs of the newest decoded group are always there, and a

@@ -682,6 +682,18 @@ static int feed_forward(orc_model *m, int layer, const char *which, float *x, in
     return 0;
 }
 
+/* The attention of the tolerance-class mode (gemm_bf16) for head sizes 64 / 128 -- the specification kernels/attention_bf16.hip implements:
+ * q, k, v and the projected position table are rounded to bf16 (their GEMM epilogues store them so); the query tile is biased ONCE,
+ * qu = bf16(q + u); content[i][j] = qu_i . k_j; position[i][p] = qu_i . P_p + c[p] with c[p] = (v - u) . P_p in fp32 (the identity
+ * (q + v) . P = (q + u) . P + (v - u) . P keeps one biased copy); scores = (content + position) * scale; e_j = exp(score_j - max) in fp32;
+ * ctx = (sum_j bf16(e_j) v_j) / (sum_j e_j) -- the probabilities enter the product rounded, the normaliser does not -- and ctx is stored as
+ * bf16 (out_proj's operand).  Accumulation is fp32 throughout; its ORDER differs on the GPU (MFMA blocks, online softmax), which is why this
+ * mode is compared within a tolerance.  Other head sizes keep the fp32 attention on the bf16-GEMM outputs. */
+static int attn_bf16_spec(const orc_config *c) {
+    const int hd = c->d_model / c->n_heads;
+    return c->gemm_bf16 && (hd == 64 || hd == 128);
+}
+
 /* pos_proj_(pos_emb) (no bias), split by head and transposed: PT[h][k][p]  src/encoder.cpp:148-151.
  * Batch-independent (the reference recomputes it per call). */
 static float *pos_proj_heads(orc_model *m, int layer, int T, const float *pos_emb) {
@@ -691,6 +703,8 @@ static float *pos_proj_heads(orc_model *m, int layer, int T, const float *pos_em
     if (!wp) return NULL;
     float *pp = (float *)xmalloc((size_t)P * d * sizeof(float));
     linear_t(m->cfg.gemm_bf16, wp, NULL, P, pos_emb, d, pp, d, 0);
+    if (attn_bf16_spec(c))                                          /* the table is stored as bf16 (the pos_proj GEMM's epilogue rounds it) */
+        for (int64_t i = 0; i < (int64_t)P * d; ++i) pp[i] = bf16_round(pp[i]);
     float *PT = (float *)xmalloc((size_t)H * hd * P * sizeof(float));
     for (int h = 0; h < H; ++h)
         for (int kk = 0; kk < hd; ++kk)
@@ -723,6 +737,10 @@ static int attention(orc_model *m, int layer, float *x, int T, const float *PT) 
     linear_t(m->cfg.gemm_bf16, wk, bk, (int)rows, n, d, k, d, 0);
     linear_t(m->cfg.gemm_bf16, wv, bv, (int)rows, n, d, v, d, 0);
     const float scale = 1.0f / sqrtf((float)hd);                   /* :126 */
+    const int spec16 = attn_bf16_spec(c);
+    if (spec16)
+        for (int64_t i = 0; i < rows * d; ++i) { q[i] = bf16_round(q[i]); k[i] = bf16_round(k[i]); v[i] = bf16_round(v[i]); }
+    float *cvec = (float *)xmalloc((size_t)P * sizeof(float));
     float *qu = (float *)xmalloc((size_t)T * hd * sizeof(float));
     float *qv = (float *)xmalloc((size_t)T * hd * sizeof(float));
     float *KT = (float *)xmalloc((size_t)hd * T * sizeof(float));
@@ -737,28 +755,47 @@ static int attention(orc_model *m, int layer, float *x, int T, const float *PT) 
                 const float qq = q[(int64_t)i * d + h * hd + kk];
                 qu[i * hd + kk] = qq + pu->data[h * hd + kk];                    /* :141-145 */
                 qv[i * hd + kk] = qq + pv->data[h * hd + kk];
+                if (spec16) { qu[i * hd + kk] = bf16_round(qu[i * hd + kk]); qv[i * hd + kk] = qu[i * hd + kk]; }   /* one biased copy */
                 KT[(int64_t)kk * T + i] = k[(int64_t)i * d + h * hd + kk];
                 Vh[i * hd + kk] = v[(int64_t)i * d + h * hd + kk];
             }
         gemm_core(T, T, hd, qu, hd, KT, T, cs, T, 0);                             /* content :145 */
         gemm_core(T, P, hd, qv, hd, PT + (int64_t)h * hd * P, P, ps, P, 0);       /* pos :154 */
+        if (spec16) {                                                             /* c[p] = (v - u) . P_p, natural k, explicit fma */
+            const float *Ph = PT + (int64_t)h * hd * P;
+            for (int p = 0; p < P; ++p) {
+                float acc = 0.0f;
+                for (int kk = 0; kk < hd; ++kk) acc = fmaf(pv->data[h * hd + kk] - pu->data[h * hd + kk], Ph[(int64_t)kk * P + p], acc);
+                cvec[p] = acc;
+            }
+        }
+        float *rsum = spec16 ? (float *)xmalloc((size_t)T * sizeof(float)) : NULL;
         for (int i = 0; i < T; ++i) {
             float *row = pr + (int64_t)i * T;
             float mx = -INFINITY;
             for (int j = 0; j < T; ++j) {
-                const float s = (cs[(int64_t)i * T + j] + ps[(int64_t)i * P + (j - i + T - 1)]) * scale; /* :157-160 */
+                const int p = j - i + T - 1;
+                const float pos = spec16 ? ps[(int64_t)i * P + p] + cvec[p] : ps[(int64_t)i * P + p];
+                const float s = (cs[(int64_t)i * T + j] + pos) * scale;            /* :157-160 */
                 row[j] = s;
                 mx = s > mx ? s : mx;
             }
             for (int j = 0; j < T; ++j) row[j] = orc_expf(row[j] - mx);            /* softmax :168 */
             const float sum = orc_sum64(row, T, 1);
-            for (int j = 0; j < T; ++j) row[j] = row[j] / sum;
+            if (spec16) {
+                rsum[i] = sum;
+                for (int j = 0; j < T; ++j) row[j] = bf16_round(row[j]);
+            } else {
+                for (int j = 0; j < T; ++j) row[j] = row[j] / sum;
+            }
         }
         gemm_core(T, hd, T, pr, T, Vh, hd, oh, hd, 0);                            /* :171 */
         for (int i = 0; i < T; ++i)
-            for (int kk = 0; kk < hd; ++kk) ctx[(int64_t)i * d + h * hd + kk] = oh[i * hd + kk];
+            for (int kk = 0; kk < hd; ++kk)
+                ctx[(int64_t)i * d + h * hd + kk] = spec16 ? bf16_round(oh[i * hd + kk] / rsum[i]) : oh[i * hd + kk];
+        free(rsum);
     }
-    free(qu); free(qv); free(KT); free(Vh); free(cs); free(ps); free(pr); free(oh);
+    free(qu); free(qv); free(KT); free(Vh); free(cs); free(ps); free(pr); free(oh); free(cvec);
     linear_t(m->cfg.gemm_bf16, wo, bo, (int)rows, ctx, d, y, d, 0);                  /* :177 */
     for (int64_t i = 0; i < rows * d; ++i) x[i] = x[i] + y[i];     /* :185 */
     free(n); free(q); free(k); free(v); free(ctx); free(y);
@@ -1313,7 +1350,7 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
                          float *state_hc /* optional [B][2][L][Hp] carried LSTM state (in/out); NULL: zeros */,
                          int32_t *state_token /* optional [B] carried last token (in/out); NULL: blank */, int clamp_end,
                          const orc_trie *trie /* optional phrase-boost trie (src/phrase_boost.cpp:177-350) */, float boost,
-                         float *min_margin /* optional [B]: smallest top-1 minus top-2 label log-prob over the utterance's decisions */,
+                         float *min_margin /* optional [B]: smallest top-1 minus top-2 log-prob (label head and, for TDT, duration head) over the utterance's decisions */,
                          float *step_margin /* optional [B][step_cap]: that margin of EVERY decision (joint evaluation), in order */,
                          int32_t *step_label /* optional [B][step_cap]: the label each decision chose (blank included) */, int step_cap) {
     const orc_config *c = &m->cfg;
@@ -1364,7 +1401,14 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
                     if (min_margin) {                                      /* how close the decision was to flipping */
                         float second = -HUGE_VALF;
                         for (int i = 0; i < V; ++i) if (i != k && lab_lp[i] > second) second = lab_lp[i];
-                        const float mg = lab_lp[k] - second;
+                        float mg = lab_lp[k] - second;
+                        if (D > 1) {                                       /* the duration argmax is a decision too: a flip there moves the frame pointer */
+                            const int dbest = argmax_first(dur_lp, D);
+                            float dsecond = -HUGE_VALF;
+                            for (int i = 0; i < D; ++i) if (i != dbest && dur_lp[i] > dsecond) dsecond = dur_lp[i];
+                            const float dmg = dur_lp[dbest] - dsecond;
+                            if (dmg < mg) mg = dmg;
+                        }
                         if (mg < margin) margin = mg;
                         if (step_margin && nsteps - 1 < step_cap) step_margin[(int64_t)b * step_cap + nsteps - 1] = mg;
                         if (step_label && nsteps - 1 < step_cap) step_label[(int64_t)b * step_cap + nsteps - 1] = k;

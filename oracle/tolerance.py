@@ -8,15 +8,26 @@ per-decision labels and margins the oracle records (oracle.Model.tdt_greedy(marg
 import numpy as np
 
 
-def first_divergence(got, oracle_labels, oracle_margins, blank):
-    """got: the token ids under test.  oracle_labels / oracle_margins: label chosen (blank included, -1 = unused slot) and top-1 / top-2
-    log-prob margin of every decision of the oracle's decode, in order.  Returns (None, None) when the token sequences are identical, else
-    (index of the first differing token, smallest oracle margin among the decisions after the last agreed token up to and including the
-    oracle's next token -- the decisions at which the two decodes can have parted)."""
+def first_divergence(got, oracle_labels, oracle_margins, blank, got_frames=None, oracle_frames=None):
+    """got: the token ids under test.  oracle_labels / oracle_margins: label chosen (blank included, -1 = unused slot) and the smallest
+    top-1 / top-2 log-prob margin (label head, duration head) of every decision of the oracle's decode, in order.
+    got_frames / oracle_frames (optional): (start, end) frame arrays of the tokens -- with them a token only counts as agreed when its id, its
+    start frame AND its end frame agree, so a flipped DURATION decision (also of a blank step: it moves the frame pointer while the next ids may
+    still coincide for a while) is located where it happened and not where the ids finally part.
+    Returns (None, None) when the sequences are identical, else (index of the first differing token, smallest oracle margin among the
+    decisions after the last agreed token's step up to and including the oracle's next token -- where the two decodes can have parted)."""
     want = [int(k) for k in oracle_labels if k >= 0 and k != blank]
     got = [int(k) for k in got]
+
+    def same(i):
+        if got[i] != want[i]:
+            return False
+        if got_frames is not None and oracle_frames is not None:
+            return int(got_frames[0][i]) == int(oracle_frames[0][i]) and int(got_frames[1][i]) == int(oracle_frames[1][i])
+        return True
+
     n_same = 0
-    while n_same < min(len(got), len(want)) and got[n_same] == want[n_same]:
+    while n_same < min(len(got), len(want)) and same(n_same):
         n_same += 1
     if n_same == len(got) == len(want):
         return None, None

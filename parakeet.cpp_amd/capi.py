@@ -128,6 +128,7 @@ _LATE_SIGNATURES = {
     "pk_batch_results_available": [C.c_void_p],
     "pk_batch_set_decode_group": [C.c_void_p, C.c_int],
     "pk_batch_sync": [C.c_void_p],
+    "pk_batch_set_decode_overlap": [C.c_void_p, C.c_int],
     "pk_batch_margins": [C.c_void_p, C.c_int, f32p],
     "pk_decode_margins": [C.c_void_p, f32p, C.c_int],
     "pk_batch_max_tokens": [C.c_void_p],
@@ -471,6 +472,10 @@ class Batch:
     def set_decode_group(self, group):
         """Throughput mode: the TDT loops of `group` consecutive runs are decoded as one lock-step batch (results unchanged, later)."""
         check(lib().pk_batch_set_decode_group(self._h, int(group)))
+
+    def set_decode_overlap(self, on):
+        """on: decode on a second stream under the next encoder (default); off: on the encoder's stream, after it.  Same results."""
+        check(lib().pk_batch_set_decode_overlap(self._h, int(bool(on))))
 
     def sync(self):
         check(lib().pk_batch_sync(self._h))

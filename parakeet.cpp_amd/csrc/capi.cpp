@@ -334,6 +334,8 @@ struct pk_batch {
     // grp[fill].ep on the ENCODER stream right after encoder(k) (the encoder workspaces are then free again); a full group is decoded
     // under the encoder of the run after it.  Results of run k are available once its group is decoded (pk_batch_results_back).
     int group = 1;
+    bool overlap = true;        // pk_batch_set_decode_overlap: false = the decode loop runs on the encoder's stream, after it
+    hipStream_t dec_stream() const { return overlap ? m->stream_dec : m->stream; }
     struct Member { int clips, row0; int64_t seq; };
     struct Group {
         Workspace w;                    // decode state of group * max_clips utterances
@@ -396,8 +398,8 @@ static void batch_decode(pk_batch *b, int slot, int decoder, hipStream_t s) {
 static void group_drive(pk_batch *b, int gi) {
     Model &m = *b->m;
     auto &G = b->grp[gi];
-    hipStream_t s = m.stream_dec;
-    PK_HIP(hipStreamWaitEvent(s, G.ep_done, 0));
+    hipStream_t s = b->dec_stream();
+    if (s != m.stream) PK_HIP(hipStreamWaitEvent(s, G.ep_done, 0));
     m.run_tdt_loop(G.w, G.rows, G.w.T, G.w.max_tokens, s);
     PK_HIP(hipEventRecord(G.dec_done, s));
     G.decoded = true;
@@ -420,7 +422,7 @@ static void batch_flush(pk_batch *b) {
     if (b->pending_slot >= 0) {
         const int slot = b->pending_slot, dec = b->pending_decoder;
         b->pending_slot = -1;
-        batch_decode(b, slot, dec, b->m->stream_dec);
+        batch_decode(b, slot, dec, b->dec_stream());
     }
     if (b->ready >= 0) { const int r = b->ready; b->ready = -1; group_drive(b, r); }
     if (b->group > 1 && !b->grp[b->fill].mem.empty()) {      // a partial group: decode what there is
@@ -445,7 +447,7 @@ static void batch_run(pk_batch *b, int decoder) {
     if (b->pending_slot >= 0) {                              // ... then the host drives decode(k-1) while it runs
         const int ps = b->pending_slot, pd = b->pending_decoder;
         b->pending_slot = -1;
-        batch_decode(b, ps, pd, m.stream_dec);
+        batch_decode(b, ps, pd, b->dec_stream());
     }
     if (grouped) {
         auto &G = b->grp[b->fill];
@@ -632,7 +634,7 @@ pk_status pk_batch_results_done(pk_batch *b, int *n_clips, int32_t *ids, int32_t
 int pk_batch_results_available(const pk_batch *b) { return b ? (int)b->done.size() : 0; }
 
 static void batch_set_group(pk_batch *b, int group) {
-    need(group >= 1 && group <= 8, "decode group: 1 .. 8 runs");
+    need(group >= 1 && group <= 16, "decode group: 1 .. 16 runs");
     Model &m = *b->m;
     m.require_gpu();
     batch_flush(b);
@@ -651,6 +653,15 @@ static void batch_set_group(pk_batch *b, int group) {
     b->fill = 0;
     b->ready = -1;
     b->group = group;
+}
+
+pk_status pk_batch_set_decode_overlap(pk_batch *b, int on) {
+    return guard([&] {
+        need(b, "batch");
+        b->m->require_gpu();
+        batch_flush(b);
+        b->overlap = on != 0;
+    });
 }
 
 pk_status pk_batch_set_decode_group(pk_batch *b, int group) {

@@ -354,6 +354,9 @@ void Model::to_gpu(int device) {
         }
 #endif
         (void)lo;
+#ifdef PK_EXPERIMENTAL
+        if (const char *e = getenv("PK_DEC_NT")) dec_nt_weights = atoi(e);
+#endif
         PK_HIP(hipStreamCreateWithPriority(&stream_dec, hipStreamNonBlocking, prio));
     }
     PK_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_done), sizeof(int), hipHostMallocDefault));
@@ -466,6 +469,12 @@ void Model::run_mel(const float *d_pcm, int B, int64_t n_samples, float *d_logme
 
 // sinusoidal_position_embedding (src/encoder.cpp:9-30): float math on the host, exactly as the reference does,
 // then pos_proj_ of every layer (src/encoder.cpp:148) -- batch-independent, so computed once per sequence length.
+bool Model::attn_bf16(int T) const {
+    if (!cfg.gemm_bf16) return false;
+    const size_t lds = relpos_attention_bf16_lds_bytes(T, cfg.hidden_size / cfg.num_heads);
+    return lds > 0 && lds <= (size_t)150 * 1024;
+}
+
 void Model::ensure_pos_tables(int T, hipStream_t s) {
     if (T == pos_T) return;
     const int d = cfg.hidden_size, P = 2 * T - 1;
@@ -482,6 +491,20 @@ void Model::ensure_pos_tables(int T, hipStream_t s) {
     pos_pe.reserve(pe.size() * 4);
     pos_proj.reserve((size_t)cfg.num_layers * P * d * 4);
     PK_HIP(hipMemcpy(pos_pe.p, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+    if (attn_bf16(T)) {
+        // tolerance-class mode: the table as bf16, natural columns (attention_bf16.hip), plus c[l][h][p] = (v_h - u_h) . P_p
+        const int H = cfg.num_heads;
+        pos_cvec.reserve((size_t)cfg.num_layers * H * P * 4);
+        for (int l = 0; l < cfg.num_layers; ++l) {
+            __bf16 *tab = reinterpret_cast<__bf16 *>(pos_proj.p) + (size_t)l * P * d;
+            GemmArgs g{pos_pe.as<float>(), d, layers[l].wpos, d, nullptr, reinterpret_cast<float *>(tab), d, nullptr, 0, 1.0f, P, d, d};
+            g.out_bf16 = 1;
+            run_gemm("pos_proj", g, EPI_NONE, s);
+            launch_pos_cvec(tab, layers[l].pos_u, layers[l].pos_v, P, d, H, pos_cvec.as<float>() + (size_t)l * H * P, s);
+        }
+        pos_T = T;
+        return;
+    }
     for (int l = 0; l < cfg.num_layers; ++l) {
         // written in the sigma column layout the attention kernel loads its MFMA operands in (kernels.hpp: GemmArgs::sigma_cols)
         GemmArgs g{pos_pe.as<float>(), d, layers[l].wpos, d, nullptr, pos_proj.as<float>() + (size_t)l * P * d, d, nullptr, 0, 1.0f, P, d, d};
@@ -545,7 +568,7 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
     if (stop_layer < 0 || stop_layer > cfg.num_layers) { stop_layer = cfg.num_layers; stop_stage = 0; }
     if (stop_layer == 0 && stop_stage == 0) return;
     float *att_scratch_p = nullptr;
-    if (relpos_attention_lds_bytes(T, d / cfg.num_heads) > 160 * 1024) {
+    if (!attn_bf16(T) && relpos_attention_lds_bytes(T, d / cfg.num_heads) > 160 * 1024) {
         // a [32][T] score block no longer fits LDS (> ~85 s of audio): the same kernel with its score blocks in global scratch
         const size_t need = relpos_attention_scratch_bytes(B, T, cfg.num_heads, d / cfg.num_heads);
         if (need == 0 || need > ((size_t)64 << 30))
@@ -556,6 +579,7 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
     }
     ensure_pos_tables(T, s);
     const int a16 = cfg.gemm_bf16 ? 1 : 0;                           // bf16 mode: LayerNorm outputs stored as bf16 GEMM operands (ffn())
+    const bool att16 = attn_bf16(T);                                 // ... and q / k / v as bf16 for the bf16-MFMA attention kernel
     bool ffn1_norm_done = false;
     for (int l = first_layer; l < cfg.num_layers; ++l) {
         if (l > stop_layer || (l == stop_layer && stop_stage == 0)) break;
@@ -569,11 +593,18 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
         {
             // q and k columns in the sigma layout (MFMA operands of the attention kernel), v natural
             GemmArgs g{n, d, L.wqkv, d, L.bqkv, w.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
-            g.sigma_cols = 2 * d;
+            g.sigma_cols = att16 ? 0 : 2 * d;
             g.a_bf16 = a16;
+            g.out_bf16 = att16 ? 1 : 0;
             run_gemm("attn_qkv", g, EPI_NONE, s);
         }
-        {
+        if (att16) {
+            const int hd = d / cfg.num_heads;
+            const double fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);
+            KL("relpos_attention", fl, 0.0,
+               launch_relpos_attention_bf16(w.qkv.p, B, T, d, cfg.num_heads, reinterpret_cast<const __bf16 *>(pos_proj.p) + (size_t)l * P * d,
+                                            pos_cvec.as<float>() + (size_t)l * cfg.num_heads * P, L.pos_u, w.ctx.p, s));
+        } else {
             const int hd = d / cfg.num_heads;
             const double fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);   // QK^T + QP^T(needed band) + AV
             KL("relpos_attention", fl, 0.0,
@@ -745,6 +776,8 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         SkinnyArgs &a = P.heads;
         a.X = w.z.as<float>(); a.W = wld_s; a.B = B; a.N = V + D; a.K = J; a.bias = bld; a.out = w.logits.as<float>(); a.ldo = V + D;
     }
+    for (int l = 0; l < L; ++l) P.cell[l].nt_weights = dec_nt_weights;
+    P.act.nt_weights = P.heads.nt_weights = dec_nt_weights;
     // ONE launch for the whole loop (kernels/decode_persist.hip): implemented, bit-identical to the per-phase loop (tests/test_gpu_decode.py),
     // and NOT faster on this hardware -- opt-in: pk_model_set_decode_loop(m, PK_DECODE_LOOP_PERSISTENT).  Measured in round 2 (profiles/r02_decode_persistent.md): the
     // grid barrier between the four all-to-all phases of a step costs ~20 us with a single system-scope arrival counter (160 arrivals

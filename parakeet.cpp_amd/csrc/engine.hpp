@@ -95,6 +95,8 @@ class Model {
     // per-layer pos_proj_(pe) [L][2T-1][d]; they depend on (T, weights) only, so they are rebuilt when T changes.
     int pos_T = 0;
     DevBuf pos_pe, pos_proj;
+    DevBuf pos_cvec;            // bf16 attention: (v_h - u_h) . P_p per (layer, head, p)
+    bool attn_bf16(int T) const;    // the bf16-MFMA attention kernel applies (gemm_bf16 mode, head size 64 / 128, strip + c band fit LDS)
     DevBuf att_scratch;         // score blocks of the attention kernel for sequences too long for LDS (grow-only)
     void ensure_pos_tables(int T, hipStream_t s);
 
@@ -126,6 +128,7 @@ class Model {
     // grow-only scratch shared by the host-buffer entry points
     DevBuf io_in, io_out, io_tmp;
     Workspace ws;       // workspace of the host-buffer stage entry points
+    int dec_nt_weights = 0;                    // decode GEMVs stream their weights with non-temporal loads (SkinnyArgs::nt_weights)
     int decode_loop = PK_DECODE_LOOP_PHASES;   // pk_model_set_decode_loop: how run_tdt_loop issues the greedy loop
     int *h_done = nullptr;   // pinned host word for the decode loop's "all utterances finished" poll
     // the two-stream batch pipeline of the one-call API (struct pk_batch, capi.cpp), owned by the model; freed first in ~Model

@@ -1,0 +1,291 @@
+// parakeet.cpp_amd/csrc/kernels/attention_bf16.hip -- relative-position multi-head attention of the TOLERANCE-class mode (pk_config.gemm_bf16,
+// the precision BASELINE configs[2] names), all three contractions on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 softmax.
+// Reference: ConformerAttention::rel_position_attention (src/encoder.cpp:135-171) with rel_shift (:85-109) in closed form:
+//     S[i][j] = ( (q_i + u_h) . k_j  +  (q_i + v_h) . P_h[j - i + T - 1] ) / sqrt(hd) ,   ctx_i = softmax_j(S[i][:]) V
+// The bit-exact fp32 kernel (attention.hip: 16x16x4 fp32 MFMA, [32][T] score block in LDS) is 34 % of the tdt-600m encoder in this mode; here:
+//   * q, k, v arrive as bf16 (the qkv GEMM's epilogue rounds them), the projected position table as bf16 (pos_proj GEMM), ctx leaves as bf16
+//     (it is only ever out_proj's operand).  (q + v_h) . P_p  is evaluated as  (q + u_h) . P_p + c_h[p]  with  c_h[p] = (v_h - u_h) . P_p  computed
+//     once per (layer, head) in fp32 (pos_cvec_kernel): ONE biased copy of the query tile in registers instead of two.
+//   * One workgroup = 128 query rows of one (utterance, head): 4 wavefronts x 32 rows, streaming over 32-key tiles with an online softmax,
+//     so nothing of size T lives in LDS and the sequence length is unbounded.  All products are formed TRANSPOSED (keys x queries): in the
+//     32x32 accumulator layout a lane then holds 16 keys of ONE query, so the softmax row statistics are in-lane reductions plus one exchange
+//     with lane ^ 32, and the probability tile IS the B operand of  ctx^T = V^T P^T  after a cvt to bf16 -- no LDS round trip for P.
+//   * rel_shift: the position scores of key tile t need band rows  p - base = (j - j0) - (i - i0) + 31  in [0, 62] = two 32-row blocks of
+//     (q + u) P^T; consecutive key tiles share a block, so ONE new 32x32 block per tile goes into a wave-private LDS strip [64][34] and the
+//     skewed read  strip[jj - n + 31][n]  is conflict-free (pitch 34: the lane stride is 33 words).
+//   * K and P tiles are MFMA A operands straight from L2 (16 bytes per lane = the 8 k of one step), reloaded right after their last use so the
+//     loads fly under the softmax / PV phases.  V needs the contraction index (key) along the lane's 8 operands: the V tile is staged in LDS as
+//     [4 keys][16 dv] sub-blocks and read with ds_read_b64_tr_b16 (gfx950 transpose read; lane-linear = conflict-free, tools/ubench/tr16_probe.cpp),
+//     double-buffered, one barrier per key tile.
+// Numerics: tolerance class (compared with the oracle's gemm_bf16 mode, which rounds the same operands: oracle/pk_oracle.c attention()).
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+
+namespace pk {
+
+typedef float ab_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 ab_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ab_bf16x4 __attribute__((ext_vector_type(4)));
+typedef short ab_s16x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int AB_QB = 128;       // query rows per workgroup (4 waves x 32)
+static constexpr int AB_SKP = 34;       // skew strip pitch (floats)
+
+// c[l][h][p] = (v_h - u_h) . P[l][p][h*HD ..]   fp32, natural k order (the oracle evaluates the same chain)
+__global__ void pos_cvec_kernel(const __bf16 *__restrict__ pos, const float *__restrict__ bias_u, const float *__restrict__ bias_v, int P, int d, int H,
+                                int HD, float *__restrict__ cvec) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * P) return;
+    const int h = idx / P, p = idx % P;
+    const __bf16 *row = pos + (int64_t)p * d + h * HD;
+    float acc = 0.0f;
+    for (int k = 0; k < HD; ++k) acc = __builtin_fmaf(bias_v[h * HD + k] - bias_u[h * HD + k], (float)row[k], acc);
+    cvec[idx] = acc;
+}
+void launch_pos_cvec(const void *pos_bf16, const float *bias_u, const float *bias_v, int P, int d, int n_heads, float *cvec, hipStream_t s) {
+    const int n = n_heads * P;
+    hipLaunchKernelGGL(pos_cvec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const __bf16 *>(pos_bf16), bias_u, bias_v, P, d, n_heads,
+                       d / n_heads, cvec);
+}
+
+__device__ __forceinline__ int ab_rowidx(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }     // row of accumulator register r (32x32 C layout)
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __bf16 *__restrict__ qkv, int ldq, int d, int T,
+                                                                       const __bf16 *__restrict__ pos /*[2T-1][d]*/, const float *__restrict__ cvec /*[H][2T-1]*/,
+                                                                       const float *__restrict__ bias_u, float scale_log2e, __bf16 *__restrict__ ctx,
+                                                                       int n_qb, int n_bh, int nkt) {
+    constexpr int NK = HD / 16;          // MFMA k-steps of a contraction over the head dimension
+    constexpr int NDT = HD / 32;         // 32-wide dv tiles of ctx^T
+    constexpr int VCH = HD / 8;          // 16-byte chunks per V row
+    constexpr int NV = 32 * VCH / 256;   // V chunks per thread per key tile
+    static_assert(NV >= 1, "HD >= 64");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];
+    __bf16 *Vimg = reinterpret_cast<__bf16 *>(ab_smem);                          // [2][32 * HD]   sub-blocked V tiles
+    float *skew = reinterpret_cast<float *>(ab_smem + 2 * 32 * HD * 2);          // [4][64 * AB_SKP]
+    float *cb = skew + 4 * 64 * AB_SKP;                                          // [32 nkt + 128]  c band of this workgroup
+    __builtin_amdgcn_s_setprio(3);
+
+    const int H = d / HD, P = 2 * T - 1;
+    int bh, qb;
+    {   // the query blocks of one (utterance, head) take consecutive slots of ONE XCD (block id % 8 = XCD): K, V and the P band stay in its L2
+        const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
+        qb = k % n_qb;
+        bh = (k / n_qb) * 8 + xcd;
+        if (bh >= n_bh) return;
+    }
+    const int b = bh / H, h = bh % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, g = lane >> 5;
+    const int i0w = qb * AB_QB + 32 * wave;                         // first query row of this wave
+    const bool active = i0w < T;                                    // wave-uniform
+    const __bf16 *qrow = qkv + (int64_t)b * T * ldq + h * HD;        // q of (b, h); k at + d, v at + 2 d
+    const __bf16 *prow = pos + h * HD;
+    float *sk = skew + wave * 64 * AB_SKP;
+    const int base0 = T - 32 - i0w;                                 // p of band row 0 of block 0 for this wave
+    const int cb_len = 32 * nkt + 128;
+
+    for (int i = tid; i < cb_len; i += 256) {                       // c band: p = (T - 128 - 128 qb) + i
+        int p = T - AB_QB - qb * AB_QB + i;
+        p = p < 0 ? 0 : (p > P - 1 ? P - 1 : p);
+        cb[i] = cvec[h * P + p];
+    }
+    // V tile staging (workgroup-cooperative): chunk c = tid + 256 i -> key c / VCH, 8 dv at 8 (c % VCH)
+    float4 vreg[NV];
+    auto v_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = tid + 256 * i, key = c / VCH, ch = c % VCH;
+            int kr = 32 * t + key;
+            kr = kr < T ? kr : T - 1;
+            vreg[i] = *reinterpret_cast<const float4 *>(qrow + (int64_t)kr * ldq + 2 * d + 8 * ch);
+        }
+    };
+    auto v_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = tid + 256 * i, key = c / VCH, ch = c % VCH;
+            const int q4 = key >> 2, pq = q4 >> 1, gq = q4 & 1, dv16 = ch >> 1, dt = dv16 >> 1, dvh = dv16 & 1;
+            const int blk = (pq * NDT + dt) * 4 + gq * 2 + dvh;
+            lds_store16(Vimg + buf * 32 * HD + blk * 64 + (key & 3) * 16 + (ch & 1) * 8, vreg[i]);
+        }
+    };
+    // A-operand tile straight from L2: lane (row n, half g) takes the 8 k of step s at 16 s + 8 g
+    ab_bf16x8 kreg[NK], preg[NK], qreg[NK];
+    auto k_load = [&](int t) {
+        int kr = 32 * t + n;
+        kr = kr < T ? kr : T - 1;
+        const __bf16 *p = qrow + (int64_t)kr * ldq + d + 8 * g;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) kreg[s] = *reinterpret_cast<const ab_bf16x8 *>(p + 16 * s);
+    };
+    auto p_load = [&](int m) {
+        int pr = base0 + 32 * m + n;
+        pr = pr < 0 ? 0 : (pr > P - 1 ? P - 1 : pr);
+        const __bf16 *p = prow + (int64_t)pr * d + 8 * g;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) preg[s] = *reinterpret_cast<const ab_bf16x8 *>(p + 16 * s);
+    };
+    // position block m -> + c -> the wave's skew strip, half m & 1
+    auto g_block = [&](int m) {
+        ab_f32x16 ga;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preg[s], qreg[s], ga, 0, 0, 0);
+        const int cbase = 96 - 32 * wave + 32 * m;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int x = ab_rowidx(r, g);
+            sk[(32 * (m & 1) + x) * AB_SKP + n] = ga[r] + cb[cbase + x];
+        }
+    };
+
+    v_load(0);
+    if (active) {
+        int qr = i0w + n;
+        qr = qr < T ? qr : T - 1;
+        const __bf16 *qp = qrow + (int64_t)qr * ldq + 8 * g;
+        const float *bu = bias_u + h * HD + 8 * g;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            const ab_bf16x8 raw = *reinterpret_cast<const ab_bf16x8 *>(qp + 16 * s);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qreg[s][e] = (__bf16)((float)raw[e] + bu[16 * s + e]);        // (q + u) as the reference forms it, rounded once
+        }
+        k_load(0);
+        p_load(0);
+    }
+    v_store(0);
+    lds_store_fence();
+    __syncthreads();                                                // V tile 0 and the c band are in LDS
+    if (active) {
+        g_block(0);
+        p_load(1);
+    }
+
+    ab_f32x16 O[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] = 0.0f;
+    float m_run = -__builtin_huge_valf(), l_run = 0.0f;
+
+    for (int t = 0; t < nkt; ++t) {
+        const bool more = t + 1 < nkt;
+        if (more) v_load(t + 1);
+        if (active) {
+            // ---- content scores, transposed: S^T[key][query] ----
+            ab_f32x16 sa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < NK; ++s) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kreg[s], qreg[s], sa, 0, 0, 0);
+            if (more) k_load(t + 1);
+            // ---- position block t + 1 into the strip, then the skewed read of blocks t and t + 1 ----
+            g_block(t + 1);
+            if (more) p_load(t + 2);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float sv[16];
+            float mloc = -__builtin_huge_valf();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = ab_rowidx(r, g);
+                const int xr = jj - n + 31;                          // band row relative to block t: 0 .. 62
+                const int phys = 32 * ((t + (xr >> 5)) & 1) + (xr & 31);
+                float v = (sa[r] + sk[phys * AB_SKP + n]) * scale_log2e;          // (content + position) * scale, in the exp2 domain
+                v = (32 * t + jj < T) ? v : -__builtin_huge_valf();
+                sv[r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                 // the strip half of block t is overwritten next iteration
+            // ---- online softmax: lanes n and n + 32 hold the two halves of query n's keys ----
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sv[r] = __builtin_amdgcn_exp2f(sv[r] - m_new);
+                psum = psum + sv[r];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            if (__ballot(alpha != 1.0f) != 0ull) {                  // (wave-uniform) the running maximum moved for some query: rescale ctx^T
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[dt][r] = O[dt][r] * alpha;
+            }
+            // ---- ctx^T += V^T P^T : two k-steps of 16 keys; the probability registers are the B operand as they lie ----
+            const __bf16 *vb = Vimg + (t & 1) * 32 * HD + lane * 4;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                ab_bf16x8 pB;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pB[e] = (__bf16)sv[8 * st + e];
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const ab_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ab_s16x4 *)(vb + ((2 * st) * NDT + dt) * 256));
+                    const ab_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ab_s16x4 *)(vb + ((2 * st + 1) * NDT + dt) * 256));
+                    ab_s16x4 both[2] = {lo, hi};
+                    ab_bf16x8 vA;
+                    __builtin_memcpy(&vA, both, 16);
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA, pB, O[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            v_store((t + 1) & 1);
+            lds_store_fence();
+        }
+        __syncthreads();                                            // V tile t + 1 visible; every wave is done with tile t's image
+    }
+    if (!active) return;
+    l_run = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(l_run);
+    const int i = i0w + n;
+    if (i < T) {
+        __bf16 *orow = ctx + ((int64_t)b * T + i) * d + h * HD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                ab_bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(O[dt][4 * rq + e] * inv);
+                *reinterpret_cast<ab_bf16x4 *>(orow + 32 * dt + 8 * rq) = o;          // dv = 32 dt + 8 rq + 4 g + e
+            }
+    }
+}
+
+size_t relpos_attention_bf16_lds_bytes(int T, int hd) {
+    if (hd != 64 && hd != 128) return 0;
+    const int nkt = (T + 31) / 32;
+    return (size_t)2 * 32 * hd * 2 + (size_t)4 * 64 * AB_SKP * 4 + (size_t)(32 * nkt + 128) * 4;
+}
+
+template <int HD>
+static void launch_att_bf16(const void *qkv, int B, int T, int d, int n_heads, const void *pos, const float *cvec, const float *bias_u, void *ctx,
+                            hipStream_t s) {
+    const int n_qb = (T + AB_QB - 1) / AB_QB, n_bh = B * n_heads, nkt = (T + 31) / 32;
+    const float scale_log2e = (1.0f / sqrtf((float)HD)) * 1.44269504088896340736f;
+    const size_t lds = relpos_attention_bf16_lds_bytes(T, HD);
+    auto kern = &relpos_attention_bf16_kernel<HD>;
+    static DynLdsSlots slots;
+    ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+    dim3 grid(((n_bh + 7) / 8) * 8 * n_qb);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, static_cast<const __bf16 *>(qkv), 3 * d, d, T, static_cast<const __bf16 *>(pos), cvec, bias_u,
+                       scale_log2e, static_cast<__bf16 *>(ctx), n_qb, n_bh, nkt);
+}
+
+void launch_relpos_attention_bf16(const void *qkv_bf16, int B, int T, int d, int n_heads, const void *pos_bf16, const float *cvec, const float *bias_u,
+                                  void *ctx_bf16, hipStream_t s) {
+    const int hd = d / n_heads;
+    if (hd == 128) launch_att_bf16<128>(qkv_bf16, B, T, d, n_heads, pos_bf16, cvec, bias_u, ctx_bf16, s);
+    else if (hd == 64) launch_att_bf16<64>(qkv_bf16, B, T, d, n_heads, pos_bf16, cvec, bias_u, ctx_bf16, s);
+}
+
+}  // namespace pk

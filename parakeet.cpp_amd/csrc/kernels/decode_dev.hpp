@@ -35,6 +35,16 @@ template <bool COH> __device__ __forceinline__ void dd_sti(int *p, int v) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// 16 bytes of the weight stream: plain, or with the non-temporal (streaming) hint
+template <bool NT> __device__ __forceinline__ float4 dd_ldw(const float4 *p) {
+    if constexpr (NT) {
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        return *p;
+    }
+}
+
 __device__ __forceinline__ int sigma16(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
 
 // NCH: compile-time number of 64-wide K chunks (10 for K = 640: fully unrolled, counted vmcnt waits keep the next
@@ -42,7 +52,9 @@ __device__ __forceinline__ int sigma16(int k) { return (k & ~15) | ((k & 3) << 2
 // COH = the operands other workgroups of the SAME kernel produced (X, c, the token / frame words, gi of the upper LSTM layers) are
 // read, and the outputs written, with system-scope accesses (sc0 sc1: no cache between the workgroups) -- the persistent decode
 // kernel (decode_persist.hip) runs every phase of a step inside one launch.
-template <int EPI, int NCH, bool COH>
+// NTW: the weight stream is loaded non-temporally (streaming hint: the decode weights of the large heads -- 42 MB per symbol step for tdt-600m --
+// pass through each XCD's 4 MB L2 once per step and otherwise evict the operand tiles of the encoder GEMMs running beside the loop).
+template <int EPI, int NCH, bool COH, bool NTW = false>
 __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgroup, float (*tile)[16][17]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
@@ -91,7 +103,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
 #define SK_LOAD(X_, W_, c_)                                                         \
     _Pragma("unroll") for (int i = 0; i < CH; ++i) {                               \
         X_[i] = dd_ld4<COH>(xq + 4 * ((c_) * CH + i));                              \
-        W_[i] = wq[4 * ((c_) * CH + i)];                                            \
+        W_[i] = dd_ldw<NTW>(wq + 4 * ((c_) * CH + i));                               \
     }                                                                               \
     __builtin_amdgcn_sched_barrier(0);
 #define SK_MMA(X_, W_)                                                              \
@@ -298,8 +310,17 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     }
     int skip = 1;
     if (wave == 1 && st.D > 0) {                                   // duration head: a few values, one wavefront
-        const BestLP dur = wave_logsoftmax_argmax(x + st.V, st.D, nullptr, lane);
+        const BestLP dur = wave_logsoftmax_argmax(x + st.V, st.D, e + st.V, lane);      // (log-probs into the free tail of e[]: read back for the margin)
         if (lane == 0) red[5] = (float)(dur.idx < st.D ? st.durations[dur.idx] : 1);
+        if (st.margin) {                                           // top-1 / top-2 margin of the duration decision (it moves the frame pointer)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float second = -__builtin_huge_valf();
+            for (int i = lane; i < st.D; i += 64)
+                if (i != dur.idx) second = fmaxf(second, e[st.V + i]);
+            second = wave_max64(second);
+            if (lane == 0) red[6] = st.D > 1 ? dur.lp - second : __builtin_huge_valf();
+        }
     }
     __syncthreads();
     const float lse = red[4];
@@ -337,7 +358,8 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     }
     if constexpr (!BOOST) {
         if (st.margin && tid == 0) {                               // running minimum over the utterance's decisions (SURVEY 8c early warning)
-            const float mg = lab.lp - sec;
+            float mg = lab.lp - sec;
+            if (st.D > 0) mg = fminf(mg, red[6]);
             const float old = dd_ldf<COH>(st.margin + b);
             dd_stf<COH>(st.margin + b, mg < old ? mg : old);
         }

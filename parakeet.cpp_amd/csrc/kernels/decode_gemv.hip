@@ -17,29 +17,31 @@
 
 namespace pk {
 
-template <int EPI, int NCH>
+template <int EPI, int NCH, bool NTW>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     __shared__ float tile[4][16][17];
-    skinny_tile<EPI, NCH, false>(a, blockIdx.x, blockIdx.y, tile);
+    skinny_tile<EPI, NCH, false, NTW>(a, blockIdx.x, blockIdx.y, tile);
+}
+
+template <int EPI>
+static void launch_skinny_epi(const SkinnyArgs &a, dim3 grid, hipStream_t s) {
+    const bool k640 = a.K == 640;
+    if (a.nt_weights) {
+        if (k640) hipLaunchKernelGGL((skinny_gemm_kernel<EPI, 10, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<EPI, 0, true>), grid, dim3(256), 0, s, a);
+    } else {
+        if (k640) hipLaunchKernelGGL((skinny_gemm_kernel<EPI, 10, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<EPI, 0, false>), grid, dim3(256), 0, s, a);
+    }
 }
 
 void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s) {
     const int n_tiles = epi == SK_CELL ? a.Hp / 4 : (a.N + 15) / 16;
     dim3 grid(n_tiles, (a.B + 63) / 64);
-    const bool k640 = a.K == 640;
     switch (epi) {
-    case SK_BIAS:
-        if (k640) hipLaunchKernelGGL((skinny_gemm_kernel<SK_BIAS, 10>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((skinny_gemm_kernel<SK_BIAS, 0>), grid, dim3(256), 0, s, a);
-        break;
-    case SK_ACT:
-        if (k640) hipLaunchKernelGGL((skinny_gemm_kernel<SK_ACT, 10>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((skinny_gemm_kernel<SK_ACT, 0>), grid, dim3(256), 0, s, a);
-        break;
-    case SK_CELL:
-        if (k640) hipLaunchKernelGGL((skinny_gemm_kernel<SK_CELL, 10>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((skinny_gemm_kernel<SK_CELL, 0>), grid, dim3(256), 0, s, a);
-        break;
+    case SK_BIAS: launch_skinny_epi<SK_BIAS>(a, grid, s); break;
+    case SK_ACT: launch_skinny_epi<SK_ACT>(a, grid, s); break;
+    case SK_CELL: launch_skinny_epi<SK_CELL>(a, grid, s); break;
     default: break;
     }
 }

@@ -88,6 +88,13 @@ int relpos_attention_max_frames(int hd);              // longest sequence one wo
 size_t relpos_attention_scratch_bytes(int B, int T, int n_heads, int hd);   // long sequences: score blocks in global scratch (hd 64 / 128)
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
                              const float *bias_v, float *ctx, hipStream_t s, float scale = 0.0f, float *scratch = nullptr, int ctx_bf16 = 0);
+// The tolerance-class (pk_config.gemm_bf16) attention, kernels/attention_bf16.hip: q / k / v as bf16 [B*T][3d] (natural columns, written by the
+// qkv GEMM), the projected position table of the layer as bf16 [2T-1][d], cvec[h][p] = (v_h - u_h) . P_p (fp32, launch_pos_cvec), ctx as bf16.
+// Head sizes 64 and 128; relpos_attention_bf16_lds_bytes returns 0 for any other.
+size_t relpos_attention_bf16_lds_bytes(int T, int hd);
+void launch_pos_cvec(const void *pos_bf16, const float *bias_u, const float *bias_v, int P, int d, int n_heads, float *cvec, hipStream_t s);
+void launch_relpos_attention_bf16(const void *qkv_bf16, int B, int T, int d, int n_heads, const void *pos_bf16, const float *cvec, const float *bias_u,
+                                  void *ctx_bf16, hipStream_t s);
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
                            const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16 = 0);
 
@@ -156,6 +163,7 @@ struct SkinnyArgs {
     const float *gi; int gi_ld; const int *gi_row; const float *c; float *cn; int Hp;
     // SK_CELL of an upper LSTM layer with the input projection fused in: gi = X2 W2^T + bias2 (X2 [B][K] sigma, W2 [4Hp][K] sigma); W2 null: gi is read
     const float *X2 = nullptr, *W2 = nullptr, *bias2 = nullptr;
+    int nt_weights = 0;            // stream W with non-temporal loads (decode_dev.hpp: NTW)
 };
 void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s);
 

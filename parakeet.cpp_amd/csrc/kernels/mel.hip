@@ -19,7 +19,8 @@ namespace pk {
 
 static constexpr int kNfft = 512;
 static constexpr int kHop = 160;
-static constexpr int kFramesPerBlock = 4;
+static constexpr int kFramesPerBlock = 4;   // wavefronts per workgroup = frames in flight
+static constexpr int kOfflineIters = 4;     // offline kernel: every wavefront walks this many frames -> 16 frames per workgroup
 
 // STREAM = false: preprocess_audio's framing (pre-emphasis, center=true, reflect padding), output [B][n_mels][n_frames].
 // STREAM = true: StreamingAudioPreprocessor::process_chunk's framing (src/audio.cpp:222-241): the buffer is ALREADY
@@ -44,6 +45,12 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
     // (round 1: 8.5e7 LDS bank-conflict cycles per dispatch).
     __shared__ float s_twr[kNfft], s_twi[kNfft];
     __shared__ float s_fb[kMelMaxTaps];
+    // Offline: the log-mel values of the workgroup's 16 frames are collected here and leave as 64-byte runs of [m][16 frames]; written
+    // straight from the frame's wavefront they were 4-byte stores 4 KB apart (round 2 PMC: 56 MB of write traffic for a 20 MB tensor).
+    // The tables above are also loaded once per 16 frames instead of once per 4.
+    constexpr int ITERS = STREAM ? 1 : kOfflineIters;
+    constexpr int FPB = kFramesPerBlock * ITERS;
+    __shared__ float s_out[STREAM ? 1 : 128][STREAM ? 1 : FPB + 1];
     for (int i = threadIdx.x; i < kNfft - 1; i += 256) {
         const int lh = 31 - __builtin_clz(i + 1), j = i + 1 - (1 << lh);   // i = 2^lh - 1 + j
         s_twr[i] = tb.tw_re[j << (8 - lh)];
@@ -53,10 +60,13 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
-    const int t = blockIdx.x * kFramesPerBlock + wave;
-    const bool live = t < n_frames;
     const float *x = pcm + (int64_t)b * n_samples;
     float *re = s_re[wave], *im = s_im[wave], *pw = s_pw[wave];
+#pragma unroll 1
+    for (int it = 0; it < ITERS; ++it) {
+    const int t = blockIdx.x * FPB + it * kFramesPerBlock + wave;
+    const bool live = t < n_frames;
+    if (it) PK_WAVE_SYNC();                                         // the previous frame's reads of pw / re / im are done
 
     if (live) {
 #pragma unroll
@@ -126,7 +136,16 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
             for (int f = lo; f <= hi; ++f) acc = __builtin_fmaf(wm[f], pw[f], acc);
             const float lm = dlogf(acc + 5.96046448e-8f);
             if constexpr (STREAM) logmel[((int64_t)b * n_frames + t) * tb.n_mels + m] = lm;
-            else logmel[((int64_t)b * tb.n_mels + m) * n_frames + t] = lm;
+            else s_out[m][it * kFramesPerBlock + wave] = lm;
+        }
+    }
+    }
+    if constexpr (!STREAM) {
+        __syncthreads();
+        const int t0 = blockIdx.x * FPB;
+        for (int idx = threadIdx.x; idx < tb.n_mels * FPB; idx += 256) {
+            const int m = idx / FPB, tt = idx % FPB;
+            if (t0 + tt < n_frames) logmel[((int64_t)b * tb.n_mels + m) * n_frames + t0 + tt] = s_out[m][tt];
         }
     }
 }
@@ -172,7 +191,8 @@ __global__ __launch_bounds__(1024) void mel_normalize_kernel(const float *__rest
 }
 
 void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s) {
-    dim3 grid((n_frames + kFramesPerBlock - 1) / kFramesPerBlock, B);
+    constexpr int fpb = kFramesPerBlock * kOfflineIters;
+    dim3 grid((n_frames + fpb - 1) / fpb, B);
     hipLaunchKernelGGL(mel_logmel_kernel<false>, grid, dim3(256), 0, s, pcm, n_samples, n_frames, t, logmel);
 }
 void launch_mel_stream(const float *pre, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel_tf, hipStream_t s) {

@@ -122,7 +122,8 @@ def test_bf16_drift_curve_and_token_contract_at_depth_24(gold, setup):
     report = []
     for b in range(len(pcm)):
         got = tokens(g, b)
-        at, mg = first_divergence(got, gold["bf16_step_label"][b], gold["bf16_step_margin"][b], cfg.blank_id)
+        at, mg = first_divergence(got, gold["bf16_step_label"][b], gold["bf16_step_margin"][b], cfg.blank_id,
+                                  got_frames=(g["start"][b], g["end"][b]), oracle_frames=(gold["bf16_start"][b], gold["bf16_end"][b]))
         want_n = int(gold["bf16_lens"][b])
         report.append((b, len(got), want_n, at, mg, float(g["min_margin"][b])))
         if at is not None:
