@@ -20,7 +20,10 @@ namespace pk {
 static constexpr int kNfft = 512;
 static constexpr int kHop = 160;
 static constexpr int kFramesPerBlock = 4;   // wavefronts per workgroup = frames in flight
-static constexpr int kOfflineIters = 4;     // offline kernel: every wavefront walks this many frames -> 16 frames per workgroup
+// Offline kernel: frames each wavefront walks one after the other (frames per workgroup = 4 x this).  Measured (round 3, bench.py on MI355X):
+// 1 -> 0.203 ms per 64-clip batch, 2 -> 0.234, 4 -> 0.237: the kernel is LDS-latency bound and wants the parallelism, so the store tile is
+// [m][4 frames] (16-byte runs) and not the 64-byte runs 16 frames per workgroup would give.
+static constexpr int kOfflineIters = 1;
 
 // STREAM = false: preprocess_audio's framing (pre-emphasis, center=true, reflect padding), output [B][n_mels][n_frames].
 // STREAM = true: StreamingAudioPreprocessor::process_chunk's framing (src/audio.cpp:222-241): the buffer is ALREADY
@@ -45,9 +48,8 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
     // (round 1: 8.5e7 LDS bank-conflict cycles per dispatch).
     __shared__ float s_twr[kNfft], s_twi[kNfft];
     __shared__ float s_fb[kMelMaxTaps];
-    // Offline: the log-mel values of the workgroup's 16 frames are collected here and leave as 64-byte runs of [m][16 frames]; written
-    // straight from the frame's wavefront they were 4-byte stores 4 KB apart (round 2 PMC: 56 MB of write traffic for a 20 MB tensor).
-    // The tables above are also loaded once per 16 frames instead of once per 4.
+    // Offline: the log-mel values of the workgroup's frames are collected here and leave as contiguous runs of [m][frames]; written straight
+    // from the frame's wavefront they were 4-byte stores 4 KB apart (round 2 PMC: 56 MB of write traffic for a 20 MB tensor).
     constexpr int ITERS = STREAM ? 1 : kOfflineIters;
     constexpr int FPB = kFramesPerBlock * ITERS;
     __shared__ float s_out[STREAM ? 1 : 128][STREAM ? 1 : FPB + 1];
