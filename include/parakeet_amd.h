@@ -389,6 +389,10 @@ pk_status pk_diag_gemm(int M, int N, int K, const float *A, const float *W, cons
 /* The bf16-operand / fp32-accumulate GEMM of pk_config.gemm_bf16 (W is given in fp32 and rounded here like at upload); K % 64 == 0. */
 pk_status pk_diag_gemm_bf16(int M, int N, int K, const float *A, const float *W, const float *bias, int epi,
                             const float *resid, float alpha, float *out);
+/* The same with the activations stored as bf16 before the product (rounded here; in the engine the producing kernel's epilogue stores them so):
+ * large shapes take the direct-to-LDS kernel (kernels/gemm_bf16_glds.hpp). */
+pk_status pk_diag_gemm_bf16_a16(int M, int N, int K, const float *A, const float *W, const float *bias, int epi,
+                                const float *resid, float alpha, float *out);
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y);
 /* sum64 of each row of x[rows][n] (the canonical wavefront reduction). */
 pk_status pk_diag_sum64(const float *x, int rows, int n, float *out);

@@ -102,6 +102,7 @@ def lib():
     L.pk_diag_math.argtypes = [C.c_int, f32p, f32p, C.c_int64]
     L.pk_diag_gemm.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, C.c_int, f32p, C.c_float, f32p]
     L.pk_diag_gemm_bf16.argtypes = L.pk_diag_gemm.argtypes
+    L.pk_diag_gemm_bf16_a16.argtypes = L.pk_diag_gemm.argtypes
     L.pk_diag_layernorm.argtypes = [f32p, C.c_int64, C.c_int, f32p, f32p, C.c_float, f32p]
     L.pk_diag_sum64.argtypes = [f32p, C.c_int, C.c_int, f32p]
     for name, at in _LATE_SIGNATURES.items():
@@ -215,14 +216,14 @@ def read_audio(path, target_rate=16000):
     return r, sr.value
 
 
-def diag_gemm(A, W, bias=None, epi="none", resid=None, alpha=1.0, bf16=False):
+def diag_gemm(A, W, bias=None, epi="none", resid=None, alpha=1.0, bf16=False, a16=False):
     A, W = _c(A), _c(W)
     M, K = A.shape
     N = W.shape[0] // 2 if epi == "glu" else W.shape[0]
     b = _c(bias) if bias is not None else None
     r = _c(resid) if resid is not None else None
     out = np.empty((M, N), np.float32)
-    fn = lib().pk_diag_gemm_bf16 if bf16 else lib().pk_diag_gemm
+    fn = (lib().pk_diag_gemm_bf16_a16 if a16 else lib().pk_diag_gemm_bf16) if bf16 else lib().pk_diag_gemm
     check(fn(M, N, K, _f(A), _f(W), _f(b) if b is not None else None, EPI[epi], _f(r) if r is not None else None, alpha, _f(out)))
     return out
 

@@ -1417,6 +1417,44 @@ pk_status pk_diag_gemm_bf16(int M, int N, int K, const float *A, const float *W,
     });
 }
 
+/* the same product with the activations handed over as bf16 (GemmArgs::a_bf16: what the producing kernels of the bf16 mode store) */
+pk_status pk_diag_gemm_bf16_a16(int M, int N, int K, const float *A, const float *W, const float *bias, int epi, const float *resid,
+                                float alpha, float *out) {
+    return guard([&] {
+        need(A && W && out && M > 0 && N > 0 && K > 0, "A/W/out/M/N/K");
+        need(K % 64 == 0, "K must be a multiple of 64");
+        need(epi >= 0 && epi <= 4, "epi");
+        need(epi != EPI_RESID || resid, "resid");
+        diag_device();
+        const int wrows = epi == EPI_GLU ? 2 * N : N;
+        auto rne = [](float f) {
+            uint32_t u;
+            memcpy(&u, &f, 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        std::vector<uint16_t> w16((size_t)wrows * K), a16((size_t)M * K);
+        for (size_t i = 0; i < w16.size(); ++i) w16[i] = rne(W[i]);
+        for (size_t i = 0; i < a16.size(); ++i) a16[i] = rne(A[i]);
+        Scratch s;
+        s.a.reserve((size_t)M * K * 2);
+        s.b.reserve((size_t)wrows * K * 2);
+        s.c.reserve((size_t)wrows * 4);
+        s.d.reserve((size_t)M * N * 4);
+        s.e.reserve((size_t)M * N * 4);
+        PK_HIP(hipMemcpy(s.a.p, a16.data(), a16.size() * 2, hipMemcpyHostToDevice));
+        PK_HIP(hipMemcpy(s.b.p, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+        if (bias) PK_HIP(hipMemcpy(s.c.p, bias, (size_t)wrows * 4, hipMemcpyHostToDevice));
+        if (resid) PK_HIP(hipMemcpy(s.d.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice));
+        GemmArgs g{s.a.as<float>(), K, s.b.as<float>(), K, bias ? s.c.as<float>() : nullptr, s.e.as<float>(), N,
+                   resid ? s.d.as<float>() : nullptr, N, alpha, M, N, K};
+        g.a_bf16 = 1;
+        launch_gemm_bf16(g, epi, nullptr);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpy(out, s.e.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y) {
     return guard([&] {
         need(x && gamma && beta && y && rows > 0 && d > 0 && d <= 1024, "x/gamma/beta/y/rows/d (d <= 1024)");

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include "gemm_pipe.hpp"
 #include "gemm_bf16.hpp"
+#include "gemm_bf16_glds.hpp"
 
 namespace pk {
 
@@ -260,8 +261,32 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
 }
 
 // bf16 operands / fp32 accumulate (a.W points to bf16 weights [N][K]); K % 64 == 0
+// The direct-to-LDS bf16 kernel (gemm_bf16_glds.hpp; activations already bf16 in HBM), 256x256 macro tiles.  Measured inside the engine on
+// tdt-600m (profiles/r03_bf16_tile_ab.txt, PK_BF16_TILE in EXPERIMENTAL builds): it is ahead of the register-staged 128x128 kernel where one
+// operand is large -- fc1 (N = 4096: 6.70 -> 6.60 ms per step) and fc2 (K = 4096: 6.51 -> 6.11) -- and behind on qkv (2.50 -> 2.70), the GLU
+// product (1.75 -> 2.03) and the N = 1024 / K = 1024 products; 256x128 and 128x128-on-4-waves variants lose everywhere.  So: N * K >= 4 M
+// elements and no GLU.  Modes (EXPERIMENTAL builds, PK_BF16_TILE): 0 = off, 1 = that rule, 2 = 256x128 everywhere, 3 = 128x128 on 4 waves
+// of 64x64, 4 = 256x256 everywhere.
+static int bf16_glds_mode() {
+#ifdef PK_EXPERIMENTAL
+    static const int m = [] { const char *e = getenv("PK_BF16_TILE"); return e ? atoi(e) : 1; }();
+    return m;
+#else
+    return 1;
+#endif
+}
+
 template <int EPI, bool A16>
 static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
+    if constexpr (A16) {
+        const int mode = bf16_glds_mode();
+        if (mode && a.M >= 2048 && a.N >= 512 && a.K >= 128 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.remap_rows == 0 && (a.ldo & 3) == 0 && (a.N & 3) == 0) {
+            const bool big_operand = EPI != EPI_GLU && (int64_t)a.N * a.K >= (int64_t)4096 * 1024;
+            if (mode == 3) { launch_gemm_bf16_glds<2, 2, 2, 2, EPI>(a, s); return; }
+            if (mode == 2) { launch_gemm_bf16_glds<4, 2, 2, 2, EPI>(a, s); return; }
+            if (mode == 4 || big_operand) { launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s); return; }
+        }
+    }
     // round 2: the staging stores decide the rate of this kernel.  As 16-byte ds_write_b128 the 128x128 tile ran at 320-340 TF and 256x256
     // macro tiles were the way to 450 (profiles/r02_gemm_bf16_tiles.txt); the SAME 16 bytes written as a ds_write2_b64 pair
     // (gemm_bf16.hpp, lstore) take the 128x128 tile to 580 TF in the sweep and 510-600 TF in the engine (profiles/r02_gemm_bf16_ablation.txt)

@@ -1,0 +1,173 @@
+// parakeet.cpp_amd/csrc/kernels/gemm_bf16_glds.hpp -- bf16 MFMA GEMM with DIRECT-TO-LDS staging (gfx950 global_load_lds_dwordx4) on large
+// tiles, for the products of the tolerance-class mode whose activations already live in HBM as bf16 (GemmArgs::a_bf16).
+//
+// out[M][N] = epi(A16[M][K] * W16[N][K]^T + bias), fp32 accumulation on v_mfma_f32_32x32x16_bf16 -- the arithmetic of gemm_bf16.hpp.
+// Round 2 located that kernel's loss (profiles/r02_gemm_bf16_ablation.txt): MFMAs + barriers alone run at 1.0-1.7 PF, the
+// global -> VGPR -> ds_write staging takes half of the remaining time, and a 128x128 tile per 8 waves re-reads its operands from L2 twice
+// as often as a 256x256 one.  This kernel removes the staging instructions altogether:
+//  * every lane issues global_load_lds_dwordx4: 16 bytes (8 consecutive k of one tile row) go from global memory straight into LDS -- no
+//    staging VGPRs, no ds_write, no conversion (both operands are bf16 in HBM).  One wave instruction fills one 1 KB block = 8 tile rows of
+//    BK = 64 k.  The hardware puts lane q's 16 bytes at (block base + 16 q); WHICH 16-byte chunk of the row lands there is chosen through the
+//    global address the lane reads: physical chunk p of row r holds logical chunk p ^ ((r >> 1) & 7).  With that XOR swizzle the
+//    ds_read_b128 fragment reads (lane = row r of a 32-row operand tile, logical chunk 2 s + (lane >> 5)) are conflict-free for the
+//    instruction's four 16-lane groups (MI355X_MICROARCH.md section LDS: groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... -- within a group
+//    the rows of equal parity have distinct (r >> 1) & 7).  The LDS image is unpadded (the DMA destination is lane-linear).
+//  * 256x256 macro tiles on 8 waves of 64x128 (wide outputs) or 256x128 / 128x128 on waves of 64x64: 6-8 fragment reads feed 8-4 MFMAs per
+//    k-step instead of 3 feeding 2.
+//  * two LDS buffers; the DMA of K tile kt+2 is issued right after the barrier that frees the buffer of tile kt and has a whole K tile of
+//    MFMAs to land (s_waitcnt vmcnt(0) + the next barrier publish it) -- the schedule of tools/ubench/gemm_dma.hpp (round 2, fp32).
+//  * the epilogue is gemm_pipe.hpp's (accumulators -> LDS -> 4 consecutive columns per thread), in 64-row bands, the residual rows of a band
+//    requested at the start of its pass.
+#ifndef PK_GEMM_BF16_GLDS_HPP
+#define PK_GEMM_BF16_GLDS_HPP
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+#include "gemm_pipe.hpp"
+#include "gemm_bf16.hpp"
+
+namespace pk {
+
+template <int WGM, int WGN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs g, int tiles_n, int n_tiles) {
+    constexpr int BK = 64, NSUB = BK / 16;                          // bf16 elements per tile row; MFMA k-steps per K tile
+    constexpr int NT = 64 * WGM * WGN, NW = WGM * WGN;
+    constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
+    constexpr int BUF = (BM + BN) * BK;                             // bf16 elements per staging buffer (unpadded: the swizzle spreads the banks)
+    constexpr int NBLK = (BM + BN) / 8, NBPW = NBLK / NW;           // 1 KB blocks of 8 rows per K tile / per wave
+    static_assert(NBLK % NW == 0, "blocks must split evenly over the waves");
+    constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
+    static_assert(EPI != EPI_GLU || (TN % 2 == 0), "GLU needs an even number of column tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char gl_smem_raw[];
+    __bf16 *smem = reinterpret_cast<__bf16 *>(gl_smem_raw);
+    float *smem_f = reinterpret_cast<float *>(gl_smem_raw);
+    (void)NT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nk = g.K / BK;
+    const __bf16 *A16 = reinterpret_cast<const __bf16 *>(g.A);
+    const __bf16 *W16 = reinterpret_cast<const __bf16 *>(g.W);
+
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap (block b runs on XCD b % 8): XCD x gets a contiguous range of tiles
+        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int m0, n0;
+    {   // grouped tile order (gemm_bf16.hpp): GROUPM tile rows down before the next tile column
+        constexpr int GROUPM = (BM >= 256) ? 4 : 8;
+        const int tiles_m = n_tiles / tiles_n, per_group = GROUPM * tiles_n;
+        const int grp = bid / per_group, first_m = grp * GROUPM;
+        const int gsz = (tiles_m - first_m) < GROUPM ? (tiles_m - first_m) : GROUPM;
+        const int in = bid - grp * per_group;
+        m0 = (first_m + in % gsz) * BM;
+        n0 = (in / gsz) * NOUT;
+    }
+
+    // DMA sources: wave w fills blocks w, w + NW, ...; lane q of block b supplies (row 8 b + q / 8, logical chunk (q % 8) ^ ((row >> 1) & 7)).
+    // Rows 0 .. BM-1 of the stacked tile are A rows, BM .. BM+BN-1 are W rows.
+    const __bf16 *src[NBPW];
+#pragma unroll
+    for (int i = 0; i < NBPW; ++i) {
+        const int b = wv + NW * i;
+        const int row = 8 * b + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        if (row < BM) {
+            int gr = m0 + row;
+            gr = gr < g.M ? gr : g.M - 1;
+            src[i] = A16 + (int64_t)gr * g.lda + 8 * c;
+        } else {
+            const int v = row - BM;
+            int wr;
+            if constexpr (EPI == EPI_GLU) {
+                constexpr int HT = TN / 2;     // tiles [0,HT) = value half, [HT,TN) = gate half of the SAME output columns
+                const int vw = v / WN, rem = v % WN, tn = rem >> 5, cc = rem & 31;
+                int col = n0 + vw * (WN / 2) + (tn % HT) * 32 + cc;
+                col = col < g.N ? col : g.N - 1;
+                wr = (tn / HT) * g.N + col;
+            } else {
+                wr = n0 + v;
+                wr = wr < g.N ? wr : g.N - 1;
+            }
+            src[i] = W16 + (int64_t)wr * g.ldw + 8 * c;
+        }
+    }
+    auto dma = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < NBPW; ++i) {
+            __bf16 *dst = smem + buf * BUF + (wv + NW * i) * 512;                    // 1 KB = 512 bf16 per block; wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+
+    bg_f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment addresses: operand-tile row r = tile base (a multiple of 32) + (lane & 31): element offset r * 64 + ((2 s + h) ^ x) * 8 with
+    // x = (r >> 1) & 7 = ((lane & 31) >> 1) & 7 -- one swizzle value per lane for every tile
+    const int h = lane >> 5, fx = ((lane & 31) >> 1) & 7;
+    const int fa_base = (wm * WM + (lane & 31)) * BK, fb_base = (BM + wn * WN + (lane & 31)) * BK;
+    bg_bf16x8 fa[2][TM], fb[2][TN];
+    auto fragload = [&](int buf, int s, int slot) {
+        const __bf16 *base = smem + buf * BUF + (((2 * s + h) ^ fx) << 3);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const bg_bf16x8 *>(base + fa_base + i * 32 * BK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const bg_bf16x8 *>(base + fb_base + j * 32 * BK);
+    };
+    auto mma = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i], fb[slot][j], acc[i][j], 0, 0, 0);
+    };
+#define GL_SB() __builtin_amdgcn_sched_barrier(0)
+#define GL_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)           /* vmcnt(0): this wave's LDS-DMA loads have landed */
+
+    dma(0, 0);
+    if (nk > 1) dma(1, 1);
+    GL_WAIT_VM0();
+    __syncthreads();
+    fragload(0, 0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+#pragma unroll
+        for (int s = 0; s < NSUB - 1; ++s) {
+            fragload(cur, s + 1, (s + 1) & 1);
+            GL_SB(); mma(s & 1); GL_SB();
+        }
+        GL_WAIT_VM0();                     // K tile kt+1 (issued a whole tile ago) is in LDS
+        __syncthreads();                   // ... for every wave; and every wave holds its last fragments of tile kt: buffer `cur` is free
+        if (more1) fragload(cur ^ 1, 0, 0);
+        if (more2) dma(kt + 2, cur);
+        GL_SB(); mma((NSUB - 1) & 1); GL_SB();
+        cur ^= 1;
+    }
+#undef GL_SB
+#undef GL_WAIT_VM0
+    gp_epilogue<WGM, WGN, TM, TN, EPI, BUF, true>(g, acc, smem_f, m0, n0);      // 2 buffers x BUF bf16 = BUF floats
+}
+
+template <int WGM, int WGN, int TM, int TN, int EPI>
+static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
+    const int n_tiles = tiles_m * tiles_n;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;
+    auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI>;
+    static DynLdsSlots slots;
+    ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+}
+
+}  // namespace pk
+#endif  // PK_GEMM_BF16_GLDS_HPP

@@ -27,7 +27,9 @@ typedef float gp_f32x16 __attribute__((ext_vector_type(16)));
 // Epilogue shared by the GEMM kernels of this directory (bias, ReLU, SiLU, residual + alpha*y, GLU, sigma column layout) on the
 // accumulators of a WGM x WGN grid of waves, each holding TM x TN 32x32 tiles.  `smem` is the kernel's staging memory (free by now),
 // CAP its size in floats: the wide path turns the C tile row-major through it (in row bands when it does not fit).
-template <int WGM, int WGN, int TM, int TN, int EPI, int CAP_FLOATS>
+// RS_PER_PASS: the residual rows of a band are requested at the start of that band's pass instead of all up front (tiles of 256 rows:
+// NCH = 32 chunks per thread would otherwise hold 128 VGPRs of residual beside the accumulators).
+template <int WGM, int WGN, int TM, int TN, int EPI, int CAP_FLOATS, bool RS_PER_PASS = false>
 __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[TM][TN], float *smem, int m0, int n0) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
@@ -101,8 +103,10 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
                 if constexpr (EPI == EPI_GLU) bg[e] = g.bias[g.N + col0 + e];
             }
         }
-        float4 rs[NCH];
-        if constexpr (EPI == EPI_RESID) {
+        constexpr int NRS = RS_PER_PASS ? NCH / NPASS : NCH;
+        static_assert(!RS_PER_PASS || NCH % NPASS == 0, "chunks must split evenly over the passes");
+        float4 rs[NRS];
+        if constexpr (EPI == EPI_RESID && !RS_PER_PASS) {
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 int row = m0 + rl0 + q * RSTEP;
@@ -112,6 +116,14 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
         }
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
+        if constexpr (EPI == EPI_RESID && RS_PER_PASS) {
+#pragma unroll
+            for (int q = 0; q < NRS; ++q) {
+                int row = m0 + rl0 + (pass * NRS + q) * RSTEP;
+                row = row < g.M ? row : g.M - 1;
+                rs[q] = col_ok ? *reinterpret_cast<const float4 *>(g.resid + (int64_t)row * g.ldr + col0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
         __syncthreads();                                            // every wave is done reading its last fragments / the previous band
         {
             const int lc = lane & 31, lr = 4 * (lane >> 5);
@@ -148,7 +160,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
                 }
             }
             float rsv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (EPI == EPI_RESID) { rsv[0] = rs[q].x; rsv[1] = rs[q].y; rsv[2] = rs[q].z; rsv[3] = rs[q].w; }
+            if constexpr (EPI == EPI_RESID) { const float4 &rr = rs[RS_PER_PASS ? q - pass * NRS : q]; rsv[0] = rr.x; rsv[1] = rr.y; rsv[2] = rr.z; rsv[3] = rr.w; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = v[e];

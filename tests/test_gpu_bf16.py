@@ -56,6 +56,37 @@ def test_bf16_gemm_against_float64(M, N, K, epi):
     assert np.all(err <= 2e-6 * mag + 1e-6), f"max err {err.max():.3e} (bound {float((2e-6 * mag + 1e-6).max()):.3e})"
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(2048, 512, 128, "none"), (4096, 4096, 1024, "silu"), (12032, 1024, 4096, "resid"), (12032, 3072, 1024, "none"),
+                                       (2500, 1024, 1024, "glu"), (3000, 1028, 512, "relu"), (8064, 2048, 512, "silu"), (2304, 1024, 256, "resid")])
+def test_bf16_glds_gemm_against_float64(M, N, K, epi):
+    """The direct-to-LDS kernel (gemm_bf16_glds.hpp: activations already bf16 in HBM, XOR-swizzled LDS image, 256-row tiles): every tile
+    variant the dispatch can pick (wide / narrow outputs, GLU, ragged M and N edges) against a float64 product of the same rounded operands."""
+    from parakeet_cpp_amd import capi
+    rng = np.random.default_rng(7 * M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    rows = 2 * N if epi == "glu" else N
+    W = (rng.standard_normal((rows, K)) / np.sqrt(K)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(rows)).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32) if epi == "resid" else None
+    got = capi.diag_gemm(A, W, bias, epi=epi, resid=resid, alpha=0.5, bf16=True, a16=True)
+    Aq, Wq = bf16_round(A).astype(np.float64), bf16_round(W).astype(np.float64)
+    acc = Aq @ Wq.T + bias
+    mag = np.abs(Aq) @ np.abs(Wq.T) + np.abs(bias)
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    if epi == "relu":
+        want = np.maximum(acc, 0)
+    elif epi == "silu":
+        want = acc * sig(acc)
+    elif epi == "resid":
+        want = resid + 0.5 * acc
+    elif epi == "glu":
+        want, mag = acc[:, :N] * sig(acc[:, N:]), mag[:, :N] + mag[:, N:]
+    else:
+        want = acc
+    err = np.abs(got - want)
+    assert np.all(err <= 2e-6 * mag + 1e-6), f"max err {err.max():.3e} (bound {float((2e-6 * mag + 1e-6).max()):.3e}) at {np.unravel_index(err.argmax(), err.shape)}"
+
+
 def close(got, want, what):
     d, mx = np.abs(got - want), np.abs(want).max()
     print(f"{what}: GPU bf16 vs oracle bf16: max {d.max():.2e} mean {d.mean():.2e} (max|x| {mx:.2f})")
