@@ -104,7 +104,9 @@ void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const fl
 // columns of (q+v) P^T WITHOUT rel_shift (:215-224), masked to the [left, right] context (:226-247).  ctx[S*c][d].
 void launch_stream_attention(const float *qkv_new, const float *kcache, const float *vcache, int cache_rows, int S, int c, int nc, int d,
                              int n_heads, const float *pos /*[P][d]*/, int P, const float *bias_u, const float *bias_v, int att_left,
-                             int att_right, float *ctx, hipStream_t s);
+                             int att_right, float *ctx, hipStream_t s, float *cache_k_out = nullptr, float *cache_v_out = nullptr, int keep_max = 0);
+// (cache_k_out / cache_v_out set: the same launch also rotates the K / V caches of every (stream, head) into those buffers -- the last
+//  min(keep_max, nc + c) rows of [cache ; new], what two launch_stream_cache_update calls would write)
 // new cache = the last min(keep_max, nc + c) rows of [cache(nc rows) ; new(c rows)]  (:193-209); row stride of both caches: cache_rows*d
 void launch_stream_cache_update(const float *cache_in, int nc, const float *qkv_new, int col0, int S, int c, int d, int cache_rows,
                                 int keep_max, float *cache_out, hipStream_t s);

@@ -8,14 +8,30 @@
 
 namespace pk {
 
+// Blocks (stream * head, query row i < c): the attention of that row.  Blocks with blockIdx.y == c (when cache_k_out is set): the cache
+// rotation of (stream, head) -- new cache = the last `keep` rows of [cache ; this chunk's k / v] (:193-209) written into the OTHER cache
+// buffer, so it runs beside the attention blocks that still read the old one: one launch instead of three per layer.
 __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__restrict__ qkv, const float *__restrict__ kcache,
                                                               const float *__restrict__ vcache, int cache_rows, int c, int nc, int d, int H,
                                                               const float *__restrict__ pos, int P, const float *__restrict__ bias_u,
                                                               const float *__restrict__ bias_v, int att_left, int att_right, float scale,
-                                                              float *__restrict__ ctx) {
+                                                              float *__restrict__ ctx, float *__restrict__ cache_k_out,
+                                                              float *__restrict__ cache_v_out, int keep) {
     extern __shared__ float sm[];                                   // [hd] q+u, [hd] q+v, [kv] probabilities
     const int hd = d / H, kv = nc + c;
     const int sidx = blockIdx.x / H, h = blockIdx.x % H, i = blockIdx.y, lane = threadIdx.x;
+    if (i == c) {                                                   // cache rotation of this (stream, head): rows r <- row nc + c - keep + r of [cache ; new]
+        const int hd4 = hd / 4;
+        for (int idx = lane; idx < keep * hd4; idx += 64) {
+            const int r = idx / hd4, e4 = idx % hd4, j = kv - keep + r;
+            const int64_t src_c = ((int64_t)sidx * cache_rows + j) * d + h * hd + 4 * e4;
+            const int64_t src_n = ((int64_t)sidx * c + (j - nc)) * 3 * d + h * hd + 4 * e4;
+            const int64_t dst = ((int64_t)sidx * cache_rows + r) * d + h * hd + 4 * e4;
+            *reinterpret_cast<float4 *>(cache_k_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(kcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + d);
+            *reinterpret_cast<float4 *>(cache_v_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(vcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + 2 * d);
+        }
+        return;
+    }
     float *qu = sm, *qv = sm + hd, *pr = sm + 2 * hd;
     const float *qrow = qkv + ((int64_t)sidx * c + i) * 3 * d + h * hd;
     for (int e = lane; e < hd; e += 64) {
@@ -34,11 +50,14 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
     const int abs_pos = kv - c + i;
     float m = -__builtin_huge_valf();
     for (int j = lane; j < kv; j += 64) {
-        const float *kr = krow(j), *pp = pos + (int64_t)(off + j) * d + h * hd;
+        // 16-byte loads of the key / position rows (each lane walks its own row); the chains stay sequential in e
+        const float4 *kr = reinterpret_cast<const float4 *>(krow(j)), *pp = reinterpret_cast<const float4 *>(pos + (int64_t)(off + j) * d + h * hd);
+        const float4 *qu4 = reinterpret_cast<const float4 *>(qu), *qv4 = reinterpret_cast<const float4 *>(qv);
         float cs = 0.0f, ps = 0.0f;
-        for (int e = 0; e < hd; ++e) {
-            cs = __builtin_fmaf(qu[e], kr[e], cs);
-            ps = __builtin_fmaf(qv[e], pp[e], ps);
+        for (int e = 0; e < hd / 4; ++e) {
+            const float4 kk = kr[e], p4 = pp[e], a = qu4[e], bq = qv4[e];
+            cs = __builtin_fmaf(a.x, kk.x, cs); cs = __builtin_fmaf(a.y, kk.y, cs); cs = __builtin_fmaf(a.z, kk.z, cs); cs = __builtin_fmaf(a.w, kk.w, cs);
+            ps = __builtin_fmaf(bq.x, p4.x, ps); ps = __builtin_fmaf(bq.y, p4.y, ps); ps = __builtin_fmaf(bq.z, p4.z, ps); ps = __builtin_fmaf(bq.w, p4.w, ps);
         }
         float sc = (cs + ps) * scale;                               // :226
         const int dist = abs_pos - j;
@@ -65,12 +84,14 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
 
 void launch_stream_attention(const float *qkv_new, const float *kcache, const float *vcache, int cache_rows, int S, int c, int nc, int d,
                              int n_heads, const float *pos, int P, const float *bias_u, const float *bias_v, int att_left, int att_right,
-                             float *ctx, hipStream_t s) {
+                             float *ctx, hipStream_t s, float *cache_k_out, float *cache_v_out, int keep_max) {
     const int hd = d / n_heads;
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t lds = (size_t)(2 * hd + nc + c) * sizeof(float);
-    hipLaunchKernelGGL(stream_attention_kernel, dim3(S * n_heads, c), dim3(64), lds, s, qkv_new, kcache, vcache, cache_rows, c, nc, d, n_heads, pos,
-                       P, bias_u, bias_v, att_left, att_right, scale, ctx);
+    const int kv = nc + c, keep = kv > keep_max ? keep_max : kv;
+    const bool rotate = cache_k_out && cache_v_out && keep > 0;
+    hipLaunchKernelGGL(stream_attention_kernel, dim3(S * n_heads, c + (rotate ? 1 : 0)), dim3(64), lds, s, qkv_new, kcache, vcache, cache_rows, c, nc, d,
+                       n_heads, pos, P, bias_u, bias_v, att_left, att_right, scale, ctx, rotate ? cache_k_out : nullptr, rotate ? cache_v_out : nullptr, keep);
 }
 
 __global__ void stream_cache_update_kernel(const float *__restrict__ cache_in, int nc, const float *__restrict__ qkv, int col0, int c, int d,

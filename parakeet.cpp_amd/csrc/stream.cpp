@@ -149,10 +149,11 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     const float *ptab = pos_table(Tp);
     const int64_t rows = (int64_t)S * c;
     const int cache_rows = left_ > 0 ? left_ : 1;
+    bool ffn1_norm_done = false;
     for (int l = 0; l < cfg.num_layers; ++l) {
         const LayerW &L = m_.layers[l];
         LayerState &Ls = *layers_[l];
-        m_.ffn(ws_, L, false, rows, st);                                                               // ffn1_ (:294)
+        m_.ffn(ws_, L, false, rows, st, ffn1_norm_done);                                               // ffn1_ (:294)
         // StreamingConformerAttention::forward_cached (:162-272)
         launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, st);
         {
@@ -160,10 +161,9 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
             m_.run_gemm("attn_qkv", g, EPI_NONE, st);                                                 // natural columns (no sigma layout here)
         }
         const float *kc = Ls.k[Ls.cur].as<float>(), *vc = Ls.v[Ls.cur].as<float>();
+        // attention of the chunk's rows + (same launch, extra blocks) the rotation of the K / V caches into the other buffer pair
         launch_stream_attention(ws_.qkv.as<float>(), kc, vc, cache_rows, S, c, Ls.n_kv, d, cfg.num_heads, ptab + (size_t)l * P * d, P, L.pos_u, L.pos_v,
-                                left_, right_, ws_.ctx.as<float>(), st);
-        launch_stream_cache_update(kc, Ls.n_kv, ws_.qkv.as<float>(), d, S, c, d, cache_rows, left_, Ls.k[Ls.cur ^ 1].as<float>(), st);
-        launch_stream_cache_update(vc, Ls.n_kv, ws_.qkv.as<float>(), 2 * d, S, c, d, cache_rows, left_, Ls.v[Ls.cur ^ 1].as<float>(), st);
+                                left_, right_, ws_.ctx.as<float>(), st, Ls.k[Ls.cur ^ 1].as<float>(), Ls.v[Ls.cur ^ 1].as<float>(), left_);
         Ls.cur ^= 1;
         Ls.n_kv = (Ls.n_kv + c > left_) ? left_ : Ls.n_kv + c;
         {
@@ -185,7 +185,12 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
             m_.run_gemm("conv_pw2_resid", g, EPI_RESID, st);
         }
         m_.ffn(ws_, L, true, rows, st);                                                                // ffn2_
-        launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, st);                                  // final_norm_
+        if (l + 1 < cfg.num_layers) {            // final_norm_ and the next block's ffn1_ norm in one pass over the rows (as the offline encoder)
+            launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, m_.layers[l + 1].ffn1_ng, m_.layers[l + 1].ffn1_nb, 1e-5f, x, n, st);
+            ffn1_norm_done = true;
+        } else {
+            launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, st);                              // final_norm_
+        }
     }
     PK_CHECK_LAUNCH();
     return c;
