@@ -72,7 +72,7 @@ class Engine {   // owns one pk_model; shared by Transcriber and TDTTranscriber
     }
 
     // New (the reference is single-device, README.md:513): one replica per GPU of this node, clips dealt to the devices in batches
-    // (pk_group: weights broadcast and results gathered over RCCL).  Empty list = every visible device.
+    // (pk_group: one replica and one host thread + two-stream pipeline per device, no collective).  Empty list = every visible device.
     void to_all_gpus(const std::vector<int> &devices = {}) {
         pk_group_free(g_);
         g_ = nullptr;
