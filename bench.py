@@ -256,6 +256,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = "WORLD_SIZE" in os.environ          # under a launcher the collectives run even at world size 1 (same code path as at 8)
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): the two must agree")
     n_gpus = world
@@ -274,12 +275,12 @@ def main():
     if capi.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, {capi.device_count()} visible")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -334,7 +335,7 @@ def main():
             if L.pk_batch_margins(batch, back, mg_.ctypes.data_as(capi.f32p)) == 0:
                 timed_margin = min(timed_margin, float(mg_[:n_.value].min()))
     per_rank_s = [elapsed]
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         allr = torch.zeros(world, dtype=torch.float64, device="cuda")
         dist.all_gather_into_tensor(allr, tt)                          # RCCL: every rank's own wall time of the timed region
@@ -444,7 +445,7 @@ def main():
                        "clips_per_step_per_gpu": args.batch, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{n_gpus} (utterance shards, no data-path collective)",
                        "decode_group": group, "decode_loop": args.decode_loop, "decode_overlap": overlap},
             "ms_per_step_per_rank": [round(x / args.steps * 1e3, 3) for x in per_rank_s],
-            "collective_ranks": (dist.get_world_size() if world > 1 else 1), "collective_backend": ("nccl (RCCL)" if world > 1 else None),
+            "collective_ranks": (dist.get_world_size() if use_dist else 1), "collective_backend": ("nccl (RCCL)" if use_dist else None),
             "sustained": sustained,
             # smallest top-1 / top-2 label log-prob margin over every decision of the timed runs read back: how far the closest greedy
             # decision was from another token (the early warning of the tolerance-class bf16 mode)
@@ -522,7 +523,7 @@ def main():
 
     L.pk_batch_free(batch)
     model.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if exit_code[0]:
         sys.exit(exit_code[0])
