@@ -1260,6 +1260,8 @@ void orc_ctc_greedy_boosted(const float *logp, int B, int T, int V, int blank_id
 /* ------------------------------------------------------------------------- */
 typedef struct {
     int L, Hp, J, V, D, de;
+    int bf16;   /* gemm_bf16 mode: the decode products take bf16 weights and bf16-stored h' / z (kernels/decode_gemv_bf16.hip); the layer-0
+                 * input projection stays fp32 (the device reads it from the fp32 table g1 = W_ih0 E + b) */
     orc_tensor *embed, *wih[4], *bih[4], *whh[4];
     orc_tensor *we, *be, *wp, *bp, *wl, *bl, *wd, *bd;
 } dec_weights;
@@ -1298,6 +1300,12 @@ static int dec_weights_get(orc_model *m, dec_weights *w, int rnnt) {
     for (int l = 0; l < w->L; ++l) { wt_of(w->wih[l]); wt_of(w->whh[l]); }
     wt_of(w->we); wt_of(w->wp); wt_of(w->wl);
     if (w->wd) wt_of(w->wd);
+    w->bf16 = c->gemm_bf16 && (w->Hp % 32 == 0) && (w->J % 32 == 0);
+    if (w->bf16) {
+        for (int l = 0; l < w->L; ++l) { wt16_of(w->wih[l]); wt16_of(w->whh[l]); }
+        wt16_of(w->wp); wt16_of(w->wl);
+        if (w->wd) wt16_of(w->wd);
+    }
     return 0;
 }
 
@@ -1307,8 +1315,9 @@ static void predict_step(const dec_weights *w, int token, float *h /*[L][Hp]*/, 
     float *gi = scratch, *gh = scratch + G;
     const float *in = w->embed->data + (int64_t)token * Hp; /* Embedding lookup; blank row is zeros by training (src/tdt.cpp:56-57) */
     for (int l = 0; l < w->L; ++l) {
-        gemm_core(1, G, Hp, in, Hp, w->wih[l]->wt, G, gi, G, 0);
-        gemm_core(1, G, Hp, h + l * Hp, Hp, w->whh[l]->wt, G, gh, G, 0);
+        /* bf16 mode: h is stored rounded (below), so the operands are already bf16 values; only the weights change */
+        gemm_core(1, G, Hp, in, Hp, (w->bf16 && l > 0) ? w->wih[l]->wt16 : w->wih[l]->wt, G, gi, G, 0);
+        gemm_core(1, G, Hp, h + l * Hp, Hp, w->bf16 ? w->whh[l]->wt16 : w->whh[l]->wt, G, gh, G, 0);
         for (int j = 0; j < Hp; ++j) {
             /* gates = input_proj(x) + hidden_proj(h); chunk(4): i, f, g, o */
             const float gi_ = (gi[j] + w->bih[l]->data[j]) + gh[j];
@@ -1318,7 +1327,7 @@ static void predict_step(const dec_weights *w, int token, float *h /*[L][Hp]*/, 
             const float ig = orc_sigmoidf(gi_), fg = orc_sigmoidf(gf_), gg = orc_tanhf(gg_), og = orc_sigmoidf(go_);
             const float cn = fg * c[l * Hp + j] + ig * gg;          /* c_new = f*c + i*g   (separate mul, add) */
             c[l * Hp + j] = cn;
-            h[l * Hp + j] = og * orc_tanhf(cn);
+            h[l * Hp + j] = w->bf16 ? bf16_round(og * orc_tanhf(cn)) : og * orc_tanhf(cn);
         }
         in = h + l * Hp;
     }
@@ -1328,12 +1337,13 @@ static void predict_step(const dec_weights *w, int token, float *h /*[L][Hp]*/, 
 /* TDTJoint::forward (src/tdt.cpp:15-24) on a pre-projected encoder frame ep = enc_proj(enc_t) (bias included) */
 static void joint_hidden(const dec_weights *w, const float *ep, const float *pred, float *z, float *scratch) {
     const int J = w->J;
-    gemm_core(1, J, w->Hp, pred, w->Hp, w->wp->wt, J, scratch, J, 0);
+    gemm_core(1, J, w->Hp, pred, w->Hp, w->bf16 ? w->wp->wt16 : w->wp->wt, J, scratch, J, 0);
     for (int j = 0; j < J; ++j) {
         float pj = scratch[j];
         if (w->bp) pj = pj + w->bp->data[j];
         const float s = ep[j] + pj;
         z[j] = s > 0.0f ? s : 0.0f;
+        if (w->bf16) z[j] = bf16_round(z[j]);                      /* z is stored as bf16: the heads' operand */
     }
 }
 
@@ -1383,10 +1393,10 @@ static int tdt_greedy_ex(orc_model *m, const float *enc, int B, int T, int max_t
                 memcpy(sh, h, (size_t)w.L * Hp * 2 * sizeof(float));      /* saved_states = states  :70 */
                 predict_step(&w, token, h, cc, pred, scratch);
                 joint_hidden(&w, ept, pred, z, scratch);
-                gemm_core(1, V, J, z, J, w.wl->wt, V, lab, V, 0);
+                gemm_core(1, V, J, z, J, w.bf16 ? w.wl->wt16 : w.wl->wt, V, lab, V, 0);
                 for (int i = 0; i < V; ++i) lab[i] = lab[i] + w.bl->data[i];
                 log_softmax_row(lab, V, lab_lp);
-                gemm_core(1, D, J, z, J, w.wd->wt, D, dur, D, 0);
+                gemm_core(1, D, J, z, J, w.bf16 ? w.wd->wt16 : w.wd->wt, D, dur, D, 0);
                 for (int i = 0; i < D; ++i) dur[i] = dur[i] + w.bd->data[i];
                 log_softmax_row(dur, D, dur_lp);
                 if (nsteps == 0 && first_label_logp) memcpy(first_label_logp + (int64_t)b * V, lab_lp, (size_t)V * sizeof(float));
@@ -1491,7 +1501,7 @@ int orc_rnnt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens
                 memcpy(sh, h, (size_t)w.L * Hp * 2 * sizeof(float));
                 predict_step(&w, token, h, cc, pred, scratch);
                 joint_hidden(&w, ept, pred, z, scratch);
-                gemm_core(1, V, J, z, J, w.wl->wt, V, lab, V, 0);
+                gemm_core(1, V, J, z, J, w.bf16 ? w.wl->wt16 : w.wl->wt, V, lab, V, 0);
                 for (int i = 0; i < V; ++i) lab[i] = lab[i] + w.bl->data[i];
                 log_softmax_row(lab, V, lab_lp);
                 const int k = argmax_first(lab_lp, V);

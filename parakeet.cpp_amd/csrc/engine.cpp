@@ -300,11 +300,16 @@ void Model::upload_weights() {
         dec.whh[l] = upload_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp});
         dec_whh_s[l] = upload_sigma(host_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp}).f32(), 4 * Hp, Hp);
         dec_wih_s[l] = l ? upload_sigma(host_tensor(q + "input_proj_.weight", {4 * Hp, Hp}).f32(), 4 * Hp, Hp) : nullptr;
+        if (cfg.gemm_bf16) {               // the decode GEMVs of the tolerance-class mode take bf16 weights (decode_gemv_bf16.hip)
+            dec_whh16[l] = upload_gemm_weight(host_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp}).f32(), (size_t)4 * Hp * Hp);
+            dec_wih16[l] = l ? upload_gemm_weight(host_tensor(q + "input_proj_.weight", {4 * Hp, Hp}).f32(), (size_t)4 * Hp * Hp) : nullptr;
+        }
     }
     const std::string jp = cfg.joint_prefix;
     dec.we = upload_gemm_tensor(jp + "enc_proj_.weight", {J, d}); dec.be = upload_tensor(jp + "enc_proj_.bias", {J});
     dec.wp = upload_tensor(jp + "pred_proj_.weight", {J, Hp});
     dec_wp_s = upload_sigma(host_tensor(jp + "pred_proj_.weight", {J, Hp}).f32(), J, Hp);
+    if (cfg.gemm_bf16) dec_wp16 = upload_gemm_weight(host_tensor(jp + "pred_proj_.weight", {J, Hp}).f32(), (size_t)J * Hp);
     dec.bp = (cfg.joint_pred_bias && st_->find(jp + "pred_proj_.bias")) ? upload_tensor(jp + "pred_proj_.bias", {J}) : nullptr;
     {
         std::vector<float> w((size_t)(V + D) * J), b((size_t)(V + D));
@@ -318,6 +323,7 @@ void Model::upload_weights() {
         wld = upload(w.data(), w.size());
         bld = upload(b.data(), b.size());
         wld_s = upload_sigma(w.data(), V + D, J);
+        if (cfg.gemm_bf16) wld16 = upload_gemm_weight(w.data(), w.size());
     }
     // g1 = E W_ih0^T + b  ([V][4Hp]) on the MFMA GEMM: the same natural-k chains the per-step projection would run
     float *g1 = dev_alloc((size_t)V * 4 * Hp);
@@ -778,6 +784,27 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     }
     for (int l = 0; l < L; ++l) P.cell[l].nt_weights = dec_nt_weights;
     P.act.nt_weights = P.heads.nt_weights = dec_nt_weights;
+    // Tolerance-class mode: the same phases on bf16 operands (decode_gemv_bf16.hip).  h / h' / z are bf16 arrays in the same buffers (natural k
+    // order), the weights are the bf16 copies; the layer-0 input projection stays the fp32 table g1.  Specification: the oracle's gemm_bf16 mode.
+    const bool dec16 = cfg.gemm_bf16 && Hp % 32 == 0 && J % 32 == 0 && wld16;
+    if (dec16) {
+        st.h_bf16 = 1;
+        P.st.h_bf16 = 1;
+        __bf16 *h16 = reinterpret_cast<__bf16 *>(w.h.p), *hn16 = reinterpret_cast<__bf16 *>(w.hn.p);
+        for (int l = 0; l < L; ++l) {
+            SkinnyArgs &a = P.cell[l];
+            a.X = reinterpret_cast<const float *>(h16 + (size_t)l * B * Hp);
+            a.W = dec_whh16[l];
+            a.out = reinterpret_cast<float *>(hn16 + (size_t)l * B * Hp);
+            if (l > 0) {
+                a.X2 = reinterpret_cast<const float *>(hn16 + (size_t)(l - 1) * B * Hp);
+                a.W2 = dec_wih16[l];
+            }
+        }
+        P.act.X = reinterpret_cast<const float *>(hn16 + (size_t)(L - 1) * B * Hp);
+        P.act.W = dec_wp16;
+        P.heads.W = wld16;
+    }
     // ONE launch for the whole loop (kernels/decode_persist.hip): implemented, bit-identical to the per-phase loop (tests/test_gpu_decode.py),
     // and NOT faster on this hardware -- opt-in: pk_model_set_decode_loop(m, PK_DECODE_LOOP_PERSISTENT).  Measured in round 2 (profiles/r02_decode_persistent.md): the
     // grid barrier between the four all-to-all phases of a step costs ~20 us with a single system-scope arrival counter (160 arrivals
@@ -785,7 +812,7 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     // resident part of the grid spins while the rest waits for CU slots.  Eligible when the decide scratch is small enough for a
     // workgroup to sit beside the encoder's GEMM workgroups, at most two LSTM layers, no phrase boosting, no carried streaming state.
     {
-        const bool want = decode_loop == PK_DECODE_LOOP_PERSISTENT;
+        const bool want = decode_loop == PK_DECODE_LOOP_PERSISTENT && !dec16;     // (the single-launch loop exists for the fp32 phases only)
         const int G = Hp / 4;
         if (want && !boost_on && !keep_state && Hp % 4 == 0 && G >= 1 && G <= 200 && L <= 2 && tdt_persistent_lds_bytes(st) <= 12 * 1024) {
             P.bar = reinterpret_cast<unsigned *>(st.done_count + 1);           // two spare words behind the per-utterance state
@@ -797,12 +824,13 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         }
     }
     const int chunk = 16;            // host polls "all finished" every 16 steps (4 / 64 / 128 measured: no difference, profiles/r02_decode_persistent.md)
+    auto skinny = [&](const SkinnyArgs &a, int epi) { if (dec16) launch_skinny_gemm_bf16(a, epi, s); else launch_skinny_gemm(a, epi, s); };
     auto enqueue_step = [&]() {
         for (int l = 0; l < L; ++l) {
-            KL("lstm_hh_cell", l ? 2.0 * f_hh : f_hh, 0.0, launch_skinny_gemm(P.cell[l], SK_CELL, s));
+            KL("lstm_hh_cell", l ? 2.0 * f_hh : f_hh, 0.0, skinny(P.cell[l], SK_CELL));
         }
-        KL("joint_pred_act", f_pp, 0.0, launch_skinny_gemm(P.act, SK_ACT, s));
-        KL("joint_heads_gemv", f_hd, 0.0, launch_skinny_gemm(P.heads, SK_BIAS, s));
+        KL("joint_pred_act", f_pp, 0.0, skinny(P.act, SK_ACT));
+        KL("joint_heads_gemv", f_hd, 0.0, skinny(P.heads, SK_BIAS));
         KL("tdt_decide", 0.0, 0.0, launch_tdt_decide(st, s));
     };
     // PK_DECODE_LOOP_GRAPH: the chunk of 16 steps is captured once into a hipGraph (every argument is step-invariant) and replayed.

@@ -90,6 +90,8 @@ class Model {
     const float *wld = nullptr, *bld = nullptr;     // [V+D][J] label_proj rows then duration_proj rows (+ biases)
     // sigma-K-layout copies used by the decode GEMVs
     const float *wld_s = nullptr, *dec_wp_s = nullptr, *dec_whh_s[4] = {}, *dec_wih_s[4] = {};
+    // bf16 copies (natural k order) for the decode GEMVs of the tolerance-class mode (kernels/decode_gemv_bf16.hip); null in fp32 mode
+    const float *wld16 = nullptr, *dec_wp16 = nullptr, *dec_whh16[4] = {}, *dec_wih16[4] = {};
 
     // relative-position tables: sinusoidal pe [2T-1][d] (src/encoder.cpp:9-30, host float math) and the
     // per-layer pos_proj_(pe) [L][2T-1][d]; they depend on (T, weights) only, so they are rebuilt when T changes.

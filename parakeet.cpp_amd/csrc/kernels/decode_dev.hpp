@@ -3,6 +3,7 @@
 #pragma once
 #include "../pk_devmath.h"
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace pk {
 
@@ -269,28 +270,70 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     constexpr int kMaxCarry = 12;                                  // L * Hp <= 12 * 256
     float hcar[kMaxCarry], ccar[kMaxCarry];
     const int n_state = st.L * st.Hp;
+    // tolerance-class mode (decode_gemv_bf16.hip): h / h' are bf16 arrays [L][B][Hp]; they are committed as Hp / 2 float-sized words per row
+    const int hp_h = st.h_bf16 ? st.Hp / 2 : st.Hp, n_h = st.L * hp_h;
     if constexpr (!COH) {                                          // (persistent kernel: copied at commit time instead -- 24 fewer live
 #pragma unroll                                                     //  registers, it has to fit beside the encoder's GEMM waves)
         for (int q = 0; q < kMaxCarry; ++q) {
             const int i = tid + 256 * q;
-            if (i < n_state) {
-                const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
-                hcar[q] = st.hn[o];
-                ccar[q] = st.cn[o];
-            }
+            if (i < n_state) ccar[q] = st.cn[((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp)];
+            if (i < n_h) hcar[q] = st.hn[((int64_t)(i / hp_h) * st.B + b) * hp_h + (i % hp_h)];
         }
     }
     float m = -__builtin_huge_valf();
-    for (int i = tid; i < VD; i += 256) {
-        const float v = dd_ldf<COH>(lg + i);
-        x[i] = v;
-        if (i < st.V) m = fmaxf(m, v);
+    // The logits row with ALL of a thread's loads in flight at once (one L2 / HBM round trip): written as a plain loop, every iteration
+    // waited for its own trip -- 33 dependent trips at vocabulary 8193, 26 us for ~3 us of arithmetic (round 3).  Rows longer than 33 x 256
+    // (and the register-capped persistent kernel) go in batches of 8.
+    auto stage_row = [&](auto nq_tag) {
+        constexpr int NQ = decltype(nq_tag)::value;
+        float v[NQ];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int i = tid + 256 * u;
+            v[u] = dd_ldf<COH>(lg + (i < VD ? i : VD - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int i = tid + 256 * u;
+            if (i < VD) {
+                x[i] = v[u];
+                if (i < st.V) m = fmaxf(m, v[u]);
+            }
+        }
+    };
+    if (!COH && VD <= 256 * 5) {
+        stage_row(std::integral_constant<int, 5>{});
+    } else if (!COH && VD <= 256 * 33) {
+        stage_row(std::integral_constant<int, 33>{});
+    } else {
+        for (int i0 = tid; i0 < VD; i0 += 256 * 8) {
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                v8[u] = dd_ldf<COH>(lg + (i < VD ? i : VD - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < VD) {
+                    x[i] = v8[u];
+                    if (i < st.V) m = fmaxf(m, v8[u]);
+                }
+            }
+        }
     }
     m = wave_max64(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    for (int i = tid; i < st.V; i += 256) e[i] = dexpf_nonpos(x[i] - m);
+    for (int i0 = tid; i0 < st.V; i0 += 256 * 4) {                 // (4 independent LDS reads / exp chains per trip)
+        float t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + 256 * u; t4[u] = x[i < st.V ? i : st.V - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + 256 * u; if (i < st.V) e[i] = dexpf_nonpos(t4[u] - m); }
+    }
     if constexpr (BOOST) {                                         // get_boosted_tokens: union of the children of the active states
         for (int a = 0; a < n_act; ++a) {
             const int sn = acts[a];
@@ -304,7 +347,13 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     __syncthreads();
     if (wave == 0) {
         float p = 0.0f;
-        for (int i = lane; i < st.V; i += 64) p = p + e[i];
+        for (int i0 = lane; i0 < st.V; i0 += 64 * 8) {              // the canonical strided partial sum, its LDS reads 8 at a time; the adds stay in index order
+            float t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; t8[u] = e[i < st.V ? i : st.V - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; if (i < st.V) p = p + t8[u]; }
+        }
         const float lse = dlogf(wave_sum64(p));
         if (lane == 0) red[4] = lse;
     }
@@ -329,11 +378,20 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     // top-1 / top-2 margin report (st.margin); the decision itself is the first-maximum argmax exactly as before.
     float second = -__builtin_huge_valf();
     int bi = 0x7fffffff;
-    for (int i = tid; i < st.V; i += 256) {
-        float l = (x[i] - m) - lse;
-        if constexpr (BOOST) l = l + (((mask[i >> 5] >> (i & 31)) & 1u) ? st.trie.boost : 0.0f);
-        if (bi == 0x7fffffff || l > best) { second = best; best = l; bi = i; }
-        else second = fmaxf(second, l);
+    for (int i0 = tid; i0 < st.V; i0 += 256 * 4) {
+        float t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + 256 * u; t4[u] = x[i < st.V ? i : st.V - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < st.V) {
+                float l = (t4[u] - m) - lse;
+                if constexpr (BOOST) l = l + (((mask[i >> 5] >> (i & 31)) & 1u) ? st.trie.boost : 0.0f);
+                if (bi == 0x7fffffff || l > best) { second = best; best = l; bi = i; }
+                else second = fmaxf(second, l);
+            }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -426,11 +484,8 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
 #pragma unroll
             for (int q = 0; q < kMaxCarry; ++q) {
                 const int i = tid + 256 * q;
-                if (i < n_state) {
-                    const int64_t o = ((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp);
-                    st.h[o] = hcar[q];
-                    st.c[o] = ccar[q];
-                }
+                if (i < n_state) st.c[((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp)] = ccar[q];
+                if (i < n_h) st.h[((int64_t)(i / hp_h) * st.B + b) * hp_h + (i % hp_h)] = hcar[q];
             }
         }
     }

@@ -1,0 +1,176 @@
+// parakeet.cpp_amd/csrc/kernels/decode_gemv_bf16.hip -- the per-step products of the TDT / RNNT loop in the TOLERANCE-class mode
+// (pk_config.gemm_bf16): bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+//
+// Why (round 3, profiles/r03_decode_overlap_ab.txt, r03_m1_kernel_stats_600m_bf16.md): with the 8193-entry vocabulary of tdt-600m the fp32
+// decode GEMVs (decode_gemv.hip) stream 42 MB of prediction-net and joint weights through L2 per symbol step and are 29 % of the GPU time of
+// the bf16 configuration -- next to an encoder whose products run at bf16 rates.  Here the weights are bf16 (half the bytes), the activations
+// that are only ever GEMV operands (h, h', z) are stored as bf16, and a K = 640 product is 20 MFMAs instead of 160.
+//
+// Specification (= the oracle's gemm_bf16 mode, oracle/pk_oracle.c predict_step / joint_hidden): W_hh, W_ih of the upper LSTM layers,
+// pred_proj and the label / duration heads are rounded to bf16 once; the layer-0 input projection stays the fp32 table g1 = W_ih0 E + b;
+// h' = bf16(o * tanh(c')) (c stays fp32), z = bf16(relu(enc_proj[t] + pred_proj h' [+ b])); every product accumulates in fp32.
+// Accumulation ORDER differs from the oracle's k-ordered chain (MFMA blocks of 32 k): compared within the mode's tolerance.
+//
+// Tiling as decode_gemv.hip: one wavefront per 16 (utterances) x 16 (outputs) tile, a workgroup = one 16-output tile x up to four
+// 16-utterance tiles; lane (row / column l & 15, quarter l >> 4) loads the 8 consecutive k of every 32-k block at 8 (l >> 4) with one 16-byte
+// load per operand per MFMA -- natural layouts, no permutation.  Epilogues: LSTM cell (gates -> c', h'), joint activation, bias.
+#include "../pk_devmath.h"
+#include "kernels.hpp"
+
+namespace pk {
+
+typedef float db_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 db_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int EPI>
+__global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
+    __shared__ float tile[4][16][17];
+    const int nt = blockIdx.x, mgroup = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int m0 = (mgroup * 4 + wave) * 16;
+    if (m0 >= a.B) return;                                       // whole wave out of range (uniform)
+    const __bf16 *X = reinterpret_cast<const __bf16 *>(a.X), *W = reinterpret_cast<const __bf16 *>(a.W);
+    int wrow;
+    if (EPI == SK_CELL) wrow = (col >> 2) * a.Hp + 4 * nt + (col & 3);   // tile columns = (gate, unit): rows g*Hp + j
+    else { wrow = 16 * nt + col; wrow = wrow < a.N ? wrow : a.N - 1; }
+    int xrow = m0 + col;
+    xrow = xrow < a.B ? xrow : a.B - 1;
+    // epilogue operands first (token -> g1 row, c, enc_proj[t_b], bias): their round trips hide under the MFMA chain
+    float e_gi[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_c = 0.0f;
+    float e_ep[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_bias = 0.0f;
+    if (EPI == SK_CELL) {
+        const int b = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
+        if (b < a.B && !a.W2) {
+            const float *gir = a.gi + (int64_t)(a.gi_row ? a.gi_row[b] : b) * a.gi_ld;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_gi[g] = gir[g * a.Hp + j];
+        }
+        if (b < a.B) e_c = a.c[(int64_t)b * a.Hp + j];
+    } else {
+        const int n = 16 * nt + col;
+        if (n < a.N) {
+            if (a.bias) e_bias = a.bias[n];
+            if (EPI == SK_ACT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = m0 + 4 * kq + r;
+                    if (b < a.B) {
+                        int tt = a.t[b];
+                        tt = tt < a.T ? tt : a.T - 1;
+                        e_ep[r] = a.ep[((int64_t)b * a.T + tt) * a.N + n];
+                    }
+                }
+            }
+        }
+    }
+    // one product acc = X W^T over K: chunks of 4 MFMAs (128 k), the next chunk's 8 loads in flight under the current chunk
+    constexpr int CH = 4;
+    auto chain = [&](const __bf16 *xr, const __bf16 *wr) -> db_f32x4 {
+        db_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const db_bf16x8 *xq = reinterpret_cast<const db_bf16x8 *>(xr) + kq, *wq = reinterpret_cast<const db_bf16x8 *>(wr) + kq;   // 32-k block i at [4 i]
+        const int nblk = a.K / 32;
+        db_bf16x8 xa[CH], wa[CH], xb[CH], wb[CH];
+        auto load = [&](db_bf16x8 (&x_)[CH], db_bf16x8 (&w_)[CH], int c0) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int blk = c0 + i < nblk ? c0 + i : nblk - 1;
+                x_[i] = xq[4 * blk];
+                w_[i] = wq[4 * blk];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mma = [&](const db_bf16x8 (&x_)[CH], const db_bf16x8 (&w_)[CH], int c0) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (c0 + i < nblk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_[i], w_[i], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load(xa, wa, 0);
+        for (int c0 = 0; c0 < nblk; c0 += 2 * CH) {
+            if (c0 + CH < nblk) load(xb, wb, c0 + CH);
+            mma(xa, wa, c0);
+            if (c0 + 2 * CH < nblk) load(xa, wa, c0 + 2 * CH);
+            if (c0 + CH < nblk) mma(xb, wb, c0 + CH);
+        }
+        return acc;
+    };
+    db_f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (EPI == SK_CELL && a.W2) {                                // upper LSTM layer: its input projection W_ih h'(l-1) + b_ih, same tile columns
+        int x2row = m0 + col;
+        x2row = x2row < a.B ? x2row : a.B - 1;
+        acc2 = chain(reinterpret_cast<const __bf16 *>(a.X2) + (int64_t)x2row * a.K, reinterpret_cast<const __bf16 *>(a.W2) + (int64_t)wrow * a.K);
+    }
+    const db_f32x4 acc = chain(X + (int64_t)xrow * a.K, W + (int64_t)wrow * a.K);
+    // C/D layout of 16x16: column = lane & 15, row (utterance) = 4 * (lane >> 4) + r
+    if (EPI == SK_BIAS) {
+        const int n = 16 * nt + col;
+        if (n < a.N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = m0 + 4 * kq + r;
+                if (b < a.B) a.out[(int64_t)b * a.ldo + n] = a.bias ? acc[r] + e_bias : acc[r];
+            }
+        }
+    } else if (EPI == SK_ACT) {
+        // z = relu(enc_proj(enc_t) + pred_proj(pred) [+ bp])   src/tdt.cpp:17-18 ; stored as bf16 (it is only ever the heads' operand)
+        const int n = 16 * nt + col;
+        if (n < a.N) {
+            __bf16 *z = reinterpret_cast<__bf16 *>(a.out);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = m0 + 4 * kq + r;
+                if (b >= a.B) continue;
+                float p = acc[r];
+                if (a.bias) p = p + e_bias;
+                const float s = e_ep[r] + p;
+                z[(int64_t)b * a.N + n] = (__bf16)(s > 0.0f ? s : 0.0f);
+            }
+        }
+    } else {
+        // LSTMCell::forward: gates = (W_ih x + b) + W_hh h ; i,f,g,o ; c' = f*c + i*g ; h' = o*tanh(c')
+        const int ul = lane >> 2, jj = lane & 3;
+        const int b = m0 + ul, j = 4 * nt + jj;
+        if (a.W2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][col] = acc2[r];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (b < a.B) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) e_gi[g] = tile[wave][ul][4 * g + jj] + a.bias2[g * a.Hp + j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][col] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (b < a.B) {
+            const float gi_ = e_gi[0] + tile[wave][ul][jj];
+            const float gf_ = e_gi[1] + tile[wave][ul][4 + jj];
+            const float gg_ = e_gi[2] + tile[wave][ul][8 + jj];
+            const float go_ = e_gi[3] + tile[wave][ul][12 + jj];
+            const float ig = dsigmoidf(gi_), fg = dsigmoidf(gf_), gg = dtanhf(gg_), og = dsigmoidf(go_);
+            const float t1 = fg * e_c;
+            const float t2 = ig * gg;
+            const float cnew = t1 + t2;
+            a.cn[(int64_t)b * a.Hp + j] = cnew;
+            reinterpret_cast<__bf16 *>(a.out)[(int64_t)b * a.Hp + j] = (__bf16)(og * dtanhf(cnew));   // h' as bf16: it is only ever a GEMV operand
+        }
+    }
+}
+
+void launch_skinny_gemm_bf16(const SkinnyArgs &a, int epi, hipStream_t s) {
+    const int n_tiles = epi == SK_CELL ? a.Hp / 4 : (a.N + 15) / 16;
+    dim3 grid(n_tiles, (a.B + 63) / 64);
+    switch (epi) {
+    case SK_BIAS: hipLaunchKernelGGL((skinny_gemm_bf16_kernel<SK_BIAS>), grid, dim3(256), 0, s, a); break;
+    case SK_ACT: hipLaunchKernelGGL((skinny_gemm_bf16_kernel<SK_ACT>), grid, dim3(256), 0, s, a); break;
+    case SK_CELL: hipLaunchKernelGGL((skinny_gemm_bf16_kernel<SK_CELL>), grid, dim3(256), 0, s, a); break;
+    default: break;
+    }
+}
+
+}  // namespace pk

@@ -143,6 +143,7 @@ struct TdtState {
     int *token, *t, *nsym, *n_out, *steps, *done, *lens, *done_count;
     int *ids, *start, *end;         // [B][max_tokens]
     float *conf;
+    int h_bf16;                     // tolerance-class mode: h / hn are bf16 arrays (decode_gemv_bf16.hip); c / cn stay fp32
     float *margin;                  // [B] or null: running min over the utterance's decisions of (top-1 - top-2) label log-prob
 };
 void launch_tdt_init(const TdtState &st, hipStream_t s);
@@ -168,6 +169,9 @@ struct SkinnyArgs {
     int nt_weights = 0;            // stream W with non-temporal loads (decode_dev.hpp: NTW)
 };
 void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s);
+// the same products in the tolerance-class mode: X / W / X2 / W2 point to bf16 data in NATURAL k order, the SK_ACT / SK_CELL outputs (z, h') are
+// bf16; K % 32 == 0 (kernels/decode_gemv_bf16.hip)
+void launch_skinny_gemm_bf16(const SkinnyArgs &a, int epi, hipStream_t s);
 
 // the whole greedy loop of a batch in one launch (kernels/decode_persist.hip): the step-invariant arguments of every phase
 struct TdtPersist {
