@@ -73,7 +73,11 @@ typedef struct pk_config {
                                       attention scores, norms and depthwise convs stay fp32.  Needs every such K % 64 == 0.  This mode is
                                       compared with the oracle within a tolerance, never bit for bit; since round 2 it also stores the
                                       activations that exist only as GEMM operands as bf16 (the same rounded values) and evaluates SiLU /
-                                      sigmoid / the attention softmax on the hardware exp2 / rcp (1 ulp fp32). */
+                                      sigmoid / the attention softmax on the hardware exp2 / rcp (1 ulp fp32).  Since round 3 the offline
+                                      attention (head sizes 64 / 128) and the decode loop's GEMVs also take bf16 operands
+                                      (kernels/attention_bf16.hip, decode_gemv_bf16.hip); the specification of the mode is the oracle's
+                                      gemm_bf16 mode.  The streaming path (pk_stream_*) and pk_transformer_* keep fp32
+                                      attention and exact activations in this mode: only their Linear products and decode GEMVs change. */
     char joint_prefix[32];         /* "tdt_joint_." (tdt_ctc.cpp:5-9) or "joint_." (tdt.cpp:28-32) */
     /* encoder-only uses (Sortformer's NEST encoder, src/sortformer.cpp:41-47): vocab_size = 0 loads no prediction net / joint */
     int32_t xscaling;              /* StreamingEncoderConfig::xscaling (streaming_encoder.cpp:402-406, :444-447): x *= sqrt(hidden) after subsampling */
