@@ -18,7 +18,7 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/p
 python tools/rocprof_summary.py $(ls $o/prof600/*/kt_kernel_trace.csv $o/prof600/kt_kernel_trace.csv 2>/dev/null | head -1) $o/kernel_stats_600m_bf16.md > /dev/null 2>&1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc600_fetch -o f -- python bench.py --config tdt-600m --bf16 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0 > $o/pmc600_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc600_write -o w -- python bench.py --config tdt-600m --bf16 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0 > $o/pmc600_write.log 2>&1
-python tools/pmc_hbm.py $o/pmc600_fetch $o/pmc600_write $o/pmc_hbm_600m_bf16.json "gemm_bf16_kernel<4, 2, 1, 2, 2" 12032 4096 2 > /dev/null 2>&1
+python tools/pmc_hbm.py $o/pmc600_fetch $o/pmc600_write $o/pmc_hbm_600m_bf16.json "gemm_bf16_glds_kernel<4, 2, 2, 4, 2" 12032 4096 2 > /dev/null 2>&1
 # raw traces are large: keep the summaries only
 rm -rf $o/prof $o/prof600 $o/pmc_fetch $o/pmc_write $o/pmc600_fetch $o/pmc600_write
 ls -la $o
