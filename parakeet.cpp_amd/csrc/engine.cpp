@@ -409,6 +409,8 @@ void Model::run_gemm(const char *name, const GemmArgs &g, int epi, hipStream_t s
         KL(name, gemm_flops(g, epi), 0.0, launch_gemm_bf16(g, epi, s));
     } else {
         if (g.a_bf16 || g.out_bf16) fail(PK_ERR_INVALID, "%s: bf16 activations outside the bf16 GEMM path", name);
+        if (g.a_sigma && !(g.W_sig && g.M <= kSmallMRows && g.K % 64 == 0))
+            fail(PK_ERR_INVALID, "%s: sigma-K activations need the small-M kernel and a sigma-K weight copy", name);
         KL(name, gemm_flops(g, epi), 0.0, launch_gemm(g, epi, s));
     }
 }

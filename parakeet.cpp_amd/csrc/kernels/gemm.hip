@@ -245,7 +245,7 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
     // up to a few hundred rows (streaming chunks, ONE utterance of up to a minute -- the reference's own benchmark protocol is batch 1):
     // one wavefront per 16x16 tile ((M/16)(N/16) independent waves) instead of a few dozen fat workgroups with a long K loop each.
     // Measured with tools/bench_reference_protocol.py: 10 s clip (M = 126) 6.3 -> 2.9 ms, 30 s (M = 376) 6.7 -> 4.3 ms per encoder pass.
-    if (a.M <= 768 && a.K % 64 == 0) { launch_gemm_smallm(a, epi, s); return; }
+    if (a.M <= kSmallMRows && a.K % 64 == 0) { launch_gemm_smallm(a, epi, s); return; }
     switch (epi) {
     case EPI_NONE: launch_epi<EPI_NONE>(a, s); break;
     case EPI_RELU: launch_epi<EPI_RELU>(a, s); break;

@@ -1,16 +1,26 @@
-// parakeet.cpp_amd/csrc/kernels/gemm_smallm.hip -- the fp32 MFMA GEMM for a HANDFUL of rows (M <= 64): the streaming
-// encoder's products (16 streams x 1-3 frames per chunk against the full 600M-parameter weight set).
+// parakeet.cpp_amd/csrc/kernels/gemm_smallm.hip -- the fp32 MFMA GEMM for a HANDFUL of rows (M <= 768): the streaming
+// encoder's products (16 streams x 1-3 frames per chunk against the full 600M-parameter weight set) and the single-clip path.
 //
 // out[M][N] = epi(A[M][K] * W[N][K]^T + bias), natural-k fma chains (bit-identical to the oracle and to the big-tile kernels).
-// With so few rows the problem is a latency-bound weight stream, not a tile problem: the 64x64-tile kernel leaves N/64
-// workgroups (16 for N = 1024) each walking a K = 4096 chain of 32x32x2 MFMAs -- 150 us.  Here:
-//  * one WAVEFRONT per 16x16 output tile (v_mfma_f32_16x16x4_f32, 40-cycle dependent chain): N/16 x ceil(M/16) independent
-//    workgroups (128 for N = 1024, M = 32), no barriers at all;
-//  * K advances in chunks of 64: the lane (row, quarter) loads one float4 of A and of W per 16 k (coalesced 64-byte row
-//    segments), parks it k-planar in LDS (plane k&3, so that the lane that feeds k = 4s + kq reads four consecutive steps with
-//    one ds_read_b128 -- the same trick as the attention kernel), the loads of the next three chunks are in flight under the
-//    MFMAs of chunk i;
-//  * GLU keeps the value and the gate tile of the same 16 columns in one wave (two interleaved chains).
+// With so few rows the problem is a latency-bound weight stream, not a tile problem: ONE dependent chain of K / 4
+// v_mfma_f32_16x16x4_f32 (8 passes = 32 clocks each) per 16x16 output tile is the floor -- 13.7 us for fc2 of the 600M model
+// (K = 4096) at 2.4 GHz -- so everything else has to stay off that chain:
+//  * one WAVEFRONT per 16x16 output tile, no LDS and no barrier in the K loop.  The first generation of this kernel parked every
+//    64-k chunk k-planar in LDS (ds_write x 32, fence, ds_read_b128 x 8) in front of its 16 MFMAs; with a single wave per
+//    workgroup that round trip sits ON the chain: 1390 clocks per chunk against the 512 of the MFMAs
+//    (profiles/r03_rocprofv3_stream_kernel_stats.md: fc2 37 us).
+//  * operands straight from L2 / HBM with 16-byte loads in the NATURAL layouts: lane (row r = lane & 15, quarter q = lane >> 4) loads
+//    A[r][16 f + 4 q .. + 3] and W[n0 + r][16 f + 4 q .. + 3] -- 64-byte row segments per 16 lanes.  The MFMA wants lane (r, q) to
+//    supply k = 4 s + q for step s, i.e. element e of the four consecutive steps 4 f + e is natural k = 16 f + 4 e + q: the 4 x 4
+//    transpose of what the four lanes (r, 0..3) hold in their four registers.  gfx950 has the instruction for exactly that:
+//    v_permlane16_swap / v_permlane32_swap exchange the odd 16-lane rows of one register with the even rows of another -- two
+//    swaps per register pair, four per float4, eight per 16-k block, issued beside the block's four MFMAs (128 clocks).
+//    (Semantics pinned on the hardware by tools/ubench/permlane_probe.cpp.)
+//  * a register ring of DEPTH = 8 chunks of 64 k (8 loads per chunk and lane; 4 / 2 / 1 when K / 64 is not a multiple of 8):
+//    7 x 512 chain clocks of cover for the weight stream, 56 loads in flight -- below vmcnt's 6-bit limit.
+//  * the row tiles of a column tile (M = 32: two) are waves of ONE workgroup, so they pull the same W lines through the same L1;
+//    GLU: the value and the gate tile of the same 16 columns are two waves (two chains side by side instead of one of double
+//    length), the gate sums cross through LDS once at the end.
 #include "../pk_devmath.h"
 #include "kernels.hpp"
 
@@ -18,98 +28,101 @@ namespace pk {
 
 typedef float sm_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI>
-__global__ __launch_bounds__(64) void gemm_smallm_kernel(GemmArgs g) {
+// 4 x 4 transpose between the four 16-lane rows of a wave and the four components of v: afterwards component e of row q holds what
+// was component q of row e.  permlane16_swap(a, b): rows 1, 3 of a <-> rows 0, 2 of b; permlane32_swap(a, b): rows 2, 3 of a <-> rows 0, 1 of b.
+__device__ __forceinline__ void sm_tr4x4(float4 &v) {
+    unsigned c0 = __builtin_bit_cast(unsigned, v.x), c1 = __builtin_bit_cast(unsigned, v.y);
+    unsigned c2 = __builtin_bit_cast(unsigned, v.z), c3 = __builtin_bit_cast(unsigned, v.w);
+    auto s01 = __builtin_amdgcn_permlane16_swap(c0, c1, false, false);
+    auto s23 = __builtin_amdgcn_permlane16_swap(c2, c3, false, false);
+    auto t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+    auto t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+    v.x = __builtin_bit_cast(float, (unsigned)t02[0]);
+    v.y = __builtin_bit_cast(float, (unsigned)t13[0]);
+    v.z = __builtin_bit_cast(float, (unsigned)t02[1]);
+    v.w = __builtin_bit_cast(float, (unsigned)t13[1]);
+}
+
+template <int EPI, int DEPTH /* chunks in the register ring; K / 64 is a multiple of it */, bool SIG /* A and W_sig already in the sigma K layout */>
+__global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmArgs g, int rt_per_wg) {
     constexpr int KC = 64;                       // k per chunk
-    constexpr int PIT = KC / 4 + 4;              // plane row pitch (floats): 20 -> pitch/4 odd, conflict-free b128 reads
-    constexpr int PLANE = 16 * PIT;
-    constexpr int NB = (EPI == EPI_GLU) ? 2 : 1; // B tiles per wave (GLU: value + gate)
-    __shared__ __attribute__((aligned(16))) float lds[(1 + NB) * 4 * PLANE];
-    float *As = lds, *Ws = lds + 4 * PLANE;
-    const int lane = threadIdx.x, r = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-    // staging: lane (r, kq) moves float4 #kq of every 16-k block of row r
-    int arow = m0 + r;
-    arow = arow < g.M ? arow : g.M - 1;
-    const float *ap = g.A + (int64_t)arow * g.lda + 4 * kq;
-    const float *wp[NB];
+    constexpr int NB = (EPI == EPI_GLU) ? 2 : 1; // waves per output tile (GLU: value + gate)
+    __shared__ float gate[2][64][4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = wave % NB, rt = wave / NB;
+    const int r = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = (blockIdx.y * rt_per_wg + rt) * 16;
+    const bool active = m0 < g.M;                // wave-uniform
+    sm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    // epilogue operands first (bias, residual rows): their round trips hide under the chain instead of following it
+    const int col = n0 + r;
+    float bias = 0.0f, bias_g = 0.0f, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (active && half == 0 && col < g.N) {
+        if (g.bias) bias = g.bias[col];
+        if constexpr (EPI == EPI_GLU) bias_g = g.bias ? g.bias[g.N + col] : 0.0f;
+        if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        int wrow = n0 + r;
-        wrow = wrow < g.N ? wrow : g.N - 1;
-        wp[b] = g.W + (int64_t)(b * g.N + wrow) * g.ldw + 4 * kq;
-    }
-    // register ring of DEPTH chunks: the loads of chunk i+DEPTH-1 are issued before chunk i is consumed, so ~DEPTH x 640 cycles of
-    // MFMA chain cover the L2 / HBM latency of the weight stream (one chunk ahead left every iteration waiting ~1 us)
-    constexpr int DEPTH = 4;
-    float4 ra[DEPTH][4], rw[DEPTH][NB][4];
-    auto gload = [&](int kc, int set) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ra[set][q] = *reinterpret_cast<const float4 *>(ap + kc * KC + 16 * q);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) rw[set][b][q] = *reinterpret_cast<const float4 *>(wp[b] + kc * KC + 16 * q);
-        }
-    };
-    auto park = [&](int set) {                   // element k = 16q + 4kq + e  ->  plane e, row r, column (k >> 2) = 4q + kq
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float *a = As + r * PIT + 4 * q + kq;
-            a[0] = ra[set][q].x; a[PLANE] = ra[set][q].y; a[2 * PLANE] = ra[set][q].z; a[3 * PLANE] = ra[set][q].w;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                float *w = Ws + b * 4 * PLANE + r * PIT + 4 * q + kq;
-                w[0] = rw[set][b][q].x; w[PLANE] = rw[set][b][q].y; w[2 * PLANE] = rw[set][b][q].z; w[3 * PLANE] = rw[set][b][q].w;
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + 4 * kq + i;
+                if (row < g.M) res[i] = g.resid[(int64_t)row * g.ldr + col];
             }
         }
-    };
-    sm_f32x4 acc[NB];
+    }
+    if (active) {
+        int arow = m0 + r;
+        arow = arow < g.M ? arow : g.M - 1;
+        int wrow = n0 + r;
+        wrow = wrow < g.N ? wrow : g.N - 1;
+        const float *ap = g.A + (int64_t)arow * g.lda + 4 * kq;
+        const float *wp = (SIG ? g.W_sig : g.W) + (int64_t)(half * g.N + wrow) * g.ldw + 4 * kq;
+        float4 ra[DEPTH][4], rw[DEPTH][4];
+        auto gload = [&](int kc, int set) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = sm_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int nkc = g.K / KC;
+            for (int q = 0; q < 4; ++q) {
+                rw[set][q] = *reinterpret_cast<const float4 *>(wp + kc * KC + 16 * q);
+                ra[set][q] = *reinterpret_cast<const float4 *>(ap + kc * KC + 16 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the loads stay HERE, DEPTH - 1 chunks ahead of their use (the scheduler would sink them)
+        };
+        // No branch inside the unrolled group: a conditional load makes the compiler's s_waitcnt bookkeeping drain the ring to vmcnt(0)
+        // every chunk.  The loads past the end re-read the last chunk (hot lines, never consumed).
+        const int nkc = g.K / KC, last = nkc - 1;
 #pragma unroll
-    for (int j = 0; j < DEPTH - 1; ++j)
-        if (j < nkc) gload(j, j);
-    for (int kc0 = 0; kc0 < nkc; kc0 += DEPTH) {
+        for (int j = 0; j < DEPTH - 1; ++j) gload(j < last ? j : last, j);
+        for (int kc0 = 0; kc0 < nkc; kc0 += DEPTH) {
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            const int kc = kc0 + j;
-            if (kc < nkc) {
-                __builtin_amdgcn_wave_barrier();     // the previous chunk's fragment reads are done (single wavefront: program order)
-                park(j);
-                if (kc + DEPTH - 1 < nkc) gload(kc + DEPTH - 1, (j + DEPTH - 1) % DEPTH);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                // the lane that feeds k = 4s + kq reads plane kq: steps s = 4f .. 4f+3 per ds_read_b128
-                const float *af = As + kq * PLANE + r * PIT;
+            for (int j = 0; j < DEPTH; ++j) {
+                const int nx = kc0 + j + DEPTH - 1;
+                if (DEPTH > 1) gload(nx < last ? nx : last, (j + DEPTH - 1) % DEPTH);
+                else gload(kc0, 0);
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const float4 a = *reinterpret_cast<const float4 *>(af + 4 * f);
-                    float4 w[NB];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) w[b] = *reinterpret_cast<const float4 *>(Ws + b * 4 * PLANE + kq * PLANE + r * PIT + 4 * f);
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[b].x, acc[b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[b].y, acc[b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[b].z, acc[b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[b].w, acc[b], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    float4 a = ra[j][q], w = rw[j][q];
+                    if (!SIG) {
+                        sm_tr4x4(a);
+                        sm_tr4x4(w);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
                 }
             }
         }
     }
+    if constexpr (EPI == EPI_GLU) {
+        if (active && half == 1) *reinterpret_cast<sm_f32x4 *>(&gate[rt][lane][0]) = acc;
+        __syncthreads();
+        if (half == 1) return;
+    }
+    if (!active) return;
     // epilogue: C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + i
-    const int col = n0 + r;
     if (col >= g.N) return;
-    const float bias = g.bias ? g.bias[col] : 0.0f;
-    float bias_g = 0.0f;
-    if constexpr (EPI == EPI_GLU) bias_g = g.bias ? g.bias[g.N + col] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = m0 + 4 * kq + i;
         if (row >= g.M) continue;
-        float v = acc[0][i];
+        float v = acc[i];
         if (g.bias) v = v + bias;
         if constexpr (EPI == EPI_RELU) {
             v = v > 0.0f ? v : 0.0f;
@@ -117,9 +130,9 @@ __global__ __launch_bounds__(64) void gemm_smallm_kernel(GemmArgs g) {
             v = dsiluf(v);
         } else if constexpr (EPI == EPI_RESID) {
             const float y = v * g.alpha;
-            v = g.resid[(int64_t)row * g.ldr + col] + y;
+            v = res[i] + y;
         } else if constexpr (EPI == EPI_GLU) {
-            float gt = acc[NB - 1][i];
+            float gt = gate[rt][lane][i];
             if (g.bias) gt = gt + bias_g;
             v = v * dsigmoidf(gt);
         }
@@ -128,14 +141,43 @@ __global__ __launch_bounds__(64) void gemm_smallm_kernel(GemmArgs g) {
     }
 }
 
+__global__ void sigma_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t rows, int K, int64_t ld) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * K) return;
+    const int64_t r = idx / K;
+    const int k = (int)(idx % K);
+    dst[r * ld + ((k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3))] = src[r * ld + k];
+}
+void launch_sigma_copy(const float *src, float *dst, int64_t rows, int K, int64_t ld, hipStream_t s) {
+    const int64_t n = rows * K;
+    hipLaunchKernelGGL(sigma_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, K, ld);
+}
+
+template <int EPI>
+static void launch_smallm_epi(const GemmArgs &a, hipStream_t s) {
+    constexpr int NB = (EPI == EPI_GLU) ? 2 : 1;
+    // one wave per workgroup (GLU: the value / gate pair): with a few hundred waves on 1024 SIMDs every chain gets a SIMD and an L1 of its own
+    const int row_tiles = (a.M + 15) / 16, rt = 1;
+    const dim3 grid((a.N + 15) / 16, (row_tiles + rt - 1) / rt), block(64 * rt * NB);
+    const int nkc = a.K / 64;
+    if (a.a_sigma && a.W_sig) {
+        if (nkc % 8 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 8, true>), grid, block, 0, s, a, rt);
+        else if (nkc % 2 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 2, true>), grid, block, 0, s, a, rt);
+        else hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 1, true>), grid, block, 0, s, a, rt);
+    } else {
+        if (nkc % 8 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 8, false>), grid, block, 0, s, a, rt);
+        else if (nkc % 2 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 2, false>), grid, block, 0, s, a, rt);
+        else hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 1, false>), grid, block, 0, s, a, rt);
+    }
+}
+
 void launch_gemm_smallm(const GemmArgs &a, int epi, hipStream_t s) {
-    const dim3 grid((a.N + 15) / 16, (a.M + 15) / 16);
     switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL(gemm_smallm_kernel<EPI_NONE>, grid, dim3(64), 0, s, a); break;
-    case EPI_RELU: hipLaunchKernelGGL(gemm_smallm_kernel<EPI_RELU>, grid, dim3(64), 0, s, a); break;
-    case EPI_SILU: hipLaunchKernelGGL(gemm_smallm_kernel<EPI_SILU>, grid, dim3(64), 0, s, a); break;
-    case EPI_RESID: hipLaunchKernelGGL(gemm_smallm_kernel<EPI_RESID>, grid, dim3(64), 0, s, a); break;
-    case EPI_GLU: hipLaunchKernelGGL(gemm_smallm_kernel<EPI_GLU>, grid, dim3(64), 0, s, a); break;
+    case EPI_NONE: launch_smallm_epi<EPI_NONE>(a, s); break;
+    case EPI_RELU: launch_smallm_epi<EPI_RELU>(a, s); break;
+    case EPI_SILU: launch_smallm_epi<EPI_SILU>(a, s); break;
+    case EPI_RESID: launch_smallm_epi<EPI_RESID>(a, s); break;
+    case EPI_GLU: launch_smallm_epi<EPI_GLU>(a, s); break;
     default: break;
     }
 }

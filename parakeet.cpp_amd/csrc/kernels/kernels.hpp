@@ -68,7 +68,14 @@ struct GemmArgs {
     // numerics contract -- that mode is compared with the oracle within a bf16-epsilon-class tolerance, not bit for bit, and at bf16 MFMA rates
     // the 38-operation SiLU is as expensive as the product itself (fc1 of tdt-600m: ~48 us of VALU against 40 us of MFMA).
     int fast_act = 0;
+    // small-M kernel (gemm_smallm.hip, M <= 768) only: W_sig = a copy of W whose K axis is in the sigma layout ([rows][ldw], launch_sigma_copy),
+    // a_sigma = A's K axis is in the sigma layout (its producer wrote it that way: sigma_cols, LayerNorm mode 2, the streaming attention /
+    // conv kernels).  Both set: a lane's 16-byte load IS its operand of four consecutive MFMA steps -- no transposes on the chain.
+    const float *W_sig = nullptr; int a_sigma = 0;
 };
+constexpr int kSmallMRows = 768;   // launch_gemm: products with M <= this (and K % 64 == 0) run on gemm_smallm.hip
+// dst[r][sigma(k)] = src[r][k], k < K (K % 16 == 0), rows x ld floats
+void launch_sigma_copy(const float *src, float *dst, int64_t rows, int K, int64_t ld, hipStream_t s);
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
 // same contract with bf16 operands and fp32 accumulation: a.W points to bf16 weights [N][K] (rounded once at upload), A is
 // rounded to bf16 while it is staged; K % 64 == 0.  Not bit-identical to the fp32 chain (kernels/gemm_bf16.hpp).
@@ -104,7 +111,8 @@ void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const fl
 // columns of (q+v) P^T WITHOUT rel_shift (:215-224), masked to the [left, right] context (:226-247).  ctx[S*c][d].
 void launch_stream_attention(const float *qkv_new, const float *kcache, const float *vcache, int cache_rows, int S, int c, int nc, int d,
                              int n_heads, const float *pos /*[P][d]*/, int P, const float *bias_u, const float *bias_v, int att_left,
-                             int att_right, float *ctx, hipStream_t s, float *cache_k_out = nullptr, float *cache_v_out = nullptr, int keep_max = 0);
+                             int att_right, float *ctx, hipStream_t s, float *cache_k_out = nullptr, float *cache_v_out = nullptr, int keep_max = 0,
+                             int ctx_sigma = 0 /* ctx columns in the sigma layout (GemmArgs::a_sigma of the out-projection) */);
 // (cache_k_out / cache_v_out set: the same launch also rotates the K / V caches of every (stream, head) into those buffers -- the last
 //  min(keep_max, nc + c) rows of [cache ; new], what two launch_stream_cache_update calls would write)
 // new cache = the last min(keep_max, nc + c) rows of [cache(nc rows) ; new(c rows)]  (:193-209); row stride of both caches: cache_rows*d
@@ -114,7 +122,7 @@ void launch_stream_cache_update(const float *cache_in, int nc, const float *qkv_
 // BatchNorm, SiLU -> out[S*c][d]; cache_out = last K-1 rows of the concatenation.
 void launch_stream_dwconv(const float *g, const float *cache_in, int has_cache, int S, int c, int d, int kc, const float *w, const float *bias,
                           const float *bn_mean, const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, float *cache_out,
-                          hipStream_t s);
+                          hipStream_t s, int out_sigma = 0 /* out channels in the sigma layout */);
 
 // ---- decoders -------------------------------------------------------------------------------------------
 void launch_logsoftmax_argmax(const float *logits, int64_t rows, int ld, int n, float *lp_out, int *best_idx, float *best_lp, hipStream_t s);
@@ -187,7 +195,7 @@ size_t tdt_persistent_lds_bytes(const TdtState &st);
 void launch_tdt_persistent(const TdtPersist &p, hipStream_t s);
 
 // ---- LayerNorm, canonical reductions, math diagnostics ------------------------------------------
-void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s, int y_bf16 = 0);   // y_bf16: y is a bf16 buffer (RNE)
+void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s, int y_bf16 = 0);   // y_bf16 = 1: y is a bf16 buffer (RNE); 2: fp32, columns in the sigma layout (GemmArgs::a_sigma)
 // y1 = LN(x; g1, b1), y2 = LN(y1; g2, b2) in one pass (y1 may alias x)
 void launch_layernorm2(const float *x, int64_t rows, int d, const float *g1, const float *b1, const float *g2, const float *b2, float eps,
                        float *y1, float *y2, hipStream_t s, int y2_bf16 = 0);

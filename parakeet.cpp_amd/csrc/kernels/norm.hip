@@ -17,14 +17,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *xr = x + row * d;
-    float v[PER_LANE];
-    float p = 0.0f;
+    float v[PER_LANE], gv[PER_LANE], bv[PER_LANE];
 #pragma unroll
-    for (int j = 0; j < PER_LANE; ++j) {
+    for (int j = 0; j < PER_LANE; ++j) {                            // the row and gamma / beta in one round trip (not one after the reductions)
         const int i = lane + 64 * j;
         v[j] = i < d ? xr[i] : 0.0f;
-        if (i < d) p = p + v[j];
+        gv[j] = i < d ? g[i] : 0.0f;
+        bv[j] = i < d ? b[i] : 0.0f;
     }
+    float p = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j)
+        if (lane + 64 * j < d) p = p + v[j];
     const float mean = wave_sum64(p) / (float)d;
     float q = 0.0f;
 #pragma unroll
@@ -43,8 +47,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     for (int j = 0; j < PER_LANE; ++j) {
         const int i = lane + 64 * j;
         if (i < d) {
-            const float o = __builtin_fmaf((v[j] - mean) * rstd, g[i], b[i]);
-            if (y_bf16) yh[i] = (__bf16)o;
+            const float o = __builtin_fmaf((v[j] - mean) * rstd, gv[j], bv[j]);
+            if (y_bf16 == 1) yh[i] = (__bf16)o;
+            else if (y_bf16 == 2) yr[(i & ~15) | ((i & 3) << 2) | ((i >> 2) & 3)] = o;   // sigma K layout (kernels.hpp: GemmArgs::a_sigma)
             else yr[i] = o;
         }
     }
@@ -63,15 +68,16 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float *__restrict
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *xr = x + row * d;
-    float v[PER_LANE];
+    float v[PER_LANE], gv[2][PER_LANE], bv[2][PER_LANE];
 #pragma unroll
     for (int j = 0; j < PER_LANE; ++j) {
         const int i = lane + 64 * j;
         v[j] = i < d ? xr[i] : 0.0f;
+        gv[0][j] = i < d ? g1[i] : 0.0f; bv[0][j] = i < d ? b1[i] : 0.0f;
+        gv[1][j] = i < d ? g2[i] : 0.0f; bv[1][j] = i < d ? b2[i] : 0.0f;
     }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        const float *g = pass ? g2 : g1, *b = pass ? b2 : b1;
         float *yr = (pass ? y2 : y1) + row * d;
         float p = 0.0f;
 #pragma unroll
@@ -91,8 +97,9 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float *__restrict
         for (int j = 0; j < PER_LANE; ++j) {
             const int i = lane + 64 * j;
             if (i < d) {
-                v[j] = __builtin_fmaf((v[j] - mean) * rstd, g[i], b[i]);
-                if (pass && y2_bf16) (reinterpret_cast<__bf16 *>(y2) + row * d)[i] = (__bf16)v[j];
+                v[j] = __builtin_fmaf((v[j] - mean) * rstd, gv[pass][j], bv[pass][j]);
+                if (pass && y2_bf16 == 1) (reinterpret_cast<__bf16 *>(y2) + row * d)[i] = (__bf16)v[j];
+                else if (pass && y2_bf16 == 2) yr[(i & ~15) | ((i & 3) << 2) | ((i >> 2) & 3)] = v[j];
                 else yr[i] = v[j];
             }
         }

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
                                                               const float *__restrict__ pos, int P, const float *__restrict__ bias_u,
                                                               const float *__restrict__ bias_v, int att_left, int att_right, float scale,
                                                               float *__restrict__ ctx, float *__restrict__ cache_k_out,
-                                                              float *__restrict__ cache_v_out, int keep) {
+                                                              float *__restrict__ cache_v_out, int keep, int ctx_sigma) {
     extern __shared__ float sm[];                                   // [hd] q+u, [hd] q+v, [kv] probabilities
     const int hd = d / H, kv = nc + c;
     const int sidx = blockIdx.x / H, h = blockIdx.x % H, i = blockIdx.y, lane = threadIdx.x;
@@ -54,8 +54,20 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
         const float4 *kr = reinterpret_cast<const float4 *>(krow(j)), *pp = reinterpret_cast<const float4 *>(pos + (int64_t)(off + j) * d + h * hd);
         const float4 *qu4 = reinterpret_cast<const float4 *>(qu), *qv4 = reinterpret_cast<const float4 *>(qv);
         float cs = 0.0f, ps = 0.0f;
-        for (int e = 0; e < hd / 4; ++e) {
-            const float4 kk = kr[e], p4 = pp[e], a = qu4[e], bq = qv4[e];
+        int e0 = 0;
+        for (; e0 + 8 <= hd / 4; e0 += 8) {                         // 16 row loads in flight per round trip
+            float4 kk[8], p4[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { kk[u] = kr[e0 + u]; p4[u] = pp[e0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 a = qu4[e0 + u], bq = qv4[e0 + u];
+                cs = __builtin_fmaf(a.x, kk[u].x, cs); cs = __builtin_fmaf(a.y, kk[u].y, cs); cs = __builtin_fmaf(a.z, kk[u].z, cs); cs = __builtin_fmaf(a.w, kk[u].w, cs);
+                ps = __builtin_fmaf(bq.x, p4[u].x, ps); ps = __builtin_fmaf(bq.y, p4[u].y, ps); ps = __builtin_fmaf(bq.z, p4[u].z, ps); ps = __builtin_fmaf(bq.w, p4[u].w, ps);
+            }
+        }
+        for (; e0 < hd / 4; ++e0) {
+            const float4 kk = kr[e0], p4 = pp[e0], a = qu4[e0], bq = qv4[e0];
             cs = __builtin_fmaf(a.x, kk.x, cs); cs = __builtin_fmaf(a.y, kk.y, cs); cs = __builtin_fmaf(a.z, kk.z, cs); cs = __builtin_fmaf(a.w, kk.w, cs);
             ps = __builtin_fmaf(bq.x, p4.x, ps); ps = __builtin_fmaf(bq.y, p4.y, ps); ps = __builtin_fmaf(bq.z, p4.z, ps); ps = __builtin_fmaf(bq.w, p4.w, ps);
         }
@@ -77,21 +89,30 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
     __syncthreads();
     for (int e = lane; e < hd; e += 64) {                           // softmax(S) V, k = key index in natural order (:250)
         float acc = 0.0f;
-        for (int j = 0; j < kv; ++j) acc = __builtin_fmaf(pr[j], vrow(j)[e], acc);
-        ctx[((int64_t)sidx * c + i) * d + h * hd + e] = acc;
+        int j = 0;
+        for (; j + 8 <= kv; j += 8) {                               // 8 value rows in flight per round trip
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = vrow(j + u)[e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(pr[j + u], vv[u], acc);
+        }
+        for (; j < kv; ++j) acc = __builtin_fmaf(pr[j], vrow(j)[e], acc);
+        const int col = h * hd + e;                                 // ctx_sigma: the out-projection reads its A operand in the sigma K layout
+        ctx[((int64_t)sidx * c + i) * d + (ctx_sigma ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = acc;
     }
 }
 
 void launch_stream_attention(const float *qkv_new, const float *kcache, const float *vcache, int cache_rows, int S, int c, int nc, int d,
                              int n_heads, const float *pos, int P, const float *bias_u, const float *bias_v, int att_left, int att_right,
-                             float *ctx, hipStream_t s, float *cache_k_out, float *cache_v_out, int keep_max) {
+                             float *ctx, hipStream_t s, float *cache_k_out, float *cache_v_out, int keep_max, int ctx_sigma) {
     const int hd = d / n_heads;
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t lds = (size_t)(2 * hd + nc + c) * sizeof(float);
     const int kv = nc + c, keep = kv > keep_max ? keep_max : kv;
     const bool rotate = cache_k_out && cache_v_out && keep > 0;
     hipLaunchKernelGGL(stream_attention_kernel, dim3(S * n_heads, c + (rotate ? 1 : 0)), dim3(64), lds, s, qkv_new, kcache, vcache, cache_rows, c, nc, d,
-                       n_heads, pos, P, bias_u, bias_v, att_left, att_right, scale, ctx, rotate ? cache_k_out : nullptr, rotate ? cache_v_out : nullptr, keep);
+                       n_heads, pos, P, bias_u, bias_v, att_left, att_right, scale, ctx, rotate ? cache_k_out : nullptr, rotate ? cache_v_out : nullptr, keep, ctx_sigma);
 }
 
 __global__ void stream_cache_update_kernel(const float *__restrict__ cache_in, int nc, const float *__restrict__ qkv, int col0, int c, int d,
@@ -116,7 +137,7 @@ template <int KC>
 __global__ void stream_dwconv_kernel(const float *__restrict__ g, const float *__restrict__ cache_in, int has_cache, int c, int d,
                                      const float *__restrict__ w /*[KC][d]*/, const float *__restrict__ bias, const float *__restrict__ bn_mean,
                                      const float *__restrict__ bn_rstd, const float *__restrict__ bn_g, const float *__restrict__ bn_b,
-                                     float *__restrict__ out, float *__restrict__ cache_out, int64_t n) {
+                                     float *__restrict__ out, float *__restrict__ cache_out, int64_t n, int out_sigma) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (stream, channel)
     if (idx >= n) return;
     const int ch = (int)(idx % d), sidx = (int)(idx / d);
@@ -131,7 +152,7 @@ __global__ void stream_dwconv_kernel(const float *__restrict__ g, const float *_
         for (int kk = 0; kk < KC; ++kk) acc = __builtin_fmaf(w[kk * d + ch], cat(t + kk), acc);      // depthwise, no padding (:71)
         float v = acc + bias[ch];
         v = __builtin_fmaf((v - bn_mean[ch]) * bn_rstd[ch], bn_g[ch], bn_b[ch]);
-        out[((int64_t)sidx * c + t) * d + ch] = dsiluf(v);
+        out[((int64_t)sidx * c + t) * d + (out_sigma ? ((ch & ~15) | ((ch & 3) << 2) | ((ch >> 2) & 3)) : ch)] = dsiluf(v);
     }
     float keep[CL];
 #pragma unroll
@@ -141,11 +162,11 @@ __global__ void stream_dwconv_kernel(const float *__restrict__ g, const float *_
 }
 void launch_stream_dwconv(const float *g, const float *cache_in, int has_cache, int S, int c, int d, int kc, const float *w, const float *bias,
                           const float *bn_mean, const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, float *cache_out,
-                          hipStream_t s) {
+                          hipStream_t s, int out_sigma) {
     const int64_t n = (int64_t)S * d;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (kc == 9) hipLaunchKernelGGL(stream_dwconv_kernel<9>, grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n);
-    else if (kc == 31) hipLaunchKernelGGL(stream_dwconv_kernel<31>, grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n);
+    if (kc == 9) hipLaunchKernelGGL(stream_dwconv_kernel<9>, grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n, out_sigma);
+    else if (kc == 31) hipLaunchKernelGGL(stream_dwconv_kernel<31>, grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n, out_sigma);
 }
 
 }  // namespace pk
