@@ -409,7 +409,7 @@ void Model::run_gemm(const char *name, const GemmArgs &g, int epi, hipStream_t s
         KL(name, gemm_flops(g, epi), 0.0, launch_gemm_bf16(g, epi, s));
     } else {
         if (g.a_bf16 || g.out_bf16) fail(PK_ERR_INVALID, "%s: bf16 activations outside the bf16 GEMM path", name);
-        if (g.a_sigma && !(g.W_sig && g.M <= kSmallMRows && g.K % 64 == 0))
+        if (g.a_sigma && !(g.W_sig && g.M <= kSmallMRows && g.K % 64 == 0 && g.N % 16 == 0))
             fail(PK_ERR_INVALID, "%s: sigma-K activations need the small-M kernel and a sigma-K weight copy", name);
         KL(name, gemm_flops(g, epi), 0.0, launch_gemm(g, epi, s));
     }
@@ -825,7 +825,10 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
             return;
         }
     }
-    const int chunk = 16;            // host polls "all finished" every 16 steps (4 / 64 / 128 measured: no difference, profiles/r02_decode_persistent.md)
+    // host polls "all finished" every `chunk` steps: 16 for whole utterances (4 / 64 / 128 measured: no difference, profiles/r02_decode_persistent.md);
+    // a streaming chunk of 1-3 frames is done after T + (symbols of its busiest stream) steps -- every step launched beyond that is four no-op
+    // kernels of ~6 us each, more than the poll costs
+    const int chunk = T + 2 < 4 ? 4 : (T + 2 < 16 ? T + 2 : 16);
     auto skinny = [&](const SkinnyArgs &a, int epi) { if (dec16) launch_skinny_gemm_bf16(a, epi, s); else launch_skinny_gemm(a, epi, s); };
     auto enqueue_step = [&]() {
         for (int l = 0; l < L; ++l) {

@@ -43,7 +43,7 @@ __device__ __forceinline__ void sm_tr4x4(float4 &v) {
     v.w = __builtin_bit_cast(float, (unsigned)t13[1]);
 }
 
-template <int EPI, int DEPTH /* chunks in the register ring; K / 64 is a multiple of it */, bool SIG /* A and W_sig already in the sigma K layout */>
+template <int EPI, int DEPTH /* chunks in the register ring; K / 64 is a multiple of it */, bool SIG /* A in the sigma K layout, W_sig tiled in load order */>
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmArgs g, int rt_per_wg) {
     constexpr int KC = 64;                       // k per chunk
     constexpr int NB = (EPI == EPI_GLU) ? 2 : 1; // waves per output tile (GLU: value + gate)
@@ -74,12 +74,14 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmArgs g, int rt_per
         int wrow = n0 + r;
         wrow = wrow < g.N ? wrow : g.N - 1;
         const float *ap = g.A + (int64_t)arow * g.lda + 4 * kq;
-        const float *wp = (SIG ? g.W_sig : g.W) + (int64_t)(half * g.N + wrow) * g.ldw + 4 * kq;
+        // SIG: W_sig is TILED -- the 16 rows x 64 k of (column tile, chunk) are one contiguous 4 KB block in load order [q][lane][4], so a wave's
+        // load instruction reads 1 KB of consecutive addresses and its whole weight stream is one contiguous run of 16 K floats
+        const float *wp = SIG ? g.W_sig + (int64_t)((half * g.N + n0) >> 4) * 16 * g.K + 4 * lane : g.W + (int64_t)(half * g.N + wrow) * g.ldw + 4 * kq;
         float4 ra[DEPTH][4], rw[DEPTH][4];
         auto gload = [&](int kc, int set) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                rw[set][q] = *reinterpret_cast<const float4 *>(wp + kc * KC + 16 * q);
+                rw[set][q] = *reinterpret_cast<const float4 *>(SIG ? wp + kc * (16 * KC) + 256 * q : wp + kc * KC + 16 * q);
                 ra[set][q] = *reinterpret_cast<const float4 *>(ap + kc * KC + 16 * q);
             }
             __builtin_amdgcn_sched_barrier(0);   // the loads stay HERE, DEPTH - 1 chunks ahead of their use (the scheduler would sink them)
@@ -141,15 +143,19 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmArgs g, int rt_per
     }
 }
 
+// W_sig of GemmArgs: dst[tile = row / 16][chunk = k / 64][q][lane = (row % 16) + 16 kq][e] = src[row][64 chunk + 16 q + 4 e + kq]
 __global__ void sigma_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t rows, int K, int64_t ld) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // destination index
     if (idx >= rows * K) return;
-    const int64_t r = idx / K;
-    const int k = (int)(idx % K);
-    dst[r * ld + ((k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3))] = src[r * ld + k];
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63), q = (int)((idx >> 8) & 3);
+    const int64_t blk = idx >> 10;                                         // (tile, chunk)
+    const int nkc = K / 64;
+    const int64_t tile = blk / nkc;
+    const int kc = (int)(blk % nkc);
+    dst[idx] = src[(tile * 16 + (lane & 15)) * ld + 64 * kc + 16 * q + 4 * e + (lane >> 4)];
 }
 void launch_sigma_copy(const float *src, float *dst, int64_t rows, int K, int64_t ld, hipStream_t s) {
-    const int64_t n = rows * K;
+    const int64_t n = rows * K;                                            // rows % 16 == 0, K % 64 == 0
     hipLaunchKernelGGL(sigma_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, K, ld);
 }
 

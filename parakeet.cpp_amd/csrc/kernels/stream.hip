@@ -87,19 +87,36 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
     const float sum = wave_sum64(p);
     for (int j = lane; j < kv; j += 64) pr[j] = pr[j] / sum;
     __syncthreads();
-    for (int e = lane; e < hd; e += 64) {                           // softmax(S) V, k = key index in natural order (:250)
-        float acc = 0.0f;
+    for (int eb = 0; eb < hd; eb += 128) {                          // softmax(S) V, k = key index in natural order (:250); two output columns per lane
+        const int e0 = eb + lane, e1 = eb + 64 + lane;
+        const bool h0 = e0 < hd, h1 = e1 < hd;
+        float acc0 = 0.0f, acc1 = 0.0f;
         int j = 0;
-        for (; j + 8 <= kv; j += 8) {                               // 8 value rows in flight per round trip
-            float vv[8];
+        for (; j + 8 <= kv; j += 8) {                               // 8 value rows (16 loads) in flight per round trip
+            float v0[8], v1[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = vrow(j + u)[e];
+            for (int u = 0; u < 8; ++u) {
+                const float *vr = vrow(j + u);
+                v0[u] = h0 ? vr[e0] : 0.0f;
+                v1[u] = h1 ? vr[e1] : 0.0f;
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(pr[j + u], vv[u], acc);
+            for (int u = 0; u < 8; ++u) {
+                acc0 = __builtin_fmaf(pr[j + u], v0[u], acc0);
+                acc1 = __builtin_fmaf(pr[j + u], v1[u], acc1);
+            }
         }
-        for (; j < kv; ++j) acc = __builtin_fmaf(pr[j], vrow(j)[e], acc);
-        const int col = h * hd + e;                                 // ctx_sigma: the out-projection reads its A operand in the sigma K layout
-        ctx[((int64_t)sidx * c + i) * d + (ctx_sigma ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = acc;
+        for (; j < kv; ++j) {
+            const float *vr = vrow(j);
+            if (h0) acc0 = __builtin_fmaf(pr[j], vr[e0], acc0);
+            if (h1) acc1 = __builtin_fmaf(pr[j], vr[e1], acc1);
+        }
+        auto put = [&](int e, float acc) {                          // ctx_sigma: the out-projection reads its A operand in the sigma K layout
+            const int col = h * hd + e;
+            ctx[((int64_t)sidx * c + i) * d + (ctx_sigma ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = acc;
+        };
+        if (h0) put(e0, acc0);
+        if (h1) put(e1, acc1);
     }
 }
 
