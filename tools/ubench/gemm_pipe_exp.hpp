@@ -46,7 +46,8 @@ __device__ long long *gp_tr2;       // micro-benchmark builds only: [n_blocks][1
 // Epilogue shared by the GEMM kernels of this directory (bias, ReLU, SiLU, residual + alpha*y, GLU, sigma column layout) on the
 // accumulators of a WGM x WGN grid of waves, each holding TM x TN 32x32 tiles.  `smem` is the kernel's staging memory (free by now),
 // CAP its size in floats: the wide path turns the C tile row-major through it (in row bands when it does not fit).
-template <int WGM, int WGN, int TM, int TN, int EPI, int CAP_FLOATS>
+// (RS_PER_PASS of the product header is accepted and ignored: this copy requests all residual rows up front)
+template <int WGM, int WGN, int TM, int TN, int EPI, int CAP_FLOATS, bool RS_PER_PASS = false>
 __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[TM][TN], float *smem, int m0, int n0) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
