@@ -264,9 +264,10 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
 // The direct-to-LDS bf16 kernel (gemm_bf16_glds.hpp; activations already bf16 in HBM), 256x256 macro tiles.  Measured inside the engine on
 // tdt-600m (profiles/r03_bf16_tile_ab.txt, PK_BF16_TILE in EXPERIMENTAL builds): it is ahead of the register-staged 128x128 kernel where one
 // operand is large -- fc1 (N = 4096: 6.70 -> 6.60 ms per step) and fc2 (K = 4096: 6.51 -> 6.11) -- and behind on qkv (2.50 -> 2.70), the GLU
-// product (1.75 -> 2.03) and the N = 1024 / K = 1024 products; 256x128 and 128x128-on-4-waves variants lose everywhere.  So: N * K >= 4 M
-// elements and no GLU.  Modes (EXPERIMENTAL builds, PK_BF16_TILE): 0 = off, 1 = that rule, 2 = 256x128 everywhere, 3 = 128x128 on 4 waves
-// of 64x64, 4 = 256x256 everywhere.
+// product (1.75 -> 2.03) and the N = 1024 / K = 1024 products; 256x128 and 128x128-on-4-waves variants lose everywhere.  The second pass
+// (tools/ubench/gemm_bf16_k.cpp) found why: the 256-row tile count of those products falls between two rounds of the 256 CUs; with the tile
+// height chosen per product (below) the kernel is ahead everywhere.  Modes (EXPERIMENTAL builds, PK_BF16_TILE): 0 = off, 1 = that rule,
+// 2 = 256x128 everywhere, 3 = 128x128 on 4 waves of 64x64, 4 = 256x256 everywhere, 5 = 192x256 everywhere.
 static int bf16_glds_mode() {
 #ifdef PK_EXPERIMENTAL
     static const int m = [] { const char *e = getenv("PK_BF16_TILE"); return e ? atoi(e) : 1; }();
@@ -281,10 +282,24 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
     if constexpr (A16) {
         const int mode = bf16_glds_mode();
         if (mode && a.M >= 2048 && a.N >= 512 && a.K >= 128 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.remap_rows == 0 && (a.ldo & 3) == 0 && (a.N & 3) == 0) {
-            const bool big_operand = EPI != EPI_GLU && (int64_t)a.N * a.K >= (int64_t)4096 * 1024;
             if (mode == 3) { launch_gemm_bf16_glds<2, 2, 2, 2, EPI>(a, s); return; }
             if (mode == 2) { launch_gemm_bf16_glds<4, 2, 2, 2, EPI>(a, s); return; }
-            if (mode == 4 || big_operand) { launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s); return; }
+            if (mode == 4) { launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s); return; }
+            if (mode == 5) { launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s); return; }
+            // One tile per CU and round (128 KB of LDS): the kernel's time is rounds x (tile's K loop + ~12 us of prologue / epilogue), so the tile
+            // HEIGHT is chosen per product for the fewest, fullest rounds of the 256 CUs (tools/ubench/gemm_bf16_k.cpp, profiles/r03_gemm_bf16_k.txt:
+            // main loop 1.3 PF on either tile).  tdt-600m (M = 12032): fc1 (N 4096) 752 tiles of 256 rows = 2.94 rounds; fc2 / out / pw2 (N 1024) 252
+            // tiles of 192 rows = ONE round (188 of 256 rows leave 68 CUs idle: 113 -> 99 us); qkv (N 3072) 756 of 192 = 2.95 rounds (564 of 256 = 2.2).
+            if (mode == 1 && a.M >= 8192 && (int64_t)a.N * a.K >= (int64_t)1024 * 1024) {
+                constexpr int NOUT = (EPI == EPI_GLU) ? 128 : 256;
+                auto est = [&](int R) {
+                    const int64_t tiles = (int64_t)((a.M + R - 1) / R) * ((a.N + NOUT - 1) / NOUT);
+                    return (double)((tiles + 255) / 256) * ((double)R * a.K * 1.008e-4 + 12.0);
+                };
+                if (est(192) < est(256)) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s);
+                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s);
+                return;
+            }
         }
     }
     // round 2: the staging stores decide the rate of this kernel.  As 16-byte ds_write_b128 the 128x128 tile ran at 320-340 TF and 256x256
