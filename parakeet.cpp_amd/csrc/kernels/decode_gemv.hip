@@ -20,6 +20,9 @@ namespace pk {
 template <int EPI, int NCH, bool NTW>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     __shared__ float tile[4][16][17];
+    // grid.x is the tile count rounded up to a multiple of 8 (launch_skinny_gemm): workgroup id % 8 = XCD, so XCD x owns the output tiles
+    // nt % 8 == x of EVERY utterance group and re-reads only its eighth of W from its own L2 step after step
+    if ((EPI == SK_CELL ? 4 : 16) * (int)blockIdx.x >= (EPI == SK_CELL ? a.Hp : a.N)) return;
     skinny_tile<EPI, NCH, false, NTW>(a, blockIdx.x, blockIdx.y, tile);
 }
 
@@ -37,7 +40,7 @@ static void launch_skinny_epi(const SkinnyArgs &a, dim3 grid, hipStream_t s) {
 
 void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s) {
     const int n_tiles = epi == SK_CELL ? a.Hp / 4 : (a.N + 15) / 16;
-    dim3 grid(n_tiles, (a.B + 63) / 64);
+    dim3 grid((n_tiles + 7) & ~7, (a.B + 63) / 64);              // padded: see skinny_gemm_kernel
     switch (epi) {
     case SK_BIAS: launch_skinny_epi<SK_BIAS>(a, grid, s); break;
     case SK_ACT: launch_skinny_epi<SK_ACT>(a, grid, s); break;
