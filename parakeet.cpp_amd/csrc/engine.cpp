@@ -282,6 +282,25 @@ void Model::upload_weights() {
             for (int k = 0; k < K; ++k) p[(size_t)r * K + sigma(k)] = w[(size_t)r * K + k];
         return upload(p.data(), p.size());
     };
+    // bf16 decode weights (tolerance-class mode) in the LOAD ORDER of skinny_gemm_bf16_kernel: per (16-output tile, 32-k block) one 1 KB block
+    // [lane][8] -- lane (col = lane & 15, kq = lane >> 4) holds W[row(tile, col)][32 blk + 8 kq .. + 7], so a wave's load instruction reads 1 KB of
+    // consecutive addresses and a tile's weight stream is one contiguous run.  cell: the tile's columns are (gate, unit) pairs of the LSTM,
+    // row = (col >> 2) * Hp + 4 tile + (col & 3); otherwise row = 16 tile + col (clamped to the last row: the kernel never stores those columns).
+    auto upload_dec16 = [&](const float *w, int rows, int K, bool cell) {
+        const int n_tiles = cell ? rows / 16 : (rows + 15) / 16, nblk = K / 32, hp = rows / 4;
+        std::vector<float> p((size_t)n_tiles * nblk * 512);
+        for (int t = 0; t < n_tiles; ++t)
+            for (int blk = 0; blk < nblk; ++blk)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int col = lane & 15, kq = lane >> 4;
+                    int row = cell ? (col >> 2) * hp + 4 * t + (col & 3) : 16 * t + col;
+                    row = row < rows ? row : rows - 1;
+                    const float *src = w + (size_t)row * K + 32 * blk + 8 * kq;
+                    float *dst = p.data() + (((size_t)t * nblk + blk) * 64 + lane) * 8;
+                    for (int e = 0; e < 8; ++e) dst[e] = src[e];
+                }
+        return upload_gemm_weight(p.data(), p.size());
+    };
     if (cfg.ctc_vocab_size > 0) {
         dec.ctc_w = upload_gemm_tensor("ctc_decoder_.proj_.weight", {cfg.ctc_vocab_size, d});
         dec.ctc_b = upload_tensor("ctc_decoder_.proj_.bias", {cfg.ctc_vocab_size});
@@ -301,15 +320,16 @@ void Model::upload_weights() {
         dec_whh_s[l] = upload_sigma(host_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp}).f32(), 4 * Hp, Hp);
         dec_wih_s[l] = l ? upload_sigma(host_tensor(q + "input_proj_.weight", {4 * Hp, Hp}).f32(), 4 * Hp, Hp) : nullptr;
         if (cfg.gemm_bf16) {               // the decode GEMVs of the tolerance-class mode take bf16 weights (decode_gemv_bf16.hip)
-            dec_whh16[l] = upload_gemm_weight(host_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp}).f32(), (size_t)4 * Hp * Hp);
-            dec_wih16[l] = l ? upload_gemm_weight(host_tensor(q + "input_proj_.weight", {4 * Hp, Hp}).f32(), (size_t)4 * Hp * Hp) : nullptr;
+            const bool t16 = Hp % 32 == 0 && J % 32 == 0;              // (run_tdt_loop's condition for the bf16 decode kernels)
+            dec_whh16[l] = t16 ? upload_dec16(host_tensor(q + "hidden_proj_.weight", {4 * Hp, Hp}).f32(), 4 * Hp, Hp, true) : nullptr;
+            dec_wih16[l] = (t16 && l) ? upload_dec16(host_tensor(q + "input_proj_.weight", {4 * Hp, Hp}).f32(), 4 * Hp, Hp, true) : nullptr;
         }
     }
     const std::string jp = cfg.joint_prefix;
     dec.we = upload_gemm_tensor(jp + "enc_proj_.weight", {J, d}); dec.be = upload_tensor(jp + "enc_proj_.bias", {J});
     dec.wp = upload_tensor(jp + "pred_proj_.weight", {J, Hp});
     dec_wp_s = upload_sigma(host_tensor(jp + "pred_proj_.weight", {J, Hp}).f32(), J, Hp);
-    if (cfg.gemm_bf16) dec_wp16 = upload_gemm_weight(host_tensor(jp + "pred_proj_.weight", {J, Hp}).f32(), (size_t)J * Hp);
+    if (cfg.gemm_bf16 && Hp % 32 == 0 && J % 32 == 0) dec_wp16 = upload_dec16(host_tensor(jp + "pred_proj_.weight", {J, Hp}).f32(), J, Hp, false);
     dec.bp = (cfg.joint_pred_bias && st_->find(jp + "pred_proj_.bias")) ? upload_tensor(jp + "pred_proj_.bias", {J}) : nullptr;
     {
         std::vector<float> w((size_t)(V + D) * J), b((size_t)(V + D));
@@ -323,7 +343,7 @@ void Model::upload_weights() {
         wld = upload(w.data(), w.size());
         bld = upload(b.data(), b.size());
         wld_s = upload_sigma(w.data(), V + D, J);
-        if (cfg.gemm_bf16) wld16 = upload_gemm_weight(w.data(), w.size());
+        if (cfg.gemm_bf16 && Hp % 32 == 0 && J % 32 == 0) wld16 = upload_dec16(w.data(), V + D, J, false);
     }
     // g1 = E W_ih0^T + b  ([V][4Hp]) on the MFMA GEMM: the same natural-k chains the per-step projection would run
     float *g1 = dev_alloc((size_t)V * 4 * Hp);

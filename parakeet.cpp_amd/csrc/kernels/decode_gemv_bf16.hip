@@ -13,7 +13,8 @@
 //
 // Tiling as decode_gemv.hip: one wavefront per 16 (utterances) x 16 (outputs) tile, a workgroup = one 16-output tile x up to four
 // 16-utterance tiles; lane (row / column l & 15, quarter l >> 4) loads the 8 consecutive k of every 32-k block at 8 (l >> 4) with one 16-byte
-// load per operand per MFMA -- natural layouts, no permutation.  Epilogues: LSTM cell (gates -> c', h'), joint activation, bias.
+// load per operand per MFMA -- activations in their natural layout, weights TILED in that load order at upload (engine.cpp upload_dec16: one
+// 1 KB block per (tile, 32-k block), a wave's load = 1 KB of consecutive addresses).  Epilogues: LSTM cell (gates -> c', h'), joint activation, bias.
 #include "../pk_devmath.h"
 #include "kernels.hpp"
 
@@ -33,10 +34,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     const int col = lane & 15, kq = lane >> 4;
     const int m0 = (mgroup * 4 + wave) * 16;
     if (m0 >= a.B) return;                                       // whole wave out of range (uniform)
-    const __bf16 *X = reinterpret_cast<const __bf16 *>(a.X), *W = reinterpret_cast<const __bf16 *>(a.W);
-    int wrow;
-    if (EPI == SK_CELL) wrow = (col >> 2) * a.Hp + 4 * nt + (col & 3);   // tile columns = (gate, unit): rows g*Hp + j
-    else { wrow = 16 * nt + col; wrow = wrow < a.N ? wrow : a.N - 1; }
+    const __bf16 *X = reinterpret_cast<const __bf16 *>(a.X);
+    // W (and W2) are TILED in this kernel's load order (engine.cpp upload_dec16): tile nt = nblk consecutive 1 KB blocks [lane][8 bf16];
+    // SK_CELL: the tile's columns are the (gate, unit) pairs g * Hp + 4 nt + j
+    const int64_t wtile = (int64_t)nt * (a.K / 32) * 64 + lane;
     int xrow = m0 + col;
     xrow = xrow < a.B ? xrow : a.B - 1;
     // epilogue operands first (token -> g1 row, c, enc_proj[t_b], bias): their round trips hide under the MFMA chain
@@ -69,9 +70,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     }
     // one product acc = X W^T over K: chunks of 4 MFMAs (128 k), the next chunk's 8 loads in flight under the current chunk
     constexpr int CH = 4;
-    auto chain = [&](const __bf16 *xr, const __bf16 *wr) -> db_f32x4 {
+    auto chain = [&](const __bf16 *xr, const void *wt) -> db_f32x4 {
         db_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        const db_bf16x8 *xq = reinterpret_cast<const db_bf16x8 *>(xr) + kq, *wq = reinterpret_cast<const db_bf16x8 *>(wr) + kq;   // 32-k block i at [4 i]
+        const db_bf16x8 *xq = reinterpret_cast<const db_bf16x8 *>(xr) + kq;                 // 32-k block i at [4 i]
+        const db_bf16x8 *wq = reinterpret_cast<const db_bf16x8 *>(wt) + wtile;              // 32-k block i at [64 i]
         const int nblk = a.K / 32;
         db_bf16x8 xa[CH], wa[CH], xb[CH], wb[CH];
         auto load = [&](db_bf16x8 (&x_)[CH], db_bf16x8 (&w_)[CH], int c0) {
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
             for (int i = 0; i < CH; ++i) {
                 const int blk = c0 + i < nblk ? c0 + i : nblk - 1;
                 x_[i] = xq[4 * blk];
-                w_[i] = wq[4 * blk];
+                w_[i] = wq[64 * blk];
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -102,9 +104,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     if (EPI == SK_CELL && a.W2) {                                // upper LSTM layer: its input projection W_ih h'(l-1) + b_ih, same tile columns
         int x2row = m0 + col;
         x2row = x2row < a.B ? x2row : a.B - 1;
-        acc2 = chain(reinterpret_cast<const __bf16 *>(a.X2) + (int64_t)x2row * a.K, reinterpret_cast<const __bf16 *>(a.W2) + (int64_t)wrow * a.K);
+        acc2 = chain(reinterpret_cast<const __bf16 *>(a.X2) + (int64_t)x2row * a.K, a.W2);
     }
-    const db_f32x4 acc = chain(X + (int64_t)xrow * a.K, W + (int64_t)wrow * a.K);
+    const db_f32x4 acc = chain(X + (int64_t)xrow * a.K, a.W);
     // C/D layout of 16x16: column = lane & 15, row (utterance) = 4 * (lane >> 4) + r
     if (EPI == SK_BIAS) {
         const int n = 16 * nt + col;
