@@ -175,16 +175,25 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
         const bool more = t + 1 < nkt;
         if (more) v_load(t + 1);
         if (active) {
-            // ---- content scores, transposed: S^T[key][query] ----
-            ab_f32x16 sa;
+            // ---- content scores, transposed: S^T[key][query], and position block t + 1: two INDEPENDENT chains of NK MFMAs, issued alternately
+            //      (one after the other, every MFMA waits for its predecessor's result: a wave issues in order) ----
+            ab_f32x16 sa, ga;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sa[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) { sa[r] = 0.0f; ga[r] = 0.0f; }
 #pragma unroll
-            for (int s = 0; s < NK; ++s) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kreg[s], qreg[s], sa, 0, 0, 0);
-            if (more) k_load(t + 1);
-            // ---- position block t + 1 into the strip, then the skewed read of blocks t and t + 1 ----
-            g_block(t + 1);
-            if (more) p_load(t + 2);
+            for (int s = 0; s < NK; ++s) {
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kreg[s], qreg[s], sa, 0, 0, 0);
+                ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preg[s], qreg[s], ga, 0, 0, 0);
+            }
+            if (more) { k_load(t + 1); p_load(t + 2); }
+            {   // block t + 1 (+ c) into the wave's skew strip, half (t + 1) & 1; then the skewed read of blocks t and t + 1
+                const int m = t + 1, cbase = 96 - 32 * wave + 32 * m;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int x = ab_rowidx(r, g);
+                    sk[(32 * (m & 1) + x) * AB_SKP + n] = ga[r] + cb[cbase + x];
+                }
+            }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             float sv[16];
