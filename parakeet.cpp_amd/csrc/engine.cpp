@@ -770,6 +770,20 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     st.lens = w.lens.as<int>();
     st.ids = w.ids.as<int>(); st.start = w.start.as<int>(); st.end = w.end.as<int>(); st.conf = w.conf.as<float>();
     st.margin = (boost_on || keep_state) ? nullptr : w.margin.as<float>();
+    // Prediction-net caching (kernels.hpp TdtState::need): after a blank the cells and pred_proj of the next step would recompute, bit for bit,
+    // what they produced the step before -- those rows are skipped (~2/3 of all utterance-steps on the benchmark's clips).  Per-phase loop only
+    // (the single-launch loop keeps every row), lock-step batches up to kMaxListRows.
+    bool pred_cache = B <= kMaxListRows && decode_loop != PK_DECODE_LOOP_PERSISTENT;
+#ifdef PK_EXPERIMENTAL
+    { static const bool off = [] { const char *e = getenv("PK_DEC_NOCACHE"); return e && atoi(e) != 0; }(); if (off) pred_cache = false; }
+#endif
+    if (pred_cache) {
+        st.need = ib + 6 * B + 8;                                    // (behind done_count and the persistent loop's two spare words)
+        st.pp = w.pp.as<float>();
+        st.ep = w.ep.as<float>();
+        st.z = w.z.as<float>();
+        st.J = J;
+    }
     if (!keep_state) {                                               // a streaming chunk continues from the carried LSTM state
         PK_HIP(hipMemsetAsync(w.h.p, 0, (size_t)L * B * Hp * 4, s));
         PK_HIP(hipMemsetAsync(w.c.p, 0, (size_t)L * B * Hp * 4, s));
@@ -806,6 +820,11 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     }
     for (int l = 0; l < L; ++l) P.cell[l].nt_weights = dec_nt_weights;
     P.act.nt_weights = P.heads.nt_weights = dec_nt_weights;
+    if (pred_cache) {
+        for (int l = 0; l < L; ++l) P.cell[l].need = st.need;
+        P.act.need = st.need;
+        P.act.pp_out = w.pp.as<float>();
+    }
     // Tolerance-class mode: the same phases on bf16 operands (decode_gemv_bf16.hip).  h / h' / z are bf16 arrays in the same buffers (natural k
     // order), the weights are the bf16 copies; the layer-0 input projection stays the fp32 table g1.  Specification: the oracle's gemm_bf16 mode.
     const bool dec16 = cfg.gemm_bf16 && Hp % 32 == 0 && J % 32 == 0 && wld16;
@@ -866,7 +885,7 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         std::vector<unsigned char> key;
         auto put = [&key](const void *p, size_t n) { const unsigned char *c = static_cast<const unsigned char *>(p); key.insert(key.end(), c, c + n); };
         const void *ptrs[] = {this, s, st.logits, st.h, st.c, st.hn, st.cn, st.token, st.lens, st.ids, st.start, st.end, st.conf, P.act.ep, P.heads.W, P.act.W, P.cell[0].W, P.cell[0].gi};
-        const int ints[] = {B, T, V, D, L, Hp, J, max_tokens, st.blank, st.max_symbols, st.max_steps, st.keep_state, boost_on ? 1 : 0};
+        const int ints[] = {B, T, V, D, L, Hp, J, max_tokens, st.blank, st.max_symbols, st.max_steps, st.keep_state, boost_on ? 1 : 0, pred_cache ? 1 : 0};
         put(ptrs, sizeof ptrs);
         put(ints, sizeof ints);
         if (!w.dec_graph || key != w.dec_graph_key) {

@@ -235,6 +235,7 @@ __global__ void tdt_init_kernel(TdtState st) {
     st.done[b] = 0;
     st.lens[b] = 0;
     if (st.margin) st.margin[b] = __builtin_huge_valf();
+    if (st.need) st.need[b] = 1;                       // the first step computes the prediction net for everyone
     if (st.trie.off) {                                 // active_states = {root} (phrase_boost.cpp:258)
         st.trie.n_act[b] = 1;
         st.trie.act[(int64_t)b * kTrieMaxActive] = 0;

@@ -48,6 +48,41 @@ template <bool NT> __device__ __forceinline__ float4 dd_ldw(const float4 *p) {
 
 __device__ __forceinline__ int sigma16(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
 
+// Compact list of the utterances whose need flag is set, ascending (TdtState::need): lst[0 .. count).  One 256-thread workgroup, B <= kMaxListRows;
+// every thread of the workgroup must call it (two barriers).
+template <bool COH>
+__device__ __forceinline__ int dd_build_rowlist(const int *need, int B, int *lst, int *wtot /* [4] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = (B + 255) >> 8;                                 // consecutive flags per thread (<= 8)
+    const int b0 = tid * F;
+    int fl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int b = b0 + i;
+        fl[i] = (i < F && b < B) ? dd_ldi<COH>(need + b) : 0;
+    }
+    unsigned bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bits |= (fl[i] != 0 ? 1u : 0u) << i;
+    const int c = __builtin_popcount(bits);
+    int x = c;                                                    // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wtot[wave] = x;
+    __syncthreads();
+    int base = x - c;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    const int cnt = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if ((bits >> i) & 1u) lst[base++] = b0 + i;
+    __syncthreads();
+    return cnt;
+}
+
 // NCH: compile-time number of 64-wide K chunks (10 for K = 640: fully unrolled, counted vmcnt waits keep the next
 // chunk's loads in flight under the MFMA chain); 0 = runtime trip count (any K % 64 == 0).
 // COH = the operands other workgroups of the SAME kernel produced (X, c, the token / frame words, gi of the upper LSTM layers) are
@@ -56,39 +91,51 @@ __device__ __forceinline__ int sigma16(int k) { return (k & ~15) | ((k & 3) << 2
 // NTW: the weight stream is loaded non-temporally (streaming hint: the decode weights of the large heads -- 42 MB per symbol step for tdt-600m --
 // pass through each XCD's 4 MB L2 once per step and otherwise evict the operand tiles of the encoder GEMMs running beside the loop).
 template <int EPI, int NCH, bool COH, bool NTW = false>
-__device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgroup, float (*tile)[16][17]) {
+__device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgroup, float (*tile)[16][17], const int *rows = nullptr, int n_rows = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int m0 = (mgroup * 4 + wave) * 16;
-    if (m0 >= a.B) return;                                       // whole wave out of range (uniform)
+    // rows != null: the launch covers the n_rows utterances rows[0 ..] (prediction-net caching, TdtState::need); row index i of the tile space
+    // is utterance rows[i]
+    const int NB = rows ? n_rows : a.B;
+    auto real = [&](int i) { return rows ? rows[i] : i; };
+    if (m0 >= NB) return;                                        // whole wave out of range (uniform)
     int wrow;
     if (EPI == SK_CELL) wrow = (col >> 2) * a.Hp + 4 * nt + (col & 3);   // tile columns = (gate, unit): rows g*Hp + j
     else { wrow = 16 * nt + col; wrow = wrow < a.N ? wrow : a.N - 1; }
     int xrow = m0 + col;
-    xrow = xrow < a.B ? xrow : a.B - 1;
+    xrow = real(xrow < NB ? xrow : NB - 1);
     const float4 *xp = reinterpret_cast<const float4 *>(a.X + (int64_t)xrow * a.K) + kq;
     const float4 *wp = reinterpret_cast<const float4 *>(a.W + (int64_t)wrow * a.K) + kq;
     // Epilogue operands are fetched FIRST (token -> g1 row, c, enc_proj[t_b], bias): in this latency-bound loop every
     // dependent round trip to L2 / HBM that can hide under the 160-MFMA chain is ~1-2 us saved per launch.
     float e_gi[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_c = 0.0f;          // SK_CELL: lane -> (utterance lane>>2, unit lane&3)
     float e_ep[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_bias = 0.0f;       // SK_ACT / SK_BIAS: lane -> column `col`, utterances 4*kq+r
+    int rb_cell = 0, rb_out[4] = {0, 0, 0, 0};                   // utterances of this lane's epilogue rows
     if (EPI == SK_CELL) {
-        const int b = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
-        if (b < a.B && !a.W2) {
+        const int bi = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
+        const int b = bi < NB ? real(bi) : 0;
+        rb_cell = b;
+        if (bi < NB && !a.W2) {
             const float *gir = a.gi + (int64_t)(a.gi_row ? dd_ldi<COH>(a.gi_row + b) : b) * a.gi_ld;
 #pragma unroll
             for (int g = 0; g < 4; ++g) e_gi[g] = a.gi_row ? gir[g * a.Hp + j] : dd_ldf<COH>(gir + g * a.Hp + j);   // layer 0: the constant g1 table
         }
-        if (b < a.B) e_c = dd_ldf<COH>(a.c + (int64_t)b * a.Hp + j);
+        if (bi < NB) e_c = dd_ldf<COH>(a.c + (int64_t)b * a.Hp + j);
     } else {
         const int n = 16 * nt + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bi = m0 + 4 * kq + r;
+            rb_out[r] = bi < NB ? real(bi) : 0;
+        }
         if (n < a.N) {
             if (a.bias) e_bias = a.bias[n];
             if (EPI == SK_ACT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int b = m0 + 4 * kq + r;
-                    if (b < a.B) {
+                    const int b = rb_out[r];
+                    if (m0 + 4 * kq + r < NB) {
                         int tt = dd_ldi<COH>(a.t + b);
                         tt = tt < a.T ? tt : a.T - 1;
                         e_ep[r] = a.ep[((int64_t)b * a.T + tt) * a.N + n];
@@ -148,9 +195,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
     // gi = chain_ih + b_ih, gates = gi + chain_hh, src/lstm.cpp:15)
     f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (EPI == SK_CELL && a.W2) {
-        int x2row = m0 + col;
-        x2row = x2row < a.B ? x2row : a.B - 1;
-        acc2 = chain(reinterpret_cast<const float4 *>(a.X2 + (int64_t)x2row * a.K) + kq, reinterpret_cast<const float4 *>(a.W2 + (int64_t)wrow * a.K) + kq);
+        acc2 = chain(reinterpret_cast<const float4 *>(a.X2 + (int64_t)xrow * a.K) + kq, reinterpret_cast<const float4 *>(a.W2 + (int64_t)wrow * a.K) + kq);
     }
     const f32x4 acc = chain(xp, wp);
 #undef SK_LOAD
@@ -161,8 +206,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
         if (n < a.N) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int b = m0 + 4 * kq + r;
-                if (b < a.B) dd_stf<COH>(a.out + (int64_t)b * a.ldo + n, a.bias ? acc[r] + e_bias : acc[r]);
+                if (m0 + 4 * kq + r < NB) dd_stf<COH>(a.out + (int64_t)rb_out[r] * a.ldo + n, a.bias ? acc[r] + e_bias : acc[r]);
             }
         }
     } else if (EPI == SK_ACT) {
@@ -171,10 +215,11 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
         if (n < a.N) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int b = m0 + 4 * kq + r;
-                if (b >= a.B) continue;
+                if (m0 + 4 * kq + r >= NB) continue;
+                const int b = rb_out[r];
                 float p = acc[r];
                 if (a.bias) p = p + e_bias;
+                if (a.pp_out) a.pp_out[(int64_t)b * a.N + n] = p;           // cached for the steps after a blank (TdtState::pp)
                 const float s = e_ep[r] + p;
                 dd_stf<COH>(a.out + (int64_t)b * a.N + sigma16(n), s > 0.0f ? s : 0.0f);
             }
@@ -182,13 +227,15 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
     } else {
         // LSTMCell::forward: gates = (W_ih x + b) + W_hh h ; i,f,g,o ; c' = f*c + i*g ; h' = o*tanh(c')
         const int ul = lane >> 2, jj = lane & 3;
-        const int b = m0 + ul, j = 4 * nt + jj;
+        const int j = 4 * nt + jj;
+        const bool row_ok = m0 + ul < NB;
+        const int b = rb_cell;
         if (a.W2) {                                   // upper layer: gi = chain_ih + b_ih, through the same LDS transposition
 #pragma unroll
             for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][col] = acc2[r];
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (b < a.B) {
+            if (row_ok) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) e_gi[g] = tile[wave][ul][4 * g + jj] + a.bias2[g * a.Hp + j];
             }
@@ -199,7 +246,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
         for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][col] = acc[r];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (b < a.B) {
+        if (row_ok) {
             const float gi_ = e_gi[0] + tile[wave][ul][jj];
             const float gf_ = e_gi[1] + tile[wave][ul][4 + jj];
             const float gg_ = e_gi[2] + tile[wave][ul][8 + jj];
@@ -486,6 +533,22 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
                 const int i = tid + 256 * q;
                 if (i < n_state) st.c[((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp)] = ccar[q];
                 if (i < n_h) st.h[((int64_t)(i / hp_h) * st.B + b) * hp_h + (i % hp_h)] = hcar[q];
+            }
+        }
+    }
+    if (st.need) {
+        // prediction-net caching (TdtState::need): a token changed (token, h, c) -> the next step runs the cells and pred_proj again; a blank
+        // changed only the frame -> this workgroup forms next step's z = relu(enc_proj[t'] + pp) from the cached pp (SK_ACT's epilogue, same
+        // operand order: enc_proj + (pred_proj [+ bias]))
+        const bool fin = t >= st.T || (st.max_steps > 0 && nsteps >= st.max_steps);
+        if (tid == 0) dd_sti<COH>(st.need + b, (commit && !fin) ? 1 : 0);
+        if (!commit && !fin) {
+            const float *epr = st.ep + ((int64_t)b * st.T + t) * st.J, *ppr = st.pp + (int64_t)b * st.J;
+            for (int n = tid; n < st.J; n += 256) {
+                const float sv = epr[n] + ppr[n];
+                const float zv = sv > 0.0f ? sv : 0.0f;
+                if (st.h_bf16) reinterpret_cast<__bf16 *>(st.z)[(int64_t)b * st.J + n] = (__bf16)zv;
+                else dd_stf<COH>(st.z + (int64_t)b * st.J + sigma16(n), zv);
             }
         }
     }

@@ -23,6 +23,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     // grid.x is the tile count rounded up to a multiple of 8 (launch_skinny_gemm): workgroup id % 8 = XCD, so XCD x owns the output tiles
     // nt % 8 == x of EVERY utterance group and re-reads only its eighth of W from its own L2 step after step
     if ((EPI == SK_CELL ? 4 : 16) * (int)blockIdx.x >= (EPI == SK_CELL ? a.Hp : a.N)) return;
+    if (a.need) {                                                // prediction-net caching: only the utterances whose flag is set (TdtState::need)
+        __shared__ int lst[kMaxListRows];
+        __shared__ int wtot[4];
+        const int cnt = dd_build_rowlist<false>(a.need, a.B, lst, wtot);
+        if ((int)blockIdx.y * 64 >= cnt) return;
+        skinny_tile<EPI, NCH, false, NTW>(a, blockIdx.x, blockIdx.y, tile, lst, cnt);
+        return;
+    }
     skinny_tile<EPI, NCH, false, NTW>(a, blockIdx.x, blockIdx.y, tile);
 }
 

@@ -15,8 +15,7 @@
 // 16-utterance tiles; lane (row / column l & 15, quarter l >> 4) loads the 8 consecutive k of every 32-k block at 8 (l >> 4) with one 16-byte
 // load per operand per MFMA -- activations in their natural layout, weights TILED in that load order at upload (engine.cpp upload_dec16: one
 // 1 KB block per (tile, 32-k block), a wave's load = 1 KB of consecutive addresses).  Epilogues: LSTM cell (gates -> c', h'), joint activation, bias.
-#include "../pk_devmath.h"
-#include "kernels.hpp"
+#include "decode_dev.hpp"
 
 namespace pk {
 
@@ -33,33 +32,48 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int m0 = (mgroup * 4 + wave) * 16;
-    if (m0 >= a.B) return;                                       // whole wave out of range (uniform)
+    // prediction-net caching (TdtState::need): the launch covers only the utterances whose flag is set, compacted in ascending order
+    __shared__ int lst[kMaxListRows];
+    __shared__ int wtot[4];
+    int NB = a.B;
+    const bool listed = a.need != nullptr;                       // (kernel argument: uniform)
+    if (listed) NB = dd_build_rowlist<false>(a.need, a.B, lst, wtot);
+    auto real = [&](int i) { return listed ? lst[i] : i; };
+    if (m0 >= NB) return;                                        // whole wave out of range (uniform)
     const __bf16 *X = reinterpret_cast<const __bf16 *>(a.X);
     // W (and W2) are TILED in this kernel's load order (engine.cpp upload_dec16): tile nt = nblk consecutive 1 KB blocks [lane][8 bf16];
     // SK_CELL: the tile's columns are the (gate, unit) pairs g * Hp + 4 nt + j
     const int64_t wtile = (int64_t)nt * (a.K / 32) * 64 + lane;
     int xrow = m0 + col;
-    xrow = xrow < a.B ? xrow : a.B - 1;
+    xrow = real(xrow < NB ? xrow : NB - 1);
     // epilogue operands first (token -> g1 row, c, enc_proj[t_b], bias): their round trips hide under the MFMA chain
     float e_gi[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_c = 0.0f;
     float e_ep[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_bias = 0.0f;
+    int rb_cell = 0, rb_out[4] = {0, 0, 0, 0};                   // utterances of this lane's epilogue rows
     if (EPI == SK_CELL) {
-        const int b = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
-        if (b < a.B && !a.W2) {
+        const int bi = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
+        const int b = bi < NB ? real(bi) : 0;
+        rb_cell = b;
+        if (bi < NB && !a.W2) {
             const float *gir = a.gi + (int64_t)(a.gi_row ? a.gi_row[b] : b) * a.gi_ld;
 #pragma unroll
             for (int g = 0; g < 4; ++g) e_gi[g] = gir[g * a.Hp + j];
         }
-        if (b < a.B) e_c = a.c[(int64_t)b * a.Hp + j];
+        if (bi < NB) e_c = a.c[(int64_t)b * a.Hp + j];
     } else {
         const int n = 16 * nt + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bi = m0 + 4 * kq + r;
+            rb_out[r] = bi < NB ? real(bi) : 0;
+        }
         if (n < a.N) {
             if (a.bias) e_bias = a.bias[n];
             if (EPI == SK_ACT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int b = m0 + 4 * kq + r;
-                    if (b < a.B) {
+                    const int b = rb_out[r];
+                    if (m0 + 4 * kq + r < NB) {
                         int tt = a.t[b];
                         tt = tt < a.T ? tt : a.T - 1;
                         e_ep[r] = a.ep[((int64_t)b * a.T + tt) * a.N + n];
@@ -102,9 +116,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     };
     db_f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (EPI == SK_CELL && a.W2) {                                // upper LSTM layer: its input projection W_ih h'(l-1) + b_ih, same tile columns
-        int x2row = m0 + col;
-        x2row = x2row < a.B ? x2row : a.B - 1;
-        acc2 = chain(reinterpret_cast<const __bf16 *>(a.X2) + (int64_t)x2row * a.K, a.W2);
+        acc2 = chain(reinterpret_cast<const __bf16 *>(a.X2) + (int64_t)xrow * a.K, a.W2);
     }
     const db_f32x4 acc = chain(X + (int64_t)xrow * a.K, a.W);
     // C/D layout of 16x16: column = lane & 15, row (utterance) = 4 * (lane >> 4) + r
@@ -112,10 +124,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
         const int n = 16 * nt + col;
         if (n < a.N) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = m0 + 4 * kq + r;
-                if (b < a.B) a.out[(int64_t)b * a.ldo + n] = a.bias ? acc[r] + e_bias : acc[r];
-            }
+            for (int r = 0; r < 4; ++r)
+                if (m0 + 4 * kq + r < NB) a.out[(int64_t)rb_out[r] * a.ldo + n] = a.bias ? acc[r] + e_bias : acc[r];
         }
     } else if (EPI == SK_ACT) {
         // z = relu(enc_proj(enc_t) + pred_proj(pred) [+ bp])   src/tdt.cpp:17-18 ; stored as bf16 (it is only ever the heads' operand)
@@ -124,10 +134,11 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
             __bf16 *z = reinterpret_cast<__bf16 *>(a.out);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int b = m0 + 4 * kq + r;
-                if (b >= a.B) continue;
+                if (m0 + 4 * kq + r >= NB) continue;
+                const int b = rb_out[r];
                 float p = acc[r];
                 if (a.bias) p = p + e_bias;
+                if (a.pp_out) a.pp_out[(int64_t)b * a.N + n] = p;           // cached for the steps after a blank (TdtState::pp)
                 const float s = e_ep[r] + p;
                 z[(int64_t)b * a.N + n] = (__bf16)(s > 0.0f ? s : 0.0f);
             }
@@ -135,13 +146,15 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     } else {
         // LSTMCell::forward: gates = (W_ih x + b) + W_hh h ; i,f,g,o ; c' = f*c + i*g ; h' = o*tanh(c')
         const int ul = lane >> 2, jj = lane & 3;
-        const int b = m0 + ul, j = 4 * nt + jj;
+        const int j = 4 * nt + jj;
+        const bool row_ok = m0 + ul < NB;
+        const int b = rb_cell;
         if (a.W2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][col] = acc2[r];
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (b < a.B) {
+            if (row_ok) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) e_gi[g] = tile[wave][ul][4 * g + jj] + a.bias2[g * a.Hp + j];
             }
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
         for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][col] = acc[r];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (b < a.B) {
+        if (row_ok) {
             const float gi_ = e_gi[0] + tile[wave][ul][jj];
             const float gf_ = e_gi[1] + tile[wave][ul][4 + jj];
             const float gg_ = e_gi[2] + tile[wave][ul][8 + jj];

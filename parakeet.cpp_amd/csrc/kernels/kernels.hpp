@@ -154,7 +154,19 @@ struct TdtState {
     float *conf;
     int h_bf16;                     // tolerance-class mode: h / hn are bf16 arrays (decode_gemv_bf16.hip); c / cn stay fp32
     float *margin;                  // [B] or null: running min over the utterance's decisions of (top-1 - top-2) label log-prob
+    // Prediction-net caching (null = off).  After a BLANK the reference reverts the LSTM state and keeps the token (src/tdt.cpp:69-93), so the next
+    // step's prediction.step and pred_proj are functions of unchanged inputs: bit for bit the values of the step before.  need[b] = 1 says
+    // utterance b's next step must run them (set at the start and after every emitted token); the cell / pred_proj launches compact the set
+    // rows and skip the rest, whose candidates hn / cn and pp = pred_proj(h') [+ bias] stay where the last computation left them.  After a blank
+    // tdt_decide itself forms the next step's joint activation z = relu(enc_proj[t'] + pp) for the new frame t' (the one line of SK_ACT's
+    // epilogue that depends on t).
+    int *need = nullptr;            // [B]
+    const float *pp = nullptr;      // [B][J] fp32, natural columns
+    const float *ep = nullptr;      // enc_proj [B][T][J]
+    float *z = nullptr;             // joint activation [B][J]: fp32 sigma layout, or bf16 natural when h_bf16
+    int J = 0;
 };
+constexpr int kMaxListRows = 2048;  // largest lock-step batch the compacted launches handle (larger batches run every row)
 void launch_tdt_init(const TdtState &st, hipStream_t s);
 void launch_lstm_cell(const float *gi, int gi_ld, const int *gi_row, const float *gh, const float *c, int B, int Hp, float *hn,
                       float *cn, hipStream_t s);
@@ -176,6 +188,10 @@ struct SkinnyArgs {
     // SK_CELL of an upper LSTM layer with the input projection fused in: gi = X2 W2^T + bias2 (X2 [B][K] sigma, W2 [4Hp][K] sigma); W2 null: gi is read
     const float *X2 = nullptr, *W2 = nullptr, *bias2 = nullptr;
     int nt_weights = 0;            // stream W with non-temporal loads (decode_dev.hpp: NTW)
+    // prediction-net caching (TdtState::need): the launch covers only the rows b with need[b] != 0, compacted in ascending order
+    // (B <= kMaxListRows); SK_ACT also stores pred_proj(h') [+ bias] to pp_out [B][N]
+    const int *need = nullptr;
+    float *pp_out = nullptr;
 };
 void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s);
 // the same products in the tolerance-class mode: X / W / X2 / W2 point to bf16 data in NATURAL k order, the SK_ACT / SK_CELL outputs (z, h') are
