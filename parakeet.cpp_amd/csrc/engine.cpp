@@ -444,6 +444,35 @@ void Model::gemm(const char *name, const float *A, int64_t lda, const float *W, 
     run_gemm(name, g, epi, s);
 }
 
+const std::vector<Model::SigW> &Model::sigma_weights() {
+    if (sig_built_) return sig_layers_;
+    require_gpu();
+    sig_built_ = true;
+    const size_t d = cfg.hidden_size, f = cfg.ffn_intermediate;
+    if (cfg.gemm_bf16 || d % 64 || f % 64) return sig_layers_;
+    const size_t per_layer = 4 * f * d + 7 * d * d;
+    sig_buf_.reserve((size_t)cfg.num_layers * per_layer * 4);
+    float *p = sig_buf_.as<float>();
+    sig_layers_.resize(cfg.num_layers);
+    for (int l = 0; l < cfg.num_layers; ++l) {
+        const LayerW &W = layers[l];
+        auto sig = [&](const float *w, size_t rows, size_t K) {
+            launch_sigma_copy(w, p, (int64_t)rows, (int)K, (int64_t)K, stream);
+            const float *r = p;
+            p += rows * K;
+            return r;
+        };
+        SigW &S = sig_layers_[l];
+        S.ffn1_w1 = sig(W.ffn1_w1, f, d); S.ffn1_w2 = sig(W.ffn1_w2, d, f);
+        S.ffn2_w1 = sig(W.ffn2_w1, f, d); S.ffn2_w2 = sig(W.ffn2_w2, d, f);
+        S.wqkv = sig(W.wqkv, 3 * d, d); S.wo = sig(W.wo, d, d);
+        S.pw1 = sig(W.pw1_w, 2 * d, d); S.pw2 = sig(W.pw2_w, d, d);
+    }
+    PK_CHECK_LAUNCH();
+    PK_HIP(hipStreamSynchronize(stream));
+    return sig_layers_;
+}
+
 // ---- workspace ----------------------------------------------------------------------------------------------
 void Workspace::size_for(const pk_config &c, int B_, int64_t n_samples_, int Tm_) {
     B = B_; Tm = Tm_;

@@ -123,6 +123,15 @@ class Model {
     DevBuf trie_off, trie_tok, trie_node;
     TrieDev trie_dev(Workspace &w, int B);
 
+    // Copies of the encoder layers' eight product weights tiled for the small-M chain kernel (kernels.hpp: GemmArgs::W_sig), built on first
+    // use (streaming: StreamBatch) and shared by every stream of the model: + the size of the encoder weights in HBM.  Empty in gemm_bf16 mode
+    // or when d / ffn are not multiples of 64.
+    struct SigW { const float *ffn1_w1 = nullptr, *ffn1_w2 = nullptr, *ffn2_w1 = nullptr, *ffn2_w2 = nullptr, *wqkv = nullptr, *wo = nullptr, *pw1 = nullptr, *pw2 = nullptr; };
+    const std::vector<SigW> &sigma_weights();
+    std::vector<SigW> sig_layers_;
+    DevBuf sig_buf_;
+    bool sig_built_ = false;
+
     ProfileSink *prof = nullptr;
     void klaunch_begin(const char *name, double flops, double bytes, hipStream_t s);
     void klaunch_end(hipStream_t s);

@@ -18,9 +18,12 @@
 //    (Semantics pinned on the hardware by tools/ubench/permlane_probe.cpp.)
 //  * a register ring of DEPTH = 8 chunks of 64 k (8 loads per chunk and lane; 4 / 2 / 1 when K / 64 is not a multiple of 8):
 //    7 x 512 chain clocks of cover for the weight stream, 56 loads in flight -- below vmcnt's 6-bit limit.
-//  * the row tiles of a column tile (M = 32: two) are waves of ONE workgroup, so they pull the same W lines through the same L1;
-//    GLU: the value and the gate tile of the same 16 columns are two waves (two chains side by side instead of one of double
-//    length), the gate sums cross through LDS once at the end.
+//  * one wave per workgroup -- with a few hundred waves on 1024 SIMDs every chain gets a SIMD and an L1 of its own (four row-tile waves in
+//    one workgroup, sharing the W lines through one L1, lost: the L1 is at its 64 B/clk with four chains); GLU: the value and the gate
+//    tile of the same 16 columns are the two waves of a workgroup (two chains side by side instead of one of double length), the gate sums
+//    cross through LDS once at the end.
+//  * SIG (GemmArgs::a_sigma + W_sig): both operands already in MFMA order -- no transposes at all; the weights TILED so that a load
+//    instruction reads 1 KB of consecutive addresses (the streaming encoder, csrc/stream.cpp; Model::sigma_weights).
 #include "../pk_devmath.h"
 #include "kernels.hpp"
 
@@ -44,14 +47,14 @@ __device__ __forceinline__ void sm_tr4x4(float4 &v) {
 }
 
 template <int EPI, int DEPTH /* chunks in the register ring; K / 64 is a multiple of it */, bool SIG /* A in the sigma K layout, W_sig tiled in load order */>
-__global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmArgs g, int rt_per_wg) {
+__global__ __launch_bounds__(128) void gemm_smallm_kernel(GemmArgs g) {
     constexpr int KC = 64;                       // k per chunk
     constexpr int NB = (EPI == EPI_GLU) ? 2 : 1; // waves per output tile (GLU: value + gate)
-    __shared__ float gate[2][64][4];
+    __shared__ float gate[64][4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = wave % NB, rt = wave / NB;
+    const int half = wave;                       // GLU: wave 0 = value tile, wave 1 = gate tile
     const int r = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = (blockIdx.y * rt_per_wg + rt) * 16;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
     const bool active = m0 < g.M;                // wave-uniform
     sm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     // epilogue operands first (bias, residual rows): their round trips hide under the chain instead of following it
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmArgs g, int rt_per
         }
     }
     if constexpr (EPI == EPI_GLU) {
-        if (active && half == 1) *reinterpret_cast<sm_f32x4 *>(&gate[rt][lane][0]) = acc;
+        if (active && half == 1) *reinterpret_cast<sm_f32x4 *>(&gate[lane][0]) = acc;
         __syncthreads();
         if (half == 1) return;
     }
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmArgs g, int rt_per
             const float y = v * g.alpha;
             v = res[i] + y;
         } else if constexpr (EPI == EPI_GLU) {
-            float gt = gate[rt][lane][i];
+            float gt = gate[lane][i];
             if (g.bias) gt = gt + bias_g;
             v = v * dsigmoidf(gt);
         }
@@ -163,17 +166,16 @@ template <int EPI>
 static void launch_smallm_epi(const GemmArgs &a, hipStream_t s) {
     constexpr int NB = (EPI == EPI_GLU) ? 2 : 1;
     // one wave per workgroup (GLU: the value / gate pair): with a few hundred waves on 1024 SIMDs every chain gets a SIMD and an L1 of its own
-    const int row_tiles = (a.M + 15) / 16, rt = 1;
-    const dim3 grid((a.N + 15) / 16, (row_tiles + rt - 1) / rt), block(64 * rt * NB);
+    const dim3 grid((a.N + 15) / 16, (a.M + 15) / 16), block(64 * NB);
     const int nkc = a.K / 64;
     if (a.a_sigma && a.W_sig) {
-        if (nkc % 8 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 8, true>), grid, block, 0, s, a, rt);
-        else if (nkc % 2 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 2, true>), grid, block, 0, s, a, rt);
-        else hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 1, true>), grid, block, 0, s, a, rt);
+        if (nkc % 8 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 8, true>), grid, block, 0, s, a);
+        else if (nkc % 2 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 2, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 1, true>), grid, block, 0, s, a);
     } else {
-        if (nkc % 8 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 8, false>), grid, block, 0, s, a, rt);
-        else if (nkc % 2 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 2, false>), grid, block, 0, s, a, rt);
-        else hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 1, false>), grid, block, 0, s, a, rt);
+        if (nkc % 8 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 8, false>), grid, block, 0, s, a);
+        else if (nkc % 2 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 2, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 1, false>), grid, block, 0, s, a);
     }
 }
 

@@ -31,25 +31,8 @@ StreamBatch::StreamBatch(Model &m, int n_streams, int att_left, int att_right) :
             L.v[i].reserve((size_t)S * (left_ > 0 ? left_ : 1) * d * 4);
             L.conv[i].reserve((size_t)S * (K - 1) * d * 4);
         }
-        if (!m_.cfg.gemm_bf16 && d % 64 == 0 && m_.cfg.ffn_intermediate % 64 == 0) {
-            const LayerW &W = m_.layers[l];
-            const size_t f = m_.cfg.ffn_intermediate, dd = d;
-            L.w_sig.reserve((4 * f * dd + 3 * dd * dd + dd * dd + 2 * dd * dd + dd * dd) * 4);
-            float *p = L.w_sig.as<float>();
-            auto sig = [&](const float *w, size_t rows, size_t Kd) {
-                launch_sigma_copy(w, p, (int64_t)rows, (int)Kd, (int64_t)Kd, m_.stream);
-                const float *r = p;
-                p += rows * Kd;
-                return r;
-            };
-            L.ffn1_w1 = sig(W.ffn1_w1, f, dd); L.ffn1_w2 = sig(W.ffn1_w2, dd, f);
-            L.ffn2_w1 = sig(W.ffn2_w1, f, dd); L.ffn2_w2 = sig(W.ffn2_w2, dd, f);
-            L.wqkv = sig(W.wqkv, 3 * dd, dd); L.wo = sig(W.wo, dd, dd);
-            L.pw1 = sig(W.pw1_w, 2 * dd, dd); L.pw2 = sig(W.pw2_w, dd, dd);
-        }
     }
-    PK_CHECK_LAUNCH();
-    PK_HIP(hipStreamSynchronize(m_.stream));
+    sig_ = &m_.sigma_weights();
     dec_cap_frames_ = 64;                                           // encoder frames per chunk the decode workspace is sized for
     wd_.size_for(m_.cfg, S, 0, 8 * (dec_cap_frames_ - 1) + 1);
     reset();
@@ -169,29 +152,31 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     const int cache_rows = left_ > 0 ? left_ : 1;
     // rows <= 768: every product of the chunk is a gemm_smallm chain -- run them on the sigma-K weight copies with sigma-K activations (the
     // producers below write that layout; x, the residual stream, stays natural)
-    const int sg = (rows <= 768 && layers_[0]->ffn1_w1) ? 1 : 0;
+    const int sg = (rows <= kSmallMRows && !sig_->empty()) ? 1 : 0;
     const int f = cfg.ffn_intermediate;
     float *hb = ws_.hbuf.as<float>();
-    auto ffn = [&](const LayerW &L, const LayerState &Ls, bool second, bool norm_done) {                // FeedForward (src/encoder.cpp:36-46)
+    auto ffn = [&](const LayerW &L, const Model::SigW &Ls, bool second, bool norm_done) {                // FeedForward (src/encoder.cpp:36-46)
         if (!norm_done) launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, st, sg ? 2 : 0);
         GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
-        g1.a_sigma = sg; g1.W_sig = sg ? (second ? Ls.ffn2_w1 : Ls.ffn1_w1) : nullptr;
+        g1.a_sigma = sg; g1.W_sig = second ? Ls.ffn2_w1 : Ls.ffn1_w1;
         g1.sigma_cols = sg ? f : 0;                                                                       // h is fc2's A operand
         m_.run_gemm("ffn_fc1_silu", g1, EPI_SILU, st);
         GemmArgs g2{hb, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, x, d, 0.5f, (int)rows, d, f};
-        g2.a_sigma = sg; g2.W_sig = sg ? (second ? Ls.ffn2_w2 : Ls.ffn1_w2) : nullptr;
+        g2.a_sigma = sg; g2.W_sig = second ? Ls.ffn2_w2 : Ls.ffn1_w2;
         m_.run_gemm("ffn_fc2_resid", g2, EPI_RESID, st);
     };
     bool ffn1_norm_done = false;
     for (int l = 0; l < cfg.num_layers; ++l) {
         const LayerW &L = m_.layers[l];
         LayerState &Ls = *layers_[l];
-        ffn(L, Ls, false, ffn1_norm_done);                                                             // ffn1_ (:294)
+        static const Model::SigW no_sig{};
+        const Model::SigW &Sg = sg ? (*sig_)[l] : no_sig;
+        ffn(L, Sg, false, ffn1_norm_done);                                                             // ffn1_ (:294)
         // StreamingConformerAttention::forward_cached (:162-272)
         launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, st, sg ? 2 : 0);
         {
             GemmArgs g{n, d, L.wqkv, d, L.bqkv, ws_.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
-            g.a_sigma = sg; g.W_sig = sg ? Ls.wqkv : nullptr;
+            g.a_sigma = sg; g.W_sig = Sg.wqkv;
             m_.run_gemm("attn_qkv", g, EPI_NONE, st);                                                 // natural columns (no sigma layout here)
         }
         const float *kc = Ls.k[Ls.cur].as<float>(), *vc = Ls.v[Ls.cur].as<float>();
@@ -202,14 +187,14 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         Ls.n_kv = (Ls.n_kv + c > left_) ? left_ : Ls.n_kv + c;
         {
             GemmArgs g{ws_.ctx.as<float>(), d, L.wo, d, L.bo, x, d, x, d, 1.0f, (int)rows, d, d};
-            g.a_sigma = sg; g.W_sig = sg ? Ls.wo : nullptr;
+            g.a_sigma = sg; g.W_sig = Sg.wo;
             m_.run_gemm("attn_out_resid", g, EPI_RESID, st);
         }
         // CausalConformerConvModule::forward_cached (:41-78)
         launch_layernorm(x, rows, d, L.cv_ng, L.cv_nb, 1e-5f, n, st, sg ? 2 : 0);
         {
             GemmArgs g{n, d, L.pw1_w, d, L.pw1_b, ws_.g.as<float>(), d, nullptr, 0, 1.0f, (int)rows, d, d};
-            g.a_sigma = sg; g.W_sig = sg ? Ls.pw1 : nullptr;
+            g.a_sigma = sg; g.W_sig = Sg.pw1;
             m_.run_gemm("conv_pw1_glu", g, EPI_GLU, st);
         }
         launch_stream_dwconv(ws_.g.as<float>(), Ls.conv[Ls.ccur].as<float>(), Ls.has_conv, S, c, d, K, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
@@ -218,10 +203,10 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         Ls.has_conv = 1;
         {
             GemmArgs g{ws_.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, x, d, 1.0f, (int)rows, d, d};
-            g.a_sigma = sg; g.W_sig = sg ? Ls.pw2 : nullptr;
+            g.a_sigma = sg; g.W_sig = Sg.pw2;
             m_.run_gemm("conv_pw2_resid", g, EPI_RESID, st);
         }
-        ffn(L, Ls, true, false);                                                                       // ffn2_
+        ffn(L, Sg, true, false);                                                                       // ffn2_
         if (l + 1 < cfg.num_layers) {            // final_norm_ and the next block's ffn1_ norm in one pass over the rows (as the offline encoder)
             launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, m_.layers[l + 1].ffn1_ng, m_.layers[l + 1].ffn1_nb, 1e-5f, x, n, st, sg ? 2 : 0);
             ffn1_norm_done = true;

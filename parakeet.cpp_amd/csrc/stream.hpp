@@ -31,14 +31,9 @@ class StreamBatch {
     // device state
     DevBuf mel_cache_;          // [S][8][F] leftover mel frames (first n_mel_cache_ valid)
     int n_mel_cache_ = 0;
-    struct LayerState {
-        DevBuf k[2], v[2], conv[2]; int cur = 0, ccur = 0, n_kv = 0, has_conv = 0;
-        // sigma-K copies of the layer's eight product weights (kernels.hpp: GemmArgs::W_sig): the chunk's products are single MFMA chains
-        // (kernels/gemm_smallm.hip), and with both operands in that layout nothing but the MFMAs is on the chain
-        DevBuf w_sig;
-        const float *ffn1_w1 = nullptr, *ffn1_w2 = nullptr, *ffn2_w1 = nullptr, *ffn2_w2 = nullptr, *wqkv = nullptr, *wo = nullptr, *pw1 = nullptr, *pw2 = nullptr;
-    };
+    struct LayerState { DevBuf k[2], v[2], conv[2]; int cur = 0, ccur = 0, n_kv = 0, has_conv = 0; };
     std::vector<std::unique_ptr<LayerState>> layers_;
+    const std::vector<Model::SigW> *sig_ = nullptr;      // the model's tiled weight copies (Model::sigma_weights); empty: natural operands
     int frame_offset_ = 0;
     Workspace ws_;              // encoder workspace of the current chunk
     Workspace wd_;              // decode workspace: h / c / token persist across chunks (never re-allocated)
