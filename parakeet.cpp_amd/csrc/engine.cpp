@@ -597,17 +597,25 @@ void Model::run_subsample(Workspace &w, const float *d_feats, int B, int Tm, flo
 }
 
 // FeedForward::forward (src/encoder.cpp:39-46): x += 0.5 * fc2(silu(fc1(LN(x))))
-void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done) {
+void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done, const SigW *sg) {
     const int d = cfg.hidden_size, f = cfg.ffn_intermediate;
     float *x = w.x.as<float>(), *n = w.n.as<float>(), *h = w.hbuf.as<float>();
     // bf16 mode: the normalised rows and the fc1 activations exist only as GEMM operands -- their producers round them to bf16 (RNE, the
     // rounding the GEMM's staging path would apply: same operand values) and store HALF the bytes in the same buffers.
+    // sg (small batches, fp32): the same buffers in the sigma K layout, the products on the tiled weight copies (run_layers).
     const int a16 = cfg.gemm_bf16 ? 1 : 0;
     if (!norm_done)    // (the first FFN's norm rides on the previous block's final_norm_ kernel, see run_layers)
         KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4,
-           launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, s, a16));
-    gemm("ffn_fc1_silu", n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, h, f, (int)rows, f, d, EPI_SILU, nullptr, 0, 1.0f, s, a16, a16);
-    gemm("ffn_fc2_resid", h, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, (int)rows, d, f, EPI_RESID, x, d, 0.5f, s, a16, 0);
+           launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, s, sg ? 2 : a16));
+    GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, h, f, nullptr, 0, 1.0f, (int)rows, f, d};
+    g1.a_bf16 = a16; g1.out_bf16 = a16;
+    g1.fast_act = a16;
+    if (sg) { g1.a_sigma = 1; g1.W_sig = second ? sg->ffn2_w1 : sg->ffn1_w1; g1.sigma_cols = f; }
+    run_gemm("ffn_fc1_silu", g1, EPI_SILU, s);
+    GemmArgs g2{h, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, x, d, 0.5f, (int)rows, d, f};
+    g2.a_bf16 = a16;
+    if (sg) { g2.a_sigma = 1; g2.W_sig = second ? sg->ffn2_w2 : sg->ffn1_w2; }
+    run_gemm("ffn_fc2_resid", g2, EPI_RESID, s);
 }
 
 // FastConformerEncoder::forward (src/encoder.cpp:253-271) -> w.x [B][T][d]
@@ -637,22 +645,31 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
     ensure_pos_tables(T, s);
     const int a16 = cfg.gemm_bf16 ? 1 : 0;                           // bf16 mode: LayerNorm outputs stored as bf16 GEMM operands (ffn())
     const bool att16 = attn_bf16(T);                                 // ... and q / k / v as bf16 for the bf16-MFMA attention kernel
+    // Small batches (rows <= kSmallMRows: one clip, the reference's own benchmark protocol): every product is a latency-bound chain of
+    // dependent MFMAs (kernels/gemm_smallm.hip).  They run on the tiled sigma-K weight copies with sigma-K activations -- written that way by
+    // their producers (LayerNorm mode 2, sigma_cols of fc1, the attention context, the depthwise conv) -- so nothing but the MFMAs is on the
+    // chain; the residual stream x stays natural.  Same arithmetic, same bits.
+    const std::vector<SigW> *sigv = (!a16 && rows <= kSmallMRows) ? &sigma_weights() : nullptr;
+    const bool sgm = sigv && !sigv->empty();
+    const int ymode = sgm ? 2 : a16;                                 // LayerNorm / attention / conv output mode: 0 fp32, 1 bf16, 2 fp32 sigma
     bool ffn1_norm_done = false;
     for (int l = first_layer; l < cfg.num_layers; ++l) {
         if (l > stop_layer || (l == stop_layer && stop_stage == 0)) break;
         const LayerW &L = layers[l];
         const int stage_cap = (l == stop_layer) ? stop_stage : 5;
-        ffn(w, L, false, rows, s, ffn1_norm_done);                                   // ffn1_  :197
+        const SigW *sg = sgm ? &(*sigv)[l] : nullptr;
+        ffn(w, L, false, rows, s, ffn1_norm_done, sg);                               // ffn1_  :197
         ffn1_norm_done = false;
         if (stage_cap == 1) break;
         // ConformerAttention::forward  :180-186
-        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, s, a16));
+        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, s, ymode));
         {
             // q and k columns in the sigma layout (MFMA operands of the attention kernel), v natural
             GemmArgs g{n, d, L.wqkv, d, L.bqkv, w.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
             g.sigma_cols = att16 ? 0 : 2 * d;
             g.a_bf16 = a16;
             g.out_bf16 = att16 ? 1 : 0;
+            if (sg) { g.a_sigma = 1; g.W_sig = sg->wqkv; }
             run_gemm("attn_qkv", g, EPI_NONE, s);
         }
         if (att16) {
@@ -666,24 +683,40 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             const double fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);   // QK^T + QP^T(needed band) + AV
             KL("relpos_attention", fl, 0.0,
                launch_relpos_attention(w.qkv.as<float>(), B, T, d, cfg.num_heads, pos_proj.as<float>() + (size_t)l * P * d, L.pos_u, L.pos_v,
-                                       w.ctx.as<float>(), s, 0.0f, att_scratch_p, a16));
+                                       w.ctx.as<float>(), s, 0.0f, att_scratch_p, ymode));
         }
-        gemm("attn_out_resid", w.ctx.as<float>(), d, L.wo, d, L.bo, x, d, (int)rows, d, d, EPI_RESID, x, d, 1.0f, s, a16, 0);
+        {
+            GemmArgs g{w.ctx.as<float>(), d, L.wo, d, L.bo, x, d, x, d, 1.0f, (int)rows, d, d};
+            g.a_bf16 = a16;
+            if (sg) { g.a_sigma = 1; g.W_sig = sg->wo; }
+            run_gemm("attn_out_resid", g, EPI_RESID, s);
+        }
         if (stage_cap == 2) break;
         // ConformerConvModule::forward  :59-75
-        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, L.cv_ng, L.cv_nb, 1e-5f, n, s, a16));
-        gemm("conv_pw1_glu", n, d, L.pw1_w, d, L.pw1_b, w.g.as<float>(), d, (int)rows, d, d, EPI_GLU, nullptr, 0, 1.0f, s, a16, 0);
+        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, L.cv_ng, L.cv_nb, 1e-5f, n, s, ymode));
+        {
+            GemmArgs g{n, d, L.pw1_w, d, L.pw1_b, w.g.as<float>(), d, nullptr, 0, 1.0f, (int)rows, d, d};
+            g.a_bf16 = a16;
+            g.fast_act = a16;
+            if (sg) { g.a_sigma = 1; g.W_sig = sg->pw1; }
+            run_gemm("conv_pw1_glu", g, EPI_GLU, s);
+        }
         KL("dwconv_bn_silu", (double)rows * d * cfg.conv_kernel_size * 2.0, 2.0 * rows * d * 4,
            launch_dwconv_bn_silu(w.g.as<float>(), B, T, d, cfg.conv_kernel_size, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
-                                 w.dwb.as<float>(), s, a16));
-        gemm("conv_pw2_resid", w.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, (int)rows, d, d, EPI_RESID, x, d, 1.0f, s, a16, 0);
+                                 w.dwb.as<float>(), s, ymode));
+        {
+            GemmArgs g{w.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, x, d, 1.0f, (int)rows, d, d};
+            g.a_bf16 = a16;
+            if (sg) { g.a_sigma = 1; g.W_sig = sg->pw2; }
+            run_gemm("conv_pw2_resid", g, EPI_RESID, s);
+        }
         if (stage_cap == 3) break;
-        ffn(w, L, true, rows, s);                                                    // ffn2_  :201
+        ffn(w, L, true, rows, s, false, sg);                                         // ffn2_  :201
         if (stage_cap == 4) break;
         const bool next_runs = l + 1 < cfg.num_layers && !(l + 1 > stop_layer || (l + 1 == stop_layer && stop_stage == 0));
         if (next_runs) {           // final_norm_ :202 and the next block's ffn1_ norm :40 in one pass over the rows
             KL("layernorm", 0.0, 3.0 * rows * d * 4,
-               launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, layers[l + 1].ffn1_ng, layers[l + 1].ffn1_nb, 1e-5f, x, n, s, a16));
+               launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, layers[l + 1].ffn1_ng, layers[l + 1].ffn1_nb, 1e-5f, x, n, s, ymode));
             ffn1_norm_done = true;
         } else {
             KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, s));   // final_norm_ :202

@@ -163,7 +163,7 @@ class Model {
     void upload_weights();
     void gemm(const char *name, const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *out, int64_t ldo,
               int M, int N, int K, int epi, const float *resid, int64_t ldr, float alpha, hipStream_t s, int a_bf16 = 0, int out_bf16 = 0);
-    void ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done = false);
+    void ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done = false, const SigW *sg = nullptr);
 };
 
 // thread-local error slot of the C ABI

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
             for (int k = 0; k < NSR; ++k) {
                 const int a = sidx(wave + 4 * k, j);
                 // bf16 mode (ctx_bf16: tolerance-class, see GemmArgs::fast_act): hardware exp2 instead of the fixed polynomial
-                const float e = ctx_bf16 ? __builtin_amdgcn_exp2f((S[a] - mx[k]) * 1.44269502162933349609375f) : dexpf_nonpos(S[a] - mx[k]);   // S <= row maximum
+                const float e = ctx_bf16 == 1 ? __builtin_amdgcn_exp2f((S[a] - mx[k]) * 1.44269502162933349609375f) : dexpf_nonpos(S[a] - mx[k]);   // S <= row maximum
                 S[a] = e;
                 sm[k] = sm[k] + e;
             }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
         for (int off = 32; off >= 1; off >>= 1)                      // the canonical sum64 butterfly, NSR rows side by side
 #pragma unroll
             for (int k = 0; k < NSR; ++k) sm[k] = sm[k] + __shfl_xor(sm[k], off, 64);
-        if (ctx_bf16) {                                              // bf16 mode: one hardware reciprocal per row, a multiplication per element
+        if (ctx_bf16 == 1) {                                         // bf16 mode: one hardware reciprocal per row, a multiplication per element
 #pragma unroll
             for (int k = 0; k < NSR; ++k) sm[k] = __builtin_amdgcn_rcpf(sm[k]);
             for (int j = lane; j < T; j += 64)
@@ -282,9 +282,11 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
         for (int r = 0; r < 4; ++r) {
             const int il = il_base + r;
             if (il < rows) {
-                const int64_t o = ((int64_t)b * T + i0 + il) * d + h * HD + (cp + 2 * m) * 16 + l15;
-                if (ctx_bf16) reinterpret_cast<__bf16 *>(ctx)[o] = (__bf16)acc[m][r];      // bf16 mode: out_proj's operand, rounded here (RNE)
-                else ctx[o] = acc[m][r];
+                const int64_t orow = ((int64_t)b * T + i0 + il) * d;
+                const int col = h * HD + (cp + 2 * m) * 16 + l15;
+                if (ctx_bf16 == 1) reinterpret_cast<__bf16 *>(ctx)[orow + col] = (__bf16)acc[m][r];      // bf16 mode: out_proj's operand, rounded here (RNE)
+                else if (ctx_bf16 == 2) ctx[orow + ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3))] = acc[m][r];   // fp32, sigma K layout (GemmArgs::a_sigma)
+                else ctx[orow + col] = acc[m][r];
             }
         }
 }

@@ -31,8 +31,11 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
     bf16x4_ *oph = reinterpret_cast<bf16x4_ *>(reinterpret_cast<__bf16 *>(out) + (int64_t)b * T * d) + c4;   // bf16 mode: the pw2 GEMM's operand (RNE)
     auto put = [&](int t, const float4 &v) {
-        if (out_bf16) oph[(int64_t)t * d4] = bf16x4_{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        else op[(int64_t)t * d4] = v;
+        if (out_bf16 == 1) oph[(int64_t)t * d4] = bf16x4_{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        else if (out_bf16 == 2) {                                       // fp32, sigma K layout (GemmArgs::a_sigma): channel 16 b + 4 q + j -> 16 b + 4 j + q
+            float *o = out + ((int64_t)b * T + t) * d + ((4 * c4) & ~15) + (c4 & 3);
+            o[0] = v.x; o[4] = v.y; o[8] = v.z; o[12] = v.w;
+        } else op[(int64_t)t * d4] = v;
     };
     float4 wt[KC];
 #pragma unroll
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
         v.y = __builtin_fmaf(((acc.y + bi.y) - mu.y) * rs.y, ga.y, be.y);
         v.z = __builtin_fmaf(((acc.z + bi.z) - mu.z) * rs.z, ga.z, be.z);
         v.w = __builtin_fmaf(((acc.w + bi.w) - mu.w) * rs.w, ga.w, be.w);
-        if (out_bf16) {                                                 // bf16 mode: tolerance-class activation (GemmArgs::fast_act)
+        if (out_bf16 == 1) {                                            // bf16 mode: tolerance-class activation (GemmArgs::fast_act)
             v.x = fast_siluf(v.x); v.y = fast_siluf(v.y); v.z = fast_siluf(v.z); v.w = fast_siluf(v.w);
         } else {
             v.x = dsiluf(v.x); v.y = dsiluf(v.y); v.z = dsiluf(v.z); v.w = dsiluf(v.w);

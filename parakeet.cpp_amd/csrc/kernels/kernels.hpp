@@ -74,7 +74,7 @@ struct GemmArgs {
     // load IS its operand of four consecutive MFMA steps -- no transposes on the chain -- and every weight load is 1 KB of consecutive addresses.
     const float *W_sig = nullptr; int a_sigma = 0;
 };
-constexpr int kSmallMRows = 768;   // launch_gemm: products with M <= this (and K % 64 == 0) run on gemm_smallm.hip
+constexpr int kSmallMRows = 512;   // launch_gemm: products with M <= this (and K % 64 == 0) run on gemm_smallm.hip
 // src [rows][ld] -> dst rows x K floats in the W_sig tiling (rows % 16 == 0, K % 64 == 0)
 void launch_sigma_copy(const float *src, float *dst, int64_t rows, int K, int64_t ld, hipStream_t s);
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
