@@ -150,7 +150,7 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     const float *ptab = pos_table(Tp);
     const int64_t rows = (int64_t)S * c;
     const int cache_rows = left_ > 0 ? left_ : 1;
-    // rows <= 768: every product of the chunk is a gemm_smallm chain -- run them on the sigma-K weight copies with sigma-K activations (the
+    // rows <= kSmallMRows: every product of the chunk is a gemm_smallm chain -- run them on the sigma-K weight copies with sigma-K activations (the
     // producers below write that layout; x, the residual stream, stays natural)
     const int sg = (rows <= kSmallMRows && !sig_->empty()) ? 1 : 0;
     const int f = cfg.ffn_intermediate;
