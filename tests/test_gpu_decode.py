@@ -106,6 +106,28 @@ def test_persistent_loop_equals_per_phase_loop(tiny_pair, B):
     assert o["lens"].sum() > 0
 
 
+@pytest.mark.parametrize("B", [300, 1100, 2048, 2100])
+def test_prediction_net_caching_large_lockstep_batches(tiny_pair, B):
+    """Prediction-net caching (kernels.hpp TdtState::need): after a blank the LSTM cells and pred_proj of the next step are skipped and the launches
+    run over the compacted list of utterances that emitted a token.  The list is built per workgroup from 1 .. 8 flags per thread (B <= 2048);
+    larger lock-step batches (2100) run every row.  Utterances of the same batch repeat with a period of 37 so the oracle decodes 37, and every
+    copy must carry the same words -- whatever tile row the compaction gave it."""
+    W, om, gm = tiny_pair
+    base = enc_like(37, 41, om.cfg.hidden_size, 7)
+    enc = np.ascontiguousarray(base[np.arange(B) % 37])
+    g = gm.tdt_decode(enc)
+    o = om.tdt_greedy(base, max_steps=0)
+    assert not o["overflow"] and o["lens"].sum() > 0
+    idx = np.arange(B) % 37
+    assert np.array_equal(g["lens"], o["lens"][idx])
+    assert np.array_equal(g["steps"], o["steps"][idx])
+    for b in range(B):
+        n = o["lens"][idx[b]]
+        for k in ("ids", "start", "end"):
+            assert np.array_equal(g[k][b, :n], o[k][idx[b], :n]), (b, k)
+        G.assert_bits_equal(g["conf"][b, :n], o["conf"][idx[b], :n], "tdt confidence")
+
+
 def test_persistent_loop_110m_heads_and_two_layers(tmp_path_factory):
     for cfg in (dataclasses.replace(pk.make_110m_config(), num_layers=1, name="110m-1L-persist"),
                 G.tiny(name="tiny-2lstm-persist", num_lstm_layers=2)):
