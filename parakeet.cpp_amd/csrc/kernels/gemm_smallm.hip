@@ -48,8 +48,7 @@ __device__ __forceinline__ void sm_tr4x4(float4 &v) {
 
 template <int EPI, int DEPTH /* chunks in the register ring; K / 64 is a multiple of it */, bool SIG /* A in the sigma K layout, W_sig tiled in load order */>
 __global__ __launch_bounds__(128) void gemm_smallm_kernel(GemmArgs g) {
-    constexpr int KC = 64;                       // k per chunk
-    constexpr int NB = (EPI == EPI_GLU) ? 2 : 1; // waves per output tile (GLU: value + gate)
+    constexpr int KC = 64;                       // k per chunk (GLU: two waves per output tile, value + gate)
     __shared__ float gate[64][4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = wave;                       // GLU: wave 0 = value tile, wave 1 = gate tile
