@@ -11,18 +11,21 @@ namespace pk {
 // Blocks (stream * head, query row i < c): the attention of that row.  Blocks with blockIdx.y == c (when cache_k_out is set): the cache
 // rotation of (stream, head) -- new cache = the last `keep` rows of [cache ; this chunk's k / v] (:193-209) written into the OTHER cache
 // buffer, so it runs beside the attention blocks that still read the old one: one launch instead of three per layer.
-__global__ __launch_bounds__(64) void stream_attention_kernel(const float *__restrict__ qkv, const float *__restrict__ kcache,
-                                                              const float *__restrict__ vcache, int cache_rows, int c, int nc, int d, int H,
-                                                              const float *__restrict__ pos, int P, const float *__restrict__ bias_u,
-                                                              const float *__restrict__ bias_v, int att_left, int att_right, float scale,
-                                                              float *__restrict__ ctx, float *__restrict__ cache_k_out,
-                                                              float *__restrict__ cache_v_out, int keep, int ctx_sigma) {
-    extern __shared__ float sm[];                                   // [hd] q+u, [hd] q+v, [kv] probabilities
+__global__ __launch_bounds__(128) void stream_attention_kernel(const float *__restrict__ qkv, const float *__restrict__ kcache,
+                                                               const float *__restrict__ vcache, int cache_rows, int c, int nc, int d, int H,
+                                                               const float *__restrict__ pos, int P, const float *__restrict__ bias_u,
+                                                               const float *__restrict__ bias_v, int att_left, int att_right, float scale,
+                                                               float *__restrict__ ctx, float *__restrict__ cache_k_out,
+                                                               float *__restrict__ cache_v_out, int keep, int ctx_sigma) {
+    extern __shared__ float sm[];                                   // [hd] q+u, [hd] q+v, [kv] probabilities, [2] wave maxima
     const int hd = d / H, kv = nc + c;
-    const int sidx = blockIdx.x / H, h = blockIdx.x % H, i = blockIdx.y, lane = threadIdx.x;
+    const int sidx = blockIdx.x / H, h = blockIdx.x % H, i = blockIdx.y;
+    // one or two wavefronts (launcher: two when there are more than 64 keys -- a 70-row cache + the chunk: both halves of the key range run
+    // their score chains side by side instead of one after the other)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     if (i == c) {                                                   // cache rotation of this (stream, head): rows r <- row nc + c - keep + r of [cache ; new]
         const int hd4 = hd / 4;
-        for (int idx = lane; idx < keep * hd4; idx += 64) {
+        for (int idx = tid; idx < keep * hd4; idx += nthr) {
             const int r = idx / hd4, e4 = idx % hd4, j = kv - keep + r;
             const int64_t src_c = ((int64_t)sidx * cache_rows + j) * d + h * hd + 4 * e4;
             const int64_t src_n = ((int64_t)sidx * c + (j - nc)) * 3 * d + h * hd + 4 * e4;
@@ -32,9 +35,9 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
         }
         return;
     }
-    float *qu = sm, *qv = sm + hd, *pr = sm + 2 * hd;
+    float *qu = sm, *qv = sm + hd, *pr = sm + 2 * hd, *red = pr + kv;
     const float *qrow = qkv + ((int64_t)sidx * c + i) * 3 * d + h * hd;
-    for (int e = lane; e < hd; e += 64) {
+    for (int e = tid; e < hd; e += nthr) {
         const float q = qrow[e];
         qu[e] = q + bias_u[h * hd + e];                             // :209-212
         qv[e] = q + bias_v[h * hd + e];
@@ -49,28 +52,33 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
     const int off = P > kv ? P - kv : 0;                            // rightmost kv columns of the position scores, NOT rel-shifted (:215-224)
     const int abs_pos = kv - c + i;
     float m = -__builtin_huge_valf();
-    for (int j = lane; j < kv; j += 64) {
-        // 16-byte loads of the key / position rows (each lane walks its own row); the chains stay sequential in e
+    for (int j = tid; j < kv; j += nthr) {
+        // 16-byte loads of the key / position rows (each lane walks its own row), 32 / 16 / 2 of them in flight per round trip; the two chains
+        // stay sequential in e
         const float4 *kr = reinterpret_cast<const float4 *>(krow(j)), *pp = reinterpret_cast<const float4 *>(pos + (int64_t)(off + j) * d + h * hd);
         const float4 *qu4 = reinterpret_cast<const float4 *>(qu), *qv4 = reinterpret_cast<const float4 *>(qv);
         float cs = 0.0f, ps = 0.0f;
+        auto step = [&](const float4 &kk, const float4 &p4, int e) {
+            const float4 a = qu4[e], bq = qv4[e];
+            cs = __builtin_fmaf(a.x, kk.x, cs); cs = __builtin_fmaf(a.y, kk.y, cs); cs = __builtin_fmaf(a.z, kk.z, cs); cs = __builtin_fmaf(a.w, kk.w, cs);
+            ps = __builtin_fmaf(bq.x, p4.x, ps); ps = __builtin_fmaf(bq.y, p4.y, ps); ps = __builtin_fmaf(bq.z, p4.z, ps); ps = __builtin_fmaf(bq.w, p4.w, ps);
+        };
         int e0 = 0;
-        for (; e0 + 8 <= hd / 4; e0 += 8) {                         // 16 row loads in flight per round trip
+        for (; e0 + 16 <= hd / 4; e0 += 16) {
+            float4 kk[16], p4[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { kk[u] = kr[e0 + u]; p4[u] = pp[e0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) step(kk[u], p4[u], e0 + u);
+        }
+        for (; e0 + 8 <= hd / 4; e0 += 8) {
             float4 kk[8], p4[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { kk[u] = kr[e0 + u]; p4[u] = pp[e0 + u]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float4 a = qu4[e0 + u], bq = qv4[e0 + u];
-                cs = __builtin_fmaf(a.x, kk[u].x, cs); cs = __builtin_fmaf(a.y, kk[u].y, cs); cs = __builtin_fmaf(a.z, kk[u].z, cs); cs = __builtin_fmaf(a.w, kk[u].w, cs);
-                ps = __builtin_fmaf(bq.x, p4[u].x, ps); ps = __builtin_fmaf(bq.y, p4[u].y, ps); ps = __builtin_fmaf(bq.z, p4[u].z, ps); ps = __builtin_fmaf(bq.w, p4[u].w, ps);
-            }
+            for (int u = 0; u < 8; ++u) step(kk[u], p4[u], e0 + u);
         }
-        for (; e0 < hd / 4; ++e0) {
-            const float4 kk = kr[e0], p4 = pp[e0], a = qu4[e0], bq = qv4[e0];
-            cs = __builtin_fmaf(a.x, kk.x, cs); cs = __builtin_fmaf(a.y, kk.y, cs); cs = __builtin_fmaf(a.z, kk.z, cs); cs = __builtin_fmaf(a.w, kk.w, cs);
-            ps = __builtin_fmaf(bq.x, p4.x, ps); ps = __builtin_fmaf(bq.y, p4.y, ps); ps = __builtin_fmaf(bq.z, p4.z, ps); ps = __builtin_fmaf(bq.w, p4.w, ps);
-        }
+        for (; e0 < hd / 4; ++e0) step(kr[e0], pp[e0], e0);
         float sc = (cs + ps) * scale;                               // :226
         const int dist = abs_pos - j;
         if ((att_left >= 0 || att_right >= 0) && (dist > att_left || -dist > att_right)) sc = -1e9f;   // masked_fill :231-247
@@ -78,21 +86,38 @@ __global__ __launch_bounds__(64) void stream_attention_kernel(const float *__res
         m = fmaxf(m, sc);
     }
     m = wave_max64(m);
-    float p = 0.0f;
-    for (int j = lane; j < kv; j += 64) {
-        const float e = dexpf_nonpos(pr[j] - m);
-        pr[j] = e;
-        p = p + e;
-    }
-    const float sum = wave_sum64(p);
-    for (int j = lane; j < kv; j += 64) pr[j] = pr[j] / sum;
+    if (lane == 0) red[wave] = m;
     __syncthreads();
-    for (int eb = 0; eb < hd; eb += 128) {                          // softmax(S) V, k = key index in natural order (:250); two output columns per lane
-        const int e0 = eb + lane, e1 = eb + 64 + lane;
+    if (nthr > 64) m = fmaxf(red[0], red[1]);
+    for (int j = tid; j < kv; j += nthr) pr[j] = dexpf_nonpos(pr[j] - m);
+    __syncthreads();
+    // the canonical sum (lane l adds elements l, l + 64, ... in index order, then the xor butterfly), by every wave for itself
+    float p = 0.0f;
+    for (int j = lane; j < kv; j += 64) p = p + pr[j];
+    const float sum = wave_sum64(p);
+    __syncthreads();                                                // (both waves have read the exponentials)
+    for (int j = tid; j < kv; j += nthr) pr[j] = pr[j] / sum;
+    __syncthreads();
+    for (int eb = 0; eb < hd; eb += 2 * nthr) {                     // softmax(S) V, k = key index in natural order (:250); two output columns per thread
+        const int e0 = eb + tid, e1 = eb + nthr + tid;
         const bool h0 = e0 < hd, h1 = e1 < hd;
         float acc0 = 0.0f, acc1 = 0.0f;
         int j = 0;
-        for (; j + 8 <= kv; j += 8) {                               // 8 value rows (16 loads) in flight per round trip
+        for (; j + 24 <= kv; j += 24) {                             // 24 value rows in flight per round trip
+            float v0[24], v1[24];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) {
+                const float *vr = vrow(j + u);
+                v0[u] = h0 ? vr[e0] : 0.0f;
+                v1[u] = h1 ? vr[e1] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 24; ++u) {
+                acc0 = __builtin_fmaf(pr[j + u], v0[u], acc0);
+                acc1 = __builtin_fmaf(pr[j + u], v1[u], acc1);
+            }
+        }
+        for (; j + 8 <= kv; j += 8) {
             float v0[8], v1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -125,10 +150,10 @@ void launch_stream_attention(const float *qkv_new, const float *kcache, const fl
                              float *ctx, hipStream_t s, float *cache_k_out, float *cache_v_out, int keep_max, int ctx_sigma) {
     const int hd = d / n_heads;
     const float scale = 1.0f / sqrtf((float)hd);
-    const size_t lds = (size_t)(2 * hd + nc + c) * sizeof(float);
+    const size_t lds = (size_t)(2 * hd + nc + c + 2) * sizeof(float);
     const int kv = nc + c, keep = kv > keep_max ? keep_max : kv;
     const bool rotate = cache_k_out && cache_v_out && keep > 0;
-    hipLaunchKernelGGL(stream_attention_kernel, dim3(S * n_heads, c + (rotate ? 1 : 0)), dim3(64), lds, s, qkv_new, kcache, vcache, cache_rows, c, nc, d,
+    hipLaunchKernelGGL(stream_attention_kernel, dim3(S * n_heads, c + (rotate ? 1 : 0)), dim3(kv > 64 ? 128 : 64), lds, s, qkv_new, kcache, vcache, cache_rows, c, nc, d,
                        n_heads, pos, P, bias_u, bias_v, att_left, att_right, scale, ctx, rotate ? cache_k_out : nullptr, rotate ? cache_v_out : nullptr, keep, ctx_sigma);
 }
 
