@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--models", default="tdt-ctc-110m,tdt-600m,rnnt-600m")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--seconds", default="", help="comma-separated audio lengths instead of the reference's table (profiling one shape)")
     args = ap.parse_args()
     import numpy as np
     import pkload
@@ -39,6 +40,8 @@ def main():
             synth.save_weights(wp, synth.synth_weights(cfg, seed=42))
         gm = capi.Model(wp, cfg, device=0)
         secs = [1, 5, 10, 30, 60] if name == "tdt-ctc-110m" else [10]
+        if args.seconds:
+            secs = [int(x) for x in args.seconds.split(",")]
         for sec in secs:
             feats = np.random.default_rng(sec).standard_normal((1, sec * 100, cfg.mel_bins)).astype(np.float32)
             gm.encode(feats)                                            # 1 warm-up (also builds the position tables for this length)
