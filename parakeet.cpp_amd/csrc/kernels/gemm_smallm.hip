@@ -145,6 +145,92 @@ __global__ __launch_bounds__(128) void gemm_smallm_kernel(GemmArgs g) {
     }
 }
 
+// Two 16-row tiles per wave (SIG operands only): the tiles share the W operand and their two independent chains are issued alternately -- 64 clocks
+// per MFMA pair instead of 44 per single MFMA, so each chain is ~1.45x slower, but the launch has half the waves and reads W once per pair.
+// For the shapes where one wave per tile would put more waves on the chip than it has SIMDs (a whole 10-30 s utterance against a wide product:
+// fc1 of tdt-ctc-110m at M = 126 is 1024 waves asking L2 for 64 MB), which are bound by L2 traffic and not by the chain.
+template <int EPI>
+__global__ __launch_bounds__(64) void gemm_smallm_rt2_kernel(GemmArgs g) {
+    constexpr int KC = 64, DEPTH = 4;
+    const int lane = threadIdx.x, r = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 32;
+    sm_f32x4 acc[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    const int col = n0 + r;
+    float bias = 0.0f, res[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    if (col < g.N) {
+        if (g.bias) bias = g.bias[col];
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + 16 * t + 4 * kq + i;
+                    if (row < g.M) res[t][i] = g.resid[(int64_t)row * g.ldr + col];
+                }
+        }
+    }
+    const float *ap[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int arow = m0 + 16 * t + r;
+        arow = arow < g.M ? arow : g.M - 1;
+        ap[t] = g.A + (int64_t)arow * g.lda + 4 * kq;
+    }
+    const float *wp = g.W_sig + (int64_t)(n0 >> 4) * 16 * g.K + 4 * lane;
+    float4 ra[DEPTH][2][4], rw[DEPTH][4];
+    auto gload = [&](int kc, int set) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rw[set][q] = *reinterpret_cast<const float4 *>(wp + kc * (16 * KC) + 256 * q);
+            ra[set][0][q] = *reinterpret_cast<const float4 *>(ap[0] + kc * KC + 16 * q);
+            ra[set][1][q] = *reinterpret_cast<const float4 *>(ap[1] + kc * KC + 16 * q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int nkc = g.K / KC, last = nkc - 1;
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; ++j) gload(j < last ? j : last, j);
+    for (int kc0 = 0; kc0 < nkc; kc0 += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const int nx = kc0 + j + DEPTH - 1;
+            gload(nx < last ? nx : last, (j + DEPTH - 1) % DEPTH);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = rw[j][q], a0 = ra[j][0][q], a1 = ra[j][1][q];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w.w, acc[1], 0, 0, 0);
+            }
+        }
+    }
+    if (col >= g.N) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + 16 * t + 4 * kq + i;
+            if (row >= g.M) continue;
+            float v = acc[t][i];
+            if (g.bias) v = v + bias;
+            if constexpr (EPI == EPI_RELU) {
+                v = v > 0.0f ? v : 0.0f;
+            } else if constexpr (EPI == EPI_SILU) {
+                v = dsiluf(v);
+            } else if constexpr (EPI == EPI_RESID) {
+                const float y = v * g.alpha;
+                v = res[t][i] + y;
+            }
+            if (g.remap_rows) g.out[(int64_t)(row / g.remap_rows) * g.remap_gs + (int64_t)(row % g.remap_rows) * g.remap_rs + (int64_t)col * g.remap_cs] = v;
+            else g.out[(int64_t)row * g.ldo + (col < g.sigma_cols ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = v;
+        }
+}
+
 // W_sig of GemmArgs: dst[tile = row / 16][chunk = k / 64][q][lane = (row % 16) + 16 kq][e] = src[row][64 chunk + 16 q + 4 e + kq]
 __global__ void sigma_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t rows, int K, int64_t ld) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // destination index
@@ -168,6 +254,14 @@ static void launch_smallm_epi(const GemmArgs &a, hipStream_t s) {
     const dim3 grid((a.N + 15) / 16, (a.M + 15) / 16), block(64 * NB);
     const int nkc = a.K / 64;
     if (a.a_sigma && a.W_sig) {
+        const int row_tiles = (a.M + 15) / 16;
+        if constexpr (EPI != EPI_GLU) {
+            // more waves than SIMDs (1024): two row tiles per wave (gemm_smallm_rt2_kernel)
+            if (nkc % 4 == 0 && row_tiles >= 4 && (int64_t)grid.x * row_tiles >= 768) {
+                hipLaunchKernelGGL((gemm_smallm_rt2_kernel<EPI>), dim3(grid.x, (row_tiles + 1) / 2), dim3(64), 0, s, a);
+                return;
+            }
+        }
         if (nkc % 8 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 8, true>), grid, block, 0, s, a);
         else if (nkc % 2 == 0) hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 2, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_smallm_kernel<EPI, 1, true>), grid, block, 0, s, a);
