@@ -1,4 +1,4 @@
-// parakeet.cpp_amd/csrc/kernels/gemm_smallm.hip -- the fp32 MFMA GEMM for a HANDFUL of rows (M <= kSmallMRows = 512): the streaming
+// parakeet.cpp_amd/csrc/kernels/gemm_smallm.hip -- the fp32 MFMA GEMM for a HANDFUL of rows (M <= kSmallMRows): the streaming
 // encoder's products (16 streams x 1-3 frames per chunk against the full 600M-parameter weight set) and the single-clip path.
 //
 // out[M][N] = epi(A[M][K] * W[N][K]^T + bias), natural-k fma chains (bit-identical to the oracle and to the big-tile kernels).

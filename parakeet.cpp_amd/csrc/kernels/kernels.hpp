@@ -74,8 +74,10 @@ struct GemmArgs {
     // load IS its operand of four consecutive MFMA steps -- no transposes on the chain -- and every weight load is 1 KB of consecutive addresses.
     const float *W_sig = nullptr; int a_sigma = 0;
 };
-constexpr int kSmallMRows = 512;   // launch_gemm: products with M <= this (and K % 64 == 0) run on gemm_smallm.hip.  Measured on the reference's
-                                   // protocol (110m encoder, batch 1): 30 s of audio (M = 376) 4.1 ms on it against 6.2 on the tile kernel, 60 s (M = 751) 7.4 against 6.9
+constexpr int kSmallMRows = 1536;  // launch_gemm: products with M <= this (and K % 64 == 0) run on gemm_smallm.hip.  Measured with the two-row-tile
+                                   // variant in place (110m encoder; reference protocol, batch 1: M = 626 5.6 ms on it vs 6.7 on the tile kernels,
+                                   // M = 751 6.1 vs 6.9, M = 1251 12.4 vs 15.1; pipelined batches of 8 / 12 / 16 clips, M = 1008 / 1512 / 2016:
+                                   // 6.75 vs 6.50, 9.14 vs 10.67, 11.35 vs 10.93 ms per step)
 // src [rows][ld] -> dst rows x K floats in the W_sig tiling (rows % 16 == 0, K % 64 == 0)
 void launch_sigma_copy(const float *src, float *dst, int64_t rows, int K, int64_t ld, hipStream_t s);
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
