@@ -101,14 +101,22 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
     }
 }
 
-void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
-                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16) {
-    constexpr int TT = 8;
+template <int TT>
+static void launch_dwconv_tt(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
+                             const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16) {
     const int n_strips = (T + TT - 1) / TT;
     const int64_t n_items = (int64_t)B * n_strips * (d / 4);          // d % 4 == 0 (hidden sizes are multiples of 32)
     const dim3 grid((unsigned)((n_items + 255) / 256));
     if (kc == 9) hipLaunchKernelGGL((dwconv_bn_silu_kernel<9, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out, out_bf16);
     else if (kc == 31) hipLaunchKernelGGL((dwconv_bn_silu_kernel<31, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out, out_bf16);
+}
+
+void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
+                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16) {
+    // strips of 8 frames per thread amortise the window loads on large batches; a single utterance (the latency-bound small-batch route) has
+    // only a handful of workgroups that way -- strips of 2 frames: four times the threads, a quarter of the serial work each
+    if ((int64_t)B * T <= 2048) launch_dwconv_tt<2>(g, B, T, d, kc, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, s, out_bf16);
+    else launch_dwconv_tt<8>(g, B, T, d, kc, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, s, out_bf16);
 }
 
 }  // namespace pk
