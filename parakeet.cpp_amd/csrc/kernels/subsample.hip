@@ -20,13 +20,13 @@ namespace pk {
 // same LDS addresses (broadcast reads with compile-time offsets), so the inner loops have no bounds checks at all.
 // Out-of-range taps multiply a zero instead of being skipped: fma(w, 0, acc) == acc for every acc reachable from +0, so
 // the chain equals the oracle's skip-the-padding chain bit for bit.
-template <int XC>
+template <int XC, int YS = 8 /* output rows per strip: 8 on batches (conv1 rows shared by consecutive outputs), 2 when one utterance is all there is */>
 __global__ __launch_bounds__(256) void sub_conv1_dw1_kernel(const float *__restrict__ feats, int Tm, int F, int C,
                                                             const float *__restrict__ w1 /*[9][C]*/, const float *__restrict__ b1,
                                                             const float *__restrict__ wd /*[9][C]*/, const float *__restrict__ bd,
                                                             int H1, int W1, int H2, int W2, int n_xc, int n_ys, int64_t n_strips,
                                                             float *__restrict__ out) {
-    constexpr int NC = 2 * XC + 1, YS = 8;
+    constexpr int NC = 2 * XC + 1;
     constexpr int WR = 4 * YS + 3, WC = 4 * XC + 3, PW = (WC + 3) & ~3, TILE = WR * PW;   // input window per strip
     extern __shared__ __attribute__((aligned(16))) float win[];       // [256/C][WR][PW]
     const int spb = 256 / C;                                           // strips per block
@@ -124,24 +124,32 @@ __global__ __launch_bounds__(256) void sub_dw_kernel(const float *__restrict__ i
     out[pix * C + c] = acc + bd[c];
 }
 
-template <int XC>
+template <int XC, int YS = 8>
 static void launch_c1d1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
                         const float *bd, int H1, int W1, int H2, int W2, float *out, hipStream_t s) {
-    constexpr int WR = 4 * 8 + 3, PW = (4 * XC + 3 + 3) & ~3;
-    const int spb = 256 / C, n_ys = (H2 + 7) / 8, n_xc = (W2 + XC - 1) / XC;
+    constexpr int WR = 4 * YS + 3, PW = (4 * XC + 3 + 3) & ~3;
+    const int spb = 256 / C, n_ys = (H2 + YS - 1) / YS, n_xc = (W2 + XC - 1) / XC;
     const int64_t n_strips = (int64_t)B * n_ys * n_xc;
     const size_t lds = (size_t)spb * WR * PW * sizeof(float);
     static DynLdsSlots slots;
-    ensure_dyn_lds(slots, reinterpret_cast<const void *>(&sub_conv1_dw1_kernel<XC>), lds);
-    hipLaunchKernelGGL(sub_conv1_dw1_kernel<XC>, dim3((unsigned)((n_strips + spb - 1) / spb)), dim3(256), lds, s, feats, Tm, F, C, w1, b1,
+    ensure_dyn_lds(slots, reinterpret_cast<const void *>(&sub_conv1_dw1_kernel<XC, YS>), lds);
+    hipLaunchKernelGGL((sub_conv1_dw1_kernel<XC, YS>), dim3((unsigned)((n_strips + spb - 1) / spb)), dim3(256), lds, s, feats, Tm, F, C, w1, b1,
                        wd, bd, H1, W1, H2, W2, n_xc, n_ys, n_strips, out);
 }
 void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
                           const float *bd, float *out, hipStream_t s) {
     const int H1 = (Tm - 1) / 2 + 1, W1 = (F - 1) / 2 + 1, H2 = (H1 - 1) / 2 + 1, W2 = (W1 - 1) / 2 + 1;
     // 80 mel bins -> one 20-column chunk per output row; 128 -> two chunks of 16
-    if (W2 <= 20 || W2 % 20 == 0) launch_c1d1<20>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
-    else launch_c1d1<16>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
+    // a strip of 8 output rows per thread shares its conv1 rows; one or two utterances give only a few dozen such strips -- strips of 2 rows
+    // (1.5x the conv1 work, four times the workgroups, a quarter of the serial chain each: 77 -> ~25 us for one 10 s clip)
+    const bool small = (int64_t)B * H2 <= 1024;
+    if (W2 <= 20 || W2 % 20 == 0) {
+        if (small) launch_c1d1<20, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
+        else launch_c1d1<20>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
+    } else {
+        if (small) launch_c1d1<16, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
+        else launch_c1d1<16>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
+    }
 }
 // Depthwise 3x3 stride-2 conv (dw2, src/encoder.cpp:230), channels-last.  One thread = 4 adjacent channels x XO adjacent output
 // pixels of one output row: the 2*XO+1 input pixels of each of the three input rows are loaded once as float4 and shared by the XO
