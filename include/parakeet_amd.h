@@ -102,7 +102,10 @@ pk_status pk_model_load(const char *safetensors_path, const char *vocab_path, co
 /* The same from a safetensors image in memory (copied): what a rank receives when rank 0 reads the file once and broadcasts it
  * (RCCL) instead of every rank going to storage. */
 pk_status pk_model_load_buffer(const void *safetensors_image, size_t n_bytes, const char *vocab_path, const pk_config *cfg, pk_model **out);
-/* Upload (packed) weights to HBM on `device` and build the execution plan.  Idempotent per device. */
+/* Upload (packed) weights to HBM on `device` and build the execution plan.  Idempotent per device.
+ * HBM use: the weights once, plus -- fp32 mode, on the first call that runs fewer than 1537 encoder rows at a time (one or a few clips,
+ * every streaming session) -- a second copy of the encoder's Linear weights tiled for the small-batch kernels (0.4 GB for tdt-ctc-110m,
+ * 2.4 GB for the 600M models), shared by all later calls and streams of the model. */
 pk_status pk_model_to_gpu(pk_model *m, int device);
 void pk_model_free(pk_model *m);
 pk_status pk_model_config(const pk_model *m, pk_config *out);
@@ -141,6 +144,27 @@ pk_status pk_ctc_decode(pk_model *m, const float *enc, int B, int T, int32_t *id
 pk_status pk_tdt_decode(pk_model *m, const float *enc, int B, int T, int max_tokens, int32_t *ids, int32_t *lens,
                         int32_t *start, int32_t *end, float *conf, int32_t *steps);
 
+/* ---- ragged (mixed-length) forms of the stage entry points -------------------------------------------------------------------
+ * The reference's roadmap item "Batch inference: pad + length-mask multiple audio files, batch through encoder and decoder" (README.md:513;
+ * mask seam src/encoder.cpp:163-165) -- done by PACKING instead of padding: the B clips of a batch lie back to back along the time axis of
+ * every tensor, GEMMs / LayerNorm / activations are row-wise and see one tall matrix, and the kernels that look across rows (STFT framing,
+ * the stride-2 convolutions, the depthwise conv, attention with its relative-position table, the greedy decoders) take per-clip extents.
+ * No padded frame is ever computed and no mask is needed; every clip's result is BIT-IDENTICAL to the same clip run alone (same fma
+ * chains, same softmax extent, same zero padding at its own edges) -- tests/test_gpu_ragged.py.
+ * pk_mel_ragged: clip i = pcm[offsets[i] .. offsets[i+1]) -> feats packed [sum_i Tm_i][mel_bins], Tm_i = pk_mel_num_frames(len_i); logmel
+ *   (optional) per clip one [mel_bins][Tm_i] block, blocks back to back.
+ * pk_encode_ragged: feats packed as above, n_mel_frames[B] -> enc packed [sum_i T_i][hidden], T_i = pk_encoder_num_frames(Tm_i).
+ * pk_conformer_blocks_ragged: x packed [sum_i n_frames[i]][hidden] in and out.
+ * pk_ctc_decode_ragged / pk_tdt_decode_ragged: enc packed, n_frames[B]; token arrays [B][max_i n_frames[i]] resp. [B][max_tokens] as in the
+ *   uniform calls; logp (optional) packed [sum_i T_i][ctc_vocab]. */
+pk_status pk_mel_ragged(pk_model *m, const float *pcm, const int64_t *offsets, int n_clips, float *feats, float *logmel);
+pk_status pk_encode_ragged(pk_model *m, const float *feats, const int32_t *n_mel_frames, int B, int stop_layer, int stop_stage, float *enc);
+pk_status pk_conformer_blocks_ragged(pk_model *m, const float *x_in, const int32_t *n_frames, int B, int first_layer, int n_layers, float *x_out);
+pk_status pk_ctc_decode_ragged(pk_model *m, const float *enc, const int32_t *n_frames, int B, int32_t *ids, int32_t *lens, int32_t *start,
+                               int32_t *end, float *conf, float *logp);
+pk_status pk_tdt_decode_ragged(pk_model *m, const float *enc, const int32_t *n_frames, int B, int max_tokens, int32_t *ids, int32_t *lens,
+                               int32_t *start, int32_t *end, float *conf, int32_t *steps);
+
 /* Early warning of the tolerance-class (bf16) mode, SURVEY.md 8(c): per utterance of the LAST pk_tdt_decode on this model, the smallest
  * (top-1 minus top-2) log-prob over all of its greedy decisions -- the label argmax (tdt.cpp:78-82) and, for TDT heads, the duration argmax
  * (:84-86: a flip there moves the frame pointer and every later token with it): how close the decode came to a different path.  A margin below the mode's numerical error marks a token that may differ from the reference.  Not produced for
@@ -153,6 +177,13 @@ enum { PK_DECODER_CTC = 0, PK_DECODER_TDT = 1 }; /* enum class Decoder (transcri
 /* A batch slot of up to max_clips clips of exactly n_samples samples, all buffers resident in HBM. */
 pk_status pk_batch_create(pk_model *m, int max_clips, int64_t n_samples, pk_batch **out);
 void pk_batch_free(pk_batch *b);
+/* The same pipeline with RAGGED capacity: every run takes up to max_clips clips of ANY lengths (<= max_clip_samples each, <=
+ * max_total_samples in all), packed -- see the ragged stage entry points above.  pk_batch_upload_ragged: clip i = pcm[offsets[i] ..
+ * offsets[i+1]); a batch whose clips all have one length runs the uniform kernels.  pk_batch_run / _sync / _results* / decode groups work
+ * as for uniform pipelines; the token arrays are [n_clips][pk_batch_max_tokens], pitched for the longest clip the pipeline can hold. */
+pk_status pk_batch_create_ragged(pk_model *m, int max_clips, int64_t max_total_samples, int64_t max_clip_samples, pk_batch **out);
+pk_status pk_batch_upload_ragged(pk_batch *b, const float *pcm, const int64_t *offsets, int n_clips);
+pk_status pk_batch_upload_ragged_async(pk_batch *b, const float *pcm, const int64_t *offsets, int n_clips);
 /* Host -> HBM copy of the PCM (outside bench's timed region). */
 pk_status pk_batch_upload(pk_batch *b, const float *pcm, int n_clips);
 /* mel -> encoder -> decode, enqueued on the batch's stream; returns without synchronising. */
@@ -231,16 +262,17 @@ typedef struct pk_result {      /* TranscribeResult (transcribe.hpp:23-30) + Tim
     int32_t n_words;
     const pk_word *words;
 } pk_result;
-/* Clips are pcm[offsets[i] .. offsets[i+1]); clips of equal length are batched together on the GPU.
+/* Clips are pcm[offsets[i] .. offsets[i+1]), of ANY lengths: they are sorted by length and packed into ragged batches (<= 256 clips, <= 64 x
+ * 10 s of audio per batch) that go through the two-stream pipeline; every clip's result is bit-identical to transcribing it alone.
  * results: array of n_clips pk_result, owned by the library until pk_results_free. */
 pk_status pk_transcribe_pcm(pk_model *m, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt,
                             pk_result **results);
 void pk_results_free(pk_result *results, int n_clips);
 /* ---- one node, several GPUs: utterance shards (the reference has no multi-device path, README.md:513) ----------
  * A pk_group is one model REPLICA per device of this process: the safetensors file is mapped once and every replica is built from that
- * one host image by its own host thread (each device uploads over its own PCIe link).  pk_group_transcribe_pcm partitions the clips into
- * batches of equal-length clips (<= 64) and deals the batches round-robin to the devices (rank r takes batches r, r+G, ...); one host
- * thread drives each device through the SAME two-stream pipeline pk_transcribe_pcm uses (PCM of batch k+1 staged and decode(k) driven
+ * one host image by its own host thread (each device uploads over its own PCIe link).  pk_group_transcribe_pcm deals the clips, longest
+ * first, each to the device with the least audio so far (equal lengths: rank r takes clips r, r+G, ...); every device packs its clips into
+ * ragged batches; one host thread drives each device through the SAME two-stream pipeline pk_transcribe_pcm uses (PCM of batch k+1 staged and decode(k) driven
  * under encoder(k+1); from four batches per rank on, decode groups of four).  Utterances share nothing, so there is NO collective: not on
  * the data path and -- one process, one address space -- not for the results either; the ranks never wait for each other.  The library has
  * no link-time dependency on RCCL.  (The multi-PROCESS deployment -- one process per GPU under torch.distributed, bench.py --gpus N,
@@ -293,7 +325,9 @@ pk_status pk_stream_create(pk_model *m, int n_streams, int att_context_left, int
 void pk_stream_free(pk_stream *s);
 pk_status pk_stream_reset(pk_stream *s);    /* NemotronTranscriber::reset (nemotron.cpp:54-58) */
 /* pcm[n_streams][n_samples] -> the tokens each stream emitted for this chunk: ids/start/end/conf [n_streams][max_tokens]
- * (start / end: encoder frames since the stream began, eou.cpp:77-79), lens[n_streams] (0 while audio is still being buffered). */
+ * (start / end: encoder frames since the stream began, eou.cpp:77-79), lens[n_streams] (0 while audio is still being buffered).
+ * Limit: one push carries at most 79 360 samples (4.96 s = 62 encoder frames: the per-chunk decode workspace); a longer push is rejected
+ * with PK_ERR_UNSUPPORTED BEFORE any carried state changes -- split it into several pushes (the reference's chunks are 1-14 frames). */
 pk_status pk_stream_push(pk_stream *s, const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start,
                          int32_t *end, float *conf);
 /* the three stages of a push, on host buffers, for parity tests (each consumes / updates the same carried state):

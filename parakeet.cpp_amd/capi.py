@@ -119,6 +119,14 @@ _LATE_SIGNATURES = {
     "pk_ctc_decode": [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, f32p],
     "pk_tdt_decode": [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, i32p],
     "pk_model_set_decode_loop": [C.c_void_p, C.c_int],
+    "pk_mel_ragged": [C.c_void_p, f32p, i64p, C.c_int, f32p, f32p],
+    "pk_encode_ragged": [C.c_void_p, f32p, i32p, C.c_int, C.c_int, C.c_int, f32p],
+    "pk_conformer_blocks_ragged": [C.c_void_p, f32p, i32p, C.c_int, C.c_int, C.c_int, f32p],
+    "pk_ctc_decode_ragged": [C.c_void_p, f32p, i32p, C.c_int, i32p, i32p, i32p, i32p, f32p, f32p],
+    "pk_tdt_decode_ragged": [C.c_void_p, f32p, i32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, i32p],
+    "pk_batch_create_ragged": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)],
+    "pk_batch_upload_ragged": [C.c_void_p, f32p, i64p, C.c_int],
+    "pk_batch_upload_ragged_async": [C.c_void_p, f32p, i64p, C.c_int],
     "pk_batch_create": [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_void_p)],
     "pk_batch_free": [C.c_void_p],
     "pk_batch_upload": [C.c_void_p, f32p, C.c_int],
@@ -453,6 +461,34 @@ class Batch:
         self._cap = max_clips
         check(lib().pk_batch_create(model._h, max_clips, n_samples, C.byref(self._h)))
 
+    @classmethod
+    def ragged(cls, model, max_clips, max_total_samples, max_clip_samples):
+        """pk_batch_create_ragged: a pipeline whose runs take clips of ANY lengths (packed, no padding)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.n_clips = 0
+        self._cap = max_clips
+        check(lib().pk_batch_create_ragged(model._h, max_clips, int(max_total_samples), int(max_clip_samples), C.byref(self._h)))
+        return self
+
+    @staticmethod
+    def _pack(clips):
+        clips = [_c(c).ravel() for c in clips]
+        off = np.zeros(len(clips) + 1, np.int64)
+        off[1:] = np.cumsum([len(c) for c in clips])
+        return np.concatenate(clips), off
+
+    def upload_ragged(self, clips):
+        pcm, off = self._pack(clips)
+        self.n_clips = len(off) - 1
+        check(lib().pk_batch_upload_ragged(self._h, _f(pcm), off.ctypes.data_as(i64p), self.n_clips))
+
+    def upload_ragged_async(self, clips):
+        pcm, off = self._pack(clips)
+        self._staged = pcm
+        self._staged_clips = len(off) - 1
+        check(lib().pk_batch_upload_ragged_async(self._h, _f(pcm), off.ctypes.data_as(i64p), len(off) - 1))
+
     def upload(self, pcm):
         pcm = _c(pcm)
         self.n_clips = pcm.shape[0]
@@ -649,6 +685,70 @@ class Model:
         lm = np.empty((B, self.cfg.mel_bins, nf), np.float32) if return_logmel else None
         check(lib().pk_mel(self._h, _f(pcm), B, n, _f(feats), _f(lm) if return_logmel else None))
         return (feats, lm) if return_logmel else feats
+
+    # ragged (mixed-length) forms: lists of per-clip arrays in, lists of per-clip arrays out (packed along time inside) -----------------
+    def mel_ragged(self, clips, return_logmel=False):
+        clips = [_c(c).ravel() for c in clips]
+        off = np.zeros(len(clips) + 1, np.int64)
+        off[1:] = np.cumsum([len(c) for c in clips])
+        pcm = np.concatenate(clips)
+        nf = [lib().pk_mel_num_frames(len(c)) for c in clips]
+        F = self.cfg.mel_bins
+        feats = np.empty((sum(nf), F), np.float32)
+        lm = np.empty(sum(nf) * F, np.float32) if return_logmel else None
+        check(lib().pk_mel_ragged(self._h, _f(pcm), off.ctypes.data_as(i64p), len(clips), _f(feats), _f(lm) if return_logmel else None))
+        o = np.concatenate([[0], np.cumsum(nf)])
+        fl = [feats[o[i]:o[i + 1]] for i in range(len(clips))]
+        if not return_logmel:
+            return fl
+        return fl, [lm[o[i] * F:o[i + 1] * F].reshape(F, nf[i]) for i in range(len(clips))]
+
+    def encode_ragged(self, feats_list, stop_layer=-1, stop_stage=0):
+        tm = np.asarray([f.shape[0] for f in feats_list], np.int32)
+        T = [lib().pk_encoder_num_frames(int(t)) for t in tm]
+        feats = _c(np.concatenate([_c(f) for f in feats_list], axis=0))
+        out = np.empty((sum(T), self.cfg.hidden_size), np.float32)
+        check(lib().pk_encode_ragged(self._h, _f(feats), _i(tm), len(tm), stop_layer, stop_stage, _f(out)))
+        o = np.concatenate([[0], np.cumsum(T)])
+        return [out[o[i]:o[i + 1]] for i in range(len(tm))]
+
+    def conformer_blocks_ragged(self, x_list, first_layer=0, n_layers=None):
+        T = np.asarray([x.shape[0] for x in x_list], np.int32)
+        x = _c(np.concatenate([_c(v) for v in x_list], axis=0))
+        out = np.empty_like(x)
+        n = self.cfg.num_layers - first_layer if n_layers is None else n_layers
+        check(lib().pk_conformer_blocks_ragged(self._h, _f(x), _i(T), len(T), first_layer, n, _f(out)))
+        o = np.concatenate([[0], np.cumsum(T)])
+        return [out[o[i]:o[i + 1]] for i in range(len(T))]
+
+    def ctc_decode_ragged(self, enc_list, return_logp=False):
+        T = np.asarray([e.shape[0] for e in enc_list], np.int32)
+        enc = _c(np.concatenate([_c(e) for e in enc_list], axis=0))
+        B, tm = len(T), int(T.max())
+        ids = np.zeros((B, tm), np.int32); st = np.zeros((B, tm), np.int32); en = np.zeros((B, tm), np.int32)
+        cf = np.zeros((B, tm), np.float32); lens = np.zeros(B, np.int32)
+        lp = np.empty((int(T.sum()), self.cfg.ctc_vocab_size), np.float32) if return_logp else None
+        check(lib().pk_ctc_decode_ragged(self._h, _f(enc), _i(T), B, _i(ids), _i(lens), _i(st), _i(en), _f(cf), _f(lp) if return_logp else None))
+        r = dict(ids=ids, lens=lens, start=st, end=en, conf=cf)
+        if return_logp:
+            o = np.concatenate([[0], np.cumsum(T)])
+            r["logp"] = [lp[o[i]:o[i + 1]] for i in range(B)]
+        return r
+
+    def tdt_decode_ragged(self, enc_list, max_tokens=None):
+        T = np.asarray([e.shape[0] for e in enc_list], np.int32)
+        enc = _c(np.concatenate([_c(e) for e in enc_list], axis=0))
+        B = len(T)
+        mt = max_tokens or int(T.max()) * self.cfg.max_symbols_per_step
+        ids = np.zeros((B, mt), np.int32); st = np.zeros((B, mt), np.int32); en = np.zeros((B, mt), np.int32)
+        cf = np.zeros((B, mt), np.float32); lens = np.zeros(B, np.int32); steps = np.zeros(B, np.int32)
+        check(lib().pk_tdt_decode_ragged(self._h, _f(enc), _i(T), B, mt, _i(ids), _i(lens), _i(st), _i(en), _f(cf), _i(steps)))
+        r = dict(ids=ids, lens=lens, start=st, end=en, conf=cf, steps=steps)
+        if not getattr(self, "_boosted", False):
+            mg = np.zeros(B, np.float32)
+            if lib().pk_decode_margins(self._h, _f(mg), B) == 0:
+                r["min_margin"] = mg
+        return r
 
     def subsample(self, feats):
         feats = _c(feats)

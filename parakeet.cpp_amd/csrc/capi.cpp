@@ -291,6 +291,134 @@ pk_status pk_tdt_decode(pk_model *h, const float *enc, int B, int T, int max_tok
 }
 
 
+/* ---- ragged (mixed-length) forms of the stage entry points: every tensor PACKED along the time axis ---------------------------------- */
+static int att_block_rows_of(Model &m, int T_max) {
+    return m.attn_bf16(T_max) ? relpos_attention_bf16_block_rows(m.cfg.hidden_size / m.cfg.num_heads) : 32;
+}
+
+pk_status pk_mel_ragged(pk_model *h, const float *pcm, const int64_t *offsets, int n_clips, float *feats, float *logmel) {
+    return guard([&] {
+        need(h && pcm && offsets && feats && n_clips > 0, "model/pcm/offsets/feats/n_clips");
+        Model &m = *h->m;
+        m.require_gpu();
+        std::vector<int64_t> lens(n_clips);
+        int64_t longest = 0;
+        for (int i = 0; i < n_clips; ++i) { lens[i] = offsets[i + 1] - offsets[i]; longest = std::max(longest, lens[i]); }
+        RagBatch r;
+        r.build_from_samples(lens.data(), n_clips, 32);
+        m.ws.size_ragged(m.cfg, n_clips, r.n_samples, longest, /*own_pcm=*/true);
+        m.ws.set_ragged(r, m.stream);
+        const size_t n_lm = (size_t)r.sum_Tm * m.cfg.mel_bins;
+        for (int i = 0; i < n_clips; ++i)        // (the clips need not be contiguous in the caller's buffer)
+            PK_HIP(hipMemcpyAsync(m.ws.pcm.as<float>() + r.pcm_off[i], pcm + offsets[i], (size_t)lens[i] * 4, hipMemcpyHostToDevice, m.stream));
+        m.run_mel_ws(m.ws, m.ws.pcm.as<float>(), n_clips, m.stream);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpyAsync(feats, m.ws.feats.p, n_lm * 4, hipMemcpyDeviceToHost, m.stream));
+        if (logmel) PK_HIP(hipMemcpyAsync(logmel, m.ws.logmel.p, n_lm * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+pk_status pk_encode_ragged(pk_model *h, const float *feats, const int32_t *n_mel_frames, int B, int stop_layer, int stop_stage, float *enc) {
+    return guard([&] {
+        need(h && feats && n_mel_frames && enc && B > 0, "model/feats/n_mel_frames/enc/B");
+        need(stop_stage >= 0 && stop_stage <= 4, "stop_stage");
+        Model &m = *h->m;
+        m.require_gpu();
+        int tm_max = 0;
+        for (int i = 0; i < B; ++i) tm_max = std::max(tm_max, (int)n_mel_frames[i]);
+        RagBatch r;
+        r.build_from_mel(n_mel_frames, B, att_block_rows_of(m, pk_encoder_num_frames(tm_max)));
+        m.ws.size_ragged(m.cfg, B, r.sum_Tm, tm_max, false, /*level=*/1);
+        m.ws.set_ragged(r, m.stream);
+        PK_HIP(hipMemcpyAsync(m.ws.feats.p, feats, (size_t)r.sum_Tm * m.cfg.mel_bins * 4, hipMemcpyHostToDevice, m.stream));
+        m.run_encoder(m.ws, m.ws.feats.as<float>(), B, 0, stop_layer, stop_stage, m.stream);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpyAsync(enc, m.ws.x.p, (size_t)r.sum_T * m.cfg.hidden_size * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+// workspace of the host-buffer decode entry points for B utterances of n_frames[b] encoder frames (packed); returns the longest
+static int size_ws_for_frames(Model &m, const int32_t *n_frames, int B) {
+    int t_max = 0;
+    for (int i = 0; i < B; ++i) t_max = std::max(t_max, (int)n_frames[i]);
+    RagBatch r;
+    r.build_from_frames(n_frames, B, att_block_rows_of(m, t_max));
+    m.ws.size_ragged(m.cfg, B, r.sum_T, t_max, false, /*level=*/2);
+    m.ws.set_ragged(r, m.stream);
+    return t_max;
+}
+
+pk_status pk_conformer_blocks_ragged(pk_model *h, const float *x_in, const int32_t *n_frames, int B, int first_layer, int n_layers, float *x_out) {
+    return guard([&] {
+        need(h && x_in && x_out && n_frames && B > 0, "model/x_in/x_out/n_frames/B");
+        Model &m = *h->m;
+        m.require_gpu();
+        need(first_layer >= 0 && n_layers >= 0 && first_layer + n_layers <= m.cfg.num_layers, "layer range");
+        size_ws_for_frames(m, n_frames, B);
+        const size_t n = (size_t)m.ws.rag.sum_T * m.cfg.hidden_size;
+        PK_HIP(hipMemcpyAsync(m.ws.x.p, x_in, n * 4, hipMemcpyHostToDevice, m.stream));
+        if (n_layers > 0) m.run_layers(m.ws, B, first_layer, first_layer + n_layers, 0, m.stream);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpyAsync(x_out, m.ws.x.p, n * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+pk_status pk_ctc_decode_ragged(pk_model *h, const float *enc, const int32_t *n_frames, int B, int32_t *ids, int32_t *lens, int32_t *start,
+                               int32_t *end, float *conf, float *logp) {
+    return guard([&] {
+        need(h && enc && n_frames && ids && lens && B > 0, "model/enc/n_frames/ids/lens/B");
+        Model &m = *h->m;
+        m.require_gpu();
+        const int T = size_ws_for_frames(m, n_frames, B);              // the token arrays are [B][T], T = the longest utterance
+        const size_t rows = (size_t)m.ws.rag.sum_T, tok = (size_t)B * T;
+        PK_HIP(hipMemcpyAsync(m.ws.x.p, enc, rows * m.cfg.hidden_size * 4, hipMemcpyHostToDevice, m.stream));
+        m.run_ctc(m.ws, m.ws.x.as<float>(), B, T, logp != nullptr, m.stream);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpyAsync(ids, m.ws.ids.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipMemcpyAsync(lens, m.ws.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost, m.stream));
+        if (start) PK_HIP(hipMemcpyAsync(start, m.ws.start.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        if (end) PK_HIP(hipMemcpyAsync(end, m.ws.end.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        if (conf) PK_HIP(hipMemcpyAsync(conf, m.ws.conf.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        if (logp) PK_HIP(hipMemcpyAsync(logp, m.ws.ctc_lp.p, rows * m.cfg.ctc_vocab_size * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+        zero_tail(ids, lens, B, T); zero_tail(start, lens, B, T); zero_tail(end, lens, B, T); zero_tail(conf, lens, B, T);
+    });
+}
+
+pk_status pk_tdt_decode_ragged(pk_model *h, const float *enc, const int32_t *n_frames, int B, int max_tokens, int32_t *ids, int32_t *lens,
+                               int32_t *start, int32_t *end, float *conf, int32_t *steps) {
+    pk_status cap_hit = PK_OK;
+    pk_status st = guard([&] {
+        need(h && enc && n_frames && ids && lens && B > 0 && max_tokens > 0, "model/enc/n_frames/ids/lens/B/max_tokens");
+        Model &m = *h->m;
+        m.require_gpu();
+        const int T = size_ws_for_frames(m, n_frames, B);
+        need(max_tokens <= m.ws.max_tokens, "max_tokens exceeds (longest utterance) * max_symbols_per_step");
+        PK_HIP(hipMemcpyAsync(m.ws.x.p, enc, (size_t)m.ws.rag.sum_T * m.cfg.hidden_size * 4, hipMemcpyHostToDevice, m.stream));
+        m.run_tdt(m.ws, m.ws.x.as<float>(), B, T, max_tokens, m.stream);
+        PK_CHECK_LAUNCH();
+        const size_t tok = (size_t)B * max_tokens;
+        PK_HIP(hipMemcpyAsync(ids, m.ws.ids.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipMemcpyAsync(lens, m.ws.lens.p, (size_t)B * 4, hipMemcpyDeviceToHost, m.stream));
+        if (start) PK_HIP(hipMemcpyAsync(start, m.ws.start.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        if (end) PK_HIP(hipMemcpyAsync(end, m.ws.end.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        if (conf) PK_HIP(hipMemcpyAsync(conf, m.ws.conf.p, tok * 4, hipMemcpyDeviceToHost, m.stream));
+        if (steps) PK_HIP(hipMemcpyAsync(steps, m.ws.ints.as<int>() + 4 * B, (size_t)B * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+        zero_tail(ids, lens, B, max_tokens); zero_tail(start, lens, B, max_tokens); zero_tail(end, lens, B, max_tokens); zero_tail(conf, lens, B, max_tokens);
+        for (int b = 0; b < B; ++b)
+            if (lens[b] < 0) cap_hit = PK_ERR_DECODE_CAP;
+    });
+    if (st == PK_OK && cap_hit != PK_OK) {
+        set_last_error("TDT decode hit the safety cap on joint evaluations for at least one utterance (lens = -1)");
+        return cap_hit;
+    }
+    return st;
+}
+
 pk_status pk_decode_margins(pk_model *h, float *min_margin, int B) {
     return guard([&] {
         need(h && min_margin && B > 0, "model/min_margin/B");
@@ -314,6 +442,10 @@ struct pk_batch {
     int cur = 0;                // buffer the next pk_batch_run reads
     int staged = -1;            // buffer filled by pk_batch_upload_async and not yet consumed by a run
     int staged_clips = 0;
+    // What each PCM buffer holds: a uniform batch (clips x n_samples) or a RAGGED one (clips of different lengths packed back to back,
+    // pk_batch_upload_ragged).  A pipeline created with pk_batch_create_ragged takes both, run by run, inside its capacity.
+    struct Held { bool ragged = false; int64_t n_samples = 0; RagBatch rag; } held[2];
+    bool rag_capacity = false;  // created with pk_batch_create_ragged (capacity in ws[].rag_cap_*)
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done[2], mel_done[2];
     bool mel_used[2] = {false, false};
@@ -341,6 +473,9 @@ struct pk_batch {
         Workspace w;                    // decode state of group * max_clips utterances
         std::vector<Member> mem;        // runs in this group, oldest first
         int rows = 0;                   // utterances so far
+        int64_t ep_rows = 0;            // enc_proj rows so far (ragged-capacity pipelines: runs of different row counts)
+        int T_max = 0;                  // longest utterance among the members (bounds the lock-step loop)
+        DevBuf tabs;                    // ragged-capacity pipelines: Tb[cap] then row0[cap] of the group's utterances (TdtState::Tb / row0)
         hipEvent_t ep_done = nullptr, dec_done = nullptr;
         bool decoded = false, used = false;
     } grp[2];
@@ -357,6 +492,13 @@ struct pk_batch {
     int ready = -1;                     // full group whose decode has not been driven yet
 };
 
+// makes the batch held by the current PCM buffer the run of workspace w
+static void batch_set_run(pk_batch *b, Workspace &w, hipStream_t s) {
+    const pk_batch::Held &H = b->held[b->cur];
+    if (H.ragged) w.set_ragged(H.rag, s);
+    else if (b->rag_capacity) w.set_uniform(b->n_clips, H.n_samples);
+}
+
 static void batch_encode(pk_batch *b, int slot) {
     Model &m = *b->m;
     Workspace &w = b->ws[slot];
@@ -370,7 +512,8 @@ static void batch_encode(pk_batch *b, int slot) {
         b->staged = -1;
         PK_HIP(hipStreamWaitEvent(s, b->copy_done[b->cur], 0));
     }
-    m.run_mel(b->pcm2[b->cur].as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
+    batch_set_run(b, w, s);                                  // uniform or ragged: what the PCM buffer holds (tables uploaded on s)
+    m.run_mel_ws(w, b->pcm2[b->cur].as<float>(), b->n_clips, s);
     PK_HIP(hipEventRecord(b->mel_done[b->cur], s));         // the PCM buffer is free again once the mel kernels have read it
     b->mel_used[b->cur] = true;
     m.run_encoder(w, w.feats.as<float>(), b->n_clips, w.Tm, -1, 0, s);
@@ -384,8 +527,8 @@ static void batch_decode(pk_batch *b, int slot, int decoder, hipStream_t s) {
     Workspace &w = b->ws[slot];
     if (s != m.stream) PK_HIP(hipStreamWaitEvent(s, b->enc_done[slot], 0));
     const int nc = b->slot_clips[slot] > 0 ? b->slot_clips[slot] : b->n_clips;
-    if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), nc, w.T, false, s);
-    else m.run_tdt(w, w.x.as<float>(), nc, w.T, w.max_tokens, s);
+    if (decoder == PK_DECODER_CTC) m.run_ctc(w, w.x.as<float>(), nc, w.T_run, false, s);
+    else m.run_tdt(w, w.x.as<float>(), nc, w.T_run, w.max_tokens, s);
     PK_HIP(hipEventRecord(b->dec_done[slot], s));
     b->last_slot = slot;
     b->last_decoder = decoder;
@@ -400,7 +543,7 @@ static void group_drive(pk_batch *b, int gi) {
     auto &G = b->grp[gi];
     hipStream_t s = b->dec_stream();
     if (s != m.stream) PK_HIP(hipStreamWaitEvent(s, G.ep_done, 0));
-    m.run_tdt_loop(G.w, G.rows, G.w.T, G.w.max_tokens, s);
+    m.run_tdt_loop(G.w, G.rows, b->rag_capacity ? G.T_max : G.w.T, G.w.max_tokens, s);
     PK_HIP(hipEventRecord(G.dec_done, s));
     G.decoded = true;
     for (auto &mm : G.mem) b->done.push_back({&G.w, mm.row0, mm.clips, PK_DECODER_TDT, G.dec_done, mm.seq});
@@ -456,12 +599,24 @@ static void batch_run(pk_batch *b, int decoder) {
             if (G.used) PK_HIP(hipStreamWaitEvent(m.stream, G.dec_done, 0));
             b->forget(&G.w);                                 // the runs of the group decoded two groups ago are overwritten from here on
             G.rows = 0;
+            G.ep_rows = 0;
+            G.T_max = 0;
             G.decoded = false;
         }
         const int nc = b->slot_clips[slot];
-        m.run_enc_proj(w.x.as<float>(), (int64_t)nc * w.T, G.w.ep.as<float>() + (size_t)G.rows * w.T * m.cfg.joint_hidden, m.stream);
+        const int64_t run_rows = w.rows(nc);
+        m.run_enc_proj(w.x.as<float>(), run_rows, G.w.ep.as<float>() + (size_t)G.ep_rows * m.cfg.joint_hidden, m.stream);
+        if (b->rag_capacity) {
+            // the group's utterances have their own frame counts / first enc_proj rows: gathered behind the earlier members' (TdtState::Tb / row0)
+            int *Tb = G.tabs.as<int>(), *row0 = Tb + G.w.B;
+            launch_rag_decode_tables(w.ragged ? w.rv.seq.T : nullptr, w.ragged ? w.rv.seq.T_off : nullptr, w.T_run, nc, (int)G.ep_rows, Tb + G.rows, row0 + G.rows,
+                                     m.stream);
+            G.w.dec_Tb = Tb; G.w.dec_row0 = row0;
+            G.T_max = std::max(G.T_max, w.t_max());
+        }
         G.mem.push_back({nc, G.rows, b->slot_seq[slot]});
         G.rows += nc;
+        G.ep_rows += run_rows;
         G.used = true;
         const bool full = (int)G.mem.size() == b->group;
         if (b->ready >= 0) {                                 // the group completed by an earlier run: decode it under this encoder
@@ -483,13 +638,24 @@ static void batch_size(pk_batch *b, int max_clips, int64_t n_samples) {
     Model &m = *b->m;
     for (auto &p : b->pcm2) p.reserve((size_t)max_clips * n_samples * 4);
     for (auto &w : b->ws) w.size_for(m.cfg, max_clips, -n_samples, pk_mel_num_frames(n_samples));
+    for (auto &h : b->held) { h.ragged = false; h.n_samples = n_samples; }
+    b->rag_capacity = false;
+}
+// capacity for ragged AND uniform batches of <= max_clips clips, <= max_total samples in all, <= max_clip per clip (buffers only ever grow)
+static void batch_size_ragged(pk_batch *b, int max_clips, int64_t max_total, int64_t max_clip) {
+    Model &m = *b->m;
+    for (auto &p : b->pcm2) p.reserve((size_t)max_total * 4);
+    for (auto &w : b->ws) w.size_ragged(m.cfg, max_clips, max_total, max_clip, /*own_pcm=*/false);
+    for (auto &h : b->held) { h.ragged = false; h.n_samples = 0; }
+    b->rag_capacity = true;
 }
 
-static std::unique_ptr<pk_batch> batch_new(Model &m, int max_clips, int64_t n_samples) {
+static std::unique_ptr<pk_batch> batch_new(Model &m, int max_clips, int64_t n_samples, int64_t rag_total = 0) {
     m.require_gpu();
     auto b = std::make_unique<pk_batch>();
     b->m = &m;
-    batch_size(b.get(), max_clips, n_samples);
+    if (rag_total > 0) batch_size_ragged(b.get(), max_clips, rag_total, n_samples);
+    else batch_size(b.get(), max_clips, n_samples);
     for (auto &e : b->ev) PK_HIP(hipEventCreate(&e));
     PK_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
@@ -506,6 +672,13 @@ pk_status pk_batch_create(pk_model *h, int max_clips, int64_t n_samples, pk_batc
     return guard([&] {
         need(h && out && max_clips > 0 && n_samples > 256, "model/out/max_clips/n_samples");
         *out = batch_new(*h->m, max_clips, n_samples).release();
+    });
+}
+
+pk_status pk_batch_create_ragged(pk_model *h, int max_clips, int64_t max_total_samples, int64_t max_clip_samples, pk_batch **out) {
+    return guard([&] {
+        need(h && out && max_clips > 0 && max_clip_samples > 256 && max_total_samples >= max_clip_samples, "model/out/max_clips/max_total_samples/max_clip_samples");
+        *out = batch_new(*h->m, max_clips, max_clip_samples, max_total_samples).release();
     });
 }
 
@@ -532,6 +705,7 @@ void pk_batch_free(pk_batch *b) {
 pk_status pk_batch_upload(pk_batch *b, const float *pcm, int n_clips) {
     return guard([&] {
         need(b && pcm && n_clips > 0 && n_clips <= b->ws[0].B, "batch/pcm/n_clips");
+        need(!b->rag_capacity, "a pipeline created with pk_batch_create_ragged takes pk_batch_upload_ragged (equal lengths are a special case of it)");
         b->m->require_gpu();
         batch_flush(b);
         PK_HIP(hipStreamSynchronize(b->copy_stream));
@@ -542,18 +716,65 @@ pk_status pk_batch_upload(pk_batch *b, const float *pcm, int n_clips) {
     });
 }
 
+// what a PCM buffer holds after staging clips of the given lengths: a uniform batch when all lengths agree (the plain kernels: no tables),
+// otherwise a ragged one
+static void batch_hold(pk_batch *b, int buf, const int64_t *lens, int n_clips) {
+    Model &m = *b->m;
+    pk_batch::Held &H = b->held[buf];
+    bool same = true;
+    int64_t total = 0, longest = 0;
+    for (int i = 0; i < n_clips; ++i) { same = same && lens[i] == lens[0]; total += lens[i]; longest = std::max(longest, lens[i]); }
+    const Workspace &w = b->ws[0];
+    if (n_clips > w.rag_cap_clips || total > w.rag_cap_samples || longest > w.rag_cap_clip)
+        fail(PK_ERR_INVALID, "batch of %d clips / %lld samples (longest %lld) exceeds the pipeline's capacity (%d clips, %lld samples, %lld per clip)", n_clips,
+             (long long)total, (long long)longest, w.rag_cap_clips, (long long)w.rag_cap_samples, (long long)w.rag_cap_clip);
+    for (int i = 0; i < n_clips; ++i) need(lens[i] > 256, "every clip needs more than 256 samples");
+    H.ragged = !same;
+    H.n_samples = same ? lens[0] : 0;
+    if (!same) {
+        const int t_max = pk_encoder_num_frames(pk_mel_num_frames(longest));
+        H.rag.build_from_samples(lens, n_clips, m.attn_bf16(t_max) ? relpos_attention_bf16_block_rows(m.cfg.hidden_size / m.cfg.num_heads) : 32);
+    }
+}
+
+pk_status pk_batch_upload_ragged(pk_batch *b, const float *pcm, const int64_t *offsets, int n_clips) {
+    return guard([&] {
+        need(b && pcm && offsets && n_clips > 0, "batch/pcm/offsets/n_clips");
+        need(b->rag_capacity, "pk_batch_upload_ragged needs a pipeline created with pk_batch_create_ragged");
+        b->m->require_gpu();
+        batch_flush(b);
+        PK_HIP(hipStreamSynchronize(b->copy_stream));
+        b->staged = -1;
+        std::vector<int64_t> lens(n_clips);
+        for (int i = 0; i < n_clips; ++i) lens[i] = offsets[i + 1] - offsets[i];
+        batch_hold(b, b->cur, lens.data(), n_clips);
+        int64_t o = 0;
+        for (int i = 0; i < n_clips; ++i) {        // packed back to back in the device buffer, whatever the gaps in the caller's
+            PK_HIP(hipMemcpyAsync(b->pcm2[b->cur].as<float>() + o, pcm + offsets[i], (size_t)lens[i] * 4, hipMemcpyHostToDevice, b->m->stream));
+            o += lens[i];
+        }
+        PK_HIP(hipStreamSynchronize(b->m->stream));
+        b->n_clips = n_clips;
+    });
+}
+
 // stages the NEXT batch into the PCM buffer the running encoder does not read, on the copy stream.  clip(i) = host pointer of clip i;
 // clips that follow each other in host memory go as one copy.
-static void batch_stage(pk_batch *b, int n_clips, const std::function<const float *(int)> &clip) {
+static void batch_stage(pk_batch *b, int n_clips, const std::function<const float *(int)> &clip, const int64_t *lens = nullptr) {
     b->m->require_gpu();
-    const int64_t n = b->ws[0].n_samples;
     const int nb = b->staged >= 0 ? b->staged : (b->cur ^ 1);      // re-staging before a run overwrites the staged batch
+    std::vector<int64_t> uni;
+    if (!lens) { uni.assign(n_clips, b->held[nb].n_samples > 0 ? b->held[nb].n_samples : b->ws[0].n_samples); lens = uni.data(); }
+    if (b->rag_capacity) batch_hold(b, nb, lens, n_clips);         // (validates the batch against the capacity before anything is copied)
     PK_HIP(hipStreamSynchronize(b->copy_stream));                  // at most one copy in flight; the previous host buffer is released here
     if (b->mel_used[nb]) PK_HIP(hipStreamWaitEvent(b->copy_stream, b->mel_done[nb], 0));   // the last mel that read this buffer
+    int64_t o = 0;
     for (int i = 0; i < n_clips;) {
         int j = i + 1;
-        while (j < n_clips && clip(j) == clip(j - 1) + n) ++j;
-        PK_HIP(hipMemcpyAsync(b->pcm2[nb].as<float>() + (size_t)i * n, clip(i), (size_t)(j - i) * n * 4, hipMemcpyHostToDevice, b->copy_stream));
+        int64_t run = lens[i];
+        while (j < n_clips && clip(j) == clip(j - 1) + lens[j - 1]) { run += lens[j]; ++j; }
+        PK_HIP(hipMemcpyAsync(b->pcm2[nb].as<float>() + o, clip(i), (size_t)run * 4, hipMemcpyHostToDevice, b->copy_stream));
+        o += run;
         i = j;
     }
     PK_HIP(hipEventRecord(b->copy_done[nb], b->copy_stream));
@@ -564,8 +785,19 @@ static void batch_stage(pk_batch *b, int n_clips, const std::function<const floa
 pk_status pk_batch_upload_async(pk_batch *b, const float *pcm, int n_clips) {
     return guard([&] {
         need(b && pcm && n_clips > 0 && n_clips <= b->ws[0].B, "batch/pcm/n_clips");
+        need(!b->rag_capacity, "a pipeline created with pk_batch_create_ragged takes pk_batch_upload_ragged_async");
         const int64_t n = b->ws[0].n_samples;
         batch_stage(b, n_clips, [&](int i) { return pcm + (size_t)i * n; });
+    });
+}
+
+pk_status pk_batch_upload_ragged_async(pk_batch *b, const float *pcm, const int64_t *offsets, int n_clips) {
+    return guard([&] {
+        need(b && pcm && offsets && n_clips > 0, "batch/pcm/offsets/n_clips");
+        need(b->rag_capacity, "pk_batch_upload_ragged_async needs a pipeline created with pk_batch_create_ragged");
+        std::vector<int64_t> lens(n_clips);
+        for (int i = 0; i < n_clips; ++i) lens[i] = offsets[i + 1] - offsets[i];
+        batch_stage(b, n_clips, [&](int i) { return pcm + offsets[i]; }, lens.data());
     });
 }
 
@@ -642,11 +874,14 @@ static void batch_set_group(pk_batch *b, int group) {
     if (group > 1) {
         need(m.cfg.vocab_size > 0, "decode groups apply to the TDT / RNNT decoder; this model has none");
         for (auto &G : b->grp) {
-            G.w.size_decode(m.cfg, group * b->ws[0].B, b->ws[0].T);
+            G.w.size_decode(m.cfg, group * b->ws[0].B, b->ws[0].T, (size_t)group * b->ws[0].rag_cap_rows);
+            if (b->rag_capacity) G.tabs.reserve((size_t)2 * group * b->ws[0].B * sizeof(int));
             if (!G.ep_done) PK_HIP(hipEventCreateWithFlags(&G.ep_done, hipEventDisableTiming));
             if (!G.dec_done) PK_HIP(hipEventCreateWithFlags(&G.dec_done, hipEventDisableTiming));
             G.mem.clear();
             G.rows = 0;
+            G.ep_rows = 0;
+            G.T_max = 0;
             G.used = G.decoded = false;
         }
     }
@@ -679,8 +914,9 @@ pk_status pk_batch_run_timed(pk_batch *b, int decoder, float ms[4]) {
         batch_flush(b);
         Workspace &w = b->ws[0];
         hipStream_t s = m.stream;
+        batch_set_run(b, w, s);
         PK_HIP(hipEventRecord(b->ev[0], s));
-        m.run_mel(b->pcm2[b->cur].as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s);
+        m.run_mel_ws(w, b->pcm2[b->cur].as<float>(), b->n_clips, s);
         PK_HIP(hipEventRecord(b->ev[1], s));
         m.run_encoder(w, w.feats.as<float>(), b->n_clips, w.Tm, -1, 0, s);
         PK_HIP(hipEventRecord(b->ev[2], s));
@@ -713,7 +949,8 @@ int pk_batch_profile(pk_batch *b, int decoder, pk_kernel_stat *out, int cap) {
         batch_flush(b);
         try {
             Workspace &w = b->ws[0];
-            m.run_mel(b->pcm2[b->cur].as<float>(), b->n_clips, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), m.stream);
+            batch_set_run(b, w, m.stream);
+            m.run_mel_ws(w, b->pcm2[b->cur].as<float>(), b->n_clips, m.stream);
             m.run_encoder(w, w.feats.as<float>(), b->n_clips, w.Tm, -1, 0, m.stream);
             b->slot_clips[0] = b->n_clips;
             batch_decode(b, 0, decoder, m.stream);
@@ -758,16 +995,16 @@ static void batch_reset(pk_batch *b) {
     b->ready = -1;
     b->staged = -1;
     b->n_clips = 0;
-    for (auto &G : b->grp) { G.mem.clear(); G.rows = 0; }
+    for (auto &G : b->grp) { G.mem.clear(); G.rows = 0; G.ep_rows = 0; G.T_max = 0; }
     b->done.clear();
 }
 
-// The pipeline a Model keeps for the one-call API (pk_transcribe_pcm, every rank of a pk_group): created on first use, re-sized per
-// length class (buffers only grow), freed with the model.
-static pk_batch *model_pipeline(Model &m, int max_clips, int64_t n_samples) {
+// The pipeline a Model keeps for the one-call API (pk_transcribe_pcm, every rank of a pk_group): created on first use with ragged capacity
+// (batches of mixed lengths AND uniform ones), re-sized when a call needs more (buffers only grow), freed with the model.
+static pk_batch *model_pipeline(Model &m, int max_clips, int64_t max_total, int64_t max_clip) {
     m.require_gpu();
     if (!m.pipe) {
-        m.pipe = batch_new(m, max_clips, n_samples).release();
+        m.pipe = batch_new(m, max_clips, max_clip, max_total).release();
         m.pipe_free = [](void *p) { pk_batch_free(static_cast<pk_batch *>(p)); };
         return static_cast<pk_batch *>(m.pipe);
     }
@@ -777,7 +1014,9 @@ static pk_batch *model_pipeline(Model &m, int max_clips, int64_t n_samples) {
     b->done.clear();
     b->staged = -1;
     b->n_clips = 0;
-    batch_size(b, max_clips, n_samples);
+    const Workspace &w = b->ws[0];
+    // the capacity never shrinks (the output pitches T / max_tokens follow the longest clip the pipeline has been sized for)
+    batch_size_ragged(b, std::max(max_clips, w.rag_cap_clips), std::max(max_total, w.rag_cap_samples), std::max(max_clip, w.rag_cap_clip));
     return b;
 }
 
@@ -813,80 +1052,97 @@ static void transcribe_clips(Model &m, const float *pcm, const int64_t *offsets,
         scope.saved = m.boost_phrases; scope.saved_score = m.boost_score; scope.active = true;
         m.set_boost(ph, opt->boost_score);
     }
-    // Clips of equal length form batches of <= 64 (the reference has no padding semantics: no masks offline, encoder.cpp:163).  The batches of
-    // a length class go through the model's two-stream pipeline (struct pk_batch): PCM of batch k+1 is staged on the copy stream and
-    // decode(k) -- or, from four batches on, the decode loops of four batches as one lock-step group -- runs under encoder(k+1).
+    // Mixed-length batching (the reference's roadmap item "batch inference: pad + length-mask", README.md:513 -- done by PACKING, no padding
+    // and no masks: every clip keeps its own extents in every kernel and comes out bit-identical to a single-clip call).  The clips are
+    // sorted by length, longest first (the position tables and the workspace are then sized once, by the first batch), and packed greedily
+    // into batches of at most kMaxBatchClips clips and kBatchSamples samples -- neighbours in length share a batch, so the lock-step decode
+    // loop of a batch ends for all of them at about the same step.  The batches go through the model's two-stream pipeline (struct
+    // pk_batch): PCM of batch k+1 is staged on the copy stream and decode(k) -- or, from four batches on, the decode loops of four batches as
+    // one lock-step group -- runs under encoder(k+1).  A batch whose clips all have the same length runs the plain uniform kernels.
     std::vector<int> order(clips);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offsets[a + 1] - offsets[a] < offsets[b + 1] - offsets[b]; });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b]; });
     const int n_clips = (int)order.size();
-    const int kMaxBatch = 64;
-    for (int i = 0; i < n_clips; ++i) need(offsets[order[i] + 1] - offsets[order[i]] > 256, "every clip needs more than 256 samples");
+    if (n_clips == 0) return;
+    const int kMaxBatchClips = 256;
+    const int64_t kBatchSamples = (int64_t)64 * 160000;           // 64 x 10 s: ~8000 encoder rows per batch, where the GEMMs run at their best
+    auto len_of = [&](int i) { return offsets[order[i] + 1] - offsets[order[i]]; };
+    for (int i = 0; i < n_clips; ++i) need(len_of(i) > 256, "every clip needs more than 256 samples");
+    std::vector<int> bstart;                                       // first clip (position in `order`) of every batch, + the end
+    int64_t cap_total = 0;
+    int cap_clips = 0;
+    for (int i = 0; i < n_clips;) {
+        bstart.push_back(i);
+        int64_t tot = 0;
+        int j = i;
+        while (j < n_clips && j - i < kMaxBatchClips && (j == i || tot + len_of(j) <= kBatchSamples)) tot += len_of(j++);
+        cap_total = std::max(cap_total, tot);
+        cap_clips = std::max(cap_clips, j - i);
+        i = j;
+    }
+    bstart.push_back(n_clips);
+    const int nb = (int)bstart.size() - 1;
     std::vector<int32_t> ids, st, en, lens;
     std::vector<float> cf;
-    for (int g0 = 0; g0 < n_clips;) {
-        const int64_t len = offsets[order[g0] + 1] - offsets[order[g0]];
-        int g1 = g0;
-        while (g1 < n_clips && offsets[order[g1] + 1] - offsets[order[g1]] == len) ++g1;
-        const int count = g1 - g0, nb = (count + kMaxBatch - 1) / kMaxBatch;
-        pk_batch *b = model_pipeline(m, std::min(count, kMaxBatch), len);
-        try {
-            batch_set_group(b, (decoder == PK_DECODER_TDT && nb >= 4) ? 4 : 1);
-            const int64_t first_seq = b->runs;
-            const int mt = b->ws[0].max_tokens;
-            std::vector<char> taken(nb, 0);
-            auto clips_of = [&](int k) { return std::min(kMaxBatch, count - k * kMaxBatch); };
-            auto stage = [&](int k) {
-                batch_stage(b, clips_of(k), [&](int i) { return pcm + offsets[order[g0 + k * kMaxBatch + i]]; });
-            };
-            auto drain = [&]() {                                  // every finished run of this class that has not been handed out yet
-                for (const auto &L : b->done) {
-                    const int64_t k = L.seq - first_seq;
-                    if (k < 0 || k >= nb || taken[k]) continue;
-                    taken[k] = 1;
-                    const int B = L.clips;
-                    const size_t tok = (size_t)B * mt;
-                    ids.resize(tok); lens.resize(B);
-                    if (ts) { st.resize(tok); en.resize(tok); cf.resize(tok); }
-                    PK_HIP(hipEventSynchronize(L.ev));
-                    copy_results(L, ids.data(), lens.data(), ts ? st.data() : nullptr, ts ? en.data() : nullptr, ts ? cf.data() : nullptr);
-                    for (int i = 0; i < B; ++i) {
-                        const int c = order[g0 + (int)k * kMaxBatch + i];
-                        if (lens[i] < 0) fail(PK_ERR_DECODE_CAP, "TDT decode hit the safety cap on clip %d", c);
-                        const int n = lens[i];
-                        R.ids[c].assign(ids.begin() + (size_t)i * mt, ids.begin() + (size_t)i * mt + n);
-                        std::vector<int> iv(R.ids[c].begin(), R.ids[c].end());
-                        if (m.tok.loaded()) R.text[c] = m.tok.decode(iv);                    // transcribe.hpp:149,172
-                        if (ts) {
-                            R.start[c].assign(st.begin() + (size_t)i * mt, st.begin() + (size_t)i * mt + n);
-                            R.end[c].assign(en.begin() + (size_t)i * mt, en.begin() + (size_t)i * mt + n);
-                            R.conf[c].assign(cf.begin() + (size_t)i * mt, cf.begin() + (size_t)i * mt + n);
-                            if (m.tok.loaded()) {                                            // group_timestamps, transcribe.hpp:150-152
-                                std::vector<TimestampedToken> tt(n);
-                                for (int q = 0; q < n; ++q) tt[q] = {R.ids[c][q], R.start[c][q], R.end[c][q], R.conf[c][q]};
-                                auto words = group_timestamps(tt, m.tok.pieces(), false);
-                                for (auto &wd : words) R.word_text[c].push_back(wd.word);
-                                for (size_t q = 0; q < words.size(); ++q)
-                                    R.words[c].push_back({R.word_text[c][q].c_str(), words[q].start, words[q].end, words[q].confidence});
-                            }
+    pk_batch *b = model_pipeline(m, cap_clips, cap_total, len_of(0));
+    try {
+        batch_set_group(b, (decoder == PK_DECODER_TDT && nb >= 4) ? 4 : 1);
+        const int64_t first_seq = b->runs;
+        const int mt = b->ws[0].max_tokens;
+        std::vector<char> taken(nb, 0);
+        std::vector<int64_t> blens;
+        auto stage = [&](int k) {
+            const int c0 = bstart[k], nc = bstart[k + 1] - c0;
+            blens.resize(nc);
+            for (int i = 0; i < nc; ++i) blens[i] = len_of(c0 + i);
+            batch_stage(b, nc, [&](int i) { return pcm + offsets[order[c0 + i]]; }, blens.data());
+        };
+        auto drain = [&]() {                                  // every finished run of this call that has not been handed out yet
+            for (const auto &L : b->done) {
+                const int64_t k = L.seq - first_seq;
+                if (k < 0 || k >= nb || taken[k]) continue;
+                taken[k] = 1;
+                const int B = L.clips;
+                const size_t tok = (size_t)B * mt;
+                ids.resize(tok); lens.resize(B);
+                if (ts) { st.resize(tok); en.resize(tok); cf.resize(tok); }
+                PK_HIP(hipEventSynchronize(L.ev));
+                copy_results(L, ids.data(), lens.data(), ts ? st.data() : nullptr, ts ? en.data() : nullptr, ts ? cf.data() : nullptr);
+                for (int i = 0; i < B; ++i) {
+                    const int c = order[bstart[k] + i];
+                    if (lens[i] < 0) fail(PK_ERR_DECODE_CAP, "TDT decode hit the safety cap on clip %d", c);
+                    const int n = lens[i];
+                    R.ids[c].assign(ids.begin() + (size_t)i * mt, ids.begin() + (size_t)i * mt + n);
+                    std::vector<int> iv(R.ids[c].begin(), R.ids[c].end());
+                    if (m.tok.loaded()) R.text[c] = m.tok.decode(iv);                    // transcribe.hpp:149,172
+                    if (ts) {
+                        R.start[c].assign(st.begin() + (size_t)i * mt, st.begin() + (size_t)i * mt + n);
+                        R.end[c].assign(en.begin() + (size_t)i * mt, en.begin() + (size_t)i * mt + n);
+                        R.conf[c].assign(cf.begin() + (size_t)i * mt, cf.begin() + (size_t)i * mt + n);
+                        if (m.tok.loaded()) {                                            // group_timestamps, transcribe.hpp:150-152
+                            std::vector<TimestampedToken> tt(n);
+                            for (int q = 0; q < n; ++q) tt[q] = {R.ids[c][q], R.start[c][q], R.end[c][q], R.conf[c][q]};
+                            auto words = group_timestamps(tt, m.tok.pieces(), false);
+                            for (auto &wd : words) R.word_text[c].push_back(wd.word);
+                            for (size_t q = 0; q < words.size(); ++q)
+                                R.words[c].push_back({R.word_text[c][q].c_str(), words[q].start, words[q].end, words[q].confidence});
                         }
                     }
                 }
-            };
-            stage(0);
-            for (int k = 0; k < nb; ++k) {
-                batch_run(b, decoder);                               // encoder(k) queued, then decode(k-1) / the finished group driven under it
-                if (k + 1 < nb) stage(k + 1);
-                drain();
             }
-            batch_flush(b);
+        };
+        stage(0);
+        for (int k = 0; k < nb; ++k) {
+            batch_run(b, decoder);                               // encoder(k) queued, then decode(k-1) / the finished group driven under it
+            if (k + 1 < nb) stage(k + 1);
             drain();
-            for (int k = 0; k < nb; ++k)
-                if (!taken[k]) fail(PK_ERR_HIP, "internal: batch %d of the pipeline produced no result", k);
-        } catch (...) {
-            batch_reset(b);
-            throw;
         }
-        g0 = g1;
+        batch_flush(b);
+        drain();
+        for (int k = 0; k < nb; ++k)
+            if (!taken[k]) fail(PK_ERR_HIP, "internal: batch %d of the pipeline produced no result", k);
+    } catch (...) {
+        batch_reset(b);
+        throw;
     }
 }
 
@@ -1007,20 +1263,20 @@ pk_status pk_group_transcribe_pcm(pk_group *g, const float *pcm, const int64_t *
     return guard([&] {
         need(g && pcm && offsets && results && n_clips > 0, "group/pcm/offsets/results/n_clips");
         const int G = (int)g->devices.size();
-        // partition: equal-length batches of <= 64 clips, dealt round-robin (rank r takes batches r, r+G, ...)
+        // partition by AUDIO: clips sorted by length, longest first, each dealt to the rank with the least audio so far (equal lengths: rank
+        // r takes clips r, r+G, ...); every rank then packs its own clips into ragged batches (transcribe_clips)
         std::vector<int> order(n_clips);
         for (int i = 0; i < n_clips; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offsets[a + 1] - offsets[a] < offsets[b + 1] - offsets[b]; });
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b]; });
         std::vector<std::vector<int>> shard(G);
-        int batch = 0;
+        std::vector<int64_t> load(G, 0);
         double audio = 0.0;
-        for (int g0 = 0; g0 < n_clips; ++batch) {
-            const int64_t len = offsets[order[g0] + 1] - offsets[order[g0]];
-            int g1 = g0;
-            while (g1 < n_clips && g1 - g0 < 64 && offsets[order[g1] + 1] - offsets[order[g1]] == len) ++g1;
-            for (int i = g0; i < g1; ++i) shard[batch % G].push_back(order[i]);
-            audio += (double)(g1 - g0) * (double)len / 16000.0;
-            g0 = g1;
+        for (int i = 0; i < n_clips; ++i) {
+            const int64_t len = offsets[order[i] + 1] - offsets[order[i]];
+            const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            shard[r].push_back(order[i]);
+            load[r] += len;
+            audio += (double)len / 16000.0;
         }
         auto store = new_store(n_clips);
         ResultStore &R = *store;

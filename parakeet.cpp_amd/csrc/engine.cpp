@@ -1,6 +1,7 @@
 // parakeet.cpp_amd/csrc/engine.cpp -- model lifetime, weight upload / derived tables, stage drivers.
 #include "engine.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <functional>
 #include <map>
@@ -447,57 +448,75 @@ void Model::gemm(const char *name, const float *A, int64_t lda, const float *W, 
 const std::vector<Model::SigW> &Model::sigma_weights() {
     if (sig_built_) return sig_layers_;
     require_gpu();
-    sig_built_ = true;
     const size_t d = cfg.hidden_size, f = cfg.ffn_intermediate;
-    if (cfg.gemm_bf16 || d % 64 || f % 64) return sig_layers_;
+    if (cfg.gemm_bf16 || d % 64 || f % 64) { sig_built_ = true; return sig_layers_; }
+    // (+ one more copy of the encoder's product weights in HBM: 0.4 GB for tdt-ctc-110m, 2.4 GB for the 600M models; pk_model_to_gpu's note)
     const size_t per_layer = 4 * f * d + 7 * d * d;
-    sig_buf_.reserve((size_t)cfg.num_layers * per_layer * 4);
-    float *p = sig_buf_.as<float>();
-    sig_layers_.resize(cfg.num_layers);
-    for (int l = 0; l < cfg.num_layers; ++l) {
-        const LayerW &W = layers[l];
-        auto sig = [&](const float *w, size_t rows, size_t K) {
-            launch_sigma_copy(w, p, (int64_t)rows, (int)K, (int64_t)K, stream);
-            const float *r = p;
-            p += rows * K;
-            return r;
-        };
-        SigW &S = sig_layers_[l];
-        S.ffn1_w1 = sig(W.ffn1_w1, f, d); S.ffn1_w2 = sig(W.ffn1_w2, d, f);
-        S.ffn2_w1 = sig(W.ffn2_w1, f, d); S.ffn2_w2 = sig(W.ffn2_w2, d, f);
-        S.wqkv = sig(W.wqkv, 3 * d, d); S.wo = sig(W.wo, d, d);
-        S.pw1 = sig(W.pw1_w, 2 * d, d); S.pw2 = sig(W.pw2_w, d, d);
+    try {
+        sig_buf_.reserve((size_t)cfg.num_layers * per_layer * 4);
+        float *p = sig_buf_.as<float>();
+        sig_layers_.resize(cfg.num_layers);
+        for (int l = 0; l < cfg.num_layers; ++l) {
+            const LayerW &W = layers[l];
+            auto sig = [&](const float *w, size_t rows, size_t K) {
+                launch_sigma_copy(w, p, (int64_t)rows, (int)K, (int64_t)K, stream);
+                const float *r = p;
+                p += rows * K;
+                return r;
+            };
+            SigW &S = sig_layers_[l];
+            S.ffn1_w1 = sig(W.ffn1_w1, f, d); S.ffn1_w2 = sig(W.ffn1_w2, d, f);
+            S.ffn2_w1 = sig(W.ffn2_w1, f, d); S.ffn2_w2 = sig(W.ffn2_w2, d, f);
+            S.wqkv = sig(W.wqkv, 3 * d, d); S.wo = sig(W.wo, d, d);
+            S.pw1 = sig(W.pw1_w, 2 * d, d); S.pw2 = sig(W.pw2_w, d, d);
+        }
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipStreamSynchronize(stream));
+    } catch (...) {
+        // nothing half-built survives: the next call tries again, and until then the natural-layout kernels are used
+        sig_layers_.clear();
+        if (sig_buf_.p) { (void)hipFree(sig_buf_.p); sig_buf_.p = nullptr; sig_buf_.cap = 0; }
+        throw;
     }
-    PK_CHECK_LAUNCH();
-    PK_HIP(hipStreamSynchronize(stream));
+    sig_built_ = true;                       // only now: every copy is complete
     return sig_layers_;
 }
 
 // ---- workspace ----------------------------------------------------------------------------------------------
+static inline int sub_len(int n) { return (n - 1) / 2 + 1; }        // one stride-2 stage of the subsampling (src/encoder.cpp:208-217)
+
+// encoder-side buffers for sum_Tm mel frames / sum_H2 rows after dw1 / sum_T encoder rows in all
+static void reserve_encoder(Workspace &w, const pk_config &c, size_t pcm_samples, bool logmel, size_t sum_Tm, size_t sum_H2, size_t sum_T) {
+    const int F = c.mel_bins, C = c.subsampling_channels, d = c.hidden_size;
+    const int W2 = sub_len(sub_len(F)), W3 = sub_len(W2);
+    const size_t f = sizeof(float), M = sum_T;
+    if (pcm_samples) w.pcm.reserve(pcm_samples * f);
+    if (logmel) w.logmel.reserve((size_t)F * sum_Tm * f);
+    w.feats.reserve(sum_Tm * F * f);
+    w.a2.reserve(sum_H2 * W2 * C * f); w.a3.reserve(sum_H2 * W2 * C * f);
+    w.a4.reserve(sum_T * W3 * C * f); w.flat.reserve(sum_T * W3 * C * f);
+    w.x.reserve(M * d * f); w.n.reserve(M * d * f); w.hbuf.reserve(M * c.ffn_intermediate * f); w.qkv.reserve(M * 3 * d * f);
+    w.ctx.reserve(M * d * f); w.g.reserve(M * d * f); w.dwb.reserve(M * d * f);
+    if (c.ctc_vocab_size > 0) { w.ctc_logits.reserve(M * c.ctc_vocab_size * f); }
+    w.best_idx.reserve(M * sizeof(int)); w.best_lp.reserve(M * f);
+}
+
 void Workspace::size_for(const pk_config &c, int B_, int64_t n_samples_, int Tm_) {
     B = B_; Tm = Tm_;
+    ragged = false;
+    dec_Tb = dec_row0 = nullptr;
     const bool own_pcm = n_samples_ > 0;          // a negative length: the caller owns the PCM buffer (pipelined batch slots)
     n_samples = n_samples_ < 0 ? -n_samples_ : n_samples_;
-    const int F = c.mel_bins, C = c.subsampling_channels, d = c.hidden_size;
-    auto sl = [](int n) { return (n - 1) / 2 + 1; };
-    const int H1 = sl(Tm), W1 = sl(F), H2 = sl(H1), W2 = sl(W1), H3 = sl(H2), W3 = sl(W2);
-    T = H3;
-    const size_t M = (size_t)B * T, f = sizeof(float);
-    if (own_pcm) pcm.reserve((size_t)B * n_samples * f);
-    if (n_samples > 0) logmel.reserve((size_t)B * F * Tm * f);
-    feats.reserve((size_t)B * Tm * F * f);
-    a2.reserve((size_t)B * H2 * W2 * C * f); a3.reserve((size_t)B * H2 * W2 * C * f);
-    a4.reserve((size_t)B * H3 * W3 * C * f); flat.reserve((size_t)B * H3 * W3 * C * f);
-    x.reserve(M * d * f); n.reserve(M * d * f); hbuf.reserve(M * c.ffn_intermediate * f); qkv.reserve(M * 3 * d * f);
-    ctx.reserve(M * d * f); g.reserve(M * d * f); dwb.reserve(M * d * f);
-    if (c.ctc_vocab_size > 0) { ctc_logits.reserve(M * c.ctc_vocab_size * f); }
-    best_idx.reserve(M * sizeof(int)); best_lp.reserve(M * f);
+    const int H2 = sub_len(sub_len(Tm));
+    T = T_run = sub_len(H2);
+    reserve_encoder(*this, c, own_pcm ? (size_t)B * n_samples : 0, n_samples > 0, (size_t)B * Tm, (size_t)B * H2, (size_t)B * T);
+    rag_cap_rows = (size_t)B * T; rag_cap_clips = B; rag_cap_samples = (int64_t)B * n_samples; rag_cap_clip = n_samples;
     reserve_decode(c);
 }
 
-// the TDT / RNNT decode state of B utterances of T frames (B, T set by the caller)
+// the TDT / RNNT decode state of B utterances of <= T frames, rag_cap_rows frames in all (B, T, rag_cap_rows set by the caller)
 void Workspace::reserve_decode(const pk_config &c) {
-    const size_t M = (size_t)B * T, f = sizeof(float);
+    const size_t M = rag_cap_rows ? rag_cap_rows : (size_t)B * T, f = sizeof(float);
     max_tokens = T * (c.max_symbols_per_step > 0 ? c.max_symbols_per_step : 10);
     const int Hp = c.pred_hidden, J = c.joint_hidden, L = c.num_lstm_layers, VD = c.vocab_size + c.num_durations;
     ep.reserve(M * J * f); gh.reserve((size_t)B * 4 * Hp * f); gi.reserve((size_t)B * 4 * Hp * f); pp.reserve((size_t)B * J * f);
@@ -511,17 +530,208 @@ void Workspace::reserve_decode(const pk_config &c) {
 }
 
 // decode-only workspace (no encoder buffers): the lock-step TDT state of a GROUP of pipelined batches (capi.cpp)
-void Workspace::size_decode(const pk_config &c, int B_, int T_) {
-    B = B_; T = T_;
+void Workspace::size_decode(const pk_config &c, int B_, int T_, size_t rows_cap) {
+    B = B_; T = T_run = T_;
+    ragged = false;
+    dec_Tb = dec_row0 = nullptr;
+    rag_cap_rows = rows_cap ? rows_cap : (size_t)B * T;
     reserve_decode(c);
 }
 
+// ---- ragged batches -------------------------------------------------------------------------------------------
+void RagBatch::build_from_samples(const int64_t *lens, int B_, int att_block_rows) {
+    B = B_; level = 0;
+    pcm_off.assign((size_t)B + 1, 0);
+    Tm.resize(B);
+    for (int b = 0; b < B; ++b) {
+        if (lens[b] <= 256) fail(PK_ERR_INVALID, "clip %d has %lld samples: every clip needs more than 256 (one STFT frame with reflect padding)", b, (long long)lens[b]);
+        if (lens[b] > ((int64_t)1 << 30)) fail(PK_ERR_UNSUPPORTED, "clip %d has %lld samples", b, (long long)lens[b]);
+        pcm_off[b + 1] = pcm_off[b] + lens[b];
+        Tm[b] = (int)(1 + lens[b] / 160);
+    }
+    n_samples = pcm_off[B];
+    finish(att_block_rows);
+}
+void RagBatch::build_from_mel(const int *Tm_, int B_, int att_block_rows) {
+    B = B_; level = 1;
+    pcm_off.clear(); n_samples = 0;
+    Tm.assign(Tm_, Tm_ + B);
+    for (int b = 0; b < B; ++b) if (Tm[b] < 1) fail(PK_ERR_INVALID, "utterance %d has %d mel frames", b, Tm[b]);
+    finish(att_block_rows);
+}
+void RagBatch::build_from_frames(const int *T_, int B_, int att_block_rows) {
+    B = B_; level = 2;
+    pcm_off.clear(); n_samples = 0; Tm.clear(); H2.clear();
+    T.assign(T_, T_ + B);
+    for (int b = 0; b < B; ++b) if (T[b] < 1) fail(PK_ERR_INVALID, "utterance %d has %d frames", b, T[b]);
+    finish(att_block_rows);
+}
+void RagBatch::finish(int att_block_rows) {
+    if (B <= 0) fail(PK_ERR_INVALID, "a ragged batch needs at least one utterance");
+    if (level <= 1) {
+        H2.resize(B); T.resize(B);
+        for (int b = 0; b < B; ++b) { H2[b] = sub_len(sub_len(Tm[b])); T[b] = sub_len(H2[b]); }
+    }
+    int64_t sTm = 0, sH2 = 0, sT = 0;
+    Tm_max = 0; T_max = 0;
+    for (int b = 0; b < B; ++b) {
+        if (level <= 1) { sTm += Tm[b]; sH2 += H2[b]; Tm_max = std::max(Tm_max, Tm[b]); }
+        sT += T[b]; T_max = std::max(T_max, T[b]);
+    }
+    if (sTm > 0x7fffffff / 2 || sT > 0x7fffffff / 2) fail(PK_ERR_UNSUPPORTED, "ragged batch too large (%lld mel frames)", (long long)sTm);
+    sum_Tm = (int)sTm; sum_H2 = (int)sH2; sum_T = (int)sT;
+    strip_rows = sub_conv1_dw1_strip_rows(sum_H2);
+    dw_frames = dwconv_strip_frames(sum_T);
+    att_rows = att_block_rows;
+    // ---- the image: every table as int32 words (pcm_off as int64 at word 0) ----
+    image.clear();
+    auto put_arr = [&](const std::vector<int> &v) { const size_t o = image.size(); image.insert(image.end(), v.begin(), v.end()); return o; };
+    auto put_off = [&](const std::vector<int> &v) {                 // exclusive prefix sums, B + 1 entries
+        const size_t o = image.size();
+        int acc = 0;
+        for (int b = 0; b < B; ++b) { image.push_back(acc); acc += v[b]; }
+        image.push_back(acc);
+        return o;
+    };
+    auto put_units = [&](const std::vector<int> &n, int gran, int &count) {   // one unit per strip of `gran` rows of one utterance
+        if (image.size() & 1) image.push_back(0);
+        const size_t o = image.size();
+        count = 0;
+        for (int b = 0; b < B; ++b)
+            for (int r0 = 0; r0 < n[b]; r0 += gran) { image.push_back(b); image.push_back(r0); ++count; }
+        return o;
+    };
+    o_pcm_off = 0;
+    if (level == 0) {
+        image.resize(2 * ((size_t)B + 1));
+        memcpy(image.data(), pcm_off.data(), ((size_t)B + 1) * 8);
+    }
+    if (level <= 1) {
+        o_Tm = put_arr(Tm); o_Tm_off = put_off(Tm); o_H2 = put_arr(H2); o_H2_off = put_off(H2);
+    }
+    o_T = put_arr(T); o_T_off = put_off(T);
+    if (level <= 1) {
+        o_u_c1 = put_units(H2, strip_rows, n_u_c1);
+        o_u_row = put_units(T, 1, n_u_row);
+    } else { n_u_c1 = n_u_row = 0; }
+    o_u_dw = put_units(T, dw_frames, n_u_dw);
+    o_u_att = put_units(T, att_rows, n_u_att);
+}
+size_t RagBatch::image_words_bound(int max_clips, int64_t max_total) {
+    // (max_total counted in samples: the frame counts below are upper bounds for every level)
+    const size_t B = (size_t)max_clips, sTm = (size_t)(max_total / 160) + B, sH2 = sTm / 4 + 2 * B, sT = sH2 / 2 + B;
+    return 2 * (B + 1) + 3 * (2 * B + 1) + 2 * (sH2 / 2 + B + sT + sT / 2 + B + sT / 32 + B) + 16;
+}
+
+void Workspace::size_ragged(const pk_config &c, int max_clips, int64_t max_total, int64_t max_clip, bool own_pcm, int level) {
+    if (max_clips <= 0 || max_total <= 0 || max_clip <= 0 || max_clip > max_total) fail(PK_ERR_INVALID, "ragged capacity: max_clips / max_total / max_clip");
+    const size_t Bc = (size_t)max_clips;
+    size_t sTm, sH2, sT;
+    int T_cap;
+    if (level == 0) {
+        sTm = (size_t)(max_total / 160) + Bc; sH2 = sTm / 4 + 2 * Bc; sT = sH2 / 2 + Bc;      // sum of ceil(n/2) <= sum n / 2 + B, twice, once
+        T_cap = sub_len(sub_len(sub_len((int)(1 + max_clip / 160))));
+    } else if (level == 1) {
+        sTm = (size_t)max_total; sH2 = sTm / 4 + 2 * Bc; sT = sH2 / 2 + Bc;
+        T_cap = sub_len(sub_len(sub_len((int)max_clip)));
+    } else {
+        sTm = sH2 = 0; sT = (size_t)max_total;
+        T_cap = (int)max_clip;
+    }
+    B = max_clips; T = T_run = T_cap; Tm = 0; n_samples = 0;
+    rag_cap_rows = sT; rag_cap_clips = max_clips; rag_cap_samples = max_total; rag_cap_clip = max_clip;
+    if (level <= 1) reserve_encoder(*this, c, (own_pcm && level == 0) ? (size_t)max_total : 0, level == 0, sTm, sH2, sT);
+    else {
+        const size_t f = sizeof(float), M = sT, d = c.hidden_size;
+        x.reserve(M * d * f); n.reserve(M * d * f); hbuf.reserve(M * c.ffn_intermediate * f); qkv.reserve(M * 3 * d * f);
+        ctx.reserve(M * d * f); g.reserve(M * d * f); dwb.reserve(M * d * f);
+        if (c.ctc_vocab_size > 0) ctc_logits.reserve(M * c.ctc_vocab_size * f);
+        best_idx.reserve(M * sizeof(int)); best_lp.reserve(M * f);
+    }
+    reserve_decode(c);
+    const size_t words = RagBatch::image_words_bound(max_clips, level == 0 ? max_total : (level == 1 ? max_total * 160 : max_total * 1280));
+    ragdev.reserve(words * 4);
+    if (words > rag_pinned_words) {
+        if (rag_copied) PK_HIP(hipEventSynchronize(rag_copied));
+        if (rag_pinned) { PK_HIP(hipHostFree(rag_pinned)); rag_pinned = nullptr; rag_pinned_words = 0; }
+        PK_HIP(hipHostMalloc(reinterpret_cast<void **>(&rag_pinned), words * 4, hipHostMallocDefault));
+        rag_pinned_words = words;
+    }
+    if (!rag_copied) PK_HIP(hipEventCreateWithFlags(&rag_copied, hipEventDisableTiming));
+}
+
+void Workspace::set_uniform(int B_, int64_t n_samples_) {
+    if (n_samples_ > 0) {
+        if (B_ > rag_cap_clips || n_samples_ > rag_cap_clip || (int64_t)B_ * n_samples_ > rag_cap_samples)
+            fail(PK_ERR_INVALID, "batch of %d clips x %lld samples exceeds the workspace (%d clips, %lld samples in all, %lld per clip)", B_, (long long)n_samples_,
+                 rag_cap_clips, (long long)rag_cap_samples, (long long)rag_cap_clip);
+        n_samples = n_samples_;
+        Tm = (int)(1 + n_samples / 160);
+        T_run = sub_len(sub_len(sub_len(Tm)));
+    }
+    ragged = false;
+    dec_Tb = dec_row0 = nullptr;
+    (void)B_;
+}
+
+void Workspace::set_ragged(const RagBatch &r, hipStream_t s) {
+    if (r.B > rag_cap_clips || (size_t)r.sum_T > rag_cap_rows || r.T_max > T || (r.level == 0 && r.n_samples > rag_cap_samples))
+        fail(PK_ERR_INVALID, "ragged batch (%d clips, %lld samples, %d encoder rows, longest %d frames) exceeds the workspace (%d clips, %lld samples, %zu rows, %d frames)",
+             r.B, (long long)r.n_samples, r.sum_T, r.T_max, rag_cap_clips, (long long)rag_cap_samples, rag_cap_rows, T);
+    rag = r;
+    ragged = true;
+    const size_t words = rag.image.size();
+    ragdev.reserve(words * 4);                                      // (no-op inside the reserved capacity)
+    if (words > rag_pinned_words) {
+        if (rag_copied) PK_HIP(hipEventSynchronize(rag_copied));
+        if (rag_pinned) { PK_HIP(hipHostFree(rag_pinned)); rag_pinned = nullptr; rag_pinned_words = 0; }
+        PK_HIP(hipHostMalloc(reinterpret_cast<void **>(&rag_pinned), words * 4, hipHostMallocDefault));
+        rag_pinned_words = words;
+    }
+    if (!rag_copied) PK_HIP(hipEventCreateWithFlags(&rag_copied, hipEventDisableTiming));
+    PK_HIP(hipEventSynchronize(rag_copied));                        // the previous upload out of the pinned copy has executed (normally long ago)
+    memcpy(rag_pinned, rag.image.data(), words * 4);
+    PK_HIP(hipMemcpyAsync(ragdev.p, rag_pinned, words * 4, hipMemcpyHostToDevice, s));
+    PK_HIP(hipEventRecord(rag_copied, s));
+    const int32_t *dv = ragdev.as<int32_t>();
+    rv = RagDev();
+    const int *dT = dv + rag.o_T, *dToff = dv + rag.o_T_off;
+    if (rag.level <= 1) {
+        const int *dTm = dv + rag.o_Tm, *dTmoff = dv + rag.o_Tm_off, *dH2 = dv + rag.o_H2, *dH2off = dv + rag.o_H2_off;
+        if (rag.level == 0) { rv.mel.pcm_off = reinterpret_cast<const int64_t *>(dv + rag.o_pcm_off); rv.mel.Tm = dTm; rv.mel.Tm_off = dTmoff; rv.mel.max_frames = rag.Tm_max; }
+        rv.c1.strips = {reinterpret_cast<const RagUnit *>(dv + rag.o_u_c1), rag.n_u_c1};
+        rv.c1.strip_rows = rag.strip_rows;
+        rv.c1.Tm = dTm; rv.c1.Tm_off = dTmoff; rv.c1.H2 = dH2; rv.c1.H2_off = dH2off; rv.c1.T = dT; rv.c1.T_off = dToff;
+        rv.dw2 = rv.c1;
+        rv.dw2.strips = {reinterpret_cast<const RagUnit *>(dv + rag.o_u_row), rag.n_u_row};
+        rv.dw2.strip_rows = 1;
+    }
+    rv.att.units = {reinterpret_cast<const RagUnit *>(dv + rag.o_u_att), rag.n_u_att};
+    rv.att.T = dT; rv.att.T_off = dToff; rv.att.T_max = rag.T_max;
+    rv.dwc = rv.att;
+    rv.dwc.units = {reinterpret_cast<const RagUnit *>(dv + rag.o_u_dw), rag.n_u_dw};
+    rv.seq = rv.att;
+    rv.seq.units = RagUnits();
+    dec_Tb = dT; dec_row0 = dToff;
+}
+
 // ---- stages ---------------------------------------------------------------------------------------------------
-void Model::run_mel(const float *d_pcm, int B, int64_t n_samples, float *d_logmel, float *d_feats, hipStream_t s) {
+void Model::run_mel(const float *d_pcm, int B, int64_t n_samples, float *d_logmel, float *d_feats, hipStream_t s, const RagDev *rv) {
+    if (rv) fail(PK_ERR_INVALID, "run_mel: ragged batches go through run_mel_ws");
     const int n_frames = (int)(1 + n_samples / 160);
     const double bytes_in = (double)B * n_samples * 4, bytes_lm = (double)B * cfg.mel_bins * n_frames * 4;
     KL("mel_logmel", 0.0, bytes_in + bytes_lm, launch_mel_logmel(d_pcm, B, n_samples, n_frames, mel, d_logmel, s));
     KL("mel_normalize", 0.0, 2.0 * bytes_lm, launch_mel_normalize(d_logmel, B, cfg.mel_bins, n_frames, cfg.mel_normalize_off ? 0 : 1, d_feats, s));
+}
+
+// preprocess_audio of the workspace's batch (uniform: w.B clips of w.n_samples; ragged: w.rag) -> w.logmel, w.feats
+void Model::run_mel_ws(Workspace &w, const float *d_pcm, int B, hipStream_t s) {
+    if (!w.ragged) { run_mel(d_pcm, B, w.n_samples, w.logmel.as<float>(), w.feats.as<float>(), s); return; }
+    if (w.rag.level != 0) fail(PK_ERR_INVALID, "run_mel_ws: the ragged batch was not built from PCM lengths");
+    const double bytes_in = (double)w.rag.n_samples * 4, bytes_lm = (double)cfg.mel_bins * w.rag.sum_Tm * 4;
+    KL("mel_logmel", 0.0, bytes_in + bytes_lm, launch_mel_logmel(d_pcm, w.rag.B, 0, 0, mel, w.logmel.as<float>(), s, w.rv.mel));
+    KL("mel_normalize", 0.0, 2.0 * bytes_lm,
+       launch_mel_normalize(w.logmel.as<float>(), w.rag.B, cfg.mel_bins, 0, cfg.mel_normalize_off ? 0 : 1, w.feats.as<float>(), s, w.rv.mel));
 }
 
 // sinusoidal_position_embedding (src/encoder.cpp:9-30): float math on the host, exactly as the reference does,
@@ -532,8 +742,12 @@ bool Model::attn_bf16(int T) const {
     return lds > 0 && lds <= (size_t)150 * 1024;
 }
 
+// The tables are kept for the LONGEST sequence seen so far: row p of the table of a T-frame sequence (position T - 1 - p) is row
+// p + (pos_T - T) of the table built for pos_T >= T frames -- the same float position, hence the same sin / cos values and the same row of
+// the row-wise pos_proj_ product.  Shorter sequences and the utterances of a ragged batch read their window of it (launch_relpos_attention:
+// pos_row0 / SeqRag::pos_T); the tables are rebuilt only when a longer sequence arrives.
 void Model::ensure_pos_tables(int T, hipStream_t s) {
-    if (T == pos_T) return;
+    if (T <= pos_T && pos_bf16 == attn_bf16(T)) return;
     const int d = cfg.hidden_size, P = 2 * T - 1;
     std::vector<float> pe((size_t)P * d);
     for (int p = 0; p < P; ++p) {
@@ -560,8 +774,10 @@ void Model::ensure_pos_tables(int T, hipStream_t s) {
             launch_pos_cvec(tab, layers[l].pos_u, layers[l].pos_v, P, d, H, pos_cvec.as<float>() + (size_t)l * H * P, s);
         }
         pos_T = T;
+        pos_bf16 = true;
         return;
     }
+    pos_bf16 = false;
     for (int l = 0; l < cfg.num_layers; ++l) {
         // written in the sigma column layout the attention kernel loads its MFMA operands in (kernels.hpp: GemmArgs::sigma_cols)
         GemmArgs g{pos_pe.as<float>(), d, layers[l].wpos, d, nullptr, pos_proj.as<float>() + (size_t)l * P * d, d, nullptr, 0, 1.0f, P, d, d};
@@ -575,14 +791,17 @@ void Model::run_subsample(Workspace &w, const float *d_feats, int B, int Tm, flo
     const int F = cfg.mel_bins, C = cfg.subsampling_channels, d = cfg.hidden_size;
     auto sl = [](int n) { return (n - 1) / 2 + 1; };
     const int H1 = sl(Tm), W1 = sl(F), H2 = sl(H1), W2 = sl(W1), H3 = sl(H2), W3 = sl(W2);
-    const double px2 = (double)B * H2 * W2, px3 = (double)B * H3 * W3;
+    // a ragged batch (w.ragged; B / Tm ignored): the same kernels on packed rows, every utterance with its own extents (kernels.hpp: SubRag)
+    const bool rg = w.ragged;
+    const double rows2 = rg ? (double)w.rag.sum_H2 : (double)B * H2, rows3 = rg ? (double)w.rag.sum_T : (double)B * H3;
+    const double px2 = rows2 * W2, px3 = rows3 * W3, frames = rg ? (double)w.rag.sum_Tm : (double)B * Tm;
     // conv1 + ReLU + dw1 (fused)  src/encoder.cpp:223-226
-    KL("sub_conv1_dw1", px2 * C * (81.0 + 9.0) * 2.0, (double)B * Tm * F * 4 + px2 * C * 4,
-       launch_sub_conv1_dw1(d_feats, B, Tm, F, C, sub.c1w, sub.c1b, sub.d1w, sub.d1b, w.a2.as<float>(), s));
+    KL("sub_conv1_dw1", px2 * C * (81.0 + 9.0) * 2.0, frames * F * 4 + px2 * C * 4,
+       launch_sub_conv1_dw1(d_feats, B, Tm, F, C, sub.c1w, sub.c1b, sub.d1w, sub.d1b, w.a2.as<float>(), s, rg ? w.rv.c1 : SubRag()));
     // conv2 (1x1) + ReLU  :227-228
     gemm("sub_pw", w.a2.as<float>(), C, sub.c2w, C, sub.c2b, w.a3.as<float>(), C, (int)px2, C, C, EPI_RELU, nullptr, 0, 1.0f, s);
     // dw2  :230
-    KL("sub_dw2", px3 * C * 18.0, (px2 + px3) * C * 4, launch_sub_dw(w.a3.as<float>(), B, H2, W2, C, sub.d2w, sub.d2b, w.a4.as<float>(), s));
+    KL("sub_dw2", px3 * C * 18.0, (px2 + px3) * C * 4, launch_sub_dw(w.a3.as<float>(), B, H2, W2, C, sub.d2w, sub.d2b, w.a4.as<float>(), s, rg ? w.rv.dw2 : SubRag()));
     // conv3 (1x1) + ReLU, written directly in permute(0,2,1,3)+reshape order (feature = c*W3 + f)  :231-238
     {
         GemmArgs g{w.a4.as<float>(), C, sub.c3w, C, sub.c3b, w.flat.as<float>(), C, nullptr, 0, 1.0f, (int)px3, C, C};
@@ -590,9 +809,9 @@ void Model::run_subsample(Workspace &w, const float *d_feats, int B, int Tm, flo
         run_gemm("sub_pw", g, EPI_RELU, s);
     }
     // proj_  :240
-    gemm("sub_proj", w.flat.as<float>(), (int64_t)C * W3, sub.pw, (int64_t)C * W3, sub.pb, d_x, d, B * H3, d, C * W3, EPI_NONE, nullptr, 0, 1.0f, s);
+    gemm("sub_proj", w.flat.as<float>(), (int64_t)C * W3, sub.pw, (int64_t)C * W3, sub.pb, d_x, d, (int)rows3, d, C * W3, EPI_NONE, nullptr, 0, 1.0f, s);
     if (cfg.xscaling)                                               // streaming_encoder.cpp:402-406: x = x * sqrt(hidden_size)
-        KL("xscale", 0.0, 2.0 * B * H3 * d * 4, launch_scale(d_x, (int64_t)B * H3 * d, sqrtf((float)d), s));
+        KL("xscale", 0.0, 2.0 * rows3 * d * 4, launch_scale(d_x, (int64_t)rows3 * d, sqrtf((float)d), s));
     (void)W1; (void)H1;
 }
 
@@ -627,15 +846,19 @@ void Model::run_encoder(Workspace &w, const float *d_feats, int B, int Tm, int s
 
 // ConformerBlock::forward x (layers first_layer ..) on w.x [B][T][d]  (src/encoder.cpp:196-204, :267-269)
 void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int stop_stage, hipStream_t s) {
-    const int d = cfg.hidden_size, T = w.T, P = 2 * T - 1;
-    const int64_t rows = (int64_t)B * T;
+    // a ragged batch (w.ragged; B ignored): packed rows; T = its longest utterance (position tables, LDS sizing)
+    const bool rg = w.ragged;
+    const int d = cfg.hidden_size, T = w.t_max();
+    if (rg) B = w.rag.B;
+    const int64_t rows = w.rows(B);
     float *x = w.x.as<float>(), *n = w.n.as<float>();
     if (stop_layer < 0 || stop_layer > cfg.num_layers) { stop_layer = cfg.num_layers; stop_stage = 0; }
     if (stop_layer == 0 && stop_stage == 0) return;
     float *att_scratch_p = nullptr;
     if (!attn_bf16(T) && relpos_attention_lds_bytes(T, d / cfg.num_heads) > 160 * 1024) {
         // a [32][T] score block no longer fits LDS (> ~85 s of audio): the same kernel with its score blocks in global scratch
-        const size_t need = relpos_attention_scratch_bytes(B, T, cfg.num_heads, d / cfg.num_heads);
+        const size_t need = rg ? relpos_attention_scratch_bytes_units(w.rag.n_u_att, T, cfg.num_heads, d / cfg.num_heads)
+                               : relpos_attention_scratch_bytes(B, T, cfg.num_heads, d / cfg.num_heads);
         if (need == 0 || need > ((size_t)64 << 30))
             fail(PK_ERR_UNSUPPORTED, "utterance of %d encoder frames (%.1f s) x %d clips: the attention scratch would need %.1f GB -- use fewer / shorter clips per call",
                  T, T * 0.08, B, need / 1e9);
@@ -643,8 +866,15 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
         att_scratch_p = att_scratch.as<float>();
     }
     ensure_pos_tables(T, s);
+    const int P = 2 * pos_T - 1;                                     // rows of the resident tables (built for pos_T >= T frames)
     const int a16 = cfg.gemm_bf16 ? 1 : 0;                           // bf16 mode: LayerNorm outputs stored as bf16 GEMM operands (ffn())
     const bool att16 = attn_bf16(T);                                 // ... and q / k / v as bf16 for the bf16-MFMA attention kernel
+    if (rg) {
+        const int want = att16 ? relpos_attention_bf16_block_rows(d / cfg.num_heads) : 32;
+        if (w.rag.att_rows != want) fail(PK_ERR_INVALID, "internal: the ragged batch's attention blocks hold %d rows, the kernel takes %d", w.rag.att_rows, want);
+        w.rv.att.pos_T = pos_T;
+    }
+    const SeqRag no_rag;
     // Small batches (rows <= kSmallMRows: one clip, the reference's own benchmark protocol): every product is a latency-bound chain of
     // dependent MFMAs (kernels/gemm_smallm.hip).  They run on the tiled sigma-K weight copies with sigma-K activations -- written that way by
     // their producers (LayerNorm mode 2, sigma_cols of fc1, the attention context, the depthwise conv) -- so nothing but the MFMAs is on the
@@ -672,18 +902,18 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             if (sg) { g.a_sigma = 1; g.W_sig = sg->wqkv; }
             run_gemm("attn_qkv", g, EPI_NONE, s);
         }
+        const int hd = d / cfg.num_heads;
+        double fl = 0.0;                                             // QK^T + QP^T (needed band) + AV over every (utterance, head)
+        if (rg) for (int tb : w.rag.T) fl += (double)cfg.num_heads * (2.0 * tb * tb * hd * 2 + 2.0 * tb * tb * hd);
+        else fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);
         if (att16) {
-            const int hd = d / cfg.num_heads;
-            const double fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);
             KL("relpos_attention", fl, 0.0,
                launch_relpos_attention_bf16(w.qkv.p, B, T, d, cfg.num_heads, reinterpret_cast<const __bf16 *>(pos_proj.p) + (size_t)l * P * d,
-                                            pos_cvec.as<float>() + (size_t)l * cfg.num_heads * P, L.pos_u, w.ctx.p, s));
+                                            pos_cvec.as<float>() + (size_t)l * cfg.num_heads * P, L.pos_u, w.ctx.p, s, pos_T, rg ? w.rv.att : no_rag));
         } else {
-            const int hd = d / cfg.num_heads;
-            const double fl = (double)B * cfg.num_heads * (2.0 * T * T * hd * 2 + 2.0 * T * T * hd);   // QK^T + QP^T(needed band) + AV
             KL("relpos_attention", fl, 0.0,
                launch_relpos_attention(w.qkv.as<float>(), B, T, d, cfg.num_heads, pos_proj.as<float>() + (size_t)l * P * d, L.pos_u, L.pos_v,
-                                       w.ctx.as<float>(), s, 0.0f, att_scratch_p, ymode));
+                                       w.ctx.as<float>(), s, 0.0f, att_scratch_p, ymode, pos_T - T, rg ? w.rv.att : no_rag));
         }
         {
             GemmArgs g{w.ctx.as<float>(), d, L.wo, d, L.bo, x, d, x, d, 1.0f, (int)rows, d, d};
@@ -702,8 +932,8 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             run_gemm("conv_pw1_glu", g, EPI_GLU, s);
         }
         KL("dwconv_bn_silu", (double)rows * d * cfg.conv_kernel_size * 2.0, 2.0 * rows * d * 4,
-           launch_dwconv_bn_silu(w.g.as<float>(), B, T, d, cfg.conv_kernel_size, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
-                                 w.dwb.as<float>(), s, ymode));
+           launch_dwconv_bn_silu(w.g.as<float>(), rg ? 1 : B, rg ? (int)rows : T, d, cfg.conv_kernel_size, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
+                                 w.dwb.as<float>(), s, ymode, rg ? w.rv.dwc : no_rag));
         {
             GemmArgs g{w.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, x, d, 1.0f, (int)rows, d, d};
             g.a_bf16 = a16;
@@ -777,7 +1007,12 @@ TrieDev Model::trie_dev(Workspace &w, int B) {
 void Model::run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_logp, hipStream_t s) {
     if (cfg.ctc_vocab_size <= 0) fail(PK_ERR_UNSUPPORTED, "this model has no ctc_decoder_ head");
     const int V = cfg.ctc_vocab_size, d = cfg.hidden_size;
-    const int64_t rows = (int64_t)B * T;
+    // a ragged batch (w.ragged; B / T ignored): packed rows, per-utterance frame counts; the token arrays are [B][w.T] (the capacity pitch)
+    const bool rg = w.ragged;
+    if (rg) B = w.rag.B;
+    const int64_t rows = rg ? w.rows(B) : (int64_t)B * T;
+    const int pitch = (rg || w.T >= T) ? w.T : T;                   // token arrays [B][pitch]: the workspace's capacity (= T for a full uniform run)
+    const SeqRag seq = rg ? w.rv.seq : SeqRag();
     gemm("ctc_head", d_enc, d, dec.ctc_w, d, dec.ctc_b, w.ctc_logits.as<float>(), V, (int)rows, V, d, EPI_NONE, nullptr, 0, 1.0f, s);
     if (boost_on) want_logp = true;                                 // the boosted argmax needs the whole log-prob rows
     if (want_logp) w.ctc_lp.reserve((size_t)rows * V * 4);
@@ -787,12 +1022,12 @@ void Model::run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_lo
     if (boost_on) {
         KL("ctc_boosted", 0.0, (double)rows * V * 4,
            launch_ctc_boosted(w.ctc_lp.as<float>(), B, T, V, cfg.blank_id < V ? cfg.blank_id : V - 1, trie_dev(w, B), w.ids.as<int>(), w.lens.as<int>(),
-                              w.start.as<int>(), w.end.as<int>(), w.conf.as<float>(), s));
+                              w.start.as<int>(), w.end.as<int>(), w.conf.as<float>(), s, pitch, seq));
         return;
     }
     KL("ctc_collapse", 0.0, 0.0,
        launch_ctc_collapse(w.best_idx.as<int>(), w.best_lp.as<float>(), B, T, cfg.blank_id < V ? cfg.blank_id : V - 1, w.ids.as<int>(), w.lens.as<int>(),
-                           w.start.as<int>(), w.end.as<int>(), w.conf.as<float>(), s));
+                           w.start.as<int>(), w.end.as<int>(), w.conf.as<float>(), s, pitch, seq));
 }
 
 // tdt_greedy_decode(_with_timestamps) / rnnt_greedy_decode  (src/tdt.cpp:36-201, src/rnnt.cpp:56-177)
@@ -804,7 +1039,8 @@ void Model::run_enc_proj(const float *d_enc, int64_t rows, float *ep_out, hipStr
 }
 
 void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_tokens, hipStream_t s, bool keep_state) {
-    run_enc_proj(d_enc, (int64_t)B * T, w.ep.as<float>(), s);
+    if (w.ragged) { B = w.rag.B; T = w.rag.T_max; }                  // ragged batch: packed rows; T bounds the loop, w.dec_Tb / dec_row0 give the extents
+    run_enc_proj(d_enc, w.ragged ? w.rows(B) : (int64_t)B * T, w.ep.as<float>(), s);
     run_tdt_loop(w, B, T, max_tokens, s, keep_state);
 }
 
@@ -818,6 +1054,7 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     st.B = B; st.T = T; st.V = V; st.D = D; st.L = L; st.Hp = Hp; st.blank = cfg.blank_id; st.max_symbols = cfg.max_symbols_per_step;
     st.max_tokens = max_tokens;
     st.keep_state = keep_state ? 1 : 0;
+    st.Tb = w.dec_Tb; st.row0 = w.dec_row0;                          // ragged batch / decode group of ragged runs (null: uniform, T frames each)
     if (boost_on) {
         if (cfg.rnnt_head || keep_state) fail(PK_ERR_UNSUPPORTED, "phrase boosting applies to the CTC and TDT greedy decoders only (src/phrase_boost.cpp)");
         st.trie = trie_dev(w, B);
@@ -874,7 +1111,7 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     {
         SkinnyArgs &a = P.act;
         a.X = w.hn.as<float>() + (size_t)(L - 1) * B * Hp; a.W = dec_wp_s; a.B = B; a.N = J; a.K = Hp; a.bias = dec.bp;
-        a.out = w.z.as<float>(); a.ep = w.ep.as<float>(); a.t = st.t; a.T = T;
+        a.out = w.z.as<float>(); a.ep = w.ep.as<float>(); a.t = st.t; a.T = T; a.Tb = st.Tb; a.row0 = st.row0;
     }
     {
         SkinnyArgs &a = P.heads;
@@ -946,7 +1183,7 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         // weight generation (a graph never outlives the weights it was captured against: the workspace is keyed by model + stream)
         std::vector<unsigned char> key;
         auto put = [&key](const void *p, size_t n) { const unsigned char *c = static_cast<const unsigned char *>(p); key.insert(key.end(), c, c + n); };
-        const void *ptrs[] = {this, s, st.logits, st.h, st.c, st.hn, st.cn, st.token, st.lens, st.ids, st.start, st.end, st.conf, P.act.ep, P.heads.W, P.act.W, P.cell[0].W, P.cell[0].gi};
+        const void *ptrs[] = {this, s, st.logits, st.h, st.c, st.hn, st.cn, st.token, st.lens, st.ids, st.start, st.end, st.conf, P.act.ep, P.heads.W, P.act.W, P.cell[0].W, P.cell[0].gi, st.Tb, st.row0};
         const int ints[] = {B, T, V, D, L, Hp, J, max_tokens, st.blank, st.max_symbols, st.max_steps, st.keep_state, boost_on ? 1 : 0, pred_cache ? 1 : 0};
         put(ptrs, sizeof ptrs);
         put(ints, sizeof ints);

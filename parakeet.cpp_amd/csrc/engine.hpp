@@ -44,9 +44,48 @@ struct ProfileSink {
     ~ProfileSink();
 };
 
+// Extents of one RAGGED batch -- clips of different lengths packed back to back along the time axis (kernels.hpp: MelRag / SubRag / SeqRag;
+// the reference's "batch inference" roadmap item, README.md:513, without padding) -- as the host knows them, and the one int32 image of
+// every table its kernels read.  build_* fill the host side; Workspace::set_ragged uploads the image and forms the device views.
+struct RagBatch {
+    int B = 0;
+    int level = 0;                                // what the batch starts from: 0 PCM samples, 1 mel frames, 2 encoder frames
+    std::vector<int64_t> pcm_off;                 // [B+1] (level 0)
+    std::vector<int> Tm, H2, T;                   // per utterance: mel frames (level <= 1), rows after conv1 / dw1, encoder frames
+    int64_t n_samples = 0;                        // totals and maxima
+    int sum_Tm = 0, sum_H2 = 0, sum_T = 0, Tm_max = 0, T_max = 0;
+    int strip_rows = 0, dw_frames = 0, att_rows = 0;   // unit granularities the tables were built for
+    std::vector<int32_t> image;
+    size_t o_pcm_off = 0, o_Tm = 0, o_Tm_off = 0, o_H2 = 0, o_H2_off = 0, o_T = 0, o_T_off = 0, o_u_c1 = 0, o_u_row = 0, o_u_dw = 0, o_u_att = 0;
+    int n_u_c1 = 0, n_u_row = 0, n_u_dw = 0, n_u_att = 0;
+    void build_from_samples(const int64_t *lens, int B, int att_block_rows);
+    void build_from_mel(const int *Tm, int B, int att_block_rows);
+    void build_from_frames(const int *T, int B, int att_block_rows);
+    // words of `image` a batch of <= max_clips clips with <= max_total_samples samples can need (capacity of the device copy)
+    static size_t image_words_bound(int max_clips, int64_t max_total_samples);
+  private:
+    void finish(int att_block_rows);
+};
+struct RagDev {                                   // device views of a RagBatch's tables (kernels.hpp)
+    MelRag mel; SubRag c1, dw2; SeqRag att, dwc, seq;
+};
+
 // Activation workspace of one resident batch (B clips of n_samples): sized once, reused every run.
 struct Workspace {
     int B = 0; int64_t n_samples = 0; int Tm = 0, T = 0, max_tokens = 0;
+    int T_run = 0;              // encoder frames per clip of the current UNIFORM run (= T unless the run is smaller than the capacity, set_uniform)
+    // Ragged runs: `ragged` set, rag / rv describe the batch; B = its clip count, T = max_tokens / T = the CAPACITY the output arrays are pitched
+    // for (fixed at size_ragged), rows = packed encoder rows.  Uniform runs: rows = B * T.
+    bool ragged = false;
+    RagBatch rag;
+    RagDev rv;
+    DevBuf ragdev;                                // device copy of rag.image (+ the decode tables of a decode group)
+    int32_t *rag_pinned = nullptr;                // pinned staging of the image (async upload on the run's stream)
+    size_t rag_pinned_words = 0;
+    hipEvent_t rag_copied = nullptr;              // the last upload out of rag_pinned has executed
+    const int *dec_Tb = nullptr, *dec_row0 = nullptr;   // decode loop on a ragged batch: frames / first enc_proj row of every utterance (device; null = uniform)
+    int64_t rows(int B_run) const { return ragged ? rag.sum_T : (int64_t)B_run * T_run; }   // packed encoder rows of the current run
+    int t_max() const { return ragged ? rag.T_max : T_run; }
     DevBuf pcm, logmel, feats, a2, a3, a4, a5, flat, x, n, hbuf, qkv, ctx, g, dwb;
     DevBuf ctc_logits, ctc_lp, best_idx, best_lp;
     DevBuf ep, gh, gi, pp, z, logits, h, c, hn, cn, ints, ids, start, end, conf, lens, margin;
@@ -54,13 +93,28 @@ struct Workspace {
     // captured chunk of decode steps (Model::run_tdt): replayed while the step-invariant kernel arguments stay the same
     hipGraphExec_t dec_graph = nullptr;
     std::vector<unsigned char> dec_graph_key;
-    ~Workspace() { if (dec_graph) (void)hipGraphExecDestroy(dec_graph); }
+    ~Workspace() {
+        if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
+        if (rag_pinned) (void)hipHostFree(rag_pinned);
+        if (rag_copied) (void)hipEventDestroy(rag_copied);
+    }
     Workspace() = default;
     Workspace(const Workspace &) = delete;
     Workspace &operator=(const Workspace &) = delete;
     void size_for(const pk_config &cfg, int B, int64_t n_samples, int Tm);
-    void size_decode(const pk_config &cfg, int B, int T);     // TDT / RNNT decode state only
+    void size_decode(const pk_config &cfg, int B, int T, size_t rows_cap = 0);     // TDT / RNNT decode state only (rows_cap: enc_proj rows, default B * T)
     void reserve_decode(const pk_config &cfg);
+    // Capacity for ragged batches of <= max_clips clips, <= max_total_samples samples in all, no clip longer than max_clip_samples
+    // (own_pcm: with a PCM buffer of its own).  level: what the batches start from (RagBatch::level; 1: max_total_samples / max_clip_samples
+    // count mel FRAMES, 2: encoder frames).
+    void size_ragged(const pk_config &cfg, int max_clips, int64_t max_total, int64_t max_clip, bool own_pcm, int level = 0);
+    // Makes `r` the batch of the next run: checks it against the capacity, uploads its tables on `s` (asynchronously, out of a pinned copy)
+    // and forms the device views.  pos_T is patched in by Model::run_layers.
+    void set_ragged(const RagBatch &r, hipStream_t s);
+    void set_uniform(int B_, int64_t n_samples_);            // a uniform run inside the reserved capacity (n_samples_ = 0: keep)
+    size_t rag_cap_rows = 0;                                  // packed encoder rows the buffers were reserved for (size_ragged / size_for)
+    int rag_cap_clips = 0;
+    int64_t rag_cap_samples = 0, rag_cap_clip = 0;
 };
 
 class StreamBatch;
@@ -95,7 +149,8 @@ class Model {
 
     // relative-position tables: sinusoidal pe [2T-1][d] (src/encoder.cpp:9-30, host float math) and the
     // per-layer pos_proj_(pe) [L][2T-1][d]; they depend on (T, weights) only, so they are rebuilt when T changes.
-    int pos_T = 0;
+    int pos_T = 0;              // the tables hold 2 pos_T - 1 rows; a shorter sequence of T frames uses rows [pos_T - T, pos_T + T - 1): identical values
+    bool pos_bf16 = false;      // ... in the bf16 attention's format
     DevBuf pos_pe, pos_proj;
     DevBuf pos_cvec;            // bf16 attention: (v_h - u_h) . P_p per (layer, head, p)
     bool attn_bf16(int T) const;    // the bf16-MFMA attention kernel applies (gemm_bf16 mode, head size 64 / 128, strip + c band fit LDS)
@@ -103,7 +158,9 @@ class Model {
     void ensure_pos_tables(int T, hipStream_t s);
 
     // stage drivers (device pointers, enqueue on `s`, never synchronise)
-    void run_mel(const float *d_pcm, int B, int64_t n_samples, float *d_logmel, float *d_feats, hipStream_t s);
+    void run_mel(const float *d_pcm, int B, int64_t n_samples, float *d_logmel, float *d_feats, hipStream_t s, const RagDev *rv = nullptr);
+    // the whole path on a workspace whose batch (uniform or ragged) has been set: w.pcm-independent, PCM given by the caller
+    void run_mel_ws(Workspace &w, const float *d_pcm, int B, hipStream_t s);
     void run_subsample(Workspace &w, const float *d_feats, int B, int Tm, float *d_x, hipStream_t s);
     void run_encoder(Workspace &w, const float *d_feats, int B, int Tm, int stop_layer, int stop_stage, hipStream_t s);  // -> w.x
     void run_layers(Workspace &w, int B, int first_layer, int stop_layer, int stop_stage, hipStream_t s);                 // w.x -> w.x

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
                                                                const float *__restrict__ pos /*[2T-1][d], sigma columns*/,
                                                                const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                float scale, float *__restrict__ ctx, int PITS, int n_rb, int n_bh,
-                                                               float *__restrict__ s_scratch, int ctx_bf16) {
+                                                               float *__restrict__ s_scratch, int ctx_bf16, int pos_row0, SeqRag rg) {
     __builtin_amdgcn_s_setprio(3);        // ahead of the overlapped decode-loop waves in the SIMD's arbitration (gemm_pipe.hpp)
     constexpr int KQ = HD / 4;
     constexpr int NQ4 = HD / 16;          // float4 fragments per lane for K = HD (one per block of 16 features)
@@ -55,23 +55,35 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
     const int H = d / HD;
     // Block b runs on XCD b % 8 (observed dispatch rule).  The row blocks of one (utterance, head) share K, V and the P band:
     // give them consecutive slots on ONE XCD so the second..last read those rows from that XCD's L2 instead of HBM.
-    int bh, rbk;
-    {
+    int h, i0;
+    int64_t row0;                                                   // first row of this utterance in the (packed) row axis of qkv / ctx
+    if (rg.units.u) {
+        // ragged batch (kernels.hpp: SeqRag): XCD x takes head x (+ 8, ...) of EVERY utterance, the row blocks of one utterance in consecutive
+        // slots -- the same L2 sharing; this utterance's own length, and its window of the position table built for rg.pos_T frames
         const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
-        rbk = k % n_rb;
-        bh = (k / n_rb) * 8 + xcd;
+        h = (k / rg.units.count) * 8 + xcd;
+        if (h >= H) return;
+        const RagUnit un = rg.units.u[k % rg.units.count];
+        i0 = un.r0;
+        T = rg.T[un.b];
+        row0 = rg.T_off[un.b];
+        pos_row0 = rg.pos_T - T;
+    } else {
+        const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
+        const int rbk = k % n_rb, bh = (k / n_rb) * 8 + xcd;
         if (bh >= n_bh) return;                                      // padding slot of the grid (whole workgroup, before any barrier)
+        h = bh % H;
+        i0 = rbk * RB;
+        row0 = (int64_t)(bh / H) * T;
     }
-    const int b = bh / H, h = bh % H;
-    const int i0 = rbk * RB;
     const int rows = (T - i0) < RB ? (T - i0) : RB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int rt = wave & 1, cp = wave >> 1;                       // this wave's 16-row tile and tile parity
     const int P = 2 * T - 1;
-    const float *qb = qkv + (int64_t)b * T * ldq + h * HD;          // q rows of this (b,h) (sigma columns)
+    const float *qb = qkv + row0 * ldq + h * HD;                    // q rows of this (b,h) (sigma columns)
     const float *kb = qb + d, *vb = qb + 2 * d;                     // k (sigma columns), v (natural)
-    const float *pb = pos + h * HD;
+    const float *pb = pos + (int64_t)pos_row0 * d + h * HD;         // row p of THIS length's table (engine.cpp: ensure_pos_tables)
     auto sidx = [&](int il, int j) { return (j & 3) * SPLANE + il * PITS + (j >> 2); };
 
     // V chunk: cooperative coalesced loads -> registers -> LDS
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
         for (int r = 0; r < 4; ++r) {
             const int il = il_base + r;
             if (il < rows) {
-                const int64_t orow = ((int64_t)b * T + i0 + il) * d;
+                const int64_t orow = (row0 + i0 + il) * d;
                 const int col = h * HD + (cp + 2 * m) * 16 + l15;
                 if (ctx_bf16 == 1) reinterpret_cast<__bf16 *>(ctx)[orow + col] = (__bf16)acc[m][r];      // bf16 mode: out_proj's operand, rounded here (RNE)
                 else if (ctx_bf16 == 2) ctx[orow + ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3))] = acc[m][r];   // fp32, sigma K layout (GemmArgs::a_sigma)
@@ -293,18 +305,20 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
 
 template <int HD, int VCH>
 static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u, const float *bias_v,
-                       float *ctx, float scale_arg, hipStream_t s, float *scratch, int ctx_bf16) {
+                       float *ctx, float scale_arg, hipStream_t s, float *scratch, int ctx_bf16, int pos_row0, const SeqRag &rag) {
     const float scale = scale_arg > 0.0f ? scale_arg : 1.0f / sqrtf((float)HD);   // src/encoder.cpp:126
+    if (rag.units.u) T = rag.T_max;                                // the score block is laid out for the longest utterance of the batch
     int pits = (T + 3) / 4;                                        // floats per score-plane row, padded so that pits/4 is odd
     pits = (pits + 3) & ~3;
     if (((pits / 4) & 1) == 0) pits += 4;
     const int n_rb = (T + RB - 1) / RB, n_bh = B * n_heads;
     dim3 grid(((n_bh + 7) / 8) * 8 * n_rb);                        // 8 XCD lanes x ceil(n_bh/8) pairs x n_rb row blocks
+    if (rag.units.u) grid = dim3((unsigned)(((n_heads + 7) / 8) * 8 * (int64_t)rag.units.count));
     if (scratch) {
         {
             const size_t lds = (size_t)VCH * (HD + 16) * sizeof(float);
             hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, true>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits,
-                               n_rb, n_bh, scratch, ctx_bf16);
+                               n_rb, n_bh, scratch, ctx_bf16, pos_row0, rag);
         }
         return;
     }
@@ -312,7 +326,7 @@ static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const
     static DynLdsSlots slots;
     ensure_dyn_lds(slots, reinterpret_cast<const void *>(&relpos_attention_kernel<HD, VCH, false>), lds);
     hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, false>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits, n_rb, n_bh,
-                       (float *)nullptr, ctx_bf16);
+                       (float *)nullptr, ctx_bf16, pos_row0, rag);
 }
 
 // LDS bytes one workgroup needs for T frames: the [32][T] score block (four k-planes) + one V chunk.  0: unsupported head size.
@@ -334,6 +348,13 @@ size_t relpos_attention_scratch_bytes(int B, int T, int n_heads, int hd) {
     const size_t n_rb = (T + RB - 1) / RB, n_bh = (size_t)B * n_heads;
     return ((n_bh + 7) / 8) * 8 * n_rb * 4 * (size_t)(RB * pits + 8) * sizeof(float);
 }
+size_t relpos_attention_scratch_bytes_units(int64_t n_units, int T_max, int n_heads, int hd) {
+    if (hd != 32 && hd != 64 && hd != 96 && hd != 128) return 0;
+    int pits = (T_max + 3) / 4;
+    pits = (pits + 3) & ~3;
+    if (((pits / 4) & 1) == 0) pits += 4;
+    return (size_t)((n_heads + 7) / 8) * 8 * (size_t)n_units * 4 * (size_t)(RB * pits + 8) * sizeof(float);
+}
 int relpos_attention_max_frames(int hd) {
     int T = 0;
     while (relpos_attention_lds_bytes(T + 8, hd) && relpos_attention_lds_bytes(T + 8, hd) <= 160 * 1024) T += 8;
@@ -341,13 +362,13 @@ int relpos_attention_max_frames(int hd) {
 }
 
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
-                             const float *bias_v, float *ctx, hipStream_t s, float scale, float *scratch, int ctx_bf16) {
+                             const float *bias_v, float *ctx, hipStream_t s, float scale, float *scratch, int ctx_bf16, int pos_row0, const SeqRag &rag) {
     const int hd = d / n_heads;
     // V chunk rows: 64 keeps the footprint at ~39 KB for 10 s clips (4 workgroups per CU at hd = 64)
-    if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16);
-    else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16);
-    else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16);
-    else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16);
+    if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
+    else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
+    else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
+    else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
 }
 
 }  // namespace pk

@@ -54,7 +54,7 @@ template <int HD>
 __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __bf16 *__restrict__ qkv, int ldq, int d, int T,
                                                                        const __bf16 *__restrict__ pos /*[2T-1][d]*/, const float *__restrict__ cvec /*[H][2T-1]*/,
                                                                        const float *__restrict__ bias_u, float scale_log2e, __bf16 *__restrict__ ctx,
-                                                                       int n_qb, int n_bh, int nkt) {
+                                                                       int n_qb, int n_bh, int nkt, int pos_T, SeqRag rg) {
     constexpr int NK = HD / 16;          // MFMA k-steps of a contraction over the head dimension
     constexpr int NDT = HD / 32;         // 32-wide dv tiles of ctx^T
     constexpr int VCH = HD / 8;          // 16-byte chunks per V row
@@ -66,21 +66,34 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
     float *cb = skew + 4 * 64 * AB_SKP;                                          // [32 nkt + 128]  c band of this workgroup
     __builtin_amdgcn_s_setprio(3);
 
-    const int H = d / HD, P = 2 * T - 1;
-    int bh, qb;
-    {   // the query blocks of one (utterance, head) take consecutive slots of ONE XCD (block id % 8 = XCD): K, V and the P band stay in its L2
+    const int H = d / HD;
+    int h, qb;
+    int64_t row0;                                                   // first row of this utterance in the (packed) row axis of qkv / ctx
+    if (rg.units.u) {   // ragged batch (kernels.hpp: SeqRag; attention.hip has the same mapping): this utterance's own length
+        const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
+        h = (k / rg.units.count) * 8 + xcd;
+        if (h >= H) return;
+        const RagUnit un = rg.units.u[k % rg.units.count];
+        qb = un.r0 / AB_QB;
+        T = rg.T[un.b];
+        row0 = rg.T_off[un.b];
+        nkt = (T + 31) / 32;
+    } else {   // the query blocks of one (utterance, head) take consecutive slots of ONE XCD (block id % 8 = XCD): K, V and the P band stay in its L2
         const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
         qb = k % n_qb;
-        bh = (k / n_qb) * 8 + xcd;
+        const int bh = (k / n_qb) * 8 + xcd;
         if (bh >= n_bh) return;
+        h = bh % H;
+        row0 = (int64_t)(bh / H) * T;
     }
-    const int b = bh / H, h = bh % H;
+    // the table / c vector were built for pos_T >= T frames: row p of a T-frame table is row p + (pos_T - T) of it (engine.cpp: ensure_pos_tables)
+    const int P = 2 * T - 1, pshift = pos_T - T, Ptab = 2 * pos_T - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, g = lane >> 5;
     const int i0w = qb * AB_QB + 32 * wave;                         // first query row of this wave
     const bool active = i0w < T;                                    // wave-uniform
-    const __bf16 *qrow = qkv + (int64_t)b * T * ldq + h * HD;        // q of (b, h); k at + d, v at + 2 d
-    const __bf16 *prow = pos + h * HD;
+    const __bf16 *qrow = qkv + row0 * ldq + h * HD;                 // q of (b, h); k at + d, v at + 2 d
+    const __bf16 *prow = pos + (int64_t)pshift * d + h * HD;
     float *sk = skew + wave * 64 * AB_SKP;
     const int base0 = T - 32 - i0w;                                 // p of band row 0 of block 0 for this wave
     const int cb_len = 32 * nkt + 128;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
     for (int i = tid; i < cb_len; i += 256) {                       // c band: p = (T - 128 - 128 qb) + i
         int p = T - AB_QB - qb * AB_QB + i;
         p = p < 0 ? 0 : (p > P - 1 ? P - 1 : p);
-        cb[i] = cvec[h * P + p];
+        cb[i] = cvec[(int64_t)h * Ptab + pshift + p];
     }
     // V tile staging (workgroup-cooperative): chunk c = tid + 256 i -> key c / VCH, 8 dv at 8 (c % VCH)
     float4 vreg[NV];
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
     const float inv = __builtin_amdgcn_rcpf(l_run);
     const int i = i0w + n;
     if (i < T) {
-        __bf16 *orow = ctx + ((int64_t)b * T + i) * d + h * HD + 4 * g;
+        __bf16 *orow = ctx + (row0 + i) * d + h * HD + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -278,7 +291,9 @@ size_t relpos_attention_bf16_lds_bytes(int T, int hd) {
 
 template <int HD>
 static void launch_att_bf16(const void *qkv, int B, int T, int d, int n_heads, const void *pos, const float *cvec, const float *bias_u, void *ctx,
-                            hipStream_t s) {
+                            hipStream_t s, int pos_T, const SeqRag &rag) {
+    if (rag.units.u) { T = rag.T_max; pos_T = rag.pos_T; }         // LDS (the c band) sized for the longest utterance
+    if (pos_T <= 0) pos_T = T;
     const int n_qb = (T + AB_QB - 1) / AB_QB, n_bh = B * n_heads, nkt = (T + 31) / 32;
     const float scale_log2e = (1.0f / sqrtf((float)HD)) * 1.44269504088896340736f;
     const size_t lds = relpos_attention_bf16_lds_bytes(T, HD);
@@ -286,15 +301,17 @@ static void launch_att_bf16(const void *qkv, int B, int T, int d, int n_heads, c
     static DynLdsSlots slots;
     ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
     dim3 grid(((n_bh + 7) / 8) * 8 * n_qb);
+    if (rag.units.u) grid = dim3((unsigned)(((n_heads + 7) / 8) * 8 * (int64_t)rag.units.count));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, static_cast<const __bf16 *>(qkv), 3 * d, d, T, static_cast<const __bf16 *>(pos), cvec, bias_u,
-                       scale_log2e, static_cast<__bf16 *>(ctx), n_qb, n_bh, nkt);
+                       scale_log2e, static_cast<__bf16 *>(ctx), n_qb, n_bh, nkt, pos_T, rag);
 }
+int relpos_attention_bf16_block_rows(int) { return AB_QB; }
 
 void launch_relpos_attention_bf16(const void *qkv_bf16, int B, int T, int d, int n_heads, const void *pos_bf16, const float *cvec, const float *bias_u,
-                                  void *ctx_bf16, hipStream_t s) {
+                                  void *ctx_bf16, hipStream_t s, int pos_T, const SeqRag &rag) {
     const int hd = d / n_heads;
-    if (hd == 128) launch_att_bf16<128>(qkv_bf16, B, T, d, n_heads, pos_bf16, cvec, bias_u, ctx_bf16, s);
-    else if (hd == 64) launch_att_bf16<64>(qkv_bf16, B, T, d, n_heads, pos_bf16, cvec, bias_u, ctx_bf16, s);
+    if (hd == 128) launch_att_bf16<128>(qkv_bf16, B, T, d, n_heads, pos_bf16, cvec, bias_u, ctx_bf16, s, pos_T, rag);
+    else if (hd == 64) launch_att_bf16<64>(qkv_bf16, B, T, d, n_heads, pos_bf16, cvec, bias_u, ctx_bf16, s, pos_T, rag);
 }
 
 }  // namespace pk

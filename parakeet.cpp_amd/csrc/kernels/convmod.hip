@@ -17,23 +17,31 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
                                                              const float *__restrict__ w /*[KC][d]*/, const float *__restrict__ bias,
                                                              const float *__restrict__ bn_mean, const float *__restrict__ bn_rstd,
                                                              const float *__restrict__ bn_g, const float *__restrict__ bn_b,
-                                                             int64_t n_items, float *__restrict__ out, int out_bf16) {
+                                                             int64_t n_items, float *__restrict__ out, int out_bf16, SeqRag rg) {
     constexpr int HALF = (KC - 1) / 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_items) return;
     const int d4 = d >> 2;
     const int c4 = (int)(idx % d4);
-    const int strip = (int)((idx / d4) % n_strips);
-    const int b = (int)(idx / ((int64_t)d4 * n_strips));
-    const int t0 = strip * TT;
-    const float4 *gp = reinterpret_cast<const float4 *>(g + (int64_t)b * T * d) + c4;       // row t at gp[t * d4]
-    float4 *op = reinterpret_cast<float4 *>(out + (int64_t)b * T * d) + c4;
+    int t0;
+    int64_t row0;                                                       // first row of this utterance in the (packed) row axis
+    if (rg.units.u) {                                                   // ragged batch (kernels.hpp: SeqRag): strips of TT frames of ONE utterance,
+        const RagUnit un = rg.units.u[idx / d4];                        // zero padding at ITS first and last frame
+        t0 = un.r0;
+        T = rg.T[un.b];
+        row0 = rg.T_off[un.b];
+    } else {
+        t0 = (int)((idx / d4) % n_strips) * TT;
+        row0 = (idx / ((int64_t)d4 * n_strips)) * T;
+    }
+    const float4 *gp = reinterpret_cast<const float4 *>(g + row0 * d) + c4;       // row t at gp[t * d4]
+    float4 *op = reinterpret_cast<float4 *>(out + row0 * d) + c4;
     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-    bf16x4_ *oph = reinterpret_cast<bf16x4_ *>(reinterpret_cast<__bf16 *>(out) + (int64_t)b * T * d) + c4;   // bf16 mode: the pw2 GEMM's operand (RNE)
+    bf16x4_ *oph = reinterpret_cast<bf16x4_ *>(reinterpret_cast<__bf16 *>(out) + row0 * d) + c4;   // bf16 mode: the pw2 GEMM's operand (RNE)
     auto put = [&](int t, const float4 &v) {
         if (out_bf16 == 1) oph[(int64_t)t * d4] = bf16x4_{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
         else if (out_bf16 == 2) {                                       // fp32, sigma K layout (GemmArgs::a_sigma): channel 16 b + 4 q + j -> 16 b + 4 j + q
-            float *o = out + ((int64_t)b * T + t) * d + ((4 * c4) & ~15) + (c4 & 3);
+            float *o = out + (row0 + t) * d + ((4 * c4) & ~15) + (c4 & 3);
             o[0] = v.x; o[4] = v.y; o[8] = v.z; o[12] = v.w;
         } else op[(int64_t)t * d4] = v;
     };
@@ -103,20 +111,22 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
 
 template <int TT>
 static void launch_dwconv_tt(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
-                             const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16) {
+                             const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16, const SeqRag &rag) {
     const int n_strips = (T + TT - 1) / TT;
-    const int64_t n_items = (int64_t)B * n_strips * (d / 4);          // d % 4 == 0 (hidden sizes are multiples of 32)
+    const int64_t n_items = (rag.units.u ? (int64_t)rag.units.count : (int64_t)B * n_strips) * (d / 4);          // d % 4 == 0 (hidden sizes are multiples of 32)
     const dim3 grid((unsigned)((n_items + 255) / 256));
-    if (kc == 9) hipLaunchKernelGGL((dwconv_bn_silu_kernel<9, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out, out_bf16);
-    else if (kc == 31) hipLaunchKernelGGL((dwconv_bn_silu_kernel<31, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out, out_bf16);
+    if (kc == 9) hipLaunchKernelGGL((dwconv_bn_silu_kernel<9, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out, out_bf16, rag);
+    else if (kc == 31) hipLaunchKernelGGL((dwconv_bn_silu_kernel<31, TT>), grid, dim3(256), 0, s, g, T, d, n_strips, w, bias, bn_mean, bn_rstd, bn_g, bn_b, n_items, out, out_bf16, rag);
 }
 
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
-                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16) {
+                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16, const SeqRag &rag) {
     // strips of 8 frames per thread amortise the window loads on large batches; a single utterance (the latency-bound small-batch route) has
     // only a handful of workgroups that way -- strips of 2 frames: four times the threads, a quarter of the serial work each
-    if ((int64_t)B * T <= 2048) launch_dwconv_tt<2>(g, B, T, d, kc, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, s, out_bf16);
-    else launch_dwconv_tt<8>(g, B, T, d, kc, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, s, out_bf16);
+    // (ragged batch: B * T = the total number of packed rows, and rag.units holds strips of dwconv_strip_frames(that total) frames)
+    if (dwconv_strip_frames((int64_t)B * T) == 2) launch_dwconv_tt<2>(g, B, T, d, kc, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, s, out_bf16, rag);
+    else launch_dwconv_tt<8>(g, B, T, d, kc, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, s, out_bf16, rag);
 }
+int dwconv_strip_frames(int64_t total_rows) { return total_rows <= 2048 ? 2 : 8; }
 
 }  // namespace pk

@@ -34,40 +34,48 @@ void launch_logsoftmax_argmax(const float *logits, int64_t rows, int ld, int n, 
 // ctc_greedy_decode(_with_timestamps): src/ctc.cpp:52-72 and :93-123, literally.
 __global__ void ctc_collapse_kernel(const int *__restrict__ best_idx, const float *__restrict__ best_lp, int B, int T, int blank,
                                     int *__restrict__ ids, int *__restrict__ lens, int *__restrict__ start, int *__restrict__ end,
-                                    float *__restrict__ conf) {
+                                    float *__restrict__ conf, int pitch, SeqRag rg) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    int64_t in0 = (int64_t)b * T;                                   // first frame of this utterance in the (packed) frame axis
+    if (rg.T) { in0 = rg.T_off[b]; T = rg.T[b]; }                   // ragged batch: its own frame count
+    const int64_t o0 = (int64_t)b * pitch;
     int prev = -1, n = 0;
     for (int t = 0; t < T; ++t) {
-        const int best = best_idx[(int64_t)b * T + t];
+        const int best = best_idx[in0 + t];
         if (best != prev) {
-            if (prev != -1 && prev != blank && n > 0) end[(int64_t)b * T + n - 1] = t - 1;
+            if (prev != -1 && prev != blank && n > 0) end[o0 + n - 1] = t - 1;
             if (best != blank) {
-                ids[(int64_t)b * T + n] = best;
-                start[(int64_t)b * T + n] = t;
-                end[(int64_t)b * T + n] = t;
-                conf[(int64_t)b * T + n] = dexpf(best_lp[(int64_t)b * T + t]);
+                ids[o0 + n] = best;
+                start[o0 + n] = t;
+                end[o0 + n] = t;
+                conf[o0 + n] = dexpf(best_lp[in0 + t]);
                 ++n;
             }
         }
         prev = best;
     }
-    if (n > 0) end[(int64_t)b * T + n - 1] = T - 1;
+    if (n > 0) end[o0 + n - 1] = T - 1;
     lens[b] = n;
 }
 void launch_ctc_collapse(const int *best_idx, const float *best_lp, int B, int T, int blank, int *ids, int *lens, int *start, int *end,
-                         float *conf, hipStream_t s) {
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, s, best_idx, best_lp, B, T, blank, ids, lens, start, end, conf);
+                         float *conf, hipStream_t s, int pitch, const SeqRag &rag) {
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, s, best_idx, best_lp, B, T, blank, ids, lens, start, end, conf,
+                       pitch > 0 ? pitch : T, rag);
 }
+
 
 // ctc_greedy_decode(_with_timestamps)_boosted (src/phrase_boost.cpp:70-171): the boosted argmax of frame t depends on the tokens
 // emitted before t (the trie's active states), so the frames of one utterance are walked in order by one 256-thread workgroup;
 // the utterances of the batch run side by side.  Outputs as ctc_collapse_kernel; confidence = exp(unboosted log-prob) (:151-152).
 __global__ __launch_bounds__(256) void ctc_boosted_kernel(const float *__restrict__ logp, int B, int T, int V, int blank, TrieDev trie,
                                                           int *__restrict__ ids, int *__restrict__ lens, int *__restrict__ start,
-                                                          int *__restrict__ end, float *__restrict__ conf) {
+                                                          int *__restrict__ end, float *__restrict__ conf, int pitch, SeqRag rg) {
     extern __shared__ __attribute__((aligned(16))) unsigned cb_sm[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t in0 = (int64_t)b * T;                                   // first frame of this utterance in the (packed) frame axis
+    if (rg.T) { in0 = rg.T_off[b]; T = rg.T[b]; }                   // ragged batch
+    const int64_t o0 = (int64_t)b * pitch;
     const int MW = (V + 31) >> 5;
     unsigned *mask = cb_sm;                                         // [MW]
     int *acts = reinterpret_cast<int *>(mask + MW);                 // [2][1 + kTrieMaxActive] (count first), double-buffered
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(256) void ctc_boosted_kernel(const float *__restric
     rebuild(acts);
     int prev = -1, n = 0;
     for (int t = 0; t < T; ++t) {
-        const float *frame = logp + ((int64_t)b * T + t) * V;
+        const float *frame = logp + (in0 + t) * V;
         float best = -__builtin_huge_valf();
         int bi = 0x7fffffff;
         for (int i = tid; i < V; i += 256) {
@@ -116,13 +124,13 @@ __global__ __launch_bounds__(256) void ctc_boosted_kernel(const float *__restric
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
         if (bi != prev) {                                            // block-uniform control flow
-            if (tid == 0 && prev != -1 && prev != blank && n > 0) end[(int64_t)b * T + n - 1] = t - 1;
+            if (tid == 0 && prev != -1 && prev != blank && n > 0) end[o0 + n - 1] = t - 1;
             if (bi != blank) {
                 if (tid == 0) {
-                    ids[(int64_t)b * T + n] = bi;
-                    start[(int64_t)b * T + n] = t;
-                    end[(int64_t)b * T + n] = t;
-                    conf[(int64_t)b * T + n] = dexpf(frame[bi]);
+                    ids[o0 + n] = bi;
+                    start[o0 + n] = t;
+                    end[o0 + n] = t;
+                    conf[o0 + n] = dexpf(frame[bi]);
                 }
                 ++n;
                 int *src = acts + cur * (1 + kTrieMaxActive), *dst = acts + (cur ^ 1) * (1 + kTrieMaxActive);
@@ -147,14 +155,15 @@ __global__ __launch_bounds__(256) void ctc_boosted_kernel(const float *__restric
         prev = bi;
     }
     if (tid == 0) {
-        if (n > 0) end[(int64_t)b * T + n - 1] = T - 1;
+        if (n > 0) end[o0 + n - 1] = T - 1;
         lens[b] = n;
     }
 }
 void launch_ctc_boosted(const float *logp, int B, int T, int V, int blank, const TrieDev &trie, int *ids, int *lens, int *start, int *end,
-                        float *conf, hipStream_t s) {
+                        float *conf, hipStream_t s, int pitch, const SeqRag &rag) {
     const size_t lds = (size_t)((V + 31) / 32 + 2 * (1 + kTrieMaxActive) + 16) * sizeof(int);
-    hipLaunchKernelGGL(ctc_boosted_kernel, dim3(B), dim3(256), lds, s, logp, B, T, V, blank, trie, ids, lens, start, end, conf);
+    hipLaunchKernelGGL(ctc_boosted_kernel, dim3(B), dim3(256), lds, s, logp, B, T, V, blank, trie, ids, lens, start, end, conf,
+                       pitch > 0 ? pitch : T, rag);
 }
 
 // ---- TDT / RNNT step kernels --------------------------------------------------------------------------
@@ -241,6 +250,18 @@ __global__ void tdt_init_kernel(TdtState st) {
         st.trie.act[(int64_t)b * kTrieMaxActive] = 0;
     }
 }
+// decode tables of n utterances appended to a decode group (capi.cpp): frames and first enc_proj row of each (TdtState::Tb / row0)
+__global__ void rag_decode_tables_kernel(const int *__restrict__ T, const int *__restrict__ T_off, int T_uniform, int n, int row_base,
+                                         int *__restrict__ Tb_out, int *__restrict__ row0_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Tb_out[i] = T ? T[i] : T_uniform;
+    row0_out[i] = row_base + (T ? T_off[i] : i * T_uniform);
+}
+void launch_rag_decode_tables(const int *T, const int *T_off, int T_uniform, int n, int row_base, int *Tb_out, int *row0_out, hipStream_t s) {
+    hipLaunchKernelGGL(rag_decode_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, s, T, T_off, T_uniform, n, row_base, Tb_out, row0_out);
+}
+
 void launch_tdt_init(const TdtState &st, hipStream_t s) { hipLaunchKernelGGL(tdt_init_kernel, dim3((st.B + 63) / 64), dim3(64), 0, s, st); }
 
 }  // namespace pk

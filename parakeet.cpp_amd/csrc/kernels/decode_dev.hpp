@@ -137,8 +137,10 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
                     const int b = rb_out[r];
                     if (m0 + 4 * kq + r < NB) {
                         int tt = dd_ldi<COH>(a.t + b);
-                        tt = tt < a.T ? tt : a.T - 1;
-                        e_ep[r] = a.ep[((int64_t)b * a.T + tt) * a.N + n];
+                        const int Tb = a.Tb ? a.Tb[b] : a.T;                                   // ragged batch: this utterance's frames / first enc_proj row
+                        const int64_t r0 = a.row0 ? (int64_t)a.row0[b] : (int64_t)b * a.T;
+                        tt = tt < Tb ? tt : Tb - 1;
+                        e_ep[r] = a.ep[(r0 + tt) * a.N + n];
                     }
                 }
             }
@@ -297,6 +299,10 @@ template <bool BOOST, bool COH>
 __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (dd_ldi<COH>(st.done + b)) return;
+    // ragged batch (TdtState::Tb / row0): this utterance's frame count, first enc_proj row and its own cap on joint evaluations
+    const int Tb = st.Tb ? st.Tb[b] : st.T;
+    const int64_t ep_row0 = st.row0 ? (int64_t)st.row0[b] : (int64_t)b * st.T;
+    const int max_steps_b = (st.Tb && st.max_steps > 0) ? Tb * (st.max_symbols + 1) + 16 : st.max_steps;
     const int VD = st.V + st.D;
     float *x = sm, *e = sm + VD;
     float *red = e + VD;                                           // [0..3] wave maxima, [4] lse, [8..11] best val, [12..15] best idx
@@ -489,7 +495,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
                 st.ids[o] = lab.idx;
                 st.start[o] = t;
                 int e = st.D > 0 ? t + (skip > 1 ? skip : 1) - 1 : t;     // src/tdt.cpp:184-187 ; rnnt.cpp:170 (end = t)
-                st.end[o] = (st.keep_state || e < st.T) ? e : st.T - 1;
+                st.end[o] = (st.keep_state || e < Tb) ? e : Tb - 1;
                 st.conf[o] = dexpf(lab.lp);                                 // confidence = exp(max log-prob) :169
             }
             dd_sti<COH>(st.token + b, lab.idx);
@@ -540,10 +546,10 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         // prediction-net caching (TdtState::need): a token changed (token, h, c) -> the next step runs the cells and pred_proj again; a blank
         // changed only the frame -> this workgroup forms next step's z = relu(enc_proj[t'] + pp) from the cached pp (SK_ACT's epilogue, same
         // operand order: enc_proj + (pred_proj [+ bias]))
-        const bool fin = t >= st.T || (st.max_steps > 0 && nsteps >= st.max_steps);
+        const bool fin = t >= Tb || (max_steps_b > 0 && nsteps >= max_steps_b);
         if (tid == 0) dd_sti<COH>(st.need + b, (commit && !fin) ? 1 : 0);
         if (!commit && !fin) {
-            const float *epr = st.ep + ((int64_t)b * st.T + t) * st.J, *ppr = st.pp + (int64_t)b * st.J;
+            const float *epr = st.ep + (ep_row0 + t) * st.J, *ppr = st.pp + (int64_t)b * st.J;
             for (int n = tid; n < st.J; n += 256) {
                 const float sv = epr[n] + ppr[n];
                 const float zv = sv > 0.0f ? sv : 0.0f;
@@ -553,9 +559,9 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         }
     }
     if (lane0 == 0) {
-        bool finished = t >= st.T;
+        bool finished = t >= Tb;
         int len = n_out < st.max_tokens ? n_out : st.max_tokens;
-        if (!finished && st.max_steps > 0 && nsteps >= st.max_steps) { finished = true; len = -1; }   // safety cap
+        if (!finished && max_steps_b > 0 && nsteps >= max_steps_b) { finished = true; len = -1; }   // safety cap
         dd_sti<COH>(st.t + b, t);
         dd_sti<COH>(st.steps + b, nsteps);
         dd_sti<COH>(st.n_out + b, n_out);

@@ -75,8 +75,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
                     const int b = rb_out[r];
                     if (m0 + 4 * kq + r < NB) {
                         int tt = a.t[b];
-                        tt = tt < a.T ? tt : a.T - 1;
-                        e_ep[r] = a.ep[((int64_t)b * a.T + tt) * a.N + n];
+                        const int Tb = a.Tb ? a.Tb[b] : a.T;                                   // ragged batch (SkinnyArgs::Tb / row0)
+                        const int64_t r0 = a.row0 ? (int64_t)a.row0[b] : (int64_t)b * a.T;
+                        tt = tt < Tb ? tt : Tb - 1;
+                        e_ep[r] = a.ep[(r0 + tt) * a.N + n];
                     }
                 }
             }

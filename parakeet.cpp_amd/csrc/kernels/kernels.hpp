@@ -15,12 +15,37 @@ struct DynLdsSlots { std::atomic<size_t> set[kMaxDevices]; };
 inline void ensure_dyn_lds(DynLdsSlots &slots, const void *kernel, size_t bytes) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::atomic<size_t> &cur = slots.set[dev >= 0 && dev < kMaxDevices ? dev : 0];
-    if (bytes > cur.load(std::memory_order_acquire) || dev >= kMaxDevices) {
+    if (dev < 0 || dev >= kMaxDevices) {          // no slot for this device: set the attribute every time, never alias another device's slot
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        return;
+    }
+    std::atomic<size_t> &cur = slots.set[dev];
+    if (bytes > cur.load(std::memory_order_acquire)) {
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         cur.store(bytes, std::memory_order_release);
     }
 }
+
+// ---- ragged (mixed-length, packed) batches -------------------------------------------------------------------------------------
+// The reference's roadmap "batch inference: pad + length-mask" (README.md:513) done WITHOUT padding: utterance b of a packed tensor owns
+// rows [off[b], off[b] + n[b]) -- GEMMs, LayerNorm and their epilogues are row-wise and never notice; kernels that look across rows (mel
+// framing, the 3x3 / depthwise convolutions, attention, the greedy decoders) take the per-utterance extents below, so every utterance sees
+// exactly the zero padding, position table and softmax extent of a single-clip run: bit-identical per clip.  A null pointer in the first
+// member = uniform batch (the launchers' plain B / T arguments apply).
+struct RagUnit { int b, r0; };                 // one strip of rows of ONE utterance: utterance b, first local row r0
+struct RagUnits { const RagUnit *u = nullptr; int count = 0; };
+struct MelRag { const int64_t *pcm_off = nullptr; const int *Tm = nullptr, *Tm_off = nullptr; int max_frames = 0; };   // [B+1] samples, [B] mel frames, [B+1]
+struct SubRag {                                 // conv subsampling: mel frames -> H2 = rows after conv1 / dw1 -> T rows after dw2
+    RagUnits strips;                            // conv1_dw1: strips of strip_rows rows of H2 ; dw2: one unit per output row
+    int strip_rows = 0;
+    const int *Tm = nullptr, *Tm_off = nullptr, *H2 = nullptr, *H2_off = nullptr, *T = nullptr, *T_off = nullptr;
+};
+struct SeqRag {                                 // encoder frames: attention row blocks (32 rows) / depthwise-conv strips / decoders
+    RagUnits units;
+    const int *T = nullptr, *T_off = nullptr;  // [B], [B+1]
+    int T_max = 0;                              // longest utterance of the batch (LDS sizing)
+    int pos_T = 0;                              // the position table was built for pos_T >= T_max frames: utterance b reads it from row pos_T - T[b]
+};
 
 // ---- mel front end (src/audio.cpp:100-158) ----------------------------------------------------
 constexpr int kMelMaxTaps = 1024;     // packed filterbank taps staged in LDS by the mel kernel (sum of the band widths; 80 / 128 bins: ~590)
@@ -38,11 +63,12 @@ struct MelTables {
     int n_mels;
     int power_via_abs;     // switch A2
 };
-void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s);
+// rag set: clip b = pcm[rag.pcm_off[b] .. rag.pcm_off[b+1]), its log-mel [n_mels][rag.Tm[b]] at logmel + n_mels * rag.Tm_off[b] (n_samples / n_frames ignored)
+void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s, const MelRag &rag = MelRag());
 // StreamingAudioPreprocessor::process_chunk (src/audio.cpp:222-252) on pre-emphasised buffers pre[B][n_samples]:
 // n_frames = (n_samples - 400) / 160 + 1 frames -> log-mel [B][n_frames][n_mels] (no normalisation)
 void launch_mel_stream(const float *pre, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel_tf, hipStream_t s);
-void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, int normalize, float *feats, hipStream_t s);
+void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, int normalize, float *feats, hipStream_t s, const MelRag &rag = MelRag());
 
 // ---- fp32 MFMA GEMM: out = epi(A[M][K] * W[N][K]^T + bias), natural-k fma chains ----------------
 enum GemmEpi { EPI_NONE = 0, EPI_RELU = 1, EPI_SILU = 2, EPI_RESID = 3, EPI_GLU = 4 };
@@ -87,9 +113,12 @@ void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s);
 double gemm_flops(const GemmArgs &a, int epi);
 
 // ---- conv subsampling (src/encoder.cpp:219-241), channels-last ---------------------------------------
+// rag set (strips = units of sub_conv1_dw1_strip_rows(...) rows of H2): packed feats [sum Tm][F] -> out [sum H2][W2][C]; B / Tm ignored
+int sub_conv1_dw1_strip_rows(int64_t total_h2_rows);       // output rows per strip the launcher will use for a batch with that many H2 rows
 void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
-                          const float *bd, float *out, hipStream_t s);
-void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, float *out, hipStream_t s);
+                          const float *bd, float *out, hipStream_t s, const SubRag &rag = SubRag());
+// rag set (strips = one unit per output row): packed in [sum H2][W][C] -> out [sum T][Wo][C]; B / H ignored
+void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, float *out, hipStream_t s, const SubRag &rag = SubRag());
 
 // ---- conformer pieces ---------------------------------------------------------------------------------
 // qkv[B*T][3d]: q and k thirds in the sigma column layout.  pos == nullptr: plain multi-head attention (src/transformer.cpp:38),
@@ -97,17 +126,27 @@ void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd,
 size_t relpos_attention_lds_bytes(int T, int hd);     // 0: unsupported head size
 int relpos_attention_max_frames(int hd);              // longest sequence one workgroup's LDS score block can hold
 size_t relpos_attention_scratch_bytes(int B, int T, int n_heads, int hd);   // long sequences: score blocks in global scratch (hd 64 / 128)
+// pos_row0: first row of the table to use (the table may have been built for a longer sequence: row p of a T-frame table is row
+// p + T_table - T of the longer one, engine.cpp ensure_pos_tables).  rag set (units = 32-row blocks): qkv / ctx are packed [sum T] rows,
+// utterance b attends over its own T[b] frames with table rows from rag.pos_T - T[b]; B / T / pos_row0 ignored, LDS sized by rag.T_max.
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
-                             const float *bias_v, float *ctx, hipStream_t s, float scale = 0.0f, float *scratch = nullptr, int ctx_bf16 = 0);
+                             const float *bias_v, float *ctx, hipStream_t s, float scale = 0.0f, float *scratch = nullptr, int ctx_bf16 = 0,
+                             int pos_row0 = 0, const SeqRag &rag = SeqRag());
+size_t relpos_attention_scratch_bytes_units(int64_t n_units, int T_max, int n_heads, int hd);   // ragged form of relpos_attention_scratch_bytes
 // The tolerance-class (pk_config.gemm_bf16) attention, kernels/attention_bf16.hip: q / k / v as bf16 [B*T][3d] (natural columns, written by the
 // qkv GEMM), the projected position table of the layer as bf16 [2T-1][d], cvec[h][p] = (v_h - u_h) . P_p (fp32, launch_pos_cvec), ctx as bf16.
 // Head sizes 64 and 128; relpos_attention_bf16_lds_bytes returns 0 for any other.
 size_t relpos_attention_bf16_lds_bytes(int T, int hd);
 void launch_pos_cvec(const void *pos_bf16, const float *bias_u, const float *bias_v, int P, int d, int n_heads, float *cvec, hipStream_t s);
+// pos_T: sequence length the table / cvec were built for (>= T; 0 = T).  rag set (units = the kernel's query-row blocks,
+// relpos_attention_bf16_block_rows()): packed rows, per-utterance T.
+int relpos_attention_bf16_block_rows(int hd);
 void launch_relpos_attention_bf16(const void *qkv_bf16, int B, int T, int d, int n_heads, const void *pos_bf16, const float *cvec, const float *bias_u,
-                                  void *ctx_bf16, hipStream_t s);
+                                  void *ctx_bf16, hipStream_t s, int pos_T = 0, const SeqRag &rag = SeqRag());
 void launch_dwconv_bn_silu(const float *g, int B, int T, int d, int kc, const float *w, const float *bias, const float *bn_mean,
-                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16 = 0);
+                           const float *bn_rstd, const float *bn_g, const float *bn_b, float *out, hipStream_t s, int out_bf16 = 0,
+                           const SeqRag &rag = SeqRag());
+int dwconv_strip_frames(int64_t total_rows);   // frames per strip launch_dwconv_bn_silu uses for a batch of that many rows (rag.units granularity)
 
 // ---- streaming encoder pieces (src/streaming_encoder.cpp) -----------------------------------------------------------------------
 // StreamingConformerAttention::forward_cached (:162-272) core for S streams x c query rows: keys / values = nc cached rows
@@ -130,8 +169,9 @@ void launch_stream_dwconv(const float *g, const float *cache_in, int has_cache, 
 
 // ---- decoders -------------------------------------------------------------------------------------------
 void launch_logsoftmax_argmax(const float *logits, int64_t rows, int ld, int n, float *lp_out, int *best_idx, float *best_lp, hipStream_t s);
+// outputs [B][pitch] (pitch 0 = T).  rag set: best_idx / best_lp are packed [sum T], utterance b has rag.T[b] frames from row rag.T_off[b].
 void launch_ctc_collapse(const int *best_idx, const float *best_lp, int B, int T, int blank, int *ids, int *lens, int *start, int *end,
-                         float *conf, hipStream_t s);
+                         float *conf, hipStream_t s, int pitch = 0, const SeqRag &rag = SeqRag());
 // ContextTrie of the phrase boosting (reference src/phrase_boost.cpp:9-66) in CSR form: the children of node i are the entries
 // [off[i], off[i+1]) of (tok, node).  Every utterance carries its active-state set (the root plus at most one node per trie
 // depth, so <= kTrieMaxActive for phrases of < kTrieMaxActive tokens).  off == nullptr: boosting is off.
@@ -143,7 +183,7 @@ struct TrieDev {
     int *act, *n_act;               // [B][kTrieMaxActive], [B]
 };
 void launch_ctc_boosted(const float *logp, int B, int T, int V, int blank, const TrieDev &trie, int *ids, int *lens, int *start, int *end,
-                        float *conf, hipStream_t s);
+                        float *conf, hipStream_t s, int pitch = 0, const SeqRag &rag = SeqRag());
 struct TdtState {
     int B, T, V, D, L, Hp, blank, max_symbols, max_tokens, max_steps;
     TrieDev trie;
@@ -168,9 +208,15 @@ struct TdtState {
     const float *ep = nullptr;      // enc_proj [B][T][J]
     float *z = nullptr;             // joint activation [B][J]: fp32 sigma layout, or bf16 natural when h_bf16
     int J = 0;
+    // ragged batches: utterance b has Tb[b] frames, its enc_proj rows start at row0[b] (null: T frames from row b * T); the safety cap on joint
+    // evaluations is then per utterance, Tb[b] * (max_symbols + 1) + 16 -- what a single-clip run of that utterance would use
+    const int *Tb = nullptr, *row0 = nullptr;
 };
 constexpr int kMaxListRows = 2048;  // largest lock-step batch the compacted launches handle (larger batches run every row)
 void launch_tdt_init(const TdtState &st, hipStream_t s);
+// Tb_out[i] / row0_out[i], i < n: frames and first enc_proj row (row_base + its offset) of the utterances of one run; T == nullptr: a uniform
+// run of T_uniform frames each
+void launch_rag_decode_tables(const int *T, const int *T_off, int T_uniform, int n, int row_base, int *Tb_out, int *row0_out, hipStream_t s);
 void launch_lstm_cell(const float *gi, int gi_ld, const int *gi_row, const float *gh, const float *c, int B, int Hp, float *hn,
                       float *cn, hipStream_t s);
 void launch_joint_act(const float *ep, const int *t, int T, int J, const float *pp, const float *bp, int B, float *z, hipStream_t s);
@@ -195,6 +241,7 @@ struct SkinnyArgs {
     // (B <= kMaxListRows); SK_ACT also stores pred_proj(h') [+ bias] to pp_out [B][N]
     const int *need = nullptr;
     float *pp_out = nullptr;
+    const int *Tb = nullptr, *row0 = nullptr;   // SK_ACT on a ragged batch (TdtState::Tb / row0)
 };
 void launch_skinny_gemm(const SkinnyArgs &a, int epi, hipStream_t s);
 // the same products in the tolerance-class mode: X / W / X2 / W2 point to bf16 data in NATURAL k order, the SK_ACT / SK_CELL outputs (z, h') are

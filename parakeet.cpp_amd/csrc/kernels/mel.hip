@@ -36,7 +36,7 @@ static constexpr int kOfflineIters = 1;
 #define PK_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <bool STREAM>
 __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict__ pcm, int64_t n_samples, int n_frames,
-                                                         MelTables tb, float *__restrict__ logmel) {
+                                                         MelTables tb, float *__restrict__ logmel, MelRag rg) {
     // FFT arrays with one pad word per 32 (element i at i + (i >> 5)): the butterfly strides 2^lh of the in-place radix-2 stages would
     // otherwise put two to eight lanes on one LDS bank
     __shared__ float s_re[kFramesPerBlock][kNfft + kNfft / 32];
@@ -53,6 +53,19 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
     constexpr int ITERS = STREAM ? 1 : kOfflineIters;
     constexpr int FPB = kFramesPerBlock * ITERS;
     __shared__ float s_out[STREAM ? 1 : 128][STREAM ? 1 : FPB + 1];
+    const int b = blockIdx.y;
+    const float *x = pcm + (int64_t)b * n_samples;
+    float *lm_clip = logmel + (int64_t)b * tb.n_mels * n_frames;         // (offline layout: this clip's [n_mels][n_frames] block)
+    if constexpr (!STREAM) {
+        if (rg.pcm_off) {                                           // ragged batch: this clip's own extent (kernels.hpp: MelRag)
+            const int64_t o = rg.pcm_off[b];
+            x = pcm + o;
+            n_samples = rg.pcm_off[b + 1] - o;
+            n_frames = rg.Tm[b];
+            lm_clip = logmel + (int64_t)tb.n_mels * rg.Tm_off[b];
+            if ((int)blockIdx.x * FPB >= n_frames) return;          // the grid covers the longest clip (whole workgroup, before any barrier)
+        }
+    }
     for (int i = threadIdx.x; i < kNfft - 1; i += 256) {
         const int lh = 31 - __builtin_clz(i + 1), j = i + 1 - (1 << lh);   // i = 2^lh - 1 + j
         s_twr[i] = tb.tw_re[j << (8 - lh)];
@@ -61,8 +74,6 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
     for (int i = threadIdx.x; i < tb.fb_nnz; i += 256) s_fb[i] = tb.fbc[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    const float *x = pcm + (int64_t)b * n_samples;
     float *re = s_re[wave], *im = s_im[wave], *pw = s_pw[wave];
 #pragma unroll 1
     for (int it = 0; it < ITERS; ++it) {
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
         const int t0 = blockIdx.x * FPB;
         for (int idx = threadIdx.x; idx < tb.n_mels * FPB; idx += 256) {
             const int m = idx / FPB, tt = idx % FPB;
-            if (t0 + tt < n_frames) logmel[((int64_t)b * tb.n_mels + m) * n_frames + t0 + tt] = s_out[m][tt];
+            if (t0 + tt < n_frames) lm_clip[(int64_t)m * n_frames + t0 + tt] = s_out[m][tt];
         }
     }
 }
@@ -160,12 +171,14 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
 // [64 frames][16 bins] LDS tile so that the transposed store writes 64-byte runs (the first version stored 4 bytes per 320-byte
 // stride: 230 MB of write traffic for a 20 MB tensor, profiles/r01_pmc_hbm.json).
 __global__ __launch_bounds__(1024) void mel_normalize_kernel(const float *__restrict__ logmel, int n_mels, int n_frames,
-                                                             int normalize, float *__restrict__ feats) {
+                                                             int normalize, float *__restrict__ feats, MelRag rg) {
     __shared__ float tile[64][17];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = blockIdx.x * 16 + wave, b = blockIdx.y;
     const bool live = m < n_mels;
-    const float *row = logmel + ((int64_t)b * n_mels + (live ? m : 0)) * n_frames;
+    int64_t frame0 = (int64_t)b * n_frames;                        // first frame of this clip in the packed frame axis
+    if (rg.pcm_off) { frame0 = rg.Tm_off[b]; n_frames = rg.Tm[b]; }   // ragged batch: the statistics run over THIS clip's frames
+    const float *row = logmel + frame0 * n_mels + (int64_t)(live ? m : 0) * n_frames;
     float mean = 0.0f, den = 1.0f;
     if (normalize && live) {
         float p = 0.0f;
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(1024) void mel_normalize_kernel(const float *__rest
         den = __builtin_sqrtf(var) + 1e-5f;                       // :149
     }
     const int of = threadIdx.x >> 4, ob = threadIdx.x & 15;        // store role: frame of the tile, bin of the group
-    float *out = feats + (int64_t)b * n_frames * n_mels + blockIdx.x * 16 + ob;
+    float *out = feats + frame0 * n_mels + blockIdx.x * 16 + ob;
     for (int t0 = 0; t0 < n_frames; t0 += 64) {
         const int t = t0 + lane;
         float v = 0.0f;
@@ -192,17 +205,18 @@ __global__ __launch_bounds__(1024) void mel_normalize_kernel(const float *__rest
     }
 }
 
-void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s) {
+void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s, const MelRag &rag) {
     constexpr int fpb = kFramesPerBlock * kOfflineIters;
+    if (rag.pcm_off) n_frames = rag.max_frames;
     dim3 grid((n_frames + fpb - 1) / fpb, B);
-    hipLaunchKernelGGL(mel_logmel_kernel<false>, grid, dim3(256), 0, s, pcm, n_samples, n_frames, t, logmel);
+    hipLaunchKernelGGL(mel_logmel_kernel<false>, grid, dim3(256), 0, s, pcm, n_samples, n_frames, t, logmel, rag);
 }
 void launch_mel_stream(const float *pre, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel_tf, hipStream_t s) {
     dim3 grid((n_frames + kFramesPerBlock - 1) / kFramesPerBlock, B);
-    hipLaunchKernelGGL(mel_logmel_kernel<true>, grid, dim3(256), 0, s, pre, n_samples, n_frames, t, logmel_tf);
+    hipLaunchKernelGGL(mel_logmel_kernel<true>, grid, dim3(256), 0, s, pre, n_samples, n_frames, t, logmel_tf, MelRag());
 }
-void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, int normalize, float *feats, hipStream_t s) {
-    hipLaunchKernelGGL(mel_normalize_kernel, dim3((n_mels + 15) / 16, B), dim3(1024), 0, s, logmel, n_mels, n_frames, normalize, feats);
+void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, int normalize, float *feats, hipStream_t s, const MelRag &rag) {
+    hipLaunchKernelGGL(mel_normalize_kernel, dim3((n_mels + 15) / 16, B), dim3(1024), 0, s, logmel, n_mels, n_frames, normalize, feats, rag);
 }
 
 }  // namespace pk

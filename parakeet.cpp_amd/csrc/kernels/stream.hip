@@ -4,6 +4,7 @@
 // wavefront per (stream, head, query row), exact k-ordered fp32 fma chains on the VALU (bit-identical to the oracle), the
 // canonical max / sum64 butterflies for the softmax.
 #include "../pk_devmath.h"
+#include "../common.hpp"
 #include "kernels.hpp"
 
 namespace pk {
@@ -149,6 +150,11 @@ void launch_stream_attention(const float *qkv_new, const float *kcache, const fl
                              int n_heads, const float *pos, int P, const float *bias_u, const float *bias_v, int att_left, int att_right,
                              float *ctx, hipStream_t s, float *cache_k_out, float *cache_v_out, int keep_max, int ctx_sigma) {
     const int hd = d / n_heads;
+    // the kernel walks the head features and the cache rows as float4 chunks: fail loudly instead of dropping a tail
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (n_heads <= 0 || d % n_heads || hd % 4 || d % 4 || !al16(qkv_new) || !al16(kcache) || !al16(vcache) || !al16(pos) || !al16(ctx) ||
+        !al16(cache_k_out) || !al16(cache_v_out))
+        fail(PK_ERR_INVALID, "launch_stream_attention: head size %d / hidden size %d must be multiples of 4 and every buffer 16-byte aligned", hd, d);
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t lds = (size_t)(2 * hd + nc + c + 2) * sizeof(float);
     const int kv = nc + c, keep = kv > keep_max ? keep_max : kv;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void sub_conv1_dw1_kernel(const float *__restr
                                                             const float *__restrict__ w1 /*[9][C]*/, const float *__restrict__ b1,
                                                             const float *__restrict__ wd /*[9][C]*/, const float *__restrict__ bd,
                                                             int H1, int W1, int H2, int W2, int n_xc, int n_ys, int64_t n_strips,
-                                                            float *__restrict__ out) {
+                                                            float *__restrict__ out, SubRag rg) {
     constexpr int NC = 2 * XC + 1;
     constexpr int WR = 4 * YS + 3, WC = 4 * XC + 3, PW = (WC + 3) & ~3, TILE = WR * PW;   // input window per strip
     extern __shared__ __attribute__((aligned(16))) float win[];       // [256/C][WR][PW]
@@ -36,9 +36,18 @@ __global__ __launch_bounds__(256) void sub_conv1_dw1_kernel(const float *__restr
         const int64_t strip = (int64_t)blockIdx.x * spb + sl;
         float v = 0.0f;
         if (strip < n_strips && wc < WC) {
-            const int xc = (int)(strip % n_xc), ys = (int)((strip / n_xc) % n_ys), b = (int)(strip / ((int64_t)n_xc * n_ys));
-            const int iy = 4 * ys * YS - 3 + wr, ix = 4 * xc * XC - 3 + wc;
-            if (iy >= 0 && iy < Tm && ix >= 0 && ix < F) v = feats[((int64_t)b * Tm + iy) * F + ix];
+            const int xc = (int)(strip % n_xc);
+            int y2s, tm_b;                                            // first output row of the strip, mel frames of its utterance
+            int64_t frame0;                                           // first mel frame of the utterance in the packed frame axis
+            if (rg.strips.u) {                                        // ragged batch: strips never straddle utterances (kernels.hpp: SubRag)
+                const RagUnit un = rg.strips.u[strip / n_xc];
+                y2s = un.r0; tm_b = rg.Tm[un.b]; frame0 = rg.Tm_off[un.b];
+            } else {
+                const int b = (int)(strip / ((int64_t)n_xc * n_ys));
+                y2s = (int)((strip / n_xc) % n_ys) * YS; tm_b = Tm; frame0 = (int64_t)b * Tm;
+            }
+            const int iy = 4 * y2s - 3 + wr, ix = 4 * xc * XC - 3 + wc;
+            if (iy >= 0 && iy < tm_b && ix >= 0 && ix < F) v = feats[(frame0 + iy) * F + ix];
         }
         win[e] = v;
     }
@@ -46,8 +55,22 @@ __global__ __launch_bounds__(256) void sub_conv1_dw1_kernel(const float *__restr
     const int c = threadIdx.x % C, sl = threadIdx.x / C;
     const int64_t strip = (int64_t)blockIdx.x * spb + sl;
     if (strip >= n_strips) return;
-    const int xc = (int)(strip % n_xc), ys = (int)((strip / n_xc) % n_ys), b = (int)(strip / ((int64_t)n_xc * n_ys));
-    const int x2_0 = xc * XC, y2_0 = ys * YS, x1_0 = 2 * x2_0 - 1;     // r[j] holds conv1 column x1_0 + j
+    const int xc = (int)(strip % n_xc);
+    int y2_0;
+    int64_t orow0;                                                     // first output row of the utterance in the packed H2 axis
+    if (rg.strips.u) {
+        const RagUnit un = rg.strips.u[strip / n_xc];
+        y2_0 = un.r0;
+        const int tm_b = rg.Tm[un.b];
+        H1 = (tm_b - 1) / 2 + 1;
+        H2 = rg.H2[un.b];
+        orow0 = rg.H2_off[un.b];
+    } else {
+        const int b = (int)(strip / ((int64_t)n_xc * n_ys));
+        y2_0 = (int)((strip / n_xc) % n_ys) * YS;
+        orow0 = (int64_t)b * H2;
+    }
+    const int x2_0 = xc * XC, x1_0 = 2 * x2_0 - 1;                     // r[j] holds conv1 column x1_0 + j
     const float *tile = win + sl * TILE;
     float k1[9], kd[9];
 #pragma unroll
@@ -83,7 +106,7 @@ __global__ __launch_bounds__(256) void sub_conv1_dw1_kernel(const float *__restr
         }
         conv_row(2 * yy + 1, r1);
         conv_row(2 * yy + 2, r2);
-        float *orow = out + (((int64_t)b * H2 + y2) * W2 + x2_0) * C + c;
+        float *orow = out + ((orow0 + y2) * W2 + x2_0) * C + c;
 #pragma unroll
         for (int xl = 0; xl < XC; ++xl) {
             float acc2 = 0.0f;                                         // dw1 :226, taps in (ky,kx) order
@@ -100,15 +123,21 @@ __global__ __launch_bounds__(256) void sub_conv1_dw1_kernel(const float *__restr
 
 __global__ __launch_bounds__(256) void sub_dw_kernel(const float *__restrict__ in, int H, int W, int C,
                                                      const float *__restrict__ wd /*[9][C]*/, const float *__restrict__ bd,
-                                                     int Ho, int Wo, int64_t n_pix, float *__restrict__ out) {
+                                                     int Ho, int Wo, int64_t n_pix, float *__restrict__ out, SubRag rg) {
     const int ppb = 256 / C;
     const int c = threadIdx.x % C;
     const int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / C;
     if (pix >= n_pix) return;
     const int xo = (int)(pix % Wo);
-    const int yo = (int)((pix / Wo) % Ho);
-    const int b = (int)(pix / ((int64_t)Wo * Ho));
-    const float *src = in + (int64_t)b * H * W * C;
+    int yo = (int)((pix / Wo) % Ho);
+    const float *src;
+    if (rg.strips.u) {                                          // ragged batch: output row pix / Wo of the packed axis = (utterance, local row)
+        const RagUnit un = rg.strips.u[pix / Wo];
+        yo = un.r0; H = rg.H2[un.b];
+        src = in + (int64_t)rg.H2_off[un.b] * W * C;
+    } else {
+        src = in + (pix / ((int64_t)Wo * Ho)) * H * W * C;
+    }
     float acc = 0.0f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -126,29 +155,32 @@ __global__ __launch_bounds__(256) void sub_dw_kernel(const float *__restrict__ i
 
 template <int XC, int YS = 8>
 static void launch_c1d1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
-                        const float *bd, int H1, int W1, int H2, int W2, float *out, hipStream_t s) {
+                        const float *bd, int H1, int W1, int H2, int W2, float *out, hipStream_t s, const SubRag &rag) {
     constexpr int WR = 4 * YS + 3, PW = (4 * XC + 3 + 3) & ~3;
     const int spb = 256 / C, n_ys = (H2 + YS - 1) / YS, n_xc = (W2 + XC - 1) / XC;
-    const int64_t n_strips = (int64_t)B * n_ys * n_xc;
+    const int64_t n_strips = rag.strips.u ? (int64_t)rag.strips.count * n_xc : (int64_t)B * n_ys * n_xc;
     const size_t lds = (size_t)spb * WR * PW * sizeof(float);
     static DynLdsSlots slots;
     ensure_dyn_lds(slots, reinterpret_cast<const void *>(&sub_conv1_dw1_kernel<XC, YS>), lds);
     hipLaunchKernelGGL((sub_conv1_dw1_kernel<XC, YS>), dim3((unsigned)((n_strips + spb - 1) / spb)), dim3(256), lds, s, feats, Tm, F, C, w1, b1,
-                       wd, bd, H1, W1, H2, W2, n_xc, n_ys, n_strips, out);
+                       wd, bd, H1, W1, H2, W2, n_xc, n_ys, n_strips, out, rag);
 }
+static constexpr int64_t kSmallStripRows = 1024;
+int sub_conv1_dw1_strip_rows(int64_t total_h2_rows) { return total_h2_rows <= kSmallStripRows ? 2 : 8; }
 void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
-                          const float *bd, float *out, hipStream_t s) {
+                          const float *bd, float *out, hipStream_t s, const SubRag &rag) {
     const int H1 = (Tm - 1) / 2 + 1, W1 = (F - 1) / 2 + 1, H2 = (H1 - 1) / 2 + 1, W2 = (W1 - 1) / 2 + 1;
     // 80 mel bins -> one 20-column chunk per output row; 128 -> two chunks of 16
     // a strip of 8 output rows per thread shares its conv1 rows; one or two utterances give only a few dozen such strips -- strips of 2 rows
     // (1.5x the conv1 work, four times the workgroups, a quarter of the serial chain each: 77 -> ~25 us for one 10 s clip)
-    const bool small = (int64_t)B * H2 <= 1024;
+    // (ragged batch: the caller built rag.strips with rag.strip_rows = sub_conv1_dw1_strip_rows(total H2 rows) rows per unit)
+    const bool small = rag.strips.u ? rag.strip_rows == 2 : (int64_t)B * H2 <= kSmallStripRows;
     if (W2 <= 20 || W2 % 20 == 0) {
-        if (small) launch_c1d1<20, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
-        else launch_c1d1<20>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
+        if (small) launch_c1d1<20, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
+        else launch_c1d1<20>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
     } else {
-        if (small) launch_c1d1<16, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
-        else launch_c1d1<16>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s);
+        if (small) launch_c1d1<16, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
+        else launch_c1d1<16>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
     }
 }
 // Depthwise 3x3 stride-2 conv (dw2, src/encoder.cpp:230), channels-last.  One thread = 4 adjacent channels x XO adjacent output
@@ -160,7 +192,7 @@ void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const
 template <int XO>
 __global__ __launch_bounds__(256) void sub_dw4_kernel(const float *__restrict__ in, int H, int W, int C,
                                                       const float *__restrict__ wd /*[9][C]*/, const float *__restrict__ bd,
-                                                      int Ho, int Wo, int n_xc, int64_t n_items, int n_blocks, float *__restrict__ out) {
+                                                      int Ho, int Wo, int n_xc, int64_t n_items, int n_blocks, float *__restrict__ out, SubRag rg) {
     const int c4n = C >> 2;                                     // float4 lanes per item
     const int ipb = 256 / c4n;                                  // items per block
     const int per_xcd = (n_blocks + 7) >> 3;
@@ -170,10 +202,19 @@ __global__ __launch_bounds__(256) void sub_dw4_kernel(const float *__restrict__ 
     if (item >= n_items) return;
     const int c4 = threadIdx.x % c4n;
     const int xc = (int)(item % n_xc);
-    const int yo = (int)((item / n_xc) % Ho);
-    const int b = (int)(item / ((int64_t)n_xc * Ho));
+    int yo;
+    int64_t in_row0, out_row;                                   // first input row of the utterance / this output row, packed axes
+    if (rg.strips.u) {                                          // ragged batch (kernels.hpp: SubRag, one unit per output row)
+        const RagUnit un = rg.strips.u[item / n_xc];
+        yo = un.r0; H = rg.H2[un.b];
+        in_row0 = rg.H2_off[un.b]; out_row = (int64_t)rg.T_off[un.b] + yo;
+    } else {
+        const int b = (int)(item / ((int64_t)n_xc * Ho));
+        yo = (int)((item / n_xc) % Ho);
+        in_row0 = (int64_t)b * H; out_row = (int64_t)b * Ho + yo;
+    }
     const int x0 = xc * XO;
-    const float4 *src = reinterpret_cast<const float4 *>(in + (int64_t)b * H * W * C) + c4;
+    const float4 *src = reinterpret_cast<const float4 *>(in + in_row0 * W * C) + c4;
     float4 wt[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wt[k] = reinterpret_cast<const float4 *>(wd + (int64_t)k * C)[c4];
@@ -204,32 +245,32 @@ __global__ __launch_bounds__(256) void sub_dw4_kernel(const float *__restrict__ 
                 acc[xl].w = __builtin_fmaf(w.w, v.w, acc[xl].w);
             }
     }
-    float4 *dst = reinterpret_cast<float4 *>(out + (((int64_t)b * Ho + yo) * Wo) * C) + c4;
+    float4 *dst = reinterpret_cast<float4 *>(out + (out_row * Wo) * C) + c4;
 #pragma unroll
     for (int xl = 0; xl < XO; ++xl)
         if (x0 + xl < Wo) dst[(int64_t)(x0 + xl) * c4n] = make_float4(acc[xl].x + bias.x, acc[xl].y + bias.y, acc[xl].z + bias.z, acc[xl].w + bias.w);
 }
 
 template <int XO>
-static void launch_dw4(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, int Ho, int Wo, float *out, hipStream_t s) {
+static void launch_dw4(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, int Ho, int Wo, float *out, hipStream_t s, const SubRag &rag) {
     const int n_xc = (Wo + XO - 1) / XO;
-    const int64_t n_items = (int64_t)B * Ho * n_xc;
+    const int64_t n_items = rag.strips.u ? (int64_t)rag.strips.count * n_xc : (int64_t)B * Ho * n_xc;
     const int ipb = 256 / (C / 4);
     const int n_blocks = (int)((n_items + ipb - 1) / ipb);
-    hipLaunchKernelGGL(sub_dw4_kernel<XO>, dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, in, H, W, C, wd, bd, Ho, Wo, n_xc, n_items, n_blocks, out);
+    hipLaunchKernelGGL(sub_dw4_kernel<XO>, dim3(((n_blocks + 7) / 8) * 8), dim3(256), 0, s, in, H, W, C, wd, bd, Ho, Wo, n_xc, n_items, n_blocks, out, rag);
 }
 
-void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, float *out, hipStream_t s) {
+void launch_sub_dw(const float *in, int B, int H, int W, int C, const float *wd, const float *bd, float *out, hipStream_t s, const SubRag &rag) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if (C % 4 == 0 && 256 % (C / 4) == 0 && C >= 16) {
-        if (Wo % 5 == 0) launch_dw4<5>(in, B, H, W, C, wd, bd, Ho, Wo, out, s);
-        else launch_dw4<4>(in, B, H, W, C, wd, bd, Ho, Wo, out, s);
+        if (Wo % 5 == 0) launch_dw4<5>(in, B, H, W, C, wd, bd, Ho, Wo, out, s, rag);
+        else launch_dw4<4>(in, B, H, W, C, wd, bd, Ho, Wo, out, s, rag);
         return;
     }
-    const int64_t n_pix = (int64_t)B * Ho * Wo;
+    const int64_t n_pix = rag.strips.u ? (int64_t)rag.strips.count * Wo : (int64_t)B * Ho * Wo;
     const int ppb = 256 / C;
     hipLaunchKernelGGL(sub_dw_kernel, dim3((unsigned)((n_pix + ppb - 1) / ppb)), dim3(256), 0, s, in, H, W, C, wd, bd, Ho, Wo,
-                       n_pix, out);
+                       n_pix, out, rag);
 }
 
 }  // namespace pk

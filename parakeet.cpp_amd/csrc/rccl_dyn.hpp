@@ -27,11 +27,13 @@ struct RcclApi {
 // libamdhip64 / librccl), and an RCCL from another stack than the HIP runtime in use fails in ncclCommInitAll ("no ROCm-capable device");
 // a bare soname would resolve to whichever copy happens to be loaded already; then $ROCM_PATH/lib, /opt/rocm/lib, and the soname last.
 inline const RcclApi *rccl_api(std::string *why) {
-    static RcclApi api;
-    static bool tried = false, ok = false;
-    static std::string err;
-    if (!tried) {
-        tried = true;
+    // resolved once, thread-safely (function-local static initialised by a lambda: C++11 guarantees a single, synchronised run)
+    struct Loaded { RcclApi api; bool ok = false; std::string err; };
+    static const Loaded L = [] {
+        Loaded R;
+        RcclApi &api = R.api;
+        std::string &err = R.err;
+        bool &ok = R.ok;
         std::string cand[8];
         int n = 0;
         if (const char *e = getenv("PK_RCCL_LIB")) cand[n++] = e;
@@ -54,7 +56,10 @@ inline const RcclApi *rccl_api(std::string *why) {
         for (int i = 0; i < n && !h; ++i) {
             h = dlopen(cand[i].c_str(), RTLD_NOW | RTLD_LOCAL);
             if (h) api.path = cand[i];
-            else err += std::string(err.empty() ? "" : "; ") + (dlerror() ? dlerror() : cand[i].c_str());
+            else {
+                const char *e = dlerror();                  // read ONCE: dlerror() clears the message it returns
+                err += std::string(err.empty() ? "" : "; ") + (e ? e : cand[i].c_str());
+            }
         }
         if (h) {
             bool all = true;
@@ -69,9 +74,10 @@ inline const RcclApi *rccl_api(std::string *why) {
             api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
             ok = all;
         }
-    }
-    if (!ok && why) *why = err;
-    return ok ? &api : nullptr;
+        return R;
+    }();
+    if (!L.ok && why) *why = L.err;
+    return L.ok ? &L.api : nullptr;
 }
 
 }  // namespace pk

@@ -11,7 +11,12 @@
 //  * boost_phrases / boost_score work as in the reference (the ContextTrie and the boosted argmax run on the GPU); the
 //    Tensor-level free functions of phrase_boost.hpp (ctc_greedy_decode_boosted(Tensor, ...)) have C-ABI counterparts instead:
 //    pk_set_boost_tokens / pk_set_boost_phrases + pk_ctc_decode / pk_tdt_decode;
-//  * new: transcribe_batch() -- clips of equal length are decoded together (the reference is batch-1 only).
+//  * TDTTranscriber decodes with blank id = vocab_size - 1 (what the reference's CLI passes, src/main.cpp:252).  The reference CLASS
+//    itself calls tdt_greedy_decode with its default blank_id = 1024 whatever the vocabulary (transcribe.hpp:274-279, tdt.hpp:78-80),
+//    which differs for the 8193-token 600M vocabulary: construct TDTTranscriber(weights, vocab, config, /*blank_id=*/1024) to
+//    reproduce the class literally;
+//  * new: transcribe_batch() -- clips of ANY lengths are packed into ragged batches and decoded together, each clip bit-identical to
+//    its single-clip result (the reference is batch-1 only; "batch inference" is a roadmap item, README.md:513).
 // Errors surface as std::runtime_error with the reference's trigger conditions (unreadable vocab / audio, ...).
 #pragma once
 
@@ -193,11 +198,14 @@ class Transcriber {
 /// TDT-only models (no CTC head), e.g. the 600M multilingual checkpoint.
 class TDTTranscriber {
   public:
-    TDTTranscriber(const std::string &weights_path, const std::string &vocab_path, const TDTConfig &config = make_tdt_600m_config())
+    // blank_id < 0 (default): vocab_size - 1, what the reference CLI passes (main.cpp:252).  blank_id = 1024 reproduces the reference
+    // class literally: its transcribe() calls tdt_greedy_decode with the decoder's default blank (transcribe.hpp:274-279, tdt.hpp:78-80).
+    TDTTranscriber(const std::string &weights_path, const std::string &vocab_path, const TDTConfig &config = make_tdt_600m_config(),
+                   int blank_id = -1)
         : config_(config),
           eng_(weights_path, vocab_path,
                detail::flatten(config.encoder, config.prediction, config.joint, config.durations, 0, "joint_.", false,
-                               config.joint.vocab_size - 1)) {}   // blank = vocab_size-1 (what the reference CLI passes, main.cpp:252)
+                               blank_id >= 0 ? blank_id : config.joint.vocab_size - 1)) {}
 
     void to_gpu() { eng_.to_gpu(0); }
     void to_gpu(int device) { eng_.to_gpu(device); }
