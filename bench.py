@@ -133,7 +133,36 @@ DEFAULT_OVERLAP = {}            # (config, bf16) -> pk_batch_set_decode_overlap 
 MARGIN_TOL_BF16 = 2e-2          # label log-prob error class of the bf16 mode at depth 24 (tests/test_gpu_600m_depth.py states the same bound)
 
 
-def fixture_parity(args, cfg, pcm, gpu_ids, gpu_frames=None):
+LOGP_TOL_BF16 = 3e-2            # max |log-prob(gpu) - log-prob(bf16 oracle)| along the oracle's decision path (tests/test_gpu_600m_depth.py states the same bound)
+
+
+def teacher_forced_parity(args, cfg, n, score_fn):
+    """bf16 mode at the LOGITS: the GPU walks the bf16 oracle's decision path of the fixture's clips (pk_tdt_score; the loop of the reference's
+    src/tdt.cpp:62-106 with the decisions given) and every step's label / duration log-probs are compared with the oracle's."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "tdt600m_depth24_score_seed42.npz")
+    if not os.path.exists(path):
+        return None
+    s = np.load(path, allow_pickle=False)
+    worst, tot, cnt, flips, steps = 0.0, 0.0, 0, 0, 0
+    for b in range(min(n, int(s["n_clips"]))):
+        k = int(s["bf16_n"][b])
+        r = score_fn(b, s["bf16_labels"][b, :k], s["bf16_dur_idx"][b, :k])
+        if r["n"] != k:
+            return {"error": f"clip {b}: {r['n']} steps walked, the oracle's path has {k}"}
+        top = np.take_along_axis(r["label_lp"], s["bf16_top_ids"][b, :k].astype(np.int64), axis=1)
+        d = np.concatenate([np.abs(top - s["bf16_top_lp"][b, :k]).ravel(), np.abs(r["dur_lp"] - s["bf16_dur_lp"][b, :k]).ravel()])
+        worst, tot, cnt = max(worst, float(d.max())), tot + float(d.sum()), cnt + d.size
+        flips += int((r["label_lp"].argmax(axis=1) != s["bf16_labels"][b, :k]).sum() + (r["dur_lp"].argmax(axis=1) != s["bf16_dur_idx"][b, :k]).sum())
+        steps += k
+    return {"clips": min(n, int(s["n_clips"])), "steps": steps, "max_abs_dlogp": round(worst, 5), "mean_abs_dlogp": round(tot / max(1, cnt), 6),
+            "bound": LOGP_TOL_BF16, "argmax_flips_along_path": flips, "decisions": 2 * steps,
+            "what": "pk_tdt_score along the bf16 oracle's greedy path (every step's label and duration given): |delta log-prob| on the oracle's top-8 "
+                    "labels and all duration log-probs of every step, encoder drift included",
+            "fixture": "tests/golden/tdt600m_depth24_score_seed42.npz (tools/make_golden_600m_score.py)"}
+
+
+def fixture_parity(args, cfg, pcm, gpu_ids, gpu_frames=None, model_score=None):
     """Parity of a tdt-600m run against the committed full-depth fixture.  fp32: token ids identical.  bf16: the tolerance statement for
     a greedy decode -- the GPU's tokens may leave the bf16 oracle's only at a decision whose top-1 / top-2 margin is within the mode's error
     (oracle/tolerance.py).  Returns (report, failed)."""
@@ -162,6 +191,9 @@ def fixture_parity(args, cfg, pcm, gpu_ids, gpu_frames=None):
                     "oracle_margin_there": (None if mg is None else round(mg, 6))})
         if at is not None and mg > MARGIN_TOL_BF16:
             failed = True
+    rep["teacher_forced"] = teacher_forced_parity(args, cfg, n, model_score) if model_score is not None else None
+    if rep["teacher_forced"] and rep["teacher_forced"].get("max_abs_dlogp", 0.0) > LOGP_TOL_BF16:
+        failed = True
     rep.update(per_clip=per, margin_tolerance=MARGIN_TOL_BF16,
                checked_against="the bf16-mode oracle's decode: tokens identical up to the first decision whose top-1/top-2 margin is within "
                                "the mode's error (random-weight models decide with margins down to 5e-5; see tests/test_gpu_600m_depth.py)")
@@ -469,7 +501,8 @@ def main():
             # fixture (tests/golden/tdt600m_depth24_seed42.npz = the oracle's and the reference code's outputs for the FIRST clips of exactly
             # this batch, tools/make_golden_600m.py) and the CPU baseline is the fp32 oracle timed live on ONE clip (~10 s of CPU work).
             try:
-                out["parity"], bad = fixture_parity(args, cfg, pcm, gpu_ids, (st_fr, en_fr))
+                score_fn = (lambda b, lab, dur: model.tdt_score(model.encode(model.mel(pcm[b:b + 1]))[0], lab, dur)) if (big and args.bf16) else None
+                out["parity"], bad = fixture_parity(args, cfg, pcm, gpu_ids, (st_fr, en_fr), model_score=score_fn)
                 if bad:
                     rc = 3
                 if W is None:

@@ -165,6 +165,16 @@ pk_status pk_ctc_decode_ragged(pk_model *m, const float *enc, const int32_t *n_f
 pk_status pk_tdt_decode_ragged(pk_model *m, const float *enc, const int32_t *n_frames, int B, int max_tokens, int32_t *ids, int32_t *lens,
                                int32_t *start, int32_t *end, float *conf, int32_t *steps);
 
+/* Teacher-forced joint scores -- "TDT logits within stated fp tolerance" made checkable for a greedy decoder: the loop of
+ * tdt_greedy_decode (src/tdt.cpp:62-106) on ONE utterance enc[T][hidden] with the decision of every step GIVEN (labels[k], and
+ * dur_idx[k] = an index into pk_config.durations) instead of taken from the argmax, so that the state every step is scored in -- frame
+ * pointer, last token, LSTM state -- is the one another implementation (the CPU oracle, the reference) was in at the same step.  A blank
+ * reverts the LSTM state and advances by max(duration, 1) (:88-93); a token commits it and advances by its duration (0: same frame,
+ * :95-105).  Outputs per step k < *n_done: label_logp[k][vocab_size], dur_logp[k][num_durations] = the joint's log-softmax outputs
+ * (TDTJoint::forward, :15-24); either may be NULL.  *n_done = steps evaluated (< n_steps when the frame pointer left the utterance). */
+pk_status pk_tdt_score(pk_model *m, const float *enc, int T, const int32_t *labels, const int32_t *dur_idx, int n_steps, float *label_logp,
+                       float *dur_logp, int *n_done);
+
 /* Early warning of the tolerance-class (bf16) mode, SURVEY.md 8(c): per utterance of the LAST pk_tdt_decode on this model, the smallest
  * (top-1 minus top-2) log-prob over all of its greedy decisions -- the label argmax (tdt.cpp:78-82) and, for TDT heads, the duration argmax
  * (:84-86: a flip there moves the frame pointer and every later token with it): how close the decode came to a different path.  A margin below the mode's numerical error marks a token that may differ from the reference.  Not produced for

@@ -291,6 +291,25 @@ class Model:
             res["first_logp"] = fl
         return res
 
+    def tdt_score(self, enc, labels=None, dur_idx=None, max_steps=None, rows=True):
+        """orc_tdt_score: the TDT loop (src/tdt.cpp:62-106) on ONE utterance enc[T][d] along a GIVEN decision path (labels[k], dur_idx[k]) --
+        or, labels=None, along its own greedy path -- returning every step's joint outputs: label log-probs [n][V], duration log-probs [n][D]
+        and the decisions walked."""
+        enc = _c(enc)
+        T = enc.shape[0]
+        V, D = self.cfg.vocab_size, len(self.cfg.durations)
+        cap = int(max_steps or (len(labels) if labels is not None else T * (self.cfg.max_symbols_per_step + 1) + 16))
+        L = lib()
+        L.orc_tdt_score.argtypes = [C.c_void_p, f32p, C.c_int, i32p, i32p, C.c_int, i32p, i32p, f32p, f32p]
+        lab_out = np.full(cap, -1, np.int32); dur_out = np.full(cap, -1, np.int32)
+        llp = np.zeros((cap, V), np.float32) if rows else None
+        dlp = np.zeros((cap, D), np.float32)
+        li = _c(labels, np.int32) if labels is not None else None
+        di = _c(dur_idx, np.int32) if labels is not None else None
+        n = self._chk(L.orc_tdt_score(self._h, _f(enc), T, _i(li) if li is not None else None, _i(di) if di is not None else None, cap,
+                                      _i(lab_out), _i(dur_out), _f(llp) if rows else None, _f(dlp)))
+        return dict(n=n, labels=lab_out[:n], dur_idx=dur_out[:n], label_lp=(llp[:n] if rows else None), dur_lp=dlp[:n])
+
     def tdt_greedy_boosted(self, enc, trie, boost=5.0, max_tokens=None, max_steps=0):
         """tdt_greedy_decode(_with_timestamps)_boosted: src/phrase_boost.cpp:177-350."""
         enc = _c(enc)

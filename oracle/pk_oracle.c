@@ -1477,6 +1477,63 @@ int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max
     return tdt_greedy_ex(m, enc, B, T, max_tokens, max_steps, ids, lens, start, end, conf, steps, NULL, NULL, NULL, 1, trie, boost, NULL, NULL, NULL, 0);
 }
 
+/*
+ * Teacher-forced joint scores: the loop of tdt_greedy_decode (src/tdt.cpp:62-106) on ONE utterance enc[T][d] with the decision of every
+ * step GIVEN -- labels_in[k], dur_in[k] (an index into the duration table) -- instead of taken from the argmax; labels_in == NULL: the
+ * decisions are the greedy ones (the function then IS the greedy decode) and are reported in labels_out / dur_out.  After step k the frame
+ * pointer, the last token and the LSTM state are what the reference's loop holds after deciding that way: a blank reverts the state and
+ * advances by max(duration, 1) (:88-93), a token commits it and advances by its duration, 0 = stay on the frame (:95-105).
+ * label_lp[k][V], dur_lp[k][D] (either may be NULL) = the joint's log-softmax outputs of step k (TDTJoint::forward, :15-24).
+ * Returns the number of steps evaluated (<= n_steps: the walk ends when the frame pointer leaves the utterance), -1 on error.
+ */
+int orc_tdt_score(orc_model *m, const float *enc, int T, const int32_t *labels_in, const int32_t *dur_in, int n_steps, int32_t *labels_out,
+                  int32_t *dur_out, float *label_lp, float *dur_lp) {
+    const orc_config *c = &m->cfg;
+    dec_weights w;
+    if (dec_weights_get(m, &w, 0)) return -1;
+    const int Hp = w.Hp, J = w.J, V = w.V, D = w.D, d = c->d_model;
+    if (D < 1 || D > 16) return orc_fail("orc_tdt_score: a TDT joint (1..16 durations) is required");
+    float *ep = (float *)xmalloc((size_t)T * J * sizeof(float));
+    linear_t(m->cfg.gemm_bf16, w.we, w.be, T, enc, d, ep, J, 1);
+    float *h = (float *)calloc((size_t)w.L * Hp * 2, sizeof(float)), *cc = h + w.L * Hp;
+    float *sh = (float *)xmalloc((size_t)w.L * Hp * 2 * sizeof(float));
+    float *pred = (float *)xmalloc((size_t)Hp * sizeof(float));
+    float *z = (float *)xmalloc((size_t)J * sizeof(float));
+    float *scratch = (float *)xmalloc((size_t)(8 * Hp + J) * sizeof(float));
+    float *lab = (float *)xmalloc((size_t)V * 2 * sizeof(float)), *lab_lp = lab + V;
+    float dur[16], dlp[16];
+    int token = c->blank_id, t = 0, k = 0, bad = 0;
+    for (; k < n_steps && t < T; ++k) {
+        memcpy(sh, h, (size_t)w.L * Hp * 2 * sizeof(float));
+        predict_step(&w, token, h, cc, pred, scratch);
+        joint_hidden(&w, ep + (int64_t)t * J, pred, z, scratch);
+        gemm_core(1, V, J, z, J, w.bf16 ? w.wl->wt16 : w.wl->wt, V, lab, V, 0);
+        for (int i = 0; i < V; ++i) lab[i] = lab[i] + w.bl->data[i];
+        log_softmax_row(lab, V, lab_lp);
+        gemm_core(1, D, J, z, J, w.bf16 ? w.wd->wt16 : w.wd->wt, D, dur, D, 0);
+        for (int i = 0; i < D; ++i) dur[i] = dur[i] + w.bd->data[i];
+        log_softmax_row(dur, D, dlp);
+        if (label_lp) memcpy(label_lp + (int64_t)k * V, lab_lp, (size_t)V * sizeof(float));
+        if (dur_lp) memcpy(dur_lp + (int64_t)k * D, dlp, (size_t)D * sizeof(float));
+        const int lk = labels_in ? labels_in[k] : argmax_first(lab_lp, V);
+        const int di = labels_in ? dur_in[k] : argmax_first(dlp, D);
+        if (lk < 0 || lk >= V || di < 0 || di >= D) { bad = 1; break; }
+        if (labels_out) labels_out[k] = lk;
+        if (dur_out) dur_out[k] = di;
+        const int skip = c->durations[di];
+        if (lk == c->blank_id) {
+            memcpy(h, sh, (size_t)w.L * Hp * 2 * sizeof(float));
+            t += skip > 1 ? skip : 1;
+        } else {
+            token = lk;
+            if (skip > 0) t += skip;
+        }
+    }
+    free(ep); free(h); free(sh); free(pred); free(z); free(scratch); free(lab);
+    if (bad) return orc_fail("orc_tdt_score: forced label / duration index out of range at step %d", k);
+    return k;
+}
+
 /* rnnt_greedy_decode(+_with_timestamps): src/rnnt.cpp:56-111, :115-177 ; RNNTJoint::forward :37-44 */
 int orc_rnnt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens, int32_t *ids, int32_t *lens,
                     int32_t *start, float *conf) {

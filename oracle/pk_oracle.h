@@ -99,6 +99,9 @@ int orc_tdt_greedy_margin(orc_model *m, const float *enc, int B, int T, int max_
                           int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps, float *min_margin,
                           float *step_margin /* optional [B][step_cap]: the margin of every decision in order */,
                           int32_t *step_label /* optional [B][step_cap]: the label every decision chose, blank included */, int step_cap);
+/* teacher-forced joint scores along a given (or, labels_in == NULL, the greedy) decision path of ONE utterance: see pk_oracle.c */
+int orc_tdt_score(orc_model *m, const float *enc, int T, const int32_t *labels_in, const int32_t *dur_in, int n_steps, int32_t *labels_out,
+                  int32_t *dur_out, float *label_lp, float *dur_lp);
 int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max_tokens, int max_steps, const orc_trie *trie, float boost,
                            int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf, int32_t *steps);
 

@@ -119,6 +119,7 @@ _LATE_SIGNATURES = {
     "pk_ctc_decode": [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, f32p],
     "pk_tdt_decode": [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, i32p],
     "pk_model_set_decode_loop": [C.c_void_p, C.c_int],
+    "pk_tdt_score": [C.c_void_p, f32p, C.c_int, i32p, i32p, C.c_int, f32p, f32p, C.POINTER(C.c_int)],
     "pk_mel_ragged": [C.c_void_p, f32p, i64p, C.c_int, f32p, f32p],
     "pk_encode_ragged": [C.c_void_p, f32p, i32p, C.c_int, C.c_int, C.c_int, f32p],
     "pk_conformer_blocks_ragged": [C.c_void_p, f32p, i32p, C.c_int, C.c_int, C.c_int, f32p],
@@ -808,6 +809,16 @@ class Model:
         if return_logp:
             r["logp"] = lp
         return r
+
+    def tdt_score(self, enc, labels, dur_idx):
+        """pk_tdt_score: the TDT loop on ONE utterance enc[T][d] along the given decisions -> per-step label / duration log-probs."""
+        enc = _c(enc)
+        lab, dur = _c(labels, np.int32), _c(dur_idx, np.int32)
+        n = len(lab)
+        llp = np.zeros((n, self.cfg.vocab_size), np.float32); dlp = np.zeros((n, len(self.cfg.durations)), np.float32)
+        done = C.c_int(0)
+        check(lib().pk_tdt_score(self._h, _f(enc), enc.shape[0], _i(lab), _i(dur), n, _f(llp), _f(dlp), C.byref(done)))
+        return dict(n=done.value, label_lp=llp[:done.value], dur_lp=dlp[:done.value])
 
     def tdt_decode(self, enc, max_tokens=None):
         enc = _c(enc)

@@ -419,6 +419,41 @@ pk_status pk_tdt_decode_ragged(pk_model *h, const float *enc, const int32_t *n_f
     return st;
 }
 
+/* tdt_greedy_decode's loop (src/tdt.cpp:62-106) along a GIVEN decision path, recording the joint's outputs (TDTJoint::forward, :15-24) */
+pk_status pk_tdt_score(pk_model *h, const float *enc, int T, const int32_t *labels, const int32_t *dur_idx, int n_steps, float *label_logp,
+                       float *dur_logp, int *n_done) {
+    return guard([&] {
+        need(h && enc && labels && dur_idx && T > 0 && n_steps > 0 && (label_logp || dur_logp), "model/enc/labels/dur_idx/T/n_steps/outputs");
+        Model &m = *h->m;
+        m.require_gpu();
+        need(m.cfg.vocab_size > 0 && !m.cfg.rnnt_head && m.cfg.num_durations > 0, "pk_tdt_score needs a TDT joint (label + duration heads)");
+        const int V = m.cfg.vocab_size, D = m.cfg.num_durations;
+        for (int k = 0; k < n_steps; ++k)
+            need(labels[k] >= 0 && labels[k] < V && dur_idx[k] >= 0 && dur_idx[k] < D, "labels[k] / dur_idx[k] out of range");
+        size_ws_for_T(m, 1, T);
+        Workspace &w = m.ws;
+        const size_t nl = (size_t)n_steps * V, nd = (size_t)n_steps * D;
+        m.io_in.reserve((size_t)2 * n_steps * sizeof(int));
+        m.io_out.reserve((nl + nd) * 4);
+        int *d_lab = m.io_in.as<int>(), *d_dur = d_lab + n_steps;
+        float *d_sl = m.io_out.as<float>(), *d_sd = d_sl + nl;
+        PK_HIP(hipMemcpyAsync(d_lab, labels, (size_t)n_steps * 4, hipMemcpyHostToDevice, m.stream));
+        PK_HIP(hipMemcpyAsync(d_dur, dur_idx, (size_t)n_steps * 4, hipMemcpyHostToDevice, m.stream));
+        PK_HIP(hipMemsetAsync(d_sl, 0, (nl + nd) * 4, m.stream));
+        PK_HIP(hipMemcpyAsync(w.x.p, enc, (size_t)T * m.cfg.hidden_size * 4, hipMemcpyHostToDevice, m.stream));
+        struct Scope { Workspace &w; ~Scope() { w.force_label = w.force_dur = nullptr; w.score_lab = w.score_dur = nullptr; w.n_force = 0; } } scope{w};
+        w.force_label = d_lab; w.force_dur = d_dur; w.n_force = n_steps; w.score_lab = d_sl; w.score_dur = d_sd;
+        m.run_tdt(w, w.x.as<float>(), 1, T, w.max_tokens, m.stream);
+        PK_CHECK_LAUNCH();
+        int steps = 0;
+        PK_HIP(hipMemcpyAsync(&steps, w.ints.as<int>() + 4, sizeof(int), hipMemcpyDeviceToHost, m.stream));      // st.steps[0] (B = 1)
+        if (label_logp) PK_HIP(hipMemcpyAsync(label_logp, d_sl, nl * 4, hipMemcpyDeviceToHost, m.stream));
+        if (dur_logp) PK_HIP(hipMemcpyAsync(dur_logp, d_sd, nd * 4, hipMemcpyDeviceToHost, m.stream));
+        PK_HIP(hipStreamSynchronize(m.stream));
+        if (n_done) *n_done = steps;
+    });
+}
+
 pk_status pk_decode_margins(pk_model *h, float *min_margin, int B) {
     return guard([&] {
         need(h && min_margin && B > 0, "model/min_margin/B");

@@ -1055,11 +1055,17 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     st.max_tokens = max_tokens;
     st.keep_state = keep_state ? 1 : 0;
     st.Tb = w.dec_Tb; st.row0 = w.dec_row0;                          // ragged batch / decode group of ragged runs (null: uniform, T frames each)
+    if (w.force_label) {                                             // pk_tdt_score: walk a given decision path, record the joint's outputs
+        if (B != 1 || boost_on || keep_state || D <= 0) fail(PK_ERR_UNSUPPORTED, "teacher-forced scoring takes one utterance of a TDT model, unboosted");
+        st.force_label = w.force_label; st.force_dur = w.force_dur; st.n_force = w.n_force;
+        st.score_lab = w.score_lab; st.score_dur = w.score_dur;
+    }
     if (boost_on) {
         if (cfg.rnnt_head || keep_state) fail(PK_ERR_UNSUPPORTED, "phrase boosting applies to the CTC and TDT greedy decoders only (src/phrase_boost.cpp)");
         st.trie = trie_dev(w, B);
     }
     st.max_steps = T * (cfg.max_symbols_per_step + 1) + 16;          // safety cap (the reference has none)
+    if (w.force_label && w.n_force + 1 > st.max_steps) st.max_steps = w.n_force + 1;
     for (int i = 0; i < D; ++i) st.durations[i] = cfg.durations[i];
     st.logits = w.logits.as<float>();
     st.h = w.h.as<float>(); st.c = w.c.as<float>(); st.hn = w.hn.as<float>(); st.cn = w.cn.as<float>();
@@ -1152,7 +1158,7 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     // resident part of the grid spins while the rest waits for CU slots.  Eligible when the decide scratch is small enough for a
     // workgroup to sit beside the encoder's GEMM workgroups, at most two LSTM layers, no phrase boosting, no carried streaming state.
     {
-        const bool want = decode_loop == PK_DECODE_LOOP_PERSISTENT && !dec16;     // (the single-launch loop exists for the fp32 phases only)
+        const bool want = decode_loop == PK_DECODE_LOOP_PERSISTENT && !dec16 && !w.force_label;     // (the single-launch loop exists for the fp32 phases only)
         const int G = Hp / 4;
         if (want && !boost_on && !keep_state && Hp % 4 == 0 && G >= 1 && G <= 200 && L <= 2 && tdt_persistent_lds_bytes(st) <= 12 * 1024) {
             P.bar = reinterpret_cast<unsigned *>(st.done_count + 1);           // two spare words behind the per-utterance state

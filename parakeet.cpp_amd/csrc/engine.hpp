@@ -83,6 +83,10 @@ struct Workspace {
     int32_t *rag_pinned = nullptr;                // pinned staging of the image (async upload on the run's stream)
     size_t rag_pinned_words = 0;
     hipEvent_t rag_copied = nullptr;              // the last upload out of rag_pinned has executed
+    // teacher-forced scoring (pk_tdt_score, one utterance): device arrays of the given decisions and of the recorded joint outputs (TdtState)
+    const int *force_label = nullptr, *force_dur = nullptr;
+    int n_force = 0;
+    float *score_lab = nullptr, *score_dur = nullptr;
     const int *dec_Tb = nullptr, *dec_row0 = nullptr;   // decode loop on a ragged batch: frames / first enc_proj row of every utterance (device; null = uniform)
     int64_t rows(int B_run) const { return ragged ? rag.sum_T : (int64_t)B_run * T_run; }   // packed encoder rows of the current run
     int t_max() const { return ragged ? rag.T_max : T_run; }

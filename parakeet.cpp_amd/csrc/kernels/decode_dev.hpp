@@ -440,6 +440,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             const int i = i0 + 256 * u;
             if (i < st.V) {
                 float l = (t4[u] - m) - lse;
+                if constexpr (!BOOST) { if (st.score_lab) st.score_lab[(int64_t)steps_in * st.V + i] = l; }   // teacher-forced scoring: the row as the joint returns it
                 if constexpr (BOOST) l = l + (((mask[i >> 5] >> (i & 31)) & 1u) ? st.trie.boost : 0.0f);
                 if (bi == 0x7fffffff || l > best) { second = best; best = l; bi = i; }
                 else second = fmaxf(second, l);
@@ -477,6 +478,15 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     }
     if constexpr (BOOST) lab.lp = (x[lab.idx] - m) - lse;          // the confidence is the UNBOOSTED log-prob (phrase_boost.cpp:313-315)
     if (st.D > 0) skip = (int)red[5];
+    if constexpr (!BOOST) {
+        if (st.force_label) {                                      // teacher-forced scoring (TdtState::force_label): the given decision, not the argmax
+            if (st.score_dur && tid < st.D) st.score_dur[(int64_t)steps_in * st.D + tid] = e[st.V + tid];
+            const int k = steps_in < st.n_force ? steps_in : st.n_force - 1;
+            lab.idx = st.force_label[k];
+            lab.lp = (x[lab.idx] - m) - lse;
+            if (st.D > 0) skip = st.durations[st.force_dur[k]];
+        }
+    }
     const int lane0 = tid;                                         // thread 0 writes the scalar state
     // scalar control (wave-uniform values; lane 0 writes)
     int t = t_in;
@@ -546,7 +556,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         // prediction-net caching (TdtState::need): a token changed (token, h, c) -> the next step runs the cells and pred_proj again; a blank
         // changed only the frame -> this workgroup forms next step's z = relu(enc_proj[t'] + pp) from the cached pp (SK_ACT's epilogue, same
         // operand order: enc_proj + (pred_proj [+ bias]))
-        const bool fin = t >= Tb || (max_steps_b > 0 && nsteps >= max_steps_b);
+        const bool fin = t >= Tb || (max_steps_b > 0 && nsteps >= max_steps_b) || (st.force_label && nsteps >= st.n_force);
         if (tid == 0) dd_sti<COH>(st.need + b, (commit && !fin) ? 1 : 0);
         if (!commit && !fin) {
             const float *epr = st.ep + (ep_row0 + t) * st.J, *ppr = st.pp + (int64_t)b * st.J;
@@ -559,7 +569,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         }
     }
     if (lane0 == 0) {
-        bool finished = t >= Tb;
+        bool finished = t >= Tb || (st.force_label && nsteps >= st.n_force);
         int len = n_out < st.max_tokens ? n_out : st.max_tokens;
         if (!finished && max_steps_b > 0 && nsteps >= max_steps_b) { finished = true; len = -1; }   // safety cap
         dd_sti<COH>(st.t + b, t);

@@ -134,3 +134,73 @@ def test_bf16_drift_curve_and_token_contract_at_depth_24(gold, setup):
         print("  ", r)
     assert all(r[1] > 0 for r in report)
     gm.close()
+
+
+# ---- teacher-forced joint scores: the logits-level half of the configs[2] statement ------------------------------------------------------
+SCORE = os.path.join(ROOT, "tests", "golden", "tdt600m_depth24_score_seed42.npz")
+LOGP_TOL, LOGP_MEAN = 3e-2, 8e-3   # bf16 mode at depth 24: max / mean |log-prob(gpu) - log-prob(bf16 oracle)| along the oracle's path, encoder drift included
+                                   # (observed on the three clips: max 2.06e-2 .. 2.48e-2, mean 4.6e-3 .. 5.0e-3; profiles/r04_600m_teacher_forced.txt)
+
+
+@pytest.fixture(scope="module")
+def score():
+    if not os.path.exists(SCORE):
+        pytest.skip("tests/golden/tdt600m_depth24_score_seed42.npz is missing (tools/make_golden_600m_score.py)")
+    return np.load(SCORE, allow_pickle=False)
+
+
+def test_fp32_teacher_forced_rows_bit_identical(gold, score, setup):
+    """pk_tdt_score walks the fp32 oracle's greedy path (every step's label AND duration given): the label log-prob ROW of every step carries
+    the oracle's bit checksums, its top-8 and the duration log-probs are bit-equal -- /root/reference/src/tdt.cpp:15-24,62-106."""
+    from parakeet_cpp_amd import capi
+    cfg, wp, pcm = setup
+    assert np.array_equal(score["pcm_digest"], gold["pcm_digest"])
+    gm = capi.Model(wp, cfg, device=0)
+    enc = gm.encode(gm.mel(pcm))
+    for b in range(len(pcm)):
+        n = int(score["fp32_n"][b])
+        r = gm.tdt_score(enc[b], score["fp32_labels"][b, :n], score["fp32_dur_idx"][b, :n])
+        assert r["n"] == n, f"clip {b}: {r['n']} steps walked, the oracle's path has {n}"
+        u = r["label_lp"].view(np.uint32)
+        assert np.array_equal(np.bitwise_xor.reduce(u, axis=1), score["fp32_row_xor"][b, :n]), f"clip {b}: label log-prob rows (xor of bits)"
+        assert np.array_equal(u.astype(np.uint64).sum(axis=1), score["fp32_row_sum"][b, :n]), f"clip {b}: label log-prob rows (sum of bits)"
+        top = np.take_along_axis(r["label_lp"], score["fp32_top_ids"][b, :n].astype(np.int64), axis=1)
+        assert np.array_equal(top.view(np.uint32), score["fp32_top_lp"][b, :n].view(np.uint32)), f"clip {b}: top-8 label log-probs"
+        assert np.array_equal(r["dur_lp"].view(np.uint32), score["fp32_dur_lp"][b, :n].view(np.uint32)), f"clip {b}: duration log-probs"
+        assert np.array_equal(r["label_lp"].argmax(axis=1), score["fp32_labels"][b, :n]), f"clip {b}: the GPU's own argmax along the path"
+    gm.close()
+
+
+def test_bf16_teacher_forced_logits_within_bound(score, setup):
+    """The tolerance statement of the bf16 mode at the logits: the GPU walks the bf16 ORACLE's decision path of every clip to the end (so a
+    near-tie does not end the comparison), and at EVERY step |delta log-prob| <= LOGP_TOL on the oracle's top-8 labels and on all duration
+    log-probs; every decision whose margin exceeds 2 x LOGP_TOL (both sides can move by the bound) is the GPU's own argmax too."""
+    from parakeet_cpp_amd import capi
+    cfg, wp, pcm = setup
+    gm = capi.Model(wp, dataclasses.replace(cfg, gemm_bf16=True, name="tdt-600m-bf16-score"), device=0)
+    enc = gm.encode(gm.mel(pcm))
+    worst, n_dec, n_clear, n_agree_all, rep = 0.0, 0, 0, 0, []
+    for b in range(len(pcm)):
+        n = int(score["bf16_n"][b])
+        lab, dur = score["bf16_labels"][b, :n], score["bf16_dur_idx"][b, :n]
+        r = gm.tdt_score(enc[b], lab, dur)
+        assert r["n"] == n, f"clip {b}: {r['n']} steps walked, the oracle's path has {n}"
+        top = np.take_along_axis(r["label_lp"], score["bf16_top_ids"][b, :n].astype(np.int64), axis=1)
+        d_lab = np.abs(top - score["bf16_top_lp"][b, :n])
+        d_dur = np.abs(r["dur_lp"] - score["bf16_dur_lp"][b, :n])
+        mg = score["bf16_margin"][b, :n]
+        g_lab, g_dur = r["label_lp"].argmax(axis=1), r["dur_lp"].argmax(axis=1)
+        clear_l, clear_d = mg[:, 0] > 2 * LOGP_TOL, mg[:, 1] > 2 * LOGP_TOL
+        assert np.array_equal(g_lab[clear_l], lab[clear_l]), f"clip {b}: a label decision with margin > {2 * LOGP_TOL} differs"
+        assert np.array_equal(g_dur[clear_d], dur[clear_d]), f"clip {b}: a duration decision with margin > {2 * LOGP_TOL} differs"
+        worst = max(worst, float(d_lab.max()), float(d_dur.max()))
+        n_dec += 2 * n; n_clear += int(clear_l.sum() + clear_d.sum()); n_agree_all += int((g_lab == lab).sum() + (g_dur == dur).sum())
+        rep.append((b, n, float(d_lab.max()), float(d_lab.mean()), float(d_dur.max()), float(d_dur.mean()), int((g_lab != lab).sum()), int((g_dur != dur).sum())))
+    print("clip: steps, label max / mean |dlogp| (top-8), duration max / mean |dlogp|, label / duration argmax flips along the path")
+    for x in rep:
+        print("  ", x)
+    print(f"bf16 teacher-forced: max |dlogp| {worst:.3e} (bound {LOGP_TOL}); {n_clear} of {n_dec} decisions have margin > {2 * LOGP_TOL} (all agree); "
+          f"{n_agree_all} of {n_dec} agree in all")
+    gm.close()
+    assert worst <= LOGP_TOL, f"max |delta log-prob| {worst:.3e} > {LOGP_TOL}"
+    assert max(max(x[3], x[5]) for x in rep) <= LOGP_MEAN, f"mean |delta log-prob| > {LOGP_MEAN}"

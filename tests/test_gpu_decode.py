@@ -144,3 +144,25 @@ def test_persistent_loop_110m_heads_and_two_layers(tmp_path_factory):
             assert np.array_equal(a[k], b[k]), (cfg.name, k)
         G.assert_bits_equal(a["conf"], b["conf"], "confidence")
         check_tdt(gm, om, enc)
+
+
+def test_teacher_forced_scores_bit_identical(tiny_pair):
+    """pk_tdt_score == orc_tdt_score row for row: along the oracle's own greedy path (then the walk reproduces the greedy decode), and along
+    an ARBITRARY path of random labels / durations (states no greedy decode visits) -- /root/reference/src/tdt.cpp:15-24,62-106."""
+    W, om, gm = tiny_pair
+    enc = enc_like(1, 60, om.cfg.hidden_size, 11)[0]
+    o = om.tdt_score(enc)
+    g = gm.tdt_score(enc, o["labels"], o["dur_idx"])
+    assert g["n"] == o["n"] > 20
+    G.assert_bits_equal(g["label_lp"], o["label_lp"], "label log-prob rows along the greedy path")
+    G.assert_bits_equal(g["dur_lp"], o["dur_lp"], "duration log-prob rows along the greedy path")
+    assert (o["labels"] != BLANK).sum() > 3, "degenerate test: nothing decoded"
+    rng = np.random.default_rng(0)
+    n = 150
+    lab = np.where(rng.random(n) < 0.5, BLANK, rng.integers(0, BLANK, n)).astype(np.int32)
+    dur = rng.integers(0, len(om.cfg.durations), n).astype(np.int32)
+    o2 = om.tdt_score(enc, lab, dur)
+    g2 = gm.tdt_score(enc, lab, dur)
+    assert g2["n"] == o2["n"] and 10 < o2["n"] <= n
+    G.assert_bits_equal(g2["label_lp"], o2["label_lp"], "label log-prob rows along a random path")
+    G.assert_bits_equal(g2["dur_lp"], o2["dur_lp"], "duration log-prob rows along a random path")

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/tdt600m_depth24_score_seed42.npz: the TEACHER-FORCED joint scores of BASELINE configs[2] (tdt-600m, 24 layers, 30 s
+clips) along the CPU oracle's own greedy decision paths -- the logits-level half of the configs[2] parity statement ("TDT logits within
+stated fp tolerance", BASELINE.json north_star; round-3 verdict: the token contract alone leaves every decision after the first near-tie
+unexamined).
+
+Same clips and weights as tools/make_golden_600m.py (synth_pcm(32, 480000, seed=1234)[:3], synth_weights(tdt-600m, seed=42)).  For the fp32
+oracle and for the bf16-mode oracle (pk_config.gemm_bf16), per clip:
+
+  labels / dur_idx      the decision of EVERY step of the oracle's greedy decode (blank steps included; duration as an index into {0,1,2,3,4})
+  dur_lp                the duration head's log-probs of every step                                                  [n][5]
+  top_ids / top_lp      the K = 8 most probable labels of every step and their log-probs                             [n][8]
+  forced_lp             log-prob of the chosen label (= top_lp[:, 0] for a greedy path)
+  margin                top-1 minus top-2 label log-prob, and the duration head's                                     [n][2]
+  row_xor / row_sum     fp32 only: xor and uint64 sum of the bit patterns of the whole label log-prob row              [n]
+
+tests/test_gpu_600m_depth.py walks these paths on the GPU with pk_tdt_score (loop of /root/reference/src/tdt.cpp:62-106, the decision given
+instead of the argmax): fp32 rows bit-identical, bf16 |delta log-prob| within the stated bound at every step of every clip, and every
+decision whose margin exceeds the bound agrees.  The oracle is run ONCE here (authoring container, ~15 min on 8 threads); the GPU box reads
+only the file.
+"""
+import dataclasses
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+OUT = os.path.join(ROOT, "tests", "golden", "tdt600m_depth24_score_seed42.npz")
+N_CLIPS, N_SAMPLES, PCM_SEED, BATCH, K = 3, 480000, 1234, 32, 8
+
+
+def main():
+    import pkload
+    pk = pkload.load()
+    from parakeet_cpp_amd import synth
+    import oracle
+    threads = min(8, os.cpu_count() or 1)
+    oracle.set_threads(threads)
+    cfg = pk.make_tdt_600m_config()
+    W = synth.synth_weights(cfg, seed=42)
+    pcm = synth.synth_pcm(BATCH, N_SAMPLES, seed=PCM_SEED)[:N_CLIPS]
+    feats = np.stack([oracle.mel(p, n_mels=cfg.mel_bins) for p in pcm])
+    out = {"n_clips": N_CLIPS, "n_samples": N_SAMPLES, "pcm_seed": PCM_SEED, "pcm_batch": BATCH, "weights_seed": 42, "top_k": K,
+           "pcm_digest": np.asarray(pcm, np.float64).sum(axis=1), "durations": np.asarray(cfg.durations, np.int32)}
+    for mode in ("fp32", "bf16"):
+        om = oracle.Model(dataclasses.replace(cfg, gemm_bf16=(mode == "bf16")), W)
+        t = time.time()
+        enc = om.encoder(feats)
+        print(f"{mode}: 24-layer encoder of {N_CLIPS} clips in {time.time() - t:.1f}s on {threads} threads", flush=True)
+        per = []
+        for b in range(N_CLIPS):
+            r = om.tdt_score(enc[b])
+            lp = r["label_lp"]
+            n = r["n"]
+            order = np.argsort(-lp, axis=1, kind="stable")[:, :K].astype(np.int32)
+            top = np.take_along_axis(lp, order, axis=1)
+            dsort = np.sort(r["dur_lp"], axis=1)
+            margin = np.stack([top[:, 0] - top[:, 1], dsort[:, -1] - dsort[:, -2]], axis=1).astype(np.float32)
+            assert np.array_equal(order[:, 0], r["labels"]), "the greedy path follows the first maximum"
+            g = om.tdt_greedy(enc[b][None])
+            toks = [int(k) for k in r["labels"] if k != cfg.blank_id]
+            assert toks == g["ids"][0, :g["lens"][0]].tolist() and n == g["steps"][0], "orc_tdt_score's greedy walk == orc_tdt_greedy"
+            u = np.ascontiguousarray(lp).view(np.uint32)
+            per.append(dict(n=n, labels=r["labels"], dur_idx=r["dur_idx"], dur_lp=r["dur_lp"], top_ids=order, top_lp=top,
+                            forced_lp=lp[np.arange(n), r["labels"]], margin=margin, row_xor=np.bitwise_xor.reduce(u, axis=1),
+                            row_sum=u.astype(np.uint64).sum(axis=1)))
+            print(f"  clip {b}: {n} steps, {len(toks)} tokens, smallest label margin {margin[:, 0].min():.2e}, duration margin {margin[:, 1].min():.2e}", flush=True)
+        nmax = max(p["n"] for p in per)
+        out[mode + "_n"] = np.array([p["n"] for p in per], np.int32)
+        for key, fill in (("labels", -1), ("dur_idx", -1), ("dur_lp", 0), ("top_ids", -1), ("top_lp", 0), ("forced_lp", 0), ("margin", 0),
+                          ("row_xor", 0), ("row_sum", 0)):
+            if mode == "bf16" and key in ("row_xor", "row_sum"):
+                continue
+            a0 = per[0][key]
+            arr = np.full((N_CLIPS, nmax) + a0.shape[1:], fill, a0.dtype)
+            for b, p in enumerate(per):
+                arr[b, :p["n"]] = p[key]
+            out[f"{mode}_{key}"] = arr
+        del om
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    np.savez_compressed(OUT, **out)
+    print(f"wrote {OUT}: {os.path.getsize(OUT) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
