@@ -80,3 +80,79 @@ def test_stream_push_equals_stages_and_emits(tmp_path_factory, orc):
     again = sum(int(gs.push(pcm[:, i * chunk:(i + 1) * chunk])["lens"].sum()) for i in range(n_chunks))
     assert again == total
     gs.close()
+
+
+# ---- full depth: BASELINE configs[4] at its own shapes ------------------------------------------------------------------------------------
+import os  # noqa: E402
+
+from conftest import ROOT  # noqa: E402
+
+STREAM_GOLD = os.path.join(ROOT, "tests", "golden", "nemotron600m_stream_depth24_seed42.npz")
+
+
+def _bits_sum_xor(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).ravel()
+    if u.size == 0:
+        return np.zeros(2, np.uint64)
+    return np.array([int(u.astype(np.uint64).sum() & 0xFFFFFFFFFFFFFFFF), int(np.bitwise_xor.reduce(u))], np.uint64)
+
+
+def test_full_depth_nemotron_600m_16_streams(tmp_path):
+    """nemotron-600m as shipped (24 layers, d 1024, vocab 8193, 2 LSTM layers; att_context 70 / 1, 160 ms chunks): 16 lock-step streams on the
+    GPU, chunk by chunk against the 24-layer CPU oracle's committed outputs (tools/make_golden_stream_600m.py) -- log-mel and encoder output
+    bits of every chunk through the staged calls, token ids / frames / confidence bits of every chunk through pk_stream_push -- and against
+    the token ids of the reference's own streaming classes (/root/reference/src/streaming_encoder.cpp:162-272,430-472, src/nemotron.cpp:24-52,
+    src/eou.cpp:17-98) recorded in the same fixture."""
+    if not os.path.exists(STREAM_GOLD):
+        pytest.skip("tests/golden/nemotron600m_stream_depth24_seed42.npz is missing (tools/make_golden_stream_600m.py)")
+    g = np.load(STREAM_GOLD, allow_pickle=False)
+    cfg = pk.make_nemotron_600m_config()
+    W = synth.synth_weights(cfg, seed=int(g["weights_seed"]))
+    wp = str(tmp_path / "nemotron600m.safetensors")
+    synth.save_weights(wp, W)
+    del W
+    S0, n_chunks, chunk = int(g["n_streams"]), int(g["n_chunks"]), int(g["chunk"])
+    pcm0 = synth.synth_pcm(S0, chunk * n_chunks, seed=int(g["pcm_seed"]))
+    assert np.array_equal(np.asarray(pcm0, np.float64).sum(axis=1), g["pcm_digest"]), "the regenerated audio differs from the fixture's"
+    S = 16
+    pcm = np.ascontiguousarray(pcm0[np.arange(S) % S0])            # stream s carries the audio of fixture stream s % 2
+    gm = capi.Model(wp, cfg, device=0)
+    left, right, mt = int(g["att_left"]), int(g["att_right"]), int(g["max_tok"])
+    # pass 1: the product call, device-resident stages
+    gs = capi.Stream(gm, S, left, right)
+    total = 0
+    for i in range(n_chunks):
+        r = gs.push(pcm[:, i * chunk:(i + 1) * chunk], max_tokens=mt)
+        for s in range(S):
+            n = int(g["n_tok"][i, s % S0])
+            assert r["lens"][s] == n, f"chunk {i} stream {s}: {r['lens'][s]} tokens, the oracle emitted {n}"
+            assert np.array_equal(r["ids"][s, :n], g["ids"][i, s % S0, :n]), f"chunk {i} stream {s}: token ids"
+            assert np.array_equal(r["start"][s, :n], g["start"][i, s % S0, :n]) and np.array_equal(r["end"][s, :n], g["end"][i, s % S0, :n]), f"chunk {i} stream {s}: frames"
+            assert np.array_equal(r["conf"][s, :n].view(np.uint32), g["conf_bits"][i, s % S0, :n]), f"chunk {i} stream {s}: confidence bits"
+            total += n
+    assert total >= 8 * int(g["n_tok"].sum()) > 0, "degenerate test: nothing decoded"
+    gs.close()
+    # pass 2: stage by stage (a fresh session set): the bits of every chunk's log-mel and encoder output
+    gs = capi.Stream(gm, S, left, right)
+    for i in range(n_chunks):
+        m = gs.mel(pcm[:, i * chunk:(i + 1) * chunk])
+        assert m.shape[1] == int(g["mel_n"][i, 0])
+        for s in range(S):
+            assert np.array_equal(_bits_sum_xor(m[s]), g["mel_bits"][i, s % S0]), f"chunk {i} stream {s}: log-mel bits"
+        if m.shape[1] == 0:
+            continue
+        e = gs.encode(m)
+        assert e.shape[1] == int(g["enc_n"][i, 0])
+        if e.shape[1] == 0:
+            continue
+        for s in range(S):
+            assert np.array_equal(e[s, 0].view(np.uint32), g["enc_row0"][i, s % S0].view(np.uint32)), f"chunk {i} stream {s}: first encoder row"
+            assert np.array_equal(_bits_sum_xor(e[s]), g["enc_bits"][i, s % S0]), f"chunk {i} stream {s}: 24-layer encoder output bits"
+        d = gs.decode(e, max_tokens=mt)
+        for s in range(S):
+            n = int(g["n_tok"][i, s % S0])
+            assert d["lens"][s] == n and np.array_equal(d["ids"][s, :n], g["ids"][i, s % S0, :n])
+    gs.close()
+    gm.close()
+    if "ref_equal_oracle" in g.files:
+        assert bool(g["ref_equal_oracle"]), "fixture: the oracle's tokens differed from the reference code's on stream 0"
