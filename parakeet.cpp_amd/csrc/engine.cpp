@@ -1161,10 +1161,12 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         const bool want = decode_loop == PK_DECODE_LOOP_PERSISTENT && !dec16 && !w.force_label;     // (the single-launch loop exists for the fp32 phases only)
         const int G = Hp / 4;
         if (want && !boost_on && !keep_state && Hp % 4 == 0 && G >= 1 && G <= 200 && L <= 2 && tdt_persistent_lds_bytes(st) <= 12 * 1024) {
-            P.bar = reinterpret_cast<unsigned *>(st.done_count + 1);           // two spare words behind the per-utterance state
-            P.abort = st.done_count + 2;
+            w.persist_bar.reserve((size_t)kTdtBarrierWords * sizeof(unsigned));
+            P.bar = w.persist_bar.as<unsigned>();
+            P.abort = st.done_count + 2;                                       // (a spare word behind the per-utterance state)
             P.timeout_ticks = 200000000LL;                                     // 2 s of the 100 MHz wall clock
-            PK_HIP(hipMemsetAsync(P.bar, 0, 2 * sizeof(int), s));
+            PK_HIP(hipMemsetAsync(P.bar, 0, (size_t)kTdtBarrierWords * sizeof(unsigned), s));
+            PK_HIP(hipMemsetAsync(P.abort, 0, sizeof(int), s));
             KL("tdt_persistent", (f_hh * L + f_pp + f_hd) * (T + 8), 0.0, launch_tdt_persistent(P, s));
             return;
         }

@@ -93,6 +93,7 @@ struct Workspace {
     DevBuf pcm, logmel, feats, a2, a3, a4, a5, flat, x, n, hbuf, qkv, ctx, g, dwb;
     DevBuf ctc_logits, ctc_lp, best_idx, best_lp;
     DevBuf ep, gh, gi, pp, z, logits, h, c, hn, cn, ints, ids, start, end, conf, lens, margin;
+    DevBuf persist_bar;         // barrier words of the single-launch decode loop (kTdtBarrierWords)
     DevBuf trie_act;            // phrase boosting: per-utterance active trie states [B][kTrieMaxActive] + counts [B]
     // captured chunk of decode steps (Model::run_tdt): replayed while the step-invariant kernel arguments stay the same
     hipGraphExec_t dec_graph = nullptr;

@@ -7,8 +7,8 @@
 // NEXT batch, which runs concurrently on the other stream, 2.5-6 us (kernel boundaries carry cache release / acquire work): 1.3 ms of
 // a 20 ms step.  Here the batch is decoded by one persistent grid:
 //  * G = Hp/4 workgroups of 256 threads (160 for Hp = 640: one per LSTM gate-column tile), all co-resident (one per CU is enough).
-//  * The phases of a step run back to back inside the kernel, separated by a grid barrier: one arrival counter in global memory,
-//    system-scope relaxed atomics, s_sleep while polling.  NO agent-scope fence is used (it would write back and invalidate the
+//  * The phases of a step run back to back inside the kernel, separated by a grid barrier (XCD-hierarchical since round 4: per-XCC arrival
+//    counters under a top counter, relaxed atomics, s_sleep while polling).  NO agent-scope fence is used (it would write back and invalidate the
 //    XCD's whole L2 under the concurrently running encoder GEMMs): the few words the workgroups exchange (h', c', z, logits, token,
 //    frame index, flags) are written and read with system-scope accesses (sc0 sc1), and a workgroup arrives at the barrier only after
 //    s_waitcnt vmcnt(0) has confirmed its stores.
@@ -32,23 +32,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     unsigned phase = 0;
     bool aborted = false;
 
+    // Grid barrier, XCD-hierarchical (MI355X_MICROARCH.md "barrier-xcd"; measured with tools/ubench/grid_barrier.cpp on an idle chip at 160
+    // workgroups: 2.7 us against 3.2 us for one flat counter, 5.3 against 6.4 us with 3-9 us of skewed phase work): every workgroup arrives on
+    // the counter of ITS XCC (8 independent words instead of one: the arrivals no longer serialise on a single address), the XCC's last
+    // arriver goes up to a top counter that sees 8 arrivals, waits there for all XCCs and then bumps its XCC's generation word, which the other
+    // workgroups of the XCC poll.  Where a workgroup runs is READ (HW_REG_XCC_ID), never assumed: a census of workgroups per XCC is taken at
+    // kernel start behind one flat barrier.  All words are agent / system-scope atomics at the memory side (workgroup-scope atomics are not
+    // coherent between the CUs of an XCC: measured, the barrier then never completes); no cache-wide fence is involved -- the exchanged
+    // vectors keep travelling through system-scope accesses (see the header).
+    unsigned *const bw = p.bar;                                      // [0] flat (census barrier), [32] top, [64 + 32 x] census / arrivals / generation of XCC x
+    __shared__ unsigned s_x, s_nx, s_nxcc;
+    auto spin = [&](auto cond) {                                     // bounded poll: true = gave up (abort raised here or elsewhere)
+        const long long t0 = wall_clock64();
+        while (cond()) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return true;
+            if (wall_clock64() - t0 > p.timeout_ticks) {
+                __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return true;
+            }
+        }
+        return false;
+    };
+    if (tid == 0) {
+        const unsigned x = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;     // HW_REG_XCC_ID
+        s_x = x;
+        __hip_atomic_fetch_add(bw + 64 + 96 * x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(bw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        int ab = spin([&] { return __hip_atomic_load(bw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (unsigned)G; }) ? 1 : 0;
+        unsigned nx = 0;
+        for (int i = 0; i < 8; ++i) nx += __hip_atomic_load(bw + 64 + 96 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 1u : 0u;
+        s_nx = __hip_atomic_load(bw + 64 + 96 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_nxcc = nx;
+        s_ctl = ab;
+    }
+    __syncthreads();
+    if (s_ctl) aborted = true;
+    unsigned *const xarr = bw + 64 + 96 * s_x + 32, *const xgen = xarr + 32;
+    const unsigned n_x = s_nx, n_xcc = s_nxcc;
+
     auto grid_barrier = [&]() {
         __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): this thread's system-scope stores are performed
         __syncthreads();
         ++phase;
         if (tid == 0) {
-            __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const unsigned target = phase * (unsigned)G;
-            const long long t0 = wall_clock64();
             int ab = 0;
-            while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (__hip_atomic_load(p.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { ab = 1; break; }
-                if (wall_clock64() - t0 > p.timeout_ticks) {
-                    __hip_atomic_store(p.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    ab = 1;
-                    break;
-                }
+            const unsigned old = __hip_atomic_fetch_add(xarr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1 == phase * n_x) {                            // this XCC's last arriver
+                __hip_atomic_fetch_add(bw + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ab = spin([&] { return __hip_atomic_load(bw + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < phase * n_xcc; }) ? 1 : 0;
+                __hip_atomic_fetch_add(xgen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (also when aborting: the pollers see the flag anyway)
+            } else {
+                ab = spin([&] { return __hip_atomic_load(xgen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase; }) ? 1 : 0;
             }
             s_ctl = ab;
         }

@@ -260,10 +260,11 @@ struct TdtPersist {
     int L;
     SkinnyArgs cell[4], ih[4];      // per LSTM layer: W_hh product + cell ; (l > 0) W_ih product of the layer below's h'
     SkinnyArgs act, heads;          // joint activation ; label (+ duration) heads
-    unsigned *bar;                  // grid-barrier arrival counter (zeroed before the launch)
+    unsigned *bar;                  // grid-barrier words, kTdtBarrierWords of them, zeroed before the launch (decode_persist.hip)
     int *abort;                     // set by a workgroup whose barrier wait timed out
     long long timeout_ticks;        // wall_clock64 ticks (100 MHz)
 };
+constexpr int kTdtBarrierWords = 64 + 8 * 96;
 size_t tdt_persistent_lds_bytes(const TdtState &st);
 void launch_tdt_persistent(const TdtPersist &p, hipStream_t s);
 
