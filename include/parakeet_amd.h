@@ -277,6 +277,14 @@ typedef struct pk_result {      /* TranscribeResult (transcribe.hpp:23-30) + Tim
  * results: array of n_clips pk_result, owned by the library until pk_results_free. */
 pk_status pk_transcribe_pcm(pk_model *m, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt,
                             pk_result **results);
+/* The packing policy of pk_transcribe_pcm / pk_group_transcribe_pcm on its own (host logic, no GPU needed): clips of n_samples[i] samples
+ * are sorted by length (longest first, stable) and cut into batches of <= 256 clips and <= 64 x 10 s of audio; batch_of_clip[i] = the
+ * batch clip i lands in (batch 0 holds the longest clips), pos_in_batch[i] (optional) = its row in that batch. */
+pk_status pk_plan_batches(const int64_t *n_samples, int n_clips, int32_t *batch_of_clip, int32_t *pos_in_batch, int *n_batches);
+/* Per-clip extents of a ragged batch (host logic): mel frames pk_mel_num_frames(n), encoder frames pk_encoder_num_frames(...) of every
+ * clip; totals (optional, 7 values): samples, mel frames, rows after the second stride-2 stage, encoder rows, attention row blocks,
+ * depthwise-conv strips, subsampling strips of the packed batch -- what the ragged kernels' grids are sized by. */
+pk_status pk_ragged_extents(const int64_t *n_samples, int n_clips, int32_t *n_mel_frames, int32_t *n_enc_frames, int64_t *totals);
 void pk_results_free(pk_result *results, int n_clips);
 /* ---- one node, several GPUs: utterance shards (the reference has no multi-device path, README.md:513) ----------
  * A pk_group is one model REPLICA per device of this process: the safetensors file is mapped once and every replica is built from that

@@ -119,6 +119,8 @@ _LATE_SIGNATURES = {
     "pk_ctc_decode": [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, f32p],
     "pk_tdt_decode": [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, f32p, i32p],
     "pk_model_set_decode_loop": [C.c_void_p, C.c_int],
+    "pk_plan_batches": [i64p, C.c_int, i32p, i32p, C.POINTER(C.c_int)],
+    "pk_ragged_extents": [i64p, C.c_int, i32p, i32p, i64p],
     "pk_tdt_score": [C.c_void_p, f32p, C.c_int, i32p, i32p, C.c_int, f32p, f32p, C.POINTER(C.c_int)],
     "pk_mel_ragged": [C.c_void_p, f32p, i64p, C.c_int, f32p, f32p],
     "pk_encode_ragged": [C.c_void_p, f32p, i32p, C.c_int, C.c_int, C.c_int, f32p],
@@ -182,6 +184,21 @@ def check(st):
         buf = C.create_string_buffer(2048)
         lib().pk_last_error(buf, 2048)
         raise PkError(st, buf.value.decode(errors="replace"))
+
+
+def plan_batches(n_samples):
+    """pk_plan_batches: how the one-call API packs clips of these lengths -> (batch_of_clip, pos_in_batch, n_batches).  Host logic."""
+    n = np.ascontiguousarray(n_samples, np.int64)
+    b = np.zeros(len(n), np.int32); p = np.zeros(len(n), np.int32); nb = C.c_int(0)
+    check(lib().pk_plan_batches(n.ctypes.data_as(i64p), len(n), _i(b), _i(p), C.byref(nb)))
+    return b, p, nb.value
+
+
+def ragged_extents(n_samples):
+    n = np.ascontiguousarray(n_samples, np.int64)
+    tm = np.zeros(len(n), np.int32); t = np.zeros(len(n), np.int32); tot = np.zeros(7, np.int64)
+    check(lib().pk_ragged_extents(n.ctypes.data_as(i64p), len(n), _i(tm), _i(t), tot.ctypes.data_as(i64p)))
+    return tm, t, tot
 
 
 def device_count():

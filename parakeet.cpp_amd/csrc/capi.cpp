@@ -1068,6 +1068,55 @@ struct ResultStore {          // owns everything a pk_result array points into
 };
 }  // namespace
 
+// The packing policy of the one-call API (pure host logic; pk_plan_batches exposes it): clips sorted by length, longest first (stable), then
+// cut greedily into batches of at most kMaxBatchClips clips and kBatchSamples samples (a single longer clip gets a batch of its own).
+static const int kMaxBatchClips = 256;
+static const int64_t kBatchSamples = (int64_t)64 * 160000;       // 64 x 10 s: ~8000 encoder rows per batch, where the GEMMs run at their best
+static void plan_batches(const int64_t *len, int n, std::vector<int> &order, std::vector<int> &bstart) {
+    order.resize(n);
+    for (int i = 0; i < n; ++i) {
+        need(len[i] > 256, "every clip needs more than 256 samples");
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+    bstart.clear();
+    for (int i = 0; i < n;) {
+        bstart.push_back(i);
+        int64_t tot = 0;
+        int j = i;
+        while (j < n && j - i < kMaxBatchClips && (j == i || tot + len[order[j]] <= kBatchSamples)) tot += len[order[j++]];
+        i = j;
+    }
+    bstart.push_back(n);
+}
+
+pk_status pk_plan_batches(const int64_t *n_samples, int n_clips, int32_t *batch_of_clip, int32_t *pos_in_batch, int *n_batches) {
+    return guard([&] {
+        need(n_samples && n_clips > 0 && batch_of_clip, "n_samples/n_clips/batch_of_clip");
+        std::vector<int> order, bstart;
+        plan_batches(n_samples, n_clips, order, bstart);
+        for (size_t k = 0; k + 1 < bstart.size(); ++k)
+            for (int i = bstart[k]; i < bstart[k + 1]; ++i) {
+                batch_of_clip[order[i]] = (int32_t)k;
+                if (pos_in_batch) pos_in_batch[order[i]] = i - bstart[k];
+            }
+        if (n_batches) *n_batches = (int)bstart.size() - 1;
+    });
+}
+
+pk_status pk_ragged_extents(const int64_t *n_samples, int n_clips, int32_t *n_mel_frames, int32_t *n_enc_frames, int64_t *totals) {
+    return guard([&] {
+        need(n_samples && n_clips > 0, "n_samples/n_clips");
+        RagBatch r;
+        r.build_from_samples(n_samples, n_clips, 32);
+        for (int i = 0; i < n_clips; ++i) {
+            if (n_mel_frames) n_mel_frames[i] = r.Tm[i];
+            if (n_enc_frames) n_enc_frames[i] = r.T[i];
+        }
+        if (totals) { totals[0] = r.n_samples; totals[1] = r.sum_Tm; totals[2] = r.sum_H2; totals[3] = r.sum_T; totals[4] = r.n_u_att; totals[5] = r.n_u_dw; totals[6] = r.n_u_c1; }
+    });
+}
+
 // Transcriber::transcribe (transcribe.hpp:99-179) of the clips listed in `clips` (global indices into offsets), results into the slots
 // of the same indices of R.  One model, one device; called by pk_transcribe_pcm (all clips) and by every rank of a pk_group.
 static void transcribe_clips(Model &m, const float *pcm, const int64_t *offsets, const std::vector<int> &clips, const pk_options *opt,
@@ -1094,27 +1143,22 @@ static void transcribe_clips(Model &m, const float *pcm, const int64_t *offsets,
     // loop of a batch ends for all of them at about the same step.  The batches go through the model's two-stream pipeline (struct
     // pk_batch): PCM of batch k+1 is staged on the copy stream and decode(k) -- or, from four batches on, the decode loops of four batches as
     // one lock-step group -- runs under encoder(k+1).  A batch whose clips all have the same length runs the plain uniform kernels.
-    std::vector<int> order(clips);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b]; });
-    const int n_clips = (int)order.size();
+    const int n_clips = (int)clips.size();
     if (n_clips == 0) return;
-    const int kMaxBatchClips = 256;
-    const int64_t kBatchSamples = (int64_t)64 * 160000;           // 64 x 10 s: ~8000 encoder rows per batch, where the GEMMs run at their best
+    std::vector<int64_t> clip_len(n_clips);
+    for (int i = 0; i < n_clips; ++i) clip_len[i] = offsets[clips[i] + 1] - offsets[clips[i]];
+    std::vector<int> order, bstart;                                // order: positions in `clips`, longest first; bstart: first position of every batch, + the end
+    plan_batches(clip_len.data(), n_clips, order, bstart);
+    for (auto &o : order) o = clips[o];                            // ... as global clip indices from here on
     auto len_of = [&](int i) { return offsets[order[i] + 1] - offsets[order[i]]; };
-    for (int i = 0; i < n_clips; ++i) need(len_of(i) > 256, "every clip needs more than 256 samples");
-    std::vector<int> bstart;                                       // first clip (position in `order`) of every batch, + the end
     int64_t cap_total = 0;
     int cap_clips = 0;
-    for (int i = 0; i < n_clips;) {
-        bstart.push_back(i);
+    for (size_t k = 0; k + 1 < bstart.size(); ++k) {
         int64_t tot = 0;
-        int j = i;
-        while (j < n_clips && j - i < kMaxBatchClips && (j == i || tot + len_of(j) <= kBatchSamples)) tot += len_of(j++);
+        for (int i = bstart[k]; i < bstart[k + 1]; ++i) tot += len_of(i);
         cap_total = std::max(cap_total, tot);
-        cap_clips = std::max(cap_clips, j - i);
-        i = j;
+        cap_clips = std::max(cap_clips, bstart[k + 1] - bstart[k]);
     }
-    bstart.push_back(n_clips);
     const int nb = (int)bstart.size() - 1;
     std::vector<int32_t> ids, st, en, lens;
     std::vector<float> cf;
