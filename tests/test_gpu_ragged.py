@@ -244,3 +244,62 @@ def test_ragged_bf16_mode_close_to_uniform(tmp_path):
         assert err < 2e-2, f"clip {i}: {err:.3e}"
     res = gm.transcribe_pcm(clips, decoder="tdt")
     assert all(len(r["token_ids"]) >= 0 for r in res)
+
+
+def _norm_rows(rng, t, d):
+    x = rng.standard_normal((t, d)).astype(np.float32)
+    return (x - x.mean(-1, keepdims=True)) / x.std(-1, keepdims=True)
+
+
+def test_ragged_boosted_decoders_vs_oracle(tiny_pair, orc):
+    """Phrase boosting (src/phrase_boost.cpp:70-350) on a ragged batch: the boosted CTC walk and the boosted TDT loop with per-clip frame
+    counts, against the oracle's single-utterance boosted decoders."""
+    W, om, gm = tiny_pair
+    rng = np.random.default_rng(17)
+    T = [126, 48, 7, 90, 33, 126, 1, 60]
+    xs = [_norm_rows(rng, t, om.cfg.hidden_size) for t in T]
+    V, blank = om.cfg.vocab_size, om.cfg.blank_id
+    base = [om.tdt_greedy(x[None]) for x in xs]
+    ph = []
+    for r in base:
+        toks = r["ids"][0, :r["lens"][0]].tolist()
+        if len(toks) >= 4:
+            ph.append(toks[:2] + [int(rng.integers(0, V - 1))])
+            ph.append(toks[1:3] + [int(rng.integers(0, V - 1)), int(rng.integers(0, V - 1))])
+    ph += [[int(t) for t in rng.integers(0, V - 1, size=4)] for _ in range(5)]
+    trie = orc.Trie(ph)
+    try:
+        gm.set_boost_tokens(ph, 5.0)
+        gm._boosted = True
+        g = gm.tdt_decode_ragged(xs)
+        c = gm.ctc_decode_ragged(xs)
+    finally:
+        gm.set_boost_tokens([])
+        gm._boosted = False
+    changed = 0
+    for i, x in enumerate(xs):
+        o = om.tdt_greedy_boosted(x[None], trie, 5.0)
+        same_tokens(g, i, o, 0, f"boosted TDT utterance {i} (T = {T[i]})")
+        changed += o["ids"][0, :o["lens"][0]].tolist() != base[i]["ids"][0, :base[i]["lens"][0]].tolist()
+        oc = orc.ctc_greedy_boosted(om.ctc_logprobs(x[None]), om.cfg.ctc_vocab_size - 1, trie, 5.0)
+        same_tokens(c, i, oc, 0, f"boosted CTC utterance {i} (T = {T[i]})")
+    assert changed > 0, "degenerate test: the boost changed nothing"
+
+
+def test_ragged_rnnt_head_and_two_lstm_layers(tmp_path):
+    """The RNNT head (src/rnnt.cpp:56-177: no duration head, max_symbols per frame) and a two-layer prediction net on a ragged batch."""
+    cfg = G.tiny(num_layers=1, head="rnnt", durations=[], joint_prefix="joint_.", ctc_vocab_size=0, num_lstm_layers=2, name="tiny-rnnt-ragged")
+    W, om, gm = G.make_pair(tmp_path, cfg, seed=9)
+    rng = np.random.default_rng(23)
+    T = [40, 126, 3, 77, 19, 64]
+    xs = [_norm_rows(rng, t, cfg.hidden_size) for t in T]
+    g = gm.tdt_decode_ragged(xs)
+    n = 0
+    for i, x in enumerate(xs):
+        o = om.rnnt_greedy(x[None])
+        k = o["lens"][0]
+        assert g["lens"][i] == k, f"utterance {i}: {g['lens'][i]} vs {k} tokens"
+        assert np.array_equal(g["ids"][i, :k], o["ids"][0, :k]) and np.array_equal(g["start"][i, :k], o["start"][0, :k])
+        assert np.array_equal(G.bits(g["conf"][i, :k]), G.bits(o["conf"][0, :k]))
+        n += k
+    assert n > 5, "degenerate decode"

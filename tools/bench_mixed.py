@@ -41,6 +41,17 @@ def timed_steps(L, capi, batch, dec, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def kernel_ms(L, capi, batch, dec, n=3):
+    """per-kernel HIP-event milliseconds of one un-pipelined step (pk_batch_profile), averaged over n steps; decode-loop kernels summed"""
+    agg = {}
+    for _ in range(n):
+        stats = (capi.PkKernelStat * 64)()
+        nk = L.pk_batch_profile(batch, dec, stats, 64)
+        for i in range(max(0, min(nk, 64))):
+            agg[stats[i].name.decode()] = agg.get(stats[i].name.decode(), 0.0) + stats[i].total_ms / n
+    return {k: round(v, 3) for k, v in agg.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
@@ -92,7 +103,13 @@ def main():
     rtfx_mx = audio_s / s_mx
     ms = np.zeros(4, np.float32)
     capi.check(L.pk_batch_run_timed(bt._h, dec, ms.ctypes.data_as(capi.f32p)))
+    kern_mx = kernel_ms(L, capi, bt._h, dec)
     bt.close()
+    eq2 = C.c_void_p()
+    capi.check(L.pk_batch_create(model._h, 64, 160000, C.byref(eq2)))
+    capi.check(L.pk_batch_upload(eq2, pcm_eq.ctypes.data_as(capi.f32p), 64))
+    kern_eq = kernel_ms(L, capi, eq2, dec)
+    L.pk_batch_free(eq2)
 
     # parity of the timed batch: every clip vs its single-clip transcription; a sample vs the CPU oracle
     mism = 0
@@ -134,6 +151,7 @@ def main():
                            "shortest_s": round(min(lens) / 16000, 2), "longest_s": round(max(lens) / 16000, 2), "decode_group": args.group,
                            "stage_ms_unpipelined": {"mel": round(float(ms[0]), 3), "encoder": round(float(ms[1]), 3), "decode": round(float(ms[2]), 3)}},
         "mixed_over_equal": round(rtfx_mx / rtfx_eq, 4),
+        "kernel_ms_unpipelined": {k: {"equal": kern_eq.get(k), "mixed": kern_mx.get(k)} for k in sorted(set(kern_eq) | set(kern_mx))},
         "one_call_from_host": {"clips": args.clips, "audio_s": round(audio2, 1), "wall_s": round(best, 4), "rtfx": round(audio2 / best, 1),
                                "note": "pk_transcribe_pcm: sort, pack (<= 256 clips / 640 s per batch), PCIe uploads, pipeline, results, detokenise-free; best of 3"},
         "one_clip_at_a_time": {"clips": len(clips), "wall_s": round(s_serial, 4), "rtfx": round(audio_s / s_serial, 1),
