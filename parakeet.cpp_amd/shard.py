@@ -14,6 +14,22 @@ def shard_indices(n_items: int, rank: int, world: int, batch: int = 64) -> List[
     return out
 
 
+def shard_by_audio(lengths: Sequence[int], rank: int, world: int) -> List[int]:
+    """Mixed-length clips (round 4): the partition pk_group_transcribe_pcm uses inside one process, for the one-process-per-GPU deployment --
+    clips sorted by length, longest first (stable), each dealt to the rank with the least audio so far (lowest rank on ties; equal lengths:
+    rank r takes clips r, r + world, ...).  Every rank then packs ITS clips into ragged batches (pk_transcribe_pcm).  Deterministic, the same
+    on every rank, no communication.  Returns the clip indices owned by `rank`, longest first."""
+    order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
+    load = [0] * world
+    mine = []
+    for i in order:
+        r = min(range(world), key=lambda q: load[q])
+        load[r] += int(lengths[i])
+        if r == rank:
+            mine.append(i)
+    return mine
+
+
 def gather_results(local: Sequence, local_idx: Sequence[int], n_items: int, world: int, dist=None) -> list:
     """All-gather per-rank (index, result) lists and reassemble them in the original clip order on every rank."""
     if world == 1 or dist is None:

@@ -9,7 +9,7 @@ import sys
 import textwrap
 
 from conftest import ROOT, pk  # noqa: F401
-from parakeet_cpp_amd.shard import gather_results, shard_indices
+from parakeet_cpp_amd.shard import gather_results, shard_by_audio, shard_indices
 
 
 def test_shard_partition_properties():
@@ -25,6 +25,24 @@ def test_shard_partition_properties():
         assert sorted(seen) == list(range(n))
     assert len(shard_indices(8192, 3, 8, 64)) == 1024         # BASELINE configs[3]: 1024 clips per GPU
     assert gather_results(["a", "b"], [1, 0], 2, 1) == ["b", "a"]
+
+
+def test_shard_by_audio_properties():
+    """Mixed-length corpora (round 4): every clip on exactly one rank, longest first, loads within one longest clip of each other, equal
+    lengths degenerate to round-robin, and the library's own in-process partition (pk_group_transcribe_pcm) follows the same rule."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for n, world in [(1000, 8), (37, 2), (5, 4), (64, 1), (3, 8)]:
+        lens = [int(x) for x in rng.integers(300, 480000, n)]
+        seen, loads = [], []
+        for r in range(world):
+            idx = shard_by_audio(lens, r, world)
+            assert [lens[i] for i in idx] == sorted((lens[i] for i in idx), reverse=True), "longest first on every rank"
+            seen += idx
+            loads.append(sum(lens[i] for i in idx))
+        assert sorted(seen) == list(range(n))
+        assert max(loads) - min(loads) <= max(lens), "greedy longest-first: no rank is more than one clip ahead"
+    assert shard_by_audio([160000] * 16, 3, 8) == [3, 11], "equal lengths: rank r takes clips r, r + world, ..."
 
 
 WORKER = textwrap.dedent("""
@@ -49,6 +67,16 @@ WORKER = textwrap.dedent("""
     gi, gl = gather_token_matrix(ids, lens, idx, n, world, dist)          # fixed-stride all_gather_into_tensor (RCCL on the GPU box)
     assert gl.tolist() == [1 + i % 5 for i in range(n)]
     assert all(gi[i, :gl[i]].tolist() == (np.arange(gl[i]) + 10 * i).tolist() for i in range(n)), "token matrix order"
+    # mixed-length corpus: the partition by audio (every rank computes it alone, no communication) and the same exchange
+    from parakeet_cpp_amd.shard import shard_by_audio
+    clip_len = [300 + (i * 7919) % 400000 for i in range(n)]
+    idx2 = shard_by_audio(clip_len, rank, world)
+    lens2 = np.array([1 + i % 5 for i in idx2], np.int32)
+    ids2 = np.zeros((len(idx2), 6), np.int32)
+    for r, i in enumerate(idx2):
+        ids2[r, :lens2[r]] = np.arange(lens2[r]) + 10 * i
+    gi2, gl2 = gather_token_matrix(ids2, lens2, idx2, n, world, dist)
+    assert gl2.tolist() == [1 + i % 5 for i in range(n)] and np.array_equal(gi2, gi), "mixed-length shards reassemble to the same matrix"
     # weight distribution: rank 0 reads the file once, one broadcast, every rank builds its model from the memory image
     from parakeet_cpp_amd.shard import broadcast_file
     from parakeet_cpp_amd import capi, synth

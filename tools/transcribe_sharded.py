@@ -90,6 +90,60 @@ def run(n_clips, batch, clip_samples, decoder, cfg_name="tdt-ctc-110m", layers=N
     return ids, lens, elapsed
 
 
+def run_mixed(n_clips, lo_s, hi_s, decoder, cfg_name="tdt-ctc-110m", layers=None, dist=None, rank=0, world=1, local_rank=0, barrier=None):
+    """Mixed-length corpus (round 4): clip i has a seeded random length in [lo_s, hi_s] seconds; shard.shard_by_audio deals the clips by audio,
+    every rank runs ITS clips through pk_transcribe_pcm (sorted, packed into ragged batches, two-stream pipeline; uploads and results inside
+    the clock), one all_gather of the token matrix at the end.  The corpus is a pure function of the clip index: any world size transcribes
+    the same audio and the digests are comparable."""
+    import dataclasses
+    import numpy as np
+    import pkload
+    pk = pkload.load()
+    from parakeet_cpp_amd import capi, shard, synth
+    cfg = pk.PRESETS[cfg_name]()
+    if layers:
+        cfg = dataclasses.replace(cfg, num_layers=layers, name=f"{cfg.name}-{layers}L")
+    wpath = f"/tmp/pk_sharded_{cfg.name}_{cfg.num_layers}_seed42.safetensors"
+    if local_rank == 0 and not os.path.exists(wpath):
+        synth.save_weights(wpath + f".{os.getpid()}", synth.synth_weights(cfg, seed=42))
+        os.replace(wpath + f".{os.getpid()}", wpath)
+    if barrier:
+        barrier()
+    model = capi.Model(wpath, cfg, device=local_rank)
+    rng = np.random.default_rng(2026)
+    lengths = [int(x) for x in rng.uniform(lo_s, hi_s, n_clips) * 16000]
+    idx = shard.shard_by_audio(lengths, rank, world)
+    POOL = 16                                              # distinct base clips at the longest length; clip i = a window of base clip i % POOL
+    base = synth.synth_pcm(POOL, int(hi_s * 16000) + 1, seed=4321)
+    clips = [base[i % POOL][(i * 37) % 97:(i * 37) % 97 + lengths[i]] for i in idx]
+    if clips:
+        model.transcribe_pcm(clips[:2], decoder=decoder)   # the pipeline's buffers exist before the clock starts
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    res = model.transcribe_pcm(clips, decoder=decoder) if clips else []
+    if barrier:
+        barrier()
+    elapsed = time.perf_counter() - t0
+    mt = max([len(r["token_ids"]) for r in res] + [1])
+    if world > 1:
+        import torch
+        t = torch.tensor([mt], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mt = int(t.item())
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ids_loc = np.zeros((len(res), mt), np.int32)
+    for k, r in enumerate(res):
+        ids_loc[k, :len(r["token_ids"])] = r["token_ids"]
+    lens_loc = np.asarray([len(r["token_ids"]) for r in res], np.int32)
+    ids, lens = shard.gather_token_matrix(ids_loc, lens_loc, idx, n_clips, world, dist if world > 1 else None,
+                                          device=f"cuda:{local_rank}" if world > 1 else None)
+    model.close()
+    return ids, lens, elapsed, sum(lengths) / 16000.0
+
+
 def digest(ids, lens):
     h = hashlib.sha256()
     for i in range(len(lens)):
@@ -107,6 +161,8 @@ def main():
     ap.add_argument("--config", default="tdt-ctc-110m")
     ap.add_argument("--layers", type=int, default=0, help="cut the encoder to this many layers (tests)")
     ap.add_argument("--broadcast-weights", action="store_true", help="rank 0 reads the weights once and broadcasts the image (RCCL)")
+    ap.add_argument("--mixed", type=float, nargs=2, metavar=("LO_S", "HI_S"), help="mixed-length corpus: clip lengths uniform in [LO_S, HI_S] seconds, "
+                    "sharded by audio, packed into ragged batches on every rank")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
@@ -121,6 +177,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.mixed:
+        ids, lens, elapsed, audio_s = run_mixed(args.clips, args.mixed[0], args.mixed[1], args.decoder, args.config, args.layers or None,
+                                                dist if world > 1 else None, rank, world, local_rank, barrier)
+        if rank == 0:
+            print(json.dumps({"workload": f"{args.config}: {args.clips} clips of {args.mixed[0]:g}-{args.mixed[1]:g} s (mixed lengths, packed), {args.decoder.upper()} greedy",
+                              "n_gpus": world, "audio_s": round(audio_s, 1), "wall_s": round(elapsed, 4), "rtfx": round(audio_s / elapsed, 1),
+                              "tokens": int(lens.sum()), "digest": digest(ids, lens),
+                              "note": "sharded by audio (shard.shard_by_audio), every rank's clips through pk_transcribe_pcm: sort, pack, PCIe, pipeline, results inside the clock"}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     n = int(args.clip_seconds * 16000)
     ids, lens, elapsed = run(args.clips, args.batch, n, args.decoder, args.config, args.layers or None, dist if world > 1 else None, rank, world,
                              local_rank, barrier, args.broadcast_weights)
