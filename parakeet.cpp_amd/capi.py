@@ -580,11 +580,21 @@ class Batch:
 
 
 # ---- model -------------------------------------------------------------------------------------------
-def _transcribe(fn, handle, clips, decoder, timestamps, boost_phrases, boost_score, with_raw=None):
+def pack_clips(clips):
+    """(pcm, offsets) of a list of clips: what pk_transcribe_pcm takes (one copy of the audio; do it outside a timed region)."""
     clips = [_c(c).ravel() for c in clips]
     off = np.zeros(len(clips) + 1, np.int64)
     off[1:] = np.cumsum([len(c) for c in clips])
-    pcm = np.concatenate(clips)
+    return np.concatenate(clips), off
+
+
+def _transcribe(fn, handle, clips, decoder, timestamps, boost_phrases, boost_score, with_raw=None):
+    if isinstance(clips, tuple):                             # already packed: (pcm, offsets)
+        pcm, off = clips
+        pcm, off = _c(pcm), np.ascontiguousarray(off, np.int64)
+        clips = range(len(off) - 1)
+    else:
+        pcm, off = pack_clips(clips)
     opt = PkOptions()
     opt.decoder = {"ctc": 0, "tdt": 1}[decoder]
     opt.timestamps = 1 if timestamps else 0

@@ -168,14 +168,15 @@ pk_status pk_mel(pk_model *h, const float *pcm, int n_clips, int64_t n_samples, 
         m.require_gpu();
         const int nf = pk_mel_num_frames(n_samples), F = m.cfg.mel_bins;
         const size_t n_in = (size_t)n_clips * n_samples, n_lm = (size_t)n_clips * F * nf;
+        const int pitch = mel_logmel_pitch(nf);                      // the device's log-mel rows are padded to 16 frames (kernels.hpp)
         m.io_in.reserve(n_in * 4);
-        m.io_tmp.reserve(n_lm * 4);
+        m.io_tmp.reserve((size_t)n_clips * F * pitch * 4);
         m.io_out.reserve(n_lm * 4);
         PK_HIP(hipMemcpyAsync(m.io_in.p, pcm, n_in * 4, hipMemcpyHostToDevice, m.stream));
         m.run_mel(m.io_in.as<float>(), n_clips, n_samples, m.io_tmp.as<float>(), m.io_out.as<float>(), m.stream);
         PK_CHECK_LAUNCH();
         PK_HIP(hipMemcpyAsync(feats, m.io_out.p, n_lm * 4, hipMemcpyDeviceToHost, m.stream));
-        if (logmel) PK_HIP(hipMemcpyAsync(logmel, m.io_tmp.p, n_lm * 4, hipMemcpyDeviceToHost, m.stream));
+        if (logmel) PK_HIP(hipMemcpy2DAsync(logmel, (size_t)nf * 4, m.io_tmp.p, (size_t)pitch * 4, (size_t)nf * 4, (size_t)n_clips * F, hipMemcpyDeviceToHost, m.stream));
         PK_HIP(hipStreamSynchronize(m.stream));
     });
 }
@@ -314,7 +315,16 @@ pk_status pk_mel_ragged(pk_model *h, const float *pcm, const int64_t *offsets, i
         m.run_mel_ws(m.ws, m.ws.pcm.as<float>(), n_clips, m.stream);
         PK_CHECK_LAUNCH();
         PK_HIP(hipMemcpyAsync(feats, m.ws.feats.p, n_lm * 4, hipMemcpyDeviceToHost, m.stream));
-        if (logmel) PK_HIP(hipMemcpyAsync(logmel, m.ws.logmel.p, n_lm * 4, hipMemcpyDeviceToHost, m.stream));
+        if (logmel) {                                               // per clip: [mel_bins][pitch] on the device -> [mel_bins][Tm] for the caller
+            const int F = m.cfg.mel_bins;
+            size_t dev_off = 0, host_off = 0;
+            for (int i = 0; i < n_clips; ++i) {
+                const int tm = r.Tm[i], pitch = mel_logmel_pitch(tm);
+                PK_HIP(hipMemcpy2DAsync(logmel + host_off, (size_t)tm * 4, m.ws.logmel.as<float>() + dev_off, (size_t)pitch * 4, (size_t)tm * 4, (size_t)F,
+                                        hipMemcpyDeviceToHost, m.stream));
+                dev_off += (size_t)F * pitch; host_off += (size_t)F * tm;
+            }
+        }
         PK_HIP(hipStreamSynchronize(m.stream));
     });
 }

@@ -491,7 +491,7 @@ static void reserve_encoder(Workspace &w, const pk_config &c, size_t pcm_samples
     const int W2 = sub_len(sub_len(F)), W3 = sub_len(W2);
     const size_t f = sizeof(float), M = sum_T;
     if (pcm_samples) w.pcm.reserve(pcm_samples * f);
-    if (logmel) w.logmel.reserve((size_t)F * sum_Tm * f);
+    if (logmel) w.logmel.reserve((size_t)F * (sum_Tm + 16 * (size_t)(w.rag_cap_clips > 0 ? w.rag_cap_clips : 1)) * f);   // rows padded to 16 frames per clip
     w.feats.reserve(sum_Tm * F * f);
     w.a2.reserve(sum_H2 * W2 * C * f); w.a3.reserve(sum_H2 * W2 * C * f);
     w.a4.reserve(sum_T * W3 * C * f); w.flat.reserve(sum_T * W3 * C * f);
@@ -509,8 +509,8 @@ void Workspace::size_for(const pk_config &c, int B_, int64_t n_samples_, int Tm_
     n_samples = n_samples_ < 0 ? -n_samples_ : n_samples_;
     const int H2 = sub_len(sub_len(Tm));
     T = T_run = sub_len(H2);
-    reserve_encoder(*this, c, own_pcm ? (size_t)B * n_samples : 0, n_samples > 0, (size_t)B * Tm, (size_t)B * H2, (size_t)B * T);
     rag_cap_rows = (size_t)B * T; rag_cap_clips = B; rag_cap_samples = (int64_t)B * n_samples; rag_cap_clip = n_samples;
+    reserve_encoder(*this, c, own_pcm ? (size_t)B * n_samples : 0, n_samples > 0, (size_t)B * Tm, (size_t)B * H2, (size_t)B * T);
     reserve_decode(c);
 }
 
@@ -608,6 +608,10 @@ void RagBatch::finish(int att_block_rows) {
     }
     if (level <= 1) {
         o_Tm = put_arr(Tm); o_Tm_off = put_off(Tm); o_H2 = put_arr(H2); o_H2_off = put_off(H2);
+        std::vector<int> padded(B);
+        for (int b = 0; b < B; ++b) padded[b] = mel_logmel_pitch(Tm[b]);
+        o_Tm_pad_off = put_off(padded);
+        sum_Tm_pad = image[o_Tm_pad_off + B];
     }
     o_T = put_arr(T); o_T_off = put_off(T);
     if (level <= 1) {
@@ -620,7 +624,7 @@ void RagBatch::finish(int att_block_rows) {
 size_t RagBatch::image_words_bound(int max_clips, int64_t max_total) {
     // (max_total counted in samples: the frame counts below are upper bounds for every level)
     const size_t B = (size_t)max_clips, sTm = (size_t)(max_total / 160) + B, sH2 = sTm / 4 + 2 * B, sT = sH2 / 2 + B;
-    return 2 * (B + 1) + 3 * (2 * B + 1) + 2 * (sH2 / 2 + B + sT + sT / 2 + B + sT / 32 + B) + 16;
+    return 2 * (B + 1) + 3 * (2 * B + 1) + (B + 1) + 2 * (sH2 / 2 + B + sT + sT / 2 + B + sT / 32 + B) + 16;
 }
 
 void Workspace::size_ragged(const pk_config &c, int max_clips, int64_t max_total, int64_t max_clip, bool own_pcm, int level) {
@@ -698,7 +702,10 @@ void Workspace::set_ragged(const RagBatch &r, hipStream_t s) {
     const int *dT = dv + rag.o_T, *dToff = dv + rag.o_T_off;
     if (rag.level <= 1) {
         const int *dTm = dv + rag.o_Tm, *dTmoff = dv + rag.o_Tm_off, *dH2 = dv + rag.o_H2, *dH2off = dv + rag.o_H2_off;
-        if (rag.level == 0) { rv.mel.pcm_off = reinterpret_cast<const int64_t *>(dv + rag.o_pcm_off); rv.mel.Tm = dTm; rv.mel.Tm_off = dTmoff; rv.mel.max_frames = rag.Tm_max; }
+        if (rag.level == 0) {
+            rv.mel.pcm_off = reinterpret_cast<const int64_t *>(dv + rag.o_pcm_off); rv.mel.Tm = dTm; rv.mel.Tm_off = dTmoff; rv.mel.max_frames = rag.Tm_max;
+            rv.mel.Tm_pad_off = dv + rag.o_Tm_pad_off;
+        }
         rv.c1.strips = {reinterpret_cast<const RagUnit *>(dv + rag.o_u_c1), rag.n_u_c1};
         rv.c1.strip_rows = rag.strip_rows;
         rv.c1.Tm = dTm; rv.c1.Tm_off = dTmoff; rv.c1.H2 = dH2; rv.c1.H2_off = dH2off; rv.c1.T = dT; rv.c1.T_off = dToff;

@@ -54,9 +54,10 @@ struct RagBatch {
     std::vector<int> Tm, H2, T;                   // per utterance: mel frames (level <= 1), rows after conv1 / dw1, encoder frames
     int64_t n_samples = 0;                        // totals and maxima
     int sum_Tm = 0, sum_H2 = 0, sum_T = 0, Tm_max = 0, T_max = 0;
+    int sum_Tm_pad = 0;                           // frames of the row-padded log-mel blocks (mel_logmel_pitch per clip)
     int strip_rows = 0, dw_frames = 0, att_rows = 0;   // unit granularities the tables were built for
     std::vector<int32_t> image;
-    size_t o_pcm_off = 0, o_Tm = 0, o_Tm_off = 0, o_H2 = 0, o_H2_off = 0, o_T = 0, o_T_off = 0, o_u_c1 = 0, o_u_row = 0, o_u_dw = 0, o_u_att = 0;
+    size_t o_pcm_off = 0, o_Tm = 0, o_Tm_off = 0, o_Tm_pad_off = 0, o_H2 = 0, o_H2_off = 0, o_T = 0, o_T_off = 0, o_u_c1 = 0, o_u_row = 0, o_u_dw = 0, o_u_att = 0;
     int n_u_c1 = 0, n_u_row = 0, n_u_dw = 0, n_u_att = 0;
     void build_from_samples(const int64_t *lens, int B, int att_block_rows);
     void build_from_mel(const int *Tm, int B, int att_block_rows);

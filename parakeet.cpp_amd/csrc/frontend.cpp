@@ -38,7 +38,7 @@ class MelFrontend {
     int features(const float *pcm, int64_t n_samples, float *feats) {
         PK_HIP(hipSetDevice(device_));
         const int n_frames = (int)(1 + n_samples / 160);
-        pcm_.reserve((size_t)n_samples * 4); logmel_.reserve((size_t)n_mels_ * n_frames * 4); feats_.reserve((size_t)n_mels_ * n_frames * 4);
+        pcm_.reserve((size_t)n_samples * 4); logmel_.reserve((size_t)n_mels_ * mel_logmel_pitch(n_frames) * 4); feats_.reserve((size_t)n_mels_ * n_frames * 4);
         PK_HIP(hipMemcpyAsync(pcm_.p, pcm, (size_t)n_samples * 4, hipMemcpyHostToDevice, stream_));
         launch_mel_logmel(pcm_.as<float>(), 1, n_samples, n_frames, tables_, logmel_.as<float>(), stream_);
         launch_mel_normalize(logmel_.as<float>(), 1, n_mels_, n_frames, normalize_ ? 1 : 0, feats_.as<float>(), stream_);

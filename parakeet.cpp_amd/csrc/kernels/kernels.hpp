@@ -34,7 +34,8 @@ inline void ensure_dyn_lds(DynLdsSlots &slots, const void *kernel, size_t bytes)
 // member = uniform batch (the launchers' plain B / T arguments apply).
 struct RagUnit { int b, r0; };                 // one strip of rows of ONE utterance: utterance b, first local row r0
 struct RagUnits { const RagUnit *u = nullptr; int count = 0; };
-struct MelRag { const int64_t *pcm_off = nullptr; const int *Tm = nullptr, *Tm_off = nullptr; int max_frames = 0; };   // [B+1] samples, [B] mel frames, [B+1]
+struct MelRag { const int64_t *pcm_off = nullptr; const int *Tm = nullptr, *Tm_off = nullptr; int max_frames = 0;   // [B+1] samples, [B] mel frames, [B+1]
+                const int *Tm_pad_off = nullptr; };   // [B+1] prefix sums of mel_logmel_pitch(Tm[b]): where clip b's log-mel block starts (in frames)
 struct SubRag {                                 // conv subsampling: mel frames -> H2 = rows after conv1 / dw1 -> T rows after dw2
     RagUnits strips;                            // conv1_dw1: strips of strip_rows rows of H2 ; dw2: one unit per output row
     int strip_rows = 0;
@@ -63,7 +64,11 @@ struct MelTables {
     int n_mels;
     int power_via_abs;     // switch A2
 };
-// rag set: clip b = pcm[rag.pcm_off[b] .. rag.pcm_off[b+1]), its log-mel [n_mels][rag.Tm[b]] at logmel + n_mels * rag.Tm_off[b] (n_samples / n_frames ignored)
+// rag set: clip b = pcm[rag.pcm_off[b] .. rag.pcm_off[b+1]), its log-mel [n_mels][pitch of rag.Tm[b]] at logmel + n_mels * rag.Tm_pad_off[b] (n_samples / n_frames ignored)
+// The log-mel intermediate is [clip][n_mels][pitch], pitch = mel_logmel_pitch(n_frames) = n_frames rounded up to 16: every run of 16 frames a
+// workgroup stores is then one aligned 64-byte segment (the un-padded rows -- 1001 floats for 10 s -- put every run across sector boundaries:
+// 1.44x write traffic).  Only mel_normalize (and the debug read-outs of pk_mel) read it.
+__host__ __device__ inline int mel_logmel_pitch(int n_frames) { return (n_frames + 15) & ~15; }
 void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s, const MelRag &rag = MelRag());
 // StreamingAudioPreprocessor::process_chunk (src/audio.cpp:222-252) on pre-emphasised buffers pre[B][n_samples]:
 // n_frames = (n_samples - 400) / 160 + 1 frames -> log-mel [B][n_frames][n_mels] (no normalisation)

@@ -19,11 +19,18 @@ namespace pk {
 
 static constexpr int kNfft = 512;
 static constexpr int kHop = 160;
-static constexpr int kFramesPerBlock = 4;   // wavefronts per workgroup = frames in flight
-// Offline kernel: frames each wavefront walks one after the other (frames per workgroup = 4 x this).  Measured (round 3, bench.py on MI355X):
-// 1 -> 0.203 ms per 64-clip batch, 2 -> 0.234, 4 -> 0.237: the kernel is LDS-latency bound and wants the parallelism, so the store tile is
-// [m][4 frames] (16-byte runs) and not the 64-byte runs 16 frames per workgroup would give.
-static constexpr int kOfflineIters = 1;
+// Wavefronts (= frames) per workgroup.  Round 3 had 4 (one frame per wave; walking 2 / 4 frames per wave for longer store runs was slower:
+// 0.203 -> 0.234 / 0.237 ms per 64-clip batch -- the kernel is LDS-latency bound and wants the parallelism).  Round 4: 16 wavefronts per
+// workgroup, still one frame each: the [m][16 frames] store tile leaves as 64-byte runs.
+static constexpr int kStreamWaves = 4;
+#ifndef PK_MEL_WAVES
+#define PK_MEL_WAVES 16
+#endif
+static constexpr int kOfflineWaves = PK_MEL_WAVES;
+template <int NW> static constexpr size_t mel_lds_bytes(bool offline) {
+    (void)offline;
+    return (size_t)(NW * 2 * (kNfft + kNfft / 32) + 2 * kNfft + kMelMaxTaps) * sizeof(float);
+}
 
 // STREAM = false: preprocess_audio's framing (pre-emphasis, center=true, reflect padding), output [B][n_mels][n_frames].
 // STREAM = true: StreamingAudioPreprocessor::process_chunk's framing (src/audio.cpp:222-241): the buffer is ALREADY
@@ -34,53 +41,54 @@ static constexpr int kOfflineIters = 1;
 // workgroup no longer wait for each other ten times per FFT.
 #define PK_FP(i) ((i) + ((i) >> 5))
 #define PK_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-template <bool STREAM>
-__global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict__ pcm, int64_t n_samples, int n_frames,
-                                                         MelTables tb, float *__restrict__ logmel, MelRag rg) {
+template <bool STREAM, int NW /* wavefronts = frames per workgroup */>
+__global__ __launch_bounds__(64 * NW) void mel_logmel_kernel(const float *__restrict__ pcm, int64_t n_samples, int n_frames,
+                                                             MelTables tb, float *__restrict__ logmel, MelRag rg) {
     // FFT arrays with one pad word per 32 (element i at i + (i >> 5)): the butterfly strides 2^lh of the in-place radix-2 stages would
     // otherwise put two to eight lanes on one LDS bank
-    __shared__ float s_re[kFramesPerBlock][kNfft + kNfft / 32];
-    __shared__ float s_im[kFramesPerBlock][kNfft + kNfft / 32];
-    __shared__ float s_pw[kFramesPerBlock][260];
+    // LDS (dynamic: NW = 16 needs 102 KB): per-frame FFT arrays and power spectrum, the tables, the output tile
+    constexpr int FA = kNfft + kNfft / 32;                          // padded FFT array of one frame
+    constexpr int ITERS = 1;
+    constexpr int FPB = NW * ITERS;
+    extern __shared__ __attribute__((aligned(16))) float mel_sm[];
+    // (the power spectrum of a frame -- 257 values -- lives in the unused upper part of its own imaginary array, words 268 .. 524: the spectrum
+    //  is read from words 0 .. 264 only; the frame's log-mel values go into the head of its real array, which is dead by then: 4.2 KB of LDS per
+    //  frame instead of 5.3 + an output tile, so that 16-frame workgroups fit twice on a CU)
+    float *const s_re_all = mel_sm, *const s_im_all = s_re_all + NW * FA;
     // twiddles and the packed filterbank bands: read ~100 times per lane and frame -- from LDS instead of dependent L1 / L2 round trips.
     // The twiddles are laid out PER STAGE (stage lh uses w^(j << (8 - lh)), j < 2^lh, stored at 2^lh - 1 + j): the lanes of a butterfly
     // stage then read consecutive words (or broadcast) instead of a 2^(8-lh)-word stride that put 8 lanes on one bank in stages 3-6
     // (round 1: 8.5e7 LDS bank-conflict cycles per dispatch).
-    __shared__ float s_twr[kNfft], s_twi[kNfft];
-    __shared__ float s_fb[kMelMaxTaps];
-    // Offline: the log-mel values of the workgroup's frames are collected here and leave as contiguous runs of [m][frames]; written straight
-    // from the frame's wavefront they were 4-byte stores 4 KB apart (round 2 PMC: 56 MB of write traffic for a 20 MB tensor).
-    constexpr int ITERS = STREAM ? 1 : kOfflineIters;
-    constexpr int FPB = kFramesPerBlock * ITERS;
-    __shared__ float s_out[STREAM ? 1 : 128][STREAM ? 1 : FPB + 1];
+    float *const s_twr = s_im_all + NW * FA, *const s_twi = s_twr + kNfft, *const s_fb = s_twi + kNfft;
+    // Offline: the log-mel values of the workgroup's NW frames leave as contiguous runs of [m][NW frames]: 64-byte, sector-aligned runs at
+    // NW = 16 with the padded frame pitch (round 4; the 16-byte runs of 4-frame workgroups were 56 MB of write traffic for the 20 MB tensor)
     const int b = blockIdx.y;
     const float *x = pcm + (int64_t)b * n_samples;
-    float *lm_clip = logmel + (int64_t)b * tb.n_mels * n_frames;         // (offline layout: this clip's [n_mels][n_frames] block)
+    float *lm_clip = logmel + (int64_t)b * tb.n_mels * mel_logmel_pitch(n_frames);         // (offline layout: this clip's [n_mels][pitch] block)
     if constexpr (!STREAM) {
         if (rg.pcm_off) {                                           // ragged batch: this clip's own extent (kernels.hpp: MelRag)
             const int64_t o = rg.pcm_off[b];
             x = pcm + o;
             n_samples = rg.pcm_off[b + 1] - o;
             n_frames = rg.Tm[b];
-            lm_clip = logmel + (int64_t)tb.n_mels * rg.Tm_off[b];
+            lm_clip = logmel + (int64_t)tb.n_mels * rg.Tm_pad_off[b];
             if ((int)blockIdx.x * FPB >= n_frames) return;          // the grid covers the longest clip (whole workgroup, before any barrier)
         }
     }
-    for (int i = threadIdx.x; i < kNfft - 1; i += 256) {
+    for (int i = threadIdx.x; i < kNfft - 1; i += 64 * NW) {
         const int lh = 31 - __builtin_clz(i + 1), j = i + 1 - (1 << lh);   // i = 2^lh - 1 + j
         s_twr[i] = tb.tw_re[j << (8 - lh)];
         s_twi[i] = tb.tw_im[j << (8 - lh)];
     }
-    for (int i = threadIdx.x; i < tb.fb_nnz; i += 256) s_fb[i] = tb.fbc[i];
+    for (int i = threadIdx.x; i < tb.fb_nnz; i += 64 * NW) s_fb[i] = tb.fbc[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *re = s_re[wave], *im = s_im[wave], *pw = s_pw[wave];
+    float *re = s_re_all + wave * FA, *im = s_im_all + wave * FA, *pw = im + 268;
 #pragma unroll 1
     for (int it = 0; it < ITERS; ++it) {
-    const int t = blockIdx.x * FPB + it * kFramesPerBlock + wave;
+    const int t = blockIdx.x * FPB + it * NW + wave;
     const bool live = t < n_frames;
-    if (it) PK_WAVE_SYNC();                                         // the previous frame's reads of pw / re / im are done
-
+    
     if (live) {
 #pragma unroll
         for (int i = 0; i < kNfft / 64; ++i) {
@@ -149,16 +157,16 @@ __global__ __launch_bounds__(256) void mel_logmel_kernel(const float *__restrict
             for (int f = lo; f <= hi; ++f) acc = __builtin_fmaf(wm[f], pw[f], acc);
             const float lm = dlogf(acc + 5.96046448e-8f);
             if constexpr (STREAM) logmel[((int64_t)b * n_frames + t) * tb.n_mels + m] = lm;
-            else s_out[m][it * kFramesPerBlock + wave] = lm;
+            else re[m] = lm;
         }
     }
     }
     if constexpr (!STREAM) {
         __syncthreads();
-        const int t0 = blockIdx.x * FPB;
-        for (int idx = threadIdx.x; idx < tb.n_mels * FPB; idx += 256) {
+        const int t0 = blockIdx.x * FPB, pitch = mel_logmel_pitch(n_frames);
+        for (int idx = threadIdx.x; idx < tb.n_mels * FPB; idx += 64 * NW) {
             const int m = idx / FPB, tt = idx % FPB;
-            if (t0 + tt < n_frames) lm_clip[(int64_t)m * n_frames + t0 + tt] = s_out[m][tt];
+            if (t0 + tt < n_frames) lm_clip[(int64_t)m * pitch + t0 + tt] = s_re_all[tt * FA + m];
         }
     }
 }
@@ -176,9 +184,10 @@ __global__ __launch_bounds__(1024) void mel_normalize_kernel(const float *__rest
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = blockIdx.x * 16 + wave, b = blockIdx.y;
     const bool live = m < n_mels;
-    int64_t frame0 = (int64_t)b * n_frames;                        // first frame of this clip in the packed frame axis
-    if (rg.pcm_off) { frame0 = rg.Tm_off[b]; n_frames = rg.Tm[b]; }   // ragged batch: the statistics run over THIS clip's frames
-    const float *row = logmel + frame0 * n_mels + (int64_t)(live ? m : 0) * n_frames;
+    int64_t frame0 = (int64_t)b * n_frames;                        // first frame of this clip in the packed frame axis of the features
+    int64_t lm0 = (int64_t)b * mel_logmel_pitch(n_frames);         // ... and of the (row-padded) log-mel blocks
+    if (rg.pcm_off) { frame0 = rg.Tm_off[b]; lm0 = rg.Tm_pad_off[b]; n_frames = rg.Tm[b]; }   // ragged batch: the statistics run over THIS clip's frames
+    const float *row = logmel + lm0 * n_mels + (int64_t)(live ? m : 0) * mel_logmel_pitch(n_frames);
     float mean = 0.0f, den = 1.0f;
     if (normalize && live) {
         float p = 0.0f;
@@ -206,14 +215,18 @@ __global__ __launch_bounds__(1024) void mel_normalize_kernel(const float *__rest
 }
 
 void launch_mel_logmel(const float *pcm, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel, hipStream_t s, const MelRag &rag) {
-    constexpr int fpb = kFramesPerBlock * kOfflineIters;
+    constexpr int fpb = kOfflineWaves;
     if (rag.pcm_off) n_frames = rag.max_frames;
     dim3 grid((n_frames + fpb - 1) / fpb, B);
-    hipLaunchKernelGGL(mel_logmel_kernel<false>, grid, dim3(256), 0, s, pcm, n_samples, n_frames, t, logmel, rag);
+    constexpr size_t lds = mel_lds_bytes<kOfflineWaves>(true);
+    static DynLdsSlots slots;
+    ensure_dyn_lds(slots, reinterpret_cast<const void *>(&mel_logmel_kernel<false, kOfflineWaves>), lds);
+    hipLaunchKernelGGL((mel_logmel_kernel<false, kOfflineWaves>), grid, dim3(64 * kOfflineWaves), lds, s, pcm, n_samples, n_frames, t, logmel, rag);
 }
 void launch_mel_stream(const float *pre, int B, int64_t n_samples, int n_frames, const MelTables &t, float *logmel_tf, hipStream_t s) {
-    dim3 grid((n_frames + kFramesPerBlock - 1) / kFramesPerBlock, B);
-    hipLaunchKernelGGL(mel_logmel_kernel<true>, grid, dim3(256), 0, s, pre, n_samples, n_frames, t, logmel_tf, MelRag());
+    dim3 grid((n_frames + kStreamWaves - 1) / kStreamWaves, B);
+    constexpr size_t lds = mel_lds_bytes<kStreamWaves>(false);
+    hipLaunchKernelGGL((mel_logmel_kernel<true, kStreamWaves>), grid, dim3(64 * kStreamWaves), lds, s, pre, n_samples, n_frames, t, logmel_tf, MelRag());
 }
 void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, int normalize, float *feats, hipStream_t s, const MelRag &rag) {
     hipLaunchKernelGGL(mel_normalize_kernel, dim3((n_mels + 15) / 16, B), dim3(1024), 0, s, logmel, n_mels, n_frames, normalize, feats, rag);

