@@ -268,6 +268,21 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
 // (tools/ubench/gemm_bf16_k.cpp) found why: the 256-row tile count of those products falls between two rounds of the 256 CUs; with the tile
 // height chosen per product (below) the kernel is ahead everywhere.  Modes (EXPERIMENTAL builds, PK_BF16_TILE): 0 = off, 1 = that rule,
 // 2 = 256x128 everywhere, 3 = 128x128 on 4 waves of 64x64, 4 = 256x256 everywhere, 5 = 192x256 everywhere.
+// Persistent form of the direct-to-LDS kernel (gemm_bf16_glds.hpp: PERSIST; one workgroup per CU walks its tiles, the next tile's first K tile is
+// requested under the epilogue).  Built and measured in round 4 (profiles/r04_bf16_persist_ab.txt, interleaved A/B on one box, tdt-600m 32 x 30 s):
+// bit-for-bit the same results, qkv 2.45 -> 2.41 ms and GLU 1.82 -> 1.77 ms per step, but fc1 6.75 -> 7.17 (140 -> 150 us) and the step 27.62 ->
+// 27.94 ms: inside one launch the next tile cannot start before `s_waitcnt vmcnt(0)` has ALSO drained the epilogue's stores (gfx950 counts loads
+// and stores in one counter, and they complete out of order relative to each other), which costs more than the cold prologue and the
+// re-dispatch it removes; and the epilogue, confined to one 64 KB buffer, needs 8 row bands instead of 4.  OFF by default; EXPERIMENTAL builds:
+// PK_BF16_PERSIST=1 selects it.
+static bool bf16_glds_persist() {
+#ifdef PK_EXPERIMENTAL
+    static const bool m = [] { const char *e = getenv("PK_BF16_PERSIST"); return e ? atoi(e) != 0 : false; }();
+    return m;
+#else
+    return false;
+#endif
+}
 static int bf16_glds_mode() {
 #ifdef PK_EXPERIMENTAL
     static const int m = [] { const char *e = getenv("PK_BF16_TILE"); return e ? atoi(e) : 1; }();
@@ -296,8 +311,8 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
                     const int64_t tiles = (int64_t)((a.M + R - 1) / R) * ((a.N + NOUT - 1) / NOUT);
                     return (double)((tiles + 255) / 256) * ((double)R * a.K * 1.008e-4 + 12.0);
                 };
-                if (est(192) < est(256)) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s);
-                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s);
+                if (est(192) < est(256)) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist());
+                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist());
                 return;
             }
         }

@@ -27,7 +27,13 @@
 
 namespace pk {
 
-template <int WGM, int WGN, int TM, int TN, int EPI>
+// PERSIST (round 4): ONE workgroup per CU walks its tiles inside the launch.  Measured in round 3 (tools/ubench/gemm_bf16_k.cpp): the K loop runs
+// at 1.25-1.3 PF, the products of this model lose ~14 us per ROUND of tiles -- a cold two-tile DMA prologue on every CU at once, the epilogue,
+// the re-dispatch -- on K loops of only 16 tiles.  Here the first K tile of tile i+1 is requested (DMA into the staging buffer the last K tile
+// of tile i did not use) BEFORE the epilogue of tile i, which turns its accumulators row-major through the OTHER buffer only (64 KB: bands of
+// 32 rows); the second K tile follows right after the epilogue, and the K loop of tile i+1 starts on data that has long landed.  XCD x owns
+// the same contiguous range of tiles as in the one-tile-per-workgroup launch, dealt round-robin to its 32 workgroups.
+template <int WGM, int WGN, int TM, int TN, int EPI, bool PERSIST = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs g, int tiles_n, int n_tiles) {
     constexpr int BK = 64, NSUB = BK / 16;                          // bf16 elements per tile row; MFMA k-steps per K tile
     constexpr int NT = 64 * WGM * WGN, NW = WGM * WGN;
@@ -49,13 +55,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
     const __bf16 *A16 = reinterpret_cast<const __bf16 *>(g.A);
     const __bf16 *W16 = reinterpret_cast<const __bf16 *>(g.W);
 
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap (block b runs on XCD b % 8): XCD x gets a contiguous range of tiles
-        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int m0, n0;
-    {   // grouped tile order (gemm_bf16.hpp): GROUPM tile rows down before the next tile column
+    // tile `bid` (after the XCD remap) -> origin, grouped tile order (gemm_bf16.hpp): GROUPM tile rows down before the next tile column
+    auto tile_origin = [&](int bid, int &m0, int &n0) {
         constexpr int GROUPM = (BM >= 256) ? 4 : 8;
         const int tiles_m = n_tiles / tiles_n, per_group = GROUPM * tiles_n;
         const int grp = bid / per_group, first_m = grp * GROUPM;
@@ -63,37 +64,45 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
         const int in = bid - grp * per_group;
         m0 = (first_m + in % gsz) * BM;
         n0 = (in / gsz) * NOUT;
-    }
+    };
+    // XCD-aware bijective remap (block b runs on XCD b % 8): XCD x gets a contiguous range of tiles [x_first, x_first + x_count)
+    const int xq = n_tiles >> 3, xr = n_tiles & 7, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int x_first = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, x_count = xq + (xcd < xr ? 1 : 0);
+    const int per_xcd = PERSIST ? (int)(gridDim.x >> 3) : 1;        // workgroups per XCD walking that range (persistent: stride)
+    int loc = idx;                                                  // index inside the XCD's range
+    if (!PERSIST && loc >= x_count) return;                         // (never: the one-tile launch has exactly n_tiles workgroups)
+    if (PERSIST && loc >= x_count) return;
 
     // DMA sources: wave w fills blocks w, w + NW, ...; lane q of block b supplies (row 8 b + q / 8, logical chunk (q % 8) ^ ((row >> 1) & 7)).
     // Rows 0 .. BM-1 of the stacked tile are A rows, BM .. BM+BN-1 are W rows.
-    const __bf16 *src[NBPW];
+    auto set_src = [&](int m0, int n0, const __bf16 *(&src)[NBPW]) {
 #pragma unroll
-    for (int i = 0; i < NBPW; ++i) {
-        const int b = wv + NW * i;
-        const int row = 8 * b + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        if (row < BM) {
-            int gr = m0 + row;
-            gr = gr < g.M ? gr : g.M - 1;
-            src[i] = A16 + (int64_t)gr * g.lda + 8 * c;
-        } else {
-            const int v = row - BM;
-            int wr;
-            if constexpr (EPI == EPI_GLU) {
-                constexpr int HT = TN / 2;     // tiles [0,HT) = value half, [HT,TN) = gate half of the SAME output columns
-                const int vw = v / WN, rem = v % WN, tn = rem >> 5, cc = rem & 31;
-                int col = n0 + vw * (WN / 2) + (tn % HT) * 32 + cc;
-                col = col < g.N ? col : g.N - 1;
-                wr = (tn / HT) * g.N + col;
+        for (int i = 0; i < NBPW; ++i) {
+            const int b = wv + NW * i;
+            const int row = 8 * b + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            if (row < BM) {
+                int gr = m0 + row;
+                gr = gr < g.M ? gr : g.M - 1;
+                src[i] = A16 + (int64_t)gr * g.lda + 8 * c;
             } else {
-                wr = n0 + v;
-                wr = wr < g.N ? wr : g.N - 1;
+                const int v = row - BM;
+                int wr;
+                if constexpr (EPI == EPI_GLU) {
+                    constexpr int HT = TN / 2;     // tiles [0,HT) = value half, [HT,TN) = gate half of the SAME output columns
+                    const int vw = v / WN, rem = v % WN, tn = rem >> 5, cc = rem & 31;
+                    int col = n0 + vw * (WN / 2) + (tn % HT) * 32 + cc;
+                    col = col < g.N ? col : g.N - 1;
+                    wr = (tn / HT) * g.N + col;
+                } else {
+                    wr = n0 + v;
+                    wr = wr < g.N ? wr : g.N - 1;
+                }
+                src[i] = W16 + (int64_t)wr * g.ldw + 8 * c;
             }
-            src[i] = W16 + (int64_t)wr * g.ldw + 8 * c;
         }
-    }
-    auto dma = [&](int kt, int buf) {
+    };
+    auto dma = [&](const __bf16 *const (&src)[NBPW], int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < NBPW; ++i) {
             __bf16 *dst = smem + buf * BUF + (wv + NW * i) * 512;                    // 1 KB = 512 bf16 per block; wave-uniform
@@ -103,13 +112,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
     };
 
     bg_f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
     // fragment addresses: operand-tile row r = tile base (a multiple of 32) + (lane & 31): element offset r * 64 + ((2 s + h) ^ x) * 8 with
     // x = (r >> 1) & 7 = ((lane & 31) >> 1) & 7 -- one swizzle value per lane for every tile
     const int h = lane >> 5, fx = ((lane & 31) >> 1) & 7;
@@ -131,39 +133,79 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
 #define GL_SB() __builtin_amdgcn_sched_barrier(0)
 #define GL_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)           /* vmcnt(0): this wave's LDS-DMA loads have landed */
 
-    dma(0, 0);
-    if (nk > 1) dma(1, 1);
-    GL_WAIT_VM0();
-    __syncthreads();
-    fragload(0, 0, 0);
+    const __bf16 *src[NBPW];
+    int m0, n0;
+    tile_origin(x_first + loc, m0, n0);
+    set_src(m0, n0, src);
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    dma(src, 0, 0);
+    if (nk > 1) dma(src, 1, 1);
+    for (;;) {
 #pragma unroll
-        for (int s = 0; s < NSUB - 1; ++s) {
-            fragload(cur, s + 1, (s + 1) & 1);
-            GL_SB(); mma(s & 1); GL_SB();
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        // K tile 0 of this tile is in flight (or long landed) in buffer `cur`, K tile 1 in the other: wait for BOTH before the first
+        // fragment read (the persistent path issued tile 0 an epilogue ago -- what is waited for here is tile 1's request, one DMA latency,
+        // once per tile instead of two on a cold chip)
+        GL_WAIT_VM0();
+        __syncthreads();
+        fragload(cur, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+#pragma unroll
+            for (int s = 0; s < NSUB - 1; ++s) {
+                fragload(cur, s + 1, (s + 1) & 1);
+                GL_SB(); mma(s & 1); GL_SB();
+            }
+            GL_WAIT_VM0();                 // K tile kt+1 (issued a whole tile ago) is in LDS
+            __syncthreads();               // ... for every wave; and every wave holds its last fragments of tile kt: buffer `cur` is free
+            if (more1) fragload(cur ^ 1, 0, 0);
+            if (more2) dma(src, kt + 2, cur);
+            GL_SB(); mma((NSUB - 1) & 1); GL_SB();
+            cur ^= 1;
         }
-        GL_WAIT_VM0();                     // K tile kt+1 (issued a whole tile ago) is in LDS
-        __syncthreads();                   // ... for every wave; and every wave holds its last fragments of tile kt: buffer `cur` is free
-        if (more1) fragload(cur ^ 1, 0, 0);
-        if (more2) dma(kt + 2, cur);
-        GL_SB(); mma((NSUB - 1) & 1); GL_SB();
-        cur ^= 1;
+        // `cur` = the buffer the last K tile did NOT use (free since the barrier of the last iteration); the other one is free too once every
+        // wave has passed that barrier -- which the epilogue's own first barrier guarantees again
+        if constexpr (PERSIST) {
+            const int em0 = m0, en0 = n0;
+            loc += per_xcd;
+            const bool more = loc < x_count;
+            if (more) {                    // next tile: its first K tile streams into `cur` UNDER this tile's epilogue
+                tile_origin(x_first + loc, m0, n0);
+                set_src(m0, n0, src);
+                dma(src, 0, cur);
+            }
+            gp_epilogue<WGM, WGN, TM, TN, EPI, BUF / 2, true>(g, acc, smem_f + (cur ^ 1) * (BUF / 2), em0, en0);   // one buffer: BUF bf16 = BUF / 2 floats
+            if (!more) break;
+            __syncthreads();               // every wave has read its last band out of the epilogue's buffer
+            if (nk > 1) dma(src, 1, cur ^ 1);
+        } else {
+            gp_epilogue<WGM, WGN, TM, TN, EPI, BUF, true>(g, acc, smem_f, m0, n0);      // 2 buffers x BUF bf16 = BUF floats
+            break;
+        }
     }
 #undef GL_SB
 #undef GL_WAIT_VM0
-    gp_epilogue<WGM, WGN, TM, TN, EPI, BUF, true>(g, acc, smem_f, m0, n0);      // 2 buffers x BUF bf16 = BUF floats
 }
 
 template <int WGM, int WGN, int TM, int TN, int EPI>
-static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s) {
+static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, bool persist = false) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
     const int n_tiles = tiles_m * tiles_n;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;
-    auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI>;
+    if (persist && n_tiles > 256) {                                // more than one round of the 256 CUs: one persistent workgroup per CU
+        auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true>;
+        static DynLdsSlots slots;
+        ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+        return;
+    }
+    auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false>;
     static DynLdsSlots slots;
     ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);

@@ -80,7 +80,8 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
         constexpr int CP = BN + 4;                                  // C tile pitch (rows stay 16-byte aligned)
         // the C tile goes through the staging buffers; when it does not fit (single-buffered variant) in NPASS row bands
         constexpr size_t CAP = (size_t)CAP_FLOATS;
-        constexpr int NPASS = ((size_t)BM * CP <= CAP) ? 1 : ((size_t)BM / 2 * CP <= CAP) ? 2 : ((size_t)BM / 4 * CP <= CAP) ? 4 : 8, PR = BM / NPASS;
+        constexpr int NPASS = ((size_t)BM * CP <= CAP) ? 1 : ((size_t)BM / 2 * CP <= CAP && (BM / 2) % 32 == 0) ? 2 : ((size_t)BM / 4 * CP <= CAP && (BM / 4) % 32 == 0) ? 4
+                              : ((size_t)BM / 8 * CP <= CAP && (BM / 8) % 32 == 0) ? 8 : BM / 32, PR = BM / NPASS;   // (last resort: bands of one MFMA tile row)
         static_assert((size_t)PR * CP <= CAP, "C tile band must fit in the staging buffers");
         static_assert(PR % 32 == 0, "row bands are whole MFMA tiles");
         constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT, RSTEP = NT / C4;   // float4 chunks per output row / per thread; row stride

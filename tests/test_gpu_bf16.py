@@ -57,7 +57,11 @@ def test_bf16_gemm_against_float64(M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(2048, 512, 128, "none"), (4096, 4096, 1024, "silu"), (12032, 1024, 4096, "resid"), (12032, 3072, 1024, "none"),
-                                       (2500, 1024, 1024, "glu"), (3000, 1028, 512, "relu"), (8064, 2048, 512, "silu"), (2304, 1024, 256, "resid")])
+                                       (2500, 1024, 1024, "glu"), (3000, 1028, 512, "relu"), (8064, 2048, 512, "silu"), (2304, 1024, 256, "resid"),
+                                       # more than one round of tiles: the PERSISTENT form (one workgroup per CU walks its tiles, next tile's first K tile
+                                       # requested under the epilogue) -- both tile heights, every epilogue, ragged edges, odd and even K-tile counts
+                                       (12032, 4096, 1024, "silu"), (12032, 1024, 1024, "glu"), (9000, 2052, 1024, "resid"), (16384, 2048, 1088, "relu"),
+                                       (12032, 3072, 1024, "resid")])
 def test_bf16_glds_gemm_against_float64(M, N, K, epi):
     """The direct-to-LDS kernel (gemm_bf16_glds.hpp: activations already bf16 in HBM, XOR-swizzled LDS image, 256-row tiles): every tile
     variant the dispatch can pick (wide / narrow outputs, GLU, ragged M and N edges) against a float64 product of the same rounded operands."""
