@@ -364,9 +364,22 @@ int relpos_attention_max_frames(int hd) {
 void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u,
                              const float *bias_v, float *ctx, hipStream_t s, float scale, float *scratch, int ctx_bf16, int pos_row0, const SeqRag &rag) {
     const int hd = d / n_heads;
-    // V chunk rows: 64 keeps the footprint at ~39 KB for 10 s clips (4 workgroups per CU at hd = 64)
-    if (hd == 64) launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
-    else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
+    // V chunk rows: 64 keeps the footprint at ~39 KB for 10 s clips (4 workgroups per CU at hd = 64).  Between ~10.5 and ~16 s (T = 132 .. 200:
+    // the longest clip of a mixed batch, 15 s uniform batches) the 64-row chunk costs the fourth resident workgroup; a 32-row chunk (two more
+    // barriers per extra chunk, the same chains: same bits) keeps it
+    if (hd == 64) {
+        const int t_lds = rag.units.u ? rag.T_max : T;
+        auto occ = [&](int vch) {
+            int pits = (t_lds + 3) / 4;
+            pits = (pits + 3) & ~3;
+            if (((pits / 4) & 1) == 0) pits += 4;
+            const size_t lds = (size_t)(4 * (RB * pits + 8) + vch * (64 + 16)) * sizeof(float);
+            const int n = (int)((size_t)160 * 1024 / lds);
+            return n < ATT_OCC ? n : ATT_OCC;
+        };
+        if (!scratch && occ(32) > occ(64)) launch_att<64, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
+        else launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
+    } else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
     else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
     else if (hd == 96) launch_att<96, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
 }
