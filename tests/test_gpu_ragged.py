@@ -303,3 +303,21 @@ def test_ragged_rnnt_head_and_two_lstm_layers(tmp_path):
         assert np.array_equal(G.bits(g["conf"][i, :k]), G.bits(o["conf"][0, :k]))
         n += k
     assert n > 5, "degenerate decode"
+
+
+def test_ragged_batch_with_a_clip_beyond_the_lds_score_block(tiny_pair, orc):
+    """One clip of 100 s (1251 encoder frames: its [32][T] score block no longer fits LDS, the attention kernel keeps the blocks in global
+    scratch) packed with short clips: the scratch variant with per-clip extents, every clip against the oracle's single-clip run."""
+    W, om, gm = tiny_pair
+    clips = clips_of([1_600_000, 16000, 40000, 700], seed=300)
+    feats = gm.mel_ragged(clips)
+    enc = gm.encode_ragged(feats)
+    for i, c in enumerate(clips):
+        of = orc.mel(c, n_mels=om.cfg.mel_bins)
+        G.assert_bits_equal(feats[i], of, f"clip {i}: features")
+        G.assert_bits_equal(enc[i], om.encoder(of[None])[0], f"clip {i} ({len(c)} samples): encoder output vs the oracle")
+    res = gm.transcribe_pcm(clips, decoder="ctc", timestamps=True)
+    for i, c in enumerate(clips):
+        e = om.encoder(orc.mel(c, n_mels=om.cfg.mel_bins)[None])
+        o = orc.ctc_greedy(om.ctc_logprobs(e), om.cfg.blank_id)
+        assert res[i]["token_ids"] == o["ids"][0, :o["lens"][0]].tolist(), f"clip {i}: CTC tokens through the one-call API"
