@@ -8,49 +8,68 @@
 
 namespace pk {
 
-template <int PER_LANE>
+// RPW rows per wavefront.  Round 4 measured 1 / 2 / 4 on the batch shapes (tools/experiments/ln_rpw_ab.sh, profiles/r04_ln_rpw_ab.txt): sharing one
+// load of gamma / beta between the rows of a wave does NOT pay -- tdt-ctc-110m 0.87 / 0.92 / 1.02 ms of LayerNorm per step, tdt-600m bf16 2.23 /
+// -- / 2.39: the kernel wants the most independent waves it can get (it runs at ~4 TB/s of combined read + write).  One row per wave it stays.
+#ifndef PK_LN_RPW
+#define PK_LN_RPW 1
+#endif
+template <int PER_LANE, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int64_t rows, int d,
                                                         const float *__restrict__ g, const float *__restrict__ b,
                                                         float eps, float *__restrict__ y, int y_bf16) {
     __builtin_amdgcn_s_setprio(3);                                  // (see gemm_pipe.hpp)
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float *xr = x + row * d;
-    float v[PER_LANE], gv[PER_LANE], bv[PER_LANE];
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    float v[RPW][PER_LANE], gv[PER_LANE], bv[PER_LANE];
 #pragma unroll
-    for (int j = 0; j < PER_LANE; ++j) {                            // the row and gamma / beta in one round trip (not one after the reductions)
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;  // (rows past the end re-read the last one; never stored)
+        const float *xr = x + row * d;
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j) {
+            const int i = lane + 64 * j;
+            v[r][j] = i < d ? xr[i] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) {                            // gamma / beta in the same round trip (not one after the reductions)
         const int i = lane + 64 * j;
-        v[j] = i < d ? xr[i] : 0.0f;
         gv[j] = i < d ? g[i] : 0.0f;
         bv[j] = i < d ? b[i] : 0.0f;
     }
-    float p = 0.0f;
 #pragma unroll
-    for (int j = 0; j < PER_LANE; ++j)
-        if (lane + 64 * j < d) p = p + v[j];
-    const float mean = wave_sum64(p) / (float)d;
-    float q = 0.0f;
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= rows) break;
+        float p = 0.0f;
 #pragma unroll
-    for (int j = 0; j < PER_LANE; ++j) {
-        const int i = lane + 64 * j;
-        if (i < d) {
-            const float c = v[j] - mean;
-            q = q + c * c;
+        for (int j = 0; j < PER_LANE; ++j)
+            if (lane + 64 * j < d) p = p + v[r][j];
+        const float mean = wave_sum64(p) / (float)d;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j) {
+            const int i = lane + 64 * j;
+            if (i < d) {
+                const float c = v[r][j] - mean;
+                q = q + c * c;
+            }
         }
-    }
-    const float var = wave_sum64(q) / (float)d;
-    const float rstd = 1.0f / __builtin_sqrtf(var + eps);
-    float *yr = y + row * d;
-    __bf16 *yh = reinterpret_cast<__bf16 *>(y) + row * d;          // bf16 mode: the consuming GEMM's operand, rounded here instead of there
+        const float var = wave_sum64(q) / (float)d;
+        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+        float *yr = y + row * d;
+        __bf16 *yh = reinterpret_cast<__bf16 *>(y) + row * d;      // bf16 mode: the consuming GEMM's operand, rounded here instead of there
 #pragma unroll
-    for (int j = 0; j < PER_LANE; ++j) {
-        const int i = lane + 64 * j;
-        if (i < d) {
-            const float o = __builtin_fmaf((v[j] - mean) * rstd, gv[j], bv[j]);
-            if (y_bf16 == 1) yh[i] = (__bf16)o;
-            else if (y_bf16 == 2) yr[(i & ~15) | ((i & 3) << 2) | ((i >> 2) & 3)] = o;   // sigma K layout (kernels.hpp: GemmArgs::a_sigma)
-            else yr[i] = o;
+        for (int j = 0; j < PER_LANE; ++j) {
+            const int i = lane + 64 * j;
+            if (i < d) {
+                const float o = __builtin_fmaf((v[r][j] - mean) * rstd, gv[j], bv[j]);
+                if (y_bf16 == 1) yh[i] = (__bf16)o;
+                else if (y_bf16 == 2) yr[(i & ~15) | ((i & 3) << 2) | ((i >> 2) & 3)] = o;   // sigma K layout (kernels.hpp: GemmArgs::a_sigma)
+                else yr[i] = o;
+            }
         }
     }
 }
@@ -114,10 +133,20 @@ void launch_layernorm2(const float *x, int64_t rows, int d, const float *g1, con
 }
 
 void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const float *b, float eps, float *y, hipStream_t s, int y_bf16) {
-    const dim3 grid((unsigned)((rows + 3) / 4));
-    if (d <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
-    else if (d <= 512) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
-    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
+    // few rows (streaming chunks, single clips): one row per wave -- the launch is latency-bound and wants every wave it can get;
+    // batches: PK_LN_RPW rows per wave share one load of gamma / beta
+    if (rows < 4096) {
+        const dim3 grid((unsigned)((rows + 3) / 4));
+        if (d <= 128) hipLaunchKernelGGL((layernorm_kernel<2, 1>), grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
+        else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<8, 1>), grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
+        else hipLaunchKernelGGL((layernorm_kernel<16, 1>), grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
+        return;
+    }
+    constexpr int RPW = PK_LN_RPW;
+    const dim3 grid((unsigned)((rows + 4 * RPW - 1) / (4 * RPW)));
+    if (d <= 128) hipLaunchKernelGGL((layernorm_kernel<2, RPW>), grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
+    else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<8, RPW>), grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
+    else hipLaunchKernelGGL((layernorm_kernel<16, RPW>), grid, dim3(256), 0, s, x, rows, d, g, b, eps, y, y_bf16);
 }
 
 __global__ __launch_bounds__(64) void sum64_rows_kernel(const float *__restrict__ x, int n, float *__restrict__ out) {
