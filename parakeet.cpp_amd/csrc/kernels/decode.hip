@@ -217,16 +217,18 @@ void launch_joint_act(const float *ep, const int *t, int T, int J, const float *
 // BOOST (phrase boosting, src/phrase_boost.cpp:177-350): the label argmax runs over log-prob + boost for the tokens that continue
 // an active trie state (a V-bit mask in LDS, rebuilt from the CSR children every step); the confidence stays the raw log-prob
 // and the active set advances on every emission.
-template <bool BOOST>
+template <bool BOOST, bool SCORE = false>
 __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // x[V+D], e[V+D], scratch[16] (+ BOOST: mask, active sets)
-    tdt_decide_one<BOOST, false>(st, blockIdx.x, sm);
+    tdt_decide_one<BOOST, false, SCORE>(st, blockIdx.x, sm);
 }
 void launch_tdt_decide(const TdtState &st, hipStream_t s) {
     const size_t lds = (size_t)(2 * (st.V + st.D) + 16) * sizeof(float);
     if (st.trie.off) {
         const size_t extra = (size_t)((st.V + 31) / 32 + 2 * kTrieMaxActive + 1) * sizeof(int);
         hipLaunchKernelGGL(tdt_decide_kernel<true>, dim3(st.B), dim3(256), lds + extra, s, st);
+    } else if (st.force_label) {
+        hipLaunchKernelGGL((tdt_decide_kernel<false, true>), dim3(st.B), dim3(256), lds, s, st);      // pk_tdt_score
     } else {
         hipLaunchKernelGGL(tdt_decide_kernel<false>, dim3(st.B), dim3(256), lds, s, st);
     }

@@ -295,7 +295,9 @@ __device__ __forceinline__ BestLP wave_logsoftmax_argmax(const float *__restrict
 
 // One utterance's decision of a lock-step decode step, by one 256-thread workgroup; sm = x[V+D], e[V+D], scratch[16] (+ BOOST: mask,
 // active sets).  COH: the words other workgroups of the same launch wrote / will read go through system-scope accesses.
-template <bool BOOST, bool COH>
+// SCORE: the teacher-forced form (pk_tdt_score, TdtState::force_label) -- compiled as its own kernel so that the decode loop's decision
+// kernel carries none of it (round 4: with the scoring code inline the V = 8193 decision went from 15.2 to 17.3 us per launch).
+template <bool BOOST, bool COH, bool SCORE = false>
 __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (dd_ldi<COH>(st.done + b)) return;
@@ -440,7 +442,6 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             const int i = i0 + 256 * u;
             if (i < st.V) {
                 float l = (t4[u] - m) - lse;
-                if constexpr (!BOOST) { if (st.score_lab) st.score_lab[(int64_t)steps_in * st.V + i] = l; }   // teacher-forced scoring: the row as the joint returns it
                 if constexpr (BOOST) l = l + (((mask[i >> 5] >> (i & 31)) & 1u) ? st.trie.boost : 0.0f);
                 if (bi == 0x7fffffff || l > best) { second = best; best = l; bi = i; }
                 else second = fmaxf(second, l);
@@ -478,7 +479,11 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     }
     if constexpr (BOOST) lab.lp = (x[lab.idx] - m) - lse;          // the confidence is the UNBOOSTED log-prob (phrase_boost.cpp:313-315)
     if (st.D > 0) skip = (int)red[5];
-    if constexpr (!BOOST) {
+    if constexpr (SCORE && !BOOST) {
+        if (st.score_lab) {                                        // teacher-forced scoring: the label log-prob row as the joint returns it (its own pass:
+            float *row = st.score_lab + (int64_t)steps_in * st.V;   // nothing of it sits in the decode loop's argmax sweep)
+            for (int i = tid; i < st.V; i += 256) row[i] = (x[i] - m) - lse;
+        }
         if (st.force_label) {                                      // teacher-forced scoring (TdtState::force_label): the given decision, not the argmax
             if (st.score_dur && tid < st.D) st.score_dur[(int64_t)steps_in * st.D + tid] = e[st.V + tid];
             const int k = steps_in < st.n_force ? steps_in : st.n_force - 1;
@@ -556,7 +561,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         // prediction-net caching (TdtState::need): a token changed (token, h, c) -> the next step runs the cells and pred_proj again; a blank
         // changed only the frame -> this workgroup forms next step's z = relu(enc_proj[t'] + pp) from the cached pp (SK_ACT's epilogue, same
         // operand order: enc_proj + (pred_proj [+ bias]))
-        const bool fin = t >= Tb || (max_steps_b > 0 && nsteps >= max_steps_b) || (st.force_label && nsteps >= st.n_force);
+        const bool fin = t >= Tb || (max_steps_b > 0 && nsteps >= max_steps_b) || (SCORE && st.force_label && nsteps >= st.n_force);
         if (tid == 0) dd_sti<COH>(st.need + b, (commit && !fin) ? 1 : 0);
         if (!commit && !fin) {
             const float *epr = st.ep + (ep_row0 + t) * st.J, *ppr = st.pp + (int64_t)b * st.J;
@@ -569,7 +574,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         }
     }
     if (lane0 == 0) {
-        bool finished = t >= Tb || (st.force_label && nsteps >= st.n_force);
+        bool finished = t >= Tb || (SCORE && st.force_label && nsteps >= st.n_force);
         int len = n_out < st.max_tokens ? n_out : st.max_tokens;
         if (!finished && max_steps_b > 0 && nsteps >= max_steps_b) { finished = true; len = -1; }   // safety cap
         dd_sti<COH>(st.t + b, t);
