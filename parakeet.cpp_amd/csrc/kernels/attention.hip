@@ -35,8 +35,14 @@ __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v
 // SG (long sequences, > ~85 s of audio): the score block of a workgroup lives in a global scratch area instead of LDS -- the same
 // code, indexing and barriers (a workgroup's own global writes are visible to it after __syncthreads()), so the same bits; slower,
 // but the length is then bounded by HBM, not by the 160 KB of LDS.
-template <int HD, int VCH, bool SG = false>
-__global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_kernel(const float *__restrict__ qkv, int ldq, int d, int T,
+// RAG: the ragged-batch form (per-unit utterance extents, kernels.hpp: SeqRag) is its own instantiation -- the uniform kernel sits exactly at
+// its 128-VGPR budget (four workgroups per CU) and must not carry a single extra live value (round 4: the shared form spilled 11 dwords per
+// lane instead of 4 and lost 2.5 %).
+// OCC: workgroups per CU the instantiation is register-budgeted for (128 / 168 / 256 VGPRs for 4 / 3 / 2).  The launcher picks the largest the
+// LDS footprint of the sequence length allows anyway: a 30 s utterance (T = 376: 71 KB of score planes + V chunk, two workgroups per CU)
+// gains nothing from the spills of the 128-VGPR build.
+template <int HD, int VCH, bool SG = false, bool RAG = false, int OCC = (HD <= 64 ? ATT_OCC : 2)>
+__global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float *__restrict__ qkv, int ldq, int d, int T,
                                                                const float *__restrict__ pos /*[2T-1][d], sigma columns*/,
                                                                const float *__restrict__ bias_u, const float *__restrict__ bias_v,
                                                                float scale, float *__restrict__ ctx, int PITS, int n_rb, int n_bh,
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
     // give them consecutive slots on ONE XCD so the second..last read those rows from that XCD's L2 instead of HBM.
     int h, i0;
     int64_t row0;                                                   // first row of this utterance in the (packed) row axis of qkv / ctx
-    if (rg.units.u) {
+    if constexpr (RAG) {
         // ragged batch (kernels.hpp: SeqRag): XCD x takes head x (+ 8, ...) of EVERY utterance, the row blocks of one utterance in consecutive
         // slots -- the same L2 sharing; this utterance's own length, and its window of the position table built for rg.pos_T frames
         const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256, HD <= 64 ? ATT_OCC : 2) void relpos_attention_
         }
 }
 
-template <int HD, int VCH>
+template <int HD, int VCH, int OCC = (HD <= 64 ? ATT_OCC : 2)>
 static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const float *pos, const float *bias_u, const float *bias_v,
                        float *ctx, float scale_arg, hipStream_t s, float *scratch, int ctx_bf16, int pos_row0, const SeqRag &rag) {
     const float scale = scale_arg > 0.0f ? scale_arg : 1.0f / sqrtf((float)HD);   // src/encoder.cpp:126
@@ -317,15 +323,26 @@ static void launch_att(const float *qkv, int B, int T, int d, int n_heads, const
     if (scratch) {
         {
             const size_t lds = (size_t)VCH * (HD + 16) * sizeof(float);
-            hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, true>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits,
-                               n_rb, n_bh, scratch, ctx_bf16, pos_row0, rag);
+            if (rag.units.u)
+                hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, true, true, OCC>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits,
+                                   n_rb, n_bh, scratch, ctx_bf16, pos_row0, rag);
+            else
+                hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, true, false, OCC>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits,
+                                   n_rb, n_bh, scratch, ctx_bf16, pos_row0, rag);
         }
         return;
     }
     const size_t lds = (size_t)(4 * (RB * pits + 8) + VCH * (HD + 16)) * sizeof(float);
+    if (rag.units.u) {
+        static DynLdsSlots slots_r;
+        ensure_dyn_lds(slots_r, reinterpret_cast<const void *>(&relpos_attention_kernel<HD, VCH, false, true, OCC>), lds);
+        hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, false, true, OCC>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits, n_rb, n_bh,
+                           (float *)nullptr, ctx_bf16, pos_row0, rag);
+        return;
+    }
     static DynLdsSlots slots;
-    ensure_dyn_lds(slots, reinterpret_cast<const void *>(&relpos_attention_kernel<HD, VCH, false>), lds);
-    hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, false>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits, n_rb, n_bh,
+    ensure_dyn_lds(slots, reinterpret_cast<const void *>(&relpos_attention_kernel<HD, VCH, false, false, OCC>), lds);
+    hipLaunchKernelGGL((relpos_attention_kernel<HD, VCH, false, false, OCC>), grid, dim3(256), lds, s, qkv, 3 * d, d, T, pos, bias_u, bias_v, scale, ctx, pits, n_rb, n_bh,
                        (float *)nullptr, ctx_bf16, pos_row0, rag);
 }
 
@@ -377,7 +394,11 @@ void launch_relpos_attention(const float *qkv, int B, int T, int d, int n_heads,
             const int n = (int)((size_t)160 * 1024 / lds);
             return n < ATT_OCC ? n : ATT_OCC;
         };
+        // (measured on a 5-15 s mixed batch, T_max = 185: 32-row chunks at four workgroups per CU 1.69 ms, 64-row chunks at three without spills 1.77,
+        //  64-row chunks at three on the 128-VGPR build 1.85)
         if (!scratch && occ(32) > occ(64)) launch_att<64, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
+        // LDS allows at most three workgroups per CU whatever the chunk (T > 200): the register budget of three (the kernel needs 134-140 VGPRs: no spills)
+        else if (!scratch && occ(64) <= 3) launch_att<64, 64, 3>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
         else launch_att<64, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
     } else if (hd == 128) launch_att<128, 32>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
     else if (hd == 32) launch_att<32, 64>(qkv, B, T, d, n_heads, pos, bias_u, bias_v, ctx, scale, s, scratch, ctx_bf16, pos_row0, rag);
