@@ -50,7 +50,7 @@ void launch_pos_cvec(const void *pos_bf16, const float *bias_u, const float *bia
 
 __device__ __forceinline__ int ab_rowidx(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }     // row of accumulator register r (32x32 C layout)
 
-template <int HD>
+template <int HD, bool RAG = false /* ragged batch: its own instantiation (the uniform kernel sits at its 256-VGPR budget) */>
 __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __bf16 *__restrict__ qkv, int ldq, int d, int T,
                                                                        const __bf16 *__restrict__ pos /*[2T-1][d]*/, const float *__restrict__ cvec /*[H][2T-1]*/,
                                                                        const float *__restrict__ bias_u, float scale_log2e, __bf16 *__restrict__ ctx,
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
     const int H = d / HD;
     int h, qb;
     int64_t row0;                                                   // first row of this utterance in the (packed) row axis of qkv / ctx
-    if (rg.units.u) {   // ragged batch (kernels.hpp: SeqRag; attention.hip has the same mapping): this utterance's own length
+    if constexpr (RAG) {   // ragged batch (kernels.hpp: SeqRag; attention.hip has the same mapping): this utterance's own length
         const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
         h = (k / rg.units.count) * 8 + xcd;
         if (h >= H) return;
@@ -297,11 +297,19 @@ static void launch_att_bf16(const void *qkv, int B, int T, int d, int n_heads, c
     const int n_qb = (T + AB_QB - 1) / AB_QB, n_bh = B * n_heads, nkt = (T + 31) / 32;
     const float scale_log2e = (1.0f / sqrtf((float)HD)) * 1.44269504088896340736f;
     const size_t lds = relpos_attention_bf16_lds_bytes(T, HD);
-    auto kern = &relpos_attention_bf16_kernel<HD>;
+    if (rag.units.u) {
+        auto kern = &relpos_attention_bf16_kernel<HD, true>;
+        static DynLdsSlots slots_r;
+        ensure_dyn_lds(slots_r, reinterpret_cast<const void *>(kern), lds);
+        const dim3 grid((unsigned)(((n_heads + 7) / 8) * 8 * (int64_t)rag.units.count));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, static_cast<const __bf16 *>(qkv), 3 * d, d, T, static_cast<const __bf16 *>(pos), cvec, bias_u,
+                           scale_log2e, static_cast<__bf16 *>(ctx), n_qb, n_bh, nkt, pos_T, rag);
+        return;
+    }
+    auto kern = &relpos_attention_bf16_kernel<HD, false>;
     static DynLdsSlots slots;
     ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
     dim3 grid(((n_bh + 7) / 8) * 8 * n_qb);
-    if (rag.units.u) grid = dim3((unsigned)(((n_heads + 7) / 8) * 8 * (int64_t)rag.units.count));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, static_cast<const __bf16 *>(qkv), 3 * d, d, T, static_cast<const __bf16 *>(pos), cvec, bias_u,
                        scale_log2e, static_cast<__bf16 *>(ctx), n_qb, n_bh, nkt, pos_T, rag);
 }
