@@ -272,13 +272,15 @@ typedef struct pk_result {      /* TranscribeResult (transcribe.hpp:23-30) + Tim
     int32_t n_words;
     const pk_word *words;
 } pk_result;
-/* Clips are pcm[offsets[i] .. offsets[i+1]), of ANY lengths: they are sorted by length and packed into ragged batches (<= 256 clips, <= 64 x
- * 10 s of audio per batch) that go through the two-stream pipeline; every clip's result is bit-identical to transcribing it alone.
+/* Clips are pcm[offsets[i] .. offsets[i+1]), of ANY lengths: they are sorted by length and packed into ragged batches (<= 256 clips, <= 8192
+ * encoder rows = 655 s of audio per batch: the row count at which every GEMM of the encoder fills whole rounds of the 256 CUs) that go through
+ * the two-stream pipeline; every clip's result is bit-identical to transcribing it alone.
  * results: array of n_clips pk_result, owned by the library until pk_results_free. */
 pk_status pk_transcribe_pcm(pk_model *m, const float *pcm, const int64_t *offsets, int n_clips, const pk_options *opt,
                             pk_result **results);
 /* The packing policy of pk_transcribe_pcm / pk_group_transcribe_pcm on its own (host logic, no GPU needed): clips of n_samples[i] samples
- * are sorted by length (longest first, stable) and cut into batches of <= 256 clips and <= 64 x 10 s of audio; batch_of_clip[i] = the
+ * are sorted by length (longest first, stable) and cut into batches of <= 256 clips and <= 8192 encoder rows (pk_encoder_num_frames of
+ * pk_mel_num_frames of the length; 65 clips of 10 s); batch_of_clip[i] = the
  * batch clip i lands in (batch 0 holds the longest clips), pos_in_batch[i] (optional) = its row in that batch. */
 pk_status pk_plan_batches(const int64_t *n_samples, int n_clips, int32_t *batch_of_clip, int32_t *pos_in_batch, int *n_batches);
 /* Per-clip extents of a ragged batch (host logic): mel frames pk_mel_num_frames(n), encoder frames pk_encoder_num_frames(...) of every

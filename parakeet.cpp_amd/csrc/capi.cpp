@@ -1079,14 +1079,21 @@ struct ResultStore {          // owns everything a pk_result array points into
 }  // namespace
 
 // The packing policy of the one-call API (pure host logic; pk_plan_batches exposes it): clips sorted by length, longest first (stable), then
-// cut greedily into batches of at most kMaxBatchClips clips and kBatchSamples samples (a single longer clip gets a batch of its own).
+// cut greedily into batches of at most kMaxBatchClips clips and kBatchRows ENCODER ROWS (a single longer clip gets a batch of its own).
+// Rows, not seconds, are what the batch costs: every product of the encoder is an M x N x K GEMM with M = the batch's packed rows, tiled 128
+// (64) rows high, and 8192 rows are exactly the tile grids the kernels were tuned on -- fc2 / out_proj / pw2: 256 (512) tiles = ONE round of the
+// 256 CUs, fc1: 1024 tiles = two rounds.  One tile row more starts another round of workgroups on every product: measured round 4
+// (profiles/r04_mixed_bench_distributions.txt) 8272 rows cost fc2 +52 %, out_proj / pw2 +59 %, the encoder 27.3 instead of ~21 ms.
 static const int kMaxBatchClips = 256;
-static const int64_t kBatchSamples = (int64_t)64 * 160000;       // 64 x 10 s: ~8000 encoder rows per batch, where the GEMMs run at their best
+static const int64_t kBatchRows = 8192;                          // 64 tile rows of 128; 64 x 10 s = 8064 rows, 65 x 10 s = 8190
 static void plan_batches(const int64_t *len, int n, std::vector<int> &order, std::vector<int> &bstart) {
     order.resize(n);
+    std::vector<int64_t> rows(n);
     for (int i = 0; i < n; ++i) {
         need(len[i] > 256, "every clip needs more than 256 samples");
+        need(len[i] <= ((int64_t)1 << 30), "clip too long");
         order[i] = i;
+        rows[i] = pk_encoder_num_frames(pk_mel_num_frames(len[i]));
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
     bstart.clear();
@@ -1094,7 +1101,7 @@ static void plan_batches(const int64_t *len, int n, std::vector<int> &order, std
         bstart.push_back(i);
         int64_t tot = 0;
         int j = i;
-        while (j < n && j - i < kMaxBatchClips && (j == i || tot + len[order[j]] <= kBatchSamples)) tot += len[order[j++]];
+        while (j < n && j - i < kMaxBatchClips && (j == i || tot + rows[order[j]] <= kBatchRows)) tot += rows[order[j++]];
         i = j;
     }
     bstart.push_back(n);

@@ -14,9 +14,15 @@ def sub_len(n):
     return n
 
 
+def rows_of(n):
+    return sub_len(1 + int(n) // 160)
+
+
 def test_plan_sorts_longest_first_and_respects_both_caps():
+    """<= 256 clips and <= 8192 ENCODER ROWS per batch (the row count at which the encoder's GEMM tile grids fill whole rounds of the 256 CUs)."""
     rng = np.random.default_rng(0)
     lens = rng.integers(300, 480001, 1000)
+    rows = np.array([rows_of(n) for n in lens])
     b, p, nb = capi.plan_batches(lens)
     assert nb == b.max() + 1 and nb >= 2
     longest_of = [lens[b == k].max() for k in range(nb)]
@@ -24,7 +30,7 @@ def test_plan_sorts_longest_first_and_respects_both_caps():
     for k in range(nb):
         idx = np.where(b == k)[0]
         assert len(idx) <= 256
-        assert lens[idx].sum() <= 64 * 160000 or len(idx) == 1
+        assert rows[idx].sum() <= 8192 or len(idx) == 1
         assert sorted(p[idx].tolist()) == list(range(len(idx))), "positions inside a batch are 0 .. n-1"
         inside = idx[np.argsort(p[idx])]
         assert (np.diff(lens[inside]) <= 0).all(), "longest first inside a batch"
@@ -32,18 +38,22 @@ def test_plan_sorts_longest_first_and_respects_both_caps():
             assert longest_of[k] <= shortest_of[k - 1], "batches are runs of the length-sorted order"
     # a batch is closed only because the next clip would not fit (or 256 clips are in it)
     order = np.lexsort((np.arange(len(lens)), -lens))
+    done = 0
     for k in range(nb - 1):
-        nxt = lens[order[(b[order] == k).sum() + sum((b == j).sum() for j in range(k))]]
-        assert (b == k).sum() == 256 or lens[b == k].sum() + nxt > 64 * 160000
+        done += (b == k).sum()
+        nxt = rows[order[done]]
+        assert (b == k).sum() == 256 or rows[b == k].sum() + nxt > 8192
 
 
 def test_plan_edge_cases():
-    b, p, nb = capi.plan_batches([160000] * 64)
-    assert nb == 1 and (b == 0).all() and p.tolist() == list(range(64)), "64 x 10 s is exactly one batch (stable order)"
     b, p, nb = capi.plan_batches([160000] * 65)
-    assert nb == 2 and (b == 0).sum() == 64
-    b, p, nb = capi.plan_batches([64 * 160000 + 1, 300])
-    assert nb == 2 and b.tolist() == [0, 1], "a clip longer than the sample budget travels alone"
+    assert nb == 1 and (b == 0).all() and p.tolist() == list(range(65)), "65 x 10 s = 8190 rows is exactly one batch (stable order)"
+    b, p, nb = capi.plan_batches([160000] * 66)
+    assert nb == 2 and (b == 0).sum() == 65
+    b, p, nb = capi.plan_batches([480000] * 22)
+    assert nb == 2 and (b == 0).sum() == 21, "21 x 30 s = 7896 rows; the 22nd clip would start another round of GEMM tiles"
+    b, p, nb = capi.plan_batches([8193 * 1280, 300])
+    assert nb == 2 and b.tolist() == [0, 1], "a clip of more rows than the budget travels alone"
     b, p, nb = capi.plan_batches([300] * 600)
     assert nb == 3 and [(b == k).sum() for k in range(3)] == [256, 256, 88], "the clip cap closes batches of short clips"
     b, p, nb = capi.plan_batches([257])
