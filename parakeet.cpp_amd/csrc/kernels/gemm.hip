@@ -226,6 +226,14 @@ static void launch_epi(const GemmArgs &a, hipStream_t s) {
     // one on every large shape, in the micro-benchmark (tools/ubench/gemm_sweep ml: main loop 130-135 vs 118-125 TF) and, by less, in the
     // engine (fc2 -8 %, fc1 -3.6 %, qkv -5 %, GLU -3 %): gemm_variant_mask().
     if (a.M >= 1024 && (a.N >= 1024 || (a.M >= 65536 && a.N >= 256))) {
+        // bit 128: 192x128 tiles (8 waves of 96x32) where they turn a fractional second round of the 512 resident 128x128 workgroups into one
+        // full round (attn_qkv of the 110M model at 64 x 10 s: 63 x 12 = 756 tiles = 1.48 rounds -> 42 x 12 = 504)
+        // Measured (profiles/r04_gemm_tile192_ab.txt): NO gain, qkv 1.97 -> 1.99 ms per step -- workgroups are handed out as slots free up, so a
+        // CU never idles for a 'round'; the bit stays off (results are bit-identical either way: same k order).
+        if constexpr (EPI != EPI_GLU) {
+            const int64_t tiles192 = (int64_t)((a.M + 191) / 192) * ((a.N + 127) / 128);
+            if ((vm & 128) && tiles192 <= 512 && tiles128 > 512 && tiles128 < 900) { launch_gemm_pipe<2, 4, 3, 1, 32, EPI, 1>(a, s); return; }
+        }
         if ((vm & 16) && a.K % 64 == 0 && a.K >= 128) launch_gemm_pipe<4, 2, 1, 2, 64, EPI, 1>(a, s);
         else if (vm & 2) launch_gemm_pipe<4, 2, 1, 2, 32, EPI, 1>(a, s);
         else launch_gemm_pipe<4, 2, 1, 2, 32, EPI>(a, s);

@@ -54,7 +54,8 @@ def test_layernorm_bit_identical(capi, orc, d):
     assert np.array_equal(bits(capi.diag_layernorm(x, g, b)), bits(orc.layer_norm(x, g, b)))
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (126, 512, 512), (300, 1025, 512), (252, 640, 2048), (1000, 256, 256)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (126, 512, 512), (300, 1025, 512), (252, 640, 2048), (1000, 256, 256),
+                                   (8000, 1536, 512), (8064, 2048, 512), (8064, 512, 2048)])   # the big-tile kernels at the headline's own shapes
 def test_mfma_gemm_is_natural_k_fma_chain(capi, orc, M, N, K):
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
