@@ -438,8 +438,14 @@ int pk_group_timestamps(const pk_model *m, const int32_t *ids, const int32_t *st
                         int n, int sentences, char *words, int cap, float *wstart, float *wend, float *wconf, int wcap);
 
 /* ---- diagnostics used by the GPU parity tests (single kernels behind the same ABI) ------------------------ */
-/* Device math, elementwise: fn 0 exp, 1 log, 2 tanh, 3 sigmoid, 4 silu, 5 sqrt, 6 reciprocal. */
+/* Device math, elementwise: fn 0 exp, 1 log, 2 tanh, 3 sigmoid, 4 silu, 5 sqrt, 6 reciprocal, 7 relu, 8 / 9 sigmoid / silu as the GEMM
+ * epilogues evaluate them (guarded short sequences, pk_devmath.h). */
 pk_status pk_diag_math(int fn, const float *in, float *out, int64_t n);
+/* Every one of the 2^32 bit patterns of x through a device-side identity (kernels/norm.hip, math_exhaustive_kernel): fn 3 / 4 = wherever the
+ * short sigmoid / SiLU instruction sequences of the GEMM epilogues claim validity they equal the specification's value; fn 13 / 14 = the guarded
+ * four-at-a-time forms equal the specification on every pattern.  checked = patterns examined, mismatches must be 0, first_bad = lowest
+ * mismatching pattern (2^32 when none).  About 0.1 s. */
+pk_status pk_diag_math_exhaustive(int fn, uint64_t *checked, uint64_t *mismatches, uint64_t *first_bad);
 /* out[M][N] = epi(A[M][K] * W[N][K]^T + bias) with the production fp32-MFMA GEMM.  epi: 0 none, 1 relu, 2 silu,
  * 3 residual: out = resid + alpha*(acc+bias), 4 glu (N even: out[M][N/2] = a * sigmoid(b)). */
 pk_status pk_diag_gemm(int M, int N, int K, const float *A, const float *W, const float *bias, int epi,

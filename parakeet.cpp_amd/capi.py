@@ -100,6 +100,7 @@ def lib():
     L.pk_mel_num_frames.argtypes = [C.c_int64]
     L.pk_encoder_num_frames.argtypes = [C.c_int]
     L.pk_diag_math.argtypes = [C.c_int, f32p, f32p, C.c_int64]
+    L.pk_diag_math_exhaustive.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pk_diag_gemm.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, C.c_int, f32p, C.c_float, f32p]
     L.pk_diag_gemm_bf16.argtypes = L.pk_diag_gemm.argtypes
     L.pk_diag_gemm_bf16_a16.argtypes = L.pk_diag_gemm.argtypes
@@ -206,7 +207,7 @@ def device_count():
 
 
 # ---- diagnostics ---------------------------------------------------------------------------------
-MATH_FN = {"exp": 0, "log": 1, "tanh": 2, "sigmoid": 3, "silu": 4, "sqrt": 5, "rcp": 6}
+MATH_FN = {"exp": 0, "log": 1, "tanh": 2, "sigmoid": 3, "silu": 4, "sqrt": 5, "rcp": 6, "sigmoid4": 8, "silu4": 9}
 EPI = {"none": 0, "relu": 1, "silu": 2, "resid": 3, "glu": 4}
 
 
@@ -215,6 +216,13 @@ def diag_math(fn, x):
     y = np.empty_like(x)
     check(lib().pk_diag_math(MATH_FN[fn], _f(x), _f(y), x.size))
     return y
+
+
+def diag_math_exhaustive(fn, guarded=False):
+    """all 2^32 bit patterns through the device-side identity of pk_diag_math_exhaustive -> (checked, mismatches, first_bad)"""
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    check(lib().pk_diag_math_exhaustive(MATH_FN[fn] + (10 if guarded else 0), C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 def resample(pcm, src_rate, dst_rate):

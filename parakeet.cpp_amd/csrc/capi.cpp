@@ -1708,6 +1708,23 @@ pk_status pk_diag_math(int fn, const float *in, float *out, int64_t n) {
     });
 }
 
+pk_status pk_diag_math_exhaustive(int fn, uint64_t *checked, uint64_t *mismatches, uint64_t *first_bad) {
+    return guard([&] {
+        need(fn == 3 || fn == 4 || fn == 13 || fn == 14, "fn must be 3, 4, 13 or 14");
+        need(checked && mismatches && first_bad, "checked/mismatches/first_bad");
+        diag_device();
+        Scratch s;
+        s.a.reserve(3 * sizeof(uint64_t));
+        const uint64_t init[3] = {0, 0, 1ull << 32};
+        PK_HIP(hipMemcpy(s.a.p, init, sizeof init, hipMemcpyHostToDevice));
+        launch_math_exhaustive(fn, s.a.as<unsigned long long>(), nullptr);
+        PK_CHECK_LAUNCH();
+        uint64_t res[3];
+        PK_HIP(hipMemcpy(res, s.a.p, sizeof res, hipMemcpyDeviceToHost));
+        *checked = res[0]; *mismatches = res[1]; *first_bad = res[2];
+    });
+}
+
 pk_status pk_diag_gemm(int M, int N, int K, const float *A, const float *W, const float *bias, int epi, const float *resid,
                        float alpha, float *out) {
     return guard([&] {

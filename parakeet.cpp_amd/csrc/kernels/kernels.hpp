@@ -280,6 +280,7 @@ void launch_layernorm2(const float *x, int64_t rows, int d, const float *g1, con
                        float *y1, float *y2, hipStream_t s, int y2_bf16 = 0);
 void launch_sum64_rows(const float *x, int rows, int n, float *out, hipStream_t s);
 void launch_math(int fn, const float *in, float *out, int64_t n, hipStream_t s);   // 0 exp 1 log 2 tanh 3 sigmoid 4 silu 5 sqrt 6 recip 7 relu
+void launch_math_exhaustive(int fn, unsigned long long *out3, hipStream_t s);   // out3 must hold {0, 0, 1 << 32} on entry
 void launch_scale(float *x, int64_t n, float a, hipStream_t s);
 
 }  // namespace pk

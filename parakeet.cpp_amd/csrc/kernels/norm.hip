@@ -173,6 +173,8 @@ __global__ void math_kernel(int fn, const float *__restrict__ in, float *__restr
         case 5: y = __builtin_sqrtf(x); break;
         case 6: y = 1.0f / x; break;
         case 7: y = x > 0.0f ? x : 0.0f; break;
+        case 8: { float v[4] = {x, x, x, x}; dsigmoid4(v); y = v[0]; break; }   // the GEMM epilogues' guarded four-at-a-time forms
+        case 9: { float v[4] = {x, x, x, x}; dsilu4(v); y = v[0]; break; }
         default: y = x;
         }
         out[i] = y;
@@ -181,6 +183,41 @@ __global__ void math_kernel(int fn, const float *__restrict__ in, float *__restr
 void launch_math(int fn, const float *in, float *out, int64_t n, hipStream_t s) {
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(math_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, fn, in, out, n);
+}
+
+// All 2^32 bit patterns of x.  fn 3 / 4: wherever the short sigmoid / SiLU sequences of pk_devmath.h claim validity (d*_mid_ok), their value
+// must equal the specification's bit for bit.  fn 13 / 14: the guarded four-at-a-time forms the GEMM epilogues call, on EVERY pattern
+// (x with three neighbours: -x, x with the exponent's low bit flipped, the next pattern), against the specification.
+// out[0] = patterns checked, out[1] = mismatches, out[2] = lowest mismatching pattern (or 2^32).
+__global__ void math_exhaustive_kernel(int fn, unsigned long long *out) {
+    unsigned long long checked = 0, bad = 0, first = 1ull << 32;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const unsigned u = (unsigned)i;
+        const float x = __uint_as_float(u);
+        bool mism = false;
+        if (fn == 3 || fn == 4) {
+            const bool ok = fn == 3 ? dsigmoid_mid_ok(x) : dsilu_mid_ok(x);
+            if (!ok) continue;
+            const float a = fn == 3 ? dsigmoidf_mid(x) : dsiluf_mid(x), b = fn == 3 ? dsigmoidf(x) : dsiluf(x);
+            mism = __float_as_uint(a) != __float_as_uint(b);
+        } else {
+            float v[4] = {x, -x, __uint_as_float(u ^ 0x00800000u), __uint_as_float(u + 1u)}, w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = fn == 13 ? dsigmoidf(v[e]) : dsiluf(v[e]);
+            if (fn == 13) dsigmoid4(v); else dsilu4(v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mism = mism || (__float_as_uint(v[e]) != __float_as_uint(w[e]) && !(v[e] != v[e] && w[e] != w[e]));
+        }
+        ++checked;
+        if (mism) { ++bad; first = i < first ? i : first; }
+    }
+    atomicAdd(out, checked);
+    atomicAdd(out + 1, bad);
+    atomicMin(out + 2, first);
+}
+void launch_math_exhaustive(int fn, unsigned long long *out3, hipStream_t s) {
+    hipLaunchKernelGGL(math_exhaustive_kernel, dim3(8192), dim3(256), 0, s, fn, out3);
 }
 
 __global__ void scale_kernel(float *__restrict__ x, int64_t n, float a) {

@@ -125,6 +125,74 @@ __device__ __forceinline__ float fast_sigmoidf(float x) { return __builtin_amdgc
 __device__ __forceinline__ float fast_siluf(float x) { return x * fast_sigmoidf(x); }
 __device__ __forceinline__ float dsiluf(float x) { return x / (1.0f + dexpf(-x)); }
 
+// ---- the same SiLU / sigmoid VALUES in fewer operations, for the GEMM epilogues (fc1 applies SiLU to 16.5 M results per launch) -------------
+// For an argument of ordinary size the specification's range selects are dead, 2^n can be applied as an add to the exponent field, and the
+// IEEE division needs neither v_div_scale nor v_div_fixup: reciprocal estimate, one Newton step, quotient, one exact-remainder correction.
+// That this 6-operation quotient is the CORRECTLY ROUNDED one (= the specification's `/`) is not a theorem for arbitrary operands; it is
+// checked for every operand pair these functions can produce: pk_diag_math_exhaustive runs all 2^32 bit patterns of x through
+// "mid_ok(x) => mid(x) == spec(x)" on the device (tests/test_gpu_primitives.py; profiles/r04_silu_exhaustive.txt), and the specification
+// path is what the oracle parity tests pin.  Lanes outside the checked range (|x| >= 80, NaN, -0) send their whole wave down the
+// specification path -- results are identical by construction, only the instruction count differs (22 instead of 34 per element).
+__device__ __forceinline__ float dexpf_mid(float a) {                   // e^a for |a| < 80, bit-equal to dexpf(a)
+    const float t = __builtin_fmaf(a, 1.44269502162933349609375f, 12582912.0f);
+    const float n = t - 12582912.0f;
+    float r = __builtin_fmaf(n, -0.693145751953125f, a);
+    r = __builtin_fmaf(n, -1.428606765330187045037746429443359375e-06f, r);
+    float e = 0x1.6d4332p-10f;
+    e = __builtin_fmaf(e, r, 0x1.120b74p-7f);
+    e = __builtin_fmaf(e, r, 0x1.5554e8p-5f);
+    e = __builtin_fmaf(e, r, 0x1.5554dcp-3f);
+    e = __builtin_fmaf(e, r, 0.5f);
+    const float q = __builtin_fmaf(r * r, e, r);
+    const float p = q + 1.0f;
+    // t = 1.5 * 2^23 + n exactly, so its low mantissa bits hold n in two's complement: p * 2^n = bits(p) + (n << 23), one v_lshl_add_u32
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(t) << 23));
+}
+__device__ __forceinline__ bool dsilu_mid_ok(float x) { return __builtin_fabsf(x) < 80.0f && __float_as_uint(x) != 0x80000000u; }
+__device__ __forceinline__ bool dsigmoid_mid_ok(float x) { return __builtin_fabsf(x) < 80.0f; }
+__device__ __forceinline__ float dsiluf_mid(float x) {                  // == dsiluf(x) where dsilu_mid_ok(x)
+    const float d = 1.0f + dexpf_mid(-x);
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, x), r, q);
+}
+__device__ __forceinline__ float dsigmoidf_mid(float x) {               // == dsigmoidf(x) where dsigmoid_mid_ok(x)
+    const float d = 1.0f + dexpf_mid(-x);
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+// four results at a time with ONE wave-uniform range check (the epilogues finish 4 consecutive output columns per thread)
+__device__ __forceinline__ void dsilu4(float (&v)[4]) {
+    const bool ok = dsilu_mid_ok(v[0]) && dsilu_mid_ok(v[1]) && dsilu_mid_ok(v[2]) && dsilu_mid_ok(v[3]);
+#ifdef PK_AB_ACT_SPEC                                             // A/B builds only (tools/experiments/act_short_ab.sh): always the long sequences
+    if (false) {
+#else
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+#endif
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dsiluf_mid(v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dsiluf(v[e]);
+    }
+}
+__device__ __forceinline__ void dsigmoid4(float (&v)[4]) {
+    const bool ok = dsigmoid_mid_ok(v[0]) && dsigmoid_mid_ok(v[1]) && dsigmoid_mid_ok(v[2]) && dsigmoid_mid_ok(v[3]);
+#ifdef PK_AB_ACT_SPEC
+    if (false) {
+#else
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+#endif
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dsigmoidf_mid(v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dsigmoidf(v[e]);
+    }
+}
+
 // 16 bytes to LDS as a ds_write2_b64 pair.  On gfx950 a 16-byte ds_write_b128 next to fragment reads is several times slower than the
 // same bytes written as two 8-byte halves (fp32 GEMM: 98 vs 120-130 TF; bf16 GEMM: 320 vs 580 TF; round 2).  The compiler does not know
 // the inline store: lds_store_fence() before the barrier that publishes it.

@@ -28,6 +28,29 @@ def test_device_math_is_bit_identical(capi, orc, fn, lo, hi):
     assert np.array_equal(bits(capi.diag_math(fn, x)), bits(orc.math_v(fn, x)))
 
 
+@pytest.mark.parametrize("fn", ["sigmoid", "silu"])
+def test_epilogue_activation_forms_are_the_specification(capi, orc, fn):
+    """The GEMM epilogues evaluate SiLU / sigmoid with a shorter instruction sequence where the argument is of ordinary size
+    (pk_devmath.h: dsilu4 / dsigmoid4).  (a) sampled against the ORACLE: ordinary arguments, the guard's edges, and uniformly random bit
+    patterns (waves that mix in-range and out-of-range lanes); (b) all 2^32 bit patterns on the device: wherever the short sequence claims
+    validity it equals the specification path, and the guarded four-at-a-time form equals it everywhere."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-30, 30, 1 << 20).astype(np.float32)
+    assert np.array_equal(bits(capi.diag_math(fn + "4", x)), bits(orc.math_v(fn, x)))
+    e = np.array([0.0, -0.0, 1e-30, -1e-30, 1e-40, -1e-40, 79.99999, -79.99999, 80.0, -80.0, 87.4, -87.4, 88.8, -88.8, 1e30, -1e30,
+                  np.inf, -np.inf, 1.1754944e-38, -1.1754944e-38], np.float32)
+    x = np.concatenate([np.repeat(e, 64), rng.uniform(-90, 90, 1 << 16).astype(np.float32)])
+    assert np.array_equal(bits(capi.diag_math(fn + "4", x)), bits(orc.math_v(fn, x)))
+    u = rng.integers(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    u = u[~np.isnan(u)]
+    assert np.array_equal(bits(capi.diag_math(fn + "4", u)), bits(orc.math_v(fn, u)))
+    checked, mism, first = capi.diag_math_exhaustive(fn)
+    assert mism == 0, f"short {fn} sequence differs from the specification at bit pattern {first:#010x}"
+    assert checked == 2 * 0x42A00000 - (1 if fn == "silu" else 0)          # every |x| < 80 (SiLU: except -0)
+    checked, mism, first = capi.diag_math_exhaustive(fn, guarded=True)
+    assert (checked, mism) == (1 << 32, 0), f"guarded {fn} differs at {first:#010x}"
+
+
 def test_device_log_sqrt_rcp_bit_identical(capi, orc):
     rng = np.random.default_rng(1)
     x = np.exp(rng.uniform(-87, 87, 1 << 20)).astype(np.float32)
