@@ -13,8 +13,8 @@
 //   * rel_shift: the position scores of key tile t need band rows  p - base = (j - j0) - (i - i0) + 31  in [0, 62] = two 32-row blocks of
 //     (q + u) P^T; consecutive key tiles share a block, so ONE new 32x32 block per tile goes into a wave-private LDS strip [64][34] and the
 //     skewed read  strip[jj - n + 31][n]  is conflict-free (pitch 34: the lane stride is 33 words).
-//   * K and P tiles are MFMA A operands straight from L2 (16 bytes per lane = the 8 k of one step), reloaded right after their last use so the
-//     loads fly under the softmax / PV phases.  V needs the contraction index (key) along the lane's 8 operands: the V tile is staged in LDS as
+//   * P tiles are MFMA A operands straight from L2 (16 bytes per lane = the 8 k of one step), reloaded right after their last use so the
+//     loads fly under the softmax / PV phases; K tiles are staged in LDS once per workgroup (natural rows, 16-byte fragment reads).  V needs the contraction index (key) along the lane's 8 operands: the V tile is staged in LDS as
 //     [4 keys][16 dv] sub-blocks and read with ds_read_b64_tr_b16 (gfx950 transpose read; lane-linear = conflict-free, tools/ubench/tr16_probe.cpp),
 //     double-buffered, one barrier per key tile.
 // Numerics: tolerance class (compared with the oracle's gemm_bf16 mode, which rounds the same operands: oracle/pk_oracle.c attention()).
@@ -48,6 +48,18 @@ void launch_pos_cvec(const void *pos_bf16, const float *bias_u, const float *bia
                        d / n_heads, cvec);
 }
 
+// Phase clocks for tools/ubench/attn_bf16_bench.cpp (-DAB_TRACE): per wave, shader clocks summed over the key tiles.  Production builds: nothing.
+#ifdef AB_TRACE
+__device__ long long *ab_trace;      // [workgroup][wave][8]
+#define AB_T0() long long ab_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ab_t_ = clock64()
+#define AB_STAMP(i) do { const long long n_ = clock64(); ab_acc_[i] += n_ - ab_t_; ab_t_ = n_; } while (0)
+#define AB_FLUSH() do { if (ab_trace && lane == 0) for (int i_ = 0; i_ < 8; ++i_) ab_trace[((long long)blockIdx.x * 4 + wave) * 8 + i_] = ab_acc_[i_]; } while (0)
+#else
+#define AB_T0() do { } while (0)
+#define AB_STAMP(i) do { } while (0)
+#define AB_FLUSH() do { } while (0)
+#endif
+
 __device__ __forceinline__ int ab_rowidx(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }     // row of accumulator register r (32x32 C layout)
 
 template <int HD, bool RAG = false /* ragged batch: its own instantiation (the uniform kernel sits at its 256-VGPR budget) */>
@@ -61,8 +73,10 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
     constexpr int NV = 32 * VCH / 256;   // V chunks per thread per key tile
     static_assert(NV >= 1, "HD >= 64");
     extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];
+    constexpr int KP = HD * 2 + 16;      // K tile row pitch in bytes (+16: the row-per-lane 16-byte fragment reads spread over the banks)
     __bf16 *Vimg = reinterpret_cast<__bf16 *>(ab_smem);                          // [2][32 * HD]   sub-blocked V tiles
-    float *skew = reinterpret_cast<float *>(ab_smem + 2 * 32 * HD * 2);          // [4][64 * AB_SKP]
+    unsigned char *Kimg = ab_smem + 2 * 32 * HD * 2;                             // [2][32 keys][KP bytes]  K tiles, natural rows
+    float *skew = reinterpret_cast<float *>(Kimg + 2 * 32 * KP);                 // [4][64 * AB_SKP]
     float *cb = skew + 4 * 64 * AB_SKP;                                          // [32 nkt + 128]  c band of this workgroup
     __builtin_amdgcn_s_setprio(3);
 
@@ -123,15 +137,29 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
             lds_store16(Vimg + buf * 32 * HD + blk * 64 + (key & 3) * 16 + (ch & 1) * 8, vreg[i]);
         }
     };
-    // A-operand tile straight from L2: lane (row n, half g) takes the 8 k of step s at 16 s + 8 g
-    ab_bf16x8 kreg[NK], preg[NK], qreg[NK];
+    // K tile: staged like V (whole rows, coalesced: a wave instruction covers 4-8 full rows) and shared by the four waves.  Round 4: as an A operand
+    // straight from L2 (row-per-lane 16-byte loads, 32 rows = 32 cache lines per instruction, every wave its own copy) the K and P loads kept the
+    // CU's vector L1 busy for ~5.5 k clocks per key tile against 0.8 k of MFMA work (tools/ubench/attn_bf16_bench: profiles/r04_attn_bf16_phases.txt).
+    float4 kst[NV];
     auto k_load = [&](int t) {
-        int kr = 32 * t + n;
-        kr = kr < T ? kr : T - 1;
-        const __bf16 *p = qrow + (int64_t)kr * ldq + d + 8 * g;
 #pragma unroll
-        for (int s = 0; s < NK; ++s) kreg[s] = *reinterpret_cast<const ab_bf16x8 *>(p + 16 * s);
+        for (int i = 0; i < NV; ++i) {
+            const int c = tid + 256 * i, key = c / VCH, ch = c % VCH;
+            int kr = 32 * t + key;
+            kr = kr < T ? kr : T - 1;
+            kst[i] = *reinterpret_cast<const float4 *>(qrow + (int64_t)kr * ldq + d + 8 * ch);
+        }
     };
+    auto k_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = tid + 256 * i, key = c / VCH, ch = c % VCH;
+            lds_store16(Kimg + buf * 32 * KP + key * KP + ch * 16, kst[i]);
+        }
+    };
+    // P block: A operand straight from L2 (every wave needs a different block at a given step; an LDS ring of four blocks does not fit beside the
+    // skew strips at two workgroups per CU): lane (row n, half g) takes the 8 k of step s at 16 s + 8 g
+    ab_bf16x8 preg[NK], qreg[NK];
     auto p_load = [&](int m) {
         int pr = base0 + 32 * m + n;
         pr = pr < 0 ? 0 : (pr > P - 1 ? P - 1 : pr);
@@ -154,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
         }
     };
 
+    AB_T0();
     v_load(0);
     if (active) {
         int qr = i0w + n;
@@ -166,10 +195,11 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
 #pragma unroll
             for (int e = 0; e < 8; ++e) qreg[s][e] = (__bf16)((float)raw[e] + bu[16 * s + e]);        // (q + u) as the reference forms it, rounded once
         }
-        k_load(0);
         p_load(0);
     }
+    k_load(0);
     v_store(0);
+    k_store(0);
     lds_store_fence();
     __syncthreads();                                                // V tile 0 and the c band are in LDS
     if (active) {
@@ -183,22 +213,26 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[dt][r] = 0.0f;
     float m_run = -__builtin_huge_valf(), l_run = 0.0f;
+    AB_STAMP(0);                                                    // prologue
 
     for (int t = 0; t < nkt; ++t) {
         const bool more = t + 1 < nkt;
-        if (more) v_load(t + 1);
+        if (more) { v_load(t + 1); k_load(t + 1); }
         if (active) {
             // ---- content scores, transposed: S^T[key][query], and position block t + 1: two INDEPENDENT chains of NK MFMAs, issued alternately
             //      (one after the other, every MFMA waits for its predecessor's result: a wave issues in order) ----
             ab_f32x16 sa, ga;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sa[r] = 0.0f; ga[r] = 0.0f; }
+            const unsigned char *kb = Kimg + (t & 1) * 32 * KP + n * KP + 16 * g;
 #pragma unroll
             for (int s = 0; s < NK; ++s) {
-                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kreg[s], qreg[s], sa, 0, 0, 0);
+                const ab_bf16x8 ka = *reinterpret_cast<const ab_bf16x8 *>(kb + 32 * s);
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[s], sa, 0, 0, 0);
                 ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preg[s], qreg[s], ga, 0, 0, 0);
             }
-            if (more) { k_load(t + 1); p_load(t + 2); }
+            AB_STAMP(1);                                            // QK^T and position MFMAs (incl. the wait for this tile's K / P operands)
+            if (more) p_load(t + 2);
             {   // block t + 1 (+ c) into the wave's skew strip, half (t + 1) & 1; then the skewed read of blocks t and t + 1
                 const int m = t + 1, cbase = 96 - 32 * wave + 32 * m;
 #pragma unroll
@@ -223,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                 // the strip half of block t is overwritten next iteration
+            AB_STAMP(2);                                            // skew strip write / read, scale, mask, local max
             // ---- online softmax: lanes n and n + 32 hold the two halves of query n's keys ----
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);
@@ -241,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
 #pragma unroll
                     for (int r = 0; r < 16; ++r) O[dt][r] = O[dt][r] * alpha;
             }
+            AB_STAMP(3);                                            // exp2, row sums, rescale
             // ---- ctx^T += V^T P^T : two k-steps of 16 keys; the probability registers are the B operand as they lie ----
             const __bf16 *vb = Vimg + (t & 1) * 32 * HD + lane * 4;
 #pragma unroll
@@ -259,12 +295,17 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
                 }
             }
         }
+        AB_STAMP(4);                                                // PV MFMAs
         if (more) {
             v_store((t + 1) & 1);
+            k_store((t + 1) & 1);
             lds_store_fence();
         }
+        AB_STAMP(5);                                                // V staging store (incl. the wait for the V load)
         __syncthreads();                                            // V tile t + 1 visible; every wave is done with tile t's image
+        AB_STAMP(6);                                                // barrier
     }
+    AB_FLUSH();
     if (!active) return;
     l_run = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = __builtin_amdgcn_rcpf(l_run);
@@ -286,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
 size_t relpos_attention_bf16_lds_bytes(int T, int hd) {
     if (hd != 64 && hd != 128) return 0;
     const int nkt = (T + 31) / 32;
-    return (size_t)2 * 32 * hd * 2 + (size_t)4 * 64 * AB_SKP * 4 + (size_t)(32 * nkt + 128) * 4;
+    return (size_t)2 * 32 * hd * 2 + (size_t)2 * 32 * (hd * 2 + 16) + (size_t)4 * 64 * AB_SKP * 4 + (size_t)(32 * nkt + 128) * 4;
 }
 
 template <int HD>
