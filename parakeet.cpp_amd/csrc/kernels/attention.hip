@@ -30,6 +30,14 @@ static constexpr int RB = 32;   // query rows per workgroup
 #define ATT_OCC 4                 // workgroups per CU the hd <= 64 kernel is compiled for (register budget 168 / 128 VGPRs for 3 / 4)
 #endif
 
+// Phase stamps for tools/ubench/attn_bench.cpp (-DATT_TRACE): shader clock of lane 0 of every wave at the phase boundaries.  Production: nothing.
+#ifdef ATT_TRACE
+__device__ long long *att_trace;    // [workgroup][wave][8]
+#define ATT_STAMP(i) do { if (att_trace && (threadIdx.x & 63) == 0) att_trace[((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = clock64(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ float f4e(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
 // SG (long sequences, > ~85 s of audio): the score block of a workgroup lives in a global scratch area instead of LDS -- the same
@@ -144,9 +152,11 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
                 qx[f] = make_float4(qx[f].x + br[16 * f], qx[f].y + br[16 * f + 4], qx[f].z + br[16 * f + 8], qx[f].w + br[16 * f + 12]);
         }
     };
+    ATT_STAMP(0);
     load_q_biased(bias_u);
     const int il_base = rt * 16 + 4 * kq;                           // C layout: column = lane & 15, row = 4*(lane>>4) + r
     const int Tpad4 = (T + 3) & ~3;
+    ATT_STAMP(1);                                                   // Q load + bias
     float4 bA0[NQ4], bA1[NQ4], bB0[NQ4], bB1[NQ4];                  // two operand-tile pairs: one computing, one in flight
 
     // ---- phase 1: content scores (q+u) K^T -> S; this wave's column tiles are t = cp, cp+2, ... (pairs, one pair ahead) ----
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
             }
         }
     }
+    ATT_STAMP(2);                                                   // QK^T -> S
     if (pos) load_q_biased(bias_v);
     // ---- phase 2: position scores (q+v) P^T, shifted, combined and scaled.  This wave's 16 query rows need
     //      p = j - i + T - 1 in [wpmin, wpmax] (T+15 rows): its own tile grid starts at wpmin, tiles t = cp, cp+2, ... ------
@@ -183,6 +194,7 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
     const int npt = (pos && w_lo < T) ? (wpmax - wpmin) / 16 + 1 : 0;
     if (cp < npt) { load_tile(pb, d, wpmin + cp * 16, P, bA0); load_tile(pb, d, wpmin + (cp + 2) * 16, P, bA1); }   // in flight across the barrier
     __syncthreads();                                              // content scores complete
+    ATT_STAMP(3);                                                   // (q+v), first P tiles requested, barrier
     {
         auto rmw = [&](int t, const f32x4 &a0, const f32x4 &a1) {
 #pragma unroll
@@ -212,8 +224,10 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
             }
         }
     }
+    ATT_STAMP(4);                                                   // QP^T shifted rmw
     v_issue(0);                                                   // first V chunk: in flight across the softmax
     __syncthreads();
+    ATT_STAMP(5);                                                   // barrier
     // ---- phase 3: softmax, one wavefront per row ----------------------------------------------------------------------------
     // Each wave owns rows wave, wave+4, ...: all NSR of them go through the three sweeps TOGETHER, so the 2 x 6 dependent
     // cross-lane butterfly stages and the exp / divide chains of different rows overlap instead of queueing up.
@@ -263,6 +277,7 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
                 }
         }
     }
+    ATT_STAMP(6);                                                   // softmax
     v_commit();
     lds_store_fence();
     __syncthreads();
@@ -307,6 +322,7 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
                 else ctx[orow + col] = acc[m][r];
             }
         }
+    ATT_STAMP(7);                                                   // V commit, barrier, AV, store
 }
 
 template <int HD, int VCH, int OCC = (HD <= 64 ? ATT_OCC : 2)>

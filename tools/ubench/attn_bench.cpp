@@ -1,5 +1,5 @@
-// tools/ubench/attn_bench.cpp -- times the relative-position attention kernel (kernels/attention.hip) on the two benchmark shapes and
-// prints the per-phase shader-clock breakdown of its wavefronts (ATT_TRACE stamps).  Random inputs; results are not checked here
+// tools/ubench/attn_bench.cpp -- times the relative-position attention kernel (kernels/attention.hip, compiled here with -DATT_TRACE) on the two
+// benchmark shapes and prints the per-phase shader-clock breakdown of its wavefronts.  Random inputs; results are not checked here
 // (tests/test_gpu_encoder.py does that bit for bit).
 #include <hip/hip_runtime.h>
 
@@ -8,7 +8,7 @@
 #include <vector>
 
 #define ATT_TRACE 1
-#include "attention_trace.hip"
+#include "../../parakeet.cpp_amd/csrc/kernels/attention.hip"
 
 using namespace pk;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -48,7 +48,7 @@ static void run(const char *name, int B, int T, int d, int H, int reps, hipStrea
     CK(hipMemcpyToSymbol(HIP_SYMBOL(att_trace), &null, 8));
     std::vector<long long> tr((size_t)n_wg * 4 * 8);
     CK(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
-    const char *ph[7] = {"Q load + bias", "QK^T -> S", "V commit + barrier", "QP^T shifted rmw", "barrier", "softmax", "barrier + AV + store"};
+    const char *ph[7] = {"Q load + bias", "QK^T -> S", "(q+v), P request, barrier", "QP^T shifted rmw", "barrier", "softmax", "V commit + AV + store"};
     double sum[7] = {0}, tot = 0;
     size_t n = 0;
     for (size_t w = 0; w < (size_t)n_wg * 4; ++w) {
