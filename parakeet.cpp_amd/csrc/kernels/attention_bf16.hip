@@ -167,6 +167,17 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
 #pragma unroll
         for (int s = 0; s < NK; ++s) preg[s] = *reinterpret_cast<const ab_bf16x8 *>(p + 16 * s);
     };
+    // the 16 c values of block m this lane adds (band rows x = ab_rowidx(r, g): four runs of four floats) -- read as four 16-byte LDS loads BEFORE the
+    // strip stores: interleaved one by one, every 4-byte read waited for its own LDS round trip in front of its store (the compiler cannot
+    // move a read of cb across a store to sk), ~2 k clocks per key tile (profiles/r04_attn_phases.txt)
+    auto c_load = [&](int m, float (&cv)[16]) {
+        const float4 *c4 = reinterpret_cast<const float4 *>(cb + 96 - 32 * wave + 32 * m + 4 * g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 c = c4[2 * k];
+            cv[4 * k] = c.x; cv[4 * k + 1] = c.y; cv[4 * k + 2] = c.z; cv[4 * k + 3] = c.w;
+        }
+    };
     // position block m -> + c -> the wave's skew strip, half m & 1
     auto g_block = [&](int m) {
         ab_f32x16 ga;
@@ -174,12 +185,10 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
         for (int r = 0; r < 16; ++r) ga[r] = 0.0f;
 #pragma unroll
         for (int s = 0; s < NK; ++s) ga = __builtin_amdgcn_mfma_f32_32x32x16_bf16(preg[s], qreg[s], ga, 0, 0, 0);
-        const int cbase = 96 - 32 * wave + 32 * m;
+        float cv[16];
+        c_load(m, cv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int x = ab_rowidx(r, g);
-            sk[(32 * (m & 1) + x) * AB_SKP + n] = ga[r] + cb[cbase + x];
-        }
+        for (int r = 0; r < 16; ++r) sk[(32 * (m & 1) + ab_rowidx(r, g)) * AB_SKP + n] = ga[r] + cv[r];
     };
 
     AB_T0();
@@ -224,6 +233,8 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
             ab_f32x16 sa, ga;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sa[r] = 0.0f; ga[r] = 0.0f; }
+            float cv[16];
+            c_load(t + 1, cv);                                      // (under the MFMA chains)
             const unsigned char *kb = Kimg + (t & 1) * 32 * KP + n * KP + 16 * g;
 #pragma unroll
             for (int s = 0; s < NK; ++s) {
@@ -234,12 +245,9 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
             AB_STAMP(1);                                            // QK^T and position MFMAs (incl. the wait for this tile's K / P operands)
             if (more) p_load(t + 2);
             {   // block t + 1 (+ c) into the wave's skew strip, half (t + 1) & 1; then the skewed read of blocks t and t + 1
-                const int m = t + 1, cbase = 96 - 32 * wave + 32 * m;
+                const int m = t + 1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int x = ab_rowidx(r, g);
-                    sk[(32 * (m & 1) + x) * AB_SKP + n] = ga[r] + cb[cbase + x];
-                }
+                for (int r = 0; r < 16; ++r) sk[(32 * (m & 1) + ab_rowidx(r, g)) * AB_SKP + n] = ga[r] + cv[r];
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
