@@ -197,19 +197,27 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
     ATT_STAMP(3);                                                   // (q+v), first P tiles requested, barrier
     {
         auto rmw = [&](int t, const f32x4 &a0, const f32x4 &a1) {
+            // the eight score elements are READ together, then combined, then stored (distinct addresses: four rows x two column tiles); one by one
+            // every read would wait behind the previous element's store (see the softmax sweep below)
+            int ad[8];
+            bool ok[8];
+            float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int il = il_base + r, i = i0 + il;
                 const int pa = wpmin + t * 16 + l15, ja = pa - (T - 1) + i;
-                if (i < T && pa < P && ja >= 0 && ja < T) {
-                    const int a = sidx(il, ja);
-                    S[a] = (S[a] + a0[r]) * scale;                              // (content + pos) * scale, src/encoder.cpp:157-160
-                }
                 const int pc = pa + 32, jc = ja + 32;
-                if (t + 2 < npt && i < T && pc < P && jc >= 0 && jc < T) {
-                    const int a = sidx(il, jc);
-                    S[a] = (S[a] + a1[r]) * scale;
-                }
+                ok[r] = i < T && pa < P && ja >= 0 && ja < T;
+                ok[4 + r] = t + 2 < npt && i < T && pc < P && jc >= 0 && jc < T;
+                ad[r] = ok[r] ? sidx(il, ja) : 0;
+                ad[4 + r] = ok[4 + r] ? sidx(il, jc) : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = S[ad[q]];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (ok[r]) S[ad[r]] = (v[r] + a0[r]) * scale;                   // (content + pos) * scale, src/encoder.cpp:157-160
+                if (ok[4 + r]) S[ad[4 + r]] = (v[4 + r] + a1[r]) * scale;
             }
         };
         for (int t = cp; t < npt; t += 8) {
@@ -246,15 +254,26 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
             for (int k = 0; k < NSR; ++k) mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
 #pragma unroll
         for (int k = 0; k < NSR; ++k) sm[k] = 0.0f;
-        for (int j = lane; j < T; j += 64)
+        // The NSR rows' values are READ first, then transformed, then stored: written element by element (read, exp, store, next row) the compiler
+        // has to keep every read behind the previous row's store -- both are LDS floats -- and the eight exp chains ran one after the other, each
+        // behind its own LDS round trip (round 4, from the ISA: profiles/r04_attn_phases.txt).  Same values, same per-row summation order.
+        for (int j = lane; j < T; j += 64) {
+            float e[NSR];
+#pragma unroll
+            for (int k = 0; k < NSR; ++k) e[k] = S[sidx(wave + 4 * k, j)] - mx[k];          // S <= row maximum
+            if (ctx_bf16 == 1) {    // bf16 mode (tolerance-class, see GemmArgs::fast_act): hardware exp2 instead of the fixed polynomial
+#pragma unroll
+                for (int k = 0; k < NSR; ++k) e[k] = __builtin_amdgcn_exp2f(e[k] * 1.44269502162933349609375f);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NSR; ++k) e[k] = dexpf_nonpos(e[k]);
+            }
 #pragma unroll
             for (int k = 0; k < NSR; ++k) {
-                const int a = sidx(wave + 4 * k, j);
-                // bf16 mode (ctx_bf16: tolerance-class, see GemmArgs::fast_act): hardware exp2 instead of the fixed polynomial
-                const float e = ctx_bf16 == 1 ? __builtin_amdgcn_exp2f((S[a] - mx[k]) * 1.44269502162933349609375f) : dexpf_nonpos(S[a] - mx[k]);   // S <= row maximum
-                S[a] = e;
-                sm[k] = sm[k] + e;
+                S[sidx(wave + 4 * k, j)] = e[k];
+                sm[k] = sm[k] + e[k];
             }
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1)                      // the canonical sum64 butterfly, NSR rows side by side
 #pragma unroll
@@ -262,19 +281,23 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
         if (ctx_bf16 == 1) {                                         // bf16 mode: one hardware reciprocal per row, a multiplication per element
 #pragma unroll
             for (int k = 0; k < NSR; ++k) sm[k] = __builtin_amdgcn_rcpf(sm[k]);
-            for (int j = lane; j < T; j += 64)
+            for (int j = lane; j < T; j += 64) {
+                float e[NSR];
 #pragma unroll
-                for (int k = 0; k < NSR; ++k) {
-                    const int a = sidx(wave + 4 * k, j);
-                    S[a] = S[a] * sm[k];
-                }
+                for (int k = 0; k < NSR; ++k) e[k] = S[sidx(wave + 4 * k, j)] * sm[k];
+#pragma unroll
+                for (int k = 0; k < NSR; ++k) S[sidx(wave + 4 * k, j)] = e[k];
+            }
         } else {
-            for (int j = lane; j < T; j += 64)
+            for (int j = lane; j < T; j += 64) {
+                float e[NSR];
 #pragma unroll
-                for (int k = 0; k < NSR; ++k) {
-                    const int a = sidx(wave + 4 * k, j);
-                    S[a] = S[a] / sm[k];
-                }
+                for (int k = 0; k < NSR; ++k) e[k] = S[sidx(wave + 4 * k, j)];
+#pragma unroll
+                for (int k = 0; k < NSR; ++k) e[k] = e[k] / sm[k];
+#pragma unroll
+                for (int k = 0; k < NSR; ++k) S[sidx(wave + 4 * k, j)] = e[k];
+            }
         }
     }
     ATT_STAMP(6);                                                   // softmax
