@@ -158,7 +158,7 @@ def main():
         "mixed_over_equal": round(rtfx_mx / rtfx_eq, 4),
         "kernel_ms_unpipelined": {k: {"equal": kern_eq.get(k), "mixed": kern_mx.get(k)} for k in sorted(set(kern_eq) | set(kern_mx))},
         "one_call_from_host": {"clips": args.clips, "audio_s": round(audio2, 1), "wall_s": round(best, 4), "rtfx": round(audio2 / best, 1),
-                               "note": "pk_transcribe_pcm: sort, pack (<= 256 clips / 640 s per batch), PCIe uploads, pipeline, results, detokenise-free; best of 3"},
+                               "note": "pk_transcribe_pcm: sort, pack (<= 256 clips / 8192 encoder rows per batch), PCIe uploads, pipeline, results, detokenise-free; best of 3"},
         "one_clip_at_a_time": {"clips": len(clips), "wall_s": round(s_serial, 4), "rtfx": round(audio_s / s_serial, 1),
                                "note": "the same mixed clips, one pk_transcribe_pcm call per clip: what every length class cost before packing"},
         "parity": {"clips": len(clips), "token_mismatches_vs_single_clip": mism, "oracle_clips": o_n, "token_mismatches_vs_oracle": o_mism},
