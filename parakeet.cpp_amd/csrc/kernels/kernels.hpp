@@ -49,7 +49,7 @@ struct SeqRag {                                 // encoder frames: attention row
 };
 
 // ---- mel front end (src/audio.cpp:100-158) ----------------------------------------------------
-constexpr int kMelMaxTaps = 1024;     // packed filterbank taps staged in LDS by the mel kernel (sum of the band widths; 80 / 128 bins: ~590)
+constexpr int kMelMaxTaps = 768;      // packed filterbank taps staged in LDS by the mel kernel (sum of the band widths; 80 / 128 bins: ~590)
 struct MelTables {
     const float *window;   // [512] symmetric Hann(400) zero-padded to n_fft, placed per switch A1 (pk_config.stft_window_centered)
     const float *window_left;  // [512] the same window left-aligned: the streaming preprocessor's frames (center=false)

@@ -27,9 +27,11 @@ static constexpr int kStreamWaves = 4;
 #define PK_MEL_WAVES 16
 #endif
 static constexpr int kOfflineWaves = PK_MEL_WAVES;
+// One frame's FFT array: 512 elements in one of three padded layouts, one per radix-8 pass (see the kernel): the largest needs 575 words.
+static constexpr int kMelFA = 576;
 template <int NW> static constexpr size_t mel_lds_bytes(bool offline) {
     (void)offline;
-    return (size_t)(NW * 2 * (kNfft + kNfft / 32) + 2 * kNfft + kMelMaxTaps) * sizeof(float);
+    return (size_t)(NW * 2 * kMelFA + 2 * kNfft + kMelMaxTaps) * sizeof(float);
 }
 
 // STREAM = false: preprocess_audio's framing (pre-emphasis, center=true, reflect padding), output [B][n_mels][n_frames].
@@ -39,20 +41,26 @@ template <int NW> static constexpr size_t mel_lds_bytes(bool offline) {
 // Every wavefront owns one frame and touches only its own LDS arrays, so the stages are ordered by wave-local fences (LDS
 // operations of one wave complete in order once the counter is drained) instead of workgroup barriers: four frames of a
 // workgroup no longer wait for each other ten times per FFT.
-#define PK_FP(i) ((i) + ((i) >> 5))
+// Element i of a frame's FFT array lives at a padded position that depends on which pass reads it next: every pass reads (and writes) a
+// lane's eight elements with eight instructions, and across the 32 lanes LDS serves per clock those addresses must fall on 32 different banks.
+//   L1: i + (i >> 5)        bit-reversed load -> pass A (a lane's elements 8 g + k: bank 8 (g & 3) + (g >> 2) + k)
+//   L2: i + (i >> 3)        pass A -> pass B (written at 9 g + k, read at 64 G + r + 8 k -> bank r + 8 G + 9 k)
+//   L3: i + 8 (i >> 6)      pass B -> pass C -> spectrum (written at r + 8 G + 8 k + ..., read at g + 72 k)
+#define PK_L1(i) ((i) + ((i) >> 5))
+#define PK_L2(i) ((i) + ((i) >> 3))
+#define PK_L3(i) ((i) + 8 * ((i) >> 6))
 #define PK_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <bool STREAM, int NW /* wavefronts = frames per workgroup */>
-__global__ __launch_bounds__(64 * NW) void mel_logmel_kernel(const float *__restrict__ pcm, int64_t n_samples, int n_frames,
+__global__ __launch_bounds__(64 * NW, STREAM ? 1 : 8 /* offline: two 16-wave workgroups per CU = 8 waves per SIMD, 64 VGPRs */) void mel_logmel_kernel(const float *__restrict__ pcm, int64_t n_samples, int n_frames,
                                                              MelTables tb, float *__restrict__ logmel, MelRag rg) {
-    // FFT arrays with one pad word per 32 (element i at i + (i >> 5)): the butterfly strides 2^lh of the in-place radix-2 stages would
-    // otherwise put two to eight lanes on one LDS bank
+    // FFT arrays: padded layouts PK_L1 / PK_L2 / PK_L3 (above), kMelFA words per frame
     // LDS (dynamic: NW = 16 needs 102 KB): per-frame FFT arrays and power spectrum, the tables, the output tile
-    constexpr int FA = kNfft + kNfft / 32;                          // padded FFT array of one frame
+    constexpr int FA = kMelFA;                                      // padded FFT array of one frame
     constexpr int ITERS = 1;
     constexpr int FPB = NW * ITERS;
     extern __shared__ __attribute__((aligned(16))) float mel_sm[];
-    // (the power spectrum of a frame -- 257 values -- lives in the unused upper part of its own imaginary array, words 268 .. 524: the spectrum
-    //  is read from words 0 .. 264 only; the frame's log-mel values go into the head of its real array, which is dead by then: 4.2 KB of LDS per
+    // (the power spectrum of a frame -- 257 values -- lives in the unused upper part of its own imaginary array, words 296 .. 552: the spectrum
+    //  is read from words 0 .. 288 only; the frame's log-mel values go into the head of its real array, which is dead by then: 4.2 KB of LDS per
     //  frame instead of 5.3 + an output tile, so that 16-frame workgroups fit twice on a CU)
     float *const s_re_all = mel_sm, *const s_im_all = s_re_all + NW * FA;
     // twiddles and the packed filterbank bands: read ~100 times per lane and frame -- from LDS instead of dependent L1 / L2 round trips.
@@ -83,63 +91,104 @@ __global__ __launch_bounds__(64 * NW) void mel_logmel_kernel(const float *__rest
     for (int i = threadIdx.x; i < tb.fb_nnz; i += 64 * NW) s_fb[i] = tb.fbc[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *re = s_re_all + wave * FA, *im = s_im_all + wave * FA, *pw = im + 268;
+    float *re = s_re_all + wave * FA, *im = s_im_all + wave * FA, *pw = im + 296;
 #pragma unroll 1
     for (int it = 0; it < ITERS; ++it) {
     const int t = blockIdx.x * FPB + it * NW + wave;
     const bool live = t < n_frames;
     
     if (live) {
+        // all of a lane's samples, their predecessors and window taps are REQUESTED first (24 independent loads), then combined: with the
+        // pre-emphasis written as a branch per element the ISA had 16 dependent memory round trips per frame (load, vmcnt(0), load, vmcnt(0), ...)
+        float xc[kNfft / 64], xp[kNfft / 64], wn[kNfft / 64];
+        bool first[kNfft / 64];
+#pragma unroll
+        for (int i = 0; i < kNfft / 64; ++i) {
+            const int n = lane + 64 * i;
+            if constexpr (STREAM) {
+                xc[i] = n < 400 ? x[(int64_t)t * kHop + n] : 0.0f;
+                wn[i] = n < 400 ? tb.window_left[n] : 0.0f;
+                xp[i] = 0.0f;
+                first[i] = false;
+            } else {
+                int64_t idx = (int64_t)t * kHop + n - kNfft / 2;  // center=true
+                if (idx < 0) idx = -idx;                          // pad_mode="reflect"
+                if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
+                first[i] = idx == 0;
+                xc[i] = x[idx];
+                xp[i] = x[first[i] ? 0 : idx - 1];
+                wn[i] = tb.window[n];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < kNfft / 64; ++i) {
             const int n = lane + 64 * i;
             const int r = (int)(__brev((unsigned)n) >> 23);       // 9-bit reversal
             if constexpr (STREAM) {
-                re[PK_FP(r)] = n < 400 ? x[(int64_t)t * kHop + n] * tb.window_left[n] : 0.0f;
+                re[PK_L1(r)] = n < 400 ? xc[i] * wn[i] : 0.0f;
             } else {
-                int64_t idx = (int64_t)t * kHop + n - kNfft / 2;  // center=true
-                if (idx < 0) idx = -idx;                          // pad_mode="reflect"
-                if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
-                float v;
-                if (idx == 0) {
-                    v = x[0];                                     // preemphasis, src/audio.cpp:104-114
-                } else {
-                    const float p = 0.97f * x[idx - 1];
-                    v = x[idx] - p;
-                }
-                re[PK_FP(r)] = v * tb.window[n];
+                const float p = 0.97f * xp[i];                    // preemphasis, src/audio.cpp:104-114: y[0] = x[0], y[n] = x[n] - 0.97 x[n-1]
+                const float v = first[i] ? xc[i] : xc[i] - p;
+                re[PK_L1(r)] = v * wn[i];
             }
-            im[PK_FP(r)] = 0.0f;
         }
     }
     PK_WAVE_SYNC();
-#pragma unroll 1
-    for (int lh = 0; lh < 9; ++lh) {
-        const int h = 1 << lh;
-        if (live) {
+    // The nine radix-2 stages, three at a time: a lane takes the eight elements that differ in index bits L, L + 1, L + 2 into registers, runs the
+    // 4 + 4 + 4 butterflies of stages L, L + 1, L + 2 on them (the same operations on the same operands as stage-by-stage: bit-identical) and
+    // stores them once -- a third of the LDS traffic of one round trip per stage, which is what bounds this kernel (105 KB of LDS traffic per
+    // frame against 3 KB of HBM; round 4: with every load batched and no dependent round trips left the time did not move).  Twiddles of stage
+    // lh: w^(j << (8 - lh)) at table slot 2^lh - 1 + j, j = (lower element's index) mod 2^lh: one per lane for the first stage of a pass, two for
+    // the second, four for the third.
+    auto bfly = [](float &ar, float &ai, float &br, float &bi, float cr, float ci) {
+        const float tr = __builtin_fmaf(-ci, bi, cr * br);
+        const float ti = __builtin_fmaf(ci, br, cr * bi);
+        const float nr = ar - tr, ni = ai - ti;
+        ar = ar + tr;
+        ai = ai + ti;
+        br = nr;
+        bi = ni;
+    };
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = lane + 64 * i;
-                const int j = q & (h - 1);
-                const int a = ((q >> lh) << (lh + 1)) + j;
-                const int bb = a + h;
-                const float cr = s_twr[h - 1 + j], ci = s_twi[h - 1 + j];
-                const int pa = PK_FP(a), pb = PK_FP(bb);
-                const float br = re[pb], bi = im[pb];
-                const float tr = __builtin_fmaf(-ci, bi, cr * br);
-                const float ti = __builtin_fmaf(ci, br, cr * bi);
-                const float ar = re[pa], ai = im[pa];
-                re[pb] = ar - tr;
-                im[pb] = ai - ti;
-                re[pa] = ar + tr;
-                im[pa] = ai + ti;
+    for (int pass = 0; pass < 3; ++pass) {
+        constexpr int kL[3] = {0, 3, 6};
+        const int L = kL[pass], h0 = 1 << L;
+        if (live) {
+            const int low = lane & (h0 - 1), a0 = ((lane >> L) << (L + 3)) | low;
+            float xr[8], xi[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = a0 + k * h0;
+                const int p = pass == 0 ? PK_L1(i) : pass == 1 ? PK_L2(i) : PK_L3(i);
+                xr[k] = re[p];
+                xi[k] = pass == 0 ? 0.0f : im[p];                   // the input is real: no zeros are parked in LDS for the first pass to read back
+            }
+            const float c0r = s_twr[h0 - 1 + low], c0i = s_twi[h0 - 1 + low];
+            float c1r[2], c1i[2], c2r[4], c2i[4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { c1r[u] = s_twr[2 * h0 - 1 + low + u * h0]; c1i[u] = s_twi[2 * h0 - 1 + low + u * h0]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { c2r[u] = s_twr[4 * h0 - 1 + low + u * h0]; c2i[u] = s_twi[4 * h0 - 1 + low + u * h0]; }
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) bfly(xr[k], xi[k], xr[k + 1], xi[k + 1], c0r, c0i);                       // stage L: pairs differ in bit L
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((k & 2) == 0) bfly(xr[k], xi[k], xr[k + 2], xi[k + 2], c1r[k & 1], c1i[k & 1]);                   // stage L + 1
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bfly(xr[k], xi[k], xr[k + 4], xi[k + 4], c2r[k], c2i[k]);                     // stage L + 2
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = a0 + k * h0;
+                const int p = pass == 0 ? PK_L2(i) : PK_L3(i);
+                re[p] = xr[k];
+                im[p] = xi[k];
             }
         }
         PK_WAVE_SYNC();
     }
     if (live) {
         for (int f = lane; f <= kNfft / 2; f += 64) {
-            const float s = __builtin_fmaf(re[PK_FP(f)], re[PK_FP(f)], im[PK_FP(f)] * im[PK_FP(f)]);
+            const float s = __builtin_fmaf(re[PK_L3(f)], re[PK_L3(f)], im[PK_L3(f)] * im[PK_L3(f)]);
             if (tb.power_via_abs) {                               // abs() then square, src/audio.cpp:123-124
                 const float mag = __builtin_sqrtf(s);
                 pw[f] = mag * mag;
@@ -154,7 +203,19 @@ __global__ __launch_bounds__(64 * NW) void mel_logmel_kernel(const float *__rest
             float acc = 0.0f;
             const int lo = tb.f_lo[m], hi = tb.f_hi[m];           // zero weights contribute fma(0, p, acc) = acc exactly
             const float *wm = s_fb + tb.fb_off[m] - lo;
-            for (int f = lo; f <= hi; ++f) acc = __builtin_fmaf(wm[f], pw[f], acc);
+            // the chain is sequential by contract (natural f order); its operands are not: four weight / power pairs per trip to LDS.  Past the
+            // band's end both factors are taken as +0: fma(+0, +0, acc) = acc for the non-negative sums of this chain.
+            for (int f = lo; f <= hi; f += 4) {
+                float w4[4], p4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool in = f + k <= hi;
+                    w4[k] = in ? wm[f + k] : 0.0f;
+                    p4[k] = in ? pw[f + k] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(w4[k], p4[k], acc);
+            }
             const float lm = dlogf(acc + 5.96046448e-8f);
             if constexpr (STREAM) logmel[((int64_t)b * n_frames + t) * tb.n_mels + m] = lm;
             else re[m] = lm;
@@ -172,7 +233,9 @@ __global__ __launch_bounds__(64 * NW) void mel_logmel_kernel(const float *__rest
 }
 
 #undef PK_WAVE_SYNC
-#undef PK_FP
+#undef PK_L1
+#undef PK_L2
+#undef PK_L3
 
 // Per-bin mean / unbiased variance normalisation + transpose to [B][n_frames][n_mels] (src/audio.cpp:140-156).  One wavefront per
 // (clip, mel bin) for the two canonical sum64 reductions over the frames; the 16 bins of a workgroup then go through a
