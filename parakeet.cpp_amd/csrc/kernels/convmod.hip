@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const float *__rest
         if (out_bf16 == 1) {                                            // bf16 mode: tolerance-class activation (GemmArgs::fast_act)
             v.x = fast_siluf(v.x); v.y = fast_siluf(v.y); v.z = fast_siluf(v.z); v.w = fast_siluf(v.w);
         } else {
-            v.x = dsiluf(v.x); v.y = dsiluf(v.y); v.z = dsiluf(v.z); v.w = dsiluf(v.w);
+            float q[4] = {v.x, v.y, v.z, v.w};
+            dsilu4(q);                                                  // the specification's values, short form (pk_devmath.h)
+            v = make_float4(q[0], q[1], q[2], q[3]);
         }
         return v;
     };
