@@ -258,11 +258,15 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_bf16_kernel(const __b
                 const int jj = ab_rowidx(r, g);
                 const int xr = jj - n + 31;                          // band row relative to block t: 0 .. 62
                 const int phys = 32 * ((t + (xr >> 5)) & 1) + (xr & 31);
-                float v = (sa[r] + sk[phys * AB_SKP + n]) * scale_log2e;          // (content + position) * scale, in the exp2 domain
-                v = (32 * t + jj < T) ? v : -__builtin_huge_valf();
+                const float v = (sa[r] + sk[phys * AB_SKP + n]) * scale_log2e;    // (content + position) * scale, in the exp2 domain
                 sv[r] = v;
-                mloc = fmaxf(mloc, v);
             }
+            if (32 * (t + 1) > T) {                                  // (wave-uniform) only the last key tile has keys past the end to mask
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] = (32 * t + ab_rowidx(r, g) < T) ? sv[r] : -__builtin_huge_valf();
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sv[r]);
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                 // the strip half of block t is overwritten next iteration
             AB_STAMP(2);                                            // skew strip write / read, scale, mask, local max
