@@ -170,17 +170,19 @@ int sub_conv1_dw1_strip_rows(int64_t total_h2_rows) { return total_h2_rows <= kS
 void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
                           const float *bd, float *out, hipStream_t s, const SubRag &rag) {
     const int H1 = (Tm - 1) / 2 + 1, W1 = (F - 1) / 2 + 1, H2 = (H1 - 1) / 2 + 1, W2 = (W1 - 1) / 2 + 1;
-    // 80 mel bins -> one 20-column chunk per output row; 128 -> two chunks of 16
+    // batches: 80 mel bins -> two 10-column chunks per output row; 128 -> four chunks of 8.  (Round 4: chunks of 20 / 16 hold three conv1 rows of
+    // 41 / 33 values in registers, 169 / 144 VGPRs = three waves per SIMD; half the chunk = 108 VGPRs, four waves: 0.317 -> 0.243 ms at 64 x 10 s
+    // for 5 % more conv1 columns; chunks of 5 measure the same.)  One or two utterances keep the wide chunk:
     // a strip of 8 output rows per thread shares its conv1 rows; one or two utterances give only a few dozen such strips -- strips of 2 rows
     // (1.5x the conv1 work, four times the workgroups, a quarter of the serial chain each: 77 -> ~25 us for one 10 s clip)
     // (ragged batch: the caller built rag.strips with rag.strip_rows = sub_conv1_dw1_strip_rows(total H2 rows) rows per unit)
     const bool small = rag.strips.u ? rag.strip_rows == 2 : (int64_t)B * H2 <= kSmallStripRows;
     if (W2 <= 20 || W2 % 20 == 0) {
         if (small) launch_c1d1<20, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
-        else launch_c1d1<20>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
+        else launch_c1d1<10>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
     } else {
         if (small) launch_c1d1<16, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
-        else launch_c1d1<16>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
+        else launch_c1d1<8>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
     }
 }
 // Depthwise 3x3 stride-2 conv (dw2, src/encoder.cpp:230), channels-last.  One thread = 4 adjacent channels x XO adjacent output
