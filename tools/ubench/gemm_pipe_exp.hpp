@@ -98,7 +98,8 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
         constexpr int CP = BN + 4;                                  // C tile pitch (rows stay 16-byte aligned)
         // the C tile goes through the staging buffers; when it does not fit (single-buffered variant) in NPASS row bands
         constexpr size_t CAP = (size_t)CAP_FLOATS;
-        constexpr int NPASS = ((size_t)BM * CP <= CAP) ? 1 : ((size_t)BM / 2 * CP <= CAP) ? 2 : ((size_t)BM / 4 * CP <= CAP) ? 4 : 8, PR = BM / NPASS;
+        constexpr int NPASS = ((size_t)BM * CP <= CAP) ? 1 : ((size_t)BM / 2 * CP <= CAP && (BM / 2) % 32 == 0) ? 2 : ((size_t)BM / 4 * CP <= CAP && (BM / 4) % 32 == 0) ? 4
+                              : ((size_t)BM / 8 * CP <= CAP && (BM / 8) % 32 == 0) ? 8 : BM / 32, PR = BM / NPASS;   // (as in the product header)
         static_assert((size_t)PR * CP <= CAP, "C tile band must fit in the staging buffers");
         static_assert(PR % 32 == 0, "row bands are whole MFMA tiles");
         constexpr int C4 = NOUT / 4, NCH = BM * C4 / NT, RSTEP = NT / C4;   // float4 chunks per output row / per thread; row stride
@@ -278,10 +279,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
         }
     };
 
+    // GP_EXP & 4096 (timing ablation, results wrong): the A operand never goes through LDS -- every lane loads the 16 k of its row and K tile
+    // straight from global memory (as if A were stored with the even / odd k of each block of 32 split: position 16 h + p <-> k = 2 p + h) one
+    // K tile ahead; only W is staged.  Measures what halving the staging would be worth against the row-per-lane loads it needs.
+    constexpr bool ADIR = (GP_EXP & 4096) != 0 && TM == 1 && BK == 32;
     float4 ra[A_CH], rw[W_CH];
+    float4 ad_cur[4], ad_nxt[4];
+    auto adload = [&](int kt, int m0_) {
+        int r_ = m0_ + (wave / WGN) * WM + (lane & 31);
+        r_ = r_ < g.M ? r_ : g.M - 1;
+        const float *p_ = g.A + (int64_t)r_ * g.lda + kt * BK + 16 * (lane >> 5);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ad_nxt[q] = *reinterpret_cast<const float4 *>(p_ + 4 * q);
+    };
     auto gload = [&](int kt) {
+        if (!ADIR) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
+        }
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const float4 *>(w_src[i] + kt * BK);
     };
@@ -303,8 +318,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     };
     auto lstore = [&](int buf) {
         float *base = smem + buf * BUF;
+        if (!ADIR) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) st2(base + a_dst[i], ra[i].x, ra[i].z, ra[i].y, ra[i].w);       // k = 4c, 4c+2 | k = 4c+1, 4c+3
+        }
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) st2(base + w_dst[i], rw[i].x, rw[i].z, rw[i].y, rw[i].w);
     };
@@ -326,17 +343,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     float4 fa[2][TM], fb[2][TN];
     auto fragload = [&](int buf, int s, int slot) {
         const float *base = smem + buf * BUF + 4 * s;
+        if (!ADIR) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const float4 *>(base + fa_off + i * 32 * PITCH);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4 *>(base + fb_off + j * 32 * PITCH);
     };
-    auto mma = [&](int slot) {
+    auto mma = [&](int slot, int sub = 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const float a = e == 0 ? fa[slot][i].x : e == 1 ? fa[slot][i].y : e == 2 ? fa[slot][i].z : fa[slot][i].w;
+                const float4 &av = ADIR ? ad_cur[sub & 3] : fa[slot][i];
+                const float a = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const float b = e == 0 ? fb[slot][j].x : e == 1 ? fb[slot][j].y : e == 2 ? fb[slot][j].z : fb[slot][j].w;
@@ -368,6 +388,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     __syncthreads();
     GP_STAMP(1);
     gload(1);                      // nk >= 2 (K >= 2*BK, checked by the launcher)
+    if (ADIR) {
+        adload(0, m0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ad_cur[q] = ad_nxt[q];
+        adload(1, m0);
+    }
     fragload(0, 0, 0);
     int cur = 0;
     zero_acc();
@@ -382,12 +408,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
 #pragma unroll
             for (int s = 0; s < NSUB - 1; ++s) {
                 fragload(0, s + 1, (s + 1) & 1);
-                GP_SB(); mma(s & 1); GP_SB();
+                GP_SB(); mma(s & 1, s); GP_SB();
             }
             __syncthreads();
             if (more1) lstore(0);
             if (more2) gload(kt + 2);
-            GP_SB(); mma((NSUB - 1) & 1); GP_SB();
+            GP_SB(); mma((NSUB - 1) & 1, NSUB - 1); GP_SB();
+            if (ADIR) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ad_cur[q] = ad_nxt[q];
+                if (more2) adload(kt + 2, m0);
+            }
             lds_store_fence();                                      // the staging stores are inline (st2)
             __syncthreads();
             if (more1) fragload(0, 0, 0);
