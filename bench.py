@@ -252,6 +252,8 @@ def also_measurements(model, capi, synth, np):
     also.append(dict({"name": "configs[2] tdt-600m 32x30s bf16"}, **d))
     d = run_json([py, os.path.join(ROOT, "tools", "bench_stream.py"), "--chunks", "100", "--warmup", "10"], 300)
     also.append(dict({"name": "configs[4] nemotron-600m streaming, 16 streams/GPU"}, **d))
+    d = run_json([py, os.path.join(ROOT, "tools", "bench_stream.py"), "--chunks", "100", "--warmup", "10", "--bf16"], 300)
+    also.append(dict({"name": "configs[4] nemotron-600m streaming, 16 streams/GPU, tolerance-class mode (bf16 operands: kernels/gemm_smallm_bf16.hip)"}, **d))
     return also
 
 

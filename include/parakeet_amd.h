@@ -457,6 +457,11 @@ pk_status pk_diag_gemm_bf16(int M, int N, int K, const float *A, const float *W,
  * large shapes take the direct-to-LDS kernel (kernels/gemm_bf16_glds.hpp). */
 pk_status pk_diag_gemm_bf16_a16(int M, int N, int K, const float *A, const float *W, const float *bias, int epi,
                                 const float *resid, float alpha, float *out);
+/* The small-M form of that product with the LayerNorm of its input rows folded in (kernels/gemm_smallm_bf16.hip; the streaming chunks of the
+ * tolerance-class mode): out = epi(bf16(LayerNorm(A; gamma, beta, eps)) * bf16(W)^T + bias).  M <= 128, K = 256 * (1 .. 8; glu: .. 4).
+ * PK_ERR_UNSUPPORTED for any other shape. */
+pk_status pk_diag_ln_gemm_bf16(int M, int N, int K, const float *A, const float *gamma, const float *beta, float eps, const float *W,
+                               const float *bias, int epi, const float *resid, float alpha, float *out);
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y);
 /* sum64 of each row of x[rows][n] (the canonical wavefront reduction). */
 pk_status pk_diag_sum64(const float *x, int rows, int n, float *out);

@@ -454,15 +454,28 @@ class Stream:
             raise RuntimeError(lib().orc_last_error().decode())
         return out[:n]
 
-    def decode(self, enc):
+    def decode(self, enc, margins=False):
+        """margins=True: also step_label / step_margin -- the label chosen (blank included) and the top-1 / top-2 log-prob margin of every decision
+        of the chunk, in order (what oracle/tolerance.py's first_divergence walks)."""
         enc = _c(enc)
         c = enc.shape[0]
         mt = max(1, c * self.model.cfg.max_symbols_per_step)
         ids = np.zeros(mt, np.int32); st = np.zeros(mt, np.int32); en = np.zeros(mt, np.int32); cf = np.zeros(mt, np.float32)
-        n = lib().orc_stream_decode(self._h, _f(enc), c, mt, _i(ids), _i(st), _i(en), _f(cf))
+        if not margins:
+            n = lib().orc_stream_decode(self._h, _f(enc), c, mt, _i(ids), _i(st), _i(en), _f(cf))
+            if n < 0:
+                raise RuntimeError(lib().orc_last_error().decode())
+            return dict(ids=ids[:n], start=st[:n], end=en[:n], conf=cf[:n])
+        L = lib()
+        f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.orc_stream_decode_ex.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, i32p, i32p, i32p, f32p, f32p, i32p, C.c_int, i32p]
+        cap = c * (self.model.cfg.max_symbols_per_step + 1) + 16
+        sm = np.zeros(cap, np.float32); sl = np.full(cap, -1, np.int32); ns = np.zeros(1, np.int32)
+        n = L.orc_stream_decode_ex(self._h, _f(enc), c, mt, _i(ids), _i(st), _i(en), _f(cf), _f(sm), _i(sl), cap, _i(ns))
         if n < 0:
-            raise RuntimeError(lib().orc_last_error().decode())
-        return dict(ids=ids[:n], start=st[:n], end=en[:n], conf=cf[:n])
+            raise RuntimeError(L.orc_last_error().decode())
+        k = int(ns[0])
+        return dict(ids=ids[:n], start=st[:n], end=en[:n], conf=cf[:n], step_label=sl[:k], step_margin=sm[:k])
 
     def sortformer_chunk(self, feats, sf):
         """Sortformer::diarize_chunk (src/sortformer.cpp:123-150) on feats [n_frames][mel] -> probs [c][S] (c may be 0)."""

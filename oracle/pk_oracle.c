@@ -696,14 +696,14 @@ static int attn_bf16_spec(const orc_config *c) {
 
 /* pos_proj_(pos_emb) (no bias), split by head and transposed: PT[h][k][p]  src/encoder.cpp:148-151.
  * Batch-independent (the reference recomputes it per call). */
-static float *pos_proj_heads(orc_model *m, int layer, int T, const float *pos_emb) {
+static float *pos_proj_heads(orc_model *m, int layer, int T, const float *pos_emb, int round16 /* store the table as bf16 (attn_bf16_spec) */) {
     const orc_config *c = &m->cfg;
     const int d = c->d_model, H = c->n_heads, hd = d / H, P = 2 * T - 1;
     orc_tensor *wp = getf(m, "encoder_.layers_.%d.attn_.pos_proj_.weight", layer);
     if (!wp) return NULL;
     float *pp = (float *)xmalloc((size_t)P * d * sizeof(float));
     linear_t(m->cfg.gemm_bf16, wp, NULL, P, pos_emb, d, pp, d, 0);
-    if (attn_bf16_spec(c))                                          /* the table is stored as bf16 (the pos_proj GEMM's epilogue rounds it) */
+    if (round16)                                                    /* the table is stored as bf16 (the pos_proj GEMM's epilogue rounds it) */
         for (int64_t i = 0; i < (int64_t)P * d; ++i) pp[i] = bf16_round(pp[i]);
     float *PT = (float *)xmalloc((size_t)H * hd * P * sizeof(float));
     for (int h = 0; h < H; ++h)
@@ -951,7 +951,7 @@ int orc_conformer_block(orc_model *m, int layer, float *x, int B, int T, const f
     const orc_config *c = &m->cfg;
     const int d = c->d_model;
     if (prepare_layer(m, layer)) return -1;
-    float *PT = pos_proj_heads(m, layer, T, pos_emb);
+    float *PT = pos_proj_heads(m, layer, T, pos_emb, attn_bf16_spec(&m->cfg));
     if (!PT) return -1;
     orc_tensor *g = getf(m, "encoder_.layers_.%d.final_norm_.weight", layer), *bb = getf(m, "encoder_.layers_.%d.final_norm_.bias", layer);
     if (!g || !bb) { free(PT); return -1; }
@@ -1583,6 +1583,12 @@ int orc_rnnt_greedy(orc_model *m, const float *enc, int B, int T, int max_tokens
 /* Streaming path (BASELINE configs[4]): one stream = the state of                     */
 /* StreamingAudioPreprocessor (src/audio.cpp:171-259), EncoderCache / BlockCache                       */
 /* (include/parakeet/streaming_encoder.hpp:25-41), StreamingDecodeState (include/parakeet/eou.hpp:80-87) */
+/* Tolerance-class mode (orc_config.gemm_bf16) of the streaming path -- the specification of the product's  */
+/* bf16 streaming mode (kernels/gemm_smallm_bf16.hip): EVERY Linear / 1x1-conv product of the chunk (sub-   */
+/* sampling, ffn, q / k / v / out, pointwise convs, pos_proj, the joint's enc_proj and the decode products)  */
+/* takes both operands rounded to bf16 with fp32 accumulation; everything between the products (LayerNorm,   */
+/* the cached attention incl. its position table, depthwise conv, caches) stays fp32 arithmetic on those      */
+/* outputs -- the caches hold fp32 values, nothing else is stored rounded.                                    */
 /* ------------------------------------------------------------------------- */
 struct orc_stream {
     orc_model *m;
@@ -1699,11 +1705,11 @@ static int stream_attention(orc_stream *s, int layer, float *x, int c, const flo
     float *k = (float *)xmalloc((size_t)kv * d * sizeof(float)), *v = (float *)xmalloc((size_t)kv * d * sizeof(float));
     float *ctx = (float *)xmalloc((size_t)c * d * sizeof(float)), *y = (float *)xmalloc((size_t)c * d * sizeof(float));
     layer_norm(x, c, d, ng->data, nb->data, cf->ln_eps, n);                          /* :165 */
-    linear_t(0, wq, bq, c, n, d, q, d, 0);                                           /* :168-170 */
+    linear_t(cf->gemm_bf16, wq, bq, c, n, d, q, d, 0);                                           /* :168-170 */
     memcpy(k, s->kc[layer], (size_t)nc * d * sizeof(float));                         /* prepend the cache :186-189 */
     memcpy(v, s->vc[layer], (size_t)nc * d * sizeof(float));
-    linear_t(0, wk, bk, c, n, d, k + (int64_t)nc * d, d, 0);
-    linear_t(0, wv, bv, c, n, d, v + (int64_t)nc * d, d, 0);
+    linear_t(cf->gemm_bf16, wk, bk, c, n, d, k + (int64_t)nc * d, d, 0);
+    linear_t(cf->gemm_bf16, wv, bv, c, n, d, v + (int64_t)nc * d, d, 0);
     {   /* cache <- last att_left rows of kv :193-209 */
         const int keep = kv > s->att_left ? s->att_left : kv, from = kv - keep;
         memmove(s->kc[layer], k + (int64_t)from * d, (size_t)keep * d * sizeof(float));
@@ -1740,7 +1746,7 @@ static int stream_attention(orc_stream *s, int layer, float *x, int c, const flo
             }
         }
     free(row);
-    linear_t(0, wo, bo, c, ctx, d, y, d, 0);                                         /* :255 */
+    linear_t(cf->gemm_bf16, wo, bo, c, ctx, d, y, d, 0);                                         /* :255 */
     for (int64_t i = 0; i < (int64_t)c * d; ++i) x[i] = x[i] + y[i];
     free(n); free(q); free(k); free(v); free(ctx); free(y);
     return 0;
@@ -1762,7 +1768,7 @@ static int stream_conv(orc_stream *s, int layer, float *x, int c) {
     float *cat = (float *)xmalloc((size_t)(cl + c) * d * sizeof(float)), *dw = (float *)xmalloc((size_t)c * d * sizeof(float));
     float *y = (float *)xmalloc((size_t)c * d * sizeof(float));
     layer_norm(x, c, d, ng->data, nb->data, cf->ln_eps, n);
-    linear_t(0, w1, b1, c, n, d, g2, 2 * d, 0);
+    linear_t(cf->gemm_bf16, w1, b1, c, n, d, g2, 2 * d, 0);
     if (s->has_conv[layer]) memcpy(cat, s->cc[layer], (size_t)cl * d * sizeof(float));   /* prepend the cache :51-63 */
     else memset(cat, 0, (size_t)cl * d * sizeof(float));
     for (int t = 0; t < c; ++t)
@@ -1778,7 +1784,7 @@ static int stream_conv(orc_stream *s, int layer, float *x, int c) {
             v = fmaf((v - bnm->data[ch]) * rstd, bng->data[ch], bnb->data[ch]);
             dw[(int64_t)t * d + ch] = orc_siluf(v);
         }
-    linear_t(0, w2, b2, c, dw, d, y, d, 0);
+    linear_t(cf->gemm_bf16, w2, b2, c, dw, d, y, d, 0);
     for (int64_t i = 0; i < (int64_t)c * d; ++i) x[i] = x[i] + y[i];
     free(n); free(g2); free(cat); free(dw); free(y);
     return 0;
@@ -1813,7 +1819,7 @@ int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc,
     orc_pos_emb(Tp, d, pe);
     for (int l = 0; l < cf->n_layers; ++l) {
         if (prepare_layer(m, l)) { free(pe); return -1; }
-        float *PT = pos_proj_heads(m, l, Tp, pe);
+        float *PT = pos_proj_heads(m, l, Tp, pe, 0);                                 /* streaming: fp32 attention arithmetic in either mode */
         if (!PT) { free(pe); return -1; }
         int r = feed_forward(m, l, "ffn1_", enc, c);
         if (!r) r = stream_attention(s, l, enc, c, PT, P);
@@ -1832,14 +1838,23 @@ int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc,
 /* rnnt_streaming_decode_chunk -- src/eou.cpp:17-98: the TDT greedy loop of tdt.cpp on one encoder chunk with the LSTM state
  * and the last token carried across chunks; frames are reported relative to the stream (frame_offset), end frames are not
  * clamped to the chunk; a duration that skips past the end of the chunk is simply lost (:31-33,95). */
-int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf) {
+/* step_margin / step_label [step_cap] (optional): top-1 / top-2 margin and chosen label of EVERY decision of the chunk, in order (the decisions
+ * of the tolerance-class mode's token statement, oracle/tolerance.py); *n_steps = how many there were. */
+int orc_stream_decode_ex(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf,
+                         float *step_margin, int32_t *step_label, int step_cap, int32_t *n_steps) {
     int32_t len = 0, steps = 0;
     const int cap = c * (s->m->cfg.max_symbols + 1) + 16;
-    const int r = tdt_greedy_ex(s->m, enc, 1, c, max_tokens, cap, ids, &len, start, end, conf, &steps, NULL, s->hc, &s->token, 0, NULL, 0.0f, NULL, NULL, NULL, 0);
+    float mm = 0.0f;                                                /* (the per-decision records are kept where the minimum is asked for) */
+    const int r = tdt_greedy_ex(s->m, enc, 1, c, max_tokens, cap, ids, &len, start, end, conf, &steps, NULL, s->hc, &s->token, 0, NULL, 0.0f,
+                                (step_margin || step_label) ? &mm : NULL, step_margin, step_label, step_cap);
     if (r || len < 0) return orc_fail("orc_stream_decode: decode cap hit");
     for (int i = 0; i < len; ++i) { if (start) start[i] += s->frame_offset; if (end) end[i] += s->frame_offset; }
     s->frame_offset += c;
+    if (n_steps) *n_steps = steps;
     return len;
+}
+int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf) {
+    return orc_stream_decode_ex(s, enc, c, max_tokens, ids, start, end, conf, NULL, NULL, 0, NULL);
 }
 
 /* Sortformer::diarize_chunk (src/sortformer.cpp:123-150): forward_chunk of the NEST encoder with the stream's caches, then

@@ -262,6 +262,21 @@ def diag_gemm(A, W, bias=None, epi="none", resid=None, alpha=1.0, bf16=False, a1
     return out
 
 
+def diag_ln_gemm_bf16(A, gamma, beta, W, bias=None, epi="none", resid=None, alpha=1.0, eps=1e-5):
+    """pk_diag_ln_gemm_bf16: epi(bf16(LayerNorm(A)) bf16(W)^T + bias) on the small-M bf16 kernel with the LayerNorm folded in."""
+    A, W, gamma, beta = _c(A), _c(W), _c(gamma), _c(beta)
+    M, K = A.shape
+    N = W.shape[0] // 2 if epi == "glu" else W.shape[0]
+    b = _c(bias) if bias is not None else None
+    r = _c(resid) if resid is not None else None
+    out = np.empty((M, N), np.float32)
+    L = lib()
+    L.pk_diag_ln_gemm_bf16.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, C.c_float, f32p, f32p, C.c_int, f32p, C.c_float, f32p]
+    check(L.pk_diag_ln_gemm_bf16(M, N, K, _f(A), _f(gamma), _f(beta), eps, _f(W), _f(b) if b is not None else None, EPI[epi],
+                                 _f(r) if r is not None else None, alpha, _f(out)))
+    return out
+
+
 class Stream:
     """pk_stream_*: n lock-step streaming sessions on the GPU (reference NemotronTranscriber::transcribe_chunk)."""
 

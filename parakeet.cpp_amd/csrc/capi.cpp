@@ -1824,6 +1824,46 @@ pk_status pk_diag_gemm_bf16_a16(int M, int N, int K, const float *A, const float
     });
 }
 
+/* ... and with the LayerNorm of the input rows folded into the product (the streaming chunks of the tolerance-class mode) */
+pk_status pk_diag_ln_gemm_bf16(int M, int N, int K, const float *A, const float *gamma, const float *beta, float eps, const float *W,
+                               const float *bias, int epi, const float *resid, float alpha, float *out) {
+    return guard([&] {
+        need(A && gamma && beta && W && out && M > 0 && N > 0 && K > 0, "A/gamma/beta/W/out/M/N/K");
+        need(epi >= 0 && epi <= 4, "epi");
+        need(epi != EPI_RESID || resid, "resid");
+        diag_device();
+        const int wrows = epi == EPI_GLU ? 2 * N : N;
+        std::vector<uint16_t> w16((size_t)wrows * K);
+        for (size_t i = 0; i < w16.size(); ++i) {
+            uint32_t u;
+            memcpy(&u, &W[i], 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            w16[i] = (uint16_t)(u >> 16);
+        }
+        Scratch s;
+        DevBuf gb;
+        s.a.reserve((size_t)M * K * 4);
+        s.b.reserve((size_t)wrows * K * 2);
+        s.c.reserve((size_t)wrows * 4);
+        s.d.reserve((size_t)M * N * 4);
+        s.e.reserve((size_t)M * N * 4);
+        gb.reserve((size_t)2 * K * 4);
+        PK_HIP(hipMemcpy(s.a.p, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+        PK_HIP(hipMemcpy(s.b.p, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+        PK_HIP(hipMemcpy(gb.p, gamma, (size_t)K * 4, hipMemcpyHostToDevice));
+        PK_HIP(hipMemcpy((char *)gb.p + (size_t)K * 4, beta, (size_t)K * 4, hipMemcpyHostToDevice));
+        if (bias) PK_HIP(hipMemcpy(s.c.p, bias, (size_t)wrows * 4, hipMemcpyHostToDevice));
+        if (resid) PK_HIP(hipMemcpy(s.d.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice));
+        GemmArgs g{s.a.as<float>(), K, s.b.as<float>(), K, bias ? s.c.as<float>() : nullptr, s.e.as<float>(), N,
+                   resid ? s.d.as<float>() : nullptr, N, alpha, M, N, K};
+        g.ln_g = gb.as<float>(); g.ln_b = gb.as<float>() + K; g.ln_eps = eps;
+        if (!gemm_smallm_bf16_ln_applies(g, epi)) fail(PK_ERR_UNSUPPORTED, "pk_diag_ln_gemm_bf16: M <= %d, K = 256 * (1 .. 8; glu: .. 4)", kSmallMRowsBf16);
+        launch_gemm_bf16(g, epi, nullptr);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpy(out, s.e.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y) {
     return guard([&] {
         need(x && gamma && beta && y && rows > 0 && d > 0 && d <= 1024, "x/gamma/beta/y/rows/d (d <= 1024)");

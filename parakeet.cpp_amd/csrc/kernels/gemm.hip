@@ -350,6 +350,8 @@ static void launch_gemm_bf16_a(const GemmArgs &a, int epi, hipStream_t s) {
 }
 void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s) {
     // (a bf16 output goes through the wide epilogue only -- row-major, 4-column groups: Model::run_gemm checks)
+    // a handful of rows (the streaming encoder's chunks): the weight-stream kernel of gemm_smallm_bf16.hip
+    if (gemm_smallm_bf16_applies(a, epi)) { launch_gemm_smallm_bf16(a, epi, s); return; }
     if (a.a_bf16) launch_gemm_bf16_a<true>(a, epi, s);
     else launch_gemm_bf16_a<false>(a, epi, s);
 }

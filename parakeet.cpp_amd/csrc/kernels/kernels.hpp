@@ -104,6 +104,9 @@ struct GemmArgs {
     // layout (its producer wrote it that way: sigma_cols, LayerNorm mode 2, the streaming attention / conv kernels).  Both set: a lane's 16-byte
     // load IS its operand of four consecutive MFMA steps -- no transposes on the chain -- and every weight load is 1 KB of consecutive addresses.
     const float *W_sig = nullptr; int a_sigma = 0;
+    // small-M bf16 kernel (gemm_smallm_bf16.hip) only: A = the UN-normalised fp32 rows, the LayerNorm (gamma ln_g[K], beta ln_b[K], ln_eps) of the
+    // product's input is applied while the rows are staged -- out = epi(bf16(LN(A)) W16^T + bias).  Callers check gemm_smallm_bf16_ln_applies().
+    const float *ln_g = nullptr, *ln_b = nullptr; float ln_eps = 0.0f;
 };
 constexpr int kSmallMRows = 1536;  // launch_gemm: products with M <= this (and K % 64 == 0) run on gemm_smallm.hip.  Measured with the two-row-tile
                                    // variant in place (110m encoder; reference protocol, batch 1: M = 626 5.6 ms on it vs 6.7 on the tile kernels,
@@ -115,6 +118,13 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
 // same contract with bf16 operands and fp32 accumulation: a.W points to bf16 weights [N][K] (rounded once at upload), A is
 // rounded to bf16 while it is staged; K % 64 == 0.  Not bit-identical to the fp32 chain (kernels/gemm_bf16.hpp).
 void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s);
+// the same for a handful of rows (streaming chunks in the tolerance-class mode): kernels/gemm_smallm_bf16.hip -- one workgroup per 16 output
+// columns, K split over its waves, every weight byte requested up front.  launch_gemm_bf16 routes the shapes gemm_smallm_bf16_applies() accepts
+// (M <= kSmallMRowsBf16, K % 256 == 0, row-major output) there.
+constexpr int kSmallMRowsBf16 = 128;
+bool gemm_smallm_bf16_applies(const GemmArgs &a, int epi);
+bool gemm_smallm_bf16_ln_applies(const GemmArgs &a, int epi);     // ... with GemmArgs::ln_g set: K = 256 * (1 .. 8 waves; GLU: 4), fp32 rows
+void launch_gemm_smallm_bf16(const GemmArgs &a, int epi, hipStream_t s);
 double gemm_flops(const GemmArgs &a, int epi);
 
 // ---- conv subsampling (src/encoder.cpp:219-241), channels-last ---------------------------------------

@@ -10,12 +10,24 @@
 // per stream): FFN / projection products run on the MFMA GEMM with M = S*c rows, the cached attention and causal conv are
 // exact-chain VALU kernels (kernels/stream.hip).  Bit-identical to the oracle's Stream (tests/test_gpu_stream.py).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
 #include "stream.hpp"
 
 namespace pk {
+
+// Tolerance-class mode: fold the LayerNorm of a product's input rows into the product (kernels/gemm_smallm_bf16.hip, GemmArgs::ln_g) -- four of a
+// block's fifteen launches go.  EXPERIMENTAL builds: PK_STREAM_FUSE_LN=0 switches it off for the A/B of tools/experiments/stream_bf16_ab.sh.
+static bool stream_fuse_ln() {
+#ifdef PK_EXPERIMENTAL
+    static const bool on = [] { const char *e = getenv("PK_STREAM_FUSE_LN"); return e ? atoi(e) != 0 : true; }();
+    return on;
+#else
+    return true;
+#endif
+}
 
 StreamBatch::StreamBatch(Model &m, int n_streams, int att_left, int att_right) : S(n_streams), m_(m), left_(att_left), right_(att_right) {
     m_.require_gpu();
@@ -153,16 +165,39 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     // rows <= kSmallMRows: every product of the chunk is a gemm_smallm chain -- run them on the sigma-K weight copies with sigma-K activations (the
     // producers below write that layout; x, the residual stream, stays natural)
     const int sg = (rows <= kSmallMRows && !sig_->empty()) ? 1 : 0;
+    // Tolerance-class mode (pk_config.gemm_bf16; specification: the oracle's Stream in its gemm_bf16 mode): every product of the chunk takes bf16
+    // operands (kernels/gemm_smallm_bf16.hip for these few rows); the rows that exist only as GEMM operands -- LayerNorm outputs, the fc1
+    // activations -- are stored as bf16 by their producers (RNE, the rounding the GEMM would apply: same operand values, half the bytes);
+    // attention, depthwise conv and the caches stay fp32 arithmetic on the products' fp32 outputs.
+    const int a16 = cfg.gemm_bf16 ? 1 : 0;
+    const int lnm = a16 ? 1 : (sg ? 2 : 0);                                                               // launch_layernorm's output mode
     const int f = cfg.ffn_intermediate;
     float *hb = ws_.hbuf.as<float>();
+    // LayerNorm(x) -> n, then the product on n -- or, where the small-M bf16 kernel can fold the norm in, the product straight on x
+    auto ln_gemm = [&](const char *name, const GemmArgs &g, int epi, const float *ng, const float *nb, bool norm_done) {
+        if (a16 && !norm_done && stream_fuse_ln()) {
+            GemmArgs fg = g;
+            fg.A = x; fg.lda = d; fg.a_bf16 = 0; fg.ln_g = ng; fg.ln_b = nb; fg.ln_eps = 1e-5f;
+            if (gemm_smallm_bf16_ln_applies(fg, epi)) { m_.run_gemm(name, fg, epi, st); return; }
+        }
+        if (!norm_done) launch_layernorm(x, rows, d, ng, nb, 1e-5f, n, st, lnm);
+        m_.run_gemm(name, g, epi, st);
+    };
+    bool ln_folds = false;                                                                                // the next block's ffn1 norm will be folded into its fc1
+    if (a16 && stream_fuse_ln()) {
+        GemmArgs pg{x, d, m_.layers[0].ffn1_w1, d, nullptr, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
+        pg.ln_g = m_.layers[0].ffn1_ng; pg.ln_b = m_.layers[0].ffn1_nb; pg.out_bf16 = 1;
+        ln_folds = gemm_smallm_bf16_ln_applies(pg, EPI_SILU);
+    }
     auto ffn = [&](const LayerW &L, const Model::SigW &Ls, bool second, bool norm_done) {                // FeedForward (src/encoder.cpp:36-46)
-        if (!norm_done) launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, st, sg ? 2 : 0);
         GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
         g1.a_sigma = sg; g1.W_sig = second ? Ls.ffn2_w1 : Ls.ffn1_w1;
+        g1.a_bf16 = a16; g1.out_bf16 = a16;
         g1.sigma_cols = sg ? f : 0;                                                                       // h is fc2's A operand
-        m_.run_gemm("ffn_fc1_silu", g1, EPI_SILU, st);
+        ln_gemm("ffn_fc1_silu", g1, EPI_SILU, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, norm_done);
         GemmArgs g2{hb, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, x, d, 0.5f, (int)rows, d, f};
         g2.a_sigma = sg; g2.W_sig = second ? Ls.ffn2_w2 : Ls.ffn1_w2;
+        g2.a_bf16 = a16;
         m_.run_gemm("ffn_fc2_resid", g2, EPI_RESID, st);
     };
     bool ffn1_norm_done = false;
@@ -173,11 +208,11 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         const Model::SigW &Sg = sg ? (*sig_)[l] : no_sig;
         ffn(L, Sg, false, ffn1_norm_done);                                                             // ffn1_ (:294)
         // StreamingConformerAttention::forward_cached (:162-272)
-        launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, st, sg ? 2 : 0);
         {
             GemmArgs g{n, d, L.wqkv, d, L.bqkv, ws_.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
             g.a_sigma = sg; g.W_sig = Sg.wqkv;
-            m_.run_gemm("attn_qkv", g, EPI_NONE, st);                                                 // natural columns (no sigma layout here)
+            g.a_bf16 = a16;
+            ln_gemm("attn_qkv", g, EPI_NONE, L.att_ng, L.att_nb, false);                              // natural columns (no sigma layout here)
         }
         const float *kc = Ls.k[Ls.cur].as<float>(), *vc = Ls.v[Ls.cur].as<float>();
         // attention of the chunk's rows + (same launch, extra blocks) the rotation of the K / V caches into the other buffer pair
@@ -191,11 +226,11 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
             m_.run_gemm("attn_out_resid", g, EPI_RESID, st);
         }
         // CausalConformerConvModule::forward_cached (:41-78)
-        launch_layernorm(x, rows, d, L.cv_ng, L.cv_nb, 1e-5f, n, st, sg ? 2 : 0);
         {
             GemmArgs g{n, d, L.pw1_w, d, L.pw1_b, ws_.g.as<float>(), d, nullptr, 0, 1.0f, (int)rows, d, d};
             g.a_sigma = sg; g.W_sig = Sg.pw1;
-            m_.run_gemm("conv_pw1_glu", g, EPI_GLU, st);
+            g.a_bf16 = a16;
+            ln_gemm("conv_pw1_glu", g, EPI_GLU, L.cv_ng, L.cv_nb, false);
         }
         launch_stream_dwconv(ws_.g.as<float>(), Ls.conv[Ls.ccur].as<float>(), Ls.has_conv, S, c, d, K, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
                              ws_.dwb.as<float>(), Ls.conv[Ls.ccur ^ 1].as<float>(), st, sg);
@@ -207,10 +242,10 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
             m_.run_gemm("conv_pw2_resid", g, EPI_RESID, st);
         }
         ffn(L, Sg, true, false);                                                                       // ffn2_
-        if (l + 1 < cfg.num_layers) {            // final_norm_ and the next block's ffn1_ norm in one pass over the rows (as the offline encoder)
-            launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, m_.layers[l + 1].ffn1_ng, m_.layers[l + 1].ffn1_nb, 1e-5f, x, n, st, sg ? 2 : 0);
+        if (l + 1 < cfg.num_layers && !ln_folds) {   // final_norm_ and the next block's ffn1_ norm in one pass over the rows (as the offline encoder)
+            launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, m_.layers[l + 1].ffn1_ng, m_.layers[l + 1].ffn1_nb, 1e-5f, x, n, st, lnm);
             ffn1_norm_done = true;
-        } else {
+        } else {                                     // (ln_folds: the next block's fc1 normalises its own input rows)
             launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, st);                              // final_norm_
         }
     }

@@ -91,6 +91,87 @@ def test_bf16_glds_gemm_against_float64(M, N, K, epi):
     assert np.all(err <= 2e-6 * mag + 1e-6), f"max err {err.max():.3e} (bound {float((2e-6 * mag + 1e-6).max()):.3e}) at {np.unravel_index(err.argmax(), err.shape)}"
 
 
+@pytest.mark.parametrize("M,N,K,epi,a16", [(32, 4096, 1024, "silu", True), (32, 1024, 4096, "resid", True), (32, 3072, 1024, "none", True),
+                                           (32, 1024, 1024, "resid", False), (32, 1024, 1024, "glu", True), (16, 640, 1024, "none", False),
+                                           (33, 512, 2048, "resid", True), (100, 1024, 4352, "none", False), (7, 2048, 512, "silu", True),
+                                           (32, 1030, 256, "relu", False), (64, 512, 512, "glu", False), (2, 4096, 1024, "silu", False),
+                                           (128, 1024, 4096, "resid", True), (20, 512, 256, "glu", True)])
+def test_bf16_smallm_gemm_against_float64(M, N, K, epi, a16):
+    """The weight-stream kernel for a handful of rows (kernels/gemm_smallm_bf16.hip: the streaming chunks of the tolerance-class mode; M <= 128,
+    K % 256 == 0): one and two row tiles per wave, several row groups, K slices of 256 / 512 k over 1..8 waves (and more slices than waves:
+    K = 4352, the subsampling projection), fp32 and bf16 activations, every epilogue, ragged N -- against float64 of the same rounded operands."""
+    from parakeet_cpp_amd import capi
+    rng = np.random.default_rng(11 * M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    rows = 2 * N if epi == "glu" else N
+    W = (rng.standard_normal((rows, K)) / np.sqrt(K)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(rows)).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32) if epi == "resid" else None
+    got = capi.diag_gemm(A, W, bias, epi=epi, resid=resid, alpha=0.5, bf16=True, a16=a16)
+    Aq, Wq = bf16_round(A).astype(np.float64), bf16_round(W).astype(np.float64)
+    acc = Aq @ Wq.T + bias
+    mag = np.abs(Aq) @ np.abs(Wq.T) + np.abs(bias)
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    if epi == "relu":
+        want = np.maximum(acc, 0)
+    elif epi == "silu":
+        want = acc * sig(acc)
+    elif epi == "resid":
+        want = resid + 0.5 * acc
+    elif epi == "glu":
+        want, mag = acc[:, :N] * sig(acc[:, N:]), mag[:, :N] + mag[:, N:]
+    else:
+        want = acc
+    err = np.abs(got - want)
+    assert np.all(err <= 2e-6 * mag + 1e-6), f"max err {err.max():.3e} (bound {float((2e-6 * mag + 1e-6).max()):.3e}) at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(32, 4096, 1024, "silu"), (32, 3072, 1024, "none"), (32, 1024, 1024, "glu"), (32, 2048, 512, "silu"),
+                                       (6, 1536, 512, "none"), (16, 512, 512, "glu"), (100, 640, 1024, "resid"), (16, 1030, 256, "relu"),
+                                       (40, 256, 2048, "none")])
+def test_bf16_smallm_gemm_with_folded_layernorm(M, N, K, epi):
+    """kernels/gemm_smallm_bf16.hip with the LayerNorm of the input rows folded in (GemmArgs::ln_g: the streaming chunks of the tolerance-class
+    mode): statistics from the K slices of the waves (two LDS exchanges), rows normalised and rounded in registers.  Against float64 of the
+    operands the specification rounds: bf16(LayerNorm_fp32(x)) and bf16(W).  The kernel's fp32 LayerNorm differs from numpy's in its last bit
+    for a few elements, and such an element may round to the neighbouring bf16 value (2^-8 relative): the bound allows a 2^-8 error on a few
+    operands per row on top of the accumulation class -- err <= 2e-6 * sum|a w| + 2^-8 * 4 * max|a w|."""
+    from parakeet_cpp_amd import capi
+    rng = np.random.default_rng(13 * M + N + K)
+    A = (rng.standard_normal((M, K)) * rng.uniform(0.5, 3.0, (M, 1)) + rng.uniform(-2, 2, (M, 1))).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(K)).astype(np.float32)
+    rows = 2 * N if epi == "glu" else N
+    W = (rng.standard_normal((rows, K)) / np.sqrt(K)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(rows)).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32) if epi == "resid" else None
+    got = capi.diag_ln_gemm_bf16(A, gamma, beta, W, bias, epi=epi, resid=resid, alpha=0.5, eps=1e-5)
+    A64 = A.astype(np.float64)
+    mean = A64.mean(axis=1, keepdims=True)
+    var = ((A64 - mean) ** 2).mean(axis=1, keepdims=True)
+    ln = ((A64 - mean) / np.sqrt(var + 1e-5) * gamma + beta).astype(np.float32)
+    Aq, Wq = bf16_round(ln).astype(np.float64), bf16_round(W).astype(np.float64)
+    acc = Aq @ Wq.T + bias
+    mag = np.abs(Aq) @ np.abs(Wq.T) + np.abs(bias)
+    flip = 4.0 * 2.0 ** -8 * (np.abs(Aq).max(axis=1, keepdims=True) * np.abs(Wq).max(axis=1)[None, :])
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    if epi == "relu":
+        want = np.maximum(acc, 0)
+    elif epi == "silu":
+        want = acc * sig(acc)
+    elif epi == "resid":
+        want = resid + 0.5 * acc
+    elif epi == "glu":
+        want, mag, flip = acc[:, :N] * sig(acc[:, N:]), mag[:, :N] + mag[:, N:], flip[:, :N] + flip[:, N:]
+    else:
+        want = acc
+    err = np.abs(got - want)
+    bound = 2e-6 * mag + flip + 1e-6
+    assert np.all(err <= bound), f"max err {err.max():.3e} (bound there {float(bound.flat[err.argmax()]):.3e}) at {np.unravel_index(err.argmax(), err.shape)}"
+    # and the plain accumulation class for the bulk: at most a handful of elements per row may carry a flipped operand
+    loose = (err > 2e-6 * mag + 1e-6).mean()
+    print(f"M {M} N {N} K {K} {epi}: max err {err.max():.2e}; elements beyond the pure accumulation bound: {100 * loose:.2f} %")
+
+
 def close(got, want, what):
     d, mx = np.abs(got - want), np.abs(want).max()
     print(f"{what}: GPU bf16 vs oracle bf16: max {d.max():.2e} mean {d.mean():.2e} (max|x| {mx:.2f})")

@@ -2,7 +2,9 @@
 """BASELINE configs[4]: nemotron-600m streaming, 16 concurrent lock-step streams on one GPU, 2560-sample (160 ms) chunks, cached
 encoder state.  Prints one JSON line: per-chunk latency (median / p95 over the timed chunks, host wall clock around pk_stream_push
 including the token copy-back) and aggregate RTFx = streams x chunk seconds / latency.
-usage: python tools/bench_stream.py [--streams 16] [--latency-frames 1] [--chunks 200] [--config nemotron-600m]"""
+--bf16: the tolerance-class mode (pk_config.gemm_bf16: bf16 weights / operands, fp32 accumulation; kernels/gemm_smallm_bf16.hip) -- compared
+with the oracle's gemm_bf16 Stream within a tolerance (tests/test_gpu_stream.py), not bit for bit like the default fp32 mode.
+usage: python tools/bench_stream.py [--streams 16] [--latency-frames 1] [--chunks 200] [--config nemotron-600m] [--bf16]"""
 import argparse
 import json
 import os
@@ -22,6 +24,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chunk-samples", type=int, default=2560)
     ap.add_argument("--config", default="nemotron-600m")
+    ap.add_argument("--bf16", action="store_true", help="tolerance-class mode: every product of the chunk on bf16 operands (pk_config.gemm_bf16)")
     a = ap.parse_args()
     import pkload
     pk = pkload.load()
@@ -29,6 +32,9 @@ def main():
     import bench
     cfg = config.PRESETS[a.config]()
     path, _ = bench.weights_file(cfg)
+    if a.bf16:
+        import dataclasses
+        cfg = dataclasses.replace(cfg, gemm_bf16=True)
     m = capi.Model(path, cfg, device=0)
     st = capi.Stream(m, a.streams, 70, a.latency_frames)
     n = a.chunk_samples
@@ -48,7 +54,7 @@ def main():
            "streams": a.streams, "chunk_ms": chunk_s * 1e3, "latency_ms_median": round(float(np.median(lat)) * 1e3, 3),
            "latency_ms_p95": round(float(np.percentile(lat, 95)) * 1e3, 3), "latency_ms_mean": round(float(lat.mean()) * 1e3, 3),
            "aggregate_rtfx": round(a.streams * chunk_s / float(lat.mean()), 1), "tokens_emitted": toks, "chunks": a.chunks,
-           "dtype": "f32", "data": "synthetic"}
+           "dtype": "bf16 operands / f32 accumulate (tolerance-class mode)" if a.bf16 else "f32", "data": "synthetic"}
     print(json.dumps(out))
     st.close(); m.close()
 
