@@ -2,23 +2,34 @@
 // streaming chunk (16 lock-step streams x 2 encoder frames against the 600M-parameter weight set) in the TOLERANCE-class mode
 // (pk_config.gemm_bf16; BASELINE configs[4] with bf16 weights).
 //
-// out[M][N] = epi(bf16(A)[M][K] * W16[N][K]^T + bias), fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+// out[M][N] = epi(bf16(A)[M][K] * W16[N][K]^T + bias), fp32 accumulation on v_mfma_f32_16x16x32_bf16; optionally with the LayerNorm of the
+// input rows folded in (GemmArgs::ln_g): out = epi(bf16(LN(A)) W16^T + bias).
 //
 // Why a kernel of its own.  The exact (fp32) streaming mode is bound by its numerics contract: a natural-k fp32 chain issues 4 k per ~33 clocks,
 // so fc2 of nemotron-600m (K = 4096) is a 14 us dependent chain whatever the bandwidth (gemm_smallm.hip; DESIGN.md section 5: 1.19 ms of
 // chain per chunk).  The tolerance-class mode has no k-order contract: one MFMA takes 32 k in the same 8 passes (8x the k rate), and K may
-// be SPLIT over the waves of a workgroup -- what is left is a pure weight stream: 8.4 MB of bf16 per ffn product, ~1 us at HBM rate.
-//   * one WORKGROUP per 16 output columns (GLU: the value and the gate tile of the same 16 columns), `split` waves per tile; wave w owns the
-//     K slices w, w + split, ... of 32 * STEPS k each.  With 16 columns x (STEPS * 32) k per wave the whole slice is requested UP FRONT
-//     (STEPS 16-byte loads per lane and operand row tile, no ring, no branch between the loads): every byte of a product's weights is in
-//     flight a few hundred clocks after the launch -- 1024 waves x 8 KB (K = 1024 products) or 512 x 16 KB (K = 4096).
-//   * up to two 16-row tiles per wave share the W registers (M = 32: the 16 streams x 2 frames of a 160 ms chunk); more rows = more row groups
-//     (grid.y), which re-read W from L2.
+// be SPLIT over the waves of a workgroup -- what is left is data movement: 8.4 MB of bf16 weights per ffn product from HBM, and the activation
+// rows, which EVERY workgroup needs, from L2.
+//   * one WORKGROUP per (16 output columns, R rows), `split` waves; wave w owns the K slices w, w + split, ... of 32 * STEPS k each and
+//     requests its whole slice UP FRONT (STEPS 16-byte loads per lane and operand tile, no ring, no branch between the loads): every byte of a
+//     product is in flight a few hundred clocks after the launch.  GLU: the value and the gate rows of the same 16 columns are two weight
+//     tiles of the SAME wave (one set of activation registers feeds both).
+//   * R = 32 (two 16-row MFMA tiles per wave sharing the W registers), 16 or 8 (one tile; rows 8..15 of the MFMA repeat rows 0..7 and are not
+//     stored).  What a product costs is the bytes its busiest CU has to pull through its L1 -- measured ~45 GB/s per CU in this access pattern
+//     (profiles/r04_stream_bf16_kernel_stats_v1.md: 64 workgroups of 8 waves took 13.3 us for fc2, 384 KB per CU) -- so a product with few column
+//     tiles (N = 1024: 64) is cut into more, smaller workgroups: with R rows and 16 columns a workgroup pulls 2 K (R + 16) bytes (bf16 rows), and
+//     the workgroups of one column tile run on the same XCD (grid.x is a multiple of 8), so the tile's weights leave HBM once.
 //   * operands in their NATURAL layouts: lane (r = lane & 15, q = lane >> 4) supplies k = 32 s + 8 q .. + 7 of MFMA step s for row / column r:
 //     one 16-byte load of a bf16 row (weights; activations when the producer stored bf16: GemmArgs::a_bf16) or two 16-byte loads of an fp32
 //     row rounded with v_cvt_pk_bf16_f32 (RNE -- the rounding the big-tile bf16 kernel applies while staging, gemm_bf16.hpp).
 //   * the partial sums of the `split` waves meet in LDS and are added in wave order (fixed: run-to-run deterministic); the first RT waves
 //     then run the epilogue (bias, SiLU / ReLU / residual / GLU; fp32 or bf16 rows out).
+//   * LayerNorm folded in (LN): A = the UN-normalised fp32 rows.  A streaming chunk is ~360 dependent launches of which 96 are LayerNorms over
+//     32 rows -- ~5 us each for a fraction of a microsecond of work; here the workgroup that needs the normalised rows derives their statistics
+//     itself: every wave already holds its K slice of the rows in registers (two-pass mean / variance as the oracle's layer_norm: the slices'
+//     partial sums meet in LDS, added in wave order), normalises with gamma / beta staged once per wave in LDS, rounds to bf16.  Slices of
+//     256 k, ONE per wave: K = 256 * split, split <= 8.  (The exact fp32 mode tried this in round 3 and lost: one WAVE per 16x16 tile
+//     re-derived the statistics over the whole K, 3-4 us on the dependent chain.  Here they cost two LDS exchanges.)
 // Specification = the oracle's gemm_bf16 mode (oracle/pk_oracle.c linear_t: both operands rounded to bf16, k-ordered fp32 accumulation);
 // the accumulation ORDER differs (MFMA blocks of 32 k, K slices), so results are compared within the mode's tolerance
 // (tests/test_gpu_bf16.py: against float64 of the same rounded operands; tests/test_gpu_stream.py: the streaming mode against the oracle's).
@@ -32,15 +43,20 @@ typedef __bf16 sb_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kSbMaxWaves = 8;      // waves per workgroup (2 per SIMD: 256 VGPRs each -- the up-front slices need them)
 
-template <int EPI, int STEPS /* MFMA steps (32 k each) per K slice */, int RT /* 16-row tiles per wave */, bool A16 /* A is bf16 [M][lda] */>
-__global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(GemmArgs g, int split /* waves per output tile */) {
-    constexpr int NH = (EPI == EPI_GLU) ? 2 : 1;
-    __shared__ sb_f32x4 part[kSbMaxWaves][RT][64];                  // partial sums [wave][row tile][lane]
+template <int EPI, int STEPS /* MFMA steps (32 k each) per K slice */, int RT /* 16-row MFMA tiles per wave */, bool A16 /* A is bf16 [M][lda] */,
+          bool LN /* fold LayerNorm(A; ln_g, ln_b, ln_eps) in: A fp32, STEPS = 8, one slice per wave */>
+__global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(GemmArgs g, int split /* waves = K slices in flight */,
+                                                                            int rvalid /* rows of a 16-row tile that exist: 16, or 8 (RT = 1) */) {
+    constexpr int NW = (EPI == EPI_GLU) ? 2 : 1;                    // weight tiles per wave (GLU: value rows [0, N), gate rows [N, 2N))
+    constexpr int SL = 32 * STEPS;
+    static_assert(!LN || (!A16 && STEPS == 8), "the folded LayerNorm reads fp32 rows in slices of 256 k");
+    __shared__ sb_f32x4 part[kSbMaxWaves][NW][RT][64];              // partial sums [wave][weight tile][row tile][lane]
+    __shared__ __attribute__((aligned(16))) float gam[LN ? kSbMaxWaves : 1][LN ? SL : 4], bet[LN ? kSbMaxWaves : 1][LN ? SL : 4];
+    __shared__ float st1[LN ? kSbMaxWaves : 1][RT][16], st2[LN ? kSbMaxWaves : 1][RT][16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    const int half = (NH == 2) ? wave / split : 0, ks = (NH == 2) ? wave % split : wave;   // GLU: waves [0, split) value tile, [split, 2 split) gate tile
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * RT);
-    const int nslices = g.K / (32 * STEPS);
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (RT == 2 ? 32 : rvalid);
+    const int nslices = g.K / SL;
 
     // epilogue operands of the waves that will finish the tile (wave t < RT finishes row tile t): requested before the weight stream
     const int col = n0 + r;
@@ -54,31 +70,37 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = m0 + 16 * wave + 4 * kq + i;
-                if (row < g.M) res[i] = g.resid[(int64_t)row * g.ldr + col];
+                if (4 * kq + i < rvalid && row < g.M) res[i] = g.resid[(int64_t)row * g.ldr + col];
             }
         }
     }
 
-    sb_f32x4 acc[RT];
+    sb_f32x4 acc[NW][RT];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t] = sb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int h = 0; h < NW; ++h)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[h][t] = sb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     int wrow = n0 + r;
     wrow = wrow < g.N ? wrow : g.N - 1;
-    const __bf16 *wp = reinterpret_cast<const __bf16 *>(g.W) + (int64_t)(half * g.N + wrow) * g.ldw + 8 * kq;
+    const __bf16 *wp[NW];
+#pragma unroll
+    for (int h = 0; h < NW; ++h) wp[h] = reinterpret_cast<const __bf16 *>(g.W) + (int64_t)(h * g.N + wrow) * g.ldw + 8 * kq;
     const __bf16 *ap16[RT];
     const float *ap32[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-        int arow = m0 + 16 * t + r;
+        int arow = m0 + 16 * t + (r & (rvalid - 1));                // rvalid = 8: MFMA rows 8..15 repeat rows 0..7 (never stored)
         arow = arow < g.M ? arow : g.M - 1;
         ap16[t] = reinterpret_cast<const __bf16 *>(g.A) + (int64_t)arow * g.lda + 8 * kq;
         ap32[t] = g.A + (int64_t)arow * g.lda + 8 * kq;
     }
 
-    for (int sl = ks; sl < nslices; sl += split) {                  // (one iteration for the shapes of the streaming encoder)
-        const int k0 = sl * (32 * STEPS);
-        sb_bf16x8 w[STEPS], a[RT][STEPS];
+    // (one iteration for the shapes of the streaming encoder; LN: exactly one per wave, the host launches split = K / 256 waves -- the
+    //  barriers below are executed by every wave once)
+    for (int sl = wave; sl < nslices; sl += split) {
+        const int k0 = sl * SL;
+        sb_bf16x8 w[NW][STEPS], a[RT][STEPS];
         float4 af[RT][STEPS][2];
         // activations first (L2 hits: they return ahead of the weight stream that follows in the same queue)
 #pragma unroll
@@ -92,10 +114,78 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                     af[t][s][1] = *reinterpret_cast<const float4 *>(ap32[t] + k0 + 32 * s + 4);
                 }
             }
+        float4 g4 = {0.0f, 0.0f, 0.0f, 0.0f}, b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (LN) {
+            g4 = *reinterpret_cast<const float4 *>(g.ln_g + k0 + 4 * lane);
+            b4 = *reinterpret_cast<const float4 *>(g.ln_b + k0 + 4 * lane);
+        }
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) w[s] = *reinterpret_cast<const sb_bf16x8 *>(wp + k0 + 32 * s);
-        __builtin_amdgcn_sched_barrier(0);                          // every load of the slice is issued before the first MFMA waits
-        if constexpr (!A16) {
+        for (int h = 0; h < NW; ++h)
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) w[h][s] = *reinterpret_cast<const sb_bf16x8 *>(wp[h] + k0 + 32 * s);
+        __builtin_amdgcn_sched_barrier(0);                          // every load of the slice is issued before anything waits
+
+        if constexpr (LN) {
+            // gamma / beta of this wave's slice: wave-private LDS rows, read back after the barriers below
+            *reinterpret_cast<float4 *>(&gam[wave][4 * lane]) = g4;
+            *reinterpret_cast<float4 *>(&bet[wave][4 * lane]) = b4;
+            // statistics of the rows (oracle layer_norm: the mean, then the mean of the squared deviations), two passes over the registers
+            const float inv_k = 1.0f / (float)g.K;
+            float mean[RT], rstd[RT];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                float p = 0.0f;
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) {
+                    const float4 lo = af[t][s][0], hi = af[t][s][1];
+                    p += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                }
+                p += __shfl_xor(p, 16);
+                p += __shfl_xor(p, 32);
+                if (kq == 0) st1[wave][t][r] = p;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                float sum = st1[0][t][r];
+                for (int w2 = 1; w2 < split; ++w2) sum += st1[w2][t][r];
+                mean[t] = sum * inv_k;
+                float p = 0.0f;
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) {
+                    const float4 lo = af[t][s][0], hi = af[t][s][1];
+                    const float c0 = lo.x - mean[t], c1 = lo.y - mean[t], c2 = lo.z - mean[t], c3 = lo.w - mean[t];
+                    const float c4 = hi.x - mean[t], c5 = hi.y - mean[t], c6 = hi.z - mean[t], c7 = hi.w - mean[t];
+                    p += ((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) + ((c4 * c4 + c5 * c5) + (c6 * c6 + c7 * c7));
+                }
+                p += __shfl_xor(p, 16);
+                p += __shfl_xor(p, 32);
+                if (kq == 0) st2[wave][t][r] = p;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                float sum = st2[0][t][r];
+                for (int w2 = 1; w2 < split; ++w2) sum += st2[w2][t][r];
+                rstd[t] = 1.0f / sqrtf(sum * inv_k + g.ln_eps);
+            }
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const float4 gl = *reinterpret_cast<const float4 *>(&gam[wave][32 * s + 8 * kq]), gh = *reinterpret_cast<const float4 *>(&gam[wave][32 * s + 8 * kq + 4]);
+                const float4 bl = *reinterpret_cast<const float4 *>(&bet[wave][32 * s + 8 * kq]), bh = *reinterpret_cast<const float4 *>(&bet[wave][32 * s + 8 * kq + 4]);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const float4 lo = af[t][s][0], hi = af[t][s][1];
+                    const float m = mean[t], rs = rstd[t];
+                    sb_bf16x8 v;                                    // y = fma((x - mean) * rstd, gamma, beta), rounded to bf16 (RNE)
+                    v[0] = (__bf16)fmaf((lo.x - m) * rs, gl.x, bl.x); v[1] = (__bf16)fmaf((lo.y - m) * rs, gl.y, bl.y);
+                    v[2] = (__bf16)fmaf((lo.z - m) * rs, gl.z, bl.z); v[3] = (__bf16)fmaf((lo.w - m) * rs, gl.w, bl.w);
+                    v[4] = (__bf16)fmaf((hi.x - m) * rs, gh.x, bh.x); v[5] = (__bf16)fmaf((hi.y - m) * rs, gh.y, bh.y);
+                    v[6] = (__bf16)fmaf((hi.z - m) * rs, gh.z, bh.z); v[7] = (__bf16)fmaf((hi.w - m) * rs, gh.w, bh.w);
+                    a[t][s] = v;
+                }
+            }
+        } else if constexpr (!A16) {
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -110,36 +200,36 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
 #pragma unroll
         for (int s = 0; s < STEPS; ++s)
 #pragma unroll
-            for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][s], w[s], acc[t], 0, 0, 0);
+            for (int h = 0; h < NW; ++h)
+#pragma unroll
+                for (int t = 0; t < RT; ++t) acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][s], w[h][s], acc[h][t], 0, 0, 0);
     }
 
     // the K slices meet: partial sums through LDS, added in wave order
-    if (split * NH > 1) {
+    if (split > 1) {
 #pragma unroll
-        for (int t = 0; t < RT; ++t) part[wave][t][lane] = acc[t];
+        for (int h = 0; h < NW; ++h)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) part[wave][h][t][lane] = acc[h][t];
         __syncthreads();
     }
-    if (wave >= RT) return;
+    if (wave >= RT) return;                                         // (RT = 2 is launched with split >= 2)
     const int t = wave;                                             // this wave finishes row tile t
-    sb_f32x4 v = acc[0], gt = sb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (split * NH > 1) {
-        v = part[0][t][lane];
-        for (int w2 = 1; w2 < split; ++w2) v += part[w2][t][lane];
+    sb_f32x4 v = acc[0][0], gt = acc[NW - 1][0];
+    if (split > 1) {
+        v = part[0][0][t][lane];
+        for (int w2 = 1; w2 < split; ++w2) v += part[w2][0][t][lane];
         if constexpr (EPI == EPI_GLU) {
-            gt = part[split][t][lane];
-            for (int w2 = 1; w2 < split; ++w2) gt += part[split + w2][t][lane];
+            gt = part[0][1][t][lane];
+            for (int w2 = 1; w2 < split; ++w2) gt += part[w2][1][t][lane];
         }
-    } else {
-#pragma unroll
-        for (int tt = 0; tt < RT; ++tt)
-            if (tt == t) v = acc[tt];
     }
     if (col >= g.N) return;
     // C/D layout of 16x16: column = lane & 15, row = 4 * (lane >> 4) + i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = m0 + 16 * t + 4 * kq + i;
-        if (row >= g.M) continue;
+        if (4 * kq + i >= rvalid || row >= g.M) continue;
         float o = v[i];
         if (g.bias) o = o + bias;
         if constexpr (EPI == EPI_RELU) {
@@ -157,184 +247,6 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
         if (g.out_bf16) reinterpret_cast<__bf16 *>(g.out)[(int64_t)row * g.ldo + col] = (__bf16)o;
         else g.out[(int64_t)row * g.ldo + col] = o;
     }
-}
-
-// The same product with the LayerNorm of its input rows folded in (GemmArgs::ln_g / ln_b / ln_eps): A = the UN-normalised fp32 rows x[M][K],
-// out = epi(bf16(LN(x)) W16^T + bias).  A streaming chunk is ~360 dependent launches of which 96 are LayerNorms over 32 rows -- ~5 us of
-// launch ramp each for a fraction of a microsecond of work; here the workgroup that needs the normalised rows derives their statistics itself:
-// every wave already holds its K slice of the rows in registers (two-pass mean / variance as the oracle's layer_norm: the slices' partial sums
-// meet in LDS, added in wave order), normalises with gamma / beta staged once per wave in LDS, rounds to bf16 and runs the product as above.
-// Slices of 256 k, one per wave: K = 256 * split, split <= 8 (GLU: 4) -- the d = 512 / 1024 rows of the streaming encoders.
-// (The exact fp32 streaming mode tried this in round 3 and lost: one WAVE per 16x16 tile re-derived the statistics of its rows over the
-//  whole K, 3-4 us on the dependent chain.  Here the statistics cost two LDS exchanges, the chain is 8 MFMAs.)
-template <int EPI, int RT>
-__global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_ln_kernel(GemmArgs g, int split /* = K / 256 waves per output tile */) {
-    constexpr int NH = (EPI == EPI_GLU) ? 2 : 1, STEPS = 8, SL = 32 * STEPS;
-    __shared__ sb_f32x4 part[kSbMaxWaves][RT][64];
-    __shared__ __attribute__((aligned(16))) float gam[kSbMaxWaves][SL], bet[kSbMaxWaves][SL];
-    __shared__ float st1[kSbMaxWaves][RT][16], st2[kSbMaxWaves][RT][16];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 15, kq = lane >> 4;
-    const int half = (NH == 2) ? wave / split : 0, ks = (NH == 2) ? wave % split : wave;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * RT);
-    const int k0 = ks * SL;
-
-    const int col = n0 + r;
-    float bias = 0.0f, bias_g = 0.0f, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (wave < RT && col < g.N) {
-        if (g.bias) {
-            bias = g.bias[col];
-            if constexpr (EPI == EPI_GLU) bias_g = g.bias[g.N + col];
-        }
-        if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = m0 + 16 * wave + 4 * kq + i;
-                if (row < g.M) res[i] = g.resid[(int64_t)row * g.ldr + col];
-            }
-        }
-    }
-
-    int wrow = n0 + r;
-    wrow = wrow < g.N ? wrow : g.N - 1;
-    const __bf16 *wp = reinterpret_cast<const __bf16 *>(g.W) + (int64_t)(half * g.N + wrow) * g.ldw + 8 * kq + k0;
-    float4 af[RT][STEPS][2];
-    sb_bf16x8 w[STEPS];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        int arow = m0 + 16 * t + r;
-        arow = arow < g.M ? arow : g.M - 1;
-        const float *ap = g.A + (int64_t)arow * g.lda + 8 * kq + k0;
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            af[t][s][0] = *reinterpret_cast<const float4 *>(ap + 32 * s);
-            af[t][s][1] = *reinterpret_cast<const float4 *>(ap + 32 * s + 4);
-        }
-    }
-    const float4 g4 = *reinterpret_cast<const float4 *>(g.ln_g + k0 + 4 * lane), b4 = *reinterpret_cast<const float4 *>(g.ln_b + k0 + 4 * lane);
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) w[s] = *reinterpret_cast<const sb_bf16x8 *>(wp + 32 * s);
-    __builtin_amdgcn_sched_barrier(0);
-    // gamma / beta of this wave's slice: wave-private LDS rows, read back after the barriers below
-    *reinterpret_cast<float4 *>(&gam[wave][4 * lane]) = g4;
-    *reinterpret_cast<float4 *>(&bet[wave][4 * lane]) = b4;
-
-    // LayerNorm statistics of the rows (oracle layer_norm: mean, then the mean of the squared deviations), two passes over the registers
-    const float inv_k = 1.0f / (float)g.K;
-    float mean[RT], rstd[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        float p = 0.0f;
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const float4 lo = af[t][s][0], hi = af[t][s][1];
-            p += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
-        }
-        p += __shfl_xor(p, 16);
-        p += __shfl_xor(p, 32);
-        if (kq == 0) st1[wave][t][r] = p;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        float sum = st1[half * split][t][r];
-        for (int w2 = 1; w2 < split; ++w2) sum += st1[half * split + w2][t][r];
-        mean[t] = sum * inv_k;
-        float p = 0.0f;
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const float4 lo = af[t][s][0], hi = af[t][s][1];
-            const float c0 = lo.x - mean[t], c1 = lo.y - mean[t], c2 = lo.z - mean[t], c3 = lo.w - mean[t];
-            const float c4 = hi.x - mean[t], c5 = hi.y - mean[t], c6 = hi.z - mean[t], c7 = hi.w - mean[t];
-            p += ((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) + ((c4 * c4 + c5 * c5) + (c6 * c6 + c7 * c7));
-        }
-        p += __shfl_xor(p, 16);
-        p += __shfl_xor(p, 32);
-        if (kq == 0) st2[wave][t][r] = p;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        float sum = st2[half * split][t][r];
-        for (int w2 = 1; w2 < split; ++w2) sum += st2[half * split + w2][t][r];
-        rstd[t] = 1.0f / sqrtf(sum * inv_k + g.ln_eps);
-    }
-
-    sb_f32x4 acc[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t] = sb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        const float4 gl = *reinterpret_cast<const float4 *>(&gam[wave][32 * s + 8 * kq]), gh = *reinterpret_cast<const float4 *>(&gam[wave][32 * s + 8 * kq + 4]);
-        const float4 bl = *reinterpret_cast<const float4 *>(&bet[wave][32 * s + 8 * kq]), bh = *reinterpret_cast<const float4 *>(&bet[wave][32 * s + 8 * kq + 4]);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const float4 lo = af[t][s][0], hi = af[t][s][1];
-            const float m = mean[t], rs = rstd[t];
-            sb_bf16x8 v;                                            // y = fma((x - mean) * rstd, gamma, beta), rounded to bf16 (RNE)
-            v[0] = (__bf16)fmaf((lo.x - m) * rs, gl.x, bl.x); v[1] = (__bf16)fmaf((lo.y - m) * rs, gl.y, bl.y);
-            v[2] = (__bf16)fmaf((lo.z - m) * rs, gl.z, bl.z); v[3] = (__bf16)fmaf((lo.w - m) * rs, gl.w, bl.w);
-            v[4] = (__bf16)fmaf((hi.x - m) * rs, gh.x, bh.x); v[5] = (__bf16)fmaf((hi.y - m) * rs, gh.y, bh.y);
-            v[6] = (__bf16)fmaf((hi.z - m) * rs, gh.z, bh.z); v[7] = (__bf16)fmaf((hi.w - m) * rs, gh.w, bh.w);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, w[s], acc[t], 0, 0, 0);
-        }
-    }
-
-    if (split * NH > 1) {
-#pragma unroll
-        for (int t = 0; t < RT; ++t) part[wave][t][lane] = acc[t];
-        __syncthreads();
-    }
-    if (wave >= RT) return;
-    const int t = wave;
-    sb_f32x4 v = acc[0], gt = sb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (split * NH > 1) {
-        v = part[0][t][lane];
-        for (int w2 = 1; w2 < split; ++w2) v += part[w2][t][lane];
-        if constexpr (EPI == EPI_GLU) {
-            gt = part[split][t][lane];
-            for (int w2 = 1; w2 < split; ++w2) gt += part[split + w2][t][lane];
-        }
-    }
-    if (col >= g.N) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + 16 * t + 4 * kq + i;
-        if (row >= g.M) continue;
-        float o = v[i];
-        if (g.bias) o = o + bias;
-        if constexpr (EPI == EPI_RELU) {
-            o = o > 0.0f ? o : 0.0f;
-        } else if constexpr (EPI == EPI_SILU) {
-            o = g.fast_act ? fast_siluf(o) : dsiluf(o);
-        } else if constexpr (EPI == EPI_RESID) {
-            const float y = o * g.alpha;
-            o = res[i] + y;
-        } else if constexpr (EPI == EPI_GLU) {
-            float gg = gt[i];
-            if (g.bias) gg = gg + bias_g;
-            o = o * (g.fast_act ? fast_sigmoidf(gg) : dsigmoidf(gg));
-        }
-        if (g.out_bf16) reinterpret_cast<__bf16 *>(g.out)[(int64_t)row * g.ldo + col] = (__bf16)o;
-        else g.out[(int64_t)row * g.ldo + col] = o;
-    }
-}
-
-bool gemm_smallm_bf16_ln_applies(const GemmArgs &a, int epi) {
-    if (!a.ln_g || !a.ln_b || a.a_bf16) return false;
-    if (!gemm_smallm_bf16_applies(a, epi)) return false;
-    const int split = a.K / 256, nh = epi == EPI_GLU ? 2 : 1;
-    if (split * nh > kSbMaxWaves) return false;
-    if (a.M > 16 && split * nh < 2) return false;                  // two row tiles are finished by two waves
-    return true;
-}
-
-template <int EPI>
-static void launch_sb_ln_epi(const GemmArgs &a, hipStream_t s) {
-    constexpr int NH = (EPI == EPI_GLU) ? 2 : 1;
-    const int split = a.K / 256;
-    if (a.M > 16) hipLaunchKernelGGL((gemm_smallm_bf16_ln_kernel<EPI, 2>), dim3((a.N + 15) / 16, (a.M + 31) / 32), dim3(64 * split * NH), 0, s, a, split);
-    else hipLaunchKernelGGL((gemm_smallm_bf16_ln_kernel<EPI, 1>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(64 * split * NH), 0, s, a, split);
 }
 
 // the shapes this kernel takes (everything else stays on the tile kernels of gemm_bf16.hpp)
@@ -344,46 +256,52 @@ bool gemm_smallm_bf16_applies(const GemmArgs &a, int epi) {
     if (a.out_bf16 && (epi == EPI_RESID || epi == EPI_GLU)) return false;
     return epi >= EPI_NONE && epi <= EPI_GLU;
 }
+bool gemm_smallm_bf16_ln_applies(const GemmArgs &a, int epi) {
+    if (!a.ln_g || !a.ln_b || a.a_bf16) return false;
+    if (!gemm_smallm_bf16_applies(a, epi)) return false;
+    return a.K / 256 <= kSbMaxWaves;                                // one slice of 256 k per wave
+}
 
-template <int EPI, int STEPS, int RT, bool A16>
+// rows per workgroup: the LARGEST of 32 (two MFMA row tiles per wave) / 16 / 8 that still gives (nearly) every CU a workgroup -- the bytes
+// all workgroups pull together are tiles * ceil(M / R) * 2 K (R + 16), least for the largest R, but a product costs what its busiest CU pulls
+// (header).  RT = 2 needs two waves to finish its two row tiles.
+static int sb_rows_per_wg(const GemmArgs &a, int nslices, bool glu) {
+    const int tiles = (a.N + 15) / 16;
+    // (GLU keeps one row tile per wave: two weight tiles AND two row tiles of fp32 rows do not fit 256 registers)
+    if (!glu && a.M > 16 && nslices >= 2 && tiles * ((a.M + 31) / 32) >= 192) return 32;
+    if (a.M > 8 && tiles * ((a.M + 15) / 16) >= 192) return 16;
+    return 8;
+}
+
+template <int EPI, int STEPS, bool A16, bool LN>
 static void launch_sb(const GemmArgs &a, hipStream_t s) {
-    constexpr int NH = (EPI == EPI_GLU) ? 2 : 1;
     const int nslices = a.K / (32 * STEPS);
-    int split = kSbMaxWaves / NH;
-    split = nslices < split ? nslices : split;
-    if (split * NH < RT) split = (RT + NH - 1) / NH;                // RT waves finish the tile (idle K slices are skipped by the slice loop)
-    const dim3 grid((a.N + 15) / 16, (a.M + 16 * RT - 1) / (16 * RT)), block(64 * split * NH);
-    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, RT, A16>), grid, block, 0, s, a, split);
+    const int split = nslices < kSbMaxWaves ? nslices : kSbMaxWaves;
+    const int R = sb_rows_per_wg(a, nslices, EPI == EPI_GLU);
+    const dim3 grid((a.N + 15) / 16, (a.M + R - 1) / R), block(64 * split);
+    if constexpr (EPI != EPI_GLU) {
+        if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN>), grid, block, 0, s, a, split, 16); return; }
+    }
+    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN>), grid, block, 0, s, a, split, R);
 }
 
 template <int EPI>
 static void launch_sb_epi(const GemmArgs &a, hipStream_t s) {
-    const bool two = a.M > 16;
-    if (a.a_bf16) {
-        // bf16 rows: 4 registers per MFMA operand -- slices of 512 k where that leaves at most kSbMaxWaves of them (fc2 of the 600M models: K = 4096)
-        constexpr int NH = (EPI == EPI_GLU) ? 2 : 1;
-        if (a.K % 512 == 0 && a.K / 256 > kSbMaxWaves / NH) {
-            if (two) launch_sb<EPI, 16, 2, true>(a, s); else launch_sb<EPI, 16, 1, true>(a, s);
-        } else {
-            if (two) launch_sb<EPI, 8, 2, true>(a, s); else launch_sb<EPI, 8, 1, true>(a, s);
+    if (a.ln_g) {                                                   // LayerNorm folded in (the caller checked gemm_smallm_bf16_ln_applies)
+        launch_sb<EPI, 8, false, true>(a, s);
+    } else if (a.a_bf16) {
+        // bf16 rows: 4 registers per MFMA operand -- slices of 512 k where 256 would leave more than kSbMaxWaves of them (fc2 of the 600M models:
+        // K = 4096); not for GLU (two weight tiles per wave)
+        if constexpr (EPI != EPI_GLU) {
+            if (a.K % 512 == 0 && a.K / 256 > kSbMaxWaves) { launch_sb<EPI, 16, true, false>(a, s); return; }
         }
+        launch_sb<EPI, 8, true, false>(a, s);
     } else {
-        if (two) launch_sb<EPI, 8, 2, false>(a, s); else launch_sb<EPI, 8, 1, false>(a, s);
+        launch_sb<EPI, 8, false, false>(a, s);
     }
 }
 
 void launch_gemm_smallm_bf16(const GemmArgs &a, int epi, hipStream_t s) {
-    if (a.ln_g) {                                                   // LayerNorm folded in (the caller checked gemm_smallm_bf16_ln_applies)
-        switch (epi) {
-        case EPI_NONE: launch_sb_ln_epi<EPI_NONE>(a, s); break;
-        case EPI_RELU: launch_sb_ln_epi<EPI_RELU>(a, s); break;
-        case EPI_SILU: launch_sb_ln_epi<EPI_SILU>(a, s); break;
-        case EPI_RESID: launch_sb_ln_epi<EPI_RESID>(a, s); break;
-        case EPI_GLU: launch_sb_ln_epi<EPI_GLU>(a, s); break;
-        default: break;
-        }
-        return;
-    }
     switch (epi) {
     case EPI_NONE: launch_sb_epi<EPI_NONE>(a, s); break;
     case EPI_RELU: launch_sb_epi<EPI_RELU>(a, s); break;

@@ -95,11 +95,13 @@ def test_bf16_glds_gemm_against_float64(M, N, K, epi):
                                            (32, 1024, 1024, "resid", False), (32, 1024, 1024, "glu", True), (16, 640, 1024, "none", False),
                                            (33, 512, 2048, "resid", True), (100, 1024, 4352, "none", False), (7, 2048, 512, "silu", True),
                                            (32, 1030, 256, "relu", False), (64, 512, 512, "glu", False), (2, 4096, 1024, "silu", False),
-                                           (128, 1024, 4096, "resid", True), (20, 512, 256, "glu", True)])
+                                           (128, 1024, 4096, "resid", True), (20, 512, 256, "glu", True),
+                                           (32, 2048, 1024, "silu", True), (20, 3200, 256, "none", False), (32, 1024, 1024, "glu", False)])
 def test_bf16_smallm_gemm_against_float64(M, N, K, epi, a16):
     """The weight-stream kernel for a handful of rows (kernels/gemm_smallm_bf16.hip: the streaming chunks of the tolerance-class mode; M <= 128,
     K % 256 == 0): one and two row tiles per wave, several row groups, K slices of 256 / 512 k over 1..8 waves (and more slices than waves:
-    K = 4352, the subsampling projection), fp32 and bf16 activations, every epilogue, ragged N -- against float64 of the same rounded operands."""
+    K = 4352, the subsampling projection), 32 / 16 / 8 rows per workgroup, fp32 and bf16 activations, every epilogue, ragged N -- against float64
+    of the same rounded operands."""
     from parakeet_cpp_amd import capi
     rng = np.random.default_rng(11 * M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
