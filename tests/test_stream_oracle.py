@@ -61,3 +61,37 @@ def test_stream_decode_carries_state(orc):
     if (np.diff(np.r_[whole["start"], 40]) <= 1).all() and (whole["end"] - whole["start"] <= 0).all():
         assert ids == whole["ids"].tolist() and starts == whole["start"].tolist()
     assert starts == sorted(starts) and all(0 <= s < 40 for s in starts)
+
+
+def test_stream_oracle_bf16_mode_rounds_every_product(orc):
+    """The tolerance-class mode of the streaming path (orc_config.gemm_bf16; the specification of kernels/gemm_smallm_bf16.hip): every Linear /
+    1x1-conv product of a chunk -- subsampling, ffn, q / k / v / out, pointwise convs -- takes operands rounded to bf16; checked against an
+    independent restatement: the torch stream with every weight matrix pre-rounded to bf16 is NOT the same thing (activations are rounded too),
+    so the check here is structural: the mode deviates from fp32 at bf16-epsilon class (not less: some product left unrounded would show a
+    much smaller gap; not more), state carried over 12 chunks, and the decode's per-decision records equal its tokens."""
+    import dataclasses
+    cfg = dataclasses.replace(pk.make_110m_config(), num_layers=2, name="110m-2L-bf16-stream")
+    W = synth.synth_weights(cfg, seed=42)
+    f32 = orc.Stream(orc.Model(cfg, W), 70, 1)
+    b16 = orc.Stream(orc.Model(dataclasses.replace(cfg, gemm_bf16=True), W), 70, 1)
+    pcm = synth.synth_pcm(1, 2560 * 12, seed=77)[0]
+    gaps, n_tok = [], 0
+    for i in range(12):
+        seg = pcm[i * 2560:(i + 1) * 2560]
+        m1, m2 = f32.mel(seg), b16.mel(seg)
+        assert np.array_equal(m1.view(np.uint32), m2.view(np.uint32)), "the log-mel front end has no product in it: identical in both modes"
+        if m1.shape[0] == 0:
+            continue
+        e1, e2 = f32.encode(m1), b16.encode(m2)
+        assert e1.shape == e2.shape
+        if e1.shape[0] == 0:
+            continue
+        gaps.append(float(np.abs(e1 - e2).mean() / np.abs(e1).max()))
+        r = b16.decode(e2, margins=True)
+        lab = [int(k) for k in r["step_label"] if k != cfg.blank_id]
+        assert lab == r["ids"].tolist(), "the per-decision labels (blank dropped) are the chunk's tokens"
+        assert len(r["step_margin"]) == len(r["step_label"]) and (r["step_margin"] >= 0).all()
+        n_tok += len(r["ids"])
+        f32.decode(e1)
+    assert len(gaps) >= 8 and n_tok > 0
+    assert 2e-4 < max(gaps) < 1e-2, f"bf16-vs-fp32 gap of the oracle's stream: {max(gaps):.2e} of max|x| (bf16 epsilon class expected)"
