@@ -50,10 +50,14 @@ def main():
             toks += int(r["lens"].sum())
     lat = np.array(lat)
     chunk_s = n / 16000.0
+    # bytes of encoder product weights one chunk streams (every Linear / 1x1-conv of every block, read once per chunk: 1.2 / 2.4 GB for the 600M models)
+    d, f, L = cfg.hidden_size, cfg.ffn_intermediate, cfg.num_layers
+    wbytes = L * (4 * d * f + 7 * d * d) * (2 if a.bf16 else 4)
     out = {"metric": f"streaming {a.config}: per-chunk latency and aggregate RTFx, {a.streams} lock-step streams/GPU, att_context_right={a.latency_frames}",
            "streams": a.streams, "chunk_ms": chunk_s * 1e3, "latency_ms_median": round(float(np.median(lat)) * 1e3, 3),
            "latency_ms_p95": round(float(np.percentile(lat, 95)) * 1e3, 3), "latency_ms_mean": round(float(lat.mean()) * 1e3, 3),
-           "aggregate_rtfx": round(a.streams * chunk_s / float(lat.mean()), 1), "tokens_emitted": toks, "chunks": a.chunks,
+           "aggregate_rtfx": round(a.streams * chunk_s / float(lat.mean()), 1),
+           "encoder_weight_mbytes_per_chunk": round(wbytes / 1e6, 1), "weight_stream_tbps": round(wbytes / float(np.median(lat)) / 1e12, 3), "tokens_emitted": toks, "chunks": a.chunks,
            "dtype": "bf16 operands / f32 accumulate (tolerance-class mode)" if a.bf16 else "f32", "data": "synthetic"}
     print(json.dumps(out))
     st.close(); m.close()
