@@ -222,3 +222,18 @@ def test_bf16_600m_two_layer_cut_vs_bf16_oracle(tmp_path_factory, orc):
     g, o = gm.tdt_decode(enc), om.tdt_greedy(oenc)
     assert agreement(g["ids"][0, : g["lens"][0]].tolist(), o["ids"][0, : o["lens"][0]].tolist()) >= 0.95
     assert o["lens"][0] > 5
+
+
+def test_bf16_short_clip_runs_the_smallm_products(tmp_path_factory, orc):
+    """One 10 s clip in the bf16 mode is 126 encoder rows: since round 4 its Linear products (K % 256 == 0, M <= 128) run on the small-M bf16 kernel
+    (kernels/gemm_smallm_bf16.hip: bf16 activation rows in, bf16 qkv rows out for the bf16 attention) instead of the 64 x 64 tile kernel.  Same
+    specification, same bounds as the 30 s test above."""
+    cfg = dataclasses.replace(pk.make_tdt_600m_config(), num_layers=2, gemm_bf16=True, name="tdt-600m-2L-bf16")
+    W, om, gm = G.make_pair(tmp_path_factory.mktemp("b2s"), cfg, seed=7)
+    pcm = synth.synth_pcm(1, 160000, seed=99)
+    feats = gm.mel(pcm)
+    enc, oenc = gm.encode(feats), om.encoder(feats)
+    assert enc.shape == (1, 126, 1024)
+    close(enc, oenc, "600m 2-layer cut, 10 s clip")
+    g, o = gm.tdt_decode(enc), om.tdt_greedy(oenc)
+    assert agreement(g["ids"][0, : g["lens"][0]].tolist(), o["ids"][0, : o["lens"][0]].tolist()) >= 0.95
