@@ -9,6 +9,14 @@
 
 namespace pk {
 
+// Phase stamps for tools/ubench/stream_att_bench.cpp (-DSA_TRACE): shader clock of lane 0 of every wave at the phase boundaries.  Production: nothing.
+#ifdef SA_TRACE
+__device__ long long *sa_trace;     // [workgroup][wave][8]
+#define SA_STAMP(i) do { if (sa_trace && (threadIdx.x & 63) == 0) sa_trace[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 6)) * 8 + (i)] = clock64(); } while (0)
+#else
+#define SA_STAMP(i) do { } while (0)
+#endif
+
 // Blocks (stream * head, query row i < c): the attention of that row.  Blocks with blockIdx.y == c (when cache_k_out is set): the cache
 // rotation of (stream, head) -- new cache = the last `keep` rows of [cache ; this chunk's k / v] (:193-209) written into the OTHER cache
 // buffer, so it runs beside the attention blocks that still read the old one: one launch instead of three per layer.
@@ -36,6 +44,7 @@ __global__ __launch_bounds__(128) void stream_attention_kernel(const float *__re
         }
         return;
     }
+    SA_STAMP(0);
     float *qu = sm, *qv = sm + hd, *pr = sm + 2 * hd, *red = pr + kv;
     const float *qrow = qkv + ((int64_t)sidx * c + i) * 3 * d + h * hd;
     for (int e = tid; e < hd; e += nthr) {
@@ -44,6 +53,7 @@ __global__ __launch_bounds__(128) void stream_attention_kernel(const float *__re
         qv[e] = q + bias_v[h * hd + e];
     }
     __syncthreads();
+    SA_STAMP(1);                                                    // q + biases in LDS
     auto krow = [&](int j) {                                        // key j: cached rows first, then this chunk's rows (:186-189)
         return j < nc ? kcache + ((int64_t)sidx * cache_rows + j) * d + h * hd : qkv + ((int64_t)sidx * c + (j - nc)) * 3 * d + d + h * hd;
     };
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(128) void stream_attention_kernel(const float *__re
         pr[j] = sc;
         m = fmaxf(m, sc);
     }
+    SA_STAMP(2);                                                    // score chains of this wave's keys
     m = wave_max64(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
@@ -99,6 +110,7 @@ __global__ __launch_bounds__(128) void stream_attention_kernel(const float *__re
     __syncthreads();                                                // (both waves have read the exponentials)
     for (int j = tid; j < kv; j += nthr) pr[j] = pr[j] / sum;
     __syncthreads();
+    SA_STAMP(3);                                                    // softmax
     for (int eb = 0; eb < hd; eb += 2 * nthr) {                     // softmax(S) V, k = key index in natural order (:250); two output columns per thread
         const int e0 = eb + tid, e1 = eb + nthr + tid;
         const bool h0 = e0 < hd, h1 = e1 < hd;
@@ -141,9 +153,147 @@ __global__ __launch_bounds__(128) void stream_attention_kernel(const float *__re
             const int col = h * hd + e;
             ctx[((int64_t)sidx * c + i) * d + (ctx_sigma ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = acc;
         };
+        SA_STAMP(4);                                                // value rows loaded, chains done
         if (h0) put(e0, acc0);
         if (h1) put(e1, acc1);
     }
+    SA_STAMP(5);
+}
+
+// The same attention for the steady state of a streaming session (a 70-row cache + the chunk: kv <= kSaKv keys, head size 64 / 128) with the
+// key and position tiles staged through LDS.  The kernel above lets every lane walk its own key row with 16-byte loads: one load instruction
+// touches 64 different 128-byte lines and needs the seven instructions after it to use them up, two tiles x two waves of that is the whole
+// 32 KB L1 -- the phase stamps (tools/ubench/stream_att_bench.cpp) show six dependent round trips per launch (q, two batches of key / position
+// rows, three of value rows: 11 of the launch's 14 us).  Here everything a workgroup reads is requested in ONE round trip before anything
+// waits: the key / position tiles COALESCED (32 lanes per 512-byte row, four waves: 10 sixteen-byte loads per lane and tile) into registers
+// and on into LDS at a pitch of hd + 4 floats (row-per-lane ds_read_b128 then hits 16 distinct bank groups: conflict-free), the value column
+// of every output feature into registers.  The chains read their operands from LDS instead of L1: same products, same order, same bits.
+constexpr int kSaKv = 80, kSaNew = 8;    // keys (cache + chunk) / rows of the chunk the LDS-tile form takes
+// (amdgpu_waves_per_eu(1, 2): without it the scheduler protects an occupancy nobody needs -- 384 workgroups on 256 CUs -- by holding the
+//  loads back until registers free up, i.e. by serialising exactly the round trips this kernel exists to merge)
+template <int HD4 /* head size / 4: 16 or 32 */>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void stream_attention_tiles_kernel(const float *__restrict__ qkv, const float *__restrict__ kcache,
+                                                                     const float *__restrict__ vcache, int cache_rows, int c, int nc, int d, int H,
+                                                                     const float *__restrict__ pos, int P, const float *__restrict__ bias_u,
+                                                                     const float *__restrict__ bias_v, int att_left, int att_right, float scale,
+                                                                     float *__restrict__ ctx, float *__restrict__ cache_k_out,
+                                                                     float *__restrict__ cache_v_out, int keep, int ctx_sigma) {
+    constexpr int HD = 4 * HD4, PITCH = HD + 4, NT = 256, TR = (kSaKv * HD4 + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // [HD] q+u, [HD] q+v, [kSaKv] probabilities, [8] wave maxima, K tile [kv + 1][PITCH], P tile [kv + 1][PITCH]
+    const int kv = nc + c;
+    const int sidx = blockIdx.x / H, h = blockIdx.x % H, i = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (i == c) {                                                   // cache rotation of this (stream, head), as in stream_attention_kernel
+        for (int idx = tid; idx < keep * HD4; idx += NT) {
+            const int r = idx / HD4, e4 = idx % HD4, j = kv - keep + r;
+            const int64_t src_c = ((int64_t)sidx * cache_rows + j) * d + h * HD + 4 * e4;
+            const int64_t src_n = ((int64_t)sidx * c + (j - nc)) * 3 * d + h * HD + 4 * e4;
+            const int64_t dst = ((int64_t)sidx * cache_rows + r) * d + h * HD + 4 * e4;
+            *reinterpret_cast<float4 *>(cache_k_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(kcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + d);
+            *reinterpret_cast<float4 *>(cache_v_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(vcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + 2 * d);
+        }
+        return;
+    }
+    SA_STAMP(0);
+    float *qu = sm, *qv = sm + HD, *pr = sm + 2 * HD, *red = pr + kSaKv, *Kt = red + 8, *Pt = Kt + (kv + 1) * PITCH;   // (tiles of kv rows + one spare)
+    const int off = P > kv ? P - kv : 0;                            // rightmost kv columns of the position scores, NOT rel-shifted (:215-224)
+    const int abs_pos = kv - c + i;
+    // ---- every global read of the workgroup, requested before anything waits.  No branch and no pointer select around a load (either makes
+    // the compiler drain the queue at every one of them): the cached rows (keys 0 .. nc - 1, :186-189) come from the caches with the row index
+    // clamped, the chunk's own c <= kSaNew rows from qkv by the first c * HD4 lanes; what was read past the end is never stored / used ----
+    // (addresses as a workgroup-uniform base + a 32-bit byte offset per lane: the `saddr` form of global_load needs no 64-bit lane arithmetic --
+    //  with it the allocator recycled load destinations as address temporaries and the loads waited on each other)
+    auto ld1 = [](const float *base, unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); };
+    auto ld4 = [](const float *base, unsigned byte_off) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off); };
+    const int qe = tid < HD ? tid : 0;
+    const float *kbase = kcache + (int64_t)sidx * cache_rows * d + h * HD, *vbase = vcache + (int64_t)sidx * cache_rows * d + h * HD;
+    const float *nbase = qkv + (int64_t)sidx * c * 3 * d + h * HD;  // row u of the chunk: + u * 3 d (+ d: k, + 2 d: v)
+    const float *pbase = pos + (int64_t)off * d + h * HD;
+    const int nc1 = nc > 0 ? nc - 1 : 0;
+    const int r0 = tid / HD4, c4 = tid % HD4;                       // tile element of load u: row r0 + (NT / HD4) u, float4 column c4
+    float4 kreg[TR], preg[TR];
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+        const int row = r0 + (NT / HD4) * u;
+        kreg[u] = ld4(kbase, (unsigned)((row < nc ? row : nc1) * d + 4 * c4) * 4u);
+        preg[u] = ld4(pbase, (unsigned)((row < kv ? row : kv - 1) * d + 4 * c4) * 4u);
+    }
+    const int tn = tid < c * HD4 ? tid : c * HD4 - 1;               // (c <= kSaNew = 8: c * HD4 <= 256 lanes)
+    const float4 knew = ld4(nbase, (unsigned)((tn / HD4) * 3 * d + d + 4 * (tn % HD4)) * 4u);
+    __builtin_amdgcn_sched_barrier(0);                              // (key / position tiles first: the scores wait for them)
+    // the value tile the same way (it takes the key tile's place in LDS once the scores are done: 35 loads per lane in all -- a wave's
+    // load counter holds 63, a column of 72 four-byte loads per lane does not fit beside the tiles)
+    float4 vreg[TR];
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+        const int row = r0 + (NT / HD4) * u;
+        vreg[u] = ld4(vbase, (unsigned)((row < nc ? row : nc1) * d + 4 * c4) * 4u);
+    }
+    const float4 vnew = ld4(nbase, (unsigned)((tn / HD4) * 3 * d + 2 * d + 4 * (tn % HD4)) * 4u);
+    const float q = ld1(nbase, (unsigned)(i * 3 * d + qe) * 4u), bu = ld1(bias_u + h * HD, (unsigned)qe * 4u), bv = ld1(bias_v + h * HD, (unsigned)qe * 4u);
+    __builtin_amdgcn_sched_barrier(0);
+    // (one basic block from the first load to the barrier: a branch in between lets the loads sink to their stores, one round trip each.
+    //  Lanes past the head size repeat lane 0's element: the same value to the same address)
+    qu[qe] = q + bu;                                                // :209-212
+    qv[qe] = q + bv;
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+        const int row = r0 + (NT / HD4) * u;
+        // (unconditional stores -- a store under a condition pulls its load in with it: what was read past the end goes to the spare row kv)
+        *reinterpret_cast<float4 *>(Kt + (row < nc ? row : kv) * PITCH + 4 * c4) = kreg[u];
+        *reinterpret_cast<float4 *>(Pt + (row < kv ? row : kv) * PITCH + 4 * c4) = preg[u];
+    }
+    *reinterpret_cast<float4 *>(Kt + (tid < c * HD4 ? nc + tid / HD4 : kv) * PITCH + 4 * (tid % HD4)) = knew;
+    __syncthreads();
+    SA_STAMP(1);                                                    // operands in LDS
+    float m = -__builtin_huge_valf();
+    if (tid < kv) {                                                 // one key per lane (kv <= kSaKv < 256); the two chains stay sequential in e
+        const int j = tid;
+        const float4 *kr = reinterpret_cast<const float4 *>(Kt + j * PITCH), *pp = reinterpret_cast<const float4 *>(Pt + j * PITCH);
+        const float4 *qu4 = reinterpret_cast<const float4 *>(qu), *qv4 = reinterpret_cast<const float4 *>(qv);
+        float cs = 0.0f, ps = 0.0f;
+#pragma unroll 8
+        for (int e = 0; e < HD4; ++e) {
+            const float4 kk = kr[e], p4 = pp[e], a = qu4[e], bq = qv4[e];
+            cs = __builtin_fmaf(a.x, kk.x, cs); cs = __builtin_fmaf(a.y, kk.y, cs); cs = __builtin_fmaf(a.z, kk.z, cs); cs = __builtin_fmaf(a.w, kk.w, cs);
+            ps = __builtin_fmaf(bq.x, p4.x, ps); ps = __builtin_fmaf(bq.y, p4.y, ps); ps = __builtin_fmaf(bq.z, p4.z, ps); ps = __builtin_fmaf(bq.w, p4.w, ps);
+        }
+        float sc = (cs + ps) * scale;                               // :226
+        const int dist = abs_pos - j;
+        if ((att_left >= 0 || att_right >= 0) && (dist > att_left || -dist > att_right)) sc = -1e9f;   // masked_fill :231-247
+        pr[j] = sc;
+        m = sc;
+    }
+    SA_STAMP(2);                                                    // score chains
+    m = wave_max64(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    // every score chain is done: the value tile takes the key tile's place (published by the barriers of the softmax below)
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+        const int row = r0 + (NT / HD4) * u;
+        *reinterpret_cast<float4 *>(Kt + (row < nc ? row : kv) * PITCH + 4 * c4) = vreg[u];
+    }
+    *reinterpret_cast<float4 *>(Kt + (tid < c * HD4 ? nc + tid / HD4 : kv) * PITCH + 4 * (tid % HD4)) = vnew;
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));        // (waves without keys contribute -inf: the maximum of the same set)
+    for (int j = tid; j < kv; j += NT) pr[j] = dexpf_nonpos(pr[j] - m);
+    __syncthreads();
+    // the canonical sum (lane l adds elements l, l + 64, ... in index order, then the xor butterfly), by every wave for itself
+    float p = 0.0f;
+    for (int j = lane; j < kv; j += 64) p = p + pr[j];
+    const float sum = wave_sum64(p);
+    __syncthreads();                                                // (every wave has read the exponentials)
+    for (int j = tid; j < kv; j += NT) pr[j] = pr[j] / sum;
+    __syncthreads();
+    SA_STAMP(3);                                                    // softmax
+    if (tid < HD) {                                                 // softmax(S) V on the prefetched column, k = key index in natural order (:250)
+        float acc = 0.0f;
+        for (int u = 0; u < kv; ++u) acc = __builtin_fmaf(pr[u], Kt[u * PITCH + tid], acc);    // (the value tile; consecutive lanes, consecutive banks)
+        const int col = h * HD + tid;
+        ctx[((int64_t)sidx * c + i) * d + (ctx_sigma ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = acc;
+    }
+    SA_STAMP(4);
+    SA_STAMP(5);
 }
 
 void launch_stream_attention(const float *qkv_new, const float *kcache, const float *vcache, int cache_rows, int S, int c, int nc, int d,
@@ -159,6 +309,19 @@ void launch_stream_attention(const float *qkv_new, const float *kcache, const fl
     const size_t lds = (size_t)(2 * hd + nc + c + 2) * sizeof(float);
     const int kv = nc + c, keep = kv > keep_max ? keep_max : kv;
     const bool rotate = cache_k_out && cache_v_out && keep > 0;
+    if (kv <= kSaKv && c <= kSaNew && (hd == 128 || hd == 64)) {    // steady state of a session: the LDS-tile form
+        const size_t lds_t = (size_t)(2 * hd + kSaKv + 8 + 2 * (kv + 1) * (hd + 4)) * sizeof(float);
+        const dim3 grid(S * n_heads, c + (rotate ? 1 : 0));
+#define PK_SAT_LAUNCH(HD4V) do { \
+            static DynLdsSlots slots; \
+            ensure_dyn_lds(slots, reinterpret_cast<const void *>(&stream_attention_tiles_kernel<HD4V>), (size_t)(2 * hd + kSaKv + 8 + 2 * (kSaKv + 1) * (hd + 4)) * sizeof(float)); \
+            hipLaunchKernelGGL((stream_attention_tiles_kernel<HD4V>), grid, dim3(256), lds_t, s, qkv_new, kcache, vcache, cache_rows, c, nc, d, n_heads, pos, P, bias_u, \
+                               bias_v, att_left, att_right, scale, ctx, rotate ? cache_k_out : nullptr, rotate ? cache_v_out : nullptr, keep, ctx_sigma); \
+        } while (0)
+        if (hd == 128) PK_SAT_LAUNCH(32); else PK_SAT_LAUNCH(16);
+#undef PK_SAT_LAUNCH
+        return;
+    }
     hipLaunchKernelGGL(stream_attention_kernel, dim3(S * n_heads, c + (rotate ? 1 : 0)), dim3(kv > 64 ? 128 : 64), lds, s, qkv_new, kcache, vcache, cache_rows, c, nc, d,
                        n_heads, pos, P, bias_u, bias_v, att_left, att_right, scale, ctx, rotate ? cache_k_out : nullptr, rotate ? cache_v_out : nullptr, keep, ctx_sigma);
 }
