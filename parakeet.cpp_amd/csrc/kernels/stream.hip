@@ -12,7 +12,7 @@ namespace pk {
 // Phase stamps for tools/ubench/stream_att_bench.cpp (-DSA_TRACE): shader clock of lane 0 of every wave at the phase boundaries.  Production: nothing.
 #ifdef SA_TRACE
 __device__ long long *sa_trace;     // [workgroup][wave][8]
-#define SA_STAMP(i) do { if (sa_trace && (threadIdx.x & 63) == 0) sa_trace[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 6)) * 8 + (i)] = clock64(); } while (0)
+#define SA_STAMP(i) do { if (sa_trace && (threadIdx.x & 63) == 0 && threadIdx.x < 128) sa_trace[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 + (threadIdx.x >> 6)) * 8 + (i)] = clock64(); } while (0)
 #else
 #define SA_STAMP(i) do { } while (0)
 #endif
