@@ -17,6 +17,22 @@ __device__ long long *sa_trace;     // [workgroup][wave][8]
 #define SA_STAMP(i) do { } while (0)
 #endif
 
+// new cache of (stream, head) = the last `keep` rows of [cache ; this chunk's k / v] (:193-209): row r <- row nc + c - keep + r, written into the
+// OTHER cache buffer (the attention blocks of the same launch still read the old one)
+__device__ __forceinline__ void stream_cache_rotate(const float *__restrict__ qkv, const float *__restrict__ kcache, const float *__restrict__ vcache,
+                                                    int cache_rows, int c, int nc, int d, int hd, int sidx, int h, int keep,
+                                                    float *__restrict__ cache_k_out, float *__restrict__ cache_v_out, int tid, int nthr) {
+    const int hd4 = hd / 4, kv = nc + c;
+    for (int idx = tid; idx < keep * hd4; idx += nthr) {
+        const int r = idx / hd4, e4 = idx % hd4, j = kv - keep + r;
+        const int64_t src_c = ((int64_t)sidx * cache_rows + j) * d + h * hd + 4 * e4;
+        const int64_t src_n = ((int64_t)sidx * c + (j - nc)) * 3 * d + h * hd + 4 * e4;
+        const int64_t dst = ((int64_t)sidx * cache_rows + r) * d + h * hd + 4 * e4;
+        *reinterpret_cast<float4 *>(cache_k_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(kcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + d);
+        *reinterpret_cast<float4 *>(cache_v_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(vcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + 2 * d);
+    }
+}
+
 // Blocks (stream * head, query row i < c): the attention of that row.  Blocks with blockIdx.y == c (when cache_k_out is set): the cache
 // rotation of (stream, head) -- new cache = the last `keep` rows of [cache ; this chunk's k / v] (:193-209) written into the OTHER cache
 // buffer, so it runs beside the attention blocks that still read the old one: one launch instead of three per layer.
@@ -32,16 +48,8 @@ __global__ __launch_bounds__(128) void stream_attention_kernel(const float *__re
     // one or two wavefronts (launcher: two when there are more than 64 keys -- a 70-row cache + the chunk: both halves of the key range run
     // their score chains side by side instead of one after the other)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
-    if (i == c) {                                                   // cache rotation of this (stream, head): rows r <- row nc + c - keep + r of [cache ; new]
-        const int hd4 = hd / 4;
-        for (int idx = tid; idx < keep * hd4; idx += nthr) {
-            const int r = idx / hd4, e4 = idx % hd4, j = kv - keep + r;
-            const int64_t src_c = ((int64_t)sidx * cache_rows + j) * d + h * hd + 4 * e4;
-            const int64_t src_n = ((int64_t)sidx * c + (j - nc)) * 3 * d + h * hd + 4 * e4;
-            const int64_t dst = ((int64_t)sidx * cache_rows + r) * d + h * hd + 4 * e4;
-            *reinterpret_cast<float4 *>(cache_k_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(kcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + d);
-            *reinterpret_cast<float4 *>(cache_v_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(vcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + 2 * d);
-        }
+    if (i == c) {                                                   // cache rotation of this (stream, head)
+        stream_cache_rotate(qkv, kcache, vcache, cache_rows, c, nc, d, hd, sidx, h, keep, cache_k_out, cache_v_out, tid, nthr);
         return;
     }
     SA_STAMP(0);
@@ -183,15 +191,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int kv = nc + c;
     const int sidx = blockIdx.x / H, h = blockIdx.x % H, i = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (i == c) {                                                   // cache rotation of this (stream, head), as in stream_attention_kernel
-        for (int idx = tid; idx < keep * HD4; idx += NT) {
-            const int r = idx / HD4, e4 = idx % HD4, j = kv - keep + r;
-            const int64_t src_c = ((int64_t)sidx * cache_rows + j) * d + h * HD + 4 * e4;
-            const int64_t src_n = ((int64_t)sidx * c + (j - nc)) * 3 * d + h * HD + 4 * e4;
-            const int64_t dst = ((int64_t)sidx * cache_rows + r) * d + h * HD + 4 * e4;
-            *reinterpret_cast<float4 *>(cache_k_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(kcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + d);
-            *reinterpret_cast<float4 *>(cache_v_out + dst) = j < nc ? *reinterpret_cast<const float4 *>(vcache + src_c) : *reinterpret_cast<const float4 *>(qkv + src_n + 2 * d);
-        }
+    if (i == c) {                                                   // cache rotation of this (stream, head)
+        stream_cache_rotate(qkv, kcache, vcache, cache_rows, c, nc, d, HD, sidx, h, keep, cache_k_out, cache_v_out, tid, NT);
         return;
     }
     SA_STAMP(0);
