@@ -54,6 +54,17 @@ def test_stream_stages_tiny(tmp_path_factory, orc, left, right, chunk):
     assert n_enc >= 10
 
 
+@pytest.mark.parametrize("left,right,chunk", [(70, 1, 4000), (10, 0, 5600), (6, 2, 1600), (70, 3, 10240)])
+def test_stream_stages_head64_chunk_shapes(tmp_path_factory, orc, left, right, chunk):
+    """The LDS-tile form of the cached attention (kernels/stream.hip: stream_attention_tiles_kernel, head size 64 here) over the chunk shapes a
+    session can produce: 1 .. 8 new frames per chunk (c varies from push to push when the chunk is not a multiple of 8 mel frames), an empty,
+    a filling and a full cache, short and long left contexts -- stage by stage, bit for bit against the oracle."""
+    cfg = dataclasses.replace(pk.make_110m_config(), num_layers=2, name="110m-2L-stream")
+    W, om, gm = G.make_pair(tmp_path_factory.mktemp("s110c"), cfg, seed=42)
+    n_enc, n_tok = run_pair(om, gm, orc, 3, left, right, chunk, 12, seed=left + chunk)
+    assert n_enc >= 12
+
+
 def test_stream_push_equals_stages_and_emits(tmp_path_factory, orc):
     """pk_stream_push (device-resident mel -> encoder -> decode) == the oracle's push; 2-layer cut of the 110M architecture so that
     the decoder actually emits tokens; 4 streams with different audio."""
