@@ -345,7 +345,10 @@ void launch_stream_cache_update(const float *cache_in, int nc, const float *qkv_
                        keep, cache_out, n);
 }
 
-template <int KC>
+// One thread per (stream, channel).  Everything the thread reads -- its column of [cache ; g] (KC - 1 + c values), the KC taps, bias and the four
+// BatchNorm parameters -- is requested in ONE round trip (the first version walked the frames one by one: a dependent round trip per frame and one
+// more for the cache copy; c <= CMAX, longer chunks take the frame loop below).  Same taps in the same order: same bits.
+template <int KC, int CMAX>
 __global__ void stream_dwconv_kernel(const float *__restrict__ g, const float *__restrict__ cache_in, int has_cache, int c, int d,
                                      const float *__restrict__ w /*[KC][d]*/, const float *__restrict__ bias, const float *__restrict__ bn_mean,
                                      const float *__restrict__ bn_rstd, const float *__restrict__ bn_g, const float *__restrict__ bn_b,
@@ -354,6 +357,43 @@ __global__ void stream_dwconv_kernel(const float *__restrict__ g, const float *_
     if (idx >= n) return;
     const int ch = (int)(idx % d), sidx = (int)(idx / d);
     constexpr int CL = KC - 1;
+    const int ocol = out_sigma ? ((ch & ~15) | ((ch & 3) << 2) | ((ch >> 2) & 3)) : ch;
+    if (c <= CMAX) {
+        // (no branch around a load: clamped indices, the first chunk's zero left padding (:55-63) applied after the loads)
+        float cat[CL + CMAX], wk[KC];
+#pragma unroll
+        for (int r = 0; r < CL; ++r) cat[r] = cache_in[((int64_t)sidx * CL + r) * d + ch];
+#pragma unroll
+        for (int t = 0; t < CMAX; ++t) cat[CL + t] = g[((int64_t)sidx * c + (t < c ? t : c - 1)) * d + ch];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) wk[kk] = w[kk * d + ch];
+        const float bs = bias[ch], mu = bn_mean[ch], rs = bn_rstd[ch], bg = bn_g[ch], bb = bn_b[ch];
+        if (!has_cache) {
+#pragma unroll
+            for (int r = 0; r < CL; ++r) cat[r] = 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < CMAX; ++t) {
+            if (t < c) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk) acc = __builtin_fmaf(wk[kk], cat[t + kk], acc);      // depthwise, no padding (:71)
+                float v = acc + bs;
+                v = __builtin_fmaf((v - mu) * rs, bg, bb);
+                out[((int64_t)sidx * c + t) * d + ocol] = dsiluf(v);
+            }
+        }
+        // last KC - 1 rows of the concatenation (:66-69): rows c .. c + CL - 1
+#pragma unroll
+        for (int r = 0; r < CL; ++r) {
+            float keep = cat[r];
+#pragma unroll
+            for (int t = 1; t <= CMAX; ++t)
+                if (t == c) keep = cat[r + t];
+            cache_out[((int64_t)sidx * CL + r) * d + ch] = keep;
+        }
+        return;
+    }
     auto cat = [&](int r) {                                         // row r of [cache(CL rows) ; g(c rows)]
         if (r < CL) return has_cache ? cache_in[((int64_t)sidx * CL + r) * d + ch] : 0.0f;   // first chunk: zero left padding (:55-63)
         return g[((int64_t)sidx * c + (r - CL)) * d + ch];
@@ -364,7 +404,7 @@ __global__ void stream_dwconv_kernel(const float *__restrict__ g, const float *_
         for (int kk = 0; kk < KC; ++kk) acc = __builtin_fmaf(w[kk * d + ch], cat(t + kk), acc);      // depthwise, no padding (:71)
         float v = acc + bias[ch];
         v = __builtin_fmaf((v - bn_mean[ch]) * bn_rstd[ch], bn_g[ch], bn_b[ch]);
-        out[((int64_t)sidx * c + t) * d + (out_sigma ? ((ch & ~15) | ((ch & 3) << 2) | ((ch >> 2) & 3)) : ch)] = dsiluf(v);
+        out[((int64_t)sidx * c + t) * d + ocol] = dsiluf(v);
     }
     float keep[CL];
 #pragma unroll
@@ -377,8 +417,8 @@ void launch_stream_dwconv(const float *g, const float *cache_in, int has_cache, 
                           hipStream_t s, int out_sigma) {
     const int64_t n = (int64_t)S * d;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (kc == 9) hipLaunchKernelGGL(stream_dwconv_kernel<9>, grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n, out_sigma);
-    else if (kc == 31) hipLaunchKernelGGL(stream_dwconv_kernel<31>, grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n, out_sigma);
+    if (kc == 9) hipLaunchKernelGGL((stream_dwconv_kernel<9, 4>), grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n, out_sigma);
+    else if (kc == 31) hipLaunchKernelGGL((stream_dwconv_kernel<31, 2>), grid, dim3(256), 0, s, g, cache_in, has_cache, c, d, w, bias, bn_mean, bn_rstd, bn_g, bn_b, out, cache_out, n, out_sigma);
 }
 
 }  // namespace pk
