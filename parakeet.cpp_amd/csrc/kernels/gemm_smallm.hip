@@ -231,6 +231,159 @@ __global__ __launch_bounds__(64) void gemm_smallm_rt2_kernel(GemmArgs g) {
         }
 }
 
+// The chain kernel with the LayerNorm of its input rows folded in (GemmArgs::ln_g / ln_b / ln_eps; A = the UN-normalised rows x[M][K], K = the
+// row length, 512 or 1024): out = epi(LayerNorm(x) W^T + bias), bit for bit what layernorm_kernel followed by gemm_smallm_kernel<.., SIG> give.
+// Round 3 folded the norm into the one-wave-per-tile kernel and lost (every wave re-derived the statistics of its 16 rows alone: 3-4 us in front
+// of its chain).  Here a workgroup is FOUR waves: each normalises four of the tile's 16 rows exactly as layernorm_kernel does (one wave per row,
+// lane l holds elements l + 64 j, the canonical sum64 butterflies, y = fma((x - mean) rstd, gamma, beta)) and stores them to LDS in the sigma K
+// order at a pitch of K + 4 floats; after one barrier waves 0 and 1 run the dependent MFMA chains of two column tiles (GLU: the value and the
+// gate tile of the same 16 columns) with their A fragments from LDS (one chunk ahead of the chain, conflict-free ds_read_b128) and the tiled
+// weight stream in the same 8-chunk register ring as gemm_smallm_kernel -- requested BEFORE the rows, so the weights' HBM round trip covers the
+// normalisation.  Saves the LayerNorm launch (~5 us of a 32-row streaming chunk's ~360) for ~1 us in front of the chain.
+template <int EPI, int PER_LANE /* K / 64 */>
+__global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g) {
+    constexpr int K = 64 * PER_LANE, PITCH = K + 4, KC = 64, NKC = PER_LANE, DEPTH = 8;
+    static_assert(NKC % DEPTH == 0, "the ring walks whole groups of 8 chunks");
+    extern __shared__ __attribute__((aligned(16))) float At[];     // [16][PITCH]: the normalised rows of the tile, K in the sigma order
+    __shared__ float gate[64][4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * 16;
+    const int half = (EPI == EPI_GLU) ? (wave & 1) : 0;            // GLU: wave 0 = value tile, wave 1 = gate tile
+    const int n0 = (EPI == EPI_GLU) ? blockIdx.x * 16 : (2 * blockIdx.x + (wave & 1)) * 16;
+    const bool chain = wave < 2 && n0 < g.N;                        // (wave-uniform)
+    // ---- chain waves: epilogue operands and the head of the weight stream first ----
+    const int col = n0 + r;
+    float bias = 0.0f, bias_g = 0.0f;
+    float4 rw[DEPTH][4];
+    const float *wp = g.W_sig + (int64_t)((half * g.N + (chain ? n0 : 0)) >> 4) * 16 * K + 4 * lane;
+    auto wload = [&](int kc, int set) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rw[set][q] = *reinterpret_cast<const float4 *>(wp + kc * (16 * KC) + 256 * q);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (chain) {
+        if (half == 0 && col < g.N && g.bias) {
+            bias = g.bias[col];
+            if constexpr (EPI == EPI_GLU) bias_g = g.bias[g.N + col];
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH - 1; ++j) wload(j, j);
+    }
+    // ---- every wave: LayerNorm of rows m0 + 4 wave .. + 3, exactly as layernorm_kernel<PER_LANE, 1> (one wave per row) ----
+    {
+        float gv[PER_LANE], bv[PER_LANE], v[4][PER_LANE];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            int row = m0 + 4 * wave + rr;
+            row = row < g.M ? row : g.M - 1;                        // (rows past the end repeat the last one; their outputs are never stored)
+            const float *xr = g.A + (int64_t)row * g.lda;
+#pragma unroll
+            for (int j = 0; j < PER_LANE; ++j) v[rr][j] = xr[lane + 64 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j) {
+            gv[j] = g.ln_g[lane + 64 * j];
+            bv[j] = g.ln_b[lane + 64 * j];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            float p = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PER_LANE; ++j) p = p + v[rr][j];
+            const float mean = wave_sum64(p) / (float)K;
+            float q = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PER_LANE; ++j) {
+                const float c = v[rr][j] - mean;
+                q = q + c * c;
+            }
+            const float var = wave_sum64(q) / (float)K;
+            const float rstd = 1.0f / __builtin_sqrtf(var + g.ln_eps);
+            float *yr = At + (4 * wave + rr) * PITCH;
+#pragma unroll
+            for (int j = 0; j < PER_LANE; ++j) {
+                const int i = lane + 64 * j;
+                yr[(i & ~15) | ((i & 3) << 2) | ((i >> 2) & 3)] = __builtin_fmaf((v[rr][j] - mean) * rstd, gv[j], bv[j]);
+            }
+        }
+    }
+    __syncthreads();
+    if (!chain) return;
+    // ---- the chain of this wave's tile: A fragments from LDS one chunk ahead, W from the ring ----
+    sm_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float *arow = At + r * PITCH + 4 * kq;
+    float4 ra[2][4];
+    auto aload = [&](int kc, int set) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[set][q] = *reinterpret_cast<const float4 *>(arow + kc * KC + 16 * q);
+    };
+    aload(0, 0);
+    constexpr int last = NKC - 1;
+    for (int kc0 = 0; kc0 < NKC; kc0 += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const int kc = kc0 + j, nx = kc + DEPTH - 1;
+            wload(nx < last ? nx : last, (j + DEPTH - 1) % DEPTH);
+            aload(kc + 1 < NKC ? kc + 1 : last, (j + 1) & 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = ra[j & 1][q], w = rw[j][q];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+            }
+        }
+    }
+    if constexpr (EPI == EPI_GLU) {
+        if (half == 1) *reinterpret_cast<sm_f32x4 *>(&gate[lane][0]) = acc;
+        __syncthreads();                                            // (waves 2 and 3 have ended: the barrier counts the two chain waves)
+        if (half == 1) return;
+    }
+    if (col >= g.N) return;
+    // epilogue: C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + 4 * kq + i;
+        if (row >= g.M) continue;
+        float v = acc[i];
+        if (g.bias) v = v + bias;
+        if constexpr (EPI == EPI_RELU) {
+            v = v > 0.0f ? v : 0.0f;
+        } else if constexpr (EPI == EPI_SILU) {
+            v = dsiluf(v);
+        } else if constexpr (EPI == EPI_GLU) {
+            float gt = gate[lane][i];
+            if (g.bias) gt = gt + bias_g;
+            v = v * dsigmoidf(gt);
+        }
+        if (g.remap_rows) g.out[(int64_t)(row / g.remap_rows) * g.remap_gs + (int64_t)(row % g.remap_rows) * g.remap_rs + (int64_t)col * g.remap_cs] = v;
+        else g.out[(int64_t)row * g.ldo + (col < g.sigma_cols ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = v;
+    }
+}
+
+bool gemm_smallm_ln_applies(const GemmArgs &a, int epi) {
+    if (!a.ln_g || !a.ln_b || !a.W_sig || a.a_bf16 || a.a_sigma) return false;
+    if (a.M <= 0 || a.M > kSmallMRows || (a.K != 512 && a.K != 1024) || a.N % 16 != 0 || a.lda < a.K) return false;
+    return epi == EPI_NONE || epi == EPI_RELU || epi == EPI_SILU || epi == EPI_GLU;
+}
+
+template <int EPI>
+static void launch_smallm_ln(const GemmArgs &a, hipStream_t s) {
+    const int tiles = a.N / 16;
+    const dim3 grid(EPI == EPI_GLU ? tiles : (tiles + 1) / 2, (a.M + 15) / 16), block(256);
+    const size_t lds = (size_t)16 * (a.K + 4) * sizeof(float);
+    static DynLdsSlots slots8, slots16;
+    if (a.K == 512) {
+        ensure_dyn_lds(slots8, reinterpret_cast<const void *>(&gemm_smallm_ln_kernel<EPI, 8>), lds);
+        hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 8>), grid, block, lds, s, a);
+    } else {
+        ensure_dyn_lds(slots16, reinterpret_cast<const void *>(&gemm_smallm_ln_kernel<EPI, 16>), lds);
+        hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 16>), grid, block, lds, s, a);
+    }
+}
+
 // W_sig of GemmArgs: dst[tile = row / 16][chunk = k / 64][q][lane = (row % 16) + 16 kq][e] = src[row][64 chunk + 16 q + 4 e + kq]
 __global__ void sigma_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t rows, int K, int64_t ld) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // destination index
@@ -273,6 +426,16 @@ static void launch_smallm_epi(const GemmArgs &a, hipStream_t s) {
 }
 
 void launch_gemm_smallm(const GemmArgs &a, int epi, hipStream_t s) {
+    if (a.ln_g) {                                                   // LayerNorm folded in (the caller checked gemm_smallm_ln_applies)
+        switch (epi) {
+        case EPI_NONE: launch_smallm_ln<EPI_NONE>(a, s); break;
+        case EPI_RELU: launch_smallm_ln<EPI_RELU>(a, s); break;
+        case EPI_SILU: launch_smallm_ln<EPI_SILU>(a, s); break;
+        case EPI_GLU: launch_smallm_ln<EPI_GLU>(a, s); break;
+        default: break;
+        }
+        return;
+    }
     switch (epi) {
     case EPI_NONE: launch_smallm_epi<EPI_NONE>(a, s); break;
     case EPI_RELU: launch_smallm_epi<EPI_RELU>(a, s); break;

@@ -104,8 +104,9 @@ struct GemmArgs {
     // layout (its producer wrote it that way: sigma_cols, LayerNorm mode 2, the streaming attention / conv kernels).  Both set: a lane's 16-byte
     // load IS its operand of four consecutive MFMA steps -- no transposes on the chain -- and every weight load is 1 KB of consecutive addresses.
     const float *W_sig = nullptr; int a_sigma = 0;
-    // small-M bf16 kernel (gemm_smallm_bf16.hip) only: A = the UN-normalised fp32 rows, the LayerNorm (gamma ln_g[K], beta ln_b[K], ln_eps) of the
-    // product's input is applied while the rows are staged -- out = epi(bf16(LN(A)) W16^T + bias).  Callers check gemm_smallm_bf16_ln_applies().
+    // small-M kernels only (gemm_smallm_bf16.hip; gemm_smallm.hip with W_sig): A = the UN-normalised fp32 rows, the LayerNorm (gamma ln_g[K], beta
+    // ln_b[K], ln_eps) of the product's input is applied while the rows are staged -- out = epi(LN(A) W^T + bias) (bf16 mode: bf16(LN(A)) W16^T).
+    // Callers check gemm_smallm_bf16_ln_applies() / gemm_smallm_ln_applies().
     const float *ln_g = nullptr, *ln_b = nullptr; float ln_eps = 0.0f;
 };
 constexpr int kSmallMRows = 1536;  // launch_gemm: products with M <= this (and K % 64 == 0) run on gemm_smallm.hip.  Measured with the two-row-tile
@@ -115,6 +116,9 @@ constexpr int kSmallMRows = 1536;  // launch_gemm: products with M <= this (and 
 // src [rows][ld] -> dst rows x K floats in the W_sig tiling (rows % 16 == 0, K % 64 == 0)
 void launch_sigma_copy(const float *src, float *dst, int64_t rows, int K, int64_t ld, hipStream_t s);
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
+// fp32 small-M chain kernel with GemmArgs::ln_g set (kernels/gemm_smallm.hip: gemm_smallm_ln_kernel): A = the un-normalised rows, K = 512 / 1024 = the
+// row length, tiled weights W_sig, epi none / relu / silu / glu -- bit for bit LayerNorm + product.  Callers check this first.
+bool gemm_smallm_ln_applies(const GemmArgs &a, int epi);
 // same contract with bf16 operands and fp32 accumulation: a.W points to bf16 weights [N][K] (rounded once at upload), A is
 // rounded to bf16 while it is staged; K % 64 == 0.  Not bit-identical to the fp32 chain (kernels/gemm_bf16.hpp).
 void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s);

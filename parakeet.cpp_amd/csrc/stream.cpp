@@ -18,8 +18,8 @@
 
 namespace pk {
 
-// Tolerance-class mode: fold the LayerNorm of a product's input rows into the product (kernels/gemm_smallm_bf16.hip, GemmArgs::ln_g) -- four of a
-// block's fifteen launches go.  EXPERIMENTAL builds: PK_STREAM_FUSE_LN=0 switches it off for the A/B of tools/experiments/stream_bf16_ab.sh.
+// Fold the LayerNorm of a product's input rows into the product (GemmArgs::ln_g; tolerance-class mode: kernels/gemm_smallm_bf16.hip, exact mode:
+// gemm_smallm_ln_kernel in kernels/gemm_smallm.hip, bit for bit) -- four of a block's fifteen launches go.  EXPERIMENTAL builds: PK_STREAM_FUSE_LN=0 switches it off for the A/B of tools/experiments/stream_bf16_ab.sh.
 static bool stream_fuse_ln() {
 #ifdef PK_EXPERIMENTAL
     static const bool on = [] { const char *e = getenv("PK_STREAM_FUSE_LN"); return e ? atoi(e) != 0 : true; }();
@@ -175,19 +175,21 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     float *hb = ws_.hbuf.as<float>();
     // LayerNorm(x) -> n, then the product on n -- or, where the small-M bf16 kernel can fold the norm in, the product straight on x
     auto ln_gemm = [&](const char *name, const GemmArgs &g, int epi, const float *ng, const float *nb, bool norm_done) {
-        if (a16 && !norm_done && stream_fuse_ln()) {
+        if (!norm_done && stream_fuse_ln()) {
             GemmArgs fg = g;
-            fg.A = x; fg.lda = d; fg.a_bf16 = 0; fg.ln_g = ng; fg.ln_b = nb; fg.ln_eps = 1e-5f;
-            if (gemm_smallm_bf16_ln_applies(fg, epi)) { m_.run_gemm(name, fg, epi, st); return; }
+            fg.A = x; fg.lda = d; fg.a_bf16 = 0; fg.a_sigma = 0; fg.ln_g = ng; fg.ln_b = nb; fg.ln_eps = 1e-5f;
+            // tolerance-class mode: gemm_smallm_bf16.hip; exact mode (tiled weight copies present): gemm_smallm_ln_kernel -- bit for bit norm + product
+            if (a16 ? gemm_smallm_bf16_ln_applies(fg, epi) : (sg && gemm_smallm_ln_applies(fg, epi))) { m_.run_gemm(name, fg, epi, st); return; }
         }
         if (!norm_done) launch_layernorm(x, rows, d, ng, nb, 1e-5f, n, st, lnm);
         m_.run_gemm(name, g, epi, st);
     };
     bool ln_folds = false;                                                                                // the next block's ffn1 norm will be folded into its fc1
-    if (a16 && stream_fuse_ln()) {
+    if (stream_fuse_ln()) {
         GemmArgs pg{x, d, m_.layers[0].ffn1_w1, d, nullptr, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
-        pg.ln_g = m_.layers[0].ffn1_ng; pg.ln_b = m_.layers[0].ffn1_nb; pg.out_bf16 = 1;
-        ln_folds = gemm_smallm_bf16_ln_applies(pg, EPI_SILU);
+        pg.ln_g = m_.layers[0].ffn1_ng; pg.ln_b = m_.layers[0].ffn1_nb; pg.out_bf16 = a16;
+        if (sg) pg.W_sig = (*sig_)[0].ffn1_w1;
+        ln_folds = a16 ? gemm_smallm_bf16_ln_applies(pg, EPI_SILU) : (sg && gemm_smallm_ln_applies(pg, EPI_SILU));
     }
     auto ffn = [&](const LayerW &L, const Model::SigW &Ls, bool second, bool norm_done) {                // FeedForward (src/encoder.cpp:36-46)
         GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
