@@ -824,6 +824,25 @@ void Model::run_subsample(Workspace &w, const float *d_feats, int B, int Tm, flo
     (void)W1; (void)H1;
 }
 
+// y = LayerNorm(x) -> n, then the product g (A = n) -- or, for a handful of rows on the fp32 chain kernels, the product with the norm folded in
+// (gemm_smallm_ln_kernel: bit for bit the same; one launch instead of two).  kLnFoldRows: beyond about one round of its workgroups the redundant
+// normalisation (every 32-column workgroup normalises its 16 rows) costs more than the LayerNorm launch it saves.
+static constexpr int kLnFoldRows = 256;
+bool Model::ln_folds(const GemmArgs &g, int epi, int64_t rows) const {
+    return !cfg.gemm_bf16 && rows <= kLnFoldRows && g.W_sig && gemm_smallm_ln_applies(g, epi);
+}
+void Model::ln_gemm(const char *name, const GemmArgs &g, int epi, const float *ng, const float *nb, bool norm_done, int ymode, const float *x, float *n,
+                    int64_t rows, hipStream_t s) {
+    const int d = cfg.hidden_size;
+    if (!norm_done) {
+        GemmArgs fg = g;
+        fg.A = x; fg.lda = d; fg.a_sigma = 0; fg.a_bf16 = 0; fg.ln_g = ng; fg.ln_b = nb; fg.ln_eps = 1e-5f;
+        if (ln_folds(fg, epi, rows)) { run_gemm(name, fg, epi, s); return; }
+        KL("layernorm", 0.0, (cfg.gemm_bf16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, ng, nb, 1e-5f, n, s, ymode));
+    }
+    run_gemm(name, g, epi, s);
+}
+
 // FeedForward::forward (src/encoder.cpp:39-46): x += 0.5 * fc2(silu(fc1(LN(x))))
 void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done, const SigW *sg) {
     const int d = cfg.hidden_size, f = cfg.ffn_intermediate;
@@ -832,14 +851,12 @@ void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStr
     // rounding the GEMM's staging path would apply: same operand values) and store HALF the bytes in the same buffers.
     // sg (small batches, fp32): the same buffers in the sigma K layout, the products on the tiled weight copies (run_layers).
     const int a16 = cfg.gemm_bf16 ? 1 : 0;
-    if (!norm_done)    // (the first FFN's norm rides on the previous block's final_norm_ kernel, see run_layers)
-        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4,
-           launch_layernorm(x, rows, d, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, 1e-5f, n, s, sg ? 2 : a16));
     GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, h, f, nullptr, 0, 1.0f, (int)rows, f, d};
     g1.a_bf16 = a16; g1.out_bf16 = a16;
     g1.fast_act = a16;
     if (sg) { g1.a_sigma = 1; g1.W_sig = second ? sg->ffn2_w1 : sg->ffn1_w1; g1.sigma_cols = f; }
-    run_gemm("ffn_fc1_silu", g1, EPI_SILU, s);
+    // (the first FFN's norm rides on the previous block's final_norm_ kernel, see run_layers -- unless the product folds it in: ln_gemm)
+    ln_gemm("ffn_fc1_silu", g1, EPI_SILU, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, norm_done, sg ? 2 : a16, x, n, rows, s);
     GemmArgs g2{h, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, x, d, 0.5f, (int)rows, d, f};
     g2.a_bf16 = a16;
     if (sg) { g2.a_sigma = 1; g2.W_sig = second ? sg->ffn2_w2 : sg->ffn1_w2; }
@@ -901,7 +918,6 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
         ffn1_norm_done = false;
         if (stage_cap == 1) break;
         // ConformerAttention::forward  :180-186
-        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, L.att_ng, L.att_nb, 1e-5f, n, s, ymode));
         {
             // q and k columns in the sigma layout (MFMA operands of the attention kernel), v natural
             GemmArgs g{n, d, L.wqkv, d, L.bqkv, w.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
@@ -909,7 +925,7 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             g.a_bf16 = a16;
             g.out_bf16 = att16 ? 1 : 0;
             if (sg) { g.a_sigma = 1; g.W_sig = sg->wqkv; }
-            run_gemm("attn_qkv", g, EPI_NONE, s);
+            ln_gemm("attn_qkv", g, EPI_NONE, L.att_ng, L.att_nb, false, ymode, x, n, rows, s);
         }
         const int hd = d / cfg.num_heads;
         double fl = 0.0;                                             // QK^T + QP^T (needed band) + AV over every (utterance, head)
@@ -932,13 +948,12 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
         }
         if (stage_cap == 2) break;
         // ConformerConvModule::forward  :59-75
-        KL("layernorm", 0.0, (a16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, L.cv_ng, L.cv_nb, 1e-5f, n, s, ymode));
         {
             GemmArgs g{n, d, L.pw1_w, d, L.pw1_b, w.g.as<float>(), d, nullptr, 0, 1.0f, (int)rows, d, d};
             g.a_bf16 = a16;
             g.fast_act = a16;
             if (sg) { g.a_sigma = 1; g.W_sig = sg->pw1; }
-            run_gemm("conv_pw1_glu", g, EPI_GLU, s);
+            ln_gemm("conv_pw1_glu", g, EPI_GLU, L.cv_ng, L.cv_nb, false, ymode, x, n, rows, s);
         }
         KL("dwconv_bn_silu", (double)rows * d * cfg.conv_kernel_size * 2.0, 2.0 * rows * d * 4,
            launch_dwconv_bn_silu(w.g.as<float>(), rg ? 1 : B, rg ? (int)rows : T, d, cfg.conv_kernel_size, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
@@ -953,7 +968,13 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
         ffn(w, L, true, rows, s, false, sg);                                         // ffn2_  :201
         if (stage_cap == 4) break;
         const bool next_runs = l + 1 < cfg.num_layers && !(l + 1 > stop_layer || (l + 1 == stop_layer && stop_stage == 0));
-        if (next_runs) {           // final_norm_ :202 and the next block's ffn1_ norm :40 in one pass over the rows
+        bool next_folds = false;   // the next block's fc1 folds its own norm in (small fp32 batches): final_norm_ alone here
+        if (next_runs && sg) {
+            GemmArgs pg{x, d, layers[l + 1].ffn1_w1, d, nullptr, w.hbuf.as<float>(), cfg.ffn_intermediate, nullptr, 0, 1.0f, (int)rows, cfg.ffn_intermediate, d};
+            pg.W_sig = (*sigv)[l + 1].ffn1_w1; pg.ln_g = layers[l + 1].ffn1_ng; pg.ln_b = layers[l + 1].ffn1_nb;
+            next_folds = ln_folds(pg, EPI_SILU, rows);
+        }
+        if (next_runs && !next_folds) {   // final_norm_ :202 and the next block's ffn1_ norm :40 in one pass over the rows
             KL("layernorm", 0.0, 3.0 * rows * d * 4,
                launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, layers[l + 1].ffn1_ng, layers[l + 1].ffn1_nb, 1e-5f, x, n, s, ymode));
             ffn1_norm_done = true;

@@ -226,6 +226,10 @@ class Model {
     void upload_weights();
     void gemm(const char *name, const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *out, int64_t ldo,
               int M, int N, int K, int epi, const float *resid, int64_t ldr, float alpha, hipStream_t s, int a_bf16 = 0, int out_bf16 = 0);
+    // LayerNorm + product, folded into one launch where the fp32 chain kernel can (engine.cpp)
+    bool ln_folds(const GemmArgs &g, int epi, int64_t rows) const;
+    void ln_gemm(const char *name, const GemmArgs &g, int epi, const float *ng, const float *nb, bool norm_done, int ymode, const float *x, float *n,
+                 int64_t rows, hipStream_t s);
     void ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done = false, const SigW *sg = nullptr);
 };
 
