@@ -82,7 +82,7 @@ typedef struct pk_config {
                                       product of a chunk on bf16 operands (kernels/gemm_smallm_bf16.hip: K split over the waves of a workgroup,
                                       the LayerNorm of a product's input folded in), specification = the oracle's Stream with gemm_bf16 = 1,
                                       compared within the bounds of tests/test_gpu_stream.py; 16 lock-step streams of
-                                      nemotron-600m cost 2.4-2.5 ms per 160 ms chunk instead of 3.4-3.5. */
+                                      nemotron-600m cost 2.4-2.5 ms per 160 ms chunk instead of 3.1-3.2. */
     char joint_prefix[32];         /* "tdt_joint_." (tdt_ctc.cpp:5-9) or "joint_." (tdt.cpp:28-32) */
     /* encoder-only uses (Sortformer's NEST encoder, src/sortformer.cpp:41-47): vocab_size = 0 loads no prediction net / joint */
     int32_t xscaling;              /* StreamingEncoderConfig::xscaling (streaming_encoder.cpp:402-406, :444-447): x *= sqrt(hidden) after subsampling */
