@@ -30,6 +30,18 @@ def shard_by_audio(lengths: Sequence[int], rank: int, world: int) -> List[int]:
     return mine
 
 
+def shard_sessions(n_sessions: int, rank: int, world: int, group: int = 16) -> List[int]:
+    """Streaming sessions (BASELINE configs[4]: N concurrent streams per GPU on the GPUs of a node): a session lives on ONE GPU for its whole
+    life (its K / V / conv caches and decoder state are resident there), so the partition is static -- sessions are dealt in lock-step GROUPS of
+    `group` (one pk_stream of `group` streams each: the batch dimension of every kernel of a chunk), group g to rank g % world.  A rank then
+    advances its groups one after the other per 160 ms tick.  No data-path collective; the same on every rank.  Returns the session ids of `rank`."""
+    out = []
+    n_groups = (n_sessions + group - 1) // group
+    for g in range(rank, n_groups, world):
+        out.extend(range(g * group, min(n_sessions, (g + 1) * group)))
+    return out
+
+
 def gather_results(local: Sequence, local_idx: Sequence[int], n_items: int, world: int, dist=None) -> list:
     """All-gather per-rank (index, result) lists and reassemble them in the original clip order on every rank."""
     if world == 1 or dist is None:

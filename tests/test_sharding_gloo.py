@@ -145,3 +145,27 @@ def test_bench_refuses_more_gpus_than_devices():
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env2, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "must agree" in (out.stdout + out.stderr)
+
+
+def test_shard_sessions_partition():
+    """Streaming sessions (configs[4]): dealt to the ranks in lock-step groups; every session on exactly one rank, groups intact."""
+    from parakeet_cpp_amd import shard
+    for n, world, group in [(128, 8, 16), (100, 8, 16), (16, 8, 16), (33, 2, 16), (7, 3, 4)]:
+        owned = [shard.shard_sessions(n, r, world, group) for r in range(world)]
+        flat = sorted(i for o in owned for i in o)
+        assert flat == list(range(n))
+        for o in owned:
+            for k in range(0, len(o), group):
+                blk = o[k:k + group]
+                assert blk == list(range(blk[0], blk[0] + len(blk))) and blk[0] % group == 0      # whole groups, in order
+        assert max(map(len, owned)) - min(map(len, owned)) <= group
+
+
+def test_bench_stream_refuses_more_gpus_than_devices():
+    from parakeet_cpp_amd import capi
+    if capi.device_count() >= 2:
+        import pytest
+        pytest.skip("this host has >= 2 devices")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_stream.py"), "--gpus", "2", "--chunks", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "device(s) visible" in (out.stdout + out.stderr)

@@ -4,7 +4,9 @@ encoder state.  Prints one JSON line: per-chunk latency (median / p95 over the t
 including the token copy-back) and aggregate RTFx = streams x chunk seconds / latency.
 --bf16: the tolerance-class mode (pk_config.gemm_bf16: bf16 weights / operands, fp32 accumulation; kernels/gemm_smallm_bf16.hip) -- compared
 with the oracle's gemm_bf16 Stream within a tolerance (tests/test_gpu_stream.py), not bit for bit like the default fp32 mode.
-usage: python tools/bench_stream.py [--streams 16] [--latency-frames 1] [--chunks 200] [--config nemotron-600m] [--bf16]"""
+--gpus N: one process per GPU (no data-path collective: a session lives on one GPU, parakeet_cpp_amd.shard.shard_sessions), --streams sessions on
+EACH; the line then carries the slowest rank's latency and the SUM of the ranks' RTFx.  Refuses N > visible devices.
+usage: python tools/bench_stream.py [--streams 16] [--latency-frames 1] [--chunks 200] [--config nemotron-600m] [--bf16] [--gpus N]"""
 import argparse
 import json
 import os
@@ -16,6 +18,43 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import numpy as np
 
 
+def run_ranks(a):
+    """--gpus N: N child processes, one per device, each the single-GPU bench on its own sessions; nothing is exchanged between them."""
+    import subprocess
+    import pkload
+    pkload.load()
+    from parakeet_cpp_amd import capi, shard
+    n_dev = capi.device_count()
+    if a.gpus > n_dev:
+        print(f"bench_stream: --gpus {a.gpus} but {n_dev} device(s) visible: a {a.gpus}-GPU figure must not come from fewer devices", file=sys.stderr)
+        sys.exit(2)
+    total = a.streams * a.gpus
+    owned = [shard.shard_sessions(total, r, a.gpus, group=a.streams) for r in range(a.gpus)]
+    assert sorted(i for o in owned for i in o) == list(range(total)) and all(len(o) == a.streams for o in owned)
+    cmd = [sys.executable, os.path.abspath(__file__), "--streams", str(a.streams), "--latency-frames", str(a.latency_frames), "--chunks", str(a.chunks),
+           "--warmup", str(a.warmup), "--chunk-samples", str(a.chunk_samples), "--config", a.config] + (["--bf16"] if a.bf16 else [])
+    if a.gpus and not os.path.exists(os.path.join(os.environ.get("PK_BENCH_CACHE", "/tmp"), f"pk_bench_{a.config}_seed42.safetensors")):
+        import bench
+        from parakeet_cpp_amd import config
+        bench.weights_file(config.PRESETS[a.config]())              # generated once, before the ranks race for it
+    procs = [subprocess.Popen(cmd + ["--device", str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(a.gpus)]
+    lines = []
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=900)
+        js = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not js:
+            print(f"bench_stream: rank {r} failed (rc {p.returncode}): {err[-400:]}", file=sys.stderr)
+            sys.exit(1)
+        lines.append(json.loads(js[-1]))
+    out = dict(lines[0])
+    out.update({"n_gpus": a.gpus, "streams_total": total, "latency_ms_median": max(l["latency_ms_median"] for l in lines),
+                "latency_ms_p95": max(l["latency_ms_p95"] for l in lines), "latency_ms_mean": max(l["latency_ms_mean"] for l in lines),
+                "aggregate_rtfx": round(sum(l["aggregate_rtfx"] for l in lines), 1), "tokens_emitted": sum(l["tokens_emitted"] for l in lines),
+                "per_rank_latency_ms_median": [l["latency_ms_median"] for l in lines], "scaling": "weak (sessions per GPU fixed)",
+                "parallelism": f"dp{a.gpus}: sessions sharded in groups of {a.streams}, no data-path collective"})
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=16)
@@ -25,7 +64,12 @@ def main():
     ap.add_argument("--chunk-samples", type=int, default=2560)
     ap.add_argument("--config", default="nemotron-600m")
     ap.add_argument("--bf16", action="store_true", help="tolerance-class mode: every product of the chunk on bf16 operands (pk_config.gemm_bf16)")
+    ap.add_argument("--gpus", type=int, default=1, help="one process per GPU, --streams sessions on each (weak scaling over sessions)")
+    ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)       # the rank's device (set by the --gpus parent)
+    ap.add_argument("--spawn", action="store_true", help="take the one-process-per-GPU path also at --gpus 1 (what the GPU test exercises)")
     a = ap.parse_args()
+    if a.gpus > 1 or a.spawn:
+        return run_ranks(a)
     import pkload
     pk = pkload.load()
     from parakeet_cpp_amd import capi, synth, config
@@ -35,7 +79,7 @@ def main():
     if a.bf16:
         import dataclasses
         cfg = dataclasses.replace(cfg, gemm_bf16=True)
-    m = capi.Model(path, cfg, device=0)
+    m = capi.Model(path, cfg, device=a.device)
     st = capi.Stream(m, a.streams, 70, a.latency_frames)
     n = a.chunk_samples
     pcm = synth.synth_pcm(a.streams, n * (a.warmup + a.chunks), seed=99)
