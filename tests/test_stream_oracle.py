@@ -95,3 +95,35 @@ def test_stream_oracle_bf16_mode_rounds_every_product(orc):
         f32.decode(e1)
     assert len(gaps) >= 8 and n_tok > 0
     assert 2e-4 < max(gaps) < 1e-2, f"bf16-vs-fp32 gap of the oracle's stream: {max(gaps):.2e} of max|x| (bf16 epsilon class expected)"
+
+
+@pytest.mark.parametrize("left,right,chunk", [(10, 1, 2560), (70, 0, 4000)])
+def test_stream_oracle_bf16_mode_matches_torch_bf16(orc, left, right, chunk):
+    """The oracle's tolerance-class streaming mode against an INDEPENDENT statement of the same specification: the torch restatement with both
+    operands of every Linear / 1x1-conv product rounded to bf16 (torch's RNE) and fp32 accumulation.  The two differ in accumulation order only,
+    so they agree far inside the mode's own distance from fp32 -- but not to fp32 round-off: a last-bit difference in an activation can round to
+    the neighbouring bf16 value in one of them.  (What this pins: WHICH products are rounded, and that nothing else is.)"""
+    import dataclasses
+    cfg = dataclasses.replace(pk.make_tiny_config(num_layers=2), gemm_bf16=True)
+    W = synth.synth_weights(cfg, seed=5)
+    st = orc.Stream(orc.Model(cfg, W), left, right)
+    f32 = orc.Stream(orc.Model(dataclasses.replace(cfg, gemm_bf16=False), W), left, right)
+    ts = TorchStream(cfg, W, orc.mel_filterbank(n_mels=cfg.mel_bins), left, right, bf16=True)
+    pcm = synth.synth_pcm(1, chunk * 14, seed=left + chunk)[0]
+    dev, gap, n = [], [], 0
+    for i in range(14):
+        seg = pcm[i * chunk:(i + 1) * chunk]
+        m, mf, tm = st.mel(seg), f32.mel(seg), ts.mel(seg)
+        if tm is None:
+            continue
+        e, ef, te = st.encode(m), f32.encode(mf), ts.encode(torch_from(m))
+        assert (te is None) == (e.shape[0] == 0)
+        if te is None:
+            continue
+        mx = np.abs(ef).max()
+        dev.append(np.abs(e - te.numpy()).mean() / mx)
+        gap.append(np.abs(e - ef).mean() / mx)
+        assert np.abs(e - te.numpy()).max() <= 2e-2 * mx, f"chunk {i}"
+        n += e.shape[0]
+    assert n >= 10
+    assert max(dev) < 0.5 * min(gap), f"oracle bf16 vs torch bf16 {max(dev):.2e} of max|x|; the mode's distance from fp32 {min(gap):.2e}"

@@ -11,7 +11,10 @@ import torch.nn.functional as F
 
 
 class TorchStream:
-    def __init__(self, cfg, W, fb, att_left, att_right):
+    def __init__(self, cfg, W, fb, att_left, att_right, bf16=False):
+        """bf16: the tolerance-class mode of the streaming path -- every Linear / 1x1-conv product takes both operands rounded to bf16 (RNE), fp32
+        accumulation; everything else (3x3 / depthwise convs, LayerNorm, attention arithmetic, caches) stays fp32 (oracle/pk_oracle.c, streaming section)."""
+        self.bf16 = bf16
         self.cfg, self.W, self.L, self.R = cfg, {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in W.items()}, att_left, att_right
         self.fb = torch.from_numpy(fb)                      # [257][n_mels]
         self.last = 0.0
@@ -40,18 +43,24 @@ class TorchStream:
     def w(self, name):
         return self.W[name]
 
+    def rb(self, t):                                         # operand rounding of the bf16 mode
+        return t.bfloat16().float() if self.bf16 else t
+
+    def linear(self, v, w, b=None):                          # the mode's product: rounded operands, fp32 accumulate
+        return F.linear(self.rb(v), self.rb(w), b)
+
     def subsample(self, mel):                                # ConvSubsampling::forward on one chunk (ReLU, src/encoder.cpp:219-241)
         p = "encoder_.subsampling_."
         C = self.cfg.subsampling_channels
         x = mel[None, None]
         x = F.relu(F.conv2d(x, self.w(p + "conv1_.weight"), self.w(p + "conv1_.bias"), stride=2, padding=1))
         x = F.conv2d(x, self.w(p + "dw1_.weight"), self.w(p + "dw1_.bias"), stride=2, padding=1, groups=C)
-        x = F.relu(F.conv2d(x, self.w(p + "conv2_.weight"), self.w(p + "conv2_.bias")))
+        x = F.relu(F.conv2d(self.rb(x), self.rb(self.w(p + "conv2_.weight")), self.w(p + "conv2_.bias")))
         x = F.conv2d(x, self.w(p + "dw2_.weight"), self.w(p + "dw2_.bias"), stride=2, padding=1, groups=C)
-        x = F.relu(F.conv2d(x, self.w(p + "conv3_.weight"), self.w(p + "conv3_.bias")))
+        x = F.relu(F.conv2d(self.rb(x), self.rb(self.w(p + "conv3_.weight")), self.w(p + "conv3_.bias")))
         b, c, t, f = x.shape
         x = x.permute(0, 2, 1, 3).reshape(b, t, c * f)
-        return F.linear(x, self.w(p + "proj_.weight"), self.w(p + "proj_.bias"))[0]
+        return self.linear(x, self.w(p + "proj_.weight"), self.w(p + "proj_.bias"))[0]
 
     def pos_emb(self, T, d):
         pe = torch.zeros(2 * T - 1, d)
@@ -77,7 +86,7 @@ class TorchStream:
         for l, cache in enumerate(self.caches):
             q = f"encoder_.layers_.{l}."
             ln = lambda v, n: F.layer_norm(v, (d,), self.w(q + n + ".weight"), self.w(q + n + ".bias"), 1e-5)
-            lin = lambda v, n, bias=True: F.linear(v, self.w(q + n + ".weight"), self.w(q + n + ".bias") if bias else None)
+            lin = lambda v, n, bias=True: self.linear(v, self.w(q + n + ".weight"), self.w(q + n + ".bias") if bias else None)
             ffn = lambda v, n: v + 0.5 * lin(F.silu(lin(ln(v, n + "norm_"), n + "fc1_")), n + "fc2_")
             x = ffn(x, "ffn1_.")
             # attention with K/V cache
@@ -116,4 +125,4 @@ class TorchStream:
 
 def lin_conv(ts, name, v):        # 1x1 Conv1d stored as [out][in][1]
     w = ts.w(name + ".weight")
-    return F.linear(v, w.reshape(w.shape[0], -1), ts.w(name + ".bias"))
+    return ts.linear(v, w.reshape(w.shape[0], -1), ts.w(name + ".bias"))
