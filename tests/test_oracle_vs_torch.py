@@ -88,3 +88,33 @@ def test_full_width_block_matches_torch(orc):
     x = np.random.default_rng(2).standard_normal((1, 126, 512)).astype(np.float32)
     pe = orc.pos_emb(126, 512)
     assert rel_err(m.conformer_block(0, x, pe), torch_ref.conformer_block(W, 0, x, pe, 8)) < 2e-5
+
+
+@pytest.mark.parametrize("preset,T", [("110m", 60), ("600m", 40), ("tiny", 37)])
+def test_bf16_mode_block_matches_independent_torch_statement(orc, preset, T):
+    """The oracle's tolerance-class mode (gemm_bf16) is the SPECIFICATION the bf16 kernels are compared with -- so it is pinned here against an
+    independent statement of the same rules (tests/torch_ref.py conformer_block(bf16=True): tensor ops, torch's own bf16 rounding): which
+    operands are rounded (every Linear / 1x1 conv), and for head sizes 64 (110m) / 128 (600m) the bf16 attention form (stored q / k / v / position
+    table, one biased query copy + the c-vector, rounded probabilities, unrounded normaliser, stored context); head size 16 (tiny) keeps the fp32
+    attention on the rounded products.  The two differ in accumulation order only: they must agree far inside the mode's own distance from
+    fp32 (a last-bit difference may still flip a bf16 rounding here and there: not fp32 round-off)."""
+    import dataclasses
+    from conftest import pk
+    base = {"110m": pk.make_110m_config, "600m": pk.make_tdt_600m_config, "tiny": pk.make_tiny_config}[preset]()
+    cfg = dataclasses.replace(base, num_layers=1, gemm_bf16=True)
+    W = synth.synth_weights(cfg, seed=3)
+    m16, m32 = orc.Model(cfg, W), orc.Model(dataclasses.replace(cfg, gemm_bf16=False), W)
+    d = cfg.hidden_size
+    x = np.random.default_rng(2).standard_normal((1, T, d)).astype(np.float32)
+    pe = orc.pos_emb(T, d)
+    for stop in (2, 0):                                             # after the attention sub-block, and the whole block
+        got = m16.conformer_block(0, x, pe, stop_after=stop)
+        ref = torch_ref.conformer_block(W, 0, x, pe, cfg.num_heads, stop_after=stop, bf16=True)
+        f32 = m32.conformer_block(0, x, pe, stop_after=stop)
+        mx = np.abs(f32).max()
+        dev, gap = np.abs(got - ref).mean() / mx, np.abs(got - f32).mean() / mx
+        print(f"{preset} stop {stop}: oracle bf16 vs torch bf16 mean {dev:.2e}, max {np.abs(got - ref).max() / mx:.2e}; oracle bf16 vs fp32 mean {gap:.2e}")
+        assert gap > 1e-4, "the mode must differ from fp32"
+        # (measured: after the attention 2e-5 .. 6e-5 against a gap of 4e-4; after the whole block -- two more rounded products, the GLU and SiLU
+        #  in between, each flip of a bf16 rounding carried on -- 1.4e-4 .. 1.8e-4 against 4.8e-4)
+        assert dev < (0.25 if stop == 2 else 0.5) * gap and np.abs(got - ref).max() <= 2e-2 * mx

@@ -52,17 +52,25 @@ def rel_shift(x):                                                       # src/en
     return x[..., :n]
 
 
-def conformer_block(W, layer, x, pe, n_heads, stop_after=0):
+def conformer_block(W, layer, x, pe, n_heads, stop_after=0, bf16=False):
+    """bf16: the tolerance-class mode (pk_config.gemm_bf16) stated independently of oracle/pk_oracle.c -- every Linear / 1x1-conv product takes
+    both operands rounded to bf16 (torch's RNE) with fp32 accumulation; for head sizes 64 / 128 the attention is the mode's bf16 form: q, k, v
+    and the projected position table stored as bf16, ONE biased query copy qu = bf16(q + u) for both score terms with the position term completed
+    by c[p] = (v - u) . P_p in fp32, probabilities rounded to bf16 for the value product, the normaliser not, the context stored as bf16."""
     q = f"encoder_.layers_.{layer}."
     x = t(x)
     d = x.shape[-1]
+    rb = (lambda v: v.bfloat16().float()) if bf16 else (lambda v: v)
+
+    def lin(v, w, b=None):
+        return F.linear(rb(v), rb(w), b)
 
     def ln(name, v):
         return F.layer_norm(v, (d,), t(W[q + name + ".weight"]), t(W[q + name + ".bias"]), 1e-5)
 
     def ffn(name, v):
-        h = F.linear(ln(name + ".norm_", v), t(W[q + name + ".fc1_.weight"]), t(W[q + name + ".fc1_.bias"]))
-        h = F.linear(F.silu(h), t(W[q + name + ".fc2_.weight"]), t(W[q + name + ".fc2_.bias"]))
+        h = lin(ln(name + ".norm_", v), t(W[q + name + ".fc1_.weight"]), t(W[q + name + ".fc1_.bias"]))
+        h = lin(F.silu(h), t(W[q + name + ".fc2_.weight"]), t(W[q + name + ".fc2_.bias"]))
         return v + 0.5 * h
 
     x = ffn("ffn1_", x)
@@ -72,27 +80,37 @@ def conformer_block(W, layer, x, pe, n_heads, stop_after=0):
     n = ln("attn_.norm_", x)
     B, T, _ = n.shape
     hd = d // n_heads
-    qq = F.linear(n, t(W[q + "attn_.mha_.q_proj.weight"]), t(W[q + "attn_.mha_.q_proj.bias"])).view(B, T, n_heads, hd).transpose(1, 2)
-    kk = F.linear(n, t(W[q + "attn_.mha_.k_proj.weight"]), t(W[q + "attn_.mha_.k_proj.bias"])).view(B, T, n_heads, hd).transpose(1, 2)
-    vv = F.linear(n, t(W[q + "attn_.mha_.v_proj.weight"]), t(W[q + "attn_.mha_.v_proj.bias"])).view(B, T, n_heads, hd).transpose(1, 2)
+    qq = lin(n, t(W[q + "attn_.mha_.q_proj.weight"]), t(W[q + "attn_.mha_.q_proj.bias"])).view(B, T, n_heads, hd).transpose(1, 2)
+    kk = lin(n, t(W[q + "attn_.mha_.k_proj.weight"]), t(W[q + "attn_.mha_.k_proj.bias"])).view(B, T, n_heads, hd).transpose(1, 2)
+    vv = lin(n, t(W[q + "attn_.mha_.v_proj.weight"]), t(W[q + "attn_.mha_.v_proj.bias"])).view(B, T, n_heads, hd).transpose(1, 2)
     u = t(W[q + "attn_.pos_bias_u_"]).view(1, n_heads, 1, hd)
     v_ = t(W[q + "attn_.pos_bias_v_"]).view(1, n_heads, 1, hd)
-    p = F.linear(t(pe), t(W[q + "attn_.pos_proj_.weight"])).view(1, -1, n_heads, hd).transpose(1, 2)
-    content = (qq + u) @ kk.transpose(-1, -2)
-    pos = rel_shift((qq + v_) @ p.transpose(-1, -2))
-    a = torch.softmax((content + pos) * (1.0 / math.sqrt(hd)), dim=-1)
-    o = (a @ vv).transpose(1, 2).reshape(B, T, d)
-    x = x + F.linear(o, t(W[q + "attn_.mha_.out_proj.weight"]), t(W[q + "attn_.mha_.out_proj.bias"]))
+    p = lin(t(pe), t(W[q + "attn_.pos_proj_.weight"])).view(1, -1, n_heads, hd).transpose(1, 2)
+    if bf16 and hd in (64, 128):
+        qq, kk, vv, p = rb(qq), rb(kk), rb(vv), rb(p)
+        qu = rb(qq + u)
+        content = qu @ kk.transpose(-1, -2)
+        cvec = ((v_ - u) @ p.transpose(-1, -2))                                   # [1][H][1][P]
+        pos = rel_shift(qu @ p.transpose(-1, -2) + cvec)
+        sc = (content + pos) * (1.0 / math.sqrt(hd))
+        e = torch.exp(sc - sc.max(dim=-1, keepdim=True).values)
+        o = rb((rb(e) @ vv) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, T, d)
+    else:
+        content = (qq + u) @ kk.transpose(-1, -2)
+        pos = rel_shift((qq + v_) @ p.transpose(-1, -2))
+        a = torch.softmax((content + pos) * (1.0 / math.sqrt(hd)), dim=-1)
+        o = (a @ vv).transpose(1, 2).reshape(B, T, d)
+    x = x + lin(o, t(W[q + "attn_.mha_.out_proj.weight"]), t(W[q + "attn_.mha_.out_proj.bias"]))
     if stop_after == 2:
         return x.numpy()
     # conv module  src/encoder.cpp:59-75
     n = ln("conv_.norm_", x).transpose(1, 2)
-    y = F.glu(F.conv1d(n, t(W[q + "conv_.pointwise_conv1_.weight"]), t(W[q + "conv_.pointwise_conv1_.bias"])), dim=1)
+    y = F.glu(F.conv1d(rb(n), rb(t(W[q + "conv_.pointwise_conv1_.weight"])), t(W[q + "conv_.pointwise_conv1_.bias"])), dim=1)
     K = W[q + "conv_.depthwise_conv_.weight"].shape[-1]
     y = F.conv1d(y, t(W[q + "conv_.depthwise_conv_.weight"]), t(W[q + "conv_.depthwise_conv_.bias"]), padding=(K - 1) // 2, groups=d)
     y = F.batch_norm(y, t(W[q + "conv_.batch_norm_.running_mean"]), t(W[q + "conv_.batch_norm_.running_var"]),
                      t(W[q + "conv_.batch_norm_.weight"]), t(W[q + "conv_.batch_norm_.bias"]), training=False, eps=1e-5)
-    y = F.conv1d(F.silu(y), t(W[q + "conv_.pointwise_conv2_.weight"]), t(W[q + "conv_.pointwise_conv2_.bias"]))
+    y = F.conv1d(rb(F.silu(y)), rb(t(W[q + "conv_.pointwise_conv2_.weight"])), t(W[q + "conv_.pointwise_conv2_.bias"]))
     x = x + y.transpose(1, 2)
     if stop_after == 3:
         return x.numpy()
