@@ -118,3 +118,28 @@ def test_bf16_mode_block_matches_independent_torch_statement(orc, preset, T):
         # (measured: after the attention 2e-5 .. 6e-5 against a gap of 4e-4; after the whole block -- two more rounded products, the GLU and SiLU
         #  in between, each flip of a bf16 rounding carried on -- 1.4e-4 .. 1.8e-4 against 4.8e-4)
         assert dev < (0.25 if stop == 2 else 0.5) * gap and np.abs(got - ref).max() <= 2e-2 * mx
+
+
+def test_bf16_mode_decode_matches_independent_torch_statement(orc):
+    """The decode rules of the tolerance-class mode (bf16 weights of the recurrent / projection / head products, h' and z stored as bf16, the
+    layer-0 input projection and the cell state fp32) against an independent torch statement, at the LOGITS: the oracle walks its own greedy
+    path, the torch restatement is forced along the same decisions, and every step's label / duration log-probs must agree far inside the
+    mode's own distance from fp32 (the fp32 oracle forced along the same path)."""
+    import dataclasses
+    from conftest import pk
+    cfg = dataclasses.replace(pk.make_110m_config(), num_layers=2, gemm_bf16=True)    # (the 2-layer cut emits tokens on synthetic audio)
+    W = synth.synth_weights(cfg, seed=42)
+    m16, m32 = orc.Model(cfg, W), orc.Model(dataclasses.replace(cfg, gemm_bf16=False), W)
+    enc = m16.encoder(orc.mel(synth.synth_pcm(1, 96000, seed=77)[0])[None])[0]
+    r = m16.tdt_score(enc)                                          # its own greedy path + every step's log-probs
+    assert r["n"] >= 20 and (r["labels"] != cfg.blank_id).sum() >= 5
+    lab, dur = torch_ref.tdt_score(W, cfg, enc, r["labels"], r["dur_idx"], bf16=True)
+    f = m32.tdt_score(enc, labels=r["labels"], dur_idx=r["dur_idx"])
+    n = min(len(lab), r["n"], f["n"])
+    assert n == r["n"]
+    top = np.argsort(-r["label_lp"][:n], axis=1)[:, :8]              # the labels that matter: the oracle's top 8 of every step
+    take = lambda a: np.take_along_axis(a[:n], top, axis=1)
+    dev = max(np.abs(take(lab) - take(r["label_lp"])).max(), np.abs(dur[:n] - r["dur_lp"][:n]).max())
+    gap = max(np.abs(take(f["label_lp"]) - take(r["label_lp"])).max(), np.abs(f["dur_lp"][:n] - r["dur_lp"][:n]).max())
+    print(f"bf16 decode, {n} steps ({int((r['labels'] != cfg.blank_id).sum())} tokens): oracle vs torch max |dlogp| {dev:.2e}; oracle bf16 vs fp32 along the same path {gap:.2e}")
+    assert gap > 1e-3 and dev < 0.4 * gap               # (measured 1.7e-3 against 7.9e-3: a flipped bf16 rounding of one h' / z element moves a logit by ~1e-3)

@@ -185,3 +185,44 @@ def tdt_greedy(W, cfg, enc, max_steps=100000):
                     break
         out.append(ids)
     return out
+
+
+def tdt_score(W, cfg, enc, labels, dur_idx, bf16=False):
+    """The TDT loop (src/tdt.cpp:62-106) of ONE utterance enc[T][d] along a GIVEN decision path, returning every step's label and duration
+    log-probs.  bf16: the tolerance-class mode's decode rules stated independently of oracle/pk_oracle.c -- enc_proj with both operands rounded
+    to bf16, the hidden-to-hidden and upper-layer input projections, pred_proj and both heads with bf16 WEIGHTS, h' = bf16(o tanh(c')) and
+    z = bf16(relu(enc_proj + pred_proj)) stored rounded; the layer-0 input projection (an embedding row times W_ih) and the cell state stay fp32."""
+    rb = (lambda v: v.bfloat16().float()) if bf16 else (lambda v: v)
+    jp = cfg.joint_prefix
+    E = t(W["prediction_.embed_.weight"])
+    L, Hp = cfg.num_lstm_layers, cfg.pred_hidden
+    e = t(enc)
+    ep = F.linear(rb(e), rb(t(W[jp + "enc_proj_.weight"])), t(W[jp + "enc_proj_.bias"]))
+    h = [torch.zeros(Hp) for _ in range(L)]
+    c = [torch.zeros(Hp) for _ in range(L)]
+    tok, tt, T = cfg.blank_id, 0, e.shape[0]
+    lab_rows, dur_rows = [], []
+    for k, di in zip(labels, dur_idx):
+        if tt >= T:
+            break
+        sh, sc = [v.clone() for v in h], [v.clone() for v in c]
+        x = E[tok]
+        for l in range(L):
+            wih = t(W[f"prediction_.lstm_.cells_.{l}.input_proj_.weight"])
+            g = F.linear(x, rb(wih) if l > 0 else wih, t(W[f"prediction_.lstm_.cells_.{l}.input_proj_.bias"])) \
+                + F.linear(h[l], rb(t(W[f"prediction_.lstm_.cells_.{l}.hidden_proj_.weight"])))
+            i, f, gg, o = g.chunk(4)
+            c[l] = torch.sigmoid(f) * c[l] + torch.sigmoid(i) * torch.tanh(gg)
+            h[l] = rb(torch.sigmoid(o) * torch.tanh(c[l]))
+            x = h[l]
+        z = rb(F.relu(ep[tt] + F.linear(x, rb(t(W[jp + "pred_proj_.weight"])))))
+        lab_rows.append(torch.log_softmax(F.linear(z, rb(t(W[jp + "label_proj_.weight"])), t(W[jp + "label_proj_.bias"])), -1).numpy())
+        dur_rows.append(torch.log_softmax(F.linear(z, rb(t(W[jp + "duration_proj_.weight"])), t(W[jp + "duration_proj_.bias"])), -1).numpy())
+        skip = cfg.durations[int(di)] if int(di) < len(cfg.durations) else 1
+        if int(k) == cfg.blank_id:
+            h, c = sh, sc
+            tt += max(skip, 1)
+        else:
+            tok = int(k)
+            tt += skip
+    return np.stack(lab_rows), np.stack(dur_rows)
