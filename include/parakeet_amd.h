@@ -343,8 +343,8 @@ void pk_free(void *p);
  * State kept per stream: pre-emphasis carry + overlap samples (StreamingAudioPreprocessor, audio.cpp:171-259), leftover mel
  * frames, per-layer K/V and conv caches (EncoderCache, streaming_encoder.hpp:25-41), LSTM state + last token + frame offset
  * (StreamingDecodeState, eou.hpp:80-87).  att_context_left / right: StreamingEncoderConfig (streaming_encoder.hpp:17-23;
- * Nemotron 70 / latency_frames, EOU 70 / 1).  xscaling and the SiLU subsampling variant of that config are not implemented
- * (no shipped preset enables them). */
+ * Nemotron 70 / latency_frames, EOU 70 / 1).  pk_config.xscaling is honoured (the Sortformer NEST preset sets it:
+ * streaming_encoder.cpp:444-447); the SiLU subsampling variant of that config is not implemented (no shipped preset enables it). */
 typedef struct pk_stream pk_stream;
 pk_status pk_stream_create(pk_model *m, int n_streams, int att_context_left, int att_context_right, pk_stream **out);
 void pk_stream_free(pk_stream *s);
@@ -362,6 +362,15 @@ pk_status pk_stream_mel(pk_stream *s, const float *pcm, int n_samples, float *ou
 pk_status pk_stream_encode(pk_stream *s, const float *mel, int n_frames, float *enc, int cap_frames, int *n_out);
 pk_status pk_stream_decode(pk_stream *s, const float *enc, int n_frames, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start,
                            int32_t *end, float *conf);
+/* rnnt_streaming_decode_chunk (src/eou.cpp:17-98) of every stream along a GIVEN decision path -- the streaming counterpart of pk_tdt_score
+ * (parity tests of the tolerance-class mode: "TDT logits within stated fp tolerance").  enc[n_streams][n_frames][hidden]; stream s walks
+ * n_steps[s] decisions labels[s][k] / dur_idx[s][k] (both [n_streams][cap]; a duration as an index into pk_config.durations) instead of its
+ * argmax, and the joint's outputs of every step (TDTJoint::forward, src/tdt.cpp:15-24) are recorded: label_logp[n_streams][cap][vocab]
+ * (may be NULL), dur_logp[n_streams][cap][num_durations] (may be NULL); rows beyond a stream's steps are zero.  The LSTM state, last token
+ * and frame offset each stream carries into its next chunk are the ones that path leaves (StreamingDecodeState, eou.hpp:80-87).
+ * n_done[n_streams] (may be NULL) = steps walked (= n_steps[s] for a path the reference's loop can take on this chunk). */
+pk_status pk_stream_score(pk_stream *s, const float *enc, int n_frames, const int32_t *labels, const int32_t *dur_idx, const int32_t *n_steps,
+                          int cap, float *label_logp, float *dur_logp, int32_t *n_done);
 
 /* ---- plain Transformer encoder: TransformerEncoder::forward / TransformerBlock::forward (src/transformer.cpp:15-88) ------------ */
 /* include/parakeet/transformer.hpp:12-21 (TransformerConfig), dropout omitted (inference). */

@@ -477,6 +477,27 @@ class Stream:
         k = int(ns[0])
         return dict(ids=ids[:n], start=st[:n], end=en[:n], conf=cf[:n], step_label=sl[:k], step_margin=sm[:k])
 
+    def score(self, enc, labels=None, dur_idx=None):
+        """orc_stream_score: the chunk loop of rnnt_streaming_decode_chunk (src/eou.cpp:17-98) along a GIVEN decision path (labels[k], dur_idx[k];
+        None: its own greedy path), the stream's LSTM state / last token carried in and out -> every step's joint outputs."""
+        enc = _c(enc)
+        c = enc.shape[0]
+        cfg = self.model.cfg
+        V, D = cfg.vocab_size, len(cfg.durations)
+        cap = int(len(labels) if labels is not None else c * (cfg.max_symbols_per_step + 1) + 16)
+        L = lib()
+        f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.orc_stream_score.argtypes = [C.c_void_p, f32p, C.c_int, i32p, i32p, C.c_int, i32p, i32p, f32p, f32p]
+        lab_out = np.full(max(cap, 1), -1, np.int32); dur_out = np.full(max(cap, 1), -1, np.int32)
+        llp = np.zeros((max(cap, 1), V), np.float32); dlp = np.zeros((max(cap, 1), D), np.float32)
+        li = _c(labels, np.int32) if labels is not None else None
+        di = _c(dur_idx, np.int32) if labels is not None else None
+        n = L.orc_stream_score(self._h, _f(enc), c, _i(li) if li is not None else None, _i(di) if di is not None else None, cap,
+                               _i(lab_out), _i(dur_out), _f(llp), _f(dlp))
+        if n < 0:
+            raise RuntimeError(L.orc_last_error().decode())
+        return dict(n=n, labels=lab_out[:n], dur_idx=dur_out[:n], label_lp=llp[:n], dur_lp=dlp[:n])
+
     def sortformer_chunk(self, feats, sf):
         """Sortformer::diarize_chunk (src/sortformer.cpp:123-150) on feats [n_frames][mel] -> probs [c][S] (c may be 0)."""
         feats = _c(feats)

@@ -1486,8 +1486,10 @@ int orc_tdt_greedy_boosted(orc_model *m, const float *enc, int B, int T, int max
  * label_lp[k][V], dur_lp[k][D] (either may be NULL) = the joint's log-softmax outputs of step k (TDTJoint::forward, :15-24).
  * Returns the number of steps evaluated (<= n_steps: the walk ends when the frame pointer leaves the utterance), -1 on error.
  */
-int orc_tdt_score(orc_model *m, const float *enc, int T, const int32_t *labels_in, const int32_t *dur_in, int n_steps, int32_t *labels_out,
-                  int32_t *dur_out, float *label_lp, float *dur_lp) {
+static int tdt_score_ex(orc_model *m, const float *enc, int T, const int32_t *labels_in, const int32_t *dur_in, int n_steps, int32_t *labels_out,
+                        int32_t *dur_out, float *label_lp, float *dur_lp,
+                        float *state_hc /* optional [2][L][Hp] carried LSTM state (in/out); NULL: zeros */,
+                        int32_t *state_token /* optional carried last token (in/out); NULL: blank */) {
     const orc_config *c = &m->cfg;
     dec_weights w;
     if (dec_weights_get(m, &w, 0)) return -1;
@@ -1496,13 +1498,14 @@ int orc_tdt_score(orc_model *m, const float *enc, int T, const int32_t *labels_i
     float *ep = (float *)xmalloc((size_t)T * J * sizeof(float));
     linear_t(m->cfg.gemm_bf16, w.we, w.be, T, enc, d, ep, J, 1);
     float *h = (float *)calloc((size_t)w.L * Hp * 2, sizeof(float)), *cc = h + w.L * Hp;
+    if (state_hc) memcpy(h, state_hc, (size_t)w.L * Hp * 2 * sizeof(float));
     float *sh = (float *)xmalloc((size_t)w.L * Hp * 2 * sizeof(float));
     float *pred = (float *)xmalloc((size_t)Hp * sizeof(float));
     float *z = (float *)xmalloc((size_t)J * sizeof(float));
     float *scratch = (float *)xmalloc((size_t)(8 * Hp + J) * sizeof(float));
     float *lab = (float *)xmalloc((size_t)V * 2 * sizeof(float)), *lab_lp = lab + V;
     float dur[16], dlp[16];
-    int token = c->blank_id, t = 0, k = 0, bad = 0;
+    int token = state_token ? *state_token : c->blank_id, t = 0, k = 0, bad = 0;
     for (; k < n_steps && t < T; ++k) {
         memcpy(sh, h, (size_t)w.L * Hp * 2 * sizeof(float));
         predict_step(&w, token, h, cc, pred, scratch);
@@ -1529,9 +1532,15 @@ int orc_tdt_score(orc_model *m, const float *enc, int T, const int32_t *labels_i
             if (skip > 0) t += skip;
         }
     }
+    if (state_hc && !bad) memcpy(state_hc, h, (size_t)w.L * Hp * 2 * sizeof(float));
+    if (state_token && !bad) *state_token = token;
     free(ep); free(h); free(sh); free(pred); free(z); free(scratch); free(lab);
     if (bad) return orc_fail("orc_tdt_score: forced label / duration index out of range at step %d", k);
     return k;
+}
+int orc_tdt_score(orc_model *m, const float *enc, int T, const int32_t *labels_in, const int32_t *dur_in, int n_steps, int32_t *labels_out,
+                  int32_t *dur_out, float *label_lp, float *dur_lp) {
+    return tdt_score_ex(m, enc, T, labels_in, dur_in, n_steps, labels_out, dur_out, label_lp, dur_lp, NULL, NULL);
 }
 
 /* rnnt_greedy_decode(+_with_timestamps): src/rnnt.cpp:56-111, :115-177 ; RNNTJoint::forward :37-44 */
@@ -1855,6 +1864,18 @@ int orc_stream_decode_ex(orc_stream *s, const float *enc, int c, int max_tokens,
 }
 int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf) {
     return orc_stream_decode_ex(s, enc, c, max_tokens, ids, start, end, conf, NULL, NULL, 0, NULL);
+}
+/* The same chunk loop (src/eou.cpp:17-98) along a GIVEN decision path -- orc_tdt_score with the stream's carried LSTM state and last token
+ * (StreamingDecodeState, eou.hpp:80-87): the decisions of the chunk's steps are labels_in[k] / dur_in[k] (NULL: the greedy ones, reported in
+ * labels_out / dur_out), the joint's log-softmax outputs of every step are recorded, and the state the stream carries into the next chunk is
+ * the one the reference's loop holds after deciding that way.  Returns the number of steps walked (the chunk is over when the frame pointer
+ * leaves it -- a duration that skips past its end is lost, :31-33,95 -- or after n_steps). */
+int orc_stream_score(orc_stream *s, const float *enc, int c, const int32_t *labels_in, const int32_t *dur_in, int n_steps, int32_t *labels_out,
+                     int32_t *dur_out, float *label_lp, float *dur_lp) {
+    const int k = tdt_score_ex(s->m, enc, c, labels_in, dur_in, n_steps, labels_out, dur_out, label_lp, dur_lp, s->hc, &s->token);
+    if (k < 0) return -1;
+    s->frame_offset += c;
+    return k;
 }
 
 /* Sortformer::diarize_chunk (src/sortformer.cpp:123-150): forward_chunk of the NEST encoder with the stream's caches, then

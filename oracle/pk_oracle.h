@@ -112,6 +112,9 @@ void orc_stream_free(orc_stream *s);
 int orc_stream_mel(orc_stream *s, const float *pcm, int n, float *out);
 int orc_stream_encode(orc_stream *s, const float *mel, int n_frames, float *enc, int max_out);
 int orc_stream_decode(orc_stream *s, const float *enc, int c, int max_tokens, int32_t *ids, int32_t *start, int32_t *end, float *conf);
+/* teacher-forced joint scores of ONE chunk along a given (or, labels_in == NULL, the greedy) decision path, state carried: see pk_oracle.c */
+int orc_stream_score(orc_stream *s, const float *enc, int c, const int32_t *labels_in, const int32_t *dur_in, int n_steps, int32_t *labels_out,
+                     int32_t *dur_out, float *label_lp, float *dur_lp);
 
 int orc_sortformer_chunk(orc_stream *s, const float *feats, int n_frames, int n_tlayers, int n_theads, int pre_ln, int has_final_norm,
                          float *probs, int max_out);

@@ -325,6 +325,23 @@ class Stream:
         enc = _c(enc)
         return self._tok(lib().pk_stream_decode, enc, enc.shape[1], max_tokens)
 
+    def score(self, enc, labels, dur_idx, n_steps, rows=True):
+        """pk_stream_score: every stream walks its GIVEN decisions labels[s][:n_steps[s]] / dur_idx[s][...] on this chunk's enc[S][c][d];
+        -> label_lp [S][cap][V] (rows=True), dur_lp [S][cap][D], n [S] steps walked."""
+        enc = _c(enc)
+        labels = _c(labels, np.int32); dur_idx = _c(dur_idx, np.int32); n_steps = _c(n_steps, np.int32)
+        assert enc.shape[0] == self.S and labels.shape == dur_idx.shape and labels.shape[0] == self.S and n_steps.shape == (self.S,)
+        cap = labels.shape[1]
+        cfg = self.model.cfg
+        V, D = cfg.vocab_size, len(cfg.durations)
+        L = lib()
+        L.pk_stream_score.argtypes = [C.c_void_p, f32p, C.c_int, i32p, i32p, i32p, C.c_int, f32p, f32p, i32p]
+        llp = np.zeros((self.S, cap, V), np.float32) if rows else None
+        dlp = np.zeros((self.S, cap, D), np.float32)
+        nd = np.zeros(self.S, np.int32)
+        check(L.pk_stream_score(self._h, _f(enc), enc.shape[1], _i(labels), _i(dur_idx), _i(n_steps), cap, _f(llp) if rows else None, _f(dlp), _i(nd)))
+        return dict(label_lp=llp, dur_lp=dlp, n=nd)
+
     def reset(self):
         check(lib().pk_stream_reset(self._h))
 

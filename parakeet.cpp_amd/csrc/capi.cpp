@@ -1044,8 +1044,9 @@ static void batch_reset(pk_batch *b) {
     b->done.clear();
 }
 
+static const size_t kTokenShrinkBytes = (size_t)512 << 20;   // token arrays of a pipeline (2 slots + 2 decode groups) above which a shorter call re-sizes them
 // The pipeline a Model keeps for the one-call API (pk_transcribe_pcm, every rank of a pk_group): created on first use with ragged capacity
-// (batches of mixed lengths AND uniform ones), re-sized when a call needs more (buffers only grow), freed with the model.
+// (batches of mixed lengths AND uniform ones), re-sized when a call needs more (buffers only grow; the token arrays may shrink, see below), freed with the model.
 static pk_batch *model_pipeline(Model &m, int max_clips, int64_t max_total, int64_t max_clip) {
     m.require_gpu();
     if (!m.pipe) {
@@ -1060,8 +1061,19 @@ static pk_batch *model_pipeline(Model &m, int max_clips, int64_t max_total, int6
     b->staged = -1;
     b->n_clips = 0;
     const Workspace &w = b->ws[0];
-    // the capacity never shrinks (the output pitches T / max_tokens follow the longest clip the pipeline has been sized for)
-    batch_size_ragged(b, std::max(max_clips, w.rag_cap_clips), std::max(max_total, w.rag_cap_samples), std::max(max_clip, w.rag_cap_clip));
+    // Buffers only grow -- except the token arrays, the one allocation pitched (clips x longest clip x max_symbols): when the pipeline was
+    // sized for a clip at least twice as long as anything in this call and those arrays are large, they are released and re-reserved for this
+    // call's longest clip, so that one long file does not make every later batch carry (and copy, and zero) its pitch (round-4 advisor finding).
+    int64_t clip_cap = std::max(max_clip, w.rag_cap_clip);
+    size_t tok = 0;
+    for (auto &x : b->ws) tok += x.token_bytes();
+    for (auto &G : b->grp) tok += G.w.token_bytes();
+    if (tok > kTokenShrinkBytes && max_clip * 2 <= w.rag_cap_clip) {
+        for (auto &x : b->ws) x.release_tokens();
+        for (auto &G : b->grp) { b->forget(&G.w); G.w.release_tokens(); }
+        clip_cap = max_clip;
+    }
+    batch_size_ragged(b, std::max(max_clips, w.rag_cap_clips), std::max(max_total, w.rag_cap_samples), clip_cap);
     return b;
 }
 
@@ -1156,7 +1168,7 @@ static void transcribe_clips(Model &m, const float *pcm, const int64_t *offsets,
     // Mixed-length batching (the reference's roadmap item "batch inference: pad + length-mask", README.md:513 -- done by PACKING, no padding
     // and no masks: every clip keeps its own extents in every kernel and comes out bit-identical to a single-clip call).  The clips are
     // sorted by length, longest first (the position tables and the workspace are then sized once, by the first batch), and packed greedily
-    // into batches of at most kMaxBatchClips clips and kBatchSamples samples -- neighbours in length share a batch, so the lock-step decode
+    // into batches of at most kMaxBatchClips clips and kBatchRows encoder rows -- neighbours in length share a batch, so the lock-step decode
     // loop of a batch ends for all of them at about the same step.  The batches go through the model's two-stream pipeline (struct
     // pk_batch): PCM of batch k+1 is staged on the copy stream and decode(k) -- or, from four batches on, the decode loops of four batches as
     // one lock-step group -- runs under encoder(k+1).  A batch whose clips all have the same length runs the plain uniform kernels.
@@ -1168,26 +1180,41 @@ static void transcribe_clips(Model &m, const float *pcm, const int64_t *offsets,
     plan_batches(clip_len.data(), n_clips, order, bstart);
     for (auto &o : order) o = clips[o];                            // ... as global clip indices from here on
     auto len_of = [&](int i) { return offsets[order[i] + 1] - offsets[order[i]]; };
-    int64_t cap_total = 0;
-    int cap_clips = 0;
-    for (size_t k = 0; k + 1 < bstart.size(); ++k) {
-        int64_t tot = 0;
-        for (int i = bstart[k]; i < bstart[k + 1]; ++i) tot += len_of(i);
-        cap_total = std::max(cap_total, tot);
-        cap_clips = std::max(cap_clips, bstart[k + 1] - bstart[k]);
-    }
-    const int nb = (int)bstart.size() - 1;
+    const int nb_all = (int)bstart.size() - 1;
+    // The output arrays of a pipeline are pitched (clips x longest clip x max_symbols).  With the clips sorted longest first, one very long
+    // file in front of many short ones would make every batch of the call carry its pitch (a 1 h file and 256 short clips: ~0.5 GB per array,
+    // per slot and decode group, copied and zeroed per batch -- round-4 advisor finding).  So the batch list is cut into SEGMENTS, each run
+    // through the pipeline sized for its own longest clip: a new segment starts where the clips have become four times shorter than the
+    // segment's first AND the segment's token arrays would be large.  Ordinary calls (10 s .. a few minutes per clip) are one segment.
+    const int sym = m.cfg.max_symbols_per_step > 0 ? m.cfg.max_symbols_per_step : 10;
+    auto frames_of = [&](int64_t n) { return (int64_t)pk_encoder_num_frames(pk_mel_num_frames(n)); };
     std::vector<int32_t> ids, st, en, lens;
     std::vector<float> cf;
-    pk_batch *b = model_pipeline(m, cap_clips, cap_total, len_of(0));
+    for (int kseg = 0; kseg < nb_all;) {
+    const int seg0 = kseg;
+    int64_t cap_total = 0;
+    int cap_clips = 0;
+    const int64_t seg_T = frames_of(len_of(bstart[seg0]));
+    for (; kseg < nb_all; ++kseg) {
+        const int nc = bstart[kseg + 1] - bstart[kseg];
+        if (kseg > seg0 && len_of(bstart[kseg]) * 4 <= len_of(bstart[seg0]) &&
+            (size_t)std::max(cap_clips, nc) * seg_T * sym * 4 * 4 > kTokenShrinkBytes / 8) break;
+        int64_t tot = 0;
+        for (int i = bstart[kseg]; i < bstart[kseg + 1]; ++i) tot += len_of(i);
+        cap_total = std::max(cap_total, tot);
+        cap_clips = std::max(cap_clips, nc);
+    }
+    const int nb = kseg - seg0;                                    // batches seg0 .. kseg-1 run as one pipeline pass
+    pk_batch *b = model_pipeline(m, cap_clips, cap_total, len_of(bstart[seg0]));
     try {
         batch_set_group(b, (decoder == PK_DECODER_TDT && nb >= 4) ? 4 : 1);
         const int64_t first_seq = b->runs;
         const int mt = b->ws[0].max_tokens;
         std::vector<char> taken(nb, 0);
         std::vector<int64_t> blens;
+        const int *bs = bstart.data() + seg0;                      // (the lambdas below index the segment's batches 0 .. nb-1)
         auto stage = [&](int k) {
-            const int c0 = bstart[k], nc = bstart[k + 1] - c0;
+            const int c0 = bs[k], nc = bs[k + 1] - c0;
             blens.resize(nc);
             for (int i = 0; i < nc; ++i) blens[i] = len_of(c0 + i);
             batch_stage(b, nc, [&](int i) { return pcm + offsets[order[c0 + i]]; }, blens.data());
@@ -1204,7 +1231,7 @@ static void transcribe_clips(Model &m, const float *pcm, const int64_t *offsets,
                 PK_HIP(hipEventSynchronize(L.ev));
                 copy_results(L, ids.data(), lens.data(), ts ? st.data() : nullptr, ts ? en.data() : nullptr, ts ? cf.data() : nullptr);
                 for (int i = 0; i < B; ++i) {
-                    const int c = order[bstart[k] + i];
+                    const int c = order[bs[k] + i];
                     if (lens[i] < 0) fail(PK_ERR_DECODE_CAP, "TDT decode hit the safety cap on clip %d", c);
                     const int n = lens[i];
                     R.ids[c].assign(ids.begin() + (size_t)i * mt, ids.begin() + (size_t)i * mt + n);
@@ -1235,11 +1262,12 @@ static void transcribe_clips(Model &m, const float *pcm, const int64_t *offsets,
         batch_flush(b);
         drain();
         for (int k = 0; k < nb; ++k)
-            if (!taken[k]) fail(PK_ERR_HIP, "internal: batch %d of the pipeline produced no result", k);
+            if (!taken[k]) fail(PK_ERR_HIP, "internal: batch %d of the pipeline produced no result", seg0 + k);
     } catch (...) {
         batch_reset(b);
         throw;
     }
+    }   // segments
 }
 
 static std::unique_ptr<ResultStore> new_store(int n_clips) {

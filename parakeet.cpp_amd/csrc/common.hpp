@@ -52,6 +52,11 @@ struct DevBuf {
         PK_HIP(hipMalloc(&p, bytes));
         cap = bytes;
     }
+    void release() {                      // give the memory back (the next reserve allocates afresh)
+        if (p) PK_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 

@@ -756,7 +756,11 @@ bool Model::attn_bf16(int T) const {
 // the row-wise pos_proj_ product.  Shorter sequences and the utterances of a ragged batch read their window of it (launch_relpos_attention:
 // pos_row0 / SeqRag::pos_T); the tables are rebuilt only when a longer sequence arrives.
 void Model::ensure_pos_tables(int T, hipStream_t s) {
-    if (T <= pos_T && pos_bf16 == attn_bf16(T)) return;
+    const bool want16 = attn_bf16(T);
+    PosTab &tab_set = want16 ? pos16 : pos32;
+    if (T <= tab_set.T) return;
+    DevBuf &pos_proj = tab_set.proj, &pos_cvec = tab_set.cvec;
+    int &pos_T = tab_set.T;
     const int d = cfg.hidden_size, P = 2 * T - 1;
     std::vector<float> pe((size_t)P * d);
     for (int p = 0; p < P; ++p) {
@@ -783,10 +787,8 @@ void Model::ensure_pos_tables(int T, hipStream_t s) {
             launch_pos_cvec(tab, layers[l].pos_u, layers[l].pos_v, P, d, H, pos_cvec.as<float>() + (size_t)l * H * P, s);
         }
         pos_T = T;
-        pos_bf16 = true;
         return;
     }
-    pos_bf16 = false;
     for (int l = 0; l < cfg.num_layers; ++l) {
         // written in the sigma column layout the attention kernel loads its MFMA operands in (kernels.hpp: GemmArgs::sigma_cols)
         GemmArgs g{pos_pe.as<float>(), d, layers[l].wpos, d, nullptr, pos_proj.as<float>() + (size_t)l * P * d, d, nullptr, 0, 1.0f, P, d, d};
@@ -892,7 +894,9 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
         att_scratch_p = att_scratch.as<float>();
     }
     ensure_pos_tables(T, s);
-    const int P = 2 * pos_T - 1;                                     // rows of the resident tables (built for pos_T >= T frames)
+    const PosTab &ptab = pos_tab(T);                                 // the resident set of this batch's attention format
+    const int pos_T = ptab.T, P = 2 * pos_T - 1;                     // its rows (built for pos_T >= T frames)
+    const DevBuf &pos_proj = ptab.proj, &pos_cvec = ptab.cvec;
     const int a16 = cfg.gemm_bf16 ? 1 : 0;                           // bf16 mode: LayerNorm outputs stored as bf16 GEMM operands (ffn())
     const bool att16 = attn_bf16(T);                                 // ... and q / k / v as bf16 for the bf16-MFMA attention kernel
     if (rg) {
@@ -1086,9 +1090,12 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     st.keep_state = keep_state ? 1 : 0;
     st.Tb = w.dec_Tb; st.row0 = w.dec_row0;                          // ragged batch / decode group of ragged runs (null: uniform, T frames each)
     if (w.force_label) {                                             // pk_tdt_score: walk a given decision path, record the joint's outputs
-        if (B != 1 || boost_on || keep_state || D <= 0) fail(PK_ERR_UNSUPPORTED, "teacher-forced scoring takes one utterance of a TDT model, unboosted");
+        const bool batched = w.force_stride > 0 && w.n_force_b;          // pk_stream_score: every stream of a lock-step chunk, state carried
+        if (boost_on || D <= 0 || (!batched && (B != 1 || keep_state)))
+            fail(PK_ERR_UNSUPPORTED, "teacher-forced scoring takes one utterance (or the streams of one chunk) of a TDT model, unboosted");
         st.force_label = w.force_label; st.force_dur = w.force_dur; st.n_force = w.n_force;
         st.score_lab = w.score_lab; st.score_dur = w.score_dur;
+        if (batched) { st.n_force_b = w.n_force_b; st.force_stride = w.force_stride; }
     }
     if (boost_on) {
         if (cfg.rnnt_head || keep_state) fail(PK_ERR_UNSUPPORTED, "phrase boosting applies to the CTC and TDT greedy decoders only (src/phrase_boost.cpp)");
@@ -1215,7 +1222,8 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         KL("tdt_decide", 0.0, 0.0, launch_tdt_decide(st, s));
     };
     // PK_DECODE_LOOP_GRAPH: the chunk of 16 steps is captured once into a hipGraph (every argument is step-invariant) and replayed.
-    const bool want_graph = decode_loop == PK_DECODE_LOOP_GRAPH;
+    // (teacher-forced scoring launches another decision kernel on per-call arrays: it never shares a captured graph with the decode loop)
+    const bool want_graph = decode_loop == PK_DECODE_LOOP_GRAPH && !w.force_label;
     if (want_graph && !prof) {
         // key = the pointer / size arguments the captured launches carry, field by field (no struct padding in the comparison) + the model's
         // weight generation (a graph never outlives the weights it was captured against: the workspace is keyed by model + stream)

@@ -88,6 +88,8 @@ struct Workspace {
     const int *force_label = nullptr, *force_dur = nullptr;
     int n_force = 0;
     float *score_lab = nullptr, *score_dur = nullptr;
+    const int *n_force_b = nullptr;               // pk_stream_score: per-stream step counts; arrays of stream b start at b * force_stride
+    int force_stride = 0;
     const int *dec_Tb = nullptr, *dec_row0 = nullptr;   // decode loop on a ragged batch: frames / first enc_proj row of every utterance (device; null = uniform)
     int64_t rows(int B_run) const { return ragged ? rag.sum_T : (int64_t)B_run * T_run; }   // packed encoder rows of the current run
     int t_max() const { return ragged ? rag.T_max : T_run; }
@@ -107,6 +109,10 @@ struct Workspace {
     Workspace() = default;
     Workspace(const Workspace &) = delete;
     Workspace &operator=(const Workspace &) = delete;
+    // the per-utterance token arrays are pitched B x T x max_symbols: the only buffers that grow with (clips x longest clip); released when a
+    // pipeline is re-sized for much shorter clips (capi.cpp model_pipeline), re-reserved by the next size_* call
+    void release_tokens() { ids.release(); start.release(); end.release(); conf.release(); }
+    size_t token_bytes() const { return ids.cap + start.cap + end.cap + conf.cap; }
     void size_for(const pk_config &cfg, int B, int64_t n_samples, int Tm);
     void size_decode(const pk_config &cfg, int B, int T, size_t rows_cap = 0);     // TDT / RNNT decode state only (rows_cap: enc_proj rows, default B * T)
     void reserve_decode(const pk_config &cfg);
@@ -155,10 +161,16 @@ class Model {
 
     // relative-position tables: sinusoidal pe [2T-1][d] (src/encoder.cpp:9-30, host float math) and the
     // per-layer pos_proj_(pe) [L][2T-1][d]; they depend on (T, weights) only, so they are rebuilt when T changes.
-    int pos_T = 0;              // the tables hold 2 pos_T - 1 rows; a shorter sequence of T frames uses rows [pos_T - T, pos_T + T - 1): identical values
-    bool pos_bf16 = false;      // ... in the bf16 attention's format
-    DevBuf pos_pe, pos_proj;
-    DevBuf pos_cvec;            // bf16 attention: (v_h - u_h) . P_p per (layer, head, p)
+    // One resident table set per attention FORMAT (fp32 sigma columns / the bf16 kernel's): which kernel a batch runs depends on its longest
+    // utterance (attn_bf16(T)), and a service alternating long and short batches in the bf16 mode must not rebuild every layer's table on
+    // every batch (round-4 advisor finding).  A set holds 2 T - 1 rows; a shorter sequence of T' frames uses rows [T - T', T + T' - 1): identical values.
+    struct PosTab {
+        int T = 0;
+        DevBuf proj;            // pos_proj_ of every layer [L][2T-1][d]
+        DevBuf cvec;            // bf16 attention: (v_h - u_h) . P_p per (layer, head, p)
+    } pos32, pos16;
+    DevBuf pos_pe;
+    const PosTab &pos_tab(int T) const { return attn_bf16(T) ? pos16 : pos32; }
     bool attn_bf16(int T) const;    // the bf16-MFMA attention kernel applies (gemm_bf16 mode, head size 64 / 128, strip + c band fit LDS)
     DevBuf att_scratch;         // score blocks of the attention kernel for sequences too long for LDS (grow-only)
     void ensure_pos_tables(int T, hipStream_t s);

@@ -301,6 +301,16 @@ template <bool BOOST, bool COH, bool SCORE = false>
 __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (dd_ldi<COH>(st.done + b)) return;
+    int n_force = 0;                                               // SCORE: steps of this utterance's given path, first element of its arrays
+    int64_t force_off = 0;
+    if constexpr (SCORE) {
+        n_force = st.n_force_b ? st.n_force_b[b] : st.n_force;
+        force_off = (int64_t)b * st.force_stride;
+        if (st.force_label && n_force <= 0) {                      // nothing to walk in this chunk: finished before the first decision
+            if (tid == 0) { st.lens[b] = 0; dd_sti<COH>(st.done + b, 1); atomicAdd(st.done_count, 1); if (st.need) dd_sti<COH>(st.need + b, 0); }
+            return;
+        }
+    }
     // ragged batch (TdtState::Tb / row0): this utterance's frame count, first enc_proj row and its own cap on joint evaluations
     const int Tb = st.Tb ? st.Tb[b] : st.T;
     const int64_t ep_row0 = st.row0 ? (int64_t)st.row0[b] : (int64_t)b * st.T;
@@ -481,15 +491,15 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     if (st.D > 0) skip = (int)red[5];
     if constexpr (SCORE && !BOOST) {
         if (st.score_lab) {                                        // teacher-forced scoring: the label log-prob row as the joint returns it (its own pass:
-            float *row = st.score_lab + (int64_t)steps_in * st.V;   // nothing of it sits in the decode loop's argmax sweep)
+            float *row = st.score_lab + (force_off + steps_in) * st.V;   // nothing of it sits in the decode loop's argmax sweep)
             for (int i = tid; i < st.V; i += 256) row[i] = (x[i] - m) - lse;
         }
         if (st.force_label) {                                      // teacher-forced scoring (TdtState::force_label): the given decision, not the argmax
-            if (st.score_dur && tid < st.D) st.score_dur[(int64_t)steps_in * st.D + tid] = e[st.V + tid];
-            const int k = steps_in < st.n_force ? steps_in : st.n_force - 1;
-            lab.idx = st.force_label[k];
+            if (st.score_dur && tid < st.D) st.score_dur[(force_off + steps_in) * st.D + tid] = e[st.V + tid];
+            const int k = steps_in < n_force ? steps_in : n_force - 1;
+            lab.idx = st.force_label[force_off + k];
             lab.lp = (x[lab.idx] - m) - lse;
-            if (st.D > 0) skip = st.durations[st.force_dur[k]];
+            if (st.D > 0) skip = st.durations[st.force_dur[force_off + k]];
         }
     }
     const int lane0 = tid;                                         // thread 0 writes the scalar state
@@ -561,7 +571,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         // prediction-net caching (TdtState::need): a token changed (token, h, c) -> the next step runs the cells and pred_proj again; a blank
         // changed only the frame -> this workgroup forms next step's z = relu(enc_proj[t'] + pp) from the cached pp (SK_ACT's epilogue, same
         // operand order: enc_proj + (pred_proj [+ bias]))
-        const bool fin = t >= Tb || (max_steps_b > 0 && nsteps >= max_steps_b) || (SCORE && st.force_label && nsteps >= st.n_force);
+        const bool fin = t >= Tb || (max_steps_b > 0 && nsteps >= max_steps_b) || (SCORE && st.force_label && nsteps >= n_force);
         if (tid == 0) dd_sti<COH>(st.need + b, (commit && !fin) ? 1 : 0);
         if (!commit && !fin) {
             const float *epr = st.ep + (ep_row0 + t) * st.J, *ppr = st.pp + (int64_t)b * st.J;
@@ -574,7 +584,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         }
     }
     if (lane0 == 0) {
-        bool finished = t >= Tb || (SCORE && st.force_label && nsteps >= st.n_force);
+        bool finished = t >= Tb || (SCORE && st.force_label && nsteps >= n_force);
         int len = n_out < st.max_tokens ? n_out : st.max_tokens;
         if (!finished && max_steps_b > 0 && nsteps >= max_steps_b) { finished = true; len = -1; }   // safety cap
         dd_sti<COH>(st.t + b, t);

@@ -44,24 +44,27 @@ typedef __bf16 sb_bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kSbMaxWaves = 8;      // waves per workgroup (2 per SIMD: 256 VGPRs each -- the up-front slices need them)
 
 template <int EPI, int STEPS /* MFMA steps (32 k each) per K slice */, int RT /* 16-row MFMA tiles per wave */, bool A16 /* A is bf16 [M][lda] */,
-          bool LN /* fold LayerNorm(A; ln_g, ln_b, ln_eps) in: A fp32, STEPS = 8, one slice per wave */>
+          bool LN /* fold LayerNorm(A; ln_g, ln_b, ln_eps) in: A fp32, STEPS = 8 or 4, one slice per wave */,
+          int CT = 1 /* 16-column tiles per wave: the activation registers of a K slice feed CT weight tiles (round 5) */, bool NTW = false /* non-temporal weight loads */>
 __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(GemmArgs g, int split /* waves = K slices in flight */,
                                                                             int rvalid /* rows of a 16-row tile that exist: 16, or 8 (RT = 1) */) {
-    constexpr int NW = (EPI == EPI_GLU) ? 2 : 1;                    // weight tiles per wave (GLU: value rows [0, N), gate rows [N, 2N))
+    constexpr int NW = (EPI == EPI_GLU) ? 2 : 1;                    // weight tiles per column tile (GLU: value rows [0, N), gate rows [N, 2N))
     constexpr int SL = 32 * STEPS;
-    static_assert(!LN || (!A16 && STEPS == 8), "the folded LayerNorm reads fp32 rows in slices of 256 k");
-    __shared__ sb_f32x4 part[kSbMaxWaves][NW][RT][64];              // partial sums [wave][weight tile][row tile][lane]
+    static_assert(!LN || (!A16 && (STEPS == 8 || STEPS == 4)), "the folded LayerNorm reads fp32 rows in slices of 256 (128) k");
+    __shared__ sb_f32x4 part[kSbMaxWaves][NW][CT][RT][64];          // partial sums [wave][weight tile][column tile][row tile][lane]
     __shared__ __attribute__((aligned(16))) float gam[LN ? kSbMaxWaves : 1][LN ? SL : 4], bet[LN ? kSbMaxWaves : 1][LN ? SL : 4];
     __shared__ float st1[LN ? kSbMaxWaves : 1][RT][16], st2[LN ? kSbMaxWaves : 1][RT][16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (RT == 2 ? 32 : rvalid);
+    const int n0 = blockIdx.x * 16 * CT, m0 = blockIdx.y * (RT == 2 ? 32 : rvalid);
     const int nslices = g.K / SL;
 
-    // epilogue operands of the waves that will finish the tile (wave t < RT finishes row tile t): requested before the weight stream
-    const int col = n0 + r;
+    // epilogue operands of the waves that will finish the output tiles (wave e < RT * CT finishes row tile e % RT of column tile e / RT):
+    // requested before the weight stream
+    const int et = wave % RT, ec = wave / RT;
+    const int col = n0 + 16 * ec + r;
     float bias = 0.0f, bias_g = 0.0f, res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (wave < RT && col < g.N) {
+    if (wave < RT * CT && col < g.N) {
         if (g.bias) {
             bias = g.bias[col];
             if constexpr (EPI == EPI_GLU) bias_g = g.bias[g.N + col];
@@ -69,23 +72,28 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
         if constexpr (EPI == EPI_RESID) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = m0 + 16 * wave + 4 * kq + i;
+                const int row = m0 + 16 * et + 4 * kq + i;
                 if (4 * kq + i < rvalid && row < g.M) res[i] = g.resid[(int64_t)row * g.ldr + col];
             }
         }
     }
 
-    sb_f32x4 acc[NW][RT];
+    sb_f32x4 acc[NW][CT][RT];
 #pragma unroll
     for (int h = 0; h < NW; ++h)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[h][t] = sb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    int wrow = n0 + r;
-    wrow = wrow < g.N ? wrow : g.N - 1;
-    const __bf16 *wp[NW];
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int h = 0; h < NW; ++h) wp[h] = reinterpret_cast<const __bf16 *>(g.W) + (int64_t)(h * g.N + wrow) * g.ldw + 8 * kq;
+            for (int t = 0; t < RT; ++t) acc[h][c][t] = sb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const __bf16 *wp[NW][CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        int wrow = n0 + 16 * c + r;
+        wrow = wrow < g.N ? wrow : g.N - 1;
+#pragma unroll
+        for (int h = 0; h < NW; ++h) wp[h][c] = reinterpret_cast<const __bf16 *>(g.W) + (int64_t)(h * g.N + wrow) * g.ldw + 8 * kq;
+    }
     const __bf16 *ap16[RT];
     const float *ap32[RT];
 #pragma unroll
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
     //  barriers below are executed by every wave once)
     for (int sl = wave; sl < nslices; sl += split) {
         const int k0 = sl * SL;
-        sb_bf16x8 w[NW][STEPS], a[RT][STEPS];
+        sb_bf16x8 w[NW][CT][STEPS], a[RT][STEPS];
         float4 af[RT][STEPS][2];
         // activations first (L2 hits: they return ahead of the weight stream that follows in the same queue)
 #pragma unroll
@@ -116,19 +124,29 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
             }
         float4 g4 = {0.0f, 0.0f, 0.0f, 0.0f}, b4 = {0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (LN) {
-            g4 = *reinterpret_cast<const float4 *>(g.ln_g + k0 + 4 * lane);
-            b4 = *reinterpret_cast<const float4 *>(g.ln_b + k0 + 4 * lane);
+            if (4 * lane < SL) {
+                g4 = *reinterpret_cast<const float4 *>(g.ln_g + k0 + 4 * lane);
+                b4 = *reinterpret_cast<const float4 *>(g.ln_b + k0 + 4 * lane);
+            }
         }
 #pragma unroll
         for (int h = 0; h < NW; ++h)
 #pragma unroll
-            for (int s = 0; s < STEPS; ++s) w[h][s] = *reinterpret_cast<const sb_bf16x8 *>(wp[h] + k0 + 32 * s);
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) {
+                    const sb_bf16x8 *src = reinterpret_cast<const sb_bf16x8 *>(wp[h][c] + k0 + 32 * s);
+                    if constexpr (NTW) w[h][c][s] = __builtin_nontemporal_load(src);      // each weight byte is read once per chunk: do not keep it
+                    else w[h][c][s] = *src;
+                }
         __builtin_amdgcn_sched_barrier(0);                          // every load of the slice is issued before anything waits
 
         if constexpr (LN) {
             // gamma / beta of this wave's slice: wave-private LDS rows, read back after the barriers below
-            *reinterpret_cast<float4 *>(&gam[wave][4 * lane]) = g4;
-            *reinterpret_cast<float4 *>(&bet[wave][4 * lane]) = b4;
+            if (4 * lane < SL) {
+                *reinterpret_cast<float4 *>(&gam[wave][4 * lane]) = g4;
+                *reinterpret_cast<float4 *>(&bet[wave][4 * lane]) = b4;
+            }
             // statistics of the rows (oracle layer_norm: the mean, then the mean of the squared deviations), two passes over the registers
             const float inv_k = 1.0f / (float)g.K;
             float mean[RT], rstd[RT];
@@ -202,7 +220,9 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
 #pragma unroll
             for (int h = 0; h < NW; ++h)
 #pragma unroll
-                for (int t = 0; t < RT; ++t) acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][s], w[h][s], acc[h][t], 0, 0, 0);
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) acc[h][c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][s], w[h][c][s], acc[h][c][t], 0, 0, 0);
     }
 
     // the K slices meet: partial sums through LDS, added in wave order
@@ -210,18 +230,20 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
 #pragma unroll
         for (int h = 0; h < NW; ++h)
 #pragma unroll
-            for (int t = 0; t < RT; ++t) part[wave][h][t][lane] = acc[h][t];
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int t = 0; t < RT; ++t) part[wave][h][c][t][lane] = acc[h][c][t];
         __syncthreads();
     }
-    if (wave >= RT) return;                                         // (RT = 2 is launched with split >= 2)
-    const int t = wave;                                             // this wave finishes row tile t
-    sb_f32x4 v = acc[0][0], gt = acc[NW - 1][0];
+    if (wave >= RT * CT) return;                                    // (launched with split >= RT * CT whenever RT * CT > 1)
+    const int t = et;                                               // this wave finishes row tile et of column tile ec
+    sb_f32x4 v = acc[0][0][0], gt = acc[NW - 1][0][0];              // (split == 1: RT = CT = 1)
     if (split > 1) {
-        v = part[0][0][t][lane];
-        for (int w2 = 1; w2 < split; ++w2) v += part[w2][0][t][lane];
+        v = part[0][0][ec][t][lane];
+        for (int w2 = 1; w2 < split; ++w2) v += part[w2][0][ec][t][lane];
         if constexpr (EPI == EPI_GLU) {
-            gt = part[0][1][t][lane];
-            for (int w2 = 1; w2 < split; ++w2) gt += part[w2][1][t][lane];
+            gt = part[0][1][ec][t][lane];
+            for (int w2 = 1; w2 < split; ++w2) gt += part[w2][1][ec][t][lane];
         }
     }
     if (col >= g.N) return;
@@ -259,30 +281,66 @@ bool gemm_smallm_bf16_applies(const GemmArgs &a, int epi) {
 bool gemm_smallm_bf16_ln_applies(const GemmArgs &a, int epi) {
     if (!a.ln_g || !a.ln_b || a.a_bf16) return false;
     if (!gemm_smallm_bf16_applies(a, epi)) return false;
+    if (epi == EPI_GLU && a.K / 256 > 4) return false;              // GLU + folded LayerNorm: two weight tiles, fp32 AND bf16 rows per wave -- 4 slices (K <= 1024)
     return a.K / 256 <= kSbMaxWaves;                                // one slice of 256 k per wave
 }
 
 // rows per workgroup: the LARGEST of 32 (two MFMA row tiles per wave) / 16 / 8 that still gives (nearly) every CU a workgroup -- the bytes
 // all workgroups pull together are tiles * ceil(M / R) * 2 K (R + 16), least for the largest R, but a product costs what its busiest CU pulls
-// (header).  RT = 2 needs two waves to finish its two row tiles.
-static int sb_rows_per_wg(const GemmArgs &a, int nslices, bool glu) {
-    const int tiles = (a.N + 15) / 16;
+// (header).  RT = 2 needs two waves to finish its two row tiles.  `tiles` = workgroups along N (column tiles / CT).
+static int sb_rows_per_wg(const GemmArgs &a, int nslices, bool glu, int tiles) {
     // (GLU keeps one row tile per wave: two weight tiles AND two row tiles of fp32 rows do not fit 256 registers)
     if (!glu && a.M > 16 && nslices >= 2 && tiles * ((a.M + 31) / 32) >= 192) return 32;
     if (a.M > 8 && tiles * ((a.M + 15) / 16) >= 192) return 16;
     return 8;
 }
 
-template <int EPI, int STEPS, bool A16, bool LN>
-static void launch_sb(const GemmArgs &a, hipStream_t s) {
+// Tuning of the column tiles per wave (CT) and the weight-load cache policy.  A production build has constants; experiment builds
+// (make EXPERIMENTAL=1) read PK_SB_CT (0 = the heuristic) / PK_SB_NT / PK_SB_ROWS (0 = the heuristic) for A/B runs (tools/experiments/).
+struct SbTune { int ct, nt, rows; };
+static SbTune sb_tune() {
+#ifdef PK_EXPERIMENTAL
+    static const SbTune t = [] {
+        auto rd = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
+        return SbTune{rd("PK_SB_CT", 0), rd("PK_SB_NT", 0), rd("PK_SB_ROWS", 0)};
+    }();
+    return t;
+#else
+    return SbTune{0, 0, 0};
+#endif
+}
+
+template <int EPI, int STEPS, bool A16, bool LN, int CT, bool NTW>
+static void launch_sb_ct(const GemmArgs &a, hipStream_t s, int rows_forced) {
     const int nslices = a.K / (32 * STEPS);
     const int split = nslices < kSbMaxWaves ? nslices : kSbMaxWaves;
-    const int R = sb_rows_per_wg(a, nslices, EPI == EPI_GLU);
-    const dim3 grid((a.N + 15) / 16, (a.M + R - 1) / R), block(64 * split);
+    const int tiles = (a.N + 16 * CT - 1) / (16 * CT);
+    int R = rows_forced ? rows_forced : sb_rows_per_wg(a, nslices, EPI == EPI_GLU, tiles * (CT > 1 ? 2 : 1));
+    if (EPI == EPI_GLU && R == 32) R = 16;
+    if (R == 32 && split < 2 * CT) R = 16;                          // the epilogue needs one wave per (row tile, column tile)
+    const dim3 grid(tiles, (a.M + R - 1) / R), block(64 * split);
     if constexpr (EPI != EPI_GLU) {
-        if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN>), grid, block, 0, s, a, split, 16); return; }
+        if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, CT, NTW>), grid, block, 0, s, a, split, 16); return; }
     }
-    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN>), grid, block, 0, s, a, split, R);
+    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, NTW>), grid, block, 0, s, a, split, R);
+}
+
+template <int EPI, int STEPS, bool A16, bool LN>
+static void launch_sb(const GemmArgs &a, hipStream_t s) {
+    const SbTune t = sb_tune();
+    const int nslices = a.K / (32 * STEPS);
+    const int split = nslices < kSbMaxWaves ? nslices : kSbMaxWaves;
+    // two column tiles per wave: the activation registers of a K slice feed both (half the activation bytes through the CU's L1 per weight
+    // byte).  Needs a wave per output tile (split >= CT) and enough column tiles to keep the CUs busy.
+    int ct = t.ct ? t.ct : 1;
+    if (ct > 1 && (split < ct || a.N % (16 * ct) != 0)) ct = 1;
+    if (ct == 2) {
+        if (t.nt) launch_sb_ct<EPI, STEPS, A16, LN, 2, true>(a, s, t.rows);
+        else launch_sb_ct<EPI, STEPS, A16, LN, 2, false>(a, s, t.rows);
+        return;
+    }
+    if (t.nt) launch_sb_ct<EPI, STEPS, A16, LN, 1, true>(a, s, t.rows);
+    else launch_sb_ct<EPI, STEPS, A16, LN, 1, false>(a, s, t.rows);
 }
 
 template <int EPI>

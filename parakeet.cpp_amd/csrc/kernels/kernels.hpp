@@ -230,12 +230,16 @@ struct TdtState {
     // ragged batches: utterance b has Tb[b] frames, its enc_proj rows start at row0[b] (null: T frames from row b * T); the safety cap on joint
     // evaluations is then per utterance, Tb[b] * (max_symbols + 1) + 16 -- what a single-clip run of that utterance would use
     const int *Tb = nullptr, *row0 = nullptr;
-    // Teacher-forced scoring (pk_tdt_score; ONE utterance): the decision of step k is GIVEN -- label force_label[k], duration
-    // durations[force_dur[k]] -- instead of taken from the argmax, and the step's joint outputs are recorded: score_lab[k][V] label
-    // log-probs, score_dur[k][D] duration log-probs.  The utterance is finished after n_force steps (or when the frame pointer leaves it).
+    // Teacher-forced scoring (pk_tdt_score: ONE utterance; pk_stream_score: every stream of a lock-step chunk): the decision of step k is
+    // GIVEN -- label force_label[k], duration durations[force_dur[k]] -- instead of taken from the argmax, and the step's joint outputs are
+    // recorded: score_lab[k][V] label log-probs, score_dur[k][D] duration log-probs.  The utterance is finished after n_force steps (or when
+    // the frame pointer leaves it).  Batched form: utterance b's arrays start at element b * force_stride (rows b * force_stride + k of the
+    // score arrays) and it walks n_force_b[b] steps (0: nothing to walk, finished at once).
     const int *force_label = nullptr, *force_dur = nullptr;
     int n_force = 0;
     float *score_lab = nullptr, *score_dur = nullptr;
+    const int *n_force_b = nullptr;
+    int force_stride = 0;
 };
 constexpr int kMaxListRows = 2048;  // largest lock-step batch the compacted launches handle (larger batches run every row)
 void launch_tdt_init(const TdtState &st, hipStream_t s);

@@ -327,6 +327,48 @@ void StreamBatch::decode(const float *enc, int c, int max_tokens, int32_t *ids, 
     frame_offset_ += c;
 }
 
+void StreamBatch::score(const float *enc, int c, const int32_t *labels, const int32_t *dur_idx, const int32_t *n_steps, int cap, float *label_logp,
+                        float *dur_logp, int32_t *n_done) {
+    m_.require_gpu();
+    if (c <= 0 || cap <= 0 || !enc || !labels || !dur_idx || !n_steps) fail(PK_ERR_INVALID, "enc / c / labels / dur_idx / n_steps / cap");
+    if (c > dec_cap_frames_) fail(PK_ERR_UNSUPPORTED, "chunk of %d encoder frames exceeds the stream's decode workspace (%d)", c, dec_cap_frames_);
+    const int d = m_.cfg.hidden_size, V = m_.cfg.vocab_size, D = m_.cfg.rnnt_head ? 0 : m_.cfg.num_durations;
+    if (V <= 0 || D <= 0) fail(PK_ERR_UNSUPPORTED, "pk_stream_score needs a TDT joint (label + duration heads)");
+    for (int s = 0; s < S; ++s) {
+        if (n_steps[s] < 0 || n_steps[s] > cap) fail(PK_ERR_INVALID, "n_steps[%d] = %d: 0 .. cap", s, n_steps[s]);
+        for (int k = 0; k < n_steps[s]; ++k) {
+            const int32_t l = labels[(size_t)s * cap + k], di = dur_idx[(size_t)s * cap + k];
+            if (l < 0 || l >= V || di < 0 || di >= D) fail(PK_ERR_INVALID, "stream %d step %d: label / duration index out of range", s, k);
+        }
+    }
+    hipStream_t st = m_.stream;
+    const size_t nk = (size_t)S * cap;
+    enc_in_.reserve((size_t)S * c * d * 4);
+    force_.reserve((2 * nk + S) * sizeof(int));
+    score_.reserve(nk * (size_t)(V + D) * 4);
+    int *d_lab = force_.as<int>(), *d_dur = d_lab + nk, *d_n = d_dur + nk;
+    float *d_sl = score_.as<float>(), *d_sd = d_sl + nk * V;
+    PK_HIP(hipMemcpyAsync(enc_in_.p, enc, (size_t)S * c * d * 4, hipMemcpyHostToDevice, st));
+    PK_HIP(hipMemcpyAsync(d_lab, labels, nk * 4, hipMemcpyHostToDevice, st));
+    PK_HIP(hipMemcpyAsync(d_dur, dur_idx, nk * 4, hipMemcpyHostToDevice, st));
+    PK_HIP(hipMemcpyAsync(d_n, n_steps, (size_t)S * 4, hipMemcpyHostToDevice, st));
+    PK_HIP(hipMemsetAsync(d_sl, 0, nk * (size_t)(V + D) * 4, st));
+    struct Scope {
+        Workspace &w;
+        ~Scope() { w.force_label = w.force_dur = w.n_force_b = nullptr; w.score_lab = w.score_dur = nullptr; w.n_force = w.force_stride = 0; }
+    } scope{wd_};
+    wd_.force_label = d_lab; wd_.force_dur = d_dur; wd_.n_force_b = d_n; wd_.force_stride = cap; wd_.n_force = cap;
+    wd_.score_lab = d_sl; wd_.score_dur = d_sd;
+    wd_.T = c;
+    m_.run_tdt(wd_, enc_in_.as<float>(), S, c, wd_.max_tokens, st, /*keep_state=*/true);
+    PK_CHECK_LAUNCH();
+    if (n_done) PK_HIP(hipMemcpyAsync(n_done, wd_.ints.as<int>() + 4 * S, (size_t)S * 4, hipMemcpyDeviceToHost, st));      // TdtState::steps
+    if (label_logp) PK_HIP(hipMemcpyAsync(label_logp, d_sl, nk * (size_t)V * 4, hipMemcpyDeviceToHost, st));
+    if (dur_logp) PK_HIP(hipMemcpyAsync(dur_logp, d_sd, nk * (size_t)D * 4, hipMemcpyDeviceToHost, st));
+    PK_HIP(hipStreamSynchronize(st));
+    frame_offset_ += c;
+}
+
 void StreamBatch::push(const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf) {
     // Validate BEFORE any carried state (pre-emphasis carry, overlap samples, caches) is touched: a rejected push must leave the streams
     // exactly where they were.  Bound on the encoder frames this push can produce: < 8 leftover mel frames + (559 overlap + n_samples) / 160 + 1
@@ -403,6 +445,13 @@ pk_status pk_stream_decode(pk_stream *s, const float *enc, int n_frames, int max
     return stream_guard([&] {
         if (!s || !enc || !ids || !lens) fail(PK_ERR_INVALID, "invalid argument: stream/enc/ids/lens");
         s->s->decode(enc, n_frames, max_tokens, ids, lens, start, end, conf);
+    });
+}
+pk_status pk_stream_score(pk_stream *s, const float *enc, int n_frames, const int32_t *labels, const int32_t *dur_idx, const int32_t *n_steps,
+                          int cap, float *label_logp, float *dur_logp, int32_t *n_done) {
+    return stream_guard([&] {
+        if (!s) fail(PK_ERR_INVALID, "stream");
+        s->s->score(enc, n_frames, labels, dur_idx, n_steps, cap, label_logp, dur_logp, n_done);
     });
 }
 

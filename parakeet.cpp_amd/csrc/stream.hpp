@@ -18,6 +18,11 @@ class StreamBatch {
     // the same, leaving the c output frames per stream on the device (*d_enc -> [S*c][d], valid until the next call); enqueued only
     int encode_keep(const float *mel_in, int n_frames, const float **d_enc);
     void decode(const float *enc, int c, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
+    // rnnt_streaming_decode_chunk (src/eou.cpp:17-98) of every stream along a GIVEN decision path: stream s walks n_steps[s] decisions
+    // labels[s][k] / dur_idx[s][k] (arrays pitched `cap`), the joint's outputs of every step are recorded -- label_logp[s][k][V] (may be null),
+    // dur_logp[s][k][D] -- and the state each stream carries into its next chunk is the one that path leaves.  n_done[s] = steps walked.
+    void score(const float *enc, int c, const int32_t *labels, const int32_t *dur_idx, const int32_t *n_steps, int cap, float *label_logp,
+               float *dur_logp, int32_t *n_done);
     // NemotronTranscriber::transcribe_chunk for S streams; device-resident between the stages
     void push(const float *pcm, int n_samples, int max_tokens, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end, float *conf);
     int S;
@@ -38,7 +43,7 @@ class StreamBatch {
     Workspace ws_;              // encoder workspace of the current chunk
     Workspace wd_;              // decode workspace: h / c / token persist across chunks (never re-allocated)
     int dec_cap_frames_ = 0;
-    DevBuf pre_, mel_dev_, mel_all_, enc_in_;
+    DevBuf pre_, mel_dev_, mel_all_, enc_in_, force_, score_;
     std::map<int, std::unique_ptr<DevBuf>> pos_tables_;   // Tp -> pos_proj of every layer [L][2Tp-1][d], natural columns
     int encode_device(const float *d_mel, int n_frames);                    // -> ws_.x [S*c][d], returns c
     const float *pos_table(int Tp);

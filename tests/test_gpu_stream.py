@@ -326,3 +326,201 @@ def test_full_depth_nemotron_600m_16_streams_bf16_mode(tmp_path):
           f"edit-distance agreement {[round(a, 3) for a in agree]}")
     if gap:
         assert dev < gap, "the GPU should be closer to the bf16 oracle than the bf16 mode is to fp32"
+
+
+# ---- teacher-forced joint scores, chunk by chunk with carried state (pk_stream_score): the logits-level statement of the streaming modes ----
+def test_stream_score_tiny_bit_identical_and_state_carried(tmp_path_factory, orc):
+    """pk_stream_score against orc_stream_score on the tiny model, 5 lock-step streams: every chunk each stream walks the ORACLE's greedy
+    decisions; the label / duration log-prob rows of every step are bit-identical, and -- the carried state being what that path leaves -- a
+    plain pk_stream_decode on the last chunks then emits exactly the oracle's tokens (src/eou.cpp:17-98)."""
+    W, om, gm = G.make_pair(tmp_path_factory.mktemp("ss"), pk.make_tiny_config(), seed=42)
+    S, chunk, n_chunks, n_plain = 5, 2560, 20, 6
+    gs = capi.Stream(gm, S, 70, 1)
+    os_ = [orc.Stream(om, 70, 1) for _ in range(S)]
+    pcm = synth.synth_pcm(S, chunk * n_chunks, seed=31)
+    n_steps_all, n_tok_plain = 0, 0
+    for i in range(n_chunks):
+        seg = pcm[:, i * chunk:(i + 1) * chunk]
+        gmel = gs.mel(seg)
+        omel = [o.mel(seg[s]) for s, o in enumerate(os_)]
+        if gmel.shape[1] == 0:
+            continue
+        genc = gs.encode(gmel)
+        oenc = [o.encode(omel[s]) for s, o in enumerate(os_)]
+        if genc.shape[1] == 0:
+            continue
+        G.assert_bits_equal(genc, np.stack(oenc), f"stream encoder, chunk {i}")
+        if i >= n_chunks - n_plain:                                   # the state left by the forced walks carries a plain decode
+            g = gs.decode(genc)
+            for s, o in enumerate(os_):
+                r = o.decode(oenc[s])
+                assert g["ids"][s, : g["lens"][s]].tolist() == r["ids"].tolist(), f"chunk {i} stream {s}: plain decode after forced walks"
+                n_tok_plain += len(r["ids"])
+            continue
+        rs = [o.score(oenc[s]) for s, o in enumerate(os_)]
+        cap = max(r["n"] for r in rs)
+        lab = np.zeros((S, cap), np.int32); dur = np.zeros((S, cap), np.int32)
+        n = np.array([r["n"] for r in rs], np.int32)
+        for s, r in enumerate(rs):
+            lab[s, : r["n"]], dur[s, : r["n"]] = r["labels"], r["dur_idx"]
+        g = gs.score(genc, lab, dur, n)
+        assert np.array_equal(g["n"], n), f"chunk {i}: steps walked {g['n'].tolist()} vs {n.tolist()}"
+        for s, r in enumerate(rs):
+            G.assert_bits_equal(g["label_lp"][s, : r["n"]], r["label_lp"], f"chunk {i} stream {s}: label log-prob rows")
+            G.assert_bits_equal(g["dur_lp"][s, : r["n"]], r["dur_lp"], f"chunk {i} stream {s}: duration log-probs")
+            assert not g["label_lp"][s, r["n"]:].any(), "rows beyond a stream's steps stay zero"
+        n_steps_all += int(n.sum())
+    gs.close()
+    assert n_steps_all > 50 and n_tok_plain > 0
+
+
+STREAM_SCORE = os.path.join(ROOT, "tests", "golden", "nemotron600m_stream_score_depth24_seed42.npz")
+S_LOGP_TOL, S_LOGP_MEAN = 3e-2, 8e-3   # bf16 streaming mode at depth 24: max / mean |log-prob(gpu) - log-prob(bf16 oracle)| along the oracle's path
+S_FP32_RATIO = 1.25                    # ... and its distance from the fp32 reference arithmetic, as a multiple of the bf16 oracle's own
+
+
+@pytest.fixture(scope="module")
+def stream_score(tmp_path_factory):
+    if not os.path.exists(STREAM_SCORE):
+        pytest.skip("tests/golden/nemotron600m_stream_score_depth24_seed42.npz is missing (tools/make_golden_stream_600m_score.py)")
+    g = np.load(STREAM_SCORE, allow_pickle=False)
+    cfg = pk.make_nemotron_600m_config()
+    W = synth.synth_weights(cfg, seed=int(g["weights_seed"]))
+    wp = str(tmp_path_factory.mktemp("sscore") / "nemotron600m.safetensors")
+    synth.save_weights(wp, W)
+    del W
+    S0, n_chunks, chunk = int(g["n_streams"]), int(g["n_chunks"]), int(g["chunk"])
+    full = synth.synth_pcm(S0, chunk * (int(g["pcm_chunks"]) if "pcm_chunks" in g.files else 80), seed=int(g["pcm_seed"]))   # (the generator synthesises pcm_chunks chunks' worth, whatever n_chunks)
+    assert np.array_equal(np.asarray(full, np.float64).sum(axis=1), g["pcm_digest"]), "the regenerated audio differs from the fixture's"
+    return g, cfg, wp, np.ascontiguousarray(full[:, : chunk * n_chunks])
+
+
+def _walk(gs, g, pcm, prefix, S, on_chunk):
+    """Feed the fixture's sessions (stream s = fixture stream s % S0) through mel -> encode -> pk_stream_score along the path `prefix`."""
+    S0, n_chunks, chunk = int(g["n_streams"]), int(g["n_chunks"]), int(g["chunk"])
+    rep = np.arange(S) % S0
+    x = np.ascontiguousarray(pcm[rep])
+    for i in range(n_chunks):
+        m = gs.mel(x[:, i * chunk:(i + 1) * chunk])
+        c = int(g["enc_n"][i, 0])
+        assert np.all(g["enc_n"][i] == c)
+        if m.shape[1] == 0:
+            assert c == 0
+            continue
+        e = gs.encode(m)
+        assert e.shape[1] == c
+        if c == 0:
+            continue
+        n = g[prefix + "_n"][i][rep].astype(np.int32)
+        cap = int(n.max())
+        r = gs.score(e, g[prefix + "_labels"][i][rep][:, :cap], g[prefix + "_dur_idx"][i][rep][:, :cap], n)
+        assert np.array_equal(r["n"], n), f"chunk {i}: steps walked {r['n'].tolist()}, the path has {n.tolist()}"
+        on_chunk(i, e, r, n, cap, rep)
+
+
+def test_stream_teacher_forced_fp32_rows_bit_identical(stream_score):
+    """configs[4] in fp32 at the logits: 4 sessions x 120 chunks of nemotron-600m (24 layers), every chunk's encoder output carries the fp32
+    oracle's checksums and -- walking that oracle's decision path with the state carried across chunks -- the label log-prob row of EVERY step
+    carries the oracle's bit checksums, its top-8 and the duration log-probs are bit-equal, and the GPU's own argmax is the oracle's decision
+    (/root/reference/src/eou.cpp:17-98, src/tdt.cpp:15-24)."""
+    g, cfg, wp, pcm = stream_score
+    gm = capi.Model(wp, cfg, device=0)
+    S = int(g["n_streams"])
+    gs = capi.Stream(gm, S, int(g["att_left"]), int(g["att_right"]))
+    tot = dict(steps=0, tokens=0)
+
+    def check(i, e, r, n, cap, rep):
+        for s in range(S):
+            u = e[s].view(np.uint32).ravel()
+            assert int(np.bitwise_xor.reduce(u)) == int(g["f32_enc_xor"][i, s]) and int(u.astype(np.uint64).sum()) == int(g["f32_enc_sum"][i, s]), \
+                f"chunk {i} stream {s}: encoder output bits"
+            k = int(n[s])
+            rows = r["label_lp"][s, :k]
+            ub = rows.view(np.uint32)
+            assert np.array_equal(np.bitwise_xor.reduce(ub, axis=1), g["f32_row_xor"][i, s, :k]), f"chunk {i} stream {s}: label rows (xor of bits)"
+            assert np.array_equal(ub.astype(np.uint64).sum(axis=1), g["f32_row_sum"][i, s, :k]), f"chunk {i} stream {s}: label rows (sum of bits)"
+            top = np.take_along_axis(rows, g["f32_top_ids"][i, s, :k].astype(np.int64), axis=1)
+            assert np.array_equal(top.view(np.uint32), g["f32_top_lp"][i, s, :k].view(np.uint32)), f"chunk {i} stream {s}: top-8 label log-probs"
+            assert np.array_equal(r["dur_lp"][s, :k].view(np.uint32), g["f32_dur_lp"][i, s, :k].view(np.uint32)), f"chunk {i} stream {s}: duration log-probs"
+            assert np.array_equal(rows.argmax(axis=1), g["f32_labels"][i, s, :k]), f"chunk {i} stream {s}: the GPU's own argmax along the path"
+            tot["steps"] += k; tot["tokens"] += int((g["f32_labels"][i, s, :k] != cfg.blank_id).sum())
+
+    _walk(gs, g, pcm, "f32", S, check)
+    gs.close(); gm.close()
+    print(f"streaming fp32 teacher-forced: {S} sessions x {int(g['n_chunks'])} chunks, {tot['steps']} steps ({tot['tokens']} tokens): every row bit-identical")
+    assert tot["tokens"] > 200
+
+
+def test_stream_teacher_forced_bf16_within_bound_and_vs_fp32(stream_score):
+    """The tolerance statement of the bf16 STREAMING mode at the logits, over whole sessions (> 200 tokens; a near-tie does not end it):
+      (1) 16 lock-step streams (the 4 fixture sessions x 4) walk the bf16 ORACLE's path chunk by chunk: |delta log-prob| <= S_LOGP_TOL on the
+          oracle's top-8 labels and all durations at EVERY step (mean <= S_LOGP_MEAN), every decision with margin > 2 x S_LOGP_TOL is the
+          GPU's own argmax, and replicas of a session are bit-identical;
+      (2) a second set of sessions walks the FP32 oracle's path: the GPU's distance from the reference's arithmetic (fp32) is at most
+          S_FP32_RATIO x the bf16 oracle's own distance along the same path (fixture b16_on_f32_*), max and mean."""
+    g, cfg, wp, pcm = stream_score
+    cfg16 = dataclasses.replace(cfg, gemm_bf16=True)
+    gm = capi.Model(wp, cfg16, device=0)
+    S0, S = int(g["n_streams"]), 16
+    # (1) along the bf16 oracle's path
+    gs = capi.Stream(gm, S, int(g["att_left"]), int(g["att_right"]))
+    acc = dict(lab=[], dur=[], steps=0, tokens=0, clear=0, agree=0, dec=0)
+
+    def check_b(i, e, r, n, cap, rep):
+        for s in range(S0, S):
+            assert np.array_equal(r["label_lp"][s].view(np.uint32), r["label_lp"][s % S0].view(np.uint32)), f"chunk {i}: replica {s} differs"
+        for s in range(S0):
+            k = int(n[s])
+            rows = r["label_lp"][s, :k]
+            top = np.take_along_axis(rows, g["b16_top_ids"][i, s, :k].astype(np.int64), axis=1)
+            acc["lab"].append(np.abs(top - g["b16_top_lp"][i, s, :k]).ravel()); acc["dur"].append(np.abs(r["dur_lp"][s, :k] - g["b16_dur_lp"][i, s, :k]).ravel())
+            lab, dur, mg = g["b16_labels"][i, s, :k], g["b16_dur_idx"][i, s, :k], g["b16_margin"][i, s, :k]
+            gl, gd = rows.argmax(axis=1), r["dur_lp"][s, :k].argmax(axis=1)
+            cl, cd = mg[:, 0] > 2 * S_LOGP_TOL, mg[:, 1] > 2 * S_LOGP_TOL
+            assert np.array_equal(gl[cl], lab[cl]) and np.array_equal(gd[cd], dur[cd]), f"chunk {i} stream {s}: a decision with margin > {2 * S_LOGP_TOL} differs"
+            acc["steps"] += k; acc["tokens"] += int((lab != cfg.blank_id).sum()); acc["clear"] += int(cl.sum() + cd.sum())
+            acc["agree"] += int((gl == lab).sum() + (gd == dur).sum()); acc["dec"] += 2 * k
+
+    _walk(gs, g, pcm, "b16", S, check_b)
+    gs.close()
+    dl, dd = np.concatenate(acc["lab"]), np.concatenate(acc["dur"])
+    print(f"streaming bf16 teacher-forced along the bf16 oracle's path: {S0} sessions (x4 replicas) x {int(g['n_chunks'])} chunks, {acc['steps']} steps, "
+          f"{acc['tokens']} tokens: label |dlogp| max {dl.max():.3e} mean {dl.mean():.3e}, duration max {dd.max():.3e} mean {dd.mean():.3e} (bound {S_LOGP_TOL} / {S_LOGP_MEAN}); "
+          f"{acc['clear']} of {acc['dec']} decisions have margin > {2 * S_LOGP_TOL} (all agree), {acc['agree']} agree in all")
+    assert acc["tokens"] > 200
+    assert max(dl.max(), dd.max()) <= S_LOGP_TOL and max(dl.mean(), dd.mean()) <= S_LOGP_MEAN
+    # (2) along the fp32 oracle's path: distance from the reference's arithmetic
+    gs = capi.Stream(gm, S0, int(g["att_left"]), int(g["att_right"]))
+    a2 = dict(g=[], o=[])
+
+    def check_a(i, e, r, n, cap, rep):
+        for s in range(S0):
+            k = int(n[s])
+            top = np.take_along_axis(r["label_lp"][s, :k], g["f32_top_ids"][i, s, :k].astype(np.int64), axis=1)
+            a2["g"].append(np.abs(top - g["f32_top_lp"][i, s, :k]).ravel()); a2["g"].append(np.abs(r["dur_lp"][s, :k] - g["f32_dur_lp"][i, s, :k]).ravel())
+            a2["o"].append(np.abs(g["b16_on_f32_top_lp"][i, s, :k] - g["f32_top_lp"][i, s, :k]).ravel())
+            a2["o"].append(np.abs(g["b16_on_f32_dur_lp"][i, s, :k] - g["f32_dur_lp"][i, s, :k]).ravel())
+
+    _walk(gs, g, pcm, "f32", S0, check_a)
+    gs.close(); gm.close()
+    gg, oo = np.concatenate(a2["g"]), np.concatenate(a2["o"])
+    print(f"streaming bf16 GPU vs the fp32 oracle along the fp32 path: max |dlogp| {gg.max():.3e} mean {gg.mean():.3e}; "
+          f"bf16 ORACLE vs the fp32 oracle on the same path: max {oo.max():.3e} mean {oo.mean():.3e}")
+    assert gg.mean() <= S_FP32_RATIO * oo.mean() and gg.max() <= S_FP32_RATIO * oo.max()
+
+
+def test_bench_stream_two_ranks_share_the_device():
+    """configs[4]'s multi-GPU launcher (tools/bench_stream.py --gpus N: one process per GPU, sessions sharded statically, no collective) with
+    N = 2 on the one device a test box has (--oversubscribe: rank r -> device r % visible): both child processes run, the sessions are
+    sharded in whole groups, and the merged line carries both ranks and says it is not a 2-GPU figure."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_stream.py"), "--gpus", "2", "--oversubscribe", "--streams", "4", "--chunks", "12",
+                          "--warmup", "3", "--config", "eou-120m"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-800:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["streams_total"] == 8 and len(line["per_rank_latency_ms_median"]) == 2
+    assert all(x > 0 for x in line["per_rank_latency_ms_median"]) and line["aggregate_rtfx"] > 0
+    if capi.device_count() < 2:
+        assert line.get("oversubscribed") is True and line["devices_visible"] == capi.device_count()

@@ -13,6 +13,10 @@ oracle and for the bf16-mode oracle (pk_config.gemm_bf16), per clip:
   forced_lp             log-prob of the chosen label (= top_lp[:, 0] for a greedy path)
   margin                top-1 minus top-2 label log-prob, and the duration head's                                     [n][2]
   row_xor / row_sum     fp32 only: xor and uint64 sum of the bit patterns of the whole label log-prob row              [n]
+  bf16_on_fp32_top_lp / bf16_on_fp32_dur_lp
+                        the bf16-mode ORACLE teacher-forced along the FP32 oracle's path: its log-probs of fp32_top_ids and its
+                        duration log-probs.  |bf16_on_fp32_* - fp32_*| is the mode's own distance from the reference's arithmetic
+                        (fp32) at the logits -- the yardstick the GPU's distance from fp32 is held against (round-4 verdict, item 1a)
 
 tests/test_gpu_600m_depth.py walks these paths on the GPU with pk_tdt_score (loop of /root/reference/src/tdt.cpp:62-106, the decision given
 instead of the argmax): fp32 rows bit-identical, bf16 |delta log-prob| within the stated bound at every step of every clip, and every
@@ -45,10 +49,31 @@ def main():
     feats = np.stack([oracle.mel(p, n_mels=cfg.mel_bins) for p in pcm])
     out = {"n_clips": N_CLIPS, "n_samples": N_SAMPLES, "pcm_seed": PCM_SEED, "pcm_batch": BATCH, "weights_seed": 42, "top_k": K,
            "pcm_digest": np.asarray(pcm, np.float64).sum(axis=1), "durations": np.asarray(cfg.durations, np.int32)}
+    augment = "--augment" in sys.argv          # keep the existing file's keys (verified below), add only the bf16-on-fp32-path scores
+    if augment:
+        old = np.load(OUT, allow_pickle=False)
+        assert np.array_equal(old["pcm_digest"], out["pcm_digest"]), "the existing fixture was generated on other clips"
+        out = {k: old[k] for k in old.files}
     for mode in ("fp32", "bf16"):
+        if augment and mode == "fp32":
+            continue
         om = oracle.Model(dataclasses.replace(cfg, gemm_bf16=(mode == "bf16")), W)
         t = time.time()
         enc = om.encoder(feats)
+        if mode == "bf16":                      # the mode's own distance from fp32 along the FP32 path
+            nmax = out["fp32_labels"].shape[1]
+            on_top = np.zeros((N_CLIPS, nmax, K), np.float32); on_dur = np.zeros((N_CLIPS, nmax, len(cfg.durations)), np.float32)
+            for b in range(N_CLIPS):
+                n = int(out["fp32_n"][b])
+                r = om.tdt_score(enc[b], out["fp32_labels"][b, :n], out["fp32_dur_idx"][b, :n])
+                assert r["n"] == n
+                on_top[b, :n] = np.take_along_axis(r["label_lp"], out["fp32_top_ids"][b, :n].astype(np.int64), axis=1)
+                on_dur[b, :n] = r["dur_lp"]
+                dl = np.abs(on_top[b, :n] - out["fp32_top_lp"][b, :n]); dd = np.abs(on_dur[b, :n] - out["fp32_dur_lp"][b, :n])
+                print(f"  clip {b}: bf16 oracle along the fp32 path: label |dlogp| max {dl.max():.3e} mean {dl.mean():.3e}; duration max {dd.max():.3e} mean {dd.mean():.3e}", flush=True)
+            out["bf16_on_fp32_top_lp"], out["bf16_on_fp32_dur_lp"] = on_top, on_dur
+            if augment:
+                break
         print(f"{mode}: 24-layer encoder of {N_CLIPS} clips in {time.time() - t:.1f}s on {threads} threads", flush=True)
         per = []
         for b in range(N_CLIPS):
