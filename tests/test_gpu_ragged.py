@@ -242,7 +242,7 @@ def test_ragged_bf16_mode_vs_bf16_oracle(tmp_path):
     clips = clips_of([16000, 48000, 33333, 100000, 7000, 160000], seed=9)
     feats = gm.mel_ragged(clips)
     enc = gm.encode_ragged(feats)
-    res = gm.transcribe_pcm(clips, decoder="tdt")
+    res = gm.transcribe_pcm(clips, decoder="tdt", timestamps=True)
     n_tok, report = 0, []
     for i, f in enumerate(feats):
         oenc = om.encoder(f[None])[0]                                    # the specification: bf16-mode oracle, this clip alone

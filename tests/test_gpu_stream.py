@@ -334,11 +334,11 @@ def test_stream_score_tiny_bit_identical_and_state_carried(tmp_path_factory, orc
     decisions; the label / duration log-prob rows of every step are bit-identical, and -- the carried state being what that path leaves -- a
     plain pk_stream_decode on the last chunks then emits exactly the oracle's tokens (src/eou.cpp:17-98)."""
     W, om, gm = G.make_pair(tmp_path_factory.mktemp("ss"), pk.make_tiny_config(), seed=42)
-    S, chunk, n_chunks, n_plain = 5, 2560, 20, 6
+    S, chunk, n_chunks = 5, 2560, 24
     gs = capi.Stream(gm, S, 70, 1)
     os_ = [orc.Stream(om, 70, 1) for _ in range(S)]
     pcm = synth.synth_pcm(S, chunk * n_chunks, seed=31)
-    n_steps_all, n_tok_plain = 0, 0
+    n_steps_all, n_tok_plain, n_plain, n_tok_forced = 0, 0, 0, 0
     for i in range(n_chunks):
         seg = pcm[:, i * chunk:(i + 1) * chunk]
         gmel = gs.mel(seg)
@@ -350,12 +350,13 @@ def test_stream_score_tiny_bit_identical_and_state_carried(tmp_path_factory, orc
         if genc.shape[1] == 0:
             continue
         G.assert_bits_equal(genc, np.stack(oenc), f"stream encoder, chunk {i}")
-        if i >= n_chunks - n_plain:                                   # the state left by the forced walks carries a plain decode
+        if i >= 4 and i % 3 == 0:                                     # the state left by the forced walks carries a plain decode (and back)
             g = gs.decode(genc)
             for s, o in enumerate(os_):
                 r = o.decode(oenc[s])
                 assert g["ids"][s, : g["lens"][s]].tolist() == r["ids"].tolist(), f"chunk {i} stream {s}: plain decode after forced walks"
                 n_tok_plain += len(r["ids"])
+            n_plain += 1
             continue
         rs = [o.score(oenc[s]) for s, o in enumerate(os_)]
         cap = max(r["n"] for r in rs)
@@ -370,8 +371,10 @@ def test_stream_score_tiny_bit_identical_and_state_carried(tmp_path_factory, orc
             G.assert_bits_equal(g["dur_lp"][s, : r["n"]], r["dur_lp"], f"chunk {i} stream {s}: duration log-probs")
             assert not g["label_lp"][s, r["n"]:].any(), "rows beyond a stream's steps stay zero"
         n_steps_all += int(n.sum())
+        n_tok_forced += sum(int((r["labels"] != om.cfg.blank_id).sum()) for r in rs)
     gs.close()
-    assert n_steps_all > 50 and n_tok_plain > 0
+    print(f"pk_stream_score tiny: {n_steps_all} forced steps ({n_tok_forced} tokens) bit-identical, {n_plain} plain-decode chunks in between ({n_tok_plain} tokens) identical")
+    assert n_steps_all > 50 and n_plain >= 5 and n_tok_forced + n_tok_plain > 0
 
 
 STREAM_SCORE = os.path.join(ROOT, "tests", "golden", "nemotron600m_stream_score_depth24_seed42.npz")
