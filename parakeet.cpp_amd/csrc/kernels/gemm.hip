@@ -26,6 +26,7 @@
 #include "gemm_pipe.hpp"
 #include "gemm_bf16.hpp"
 #include "gemm_bf16_glds.hpp"
+#include "gemm_bf16_ring.hpp"
 
 namespace pk {
 
@@ -283,12 +284,13 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
 // and stores in one counter, and they complete out of order relative to each other), which costs more than the cold prologue and the
 // re-dispatch it removes; and the epilogue, confined to one 64 KB buffer, needs 8 row bands instead of 4.  OFF by default; EXPERIMENTAL builds:
 // PK_BF16_PERSIST=1 selects it.
-static bool bf16_glds_persist() {
+// Round 5: PK_BF16_PERSIST = 2 / 3 select the DIRECT register epilogue (gemm_bf16_glds.hpp), persistent / one tile per workgroup.
+static int bf16_glds_persist() {
 #ifdef PK_EXPERIMENTAL
-    static const bool m = [] { const char *e = getenv("PK_BF16_PERSIST"); return e ? atoi(e) != 0 : false; }();
+    static const int m = [] { const char *e = getenv("PK_BF16_PERSIST"); return e ? atoi(e) : 0; }();
     return m;
 #else
-    return false;
+    return 0;
 #endif
 }
 static int bf16_glds_mode() {
@@ -319,7 +321,18 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
                     const int64_t tiles = (int64_t)((a.M + R - 1) / R) * ((a.N + NOUT - 1) / NOUT);
                     return (double)((tiles + 255) / 256) * ((double)R * a.K * 1.008e-4 + 12.0);
                 };
-                if (est(192) < est(256)) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist());
+                const bool tall = !(est(192) < est(256));
+                if constexpr (EPI != EPI_RESID) {
+                    // the continuous-stream form (gemm_bf16_ring.hpp): more tiles than CUs, no residual read
+                    constexpr int NO = (EPI == EPI_GLU) ? 128 : 256;
+                    const int64_t tiles = (int64_t)((a.M + (tall ? 256 : 192) - 1) / (tall ? 256 : 192)) * ((a.N + NO - 1) / NO);
+                    if (bf16_glds_persist() == 4 && tiles > 256 && gemm_bf16_ring_applies<EPI>(a)) {
+                        if (tall) launch_gemm_bf16_ring<4, 2, 2, 4, EPI>(a, s);
+                        else launch_gemm_bf16_ring<2, 4, 3, 2, EPI>(a, s);
+                        return;
+                    }
+                }
+                if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist());
                 else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist());
                 return;
             }

@@ -27,13 +27,119 @@
 
 namespace pk {
 
+// DIRECT epilogue (round 5): the accumulators go from registers to global memory -- no LDS, no barrier, no load.  The K loop feeds the MFMA
+// with the operands SWAPPED (acc = mfma(W fragment, A fragment)): the same products summed in the same k order, so every result is bit for
+// bit the other form's, but the C/D layout now gives lane (lr = lane & 31, h = lane >> 5) output ROW lr of its 32-row tile and, per group
+// q = reg >> 2, the FOUR CONSECUTIVE columns 8 q + 4 h .. + 3 of the 32-column tile: a float4, or 4 bf16 = 8 bytes; v_permlane32_swap between
+// the groups q and q + 1 makes that 16 bytes per lane (lanes 0-31: columns 8 q .. 8 q + 7, lanes 32-63: 8 (q + 1) .. + 7 of the same row;
+// cdna_hip_programming.md T21).  The bias of a column group is wave-uniform up to h: eight consecutive floats read through the scalar cache
+// and selected by h, so the epilogue issues no vector load and its first instruction does not wait for the DMA of the next tile -- which the
+// persistent loop has ALREADY requested into both staging buffers (nothing of the epilogue touches LDS).  bf16 or fp32 rows out; EPI_NONE,
+// EPI_RELU, EPI_SILU, EPI_GLU (the residual epilogue would need vector loads: it keeps the LDS form).
+template <int WGM, int WGN, int TM, int TN, int EPI>
+__device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 (&acc)[TM][TN], int m0, int n0) {
+    static_assert(EPI != EPI_RESID, "the residual epilogue keeps the LDS form");
+    constexpr bool GLU = EPI == EPI_GLU;
+    constexpr int WM = TM * 32, WN = TN * 32, TNO = GLU ? TN / 2 : TN, WNO = GLU ? WN / 2 : WN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WGN, wn = wave % WGN, lr = lane & 31, h = lane >> 5;
+    const int cw = n0 + wn * WNO;                                   // first output column of this wave (wave-uniform)
+    // the bias through the SCALAR cache: eight consecutive floats per load from a constant-address-space pointer at a wave-uniform index
+    // (s_load_dwordx8); the per-half select picks among loaded SGPRs, so the compiler cannot fold it into a per-lane address
+    typedef float f32x8_ __attribute__((ext_vector_type(8)));
+    typedef const f32x8_ __attribute__((address_space(4))) *cf8p;
+    const bool has_bias = g.bias != nullptr;
+    auto sld8 = [&](int idx) {
+        f32x8_ z = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        return has_bias ? *(cf8p)(const void *)(g.bias + idx) : z;
+    };
+#pragma unroll
+    for (int j = 0; j < TNO; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; q += 2) {                            // column groups q, q + 1 of tile j: columns 8 q .. 8 q + 15
+            const int cb = __builtin_amdgcn_readfirstlane(cw + j * 32 + 8 * q);   // wave-uniform; the whole 16-column span is inside N or outside (N % 16 == 0: launcher)
+            if (cb >= g.N) continue;
+            float bs[2][4], bg[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x8_ b8 = sld8(cb + 8 * u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bs[u][e] = h ? b8[4 + e] : b8[e];
+                if constexpr (GLU) {
+                    const f32x8_ g8 = sld8(g.N + cb + 8 * u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bg[u][e] = h ? g8[4 + e] : g8[e];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = m0 + wm * WM + i * 32 + lr;
+                float v[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = acc[i][j][4 * (q + u) + e] + bs[u][e];
+                    if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] > 0.0f ? v[u][e] : 0.0f;
+                    } else if constexpr (EPI == EPI_SILU) {
+                        if (g.fast_act) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[u][e] = fast_siluf(v[u][e]);
+                        } else {
+                            dsilu4(v[u]);
+                        }
+                    } else if constexpr (GLU) {
+                        float gt[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gt[e] = acc[i][j + TN / 2][4 * (q + u) + e] + bg[u][e];
+                        if (g.fast_act) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) gt[e] = fast_sigmoidf(gt[e]);
+                        } else {
+                            dsigmoid4(gt);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] * gt[e];
+                    }
+                }
+                if (g.out_bf16) {
+                    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const bf16x2_ a = {(__bf16)v[u][0], (__bf16)v[u][1]}, b = {(__bf16)v[u][2], (__bf16)v[u][3]};
+                        pk[u][0] = __builtin_bit_cast(unsigned, a);
+                        pk[u][1] = __builtin_bit_cast(unsigned, b);
+                    }
+                    // upper half of group q <-> lower half of group q + 1: lanes 0-31 hold columns 8 q .. 8 q + 7, lanes 32-63 8 (q + 1) .. + 7
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                    if (row < g.M) {
+                        uint4 o;
+                        o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<__bf16 *>(g.out) + (int64_t)row * g.ldo + cb + 8 * h) = o;
+                    }
+                } else if (row < g.M) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + cb + 8 * u + 4 * h) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+                }
+            }
+        }
+    }
+}
+
 // PERSIST (round 4): ONE workgroup per CU walks its tiles inside the launch.  Measured in round 3 (tools/ubench/gemm_bf16_k.cpp): the K loop runs
 // at 1.25-1.3 PF, the products of this model lose ~14 us per ROUND of tiles -- a cold two-tile DMA prologue on every CU at once, the epilogue,
 // the re-dispatch -- on K loops of only 16 tiles.  Here the first K tile of tile i+1 is requested (DMA into the staging buffer the last K tile
 // of tile i did not use) BEFORE the epilogue of tile i, which turns its accumulators row-major through the OTHER buffer only (64 KB: bands of
 // 32 rows); the second K tile follows right after the epilogue, and the K loop of tile i+1 starts on data that has long landed.  XCD x owns
 // the same contiguous range of tiles as in the one-tile-per-workgroup launch, dealt round-robin to its 32 workgroups.
-template <int WGM, int WGN, int TM, int TN, int EPI, bool PERSIST = false>
+// PERSIST + DIRECT (round 5): with the register epilogue nothing after the last K tile's barrier touches LDS, so BOTH first K tiles of the next
+// output tile are requested before the epilogue starts; the wait at the top of the loop then covers DMA that landed microseconds ago and the
+// epilogue's own stores (one counter for loads and stores on gfx950), instead of a cold two-tile prologue per round of tiles.
+template <int WGM, int WGN, int TM, int TN, int EPI, bool PERSIST = false, bool DIRECT = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs g, int tiles_n, int n_tiles) {
     constexpr int BK = 64, NSUB = BK / 16;                          // bf16 elements per tile row; MFMA k-steps per K tile
     constexpr int NT = 64 * WGM * WGN, NW = WGM * WGN;
@@ -128,7 +234,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i], fb[slot][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[slot][j], fa[slot][i], acc[i][j], 0, 0, 0);   // C^T: lane = output row
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][i], fb[slot][j], acc[i][j], 0, 0, 0);
+            }
     };
 #define GL_SB() __builtin_amdgcn_sched_barrier(0)
 #define GL_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)           /* vmcnt(0): this wave's LDS-DMA loads have landed */
@@ -169,7 +278,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
         }
         // `cur` = the buffer the last K tile did NOT use (free since the barrier of the last iteration); the other one is free too once every
         // wave has passed that barrier -- which the epilogue's own first barrier guarantees again
-        if constexpr (PERSIST) {
+        if constexpr (PERSIST && DIRECT) {
+            const int em0 = m0, en0 = n0;
+            loc += per_xcd;
+            const bool more = loc < x_count;
+            if (more) {                    // both staging buffers are free (every wave is past the last K tile's barrier, the epilogue uses none)
+                tile_origin(x_first + loc, m0, n0);
+                set_src(m0, n0, src);
+                dma(src, 0, cur);
+                if (nk > 1) dma(src, 1, cur ^ 1);
+            }
+            gl_epilogue_direct<WGM, WGN, TM, TN, EPI>(g, acc, em0, en0);
+            if (!more) break;
+        } else if constexpr (DIRECT) {
+            gl_epilogue_direct<WGM, WGN, TM, TN, EPI>(g, acc, m0, n0);
+            break;
+        } else if constexpr (PERSIST) {
             const int em0 = m0, en0 = n0;
             loc += per_xcd;
             const bool more = loc < x_count;
@@ -191,14 +315,33 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
 #undef GL_WAIT_VM0
 }
 
+// persist: 0 = one tile per workgroup, 1 = persistent with the LDS epilogue (round 4), 2 = persistent (more than 256 tiles) with the DIRECT
+// register epilogue, 3 = the direct epilogue on one tile per workgroup
 template <int WGM, int WGN, int TM, int TN, int EPI>
-static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, bool persist = false) {
+static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist = 0) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
     const int n_tiles = tiles_m * tiles_n;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;
-    if (persist && n_tiles > 256) {                                // more than one round of the 256 CUs: one persistent workgroup per CU
+    if constexpr (EPI != EPI_RESID) {
+        const bool direct_ok = a.sigma_cols == 0 && a.remap_rows == 0 && (a.N % 16) == 0 && (a.ldo % 8) == 0;
+        if (persist >= 2 && direct_ok) {
+            if (persist == 2 && n_tiles > 256) {
+                auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true>;
+                static DynLdsSlots slots;
+                ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+                hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+                return;
+            }
+            auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, true>;
+            static DynLdsSlots slots;
+            ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+            hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+            return;
+        }
+    }
+    if (persist == 1 && n_tiles > 256) {                                // more than one round of the 256 CUs: one persistent workgroup per CU
         auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true>;
         static DynLdsSlots slots;
         ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);

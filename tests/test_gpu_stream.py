@@ -422,7 +422,7 @@ def _walk(gs, g, pcm, prefix, S, on_chunk):
 
 
 def test_stream_teacher_forced_fp32_rows_bit_identical(stream_score):
-    """configs[4] in fp32 at the logits: 4 sessions x 120 chunks of nemotron-600m (24 layers), every chunk's encoder output carries the fp32
+    """configs[4] in fp32 at the logits: 8 sessions x 80 chunks of nemotron-600m (24 layers), every chunk's encoder output carries the fp32
     oracle's checksums and -- walking that oracle's decision path with the state carried across chunks -- the label log-prob row of EVERY step
     carries the oracle's bit checksums, its top-8 and the duration log-probs are bit-equal, and the GPU's own argmax is the oracle's decision
     (/root/reference/src/eou.cpp:17-98, src/tdt.cpp:15-24)."""
@@ -456,7 +456,7 @@ def test_stream_teacher_forced_fp32_rows_bit_identical(stream_score):
 
 def test_stream_teacher_forced_bf16_within_bound_and_vs_fp32(stream_score):
     """The tolerance statement of the bf16 STREAMING mode at the logits, over whole sessions (> 200 tokens; a near-tie does not end it):
-      (1) 16 lock-step streams (the 4 fixture sessions x 4) walk the bf16 ORACLE's path chunk by chunk: |delta log-prob| <= S_LOGP_TOL on the
+      (1) 16 lock-step streams (the 8 fixture sessions x 2) walk the bf16 ORACLE's path chunk by chunk: |delta log-prob| <= S_LOGP_TOL on the
           oracle's top-8 labels and all durations at EVERY step (mean <= S_LOGP_MEAN), every decision with margin > 2 x S_LOGP_TOL is the
           GPU's own argmax, and replicas of a session are bit-identical;
       (2) a second set of sessions walks the FP32 oracle's path: the GPU's distance from the reference's arithmetic (fp32) is at most
@@ -487,7 +487,7 @@ def test_stream_teacher_forced_bf16_within_bound_and_vs_fp32(stream_score):
     _walk(gs, g, pcm, "b16", S, check_b)
     gs.close()
     dl, dd = np.concatenate(acc["lab"]), np.concatenate(acc["dur"])
-    print(f"streaming bf16 teacher-forced along the bf16 oracle's path: {S0} sessions (x4 replicas) x {int(g['n_chunks'])} chunks, {acc['steps']} steps, "
+    print(f"streaming bf16 teacher-forced along the bf16 oracle's path: {S0} sessions (replicated to {S} lock-step streams) x {int(g['n_chunks'])} chunks, {acc['steps']} steps, "
           f"{acc['tokens']} tokens: label |dlogp| max {dl.max():.3e} mean {dl.mean():.3e}, duration max {dd.max():.3e} mean {dd.mean():.3e} (bound {S_LOGP_TOL} / {S_LOGP_MEAN}); "
           f"{acc['clear']} of {acc['dec']} decisions have margin > {2 * S_LOGP_TOL} (all agree), {acc['agree']} agree in all")
     assert acc["tokens"] > 200

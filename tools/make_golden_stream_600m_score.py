@@ -22,7 +22,7 @@ Per chunk i, stream s, step k (arrays [N_CHUNKS][N_STREAMS][STEP_CAP], n = *_n[i
   enc_n                 encoder frames of the chunk (0: buffered)
 tests/test_gpu_stream.py walks these paths on the GPU with pk_stream_score: fp32 rows bit-identical along A; bf16 mode within a stated bound
 of B along B, and its distance from A (along A) held against C's.
-usage (authoring container, ~20 min of CPU on 8 threads): python tools/make_golden_stream_600m_score.py"""
+usage (authoring container, ~25 min of CPU on 8 threads): python tools/make_golden_stream_600m_score.py"""
 import dataclasses
 import os
 import sys
@@ -33,7 +33,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 OUT = os.path.join(ROOT, "tests", "golden", "nemotron600m_stream_score_depth24_seed42.npz")
-N_STREAMS, N_CHUNKS, CHUNK, PCM_SEED, LEFT, RIGHT, K = 4, 120, 2560, 4242, 70, 1, 8
+N_STREAMS, N_CHUNKS, CHUNK, PCM_SEED, LEFT, RIGHT, K = 8, 80, 2560, 4242, 70, 1, 8
 
 
 def main():

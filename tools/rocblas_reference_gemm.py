@@ -23,4 +23,18 @@ for name, (M, N, K) in shapes.items():
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 50 * 1e3
     out[name] = {"us": round(us, 1), "tflops": round(2.0 * M * N * K / us / 1e6, 1)}
+# the same for the bf16 products of configs[2] (bf16 operands, fp32 accumulation inside the library, bf16 output)
+for name, (M, N, K) in {"bf16 600m fc1 12032x4096x1024": (12032, 4096, 1024), "bf16 600m qkv 12032x3072x1024": (12032, 3072, 1024),
+                        "bf16 600m fc2 12032x1024x4096": (12032, 1024, 4096), "bf16 600m out 12032x1024x1024": (12032, 1024, 1024)}.items():
+    a = torch.randn(M, K, device="cuda").bfloat16(); w = torch.randn(N, K, device="cuda").bfloat16()
+    for _ in range(5):
+        (a @ w.t())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        (a @ w.t())
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 50 * 1e3
+    out[name] = {"us": round(us, 1), "tflops": round(2.0 * M * N * K / us / 1e6, 1)}
 print(json.dumps(out))
