@@ -284,13 +284,19 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
 // and stores in one counter, and they complete out of order relative to each other), which costs more than the cold prologue and the
 // re-dispatch it removes; and the epilogue, confined to one 64 KB buffer, needs 8 row bands instead of 4.  OFF by default; EXPERIMENTAL builds:
 // PK_BF16_PERSIST=1 selects it.
-// Round 5: PK_BF16_PERSIST = 2 / 3 select the DIRECT register epilogue (gemm_bf16_glds.hpp), persistent / one tile per workgroup.
+// Round 5: 2 = the persistent form with the DIRECT register epilogue (gemm_bf16_glds.hpp: operands swapped in the MFMA, no LDS / barrier / vector load
+// in the epilogue, both first K tiles of the next output tile requested before it) -- the production setting for the products without a residual
+// read whose tiles exceed one round of the CUs: bit-identical results, fc1 142 -> 134 us, qkv / GLU -4 %, the tdt-600m step 27.11 -> 26.73 ms
+// (profiles/r05_bf16_direct_epilogue_ab.txt, r05_bf16_ring_ab.txt: three interleaved repetitions each).  3 = the direct epilogue on one tile per
+// workgroup (-1.5 % on fc1 alone).  4 = the continuous-stream kernel of gemm_bf16_ring.hpp (ring of four 32-k slots, counted vmcnt): correct and
+// NOT faster than 2 -- the K loop is not bound by the DMA's latency (r05_bf16_ring_ab.txt; SQ counters r05_pmc_sq_600m_bf16_p*.md: the matrix pipe
+// is busy 31-33 % of the launch in every form).  EXPERIMENTAL builds: PK_BF16_PERSIST selects.
 static int bf16_glds_persist() {
 #ifdef PK_EXPERIMENTAL
-    static const int m = [] { const char *e = getenv("PK_BF16_PERSIST"); return e ? atoi(e) : 0; }();
+    static const int m = [] { const char *e = getenv("PK_BF16_PERSIST"); return e ? atoi(e) : 2; }();
     return m;
 #else
-    return 0;
+    return 2;
 #endif
 }
 static int bf16_glds_mode() {
