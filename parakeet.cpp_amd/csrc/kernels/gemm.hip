@@ -299,6 +299,15 @@ static int bf16_glds_persist() {
     return 2;
 #endif
 }
+// STAGGER instantiations of the direct-to-LDS bf16 kernels (gemm_bf16_glds.hpp / gemm_bf16_ring.hpp): PK_BF16_FLAGS=1 in EXPERIMENTAL builds.
+static int bf16_glds_flags() {
+#ifdef PK_EXPERIMENTAL
+    static const int m = [] { const char *e = getenv("PK_BF16_FLAGS"); return e ? atoi(e) : 0; }();
+    return m;
+#else
+    return 0;
+#endif
+}
 static int bf16_glds_mode() {
 #ifdef PK_EXPERIMENTAL
     static const int m = [] { const char *e = getenv("PK_BF16_TILE"); return e ? atoi(e) : 1; }();
@@ -333,13 +342,13 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
                     constexpr int NO = (EPI == EPI_GLU) ? 128 : 256;
                     const int64_t tiles = (int64_t)((a.M + (tall ? 256 : 192) - 1) / (tall ? 256 : 192)) * ((a.N + NO - 1) / NO);
                     if (bf16_glds_persist() == 4 && tiles > 256 && gemm_bf16_ring_applies<EPI>(a)) {
-                        if (tall) launch_gemm_bf16_ring<4, 2, 2, 4, EPI>(a, s);
-                        else launch_gemm_bf16_ring<2, 4, 3, 2, EPI>(a, s);
+                        if (tall) launch_gemm_bf16_ring<4, 2, 2, 4, EPI>(a, s, (bf16_glds_flags() & 1) != 0);
+                        else launch_gemm_bf16_ring<2, 4, 3, 2, EPI>(a, s, (bf16_glds_flags() & 1) != 0);
                         return;
                     }
                 }
-                if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist());
-                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist());
+                if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0);
+                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0);
                 return;
             }
         }

@@ -139,7 +139,7 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
 // PERSIST + DIRECT (round 5): with the register epilogue nothing after the last K tile's barrier touches LDS, so BOTH first K tiles of the next
 // output tile are requested before the epilogue starts; the wait at the top of the loop then covers DMA that landed microseconds ago and the
 // epilogue's own stores (one counter for loads and stores on gfx950), instead of a cold two-tile prologue per round of tiles.
-template <int WGM, int WGN, int TM, int TN, int EPI, bool PERSIST = false, bool DIRECT = false>
+template <int WGM, int WGN, int TM, int TN, int EPI, bool PERSIST = false, bool DIRECT = false, bool STAGGER = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs g, int tiles_n, int n_tiles) {
     constexpr int BK = 64, NSUB = BK / 16;                          // bf16 elements per tile row; MFMA k-steps per K tile
     constexpr int NT = 64 * WGM * WGN, NW = WGM * WGN;
@@ -157,6 +157,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave / WGN, wn = wave % WGN;
+    // STAGGER (round 5): waves w and w + NW / 2 share a SIMD; the second half requests its DMA pieces after the MFMA group that follows the
+    // barrier instead of before it, so that one wave of a SIMD issues LDS-DMA (60-185 clocks per 1 KB piece) while the other feeds the matrix
+    // pipe.  A template parameter: as a run-time flag the extra branches in the K loop cost more than the stagger gains
+    // (profiles/r05_bf16_stagger_runtime_flags_ab.txt).
+    const bool late = STAGGER && wv >= NW / 2;
     const int nk = g.K / BK;
     const __bf16 *A16 = reinterpret_cast<const __bf16 *>(g.A);
     const __bf16 *W16 = reinterpret_cast<const __bf16 *>(g.W);
@@ -272,8 +277,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
             GL_WAIT_VM0();                 // K tile kt+1 (issued a whole tile ago) is in LDS
             __syncthreads();               // ... for every wave; and every wave holds its last fragments of tile kt: buffer `cur` is free
             if (more1) fragload(cur ^ 1, 0, 0);
-            if (more2) dma(src, kt + 2, cur);
+            if (more2 && !late) dma(src, kt + 2, cur);
             GL_SB(); mma((NSUB - 1) & 1); GL_SB();
+            if constexpr (STAGGER) { if (more2 && late) dma(src, kt + 2, cur); }
             cur ^= 1;
         }
         // `cur` = the buffer the last K tile did NOT use (free since the barrier of the last iteration); the other one is free too once every
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
 // persist: 0 = one tile per workgroup, 1 = persistent with the LDS epilogue (round 4), 2 = persistent (more than 256 tiles) with the DIRECT
 // register epilogue, 3 = the direct epilogue on one tile per workgroup
 template <int WGM, int WGN, int TM, int TN, int EPI>
-static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist = 0) {
+static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist = 0, bool stagger = false) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
@@ -328,6 +334,13 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
         const bool direct_ok = a.sigma_cols == 0 && a.remap_rows == 0 && (a.N % 16) == 0 && (a.ldo % 8) == 0;
         if (persist >= 2 && direct_ok) {
             if (persist == 2 && n_tiles > 256) {
+                if (stagger) {
+                    auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true, true>;
+                    static DynLdsSlots slots;
+                    ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+                    hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+                    return;
+                }
                 auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true>;
                 static DynLdsSlots slots;
                 ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
@@ -346,6 +359,13 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
         static DynLdsSlots slots;
         ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
         hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+        return;
+    }
+    if (stagger) {
+        auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, false, true>;
+        static DynLdsSlots slots;
+        ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
         return;
     }
     auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false>;

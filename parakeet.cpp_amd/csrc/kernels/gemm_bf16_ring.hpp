@@ -27,7 +27,7 @@
 
 namespace pk {
 
-template <int WGM, int WGN, int TM, int TN, int EPI>
+template <int WGM, int WGN, int TM, int TN, int EPI, bool STAGGER = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_ring_kernel(GemmArgs g, int tiles_n, int n_tiles) {
     constexpr int BK = 32, NR = 4;                                  // bf16 elements per slot row; ring slots
     constexpr int NW = WGM * WGN;
@@ -46,6 +46,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_ring_kernel(GemmArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave / WGN, wn = wave % WGN;
+    // STAGGER: as in gemm_bf16_glds.hpp -- the second half of the waves requests its DMA pieces after the MFMA group that follows the barrier
+    const bool late = STAGGER && wv >= NW / 2;
     const int nk = g.K / BK;                                        // a multiple of NR (launcher): slot of K tile kt = kt % NR in every output tile
     const __bf16 *A16 = reinterpret_cast<const __bf16 *>(g.A);
     const __bf16 *W16 = reinterpret_cast<const __bf16 *>(g.W);
@@ -181,9 +183,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_ring_kernel(GemmArgs
                 if (stores_pending || gt + NR - 1 >= total) { RG_WAIT(0); stores_pending = false; }
                 else RG_WAIT(NR - 2);
                 RG_BARRIER();                                       // tile gt + 1 is in LDS for every wave; every wave holds its last fragments of tile gt
-                produce();                                          // tile gt + NR into the slot tile gt just left
+                if (!late) produce();                               // tile gt + NR into the slot tile gt just left
                 if (gt + 1 < total) fragload((u + 1) & (NR - 1), 0, 0);
                 RG_SB(); mma(1); RG_SB();
+                if constexpr (STAGGER) { if (late) produce(); }     // (same order of requests per wave: the counted waits are unchanged)
                 ++gt;
             }
         }
@@ -207,13 +210,20 @@ static bool gemm_bf16_ring_applies(const GemmArgs &a) {
 }
 
 template <int WGM, int WGN, int TM, int TN, int EPI>
-static void launch_gemm_bf16_ring(const GemmArgs &a, hipStream_t s) {
+static void launch_gemm_bf16_ring(const GemmArgs &a, hipStream_t s, bool stagger = false) {
     if constexpr (EPI != EPI_RESID) {
         constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
         constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
         const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
         const int n_tiles = tiles_m * tiles_n;
         constexpr size_t lds = 4 * (size_t)(BM + BN) * 32 * 2;
+        if (stagger) {
+            auto kern = &gemm_bf16_ring_kernel<WGM, WGN, TM, TN, EPI, true>;
+            static DynLdsSlots slots;
+            ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+            hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+            return;
+        }
         auto kern = &gemm_bf16_ring_kernel<WGM, WGN, TM, TN, EPI>;
         static DynLdsSlots slots;
         ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
