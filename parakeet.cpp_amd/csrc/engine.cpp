@@ -856,11 +856,17 @@ void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStr
     GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, h, f, nullptr, 0, 1.0f, (int)rows, f, d};
     g1.a_bf16 = a16; g1.out_bf16 = a16;
     g1.fast_act = a16;
+    // bf16 mode, large batches: the fc1 activations live in 32 x 16 blocks between fc1's register epilogue and fc2's LDS-DMA
+    // (GemmArgs::out_blocked / a_blocked: every store instruction of the epilogue writes one contiguous KB); h holds rows rounded up to 32
+    const bool blocked = a16 && !sg && gemm_bf16_blocked_handoff((int)rows, f, d, EPI_SILU, true) && gemm_bf16_blocked_handoff((int)rows, d, f, EPI_RESID, false) &&
+                         (size_t)((rows + 31) / 32 * 32) * f * 2 <= w.hbuf.cap;
+    g1.out_blocked = blocked ? 1 : 0;
     if (sg) { g1.a_sigma = 1; g1.W_sig = second ? sg->ffn2_w1 : sg->ffn1_w1; g1.sigma_cols = f; }
     // (the first FFN's norm rides on the previous block's final_norm_ kernel, see run_layers -- unless the product folds it in: ln_gemm)
     ln_gemm("ffn_fc1_silu", g1, EPI_SILU, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, norm_done, sg ? 2 : a16, x, n, rows, s);
     GemmArgs g2{h, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, x, d, 0.5f, (int)rows, d, f};
     g2.a_bf16 = a16;
+    g2.a_blocked = blocked ? 1 : 0;
     if (sg) { g2.a_sigma = 1; g2.W_sig = second ? sg->ffn2_w2 : sg->ffn1_w2; }
     run_gemm("ffn_fc2_resid", g2, EPI_RESID, s);
 }

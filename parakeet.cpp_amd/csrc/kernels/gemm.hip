@@ -22,6 +22,7 @@
 //    no separate elementwise passes over HBM.
 #include "../pk_devmath.h"
 #include "kernels.hpp"
+#include <cstdio>
 #include <cstdlib>
 #include "gemm_pipe.hpp"
 #include "gemm_bf16.hpp"
@@ -299,13 +300,19 @@ static int bf16_glds_persist() {
     return 2;
 #endif
 }
-// STAGGER instantiations of the direct-to-LDS bf16 kernels (gemm_bf16_glds.hpp / gemm_bf16_ring.hpp): PK_BF16_FLAGS=1 in EXPERIMENTAL builds.
+// Instantiation flags of the direct-to-LDS bf16 kernels (gemm_bf16_glds.hpp / gemm_bf16_ring.hpp), EXPERIMENTAL builds: PK_BF16_FLAGS bit 1 = STAGGER,
+// bit 2 = ASMFRAG (hand-counted fragment reads).
+// Production: 2 (ASMFRAG: bit-identical, -0.7 % per tdt-600m step, profiles/r05_bf16_asmfrag_ab.txt).  With PK_BF16_PERSIST=4 the low two bits select
+// the ring kernel's form instead: 0 plain, 1 STAGGER, 2 PHASED, 3 PHASED + s_setprio -- every one of them measured level with the persistent
+// form on fc1 (117 us) and behind it on the step (profiles/r05_bf16_ring_ab.txt, r05_bf16_phased_ab.txt): three different K-loop schedules, one
+// time -- the loop is bound by what a CU can pull from L2 into LDS (64 KB per 64-k tile at ~14 B/clock against the 32 B/clock the MFMAs could use),
+// not by how the pulls are scheduled.
 static int bf16_glds_flags() {
 #ifdef PK_EXPERIMENTAL
-    static const int m = [] { const char *e = getenv("PK_BF16_FLAGS"); return e ? atoi(e) : 0; }();
+    static const int m = [] { const char *e = getenv("PK_BF16_FLAGS"); return e ? atoi(e) : 2; }();
     return m;
 #else
-    return 0;
+    return 2;
 #endif
 }
 static int bf16_glds_mode() {
@@ -317,11 +324,27 @@ static int bf16_glds_mode() {
 #endif
 }
 
+// the one rule both launch_bf16_epi and gemm_bf16_blocked_handoff apply: the product runs on the tile-height-per-product direct-to-LDS kernels
+static bool bf16_glds_rule(int M, int N, int K) {
+    return bf16_glds_mode() == 1 && M >= 8192 && N >= 512 && K >= 128 && (int64_t)N * K >= (int64_t)1024 * 1024 && (N & 3) == 0;
+}
+bool gemm_bf16_blocked_handoff(int M, int N, int K, int epi, bool producer) {
+    if (!bf16_glds_rule(M, N, K) || (N % 16) != 0 || (K % 64) != 0) return false;
+    if (!producer) return bf16_glds_persist() != 4;                 // every gemm_bf16_glds_kernel form reads the blocked A (the ring kernel does not)
+    const int p = bf16_glds_persist();
+    return (p == 2 || p == 3) && epi != EPI_RESID && (int64_t)(M + 31) * N < ((int64_t)1 << 31);   // the register epilogue writes it (callers set fast_act: bf16 mode)
+}
+[[noreturn]] static void bf16_layout_bug(const char *what) {
+    fprintf(stderr, "parakeet_amd: internal error: %s (GemmArgs::out_blocked / a_blocked on a kernel that does not implement it)\n", what);
+    abort();
+}
+
 template <int EPI, bool A16>
 static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
     if constexpr (A16) {
         const int mode = bf16_glds_mode();
         if (mode && a.M >= 2048 && a.N >= 512 && a.K >= 128 && (a.lda % 8) == 0 && (a.ldw % 8) == 0 && a.remap_rows == 0 && (a.ldo & 3) == 0 && (a.N & 3) == 0) {
+            if (mode != 1 && a.out_blocked) bf16_layout_bug("blocked output outside the production tile rule");
             if (mode == 3) { launch_gemm_bf16_glds<2, 2, 2, 2, EPI>(a, s); return; }
             if (mode == 2) { launch_gemm_bf16_glds<4, 2, 2, 2, EPI>(a, s); return; }
             if (mode == 4) { launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s); return; }
@@ -342,17 +365,18 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
                     constexpr int NO = (EPI == EPI_GLU) ? 128 : 256;
                     const int64_t tiles = (int64_t)((a.M + (tall ? 256 : 192) - 1) / (tall ? 256 : 192)) * ((a.N + NO - 1) / NO);
                     if (bf16_glds_persist() == 4 && tiles > 256 && gemm_bf16_ring_applies<EPI>(a)) {
-                        if (tall) launch_gemm_bf16_ring<4, 2, 2, 4, EPI>(a, s, (bf16_glds_flags() & 1) != 0);
-                        else launch_gemm_bf16_ring<2, 4, 3, 2, EPI>(a, s, (bf16_glds_flags() & 1) != 0);
+                        if (tall) launch_gemm_bf16_ring<4, 2, 2, 4, EPI>(a, s, bf16_glds_flags() & 3);
+                        else launch_gemm_bf16_ring<2, 4, 3, 2, EPI>(a, s, bf16_glds_flags() & 3);
                         return;
                     }
                 }
-                if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0);
-                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0);
+                if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0);
+                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0);
                 return;
             }
         }
     }
+    if (a.out_blocked || a.a_blocked) bf16_layout_bug("blocked activation layout requested for the register-staged bf16 kernel");
     // round 2: the staging stores decide the rate of this kernel.  As 16-byte ds_write_b128 the 128x128 tile ran at 320-340 TF and 256x256
     // macro tiles were the way to 450 (profiles/r02_gemm_bf16_tiles.txt); the SAME 16 bytes written as a ds_write2_b64 pair
     // (gemm_bf16.hpp, lstore) take the 128x128 tile to 580 TF in the sweep and 510-600 TF in the engine (profiles/r02_gemm_bf16_ablation.txt)

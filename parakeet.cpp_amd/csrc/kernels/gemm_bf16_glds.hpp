@@ -20,12 +20,27 @@
 //    requested at the start of its pass.
 #ifndef PK_GEMM_BF16_GLDS_HPP
 #define PK_GEMM_BF16_GLDS_HPP
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 #include "../pk_devmath.h"
 #include "kernels.hpp"
 #include "gemm_pipe.hpp"
 #include "gemm_bf16.hpp"
 
 namespace pk {
+
+// Phase stamps for tools/ubench/gemm_bf16_trace.cpp (-DGL_TRACE): the shader clock of lane 0 of wave 0 of every workgroup at the phase
+// boundaries of its output tiles -- [workgroup][tile][GL_TRACE_SLOTS]: 0 = tile start, 1 = first fragments readable (prologue wait + barrier),
+// 2 + kt = K tile kt's barrier passed, 2 + nk = K loop done, 3 + nk = epilogue issued.  Production builds: nothing.
+#ifdef GL_TRACE
+constexpr int GL_TRACE_SLOTS = 72, GL_TRACE_TILES = 4;
+__device__ unsigned long long *gl_trace;
+#define GL_STAMP(tile, i) do { if (gl_trace && threadIdx.x == 0 && (tile) < GL_TRACE_TILES && (i) < GL_TRACE_SLOTS) \
+        gl_trace[((size_t)blockIdx.x * GL_TRACE_TILES + (tile)) * GL_TRACE_SLOTS + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GL_STAMP(tile, i) do { } while (0)
+#endif
 
 // DIRECT epilogue (round 5): the accumulators go from registers to global memory -- no LDS, no barrier, no load.  The K loop feeds the MFMA
 // with the operands SWAPPED (acc = mfma(W fragment, A fragment)): the same products summed in the same k order, so every result is bit for
@@ -36,14 +51,17 @@ namespace pk {
 // and selected by h, so the epilogue issues no vector load and its first instruction does not wait for the DMA of the next tile -- which the
 // persistent loop has ALREADY requested into both staging buffers (nothing of the epilogue touches LDS).  bf16 or fp32 rows out; EPI_NONE,
 // EPI_RELU, EPI_SILU, EPI_GLU (the residual epilogue would need vector loads: it keeps the LDS form).
-template <int WGM, int WGN, int TM, int TN, int EPI>
-__device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 (&acc)[TM][TN], int m0, int n0) {
+// The run-time switches of the epilogue (hardware exp / rcp activations, bf16 rows out, blocked hand-off) are TEMPLATE parameters of the body
+// and dispatched once per tile: inside the fully unrolled body they were a branch per four values, 64-bit address arithmetic per store and
+// ~25 000 clocks of epilogue per 256 x 256 tile -- a quarter of the tile's time (tools/ubench/gemm_bf16_trace.cpp, profiles/r05_bf16_fc1_phase_trace.txt).
+template <int WGM, int WGN, int TM, int TN, int EPI, bool FAST, bool OUT16, bool BLOCKED>
+__device__ __forceinline__ void gl_epilogue_direct_body(const GemmArgs &g, bg_f32x16 (&acc)[TM][TN], int m0, int n0) {
     static_assert(EPI != EPI_RESID, "the residual epilogue keeps the LDS form");
     constexpr bool GLU = EPI == EPI_GLU;
     constexpr int WM = TM * 32, WN = TN * 32, TNO = GLU ? TN / 2 : TN, WNO = GLU ? WN / 2 : WN;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WGN, wn = wave % WGN, lr = lane & 31, h = lane >> 5;
-    const int cw = n0 + wn * WNO;                                   // first output column of this wave (wave-uniform)
+    const int cw = __builtin_amdgcn_readfirstlane(n0 + wn * WNO);   // first output column of this wave (wave-uniform)
     // the bias through the SCALAR cache: eight consecutive floats per load from a constant-address-space pointer at a wave-uniform index
     // (s_load_dwordx8); the per-half select picks among loaded SGPRs, so the compiler cannot fold it into a per-lane address
     typedef float f32x8_ __attribute__((ext_vector_type(8)));
@@ -53,11 +71,22 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
         f32x8_ z = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         return has_bias ? *(cf8p)(const void *)(g.bias + idx) : z;
     };
+    // per accumulator row block: this lane's output row, whether it exists, and the element offset of its first column of the wave
+    bool rok[TM];
+    int roff[TM];                                                   // (32-bit element offsets: the launcher checks the tensor stays below 2^31 elements)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * WM + i * 32 + lr;
+        rok[i] = row < g.M;
+        if constexpr (BLOCKED) roff[i] = ((row >> 5) * ((int)g.ldo >> 4) + (cw >> 4)) * 512 + (row & 31) * 16 + 8 * h;
+        else roff[i] = row * (int)g.ldo + cw + (OUT16 ? 8 : 4) * h;
+    }
+    __bf16 *out16 = reinterpret_cast<__bf16 *>(g.out);
 #pragma unroll
     for (int j = 0; j < TNO; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; q += 2) {                            // column groups q, q + 1 of tile j: columns 8 q .. 8 q + 15
-            const int cb = __builtin_amdgcn_readfirstlane(cw + j * 32 + 8 * q);   // wave-uniform; the whole 16-column span is inside N or outside (N % 16 == 0: launcher)
+            const int cb = cw + j * 32 + 8 * q;                     // wave-uniform; the whole 16-column span is inside N or outside (N % 16 == 0: launcher)
             if (cb >= g.N) continue;
             float bs[2][4], bg[2][4];
 #pragma unroll
@@ -73,7 +102,6 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int row = m0 + wm * WM + i * 32 + lr;
                 float v[2][4];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -83,7 +111,7 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] > 0.0f ? v[u][e] : 0.0f;
                     } else if constexpr (EPI == EPI_SILU) {
-                        if (g.fast_act) {
+                        if constexpr (FAST) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[u][e] = fast_siluf(v[u][e]);
                         } else {
@@ -93,7 +121,7 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
                         float gt[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) gt[e] = acc[i][j + TN / 2][4 * (q + u) + e] + bg[u][e];
-                        if (g.fast_act) {
+                        if constexpr (FAST) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) gt[e] = fast_sigmoidf(gt[e]);
                         } else {
@@ -103,7 +131,9 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
                         for (int e = 0; e < 4; ++e) v[u][e] = v[u][e] * gt[e];
                     }
                 }
-                if (g.out_bf16) {
+                constexpr int cq = 0;
+                (void)cq;
+                if constexpr (OUT16) {
                     typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
                     unsigned pk[2][2];
 #pragma unroll
@@ -115,18 +145,32 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
                     // upper half of group q <-> lower half of group q + 1: lanes 0-31 hold columns 8 q .. 8 q + 7, lanes 32-63 8 (q + 1) .. + 7
                     const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-                    if (row < g.M) {
+                    if (rok[i]) {
                         uint4 o;
                         o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
-                        *reinterpret_cast<uint4 *>(reinterpret_cast<__bf16 *>(g.out) + (int64_t)row * g.ldo + cb + 8 * h) = o;
+                        // blocked hand-off (GemmArgs::out_blocked): block (row / 32, cb / 16) of 32 x 16 elements, row-major inside -- the
+                        // wave's 64 stores of this instruction fill exactly one contiguous KB.  (compile-time offset from the row's base)
+                        const int rel = BLOCKED ? (2 * j + q / 2) * 512 : j * 32 + 8 * q;
+                        *reinterpret_cast<uint4 *>(out16 + roff[i] + rel) = o;
                     }
-                } else if (row < g.M) {
+                } else if (rok[i]) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
-                        *reinterpret_cast<float4 *>(g.out + (int64_t)row * g.ldo + cb + 8 * u + 4 * h) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+                        *reinterpret_cast<float4 *>(g.out + roff[i] + j * 32 + 8 * (q + u)) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
                 }
             }
         }
+    }
+}
+// (the direct form exists for the hardware-exp activations only -- what the bf16 mode always asks for, GemmArgs::fast_act: the launcher sends a
+// product with the polynomial activations to the LDS epilogue)
+template <int WGM, int WGN, int TM, int TN, int EPI>
+__device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 (&acc)[TM][TN], int m0, int n0) {
+    if (g.out_bf16) {
+        if (g.out_blocked) gl_epilogue_direct_body<WGM, WGN, TM, TN, EPI, true, true, true>(g, acc, m0, n0);
+        else gl_epilogue_direct_body<WGM, WGN, TM, TN, EPI, true, true, false>(g, acc, m0, n0);
+    } else {
+        gl_epilogue_direct_body<WGM, WGN, TM, TN, EPI, true, false, false>(g, acc, m0, n0);
     }
 }
 
@@ -139,7 +183,14 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
 // PERSIST + DIRECT (round 5): with the register epilogue nothing after the last K tile's barrier touches LDS, so BOTH first K tiles of the next
 // output tile are requested before the epilogue starts; the wait at the top of the loop then covers DMA that landed microseconds ago and the
 // epilogue's own stores (one counter for loads and stores on gfx950), instead of a cold two-tile prologue per round of tiles.
-template <int WGM, int WGN, int TM, int TN, int EPI, bool PERSIST = false, bool DIRECT = false, bool STAGGER = false>
+// ASMFRAG (round 5): the fragment reads are inline-asm ds_read_b128 with hand-counted s_waitcnt lgkmcnt(N).  Left to the compiler, two of the
+// four MFMA groups of a K tile were preceded by `s_waitcnt lgkmcnt(0)` -- its wait for the fragments loaded one sub-step earlier also drained
+// the six reads just issued for the NEXT sub-step (it does not count across the loop's back edge), i.e. a whole LDS round trip in front of the
+// MFMAs it was meant to overlap (ISA of round 4's kernel; tools/ubench/gemm_bf16_trace.cpp: 4500 clocks per K tile against 2048 of MFMA work).
+// Here the reads of sub-step s+1 stay in flight (lgkmcnt(TM + TN)) while the MFMAs of sub-step s issue; LDS reads return in order and no
+// scalar load is outstanding inside the loop.  The destination registers are tied to the wait by empty "+v" statements (cdna_hip_programming.md
+// 5.7 items 1 and 3), sched_barrier(0) keeps the MFMA builtins below them.
+template <int WGM, int WGN, int TM, int TN, int EPI, bool PERSIST = false, bool DIRECT = false, bool STAGGER = false, bool ASMFRAG = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs g, int tiles_n, int n_tiles) {
     constexpr int BK = 64, NSUB = BK / 16;                          // bf16 elements per tile row; MFMA k-steps per K tile
     constexpr int NT = 64 * WGM * WGN, NW = WGM * WGN;
@@ -195,7 +246,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
             if (row < BM) {
                 int gr = m0 + row;
                 gr = gr < g.M ? gr : g.M - 1;
-                src[i] = A16 + (int64_t)gr * g.lda + 8 * c;
+                // blocked hand-off (GemmArgs::a_blocked): chunk c of row gr, K tile 0 = block (gr / 32, c / 2), row gr % 32, half c % 2
+                if (g.a_blocked) src[i] = A16 + ((int64_t)(gr >> 5) * (g.lda >> 4) + (c >> 1)) * 512 + (gr & 31) * 16 + 8 * (c & 1);
+                else src[i] = A16 + (int64_t)gr * g.lda + 8 * c;
             } else {
                 const int v = row - BM;
                 int wr;
@@ -213,11 +266,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
             }
         }
     };
+    // elements between consecutive K tiles of a source: BK in a row-major operand, 4 blocks of 512 in the blocked A (64 k = 4 column groups of 16)
+    const int a_kstep = g.a_blocked ? 4 * 512 : BK;
     auto dma = [&](const __bf16 *const (&src)[NBPW], int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < NBPW; ++i) {
             __bf16 *dst = smem + buf * BUF + (wv + NW * i) * 512;                    // 1 KB = 512 bf16 per block; wave-uniform
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + kt * BK),
+            const bool is_a = 8 * (wv + NW * i) < BM;                                // (wave-uniform: a block is 8 rows of A or of W; BM % 8 == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + kt * (is_a ? a_kstep : BK)),
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
@@ -228,12 +284,41 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
     const int h = lane >> 5, fx = ((lane & 31) >> 1) & 7;
     const int fa_base = (wm * WM + (lane & 31)) * BK, fb_base = (BM + wn * WN + (lane & 31)) * BK;
     bg_bf16x8 fa[2][TM], fb[2][TN];
+    const unsigned lds0 = (unsigned)(size_t)smem;                   // low 32 bits of a flat LDS address = the LDS offset
     auto fragload = [&](int buf, int s, int slot) {
-        const __bf16 *base = smem + buf * BUF + (((2 * s + h) ^ fx) << 3);
+        if constexpr (ASMFRAG) {
+            const unsigned e = (unsigned)(buf * BUF + (((2 * s + h) ^ fx) << 3));
+            const unsigned aa = lds0 + 2u * (e + (unsigned)fa_base), ab = lds0 + 2u * (e + (unsigned)fb_base);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const bg_bf16x8 *>(base + fa_base + i * 32 * BK);
+            for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[slot][i]) : "v"(aa), "n"(i * 32 * BK * 2));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const bg_bf16x8 *>(base + fb_base + j * 32 * BK);
+            for (int j = 0; j < TN; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[slot][j]) : "v"(ab), "n"(j * 32 * BK * 2));
+        } else {
+            const __bf16 *base = smem + buf * BUF + (((2 * s + h) ^ fx) << 3);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const bg_bf16x8 *>(base + fa_base + i * 32 * BK);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const bg_bf16x8 *>(base + fb_base + j * 32 * BK);
+        }
+    };
+    // ASMFRAG: the fragments of `slot` are needed now; the TM + TN reads issued after them (frag_ready_one) / none (frag_ready_none) may stay in flight
+    auto frag_pin = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[slot][i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[slot][j]));
+    };
+    auto frag_ready_one = [&](int slot) {
+        if constexpr (ASMFRAG) {
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
+            frag_pin(slot);
+        }
+    };
+    auto frag_ready_none = [&](int slot) {
+        if constexpr (ASMFRAG) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            frag_pin(slot);
+        }
     };
     auto mma = [&](int slot) {
 #pragma unroll
@@ -246,15 +331,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
     };
 #define GL_SB() __builtin_amdgcn_sched_barrier(0)
 #define GL_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)           /* vmcnt(0): this wave's LDS-DMA loads have landed */
+#define GL_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)         /* lgkmcnt(0) only: this wave's LDS reads have returned */
 
     const __bf16 *src[NBPW];
     int m0, n0;
     tile_origin(x_first + loc, m0, n0);
     set_src(m0, n0, src);
     int cur = 0;
+    int tr_tile = 0;
+    (void)tr_tile;
     dma(src, 0, 0);
     if (nk > 1) dma(src, 1, 1);
     for (;;) {
+        GL_STAMP(tr_tile, 0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -266,24 +355,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
         // once per tile instead of two on a cold chip)
         GL_WAIT_VM0();
         __syncthreads();
+        GL_STAMP(tr_tile, 1);
         fragload(cur, 0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
 #pragma unroll
             for (int s = 0; s < NSUB - 1; ++s) {
                 fragload(cur, s + 1, (s + 1) & 1);
+                frag_ready_one(s & 1);                        // (the reads just issued stay in flight)
                 GL_SB(); mma(s & 1); GL_SB();
             }
+            frag_ready_none((NSUB - 1) & 1);                  // the last fragments of this K tile are in registers: every read of `cur` has returned
             GL_WAIT_VM0();                 // K tile kt+1 (issued a whole tile ago) is in LDS
             __syncthreads();               // ... for every wave; and every wave holds its last fragments of tile kt: buffer `cur` is free
+            GL_STAMP(tr_tile, 2 + kt);
             if (more1) fragload(cur ^ 1, 0, 0);
             if (more2 && !late) dma(src, kt + 2, cur);
             GL_SB(); mma((NSUB - 1) & 1); GL_SB();
             if constexpr (STAGGER) { if (more2 && late) dma(src, kt + 2, cur); }
+            // (compiler-scheduled reads only; ASMFRAG counts by hand)
+            // The fragments read after the barrier are long in their registers by now (eight DMA issues and eight MFMAs later); saying so HERE
+            // keeps the compiler from draining LDS at the top of the loop instead -- where its wait (it cannot count across the back edge: lgkmcnt(0))
+            // would also cover the six reads issued there for the NEXT sub-step and put a whole LDS round trip in front of the first MFMA group of
+            // every K tile (found in the ISA, round 5; tools/ubench/gemm_bf16_trace.cpp: K tile 4500 -> see profiles/r05_bf16_lgkm_ab.txt)
+            if constexpr (!ASMFRAG) GL_WAIT_LGKM0();
             cur ^= 1;
         }
         // `cur` = the buffer the last K tile did NOT use (free since the barrier of the last iteration); the other one is free too once every
         // wave has passed that barrier -- which the epilogue's own first barrier guarantees again
+        GL_STAMP(tr_tile, 2 + nk);
         if constexpr (PERSIST && DIRECT) {
             const int em0 = m0, en0 = n0;
             loc += per_xcd;
@@ -295,6 +395,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
                 if (nk > 1) dma(src, 1, cur ^ 1);
             }
             gl_epilogue_direct<WGM, WGN, TM, TN, EPI>(g, acc, em0, en0);
+            GL_STAMP(tr_tile, 3 + nk);
+            ++tr_tile;
             if (!more) break;
         } else if constexpr (DIRECT) {
             gl_epilogue_direct<WGM, WGN, TM, TN, EPI>(g, acc, m0, n0);
@@ -319,23 +421,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
     }
 #undef GL_SB
 #undef GL_WAIT_VM0
+#undef GL_WAIT_LGKM0
 }
 
 // persist: 0 = one tile per workgroup, 1 = persistent with the LDS epilogue (round 4), 2 = persistent (more than 256 tiles) with the DIRECT
 // register epilogue, 3 = the direct epilogue on one tile per workgroup
 template <int WGM, int WGN, int TM, int TN, int EPI>
-static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist = 0, bool stagger = false) {
+static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist = 0, bool stagger = false, bool asmfrag = false) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
     const int n_tiles = tiles_m * tiles_n;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;
     if constexpr (EPI != EPI_RESID) {
-        const bool direct_ok = a.sigma_cols == 0 && a.remap_rows == 0 && (a.N % 16) == 0 && (a.ldo % 8) == 0;
+        const bool direct_ok = a.sigma_cols == 0 && a.remap_rows == 0 && (a.N % 16) == 0 && (a.ldo % 8) == 0 &&
+                               (a.fast_act || (EPI != EPI_SILU && EPI != EPI_GLU)) && ((int64_t)(a.M + 31) * a.ldo < ((int64_t)1 << 31));
         if (persist >= 2 && direct_ok) {
             if (persist == 2 && n_tiles > 256) {
                 if (stagger) {
                     auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true, true>;
+                    static DynLdsSlots slots;
+                    ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+                    hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+                    return;
+                }
+                if (asmfrag) {
+                    auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true, false, true>;
                     static DynLdsSlots slots;
                     ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
                     hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
@@ -354,6 +465,7 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
             return;
         }
     }
+    if (a.out_blocked) { fprintf(stderr, "parakeet_amd: internal error: blocked output on the LDS epilogue\n"); abort(); }
     if (persist == 1 && n_tiles > 256) {                                // more than one round of the 256 CUs: one persistent workgroup per CU
         auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true>;
         static DynLdsSlots slots;
@@ -363,6 +475,13 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
     }
     if (stagger) {
         auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, false, true>;
+        static DynLdsSlots slots;
+        ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+        return;
+    }
+    if (asmfrag) {
+        auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, false, false, true>;
         static DynLdsSlots slots;
         ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);

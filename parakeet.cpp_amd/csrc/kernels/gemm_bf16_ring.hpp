@@ -27,7 +27,16 @@
 
 namespace pk {
 
-template <int WGM, int WGN, int TM, int TN, int EPI, bool STAGGER = false>
+// PHASED (round 5, second form): the 8-phase idea of cdna_hip_programming.md section 5 on this ring.  The K loop of the forms above keeps the matrix
+// pipe busy ~45 % of its clocks (tools/ubench/gemm_bf16_trace.cpp: 4500 clocks per 64-k tile against 2048 of MFMA issue) although neither the DMA's
+// latency (ring), nor the LDS round trips (ASMFRAG), nor the epilogue are in the way any more: the two waves of a SIMD do the same thing at the same
+// time -- both read fragments and request DMA, then both want the pipe.  Here every 32-k tile is four ITEMS per wave -- L0 (read the fragments of
+// k-step 0, wait for them), M0 (8-12 MFMAs, the first half of this wave's DMA requests of tile t+3 between them), L1 (fragments of k-step 1; the
+// counted wait that publishes tile t+1), M1 -- with a raw s_barrier after every item, and the second half of the waves (w + NW / 2 shares its SIMD
+// with w) runs ONE ITEM BEHIND the first: while one wave of a SIMD is in an M item the other is in an L item, enforced by the barriers rather than
+// hoped for.  The halves re-align around the epilogue (one extra barrier each), which both run together.  One fragment register set.
+// PRIO: s_setprio 1 around the MFMA items (T5: it has something to arbitrate in this structure).
+template <int WGM, int WGN, int TM, int TN, int EPI, bool STAGGER = false, bool PHASED = false, bool PRIO = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_ring_kernel(GemmArgs g, int tiles_n, int n_tiles) {
     constexpr int BK = 32, NR = 4;                                  // bf16 elements per slot row; ring slots
     constexpr int NW = WGM * WGN;
@@ -99,9 +108,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_ring_kernel(GemmArgs
             }
         }
     };
-    auto dma = [&](const __bf16 *const (&src)[NBPW], int kt, int slot) {
+    auto dma = [&](const __bf16 *const (&src)[NBPW], int kt, int slot, int i0, int i1) {
 #pragma unroll
         for (int i = 0; i < NBPW; ++i) {
+            if (i < i0 || i >= i1) continue;                                         // (PHASED: the pieces of one half)
             if (NEXTRA != 0 && i == NBPW - 1 && wv >= NEXTRA) continue;              // (wave-uniform: this wave has one block fewer)
             __bf16 *dst = smem + slot * SLOT + (wv + NW * i) * 512;                  // 1 KB = 512 bf16 per block; wave-uniform
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + kt * BK),
@@ -117,7 +127,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_ring_kernel(GemmArgs
     set_src(p_m0, p_n0, p_src);
     auto produce = [&]() {
         if (!p_valid) return;                                       // (wave-uniform: the stream has ended)
-        dma(p_src, p_kt, p_kt & (NR - 1));
+        dma(p_src, p_kt, p_kt & (NR - 1), 0, NBPW);
+        if (++p_kt == nk) {
+            p_kt = 0;
+            p_loc += per_xcd;
+            p_valid = p_loc < x_count;
+            if (p_valid) {
+                tile_origin(x_first + p_loc, p_m0, p_n0);
+                set_src(p_m0, p_n0, p_src);
+            }
+        }
+    };
+
+    // PHASED: the same cursor in two halves -- half 0 requests pieces [0, NBPW / 2) of the cursor's tile, half 1 the rest and advances
+    auto produce_half = [&](int half) {
+        if (!p_valid) return;
+        if (half == 0) { dma(p_src, p_kt, p_kt & (NR - 1), 0, NBPW / 2); return; }
+        dma(p_src, p_kt, p_kt & (NR - 1), NBPW / 2, NBPW);
         if (++p_kt == nk) {
             p_kt = 0;
             p_loc += per_xcd;
@@ -156,6 +182,88 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_ring_kernel(GemmArgs
     // raw s_barrier (a __syncthreads() would drain the LDS-DMA still in flight: vmcnt(0)); the empty asm keeps the compiler's LDS reads below it
 #define RG_BARRIER() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
+    if constexpr (PHASED) {
+        const bool grp1 = wv >= NW / 2;                             // the half that runs one item behind
+        const unsigned lds0 = (unsigned)(size_t)smem;
+        auto fragload_asm = [&](int slot, int s_) {                 // hand-counted reads (gemm_bf16_glds.hpp ASMFRAG), one register set
+            const unsigned e = (unsigned)(slot * SLOT + (((2 * s_ + h) ^ fx) << 3));
+            const unsigned aa = lds0 + 2u * (e + (unsigned)fa_base), ab = lds0 + 2u * (e + (unsigned)fb_base);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i]) : "v"(aa), "n"(i * 32 * BK * 2));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][j]) : "v"(ab), "n"(j * 32 * BK * 2));
+        };
+        auto frag_pin = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[0][i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[0][j]));
+        };
+        // an M item: the MFMAs of one k-step with one half of this wave's DMA requests of tile t + 3 between them
+        auto m_item = [&](int half) {
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
+                    if (++n == 2) produce_half(half);
+                }
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+        };
+        // pieces of one tile this wave requests (P) and of its first half (H0): the counted wait of L1 lets tile t + 2 and the first half of t + 3 fly
+        const bool short_wave = NEXTRA != 0 && wv >= NEXTRA;
+#define RG_WAIT_L1() do { if (short_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NBPW - 1 + NBPW / 2) : "memory"); \
+                          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NBPW + NBPW / 2) : "memory"); } while (0)
+        // prologue: tiles 0, 1, 2 requested in full; tile 0 landed and published
+#pragma unroll
+        for (int i = 0; i < NR - 1; ++i) { produce_half(0); produce_half(1); }
+        if (total > NR - 2) RG_WAIT(NR - 2); else RG_WAIT(0);
+        RG_BARRIER();
+        int gt = 0;
+        int loc = idx, m0, n0;
+        tile_origin(x_first + loc, m0, n0);
+        for (;;) {
+            if (grp1) RG_BARRIER();                                 // one item behind the first half
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int kt0 = 0; kt0 < nk; kt0 += NR) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {                      // K tile kt0 + u lives in slot u
+                    // L0: fragments of k-step 0 (published by the L1 barriers of tile gt - 1 / the prologue)
+                    fragload_asm(u, 0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    frag_pin();
+                    RG_BARRIER();
+                    // M0 (+ first half of the requests of tile gt + 3 into the slot tile gt - 1 left two barriers ago)
+                    RG_SB(); m_item(0); RG_SB();
+                    RG_BARRIER();
+                    // L1: fragments of k-step 1; tile gt + 1 must have landed before the next tile's L0 of EITHER half: every wave waits for its own
+                    // pieces here, and both halves' L1 barriers lie before the first half's next L0
+                    fragload_asm(u, 1);
+                    if (gt + NR - 1 >= total) RG_WAIT(0); else RG_WAIT_L1();
+                    frag_pin();
+                    RG_BARRIER();
+                    // M1 (+ second half of the requests)
+                    RG_SB(); m_item(1); RG_SB();
+                    RG_BARRIER();
+                    ++gt;
+                }
+            }
+            if (!grp1) RG_BARRIER();                                // the halves meet again: the epilogue runs on both together
+            gl_epilogue_direct<WGM, WGN, TM, TN, EPI>(g, acc, m0, n0);
+            loc += per_xcd;
+            if (loc >= x_count) break;
+            tile_origin(x_first + loc, m0, n0);
+        }
+#undef RG_WAIT_L1
+        return;
+    }
     // prologue: the first NR tiles of the stream are requested; tile 0 must have landed before the first fragment read
 #pragma unroll
     for (int i = 0; i < NR; ++i) produce();
@@ -205,19 +313,34 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_ring_kernel(GemmArgs
 // applies: persistent walk over more tiles than CUs, K a multiple of 4 x 32, the direct epilogue's output form
 template <int EPI>
 static bool gemm_bf16_ring_applies(const GemmArgs &a) {
-    return EPI != EPI_RESID && a.sigma_cols == 0 && a.remap_rows == 0 && (a.N % 16) == 0 && (a.ldo % 8) == 0 && (a.K % 128) == 0 && (a.lda % 8) == 0 &&
+    return EPI != EPI_RESID && !a.out_blocked && !a.a_blocked && a.sigma_cols == 0 && a.remap_rows == 0 && (a.N % 16) == 0 && (a.ldo % 8) == 0 && (a.K % 128) == 0 && (a.lda % 8) == 0 &&
            (a.ldw % 8) == 0;
 }
 
+// mode: 0 = the plain ring, 1 = STAGGER, 2 = PHASED, 3 = PHASED + s_setprio
 template <int WGM, int WGN, int TM, int TN, int EPI>
-static void launch_gemm_bf16_ring(const GemmArgs &a, hipStream_t s, bool stagger = false) {
+static void launch_gemm_bf16_ring(const GemmArgs &a, hipStream_t s, int mode = 0) {
     if constexpr (EPI != EPI_RESID) {
         constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
         constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
         const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
         const int n_tiles = tiles_m * tiles_n;
         constexpr size_t lds = 4 * (size_t)(BM + BN) * 32 * 2;
-        if (stagger) {
+        if (mode == 2 || mode == 3) {                               // PHASED (3: + s_setprio)
+            if (mode == 3) {
+                auto kern = &gemm_bf16_ring_kernel<WGM, WGN, TM, TN, EPI, false, true, true>;
+                static DynLdsSlots slots;
+                ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+                hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+                return;
+            }
+            auto kern = &gemm_bf16_ring_kernel<WGM, WGN, TM, TN, EPI, false, true, false>;
+            static DynLdsSlots slots;
+            ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+            hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+            return;
+        }
+        if (mode == 1) {
             auto kern = &gemm_bf16_ring_kernel<WGM, WGN, TM, TN, EPI, true>;
             static DynLdsSlots slots;
             ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);

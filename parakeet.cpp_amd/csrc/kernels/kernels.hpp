@@ -95,6 +95,14 @@ struct GemmArgs {
     // rounding the staging path would apply -- same operand values, half the bytes); out points to a bf16 buffer [M][ldo] (the next
     // product's A operand; row-major wide outputs only).
     int a_bf16 = 0, out_bf16 = 0;
+    // bf16 mode, direct-to-LDS kernels (gemm_bf16_glds.hpp) only: the bf16 activation tensor between a producer's register epilogue and the
+    // next product's LDS-DMA lives in BLOCKS of 32 rows x 16 columns (1 KB, row-major inside; blocks ordered [row / 32][col / 16]): one store
+    // instruction of the producer's epilogue (32 rows x 2 x 16 bytes) then writes ONE contiguous KB instead of 32 row slivers of 32 bytes,
+    // and the consumer's DMA (which gathers 16-byte chunks by per-lane address anyway) reads it in 256-byte runs.  out_blocked: `out` is
+    // written that way (ldo = the row length in elements, a multiple of 16; rows padded to a multiple of 32 by the allocation);
+    // a_blocked: `A` is read that way (lda = its row length).  Set by the engine for fc1 -> fc2 when gemm_bf16_blocked_handoff() says both take
+    // those kernels.
+    int out_blocked = 0, a_blocked = 0;
     // bf16 mode only: SiLU / sigmoid of the epilogue on the hardware exp2 / rcp (1 ulp) instead of the fixed polynomial + IEEE division of the
     // numerics contract -- that mode is compared with the oracle within a bf16-epsilon-class tolerance, not bit for bit, and at bf16 MFMA rates
     // the 38-operation SiLU is as expensive as the product itself (fc1 of tdt-600m: ~48 us of VALU against 40 us of MFMA).
@@ -116,6 +124,9 @@ constexpr int kSmallMRows = 1536;  // launch_gemm: products with M <= this (and 
 // src [rows][ld] -> dst rows x K floats in the W_sig tiling (rows % 16 == 0, K % 64 == 0)
 void launch_sigma_copy(const float *src, float *dst, int64_t rows, int K, int64_t ld, hipStream_t s);
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
+// bf16 mode: true when the product (M x N x K, bf16 A already in HBM, epilogue `epi`) runs on a direct-to-LDS kernel that can write
+// (producer = true: register epilogue) / read (producer = false: LDS-DMA) the blocked activation layout of GemmArgs::out_blocked / a_blocked
+bool gemm_bf16_blocked_handoff(int M, int N, int K, int epi, bool producer);
 // fp32 small-M chain kernel with GemmArgs::ln_g set (kernels/gemm_smallm.hip: gemm_smallm_ln_kernel): A = the un-normalised rows, K = 512 / 1024 = the
 // row length, tiled weights W_sig, epi none / relu / silu / glu -- bit for bit LayerNorm + product.  Callers check this first.
 bool gemm_smallm_ln_applies(const GemmArgs &a, int epi);
