@@ -451,19 +451,23 @@ const std::vector<Model::SigW> &Model::sigma_weights() {
     if (sig_built_) return sig_layers_;
     require_gpu();
     const size_t d = cfg.hidden_size, f = cfg.ffn_intermediate;
-    if (cfg.gemm_bf16 || d % 64 || f % 64) { sig_built_ = true; return sig_layers_; }
-    // (+ one more copy of the encoder's product weights in HBM: 0.4 GB for tdt-ctc-110m, 2.4 GB for the 600M models; pk_model_to_gpu's note)
+    if (d % 64 || f % 64) { sig_built_ = true; return sig_layers_; }
+    // (+ one more copy of the encoder's product weights in HBM: 0.4 GB for tdt-ctc-110m, 2.4 GB for the 600M models, half that in the bf16
+    //  mode; pk_model_to_gpu's note)
+    // gemm_bf16 mode: the same eight weights per layer as bf16 OPERAND TILES of the small-M bf16 kernel (GemmArgs::W_t16)
+    const bool b16 = cfg.gemm_bf16 != 0;
     const size_t per_layer = 4 * f * d + 7 * d * d;
     try {
-        sig_buf_.reserve((size_t)cfg.num_layers * per_layer * 4);
+        sig_buf_.reserve((size_t)cfg.num_layers * per_layer * (b16 ? 2 : 4));
         float *p = sig_buf_.as<float>();
         sig_layers_.resize(cfg.num_layers);
         for (int l = 0; l < cfg.num_layers; ++l) {
             const LayerW &W = layers[l];
             auto sig = [&](const float *w, size_t rows, size_t K) {
-                launch_sigma_copy(w, p, (int64_t)rows, (int)K, (int64_t)K, stream);
+                if (b16) launch_tile_copy_bf16(w, p, (int64_t)rows, (int)K, (int64_t)K, stream);
+                else launch_sigma_copy(w, p, (int64_t)rows, (int)K, (int64_t)K, stream);
                 const float *r = p;
-                p += rows * K;
+                p += b16 ? rows * K / 2 : rows * K;                 // (bf16: two elements per float slot)
                 return r;
             };
             SigW &S = sig_layers_[l];

@@ -438,6 +438,7 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
                                (a.fast_act || (EPI != EPI_SILU && EPI != EPI_GLU)) && ((int64_t)(a.M + 31) * a.ldo < ((int64_t)1 << 31));
         if (persist >= 2 && direct_ok) {
             if (persist == 2 && n_tiles > 256) {
+#ifdef PK_EXPERIMENTAL
                 if (stagger) {
                     auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true, true>;
                     static DynLdsSlots slots;
@@ -445,6 +446,7 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
                     hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
                     return;
                 }
+#endif
                 if (asmfrag) {
                     auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true, false, true>;
                     static DynLdsSlots slots;
@@ -466,6 +468,7 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
         }
     }
     if (a.out_blocked) { fprintf(stderr, "parakeet_amd: internal error: blocked output on the LDS epilogue\n"); abort(); }
+#ifdef PK_EXPERIMENTAL
     if (persist == 1 && n_tiles > 256) {                                // more than one round of the 256 CUs: one persistent workgroup per CU
         auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true>;
         static DynLdsSlots slots;
@@ -480,6 +483,7 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
         return;
     }
+#endif
     if (asmfrag) {
         auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, false, false, true>;
         static DynLdsSlots slots;

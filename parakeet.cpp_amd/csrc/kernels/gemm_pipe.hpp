@@ -17,6 +17,8 @@
 //    MFMA rate; what is left is the write burst of the output tile (all workgroups of a round finish together).
 #ifndef PK_GEMM_PIPE_HPP
 #define PK_GEMM_PIPE_HPP
+#include <cstdio>
+#include <cstdlib>
 #include "../pk_devmath.h"
 #include "kernels.hpp"
 
@@ -29,8 +31,14 @@ typedef float gp_f32x16 __attribute__((ext_vector_type(16)));
 // CAP its size in floats: the wide path turns the C tile row-major through it (in row bands when it does not fit).
 // RS_PER_PASS: the residual rows of a band are requested at the start of that band's pass instead of all up front (tiles of 256 rows:
 // NCH = 32 chunks per thread would otherwise hold 128 VGPRs of residual beside the accumulators).
-template <int WGM, int WGN, int TM, int TN, int EPI, int CAP_FLOATS, bool RS_PER_PASS = false>
-__device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[TM][TN], float *smem, int m0, int n0) {
+// EXACT (round 5): the caller is an fp32-contract kernel (gemm_pipe_kernel: GemmArgs::fast_act and out_bf16 are never set, the launcher checks) --
+// the two run-time switches become compile-time false, which removes a branch and the hardware-exp twin of the activation from every group of four
+// results of the fully unrolled epilogue (the bf16 register epilogue lost a third of its clocks to exactly this: gemm_bf16_glds.hpp).
+template <int WGM, int WGN, int TM, int TN, int EPI, int CAP_FLOATS, bool RS_PER_PASS = false, bool EXACT = false>
+__device__ __forceinline__ void gp_epilogue(const GemmArgs &g_, gp_f32x16 (&acc)[TM][TN], float *smem, int m0, int n0) {
+    struct Flags { int fast_act, out_bf16; };
+    const Flags gf{EXACT ? 0 : g_.fast_act, EXACT ? 0 : g_.out_bf16};
+    const GemmArgs &g = g_;
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
@@ -58,14 +66,14 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
                     if constexpr (EPI == EPI_RELU) {
                         v = v > 0.0f ? v : 0.0f;
                     } else if constexpr (EPI == EPI_SILU) {
-                        v = g.fast_act ? fast_siluf(v) : dsiluf(v);
+                        v = gf.fast_act ? fast_siluf(v) : dsiluf(v);
                     } else if constexpr (EPI == EPI_RESID) {
                         const float y = v * g.alpha;
                         v = g.resid[(int64_t)row * g.ldr + col] + y;
                     } else if constexpr (EPI == EPI_GLU) {
                         float gt = acc[i][j + TN / 2][r];
                         if (g.bias) gt = gt + bias_g;
-                        v = v * (g.fast_act ? fast_sigmoidf(gt) : dsigmoidf(gt));
+                        v = v * (gf.fast_act ? fast_sigmoidf(gt) : dsigmoidf(gt));
                     }
                     if (g.remap_rows) g.out[(int64_t)(row / g.remap_rows) * g.remap_gs + (int64_t)(row % g.remap_rows) * g.remap_rs + (int64_t)col * g.remap_cs] = v;
                     else g.out[(int64_t)row * g.ldo + (col < g.sigma_cols ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = v;
@@ -173,7 +181,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
             } else if constexpr (EPI == EPI_SILU) {
-                if (g.fast_act) {
+                if (gf.fast_act) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fast_siluf(v[e]);
                 } else {
@@ -183,7 +191,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float y = v[e] * g.alpha; v[e] = rsv[e] + y; }
             } else if constexpr (EPI == EPI_GLU) {
-                if (g.fast_act) {
+                if (gf.fast_act) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) gt[e] = fast_sigmoidf(gt[e]);
                 } else {
@@ -193,7 +201,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g, gp_f32x16 (&acc)[
                 for (int e = 0; e < 4; ++e) v[e] = v[e] * gt[e];
             }
             if (row < g.M && col_ok) {
-                if (g.out_bf16) {                                   // bf16 activations (gemm_bf16.hpp): 4 results = 8 bytes
+                if (gf.out_bf16) {                                  // bf16 activations (gemm_bf16.hpp): 4 results = 8 bytes
                     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
                     const bf16x4_ o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                     *reinterpret_cast<bf16x4_ *>(reinterpret_cast<__bf16 *>(g.out) + (int64_t)row * g.ldo + col0) = o;
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             }
         }
     };
-    auto epilogue = [&](int m0, int n0) { gp_epilogue<WGM, WGN, TM, TN, EPI, NBUF * BUF>(g, acc, smem, m0, n0); };
+    auto epilogue = [&](int m0, int n0) { gp_epilogue<WGM, WGN, TM, TN, EPI, NBUF * BUF, false, true>(g, acc, smem, m0, n0); };
 #define GP_SB() __builtin_amdgcn_sched_barrier(0)
 
     int m0, n0;
@@ -408,6 +416,7 @@ static void launch_gemm_pipe(const GemmArgs &a, hipStream_t s) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
     const int n_tiles = tiles_m * tiles_n;
     constexpr size_t lds = NBUF * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    if (a.fast_act || a.out_bf16) { fprintf(stderr, "parakeet_amd: internal error: bf16-mode switches on the fp32 GEMM\n"); abort(); }
     auto kern = &gemm_pipe_kernel<WGM, WGN, TM, TN, BK, EPI, NBUF>;
     static DynLdsSlots slots;
     ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);

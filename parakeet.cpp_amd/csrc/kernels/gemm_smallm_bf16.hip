@@ -30,6 +30,10 @@
 //     partial sums meet in LDS, added in wave order), normalises with gamma / beta staged once per wave in LDS, rounds to bf16.  Slices of
 //     256 k, ONE per wave: K = 256 * split, split <= 8.  (The exact fp32 mode tried this in round 3 and lost: one WAVE per 16x16 tile
 //     re-derived the statistics over the whole K, 3-4 us on the dependent chain.  Here they cost two LDS exchanges.)
+//   * weights in OPERAND TILES (GemmArgs::W_t16, round 5): a copy of W16 in the order the lanes load it -- per (16 output columns, 32 k) one KB
+//     [lane][8 bf16], tiles ordered [N / 16][K / 32] -- so a load instruction reads ONE contiguous KB instead of 16 row segments of 64 bytes
+//     (tools/ubench/cu_ingest.cpp, profiles/r05_cu_ingest_patterns.txt: out of L2 a CU pulls 14-18 B/clk in whole lines against 10-12 B/clk in
+//     64-byte segments of 16 rows; what a product costs is what its busiest CU pulls).  Same values in the same lanes: bit-identical results.
 // Specification = the oracle's gemm_bf16 mode (oracle/pk_oracle.c linear_t: both operands rounded to bf16, k-ordered fp32 accumulation);
 // the accumulation ORDER differs (MFMA blocks of 32 k, K slices), so results are compared within the mode's tolerance
 // (tests/test_gpu_bf16.py: against float64 of the same rounded operands; tests/test_gpu_stream.py: the streaming mode against the oracle's).
@@ -43,9 +47,20 @@ typedef __bf16 sb_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kSbMaxWaves = 8;      // waves per workgroup (2 per SIMD: 256 VGPRs each -- the up-front slices need them)
 
+// Phase stamps for tools/ubench/smallm_bf16_trace.cpp (-DSB_TRACE): shader clock of lane 0 of every wave -- [workgroup][wave][8]: 0 kernel entry,
+// 1 every load of the slice issued, 2 activation rows arrived (first use), 3 LayerNorm applied / rows converted, 4 weights arrived + MFMAs issued,
+// 5 partial sums exchanged (after the barrier), 6 epilogue stores issued.  Production builds: nothing.
+#ifdef SB_TRACE
+__device__ unsigned long long *sb_trace;
+#define SB_STAMP(i) do { if (sb_trace && (threadIdx.x & 63) == 0) sb_trace[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kSbMaxWaves + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SB_STAMP(i) do { } while (0)
+#endif
+
 template <int EPI, int STEPS /* MFMA steps (32 k each) per K slice */, int RT /* 16-row MFMA tiles per wave */, bool A16 /* A is bf16 [M][lda] */,
           bool LN /* fold LayerNorm(A; ln_g, ln_b, ln_eps) in: A fp32, STEPS = 8 or 4, one slice per wave */,
-          int CT = 1 /* 16-column tiles per wave: the activation registers of a K slice feed CT weight tiles (round 5) */, bool NTW = false /* non-temporal weight loads */>
+          int CT = 1 /* 16-column tiles per wave: the activation registers of a K slice feed CT weight tiles (round 5) */, bool NTW = false /* non-temporal weight loads */,
+          bool WT = false /* weights from the operand-tile copy GemmArgs::W_t16 */>
 __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(GemmArgs g, int split /* waves = K slices in flight */,
                                                                             int rvalid /* rows of a 16-row tile that exist: 16, or 8 (RT = 1) */) {
     constexpr int NW = (EPI == EPI_GLU) ? 2 : 1;                    // weight tiles per column tile (GLU: value rows [0, N), gate rows [N, 2N))
@@ -55,6 +70,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
     __shared__ __attribute__((aligned(16))) float gam[LN ? kSbMaxWaves : 1][LN ? SL : 4], bet[LN ? kSbMaxWaves : 1][LN ? SL : 4];
     __shared__ float st1[LN ? kSbMaxWaves : 1][RT][16], st2[LN ? kSbMaxWaves : 1][RT][16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SB_STAMP(0);
     const int r = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16 * CT, m0 = blockIdx.y * (RT == 2 ? 32 : rvalid);
     const int nslices = g.K / SL;
@@ -92,7 +108,10 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
         int wrow = n0 + 16 * c + r;
         wrow = wrow < g.N ? wrow : g.N - 1;
 #pragma unroll
-        for (int h = 0; h < NW; ++h) wp[h][c] = reinterpret_cast<const __bf16 *>(g.W) + (int64_t)(h * g.N + wrow) * g.ldw + 8 * kq;
+        for (int h = 0; h < NW; ++h) {
+            if constexpr (WT) wp[h][c] = reinterpret_cast<const __bf16 *>(g.W_t16) + (int64_t)((h * g.N + n0 + 16 * c) >> 4) * (g.K >> 5) * 512 + 8 * lane;   // (N % 16 == 0)
+            else wp[h][c] = reinterpret_cast<const __bf16 *>(g.W) + (int64_t)(h * g.N + wrow) * g.ldw + 8 * kq;
+        }
     }
     const __bf16 *ap16[RT];
     const float *ap32[RT];
@@ -135,11 +154,12 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
             for (int c = 0; c < CT; ++c)
 #pragma unroll
                 for (int s = 0; s < STEPS; ++s) {
-                    const sb_bf16x8 *src = reinterpret_cast<const sb_bf16x8 *>(wp[h][c] + k0 + 32 * s);
+                    const sb_bf16x8 *src = reinterpret_cast<const sb_bf16x8 *>(WT ? wp[h][c] + (k0 / 32 + s) * 512 : wp[h][c] + k0 + 32 * s);
                     if constexpr (NTW) w[h][c][s] = __builtin_nontemporal_load(src);      // each weight byte is read once per chunk: do not keep it
                     else w[h][c][s] = *src;
                 }
         __builtin_amdgcn_sched_barrier(0);                          // every load of the slice is issued before anything waits
+        SB_STAMP(1);
 
         if constexpr (LN) {
             // gamma / beta of this wave's slice: wave-private LDS rows, read back after the barriers below
@@ -162,6 +182,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                 p += __shfl_xor(p, 32);
                 if (kq == 0) st1[wave][t][r] = p;
             }
+            SB_STAMP(2);
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
@@ -215,6 +236,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                     a[t][s] = v;
                 }
         }
+        SB_STAMP(3);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s)
 #pragma unroll
@@ -225,6 +247,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                     for (int t = 0; t < RT; ++t) acc[h][c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][s], w[h][c][s], acc[h][c][t], 0, 0, 0);
     }
 
+    SB_STAMP(4);
     // the K slices meet: partial sums through LDS, added in wave order
     if (split > 1) {
 #pragma unroll
@@ -235,6 +258,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                 for (int t = 0; t < RT; ++t) part[wave][h][c][t][lane] = acc[h][c][t];
         __syncthreads();
     }
+    SB_STAMP(5);
     if (wave >= RT * CT) return;                                    // (launched with split >= RT * CT whenever RT * CT > 1)
     const int t = et;                                               // this wave finishes row tile et of column tile ec
     sb_f32x4 v = acc[0][0][0], gt = acc[NW - 1][0][0];              // (split == 1: RT = CT = 1)
@@ -269,6 +293,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
         if (g.out_bf16) reinterpret_cast<__bf16 *>(g.out)[(int64_t)row * g.ldo + col] = (__bf16)o;
         else g.out[(int64_t)row * g.ldo + col] = o;
     }
+    SB_STAMP(6);
 }
 
 // the shapes this kernel takes (everything else stays on the tile kernels of gemm_bf16.hpp)
@@ -295,52 +320,69 @@ static int sb_rows_per_wg(const GemmArgs &a, int nslices, bool glu, int tiles) {
     return 8;
 }
 
-// Tuning of the column tiles per wave (CT) and the weight-load cache policy.  A production build has constants; experiment builds
-// (make EXPERIMENTAL=1) read PK_SB_CT (0 = the heuristic) / PK_SB_NT / PK_SB_ROWS (0 = the heuristic) for A/B runs (tools/experiments/).
-struct SbTune { int ct, nt, rows; };
+// Tuning of the column tiles per wave (CT) and the weight-load cache policy.  A production build has the heuristic below; experiment builds
+// (make EXPERIMENTAL=1) read PK_SB_CT (0 = the heuristic) / PK_SB_NT / PK_SB_ROWS (0 = the heuristic) / PK_SB_WT (0: ignore the operand-tile
+// copy) for A/B runs (tools/experiments/).
+struct SbTune { int ct, nt, rows, wt; };
 static SbTune sb_tune() {
 #ifdef PK_EXPERIMENTAL
     static const SbTune t = [] {
         auto rd = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
-        return SbTune{rd("PK_SB_CT", 0), rd("PK_SB_NT", 0), rd("PK_SB_ROWS", 0)};
+        return SbTune{rd("PK_SB_CT", 0), rd("PK_SB_NT", 0), rd("PK_SB_ROWS", 0), rd("PK_SB_WT", 1)};
     }();
     return t;
 #else
-    return SbTune{0, 0, 0};
+    return SbTune{0, 0, 0, 1};
 #endif
 }
 
-template <int EPI, int STEPS, bool A16, bool LN, int CT, bool NTW>
-static void launch_sb_ct(const GemmArgs &a, hipStream_t s, int rows_forced) {
+template <int EPI, int STEPS, bool A16, bool LN, int CT, bool NTW, bool WT>
+static void launch_sb_ct(const GemmArgs &a, hipStream_t s, int R) {
     const int nslices = a.K / (32 * STEPS);
     const int split = nslices < kSbMaxWaves ? nslices : kSbMaxWaves;
     const int tiles = (a.N + 16 * CT - 1) / (16 * CT);
-    int R = rows_forced ? rows_forced : sb_rows_per_wg(a, nslices, EPI == EPI_GLU, tiles * (CT > 1 ? 2 : 1));
     if (EPI == EPI_GLU && R == 32) R = 16;
-    if (R == 32 && split < 2 * CT) R = 16;                          // the epilogue needs one wave per (row tile, column tile)
+    if (R == 32 && (CT > 1 || split < 2)) R = 16;                   // two row tiles per wave: one column tile (registers), a wave per output tile
     const dim3 grid(tiles, (a.M + R - 1) / R), block(64 * split);
-    if constexpr (EPI != EPI_GLU) {
-        if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, CT, NTW>), grid, block, 0, s, a, split, 16); return; }
+    if constexpr (EPI != EPI_GLU && CT == 1) {
+        if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, 16); return; }
     }
-    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, NTW>), grid, block, 0, s, a, split, R);
+    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, R);
+}
+
+template <int EPI, int STEPS, bool A16, bool LN, bool WT>
+static void launch_sb_wt(const GemmArgs &a, hipStream_t s) {
+    const SbTune t = sb_tune();
+    const int nslices = a.K / (32 * STEPS);
+    const int split = nslices < kSbMaxWaves ? nslices : kSbMaxWaves;
+    const int tiles1 = (a.N + 15) / 16;
+    int R = t.rows ? t.rows : sb_rows_per_wg(a, nslices, EPI == EPI_GLU, tiles1);
+    // Two column tiles per wave (the activation registers of a K slice feed both) where that lowers what the busiest CU pulls: fp32 rows (4 bytes
+    // per k and row against 2 per k and column) of products wide enough to keep every CU busy with 16 rows x 32 columns per workgroup -- fc1 and
+    // qkv of the 600M models: K (16 * 4 + 32 * 2) = 128 KB per CU instead of K (32 * 4 + 16 * 2) = 160 KB.
+    int ct = 1;
+    if constexpr (!A16 && EPI != EPI_GLU) {
+        if (R == 32 && split >= 2 && a.N % 32 == 0 && (tiles1 / 2) * ((a.M + 15) / 16) >= 192) ct = 2;
+        if (t.ct) ct = (t.ct == 2 && split >= 2 && a.N % 32 == 0) ? 2 : 1;
+        if (ct == 2) {
+            if (!t.rows) R = 16;
+#ifdef PK_EXPERIMENTAL
+            if (t.nt) { launch_sb_ct<EPI, STEPS, A16, LN, 2, true, WT>(a, s, R); return; }
+#endif
+            launch_sb_ct<EPI, STEPS, A16, LN, 2, false, WT>(a, s, R);
+            return;
+        }
+    }
+#ifdef PK_EXPERIMENTAL
+    if (t.nt) { launch_sb_ct<EPI, STEPS, A16, LN, 1, true, WT>(a, s, R); return; }
+#endif
+    launch_sb_ct<EPI, STEPS, A16, LN, 1, false, WT>(a, s, R);
 }
 
 template <int EPI, int STEPS, bool A16, bool LN>
 static void launch_sb(const GemmArgs &a, hipStream_t s) {
-    const SbTune t = sb_tune();
-    const int nslices = a.K / (32 * STEPS);
-    const int split = nslices < kSbMaxWaves ? nslices : kSbMaxWaves;
-    // two column tiles per wave: the activation registers of a K slice feed both (half the activation bytes through the CU's L1 per weight
-    // byte).  Needs a wave per output tile (split >= CT) and enough column tiles to keep the CUs busy.
-    int ct = t.ct ? t.ct : 1;
-    if (ct > 1 && (split < ct || a.N % (16 * ct) != 0)) ct = 1;
-    if (ct == 2) {
-        if (t.nt) launch_sb_ct<EPI, STEPS, A16, LN, 2, true>(a, s, t.rows);
-        else launch_sb_ct<EPI, STEPS, A16, LN, 2, false>(a, s, t.rows);
-        return;
-    }
-    if (t.nt) launch_sb_ct<EPI, STEPS, A16, LN, 1, true>(a, s, t.rows);
-    else launch_sb_ct<EPI, STEPS, A16, LN, 1, false>(a, s, t.rows);
+    if (a.W_t16 && a.N % 16 == 0 && sb_tune().wt) launch_sb_wt<EPI, STEPS, A16, LN, true>(a, s);
+    else launch_sb_wt<EPI, STEPS, A16, LN, false>(a, s);
 }
 
 template <int EPI>
@@ -357,6 +399,21 @@ static void launch_sb_epi(const GemmArgs &a, hipStream_t s) {
     } else {
         launch_sb<EPI, 8, false, false>(a, s);
     }
+}
+
+// W16 [rows][ld] (bf16) -> the operand tiles of GemmArgs::W_t16: per (16 rows, 32 k) one KB [lane = (row & 15) + 16 * (k / 8 & 3)][8 bf16]
+__global__ __launch_bounds__(256) void tile_copy_bf16_kernel(const uint4 *src, uint4 *dst, int64_t n_chunks, int ksteps, int64_t ld8 /* ld / 8 */) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 16-byte chunk (8 bf16) each
+    if (i >= n_chunks) return;
+    const int lane = (int)(i & 63);
+    const int64_t ts = i >> 6, tile = ts / ksteps;
+    const int st = (int)(ts - tile * ksteps);
+    dst[i] = src[(tile * 16 + (lane & 15)) * ld8 + 4 * st + (lane >> 4)];
+}
+void launch_tile_copy_bf16(const float *src16, float *dst16, int64_t rows, int K, int64_t ld, hipStream_t s) {
+    const int64_t n = rows * K / 8;
+    hipLaunchKernelGGL(tile_copy_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint4 *>(src16),
+                       reinterpret_cast<uint4 *>(dst16), n, K / 32, ld / 8);
 }
 
 void launch_gemm_smallm_bf16(const GemmArgs &a, int epi, hipStream_t s) {

@@ -112,6 +112,10 @@ struct GemmArgs {
     // layout (its producer wrote it that way: sigma_cols, LayerNorm mode 2, the streaming attention / conv kernels).  Both set: a lane's 16-byte
     // load IS its operand of four consecutive MFMA steps -- no transposes on the chain -- and every weight load is 1 KB of consecutive addresses.
     const float *W_sig = nullptr; int a_sigma = 0;
+    // small-M bf16 kernel (gemm_smallm_bf16.hip) only: a copy of the bf16 weights in the kernel's OPERAND TILES (launch_tile_copy_bf16: per
+    // (16 rows, 32 k) one KB in lane order, tiles [rows / 16][K / 32]; rows % 16 == 0, K % 32 == 0) -- every weight load instruction reads one
+    // contiguous KB.  W stays set (the natural layout: every other kernel reads that).
+    const float *W_t16 = nullptr;
     // small-M kernels only (gemm_smallm_bf16.hip; gemm_smallm.hip with W_sig): A = the UN-normalised fp32 rows, the LayerNorm (gamma ln_g[K], beta
     // ln_b[K], ln_eps) of the product's input is applied while the rows are staged -- out = epi(LN(A) W^T + bias) (bf16 mode: bf16(LN(A)) W16^T).
     // Callers check gemm_smallm_bf16_ln_applies() / gemm_smallm_ln_applies().
@@ -123,6 +127,8 @@ constexpr int kSmallMRows = 1536;  // launch_gemm: products with M <= this (and 
                                    // 6.75 vs 6.50, 9.14 vs 10.67, 11.35 vs 10.93 ms per step)
 // src [rows][ld] -> dst rows x K floats in the W_sig tiling (rows % 16 == 0, K % 64 == 0)
 void launch_sigma_copy(const float *src, float *dst, int64_t rows, int K, int64_t ld, hipStream_t s);
+// bf16 src [rows][ld] -> dst rows x K bf16 in the W_t16 operand tiles (rows % 16 == 0, K % 32 == 0, ld % 8 == 0)
+void launch_tile_copy_bf16(const float *src16, float *dst16, int64_t rows, int K, int64_t ld, hipStream_t s);
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
 // bf16 mode: true when the product (M x N x K, bf16 A already in HBM, epilogue `epi`) runs on a direct-to-LDS kernel that can write
 // (producer = true: register epilogue) / read (producer = false: LDS-DMA) the blocked activation layout of GemmArgs::out_blocked / a_blocked

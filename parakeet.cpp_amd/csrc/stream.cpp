@@ -164,7 +164,9 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     const int cache_rows = left_ > 0 ? left_ : 1;
     // rows <= kSmallMRows: every product of the chunk is a gemm_smallm chain -- run them on the sigma-K weight copies with sigma-K activations (the
     // producers below write that layout; x, the residual stream, stays natural)
-    const int sg = (rows <= kSmallMRows && !sig_->empty()) ? 1 : 0;
+    const int sg = (!cfg.gemm_bf16 && rows <= kSmallMRows && !sig_->empty()) ? 1 : 0;
+    // (tolerance-class mode: the copies are the bf16 operand tiles of the small-M bf16 kernel, GemmArgs::W_t16 -- a weight load reads one contiguous KB)
+    const bool wt = cfg.gemm_bf16 && rows <= kSmallMRowsBf16 && !sig_->empty();
     // Tolerance-class mode (pk_config.gemm_bf16; specification: the oracle's Stream in its gemm_bf16 mode): every product of the chunk takes bf16
     // operands (kernels/gemm_smallm_bf16.hip for these few rows); the rows that exist only as GEMM operands -- LayerNorm outputs, the fc1
     // activations -- are stored as bf16 by their producers (RNE, the rounding the GEMM would apply: same operand values, half the bytes);
@@ -189,16 +191,17 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         GemmArgs pg{x, d, m_.layers[0].ffn1_w1, d, nullptr, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
         pg.ln_g = m_.layers[0].ffn1_ng; pg.ln_b = m_.layers[0].ffn1_nb; pg.out_bf16 = a16;
         if (sg) pg.W_sig = (*sig_)[0].ffn1_w1;
+        if (wt) pg.W_t16 = (*sig_)[0].ffn1_w1;
         ln_folds = a16 ? gemm_smallm_bf16_ln_applies(pg, EPI_SILU) : (sg && gemm_smallm_ln_applies(pg, EPI_SILU));
     }
     auto ffn = [&](const LayerW &L, const Model::SigW &Ls, bool second, bool norm_done) {                // FeedForward (src/encoder.cpp:36-46)
         GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
-        g1.a_sigma = sg; g1.W_sig = second ? Ls.ffn2_w1 : Ls.ffn1_w1;
+        g1.a_sigma = sg; (wt ? g1.W_t16 : g1.W_sig) = second ? Ls.ffn2_w1 : Ls.ffn1_w1;
         g1.a_bf16 = a16; g1.out_bf16 = a16;
         g1.sigma_cols = sg ? f : 0;                                                                       // h is fc2's A operand
         ln_gemm("ffn_fc1_silu", g1, EPI_SILU, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, norm_done);
         GemmArgs g2{hb, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, x, d, 0.5f, (int)rows, d, f};
-        g2.a_sigma = sg; g2.W_sig = second ? Ls.ffn2_w2 : Ls.ffn1_w2;
+        g2.a_sigma = sg; (wt ? g2.W_t16 : g2.W_sig) = second ? Ls.ffn2_w2 : Ls.ffn1_w2;
         g2.a_bf16 = a16;
         m_.run_gemm("ffn_fc2_resid", g2, EPI_RESID, st);
     };
@@ -207,12 +210,12 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         const LayerW &L = m_.layers[l];
         LayerState &Ls = *layers_[l];
         static const Model::SigW no_sig{};
-        const Model::SigW &Sg = sg ? (*sig_)[l] : no_sig;
+        const Model::SigW &Sg = (sg || wt) ? (*sig_)[l] : no_sig;
         ffn(L, Sg, false, ffn1_norm_done);                                                             // ffn1_ (:294)
         // StreamingConformerAttention::forward_cached (:162-272)
         {
             GemmArgs g{n, d, L.wqkv, d, L.bqkv, ws_.qkv.as<float>(), 3 * d, nullptr, 0, 1.0f, (int)rows, 3 * d, d};
-            g.a_sigma = sg; g.W_sig = Sg.wqkv;
+            g.a_sigma = sg; (wt ? g.W_t16 : g.W_sig) = Sg.wqkv;
             g.a_bf16 = a16;
             ln_gemm("attn_qkv", g, EPI_NONE, L.att_ng, L.att_nb, false);                              // natural columns (no sigma layout here)
         }
@@ -224,13 +227,13 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         Ls.n_kv = (Ls.n_kv + c > left_) ? left_ : Ls.n_kv + c;
         {
             GemmArgs g{ws_.ctx.as<float>(), d, L.wo, d, L.bo, x, d, x, d, 1.0f, (int)rows, d, d};
-            g.a_sigma = sg; g.W_sig = Sg.wo;
+            g.a_sigma = sg; (wt ? g.W_t16 : g.W_sig) = Sg.wo;
             m_.run_gemm("attn_out_resid", g, EPI_RESID, st);
         }
         // CausalConformerConvModule::forward_cached (:41-78)
         {
             GemmArgs g{n, d, L.pw1_w, d, L.pw1_b, ws_.g.as<float>(), d, nullptr, 0, 1.0f, (int)rows, d, d};
-            g.a_sigma = sg; g.W_sig = Sg.pw1;
+            g.a_sigma = sg; (wt ? g.W_t16 : g.W_sig) = Sg.pw1;
             g.a_bf16 = a16;
             ln_gemm("conv_pw1_glu", g, EPI_GLU, L.cv_ng, L.cv_nb, false);
         }
@@ -240,7 +243,7 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         Ls.has_conv = 1;
         {
             GemmArgs g{ws_.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, x, d, 1.0f, (int)rows, d, d};
-            g.a_sigma = sg; g.W_sig = Sg.pw2;
+            g.a_sigma = sg; (wt ? g.W_t16 : g.W_sig) = Sg.pw2;
             m_.run_gemm("conv_pw2_resid", g, EPI_RESID, st);
         }
         ffn(L, Sg, true, false);                                                                       // ffn2_
