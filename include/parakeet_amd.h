@@ -476,6 +476,14 @@ pk_status pk_diag_gemm_bf16_a16(int M, int N, int K, const float *A, const float
  * PK_ERR_UNSUPPORTED for any other shape. */
 pk_status pk_diag_ln_gemm_bf16(int M, int N, int K, const float *A, const float *gamma, const float *beta, float eps, const float *W,
                                const float *bias, int epi, const float *resid, float alpha, float *out);
+/* The conv module's first half on a streaming chunk of the tolerance-class mode: GLU(bf16(LayerNorm(A)) bf16(W)^T + bias) -> causal depthwise
+ * conv (kernel 9) over [cache_in ; the c new rows] of every stream -> BatchNorm -> SiLU (reference src/streaming_encoder.cpp:41-78).  A = [n_streams * c][d]
+ * rows, stream-major; W [2 d][d]; cache_in / cache_out [n_streams][8][d]; gamma = beta = NULL: A is taken as it is.  fused = 1: the conv runs in
+ * the product's epilogue (kernels.hpp DwTail; c = 1, 2 or 4), fused = 0: the separate kernel -- both bit for bit the same (tests/test_gpu_bf16.py). */
+pk_status pk_diag_glu_dwconv_bf16(int n_streams, int c, int d, const float *A, const float *gamma, const float *beta, float eps, const float *W,
+                                  const float *bias, const float *cache_in, int has_cache, const float *dw_w, const float *dw_bias,
+                                  const float *bn_mean, const float *bn_rstd, const float *bn_g, const float *bn_b, int fused, float *out,
+                                  float *cache_out);
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y);
 /* sum64 of each row of x[rows][n] (the canonical wavefront reduction). */
 pk_status pk_diag_sum64(const float *x, int rows, int n, float *out);

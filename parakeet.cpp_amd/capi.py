@@ -277,6 +277,21 @@ def diag_ln_gemm_bf16(A, gamma, beta, W, bias=None, epi="none", resid=None, alph
     return out
 
 
+def diag_glu_dwconv_bf16(A, W, bias, cache_in, has_cache, dw_w, dw_bias, bn_mean, bn_rstd, bn_g, bn_b, c, fused, gamma=None, beta=None, eps=1e-5):
+    """pk_diag_glu_dwconv_bf16: pw1 (GLU) + causal depthwise conv + BatchNorm + SiLU of a streaming chunk; fused = the conv in the product's epilogue."""
+    A, W, bias, cache_in = _c(A), _c(W), _c(bias), _c(cache_in)
+    M, d = A.shape
+    S = M // c
+    ps = [_c(v) for v in (dw_w, dw_bias, bn_mean, bn_rstd, bn_g, bn_b)]
+    g, b = (_c(gamma), _c(beta)) if gamma is not None else (None, None)
+    out = np.empty((M, d), np.float32); cache_out = np.empty((S, 8, d), np.float32)
+    L = lib()
+    L.pk_diag_glu_dwconv_bf16.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, C.c_float, f32p, f32p, f32p, C.c_int] + [f32p] * 6 + [C.c_int, f32p, f32p]
+    check(L.pk_diag_glu_dwconv_bf16(S, c, d, _f(A), _f(g) if g is not None else None, _f(b) if b is not None else None, eps, _f(W), _f(bias), _f(cache_in),
+                                    int(has_cache), *[_f(v) for v in ps], int(fused), _f(out), _f(cache_out)))
+    return out, cache_out
+
+
 class Stream:
     """pk_stream_*: n lock-step streaming sessions on the GPU (reference NemotronTranscriber::transcribe_chunk)."""
 

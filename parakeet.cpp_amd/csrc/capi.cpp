@@ -1892,6 +1892,58 @@ pk_status pk_diag_ln_gemm_bf16(int M, int N, int K, const float *A, const float 
     });
 }
 
+pk_status pk_diag_glu_dwconv_bf16(int n_streams, int c, int d, const float *A, const float *gamma, const float *beta, float eps, const float *W,
+                                  const float *bias, const float *cache_in, int has_cache, const float *dw_w, const float *dw_bias,
+                                  const float *bn_mean, const float *bn_rstd, const float *bn_g, const float *bn_b, int fused, float *out,
+                                  float *cache_out) {
+    return guard([&] {
+        need(n_streams > 0 && c > 0 && d > 0 && A && W && cache_in && dw_w && dw_bias && bn_mean && bn_rstd && bn_g && bn_b && out && cache_out, "arguments");
+        need((gamma != nullptr) == (beta != nullptr), "gamma and beta: both or neither");
+        diag_device();
+        const int M = n_streams * c, K = d, N = d;
+        std::vector<uint16_t> w16((size_t)2 * N * K);
+        for (size_t i = 0; i < w16.size(); ++i) {
+            uint32_t u;
+            memcpy(&u, &W[i], 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            w16[i] = (uint16_t)(u >> 16);
+        }
+        DevBuf a, w, b, gb, ci, co, par, glu, o;
+        auto up = [&](DevBuf &buf, const void *src, size_t bytes) { buf.reserve(bytes); PK_HIP(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice)); };
+        up(a, A, (size_t)M * K * 4);
+        up(w, w16.data(), w16.size() * 2);
+        if (bias) up(b, bias, (size_t)2 * N * 4);
+        if (gamma) { gb.reserve((size_t)2 * K * 4); PK_HIP(hipMemcpy(gb.p, gamma, (size_t)K * 4, hipMemcpyHostToDevice)); PK_HIP(hipMemcpy((char *)gb.p + (size_t)K * 4, beta, (size_t)K * 4, hipMemcpyHostToDevice)); }
+        up(ci, cache_in, (size_t)n_streams * 8 * d * 4);
+        co.reserve((size_t)n_streams * 8 * d * 4);
+        par.reserve((size_t)(9 + 5) * d * 4);
+        float *pp = par.as<float>();
+        PK_HIP(hipMemcpy(pp, dw_w, (size_t)9 * d * 4, hipMemcpyHostToDevice));
+        const float *five[5] = {dw_bias, bn_mean, bn_rstd, bn_g, bn_b};
+        for (int i = 0; i < 5; ++i) PK_HIP(hipMemcpy(pp + (size_t)(9 + i) * d, five[i], (size_t)d * 4, hipMemcpyHostToDevice));
+        glu.reserve((size_t)M * N * 4);
+        o.reserve((size_t)M * N * 4);
+        GemmArgs g{a.as<float>(), K, w.as<float>(), K, bias ? b.as<float>() : nullptr, glu.as<float>(), N, nullptr, 0, 1.0f, M, N, K};
+        g.fast_act = 1;
+        if (gamma) { g.ln_g = gb.as<float>(); g.ln_b = gb.as<float>() + K; g.ln_eps = eps; }
+        if (!(gamma ? gemm_smallm_bf16_ln_applies(g, EPI_GLU) : gemm_smallm_bf16_applies(g, EPI_GLU)))
+            fail(PK_ERR_UNSUPPORTED, "pk_diag_glu_dwconv_bf16: M <= %d, d = 256 * (1 .. 4)", kSmallMRowsBf16);
+        DwTail tail{ci.as<float>(), co.as<float>(), has_cache, c, pp, pp + 9 * (size_t)d, pp + 10 * (size_t)d, pp + 11 * (size_t)d, pp + 12 * (size_t)d, pp + 13 * (size_t)d};
+        if (fused) {
+            if (!gemm_smallm_bf16_dw_applies(g, EPI_GLU, c, 9)) fail(PK_ERR_UNSUPPORTED, "pk_diag_glu_dwconv_bf16: the fused tail takes c = 1, 2 or 4 frames per stream");
+            g.dw_tail = &tail; g.out = o.as<float>();
+            launch_gemm_bf16(g, EPI_GLU, nullptr);
+        } else {
+            launch_gemm_bf16(g, EPI_GLU, nullptr);
+            launch_stream_dwconv(glu.as<float>(), tail.cache_in, has_cache, n_streams, c, d, 9, tail.w, tail.bias, tail.bn_mean, tail.bn_rstd, tail.bn_g, tail.bn_b,
+                                 o.as<float>(), tail.cache_out, nullptr, 0);
+        }
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpy(out, o.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(cache_out, co.p, (size_t)n_streams * 8 * d * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y) {
     return guard([&] {
         need(x && gamma && beta && y && rows > 0 && d > 0 && d <= 1024, "x/gamma/beta/y/rows/d (d <= 1024)");

@@ -37,6 +37,7 @@
 // Specification = the oracle's gemm_bf16 mode (oracle/pk_oracle.c linear_t: both operands rounded to bf16, k-ordered fp32 accumulation);
 // the accumulation ORDER differs (MFMA blocks of 32 k, K slices), so results are compared within the mode's tolerance
 // (tests/test_gpu_bf16.py: against float64 of the same rounded operands; tests/test_gpu_stream.py: the streaming mode against the oracle's).
+#include <type_traits>
 #include "../pk_devmath.h"
 #include "kernels.hpp"
 
@@ -60,9 +61,11 @@ __device__ unsigned long long *sb_trace;
 template <int EPI, int STEPS /* MFMA steps (32 k each) per K slice */, int RT /* 16-row MFMA tiles per wave */, bool A16 /* A is bf16 [M][lda] */,
           bool LN /* fold LayerNorm(A; ln_g, ln_b, ln_eps) in: A fp32, STEPS = 8 or 4, one slice per wave */,
           int CT = 1 /* 16-column tiles per wave: the activation registers of a K slice feed CT weight tiles (round 5) */, bool NTW = false /* non-temporal weight loads */,
-          bool WT = false /* weights from the operand-tile copy GemmArgs::W_t16 */>
+          bool WT = false /* weights from the operand-tile copy GemmArgs::W_t16 */, bool DW = false /* EPI_GLU: the depthwise-conv tail (DwTail) */>
 __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(GemmArgs g, int split /* waves = K slices in flight */,
-                                                                            int rvalid /* rows of a 16-row tile that exist: 16, or 8 (RT = 1) */) {
+                                                                            int rvalid /* rows of a 16-row tile that exist: 16, or 8 (RT = 1) */,
+                                                                            DwTail dw = DwTail{}) {
+    static_assert(!DW || (EPI == EPI_GLU && RT == 1 && CT == 1), "the conv tail finishes the GLU tile of one wave");
     constexpr int NW = (EPI == EPI_GLU) ? 2 : 1;                    // weight tiles per column tile (GLU: value rows [0, N), gate rows [N, 2N))
     constexpr int SL = 32 * STEPS;
     static_assert(!LN || (!A16 && (STEPS == 8 || STEPS == 4)), "the folded LayerNorm reads fp32 rows in slices of 256 (128) k");
@@ -91,6 +94,25 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                 const int row = m0 + 16 * et + 4 * kq + i;
                 if (4 * kq + i < rvalid && row < g.M) res[i] = g.resid[(int64_t)row * g.ldr + col];
             }
+        }
+    }
+    // conv tail: the cached rows of this lane's streams (rows m0 + 4 kq .. + 3 = 4 / c streams of c frames) and the conv's parameters of its
+    // channel, requested before the weight stream like the operands above
+    [[maybe_unused]] float dpre[4][8], dwk[9], dbs = 0.0f, dmu = 0.0f, drs = 0.0f, dbg = 0.0f, dbb = 0.0f;
+    if constexpr (DW) {
+        if (wave == 0 && col < g.N && 4 * kq < rvalid) {
+            const int nstr = 4 / dw.c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rw = m0 + 4 * kq + j * dw.c;
+                const bool on = j < nstr && rw < g.M && dw.has_cache;
+                const int64_t sidx = on ? rw / dw.c : 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dpre[j][q] = on ? dw.cache_in[(sidx * 8 + q) * g.N + col] : 0.0f;   // (first chunk: zero left padding, :55-63)
+            }
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) dwk[kk] = dw.w[kk * g.N + col];
+            dbs = dw.bias[col]; dmu = dw.bn_mean[col]; drs = dw.bn_rstd[col]; dbg = dw.bn_g[col]; dbb = dw.bn_b[col];
         }
     }
 
@@ -271,6 +293,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
         }
     }
     if (col >= g.N) return;
+    [[maybe_unused]] float glu[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     // C/D layout of 16x16: column = lane & 15, row = 4 * (lane >> 4) + i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -290,8 +313,42 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
             if (g.bias) gg = gg + bias_g;
             o = o * (g.fast_act ? fast_sigmoidf(gg) : dsigmoidf(gg));
         }
+        if constexpr (DW) { glu[i] = o; continue; }
         if (g.out_bf16) reinterpret_cast<__bf16 *>(g.out)[(int64_t)row * g.ldo + col] = (__bf16)o;
         else g.out[(int64_t)row * g.ldo + col] = o;
+    }
+    if constexpr (DW) {
+        // depthwise conv over [cached 8 rows ; the c new GLU rows] of (stream, channel), BatchNorm, SiLU; the last 8 rows of the concatenation
+        // are the stream's cache for the next chunk (stream_dwconv_kernel, kernels/stream.hip: the same operations in the same order)
+        if (4 * kq >= rvalid) return;
+        auto tail = [&](auto cc) {
+            constexpr int C = decltype(cc)::value;
+#pragma unroll
+            for (int j = 0; j < 4 / C; ++j) {
+                const int rw = m0 + 4 * kq + j * C;
+                if (rw >= g.M) continue;
+                const int64_t sidx = rw / C;
+                float cat[8 + C];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cat[q] = dpre[j][q];
+#pragma unroll
+                for (int f = 0; f < C; ++f) cat[8 + f] = glu[j * C + f];
+#pragma unroll
+                for (int f = 0; f < C; ++f) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int kk = 0; kk < 9; ++kk) acc = __builtin_fmaf(dwk[kk], cat[f + kk], acc);
+                    float y = acc + dbs;
+                    y = __builtin_fmaf((y - dmu) * drs, dbg, dbb);
+                    g.out[(int64_t)(rw + f) * g.ldo + col] = dsiluf(y);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dw.cache_out[(sidx * 8 + q) * g.N + col] = cat[q + C];
+            }
+        };
+        if (dw.c == 1) tail(std::integral_constant<int, 1>{});
+        else if (dw.c == 2) tail(std::integral_constant<int, 2>{});
+        else tail(std::integral_constant<int, 4>{});
     }
     SB_STAMP(6);
 }
@@ -302,6 +359,10 @@ bool gemm_smallm_bf16_applies(const GemmArgs &a, int epi) {
     if ((a.ldw % 8) != 0 || (a.lda % (a.a_bf16 ? 8 : 4)) != 0) return false;
     if (a.out_bf16 && (epi == EPI_RESID || epi == EPI_GLU)) return false;
     return epi >= EPI_NONE && epi <= EPI_GLU;
+}
+bool gemm_smallm_bf16_dw_applies(const GemmArgs &a, int epi, int c, int kc) {
+    if (epi != EPI_GLU || kc != 9 || !(c == 1 || c == 2 || c == 4) || a.M % c != 0 || a.N % 16 != 0 || a.out_bf16) return false;
+    return a.ln_g ? gemm_smallm_bf16_ln_applies(a, epi) : gemm_smallm_bf16_applies(a, epi);
 }
 bool gemm_smallm_bf16_ln_applies(const GemmArgs &a, int epi) {
     if (!a.ln_g || !a.ln_b || a.a_bf16) return false;
@@ -345,9 +406,12 @@ static void launch_sb_ct(const GemmArgs &a, hipStream_t s, int R) {
     if (R == 32 && (CT > 1 || split < 2)) R = 16;                   // two row tiles per wave: one column tile (registers), a wave per output tile
     const dim3 grid(tiles, (a.M + R - 1) / R), block(64 * split);
     if constexpr (EPI != EPI_GLU && CT == 1) {
-        if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, 16); return; }
+        if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, 16, DwTail{}); return; }
     }
-    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, R);
+    if constexpr (EPI == EPI_GLU && CT == 1 && !NTW) {
+        if (a.dw_tail) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, 1, false, WT, true>), grid, block, 0, s, a, split, R, *a.dw_tail); return; }
+    }
+    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, R, DwTail{});
 }
 
 template <int EPI, int STEPS, bool A16, bool LN, bool WT>

@@ -77,6 +77,17 @@ void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, 
 
 // ---- fp32 MFMA GEMM: out = epi(A[M][K] * W[N][K]^T + bias), natural-k fma chains ----------------
 enum GemmEpi { EPI_NONE = 0, EPI_RELU = 1, EPI_SILU = 2, EPI_RESID = 3, EPI_GLU = 4 };
+// Streaming conv module, tolerance-class mode: the causal depthwise conv (kernel 9) + BatchNorm + SiLU of
+// CausalConformerConvModule::forward_cached (src/streaming_encoder.cpp:41-78) run in the GLU epilogue of pw1 (gemm_smallm_bf16.hip): the lane that
+// finishes column ch of a stream's c new frames holds everything the conv of (stream, ch) needs next to the stream's cached 8 frames -- no
+// exchange, one launch less per block.  Rows of the product = [S][c] stream-major; GemmArgs::out receives the conv module's activations
+// (the GLU values themselves are not stored).  Same operations in the same order as stream_dwconv_kernel: bit-identical.
+struct DwTail {
+    const float *cache_in = nullptr; float *cache_out = nullptr;     // [S][8][d]: the last 8 GLU rows of every stream before / after this chunk
+    int has_cache = 0, c = 0;                                        // first chunk: zero left padding; c = new frames per stream (1, 2 or 4)
+    const float *w = nullptr /* [9][d] */, *bias = nullptr, *bn_mean = nullptr, *bn_rstd = nullptr, *bn_g = nullptr, *bn_b = nullptr;
+};
+
 struct GemmArgs {
     const float *A; int64_t lda;
     const float *W; int64_t ldw;
@@ -120,6 +131,9 @@ struct GemmArgs {
     // ln_b[K], ln_eps) of the product's input is applied while the rows are staged -- out = epi(LN(A) W^T + bias) (bf16 mode: bf16(LN(A)) W16^T).
     // Callers check gemm_smallm_bf16_ln_applies() / gemm_smallm_ln_applies().
     const float *ln_g = nullptr, *ln_b = nullptr; float ln_eps = 0.0f;
+    // small-M bf16 kernel, EPI_GLU only: HOST pointer to the depthwise-conv tail of the epilogue (read during the launch call).  Callers check
+    // gemm_smallm_bf16_dw_applies().
+    const DwTail *dw_tail = nullptr;
 };
 constexpr int kSmallMRows = 1536;  // launch_gemm: products with M <= this (and K % 64 == 0) run on gemm_smallm.hip.  Measured with the two-row-tile
                                    // variant in place (110m encoder; reference protocol, batch 1: M = 626 5.6 ms on it vs 6.7 on the tile kernels,
@@ -144,6 +158,7 @@ void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s);
 // (M <= kSmallMRowsBf16, K % 256 == 0, row-major output) there.
 constexpr int kSmallMRowsBf16 = 128;
 bool gemm_smallm_bf16_applies(const GemmArgs &a, int epi);
+bool gemm_smallm_bf16_dw_applies(const GemmArgs &a, int epi, int c, int kc);   // ... with GemmArgs::dw_tail: GLU, conv kernel 9, c = 1 / 2 / 4 frames per stream
 bool gemm_smallm_bf16_ln_applies(const GemmArgs &a, int epi);     // ... with GemmArgs::ln_g set: K = 256 * (1 .. 8 waves; GLU: 4), fp32 rows
 void launch_gemm_smallm_bf16(const GemmArgs &a, int epi, hipStream_t s);
 double gemm_flops(const GemmArgs &a, int epi);

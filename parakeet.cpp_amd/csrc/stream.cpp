@@ -20,6 +20,16 @@ namespace pk {
 
 // Fold the LayerNorm of a product's input rows into the product (GemmArgs::ln_g; tolerance-class mode: kernels/gemm_smallm_bf16.hip, exact mode:
 // gemm_smallm_ln_kernel in kernels/gemm_smallm.hip, bit for bit) -- four of a block's fifteen launches go.  EXPERIMENTAL builds: PK_STREAM_FUSE_LN=0 switches it off for the A/B of tools/experiments/stream_bf16_ab.sh.
+// Tolerance-class mode: the depthwise conv + BatchNorm + SiLU of the conv module in the GLU epilogue of pw1 (kernels.hpp: DwTail) -- one launch
+// less per block, bit-identical to the separate kernel.  EXPERIMENTAL builds: PK_STREAM_FUSE_DW=0 switches it off.
+static bool stream_fuse_dw() {
+#ifdef PK_EXPERIMENTAL
+    static const bool on = [] { const char *e = getenv("PK_STREAM_FUSE_DW"); return e ? atoi(e) != 0 : true; }();
+    return on;
+#else
+    return true;
+#endif
+}
 static bool stream_fuse_ln() {
 #ifdef PK_EXPERIMENTAL
     static const bool on = [] { const char *e = getenv("PK_STREAM_FUSE_LN"); return e ? atoi(e) != 0 : true; }();
@@ -235,12 +245,21 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
             GemmArgs g{n, d, L.pw1_w, d, L.pw1_b, ws_.g.as<float>(), d, nullptr, 0, 1.0f, (int)rows, d, d};
             g.a_sigma = sg; (wt ? g.W_t16 : g.W_sig) = Sg.pw1;
             g.a_bf16 = a16;
+            // the depthwise conv in pw1's epilogue where the small-M bf16 kernel can (rows stream-major, c = 1 / 2 / 4 frames per stream)
+            DwTail tail{Ls.conv[Ls.ccur].as<float>(), Ls.conv[Ls.ccur ^ 1].as<float>(), Ls.has_conv, c, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b};
+            GemmArgs probe = g;
+            if (stream_fuse_ln()) { probe.A = x; probe.a_bf16 = 0; probe.ln_g = L.cv_ng; probe.ln_b = L.cv_nb; }
+            const bool fused_dw = a16 && stream_fuse_dw() && gemm_smallm_bf16_dw_applies(probe, EPI_GLU, c, K) && gemm_smallm_bf16_dw_applies(g, EPI_GLU, c, K);
+            if (fused_dw) { g.dw_tail = &tail; g.out = ws_.dwb.as<float>(); }
             ln_gemm("conv_pw1_glu", g, EPI_GLU, L.cv_ng, L.cv_nb, false);
+            if (!fused_dw)
+                launch_stream_dwconv(ws_.g.as<float>(), Ls.conv[Ls.ccur].as<float>(), Ls.has_conv, S, c, d, K, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
+                                     ws_.dwb.as<float>(), Ls.conv[Ls.ccur ^ 1].as<float>(), st, sg);
         }
-        launch_stream_dwconv(ws_.g.as<float>(), Ls.conv[Ls.ccur].as<float>(), Ls.has_conv, S, c, d, K, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
-                             ws_.dwb.as<float>(), Ls.conv[Ls.ccur ^ 1].as<float>(), st, sg);
-        Ls.ccur ^= 1;
-        Ls.has_conv = 1;
+        {
+            Ls.ccur ^= 1;
+            Ls.has_conv = 1;
+        }
         {
             GemmArgs g{ws_.dwb.as<float>(), d, L.pw2_w, d, L.pw2_b, x, d, x, d, 1.0f, (int)rows, d, d};
             g.a_sigma = sg; (wt ? g.W_t16 : g.W_sig) = Sg.pw2;

@@ -237,3 +237,38 @@ def test_bf16_short_clip_runs_the_smallm_products(tmp_path_factory, orc):
     close(enc, oenc, "600m 2-layer cut, 10 s clip")
     g, o = gm.tdt_decode(enc), om.tdt_greedy(oenc)
     assert agreement(g["ids"][0, : g["lens"][0]].tolist(), o["ids"][0, : o["lens"][0]].tolist()) >= 0.95
+
+
+@pytest.mark.parametrize("S,c,d,ln,has_cache", [(16, 2, 1024, True, 1), (16, 2, 1024, True, 0), (16, 1, 1024, True, 1), (8, 4, 1024, True, 1), (5, 2, 512, True, 1),
+                                                (3, 1, 256, False, 1), (7, 4, 512, False, 0), (64, 2, 1024, True, 1), (1, 2, 1024, True, 1)])
+def test_bf16_glu_epilogue_with_depthwise_conv_tail_bit_identical(S, c, d, ln, has_cache):
+    """The streaming conv module of the tolerance-class mode: the causal depthwise conv (kernel 9) + BatchNorm + SiLU in the GLU epilogue of pw1
+    (kernels.hpp DwTail: one launch less per block) against the separate launch (stream_dwconv_kernel) on the same GLU product -- bit for bit,
+    activations and the next chunk's cache; and the conv itself against float64 of the same GLU values (reference
+    src/streaming_encoder.cpp:41-78: cat(cache, x), depthwise conv without padding, the last 8 rows are the new cache)."""
+    from parakeet_cpp_amd import capi
+    rng = np.random.default_rng(1000 * S + 10 * c + d)
+    M = S * c
+    A = (rng.standard_normal((M, d)) * rng.uniform(0.5, 2.0, (M, 1))).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, d).astype(np.float32) if ln else None
+    beta = (0.2 * rng.standard_normal(d)).astype(np.float32) if ln else None
+    W = (rng.standard_normal((2 * d, d)) / np.sqrt(d)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(2 * d)).astype(np.float32)
+    cache = rng.standard_normal((S, 8, d)).astype(np.float32)
+    dw_w = (rng.standard_normal((9, d)) / 3).astype(np.float32)
+    dw_b, mu = (0.1 * rng.standard_normal(d)).astype(np.float32), (0.1 * rng.standard_normal(d)).astype(np.float32)
+    rstd, bg, bb = rng.uniform(0.5, 2.0, d).astype(np.float32), rng.uniform(0.5, 1.5, d).astype(np.float32), (0.1 * rng.standard_normal(d)).astype(np.float32)
+    args = (A, W, bias, cache, has_cache, dw_w, dw_b, mu, rstd, bg, bb, c)
+    out_f, cache_f = capi.diag_glu_dwconv_bf16(*args, fused=1, gamma=gamma, beta=beta)
+    out_s, cache_s = capi.diag_glu_dwconv_bf16(*args, fused=0, gamma=gamma, beta=beta)
+    assert np.array_equal(out_f.view(np.uint32), out_s.view(np.uint32)), f"{int((out_f != out_s).sum())} activations differ"
+    assert np.array_equal(cache_f.view(np.uint32), cache_s.view(np.uint32)), f"{int((cache_f != cache_s).sum())} cache words differ"
+    # the new cache's tail IS the chunk's GLU rows (c <= 8): recover them and restate the conv in float64
+    glu = cache_f[:, 8 - c:, :]                                           # [S][c][d]
+    old = cache if has_cache else np.zeros_like(cache)
+    cat = np.concatenate([old, glu], axis=1).astype(np.float64)           # [S][8 + c][d]
+    assert np.array_equal(cache_f, cat[:, c:, :].astype(np.float32))
+    y = np.stack([(cat[:, t:t + 9, :] * dw_w[None].astype(np.float64)).sum(axis=1) for t in range(c)], axis=1) + dw_b
+    y = (y - mu) * rstd * bg + bb
+    want = (y / (1.0 + np.exp(-y))).reshape(M, d)
+    assert np.abs(out_f - want).max() <= 1e-5 * (1.0 + np.abs(want).max())
