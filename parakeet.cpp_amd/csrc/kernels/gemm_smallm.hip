@@ -25,6 +25,7 @@
 //  * SIG (GemmArgs::a_sigma + W_sig): both operands already in MFMA order -- no transposes at all; the weights TILED so that a load
 //    instruction reads 1 KB of consecutive addresses (the streaming encoder, csrc/stream.cpp; Model::sigma_weights).
 #include "../pk_devmath.h"
+#include <type_traits>
 #include "kernels.hpp"
 
 namespace pk {
@@ -240,8 +241,11 @@ __global__ __launch_bounds__(64) void gemm_smallm_rt2_kernel(GemmArgs g) {
 // gate tile of the same 16 columns) with their A fragments from LDS (one chunk ahead of the chain, conflict-free ds_read_b128) and the tiled
 // weight stream in the same 8-chunk register ring as gemm_smallm_kernel -- requested BEFORE the rows, so the weights' HBM round trip covers the
 // normalisation.  Saves the LayerNorm launch (~5 us of a 32-row streaming chunk's ~360) for ~1 us in front of the chain.
-template <int EPI, int PER_LANE /* K / 64 */>
-__global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g) {
+// DW (EPI_GLU; kernels.hpp DwTail): the streaming conv module's depthwise conv + BatchNorm + SiLU run by the lane that finishes (stream, channel) --
+// the same operations in the same order as stream_dwconv_kernel (kernels/stream.hip), one launch less per block.
+template <int EPI, int PER_LANE /* K / 64 */, bool DW = false>
+__global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g, DwTail dw = DwTail{}) {
+    static_assert(!DW || EPI == EPI_GLU, "the conv tail finishes a GLU tile");
     constexpr int K = 64 * PER_LANE, PITCH = K + 4, KC = 64, NKC = PER_LANE, DEPTH = 8;
     static_assert(NKC % DEPTH == 0, "the ring walks whole groups of 8 chunks");
     extern __shared__ __attribute__((aligned(16))) float At[];     // [16][PITCH]: the normalised rows of the tile, K in the sigma order
@@ -269,6 +273,24 @@ __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g) {
         }
 #pragma unroll
         for (int j = 0; j < DEPTH - 1; ++j) wload(j, j);
+    }
+    // conv tail: the cached rows of this lane's streams (rows m0 + 4 kq .. + 3 = 4 / c streams of c frames) and the conv's parameters of its channel
+    [[maybe_unused]] float dpre[4][8], dwk[9], dbs = 0.0f, dmu = 0.0f, drs = 0.0f, dbg = 0.0f, dbb = 0.0f;
+    if constexpr (DW) {
+        if (chain && half == 0 && col < g.N) {
+            const int nstr = 4 / dw.c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rw0 = m0 + 4 * kq + j * dw.c;
+                const bool on = j < nstr && rw0 < g.M && dw.has_cache;
+                const int64_t sidx = on ? rw0 / dw.c : 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dpre[j][q] = on ? dw.cache_in[(sidx * 8 + q) * g.N + col] : 0.0f;   // (first chunk: zero left padding)
+            }
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) dwk[kk] = dw.w[kk * g.N + col];
+            dbs = dw.bias[col]; dmu = dw.bn_mean[col]; drs = dw.bn_rstd[col]; dbg = dw.bn_g[col]; dbb = dw.bn_b[col];
+        }
     }
     // ---- every wave: LayerNorm of rows m0 + 4 wave .. + 3, exactly as layernorm_kernel<PER_LANE, 1> (one wave per row) ----
     {
@@ -342,6 +364,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g) {
         if (half == 1) return;
     }
     if (col >= g.N) return;
+    [[maybe_unused]] float glu[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     // epilogue: C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -358,11 +381,47 @@ __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g) {
             if (g.bias) gt = gt + bias_g;
             v = v * dsigmoidf(gt);
         }
+        if constexpr (DW) { glu[i] = v; continue; }
         if (g.remap_rows) g.out[(int64_t)(row / g.remap_rows) * g.remap_gs + (int64_t)(row % g.remap_rows) * g.remap_rs + (int64_t)col * g.remap_cs] = v;
         else g.out[(int64_t)row * g.ldo + (col < g.sigma_cols ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col)] = v;
     }
+    if constexpr (DW) {
+        const int ocol = dw.out_sigma ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col;
+        auto tail = [&](auto cc) {
+            constexpr int C = decltype(cc)::value;
+#pragma unroll
+            for (int j = 0; j < 4 / C; ++j) {
+                const int rw0 = m0 + 4 * kq + j * C;
+                if (rw0 >= g.M) continue;
+                const int64_t sidx = rw0 / C;
+                float cat[8 + C];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cat[q] = dpre[j][q];
+#pragma unroll
+                for (int f = 0; f < C; ++f) cat[8 + f] = glu[j * C + f];
+#pragma unroll
+                for (int f = 0; f < C; ++f) {
+                    float a2 = 0.0f;
+#pragma unroll
+                    for (int kk = 0; kk < 9; ++kk) a2 = __builtin_fmaf(dwk[kk], cat[f + kk], a2);      // depthwise, no padding (:71)
+                    float y = a2 + dbs;
+                    y = __builtin_fmaf((y - dmu) * drs, dbg, dbb);
+                    g.out[(int64_t)(rw0 + f) * g.ldo + ocol] = dsiluf(y);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dw.cache_out[(sidx * 8 + q) * g.N + col] = cat[q + C];
+            }
+        };
+        if (dw.c == 1) tail(std::integral_constant<int, 1>{});
+        else if (dw.c == 2) tail(std::integral_constant<int, 2>{});
+        else tail(std::integral_constant<int, 4>{});
+    }
 }
 
+bool gemm_smallm_dw_applies(const GemmArgs &a, int epi, int c, int kc) {
+    if (epi != EPI_GLU || kc != 9 || !(c == 1 || c == 2 || c == 4) || a.M % c != 0 || a.remap_rows != 0 || a.sigma_cols != 0) return false;
+    return gemm_smallm_ln_applies(a, epi);
+}
 bool gemm_smallm_ln_applies(const GemmArgs &a, int epi) {
     if (!a.ln_g || !a.ln_b || !a.W_sig || a.a_bf16 || a.a_sigma) return false;
     if (a.M <= 0 || a.M > kSmallMRows || (a.K != 512 && a.K != 1024) || a.N % 16 != 0 || a.lda < a.K) return false;
@@ -375,12 +434,25 @@ static void launch_smallm_ln(const GemmArgs &a, hipStream_t s) {
     const dim3 grid(EPI == EPI_GLU ? tiles : (tiles + 1) / 2, (a.M + 15) / 16), block(256);
     const size_t lds = (size_t)16 * (a.K + 4) * sizeof(float);
     static DynLdsSlots slots8, slots16;
+    if constexpr (EPI == EPI_GLU) {
+        if (a.dw_tail) {
+            static DynLdsSlots dslots8, dslots16;
+            if (a.K == 512) {
+                ensure_dyn_lds(dslots8, reinterpret_cast<const void *>(&gemm_smallm_ln_kernel<EPI, 8, true>), lds);
+                hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 8, true>), grid, block, lds, s, a, *a.dw_tail);
+            } else {
+                ensure_dyn_lds(dslots16, reinterpret_cast<const void *>(&gemm_smallm_ln_kernel<EPI, 16, true>), lds);
+                hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 16, true>), grid, block, lds, s, a, *a.dw_tail);
+            }
+            return;
+        }
+    }
     if (a.K == 512) {
         ensure_dyn_lds(slots8, reinterpret_cast<const void *>(&gemm_smallm_ln_kernel<EPI, 8>), lds);
-        hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 8>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 8>), grid, block, lds, s, a, DwTail{});
     } else {
         ensure_dyn_lds(slots16, reinterpret_cast<const void *>(&gemm_smallm_ln_kernel<EPI, 16>), lds);
-        hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 16>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 16>), grid, block, lds, s, a, DwTail{});
     }
 }
 

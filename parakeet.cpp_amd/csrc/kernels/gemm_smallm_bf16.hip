@@ -321,6 +321,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
         // depthwise conv over [cached 8 rows ; the c new GLU rows] of (stream, channel), BatchNorm, SiLU; the last 8 rows of the concatenation
         // are the stream's cache for the next chunk (stream_dwconv_kernel, kernels/stream.hip: the same operations in the same order)
         if (4 * kq >= rvalid) return;
+        const int ocol = dw.out_sigma ? ((col & ~15) | ((col & 3) << 2) | ((col >> 2) & 3)) : col;
         auto tail = [&](auto cc) {
             constexpr int C = decltype(cc)::value;
 #pragma unroll
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                     for (int kk = 0; kk < 9; ++kk) acc = __builtin_fmaf(dwk[kk], cat[f + kk], acc);
                     float y = acc + dbs;
                     y = __builtin_fmaf((y - dmu) * drs, dbg, dbb);
-                    g.out[(int64_t)(rw + f) * g.ldo + col] = dsiluf(y);
+                    g.out[(int64_t)(rw + f) * g.ldo + ocol] = dsiluf(y);
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) dw.cache_out[(sidx * 8 + q) * g.N + col] = cat[q + C];

@@ -77,8 +77,9 @@ void launch_mel_normalize(const float *logmel, int B, int n_mels, int n_frames, 
 
 // ---- fp32 MFMA GEMM: out = epi(A[M][K] * W[N][K]^T + bias), natural-k fma chains ----------------
 enum GemmEpi { EPI_NONE = 0, EPI_RELU = 1, EPI_SILU = 2, EPI_RESID = 3, EPI_GLU = 4 };
-// Streaming conv module, tolerance-class mode: the causal depthwise conv (kernel 9) + BatchNorm + SiLU of
-// CausalConformerConvModule::forward_cached (src/streaming_encoder.cpp:41-78) run in the GLU epilogue of pw1 (gemm_smallm_bf16.hip): the lane that
+// Streaming conv module: the causal depthwise conv (kernel 9) + BatchNorm + SiLU of
+// CausalConformerConvModule::forward_cached (src/streaming_encoder.cpp:41-78) run in the GLU epilogue of pw1 (tolerance-class mode:
+// gemm_smallm_bf16.hip; exact mode: gemm_smallm_ln_kernel of gemm_smallm.hip): the lane that
 // finishes column ch of a stream's c new frames holds everything the conv of (stream, ch) needs next to the stream's cached 8 frames -- no
 // exchange, one launch less per block.  Rows of the product = [S][c] stream-major; GemmArgs::out receives the conv module's activations
 // (the GLU values themselves are not stored).  Same operations in the same order as stream_dwconv_kernel: bit-identical.
@@ -86,6 +87,7 @@ struct DwTail {
     const float *cache_in = nullptr; float *cache_out = nullptr;     // [S][8][d]: the last 8 GLU rows of every stream before / after this chunk
     int has_cache = 0, c = 0;                                        // first chunk: zero left padding; c = new frames per stream (1, 2 or 4)
     const float *w = nullptr /* [9][d] */, *bias = nullptr, *bn_mean = nullptr, *bn_rstd = nullptr, *bn_g = nullptr, *bn_b = nullptr;
+    int out_sigma = 0;                                               // the activations' columns in the sigma layout (exact mode: pw2 reads a_sigma rows)
 };
 
 struct GemmArgs {
@@ -131,8 +133,8 @@ struct GemmArgs {
     // ln_b[K], ln_eps) of the product's input is applied while the rows are staged -- out = epi(LN(A) W^T + bias) (bf16 mode: bf16(LN(A)) W16^T).
     // Callers check gemm_smallm_bf16_ln_applies() / gemm_smallm_ln_applies().
     const float *ln_g = nullptr, *ln_b = nullptr; float ln_eps = 0.0f;
-    // small-M bf16 kernel, EPI_GLU only: HOST pointer to the depthwise-conv tail of the epilogue (read during the launch call).  Callers check
-    // gemm_smallm_bf16_dw_applies().
+    // small-M kernels with the LayerNorm folded in (exact mode) / small-M bf16 kernel, EPI_GLU only: HOST pointer to the depthwise-conv tail of
+    // the epilogue (read during the launch call).  Callers check gemm_smallm_dw_applies() / gemm_smallm_bf16_dw_applies().
     const DwTail *dw_tail = nullptr;
 };
 constexpr int kSmallMRows = 1536;  // launch_gemm: products with M <= this (and K % 64 == 0) run on gemm_smallm.hip.  Measured with the two-row-tile
@@ -150,6 +152,7 @@ bool gemm_bf16_blocked_handoff(int M, int N, int K, int epi, bool producer);
 // fp32 small-M chain kernel with GemmArgs::ln_g set (kernels/gemm_smallm.hip: gemm_smallm_ln_kernel): A = the un-normalised rows, K = 512 / 1024 = the
 // row length, tiled weights W_sig, epi none / relu / silu / glu -- bit for bit LayerNorm + product.  Callers check this first.
 bool gemm_smallm_ln_applies(const GemmArgs &a, int epi);
+bool gemm_smallm_dw_applies(const GemmArgs &a, int epi, int c, int kc);        // ... with GemmArgs::dw_tail (GLU, conv kernel 9, c = 1 / 2 / 4 frames per stream)
 // same contract with bf16 operands and fp32 accumulation: a.W points to bf16 weights [N][K] (rounded once at upload), A is
 // rounded to bf16 while it is staged; K % 64 == 0.  Not bit-identical to the fp32 chain (kernels/gemm_bf16.hpp).
 void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s);

@@ -20,8 +20,8 @@ namespace pk {
 
 // Fold the LayerNorm of a product's input rows into the product (GemmArgs::ln_g; tolerance-class mode: kernels/gemm_smallm_bf16.hip, exact mode:
 // gemm_smallm_ln_kernel in kernels/gemm_smallm.hip, bit for bit) -- four of a block's fifteen launches go.  EXPERIMENTAL builds: PK_STREAM_FUSE_LN=0 switches it off for the A/B of tools/experiments/stream_bf16_ab.sh.
-// Tolerance-class mode: the depthwise conv + BatchNorm + SiLU of the conv module in the GLU epilogue of pw1 (kernels.hpp: DwTail) -- one launch
-// less per block, bit-identical to the separate kernel.  EXPERIMENTAL builds: PK_STREAM_FUSE_DW=0 switches it off.
+// The depthwise conv + BatchNorm + SiLU of the conv module in the GLU epilogue of pw1 (kernels.hpp: DwTail) -- one launch less per block,
+// bit-identical to the separate kernel (both modes).  EXPERIMENTAL builds: PK_STREAM_FUSE_DW=0 switches it off.
 static bool stream_fuse_dw() {
 #ifdef PK_EXPERIMENTAL
     static const bool on = [] { const char *e = getenv("PK_STREAM_FUSE_DW"); return e ? atoi(e) != 0 : true; }();
@@ -246,10 +246,12 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
             g.a_sigma = sg; (wt ? g.W_t16 : g.W_sig) = Sg.pw1;
             g.a_bf16 = a16;
             // the depthwise conv in pw1's epilogue where the small-M bf16 kernel can (rows stream-major, c = 1 / 2 / 4 frames per stream)
-            DwTail tail{Ls.conv[Ls.ccur].as<float>(), Ls.conv[Ls.ccur ^ 1].as<float>(), Ls.has_conv, c, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b};
-            GemmArgs probe = g;
-            if (stream_fuse_ln()) { probe.A = x; probe.a_bf16 = 0; probe.ln_g = L.cv_ng; probe.ln_b = L.cv_nb; }
-            const bool fused_dw = a16 && stream_fuse_dw() && gemm_smallm_bf16_dw_applies(probe, EPI_GLU, c, K) && gemm_smallm_bf16_dw_applies(g, EPI_GLU, c, K);
+            DwTail tail{Ls.conv[Ls.ccur].as<float>(), Ls.conv[Ls.ccur ^ 1].as<float>(), Ls.has_conv, c, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b, sg};
+            GemmArgs probe = g;                                                                          // what ln_gemm will launch when the norm folds
+            if (stream_fuse_ln()) { probe.A = x; probe.a_bf16 = 0; probe.a_sigma = 0; probe.ln_g = L.cv_ng; probe.ln_b = L.cv_nb; probe.ln_eps = 1e-5f; }
+            // (tolerance-class mode: with or without the folded norm; exact mode: the tail lives in the kernel with the norm folded in)
+            const bool fused_dw = stream_fuse_dw() && (a16 ? gemm_smallm_bf16_dw_applies(probe, EPI_GLU, c, K) && gemm_smallm_bf16_dw_applies(g, EPI_GLU, c, K)
+                                                           : sg && stream_fuse_ln() && gemm_smallm_dw_applies(probe, EPI_GLU, c, K));
             if (fused_dw) { g.dw_tail = &tail; g.out = ws_.dwb.as<float>(); }
             ln_gemm("conv_pw1_glu", g, EPI_GLU, L.cv_ng, L.cv_nb, false);
             if (!fused_dw)
