@@ -484,6 +484,11 @@ pk_status pk_diag_glu_dwconv_bf16(int n_streams, int c, int d, const float *A, c
                                   const float *bias, const float *cache_in, int has_cache, const float *dw_w, const float *dw_bias,
                                   const float *bn_mean, const float *bn_rstd, const float *bn_g, const float *bn_b, int fused, float *out,
                                   float *cache_out);
+/* One feed-forward module of a streaming chunk in the tolerance-class mode, on the small-M bf16 kernel: out = x + 0.5 * (W2 bf16(silu(W1 bf16(LN(x)) + b1)) + b2)
+ * (reference src/encoder.cpp:36-46), x [M][d], W1 [f][d], W2 [d][f].  act_tiles = 1: the fc1 activations travel in the kernel's 8-row operand
+ * tiles (kernels.hpp GemmArgs::out_t8 / a_t8; M % 8 == 0), 0: as rows -- bit for bit the same (tests/test_gpu_bf16.py). */
+pk_status pk_diag_ffn_bf16_smallm(int M, int d, int f, const float *x, const float *gamma, const float *beta, float eps, const float *W1, const float *b1,
+                                  const float *W2, const float *b2, int act_tiles, float *out);
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y);
 /* sum64 of each row of x[rows][n] (the canonical wavefront reduction). */
 pk_status pk_diag_sum64(const float *x, int rows, int n, float *out);

@@ -277,6 +277,18 @@ def diag_ln_gemm_bf16(A, gamma, beta, W, bias=None, epi="none", resid=None, alph
     return out
 
 
+def diag_ffn_bf16_smallm(x, gamma, beta, W1, b1, W2, b2, act_tiles, eps=1e-5):
+    """pk_diag_ffn_bf16_smallm: x + 0.5 * ffn(LN(x)) of a streaming chunk on the small-M bf16 kernel; act_tiles = fc1 activations in 8-row operand tiles."""
+    x, gamma, beta, W1, b1, W2, b2 = (_c(v) for v in (x, gamma, beta, W1, b1, W2, b2))
+    M, d = x.shape
+    f = W1.shape[0]
+    out = np.empty((M, d), np.float32)
+    L = lib()
+    L.pk_diag_ffn_bf16_smallm.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, C.c_float, f32p, f32p, f32p, f32p, C.c_int, f32p]
+    check(L.pk_diag_ffn_bf16_smallm(M, d, f, _f(x), _f(gamma), _f(beta), eps, _f(W1), _f(b1), _f(W2), _f(b2), int(act_tiles), _f(out)))
+    return out
+
+
 def diag_glu_dwconv_bf16(A, W, bias, cache_in, has_cache, dw_w, dw_bias, bn_mean, bn_rstd, bn_g, bn_b, c, fused, gamma=None, beta=None, eps=1e-5):
     """pk_diag_glu_dwconv_bf16: pw1 (GLU) + causal depthwise conv + BatchNorm + SiLU of a streaming chunk; fused = the conv in the product's epilogue."""
     A, W, bias, cache_in = _c(A), _c(W), _c(bias), _c(cache_in)

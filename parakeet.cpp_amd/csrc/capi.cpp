@@ -1944,6 +1944,43 @@ pk_status pk_diag_glu_dwconv_bf16(int n_streams, int c, int d, const float *A, c
     });
 }
 
+pk_status pk_diag_ffn_bf16_smallm(int M, int d, int f, const float *x, const float *gamma, const float *beta, float eps, const float *W1, const float *b1,
+                                  const float *W2, const float *b2, int act_tiles, float *out) {
+    return guard([&] {
+        need(M > 0 && d > 0 && f > 0 && x && gamma && beta && W1 && b1 && W2 && b2 && out, "arguments");
+        diag_device();
+        auto to16 = [](const float *w, size_t n) {
+            std::vector<uint16_t> v(n);
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t u;
+                memcpy(&u, &w[i], 4);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                v[i] = (uint16_t)(u >> 16);
+            }
+            return v;
+        };
+        const std::vector<uint16_t> w1 = to16(W1, (size_t)f * d), w2 = to16(W2, (size_t)d * f);
+        DevBuf xb, gb, w1b, w2b, b1b, b2b, hb, ob;
+        auto up = [&](DevBuf &buf, const void *src, size_t bytes) { buf.reserve(bytes); PK_HIP(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice)); };
+        up(xb, x, (size_t)M * d * 4); up(w1b, w1.data(), w1.size() * 2); up(w2b, w2.data(), w2.size() * 2); up(b1b, b1, (size_t)f * 4); up(b2b, b2, (size_t)d * 4);
+        gb.reserve((size_t)2 * d * 4);
+        PK_HIP(hipMemcpy(gb.p, gamma, (size_t)d * 4, hipMemcpyHostToDevice));
+        PK_HIP(hipMemcpy((char *)gb.p + (size_t)d * 4, beta, (size_t)d * 4, hipMemcpyHostToDevice));
+        hb.reserve((size_t)((M + 7) / 8 * 8) * f * 2);
+        up(ob, x, (size_t)M * d * 4);                                   // the residual stream: out = x + 0.5 * ffn(LN(x))
+        GemmArgs g1{xb.as<float>(), d, w1b.as<float>(), d, b1b.as<float>(), hb.as<float>(), f, nullptr, 0, 1.0f, M, f, d};
+        g1.ln_g = gb.as<float>(); g1.ln_b = gb.as<float>() + d; g1.ln_eps = eps; g1.out_bf16 = 1; g1.fast_act = 1; g1.out_t8 = act_tiles ? 1 : 0;
+        GemmArgs g2{hb.as<float>(), f, w2b.as<float>(), f, b2b.as<float>(), ob.as<float>(), d, ob.as<float>(), d, 0.5f, M, d, f};
+        g2.a_bf16 = 1; g2.a_t8 = act_tiles ? 1 : 0;
+        if (!gemm_smallm_bf16_ln_applies(g1, EPI_SILU) || !gemm_smallm_bf16_applies(g2, EPI_RESID))
+            fail(PK_ERR_UNSUPPORTED, "pk_diag_ffn_bf16_smallm: M <= %d (act_tiles: M %% 8 == 0), d = 256 * (1 .. 8), f %% 256 == 0", kSmallMRowsBf16);
+        launch_gemm_bf16(g1, EPI_SILU, nullptr);
+        launch_gemm_bf16(g2, EPI_RESID, nullptr);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpy(out, ob.p, (size_t)M * d * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y) {
     return guard([&] {
         need(x && gamma && beta && y && rows > 0 && d > 0 && d <= 1024, "x/gamma/beta/y/rows/d (d <= 1024)");

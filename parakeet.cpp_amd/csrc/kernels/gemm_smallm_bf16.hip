@@ -61,7 +61,8 @@ __device__ unsigned long long *sb_trace;
 template <int EPI, int STEPS /* MFMA steps (32 k each) per K slice */, int RT /* 16-row MFMA tiles per wave */, bool A16 /* A is bf16 [M][lda] */,
           bool LN /* fold LayerNorm(A; ln_g, ln_b, ln_eps) in: A fp32, STEPS = 8 or 4, one slice per wave */,
           int CT = 1 /* 16-column tiles per wave: the activation registers of a K slice feed CT weight tiles (round 5) */, bool NTW = false /* non-temporal weight loads */,
-          bool WT = false /* weights from the operand-tile copy GemmArgs::W_t16 */, bool DW = false /* EPI_GLU: the depthwise-conv tail (DwTail) */>
+          bool WT = false /* weights from the operand-tile copy GemmArgs::W_t16 */, bool DW = false /* EPI_GLU: the depthwise-conv tail (DwTail) */,
+          bool AT = false /* A16: the rows in 8-row operand tiles (GemmArgs::a_t8) */>
 __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(GemmArgs g, int split /* waves = K slices in flight */,
                                                                             int rvalid /* rows of a 16-row tile that exist: 16, or 8 (RT = 1) */,
                                                                             DwTail dw = DwTail{}) {
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
     for (int t = 0; t < RT; ++t) {
         int arow = m0 + 16 * t + (r & (rvalid - 1));                // rvalid = 8: MFMA rows 8..15 repeat rows 0..7 (never stored)
         arow = arow < g.M ? arow : g.M - 1;
-        ap16[t] = reinterpret_cast<const __bf16 *>(g.A) + (int64_t)arow * g.lda + 8 * kq;
+        if constexpr (AT) ap16[t] = reinterpret_cast<const __bf16 *>(g.A) + (int64_t)(arow >> 3) * (g.lda >> 5) * 256 + ((arow & 7) + 8 * kq) * 8;
+        else ap16[t] = reinterpret_cast<const __bf16 *>(g.A) + (int64_t)arow * g.lda + 8 * kq;
         ap32[t] = g.A + (int64_t)arow * g.lda + 8 * kq;
     }
 
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 if constexpr (A16) {
-                    a[t][s] = *reinterpret_cast<const sb_bf16x8 *>(ap16[t] + k0 + 32 * s);
+                    a[t][s] = *reinterpret_cast<const sb_bf16x8 *>(AT ? ap16[t] + (k0 / 32 + s) * 256 : ap16[t] + k0 + 32 * s);
                 } else {
                     af[t][s][0] = *reinterpret_cast<const float4 *>(ap32[t] + k0 + 32 * s);
                     af[t][s][1] = *reinterpret_cast<const float4 *>(ap32[t] + k0 + 32 * s + 4);
@@ -314,7 +316,8 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
             o = o * (g.fast_act ? fast_sigmoidf(gg) : dsigmoidf(gg));
         }
         if constexpr (DW) { glu[i] = o; continue; }
-        if (g.out_bf16) reinterpret_cast<__bf16 *>(g.out)[(int64_t)row * g.ldo + col] = (__bf16)o;
+        if (g.out_t8) reinterpret_cast<__bf16 *>(g.out)[((int64_t)(row >> 3) * (g.ldo >> 5) + (col >> 5)) * 256 + ((row & 7) + 8 * ((col & 31) >> 3)) * 8 + (col & 7)] = (__bf16)o;
+        else if (g.out_bf16) reinterpret_cast<__bf16 *>(g.out)[(int64_t)row * g.ldo + col] = (__bf16)o;
         else g.out[(int64_t)row * g.ldo + col] = o;
     }
     if constexpr (DW) {
@@ -359,6 +362,8 @@ bool gemm_smallm_bf16_applies(const GemmArgs &a, int epi) {
     if (a.M > kSmallMRowsBf16 || a.M <= 0 || a.K % 256 != 0 || a.remap_rows != 0 || a.sigma_cols != 0) return false;
     if ((a.ldw % 8) != 0 || (a.lda % (a.a_bf16 ? 8 : 4)) != 0) return false;
     if (a.out_bf16 && (epi == EPI_RESID || epi == EPI_GLU)) return false;
+    if (a.out_t8 && !(a.out_bf16 && a.M % 8 == 0 && a.N % 32 == 0 && a.ldo == a.N)) return false;
+    if (a.a_t8 && !(a.a_bf16 && a.M % 8 == 0 && a.lda == a.K && epi == EPI_RESID)) return false;   // (instantiated for the product that takes them: fc2)
     return epi >= EPI_NONE && epi <= EPI_GLU;
 }
 bool gemm_smallm_bf16_dw_applies(const GemmArgs &a, int epi, int c, int kc) {
@@ -406,11 +411,17 @@ static void launch_sb_ct(const GemmArgs &a, hipStream_t s, int R) {
     if (EPI == EPI_GLU && R == 32) R = 16;
     if (R == 32 && (CT > 1 || split < 2)) R = 16;                   // two row tiles per wave: one column tile (registers), a wave per output tile
     const dim3 grid(tiles, (a.M + R - 1) / R), block(64 * split);
+    if constexpr (EPI == EPI_RESID && A16 && CT == 1 && !NTW) {
+        if (a.a_t8 && R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, 1, false, WT, false, true>), grid, block, 0, s, a, split, 16, DwTail{}); return; }
+    }
     if constexpr (EPI != EPI_GLU && CT == 1) {
         if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, 16, DwTail{}); return; }
     }
     if constexpr (EPI == EPI_GLU && CT == 1 && !NTW) {
         if (a.dw_tail) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, 1, false, WT, true>), grid, block, 0, s, a, split, R, *a.dw_tail); return; }
+    }
+    if constexpr (EPI == EPI_RESID && A16 && CT == 1 && !NTW) {
+        if (a.a_t8) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, 1, false, WT, false, true>), grid, block, 0, s, a, split, R, DwTail{}); return; }
     }
     hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, R, DwTail{});
 }

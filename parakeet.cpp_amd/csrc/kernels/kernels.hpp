@@ -116,6 +116,11 @@ struct GemmArgs {
     // a_blocked: `A` is read that way (lda = its row length).  Set by the engine for fc1 -> fc2 when gemm_bf16_blocked_handoff() says both take
     // those kernels.
     int out_blocked = 0, a_blocked = 0;
+    // small-M bf16 kernel only (gemm_smallm_bf16.hip): the bf16 activation rows between two of its products (fc1 -> fc2 of a streaming chunk) in
+    // OPERAND TILES of 8 rows: per (8 rows, 32 k) 512 bytes [lane32 = (row & 7) + 8 * (k / 8 & 3)][8 bf16], tiles ordered [rows / 8][K / 32] -- the
+    // consumer's load instruction reads whole lines (512 B, or two runs of 512 B for 16 rows) instead of 8 / 16 row segments of 64 bytes.
+    // M % 8 == 0, row length % 32 == 0.  out_t8: `out` is written that way (ldo = the row length), a_t8: `A` is read that way (lda = the row length).
+    int out_t8 = 0, a_t8 = 0;
     // bf16 mode only: SiLU / sigmoid of the epilogue on the hardware exp2 / rcp (1 ulp) instead of the fixed polynomial + IEEE division of the
     // numerics contract -- that mode is compared with the oracle within a bf16-epsilon-class tolerance, not bit for bit, and at bf16 MFMA rates
     // the 38-operation SiLU is as expensive as the product itself (fc1 of tdt-600m: ~48 us of VALU against 40 us of MFMA).

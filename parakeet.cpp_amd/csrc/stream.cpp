@@ -30,6 +30,15 @@ static bool stream_fuse_dw() {
     return true;
 #endif
 }
+// Tolerance-class mode: fc1 -> fc2 activations in the small-M bf16 kernel's 8-row operand tiles.  EXPERIMENTAL builds: PK_STREAM_ACT_TILES=0 keeps rows.
+static bool stream_act_tiles() {
+#ifdef PK_EXPERIMENTAL
+    static const bool on = [] { const char *e = getenv("PK_STREAM_ACT_TILES"); return e ? atoi(e) != 0 : true; }();
+    return on;
+#else
+    return true;
+#endif
+}
 static bool stream_fuse_ln() {
 #ifdef PK_EXPERIMENTAL
     static const bool on = [] { const char *e = getenv("PK_STREAM_FUSE_LN"); return e ? atoi(e) != 0 : true; }();
@@ -208,11 +217,16 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
         g1.a_sigma = sg; (wt ? g1.W_t16 : g1.W_sig) = second ? Ls.ffn2_w1 : Ls.ffn1_w1;
         g1.a_bf16 = a16; g1.out_bf16 = a16;
+        // tolerance-class mode, both products on the small-M bf16 kernel: the fc1 activations in its 8-row operand tiles (GemmArgs::out_t8 / a_t8)
+        GemmArgs p1 = g1, p2{hb, f, second ? L.ffn2_w2 : L.ffn1_w2, f, nullptr, x, d, x, d, 0.5f, (int)rows, d, f};
+        p1.out_t8 = 1; p2.a_bf16 = 1; p2.a_t8 = 1;
+        const bool t8 = a16 && stream_act_tiles() && gemm_smallm_bf16_applies(p1, EPI_SILU) && gemm_smallm_bf16_applies(p2, EPI_RESID);
+        g1.out_t8 = t8;
         g1.sigma_cols = sg ? f : 0;                                                                       // h is fc2's A operand
         ln_gemm("ffn_fc1_silu", g1, EPI_SILU, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, norm_done);
         GemmArgs g2{hb, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, x, d, 0.5f, (int)rows, d, f};
         g2.a_sigma = sg; (wt ? g2.W_t16 : g2.W_sig) = second ? Ls.ffn2_w2 : Ls.ffn1_w2;
-        g2.a_bf16 = a16;
+        g2.a_bf16 = a16; g2.a_t8 = t8;
         m_.run_gemm("ffn_fc2_resid", g2, EPI_RESID, st);
     };
     bool ffn1_norm_done = false;

@@ -272,3 +272,26 @@ def test_bf16_glu_epilogue_with_depthwise_conv_tail_bit_identical(S, c, d, ln, h
     y = (y - mu) * rstd * bg + bb
     want = (y / (1.0 + np.exp(-y))).reshape(M, d)
     assert np.abs(out_f - want).max() <= 1e-5 * (1.0 + np.abs(want).max())
+
+
+@pytest.mark.parametrize("M,d,f", [(32, 1024, 4096), (16, 1024, 4096), (8, 512, 2048), (64, 1024, 4096), (128, 512, 1024), (24, 256, 1024)])
+def test_bf16_smallm_ffn_activation_operand_tiles_bit_identical(M, d, f):
+    """fc1 -> fc2 of a streaming chunk (tolerance-class mode): the bf16 activations between the two small-M products in the kernel's 8-row operand
+    tiles (GemmArgs::out_t8 / a_t8: the consumer's loads read whole lines) against the same two launches with plain rows -- the same values in the
+    same lanes, bit for bit; and the module against float64 of the operands the specification rounds."""
+    from parakeet_cpp_amd import capi
+    rng = np.random.default_rng(M + d + f)
+    x = (rng.standard_normal((M, d)) * rng.uniform(0.5, 2.0, (M, 1))).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, d).astype(np.float32), (0.2 * rng.standard_normal(d)).astype(np.float32)
+    W1, b1 = (rng.standard_normal((f, d)) / np.sqrt(d)).astype(np.float32), (0.1 * rng.standard_normal(f)).astype(np.float32)
+    W2, b2 = (rng.standard_normal((d, f)) / np.sqrt(f)).astype(np.float32), (0.1 * rng.standard_normal(d)).astype(np.float32)
+    tiled = capi.diag_ffn_bf16_smallm(x, gamma, beta, W1, b1, W2, b2, act_tiles=1)
+    rows = capi.diag_ffn_bf16_smallm(x, gamma, beta, W1, b1, W2, b2, act_tiles=0)
+    assert np.array_equal(tiled.view(np.uint32), rows.view(np.uint32)), f"{int((tiled != rows).sum())} outputs differ"
+    x64 = x.astype(np.float64)
+    mean = x64.mean(axis=1, keepdims=True)
+    ln = ((x64 - mean) / np.sqrt(((x64 - mean) ** 2).mean(axis=1, keepdims=True) + 1e-5) * gamma + beta).astype(np.float32)
+    h = bf16_round(ln).astype(np.float64) @ bf16_round(W1).astype(np.float64).T + b1
+    h = bf16_round((h / (1.0 + np.exp(-h))).astype(np.float32)).astype(np.float64)
+    want = x64 + 0.5 * (h @ bf16_round(W2).astype(np.float64).T + b2)
+    assert np.abs(tiled - want).max() <= 2e-2 * (1.0 + np.abs(want).max()), f"max err {np.abs(tiled - want).max():.3e}"
