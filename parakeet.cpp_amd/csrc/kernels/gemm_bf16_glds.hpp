@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
             // The fragments read after the barrier are long in their registers by now (eight DMA issues and eight MFMAs later); saying so HERE
             // keeps the compiler from draining LDS at the top of the loop instead -- where its wait (it cannot count across the back edge: lgkmcnt(0))
             // would also cover the six reads issued there for the NEXT sub-step and put a whole LDS round trip in front of the first MFMA group of
-            // every K tile (found in the ISA, round 5; tools/ubench/gemm_bf16_trace.cpp: K tile 4500 -> see profiles/r05_bf16_lgkm_ab.txt)
+            // every K tile (found in the ISA, round 5; tools/ubench/gemm_bf16_trace.cpp: K tile 4500 -> see profiles/r05_bf16_asmfrag_ab.txt)
             if constexpr (!ASMFRAG) GL_WAIT_LGKM0();
             cur ^= 1;
         }
