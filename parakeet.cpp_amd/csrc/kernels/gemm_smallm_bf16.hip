@@ -62,7 +62,8 @@ template <int EPI, int STEPS /* MFMA steps (32 k each) per K slice */, int RT /*
           bool LN /* fold LayerNorm(A; ln_g, ln_b, ln_eps) in: A fp32, STEPS = 8 or 4, one slice per wave */,
           int CT = 1 /* 16-column tiles per wave: the activation registers of a K slice feed CT weight tiles (round 5) */, bool NTW = false /* non-temporal weight loads */,
           bool WT = false /* weights from the operand-tile copy GemmArgs::W_t16 */, bool DW = false /* EPI_GLU: the depthwise-conv tail (DwTail) */,
-          bool AT = false /* A16: the rows in 8-row operand tiles (GemmArgs::a_t8) */>
+          bool AT = false /* A16: the rows in 8-row operand tiles (GemmArgs::a_t8) */,
+          bool AL = false /* fp32 rows: the wave's K slice of the rows travels global -> LDS by DMA (1 KB of consecutive addresses per instruction) */>
 __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(GemmArgs g, int split /* waves = K slices in flight */,
                                                                             int rvalid /* rows of a 16-row tile that exist: 16, or 8 (RT = 1) */,
                                                                             DwTail dw = DwTail{}) {
@@ -70,7 +71,16 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
     constexpr int NW = (EPI == EPI_GLU) ? 2 : 1;                    // weight tiles per column tile (GLU: value rows [0, N), gate rows [N, 2N))
     constexpr int SL = 32 * STEPS;
     static_assert(!LN || (!A16 && (STEPS == 8 || STEPS == 4)), "the folded LayerNorm reads fp32 rows in slices of 256 (128) k");
-    __shared__ sb_f32x4 part[kSbMaxWaves][NW][CT][RT][64];          // partial sums [wave][weight tile][column tile][row tile][lane]
+    static_assert(!AL || (!A16 && RT == 1 && STEPS == 8), "LDS-DMA rows: fp32, one row tile, slices of 256 k (1 KB per row)");
+    // AL: every wave owns 16 row slots of 1 KB + 16 B (the pad makes the operand reads conflict-free: 16 lanes of one k group read 16 rows, 65
+    // 16-byte chunks apart); once the rows are in registers the slot holds the wave's partial sums.
+    constexpr int APITCH = 4 * SL + 16;
+    extern __shared__ __attribute__((aligned(16))) char arows[];    // AL: [kSbMaxWaves][16][APITCH] (dynamic; 0 bytes otherwise)
+    __shared__ sb_f32x4 part_s[AL ? 1 : kSbMaxWaves][NW][CT][RT][64];   // partial sums [wave][weight tile][column tile][row tile][lane]
+    auto part = [&](int w, int h, int c, int t) -> sb_f32x4 * {
+        if constexpr (AL) return reinterpret_cast<sb_f32x4 *>(arows + (size_t)w * 16 * APITCH) + ((h * CT + c) * RT + t) * 64;
+        else return &part_s[w][h][c][t][0];
+    };
     __shared__ __attribute__((aligned(16))) float gam[LN ? kSbMaxWaves : 1][LN ? SL : 4], bet[LN ? kSbMaxWaves : 1][LN ? SL : 4];
     __shared__ float st1[LN ? kSbMaxWaves : 1][RT][16], st2[LN ? kSbMaxWaves : 1][RT][16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -154,11 +164,37 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
         sb_bf16x8 w[NW][CT][STEPS], a[RT][STEPS];
         float4 af[RT][STEPS][2];
         // activations first (L2 hits: they return ahead of the weight stream that follows in the same queue)
+        if constexpr (AL) {
+            // one instruction per row: 64 lanes x 16 bytes = the row's 256 k of this slice, into the wave's slot of that row
+            // (inline asm, and inline-asm reads below: an LDS access the compiler can see after an LDS-DMA it can see is preceded by
+            //  s_waitcnt vmcnt(0) -- the whole weight stream would have to land before the LayerNorm starts.  Unknown to the compiler, the DMAs are
+            //  only OLDER entries of the in-order vmcnt queue: its counted waits for the loads behind them stay sufficient.)
+            const unsigned slot0 = (unsigned)(size_t)(arows + (size_t)wave * 16 * APITCH);
+            auto row_dma = [&](int q) {
+                int arow = m0 + q;
+                arow = arow < g.M ? arow : g.M - 1;
+                const float *src = g.A + (int64_t)arow * g.lda + k0 + 4 * lane;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot0 + q * APITCH);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"                      // (m0 is a reserved register: named so that the compiler knows it changes)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
+#pragma clang diagnostic pop
+            };
+#pragma unroll
+            for (int q = 0; q < 8; ++q) row_dma(q);
+            if (rvalid > 8) {                                       // (kernel argument: 8 or 16)
+#pragma unroll
+                for (int q = 8; q < 16; ++q) row_dma(q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
-                if constexpr (A16) {
+                if constexpr (AL) {
+                    // (read from LDS below, once the DMA has landed)
+                } else if constexpr (A16) {
                     a[t][s] = *reinterpret_cast<const sb_bf16x8 *>(AT ? ap16[t] + (k0 / 32 + s) * 256 : ap16[t] + k0 + 32 * s);
                 } else {
                     af[t][s][0] = *reinterpret_cast<const float4 *>(ap32[t] + k0 + 32 * s);
@@ -184,6 +220,26 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                 }
         __builtin_amdgcn_sched_barrier(0);                          // every load of the slice is issued before anything waits
         SB_STAMP(1);
+        if constexpr (AL) {
+            // the rows were requested first: they have landed when only the loads issued after them are outstanding (gamma / beta, the weights)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LN ? 2 : 0) + NW * CT * STEPS) : "memory");
+            // (inline-asm reads: left to the compiler, an LDS read after an LDS-DMA write is preceded by s_waitcnt vmcnt(0) -- the whole weight
+            //  stream would have to land before the LayerNorm starts)
+            const unsigned ar = (unsigned)(size_t)(arows + ((size_t)wave * 16 + (r & (rvalid - 1))) * APITCH + 32 * kq);
+            sb_f32x4 lo[STEPS], hi[STEPS];
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lo[s]) : "v"(ar), "n"(128 * s));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hi[s]) : "v"(ar), "n"(128 * s + 16));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                asm volatile("" : "+v"(lo[s]), "+v"(hi[s]));         // (the uses stay behind the wait)
+                af[0][s][0] = float4{lo[s][0], lo[s][1], lo[s][2], lo[s][3]};
+                af[0][s][1] = float4{hi[s][0], hi[s][1], hi[s][2], hi[s][3]};
+            }
+        }
 
         if constexpr (LN) {
             // gamma / beta of this wave's slice: wave-private LDS rows, read back after the barriers below
@@ -279,7 +335,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int t = 0; t < RT; ++t) part[wave][h][c][t][lane] = acc[h][c][t];
+                for (int t = 0; t < RT; ++t) part(wave, h, c, t)[lane] = acc[h][c][t];
         __syncthreads();
     }
     SB_STAMP(5);
@@ -287,11 +343,11 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
     const int t = et;                                               // this wave finishes row tile et of column tile ec
     sb_f32x4 v = acc[0][0][0], gt = acc[NW - 1][0][0];              // (split == 1: RT = CT = 1)
     if (split > 1) {
-        v = part[0][0][ec][t][lane];
-        for (int w2 = 1; w2 < split; ++w2) v += part[w2][0][ec][t][lane];
+        v = part(0, 0, ec, t)[lane];
+        for (int w2 = 1; w2 < split; ++w2) v += part(w2, 0, ec, t)[lane];
         if constexpr (EPI == EPI_GLU) {
-            gt = part[0][1][ec][t][lane];
-            for (int w2 = 1; w2 < split; ++w2) gt += part[w2][1][ec][t][lane];
+            gt = part(0, 1, ec, t)[lane];
+            for (int w2 = 1; w2 < split; ++w2) gt += part(w2, 1, ec, t)[lane];
         }
     }
     if (col >= g.N) return;
@@ -389,17 +445,17 @@ static int sb_rows_per_wg(const GemmArgs &a, int nslices, bool glu, int tiles) {
 
 // Tuning of the column tiles per wave (CT) and the weight-load cache policy.  A production build has the heuristic below; experiment builds
 // (make EXPERIMENTAL=1) read PK_SB_CT (0 = the heuristic) / PK_SB_NT / PK_SB_ROWS (0 = the heuristic) / PK_SB_WT (0: ignore the operand-tile
-// copy) for A/B runs (tools/experiments/).
-struct SbTune { int ct, nt, rows, wt; };
+// copy) / PK_SB_AL (0: fp32 rows by per-lane loads instead of LDS-DMA) for A/B runs (tools/experiments/).
+struct SbTune { int ct, nt, rows, wt, al; };
 static SbTune sb_tune() {
 #ifdef PK_EXPERIMENTAL
     static const SbTune t = [] {
         auto rd = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
-        return SbTune{rd("PK_SB_CT", 0), rd("PK_SB_NT", 0), rd("PK_SB_ROWS", 0), rd("PK_SB_WT", 1)};
+        return SbTune{rd("PK_SB_CT", 0), rd("PK_SB_NT", 0), rd("PK_SB_ROWS", 0), rd("PK_SB_WT", 1), rd("PK_SB_AL", 1)};
     }();
     return t;
 #else
-    return SbTune{0, 0, 0, 1};
+    return SbTune{0, 0, 0, 1, 1};
 #endif
 }
 
@@ -416,6 +472,23 @@ static void launch_sb_ct(const GemmArgs &a, hipStream_t s, int R) {
     }
     if constexpr (EPI != EPI_GLU && CT == 1) {
         if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, 16, DwTail{}); return; }
+    }
+    // fp32 rows of one row tile: the wave's slice of the rows by LDS-DMA (template AL) -- production: with the operand-tiled weights
+    if constexpr (!A16 && STEPS == 8 && WT && !NTW) {
+        if (sb_tune().al) {
+            constexpr size_t lds = (size_t)kSbMaxWaves * 16 * (4 * 32 * STEPS + 16);
+            static DynLdsSlots slots, slots_dw;
+            if constexpr (EPI == EPI_GLU && CT == 1) {
+                if (a.dw_tail) {
+                    ensure_dyn_lds(slots_dw, reinterpret_cast<const void *>(&gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, 1, false, WT, true, false, true>), lds);
+                    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, 1, false, WT, true, false, true>), grid, block, lds, s, a, split, R, *a.dw_tail);
+                    return;
+                }
+            }
+            ensure_dyn_lds(slots, reinterpret_cast<const void *>(&gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, false, WT, false, false, true>), lds);
+            hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, false, WT, false, false, true>), grid, block, lds, s, a, split, R, DwTail{});
+            return;
+        }
     }
     if constexpr (EPI == EPI_GLU && CT == 1 && !NTW) {
         if (a.dw_tail) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, 1, false, WT, true>), grid, block, 0, s, a, split, R, *a.dw_tail); return; }
