@@ -303,7 +303,8 @@ static int bf16_glds_persist() {
 #endif
 }
 // Instantiation flags of the direct-to-LDS bf16 kernels (gemm_bf16_glds.hpp / gemm_bf16_ring.hpp), EXPERIMENTAL builds: PK_BF16_FLAGS bit 1 = STAGGER,
-// bit 2 = ASMFRAG (hand-counted fragment reads).
+// bit 2 = ASMFRAG (hand-counted fragment reads), bit 4 = row-block walk of the persistent form (XCD x owns a block of tile rows:
+// fetch bytes per fc1 launch 176 -> 150 MB, time +1.5 %: off -- profiles/r05_bf16_rowblock_ab.txt).
 // Production: 2 (ASMFRAG: bit-identical, -0.7 % per tdt-600m step, profiles/r05_bf16_asmfrag_ab.txt).  With PK_BF16_PERSIST=4 the low two bits select
 // the ring kernel's form instead: 0 plain, 1 STAGGER, 2 PHASED, 3 PHASED + s_setprio -- every one of them measured level with the persistent
 // form on fc1 (117 us) and behind it on the step (profiles/r05_bf16_ring_ab.txt, r05_bf16_phased_ab.txt): three different K-loop schedules, one
@@ -374,8 +375,8 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
                     }
                 }
 #endif
-                if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0);
-                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0);
+                if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
+                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
                 return;
             }
         }

@@ -191,7 +191,7 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
 // scalar load is outstanding inside the loop.  The destination registers are tied to the wait by empty "+v" statements (cdna_hip_programming.md
 // 5.7 items 1 and 3), sched_barrier(0) keeps the MFMA builtins below them.
 template <int WGM, int WGN, int TM, int TN, int EPI, bool PERSIST = false, bool DIRECT = false, bool STAGGER = false, bool ASMFRAG = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs g, int tiles_n, int n_tiles) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs g, int tiles_n, int n_tiles, int rowblock = 0) {
     constexpr int BK = 64, NSUB = BK / 16;                          // bf16 elements per tile row; MFMA k-steps per K tile
     constexpr int NT = 64 * WGM * WGN, NW = WGM * WGN;
     constexpr int WM = TM * 32, WN = TN * 32, BM = WGM * WM, BN = WGN * WN;
@@ -232,8 +232,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
     const int x_first = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, x_count = xq + (xcd < xr ? 1 : 0);
     const int per_xcd = PERSIST ? (int)(gridDim.x >> 3) : 1;        // workgroups per XCD walking that range (persistent: stride)
     int loc = idx;                                                  // index inside the XCD's range
-    if (!PERSIST && loc >= x_count) return;                         // (never: the one-tile launch has exactly n_tiles workgroups)
-    if (PERSIST && loc >= x_count) return;
+    // rowblock (persistent walk, round 5): XCD x owns a BLOCK OF TILE ROWS (tiles_m split as evenly as it goes) and walks it row-fastest -- its
+    // A rows (a few MB) stay in ITS L2 for the whole launch and only W streams through, instead of every XCD streaming (nearly) all of both.
+    // Measured (profiles/r05_bf16_rowblock_ab.txt, fc1 of tdt-600m): L2 fetch bytes per launch 176 -> 150 MB, bit-identical, and 1.5 % SLOWER
+    // (119.3 -> 121.2 us) -- the K loop is not waiting for the fabric behind L2.  Off in production (the launcher's rowblock_ok).
+    const int tiles_m_all = n_tiles / tiles_n;
+    const int rq = tiles_m_all >> 3, rr = tiles_m_all & 7;
+    const int r_first = xcd < rr ? xcd * (rq + 1) : rr * (rq + 1) + (xcd - rr) * rq, r_cnt = rq + (xcd < rr ? 1 : 0);
+    const bool rb = PERSIST && rowblock != 0;
+    const int x_cnt = rb ? r_cnt * tiles_n : x_count;
+    auto origin_of = [&](int l, int &m0, int &n0) {
+        if (rb) { m0 = (r_first + l % r_cnt) * BM; n0 = (l / r_cnt) * NOUT; }
+        else tile_origin(x_first + l, m0, n0);
+    };
+    if (loc >= x_cnt) return;                                       // (one-tile launches have exactly n_tiles workgroups)
 
     // DMA sources: wave w fills blocks w, w + NW, ...; lane q of block b supplies (row 8 b + q / 8, logical chunk (q % 8) ^ ((row >> 1) & 7)).
     // Rows 0 .. BM-1 of the stacked tile are A rows, BM .. BM+BN-1 are W rows.
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
 
     const __bf16 *src[NBPW];
     int m0, n0;
-    tile_origin(x_first + loc, m0, n0);
+    origin_of(loc, m0, n0);
     set_src(m0, n0, src);
     int cur = 0;
     int tr_tile = 0;
@@ -387,9 +399,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
         if constexpr (PERSIST && DIRECT) {
             const int em0 = m0, en0 = n0;
             loc += per_xcd;
-            const bool more = loc < x_count;
+            const bool more = loc < x_cnt;
             if (more) {                    // both staging buffers are free (every wave is past the last K tile's barrier, the epilogue uses none)
-                tile_origin(x_first + loc, m0, n0);
+                origin_of(loc, m0, n0);
                 set_src(m0, n0, src);
                 dma(src, 0, cur);
                 if (nk > 1) dma(src, 1, cur ^ 1);
@@ -404,9 +416,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
         } else if constexpr (PERSIST) {
             const int em0 = m0, en0 = n0;
             loc += per_xcd;
-            const bool more = loc < x_count;
+            const bool more = loc < x_cnt;
             if (more) {                    // next tile: its first K tile streams into `cur` UNDER this tile's epilogue
-                tile_origin(x_first + loc, m0, n0);
+                origin_of(loc, m0, n0);
                 set_src(m0, n0, src);
                 dma(src, 0, cur);
             }
@@ -427,12 +439,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
 // persist: 0 = one tile per workgroup, 1 = persistent with the LDS epilogue (round 4), 2 = persistent (more than 256 tiles) with the DIRECT
 // register epilogue, 3 = the direct epilogue on one tile per workgroup
 template <int WGM, int WGN, int TM, int TN, int EPI>
-static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist = 0, bool stagger = false, bool asmfrag = false) {
+static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist = 0, bool stagger = false, bool asmfrag = false, bool rowblock_ok = false) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
     const int n_tiles = tiles_m * tiles_n;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;
+    // persistent walk by row blocks per XCD (kernel comment) when no XCD needs an extra round for it
+    const int rb_tiles = ((tiles_m + 7) / 8) * tiles_n, even_tiles = (n_tiles + 7) / 8;
+    const int rowblock = (rowblock_ok && tiles_m >= 8 && (rb_tiles + 31) / 32 <= (even_tiles + 31) / 32) ? 1 : 0;
     if constexpr (EPI != EPI_RESID) {
         const bool direct_ok = a.sigma_cols == 0 && a.remap_rows == 0 && (a.N % 16) == 0 && (a.ldo % 8) == 0 &&
                                (a.fast_act || (EPI != EPI_SILU && EPI != EPI_GLU)) && ((int64_t)(a.M + 31) * a.ldo < ((int64_t)1 << 31));
@@ -443,7 +458,7 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
                     auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true, true>;
                     static DynLdsSlots slots;
                     ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
-                    hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+                    hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, rowblock);
                     return;
                 }
 #endif
@@ -451,19 +466,19 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
                     auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true, false, true>;
                     static DynLdsSlots slots;
                     ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
-                    hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+                    hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, rowblock);
                     return;
                 }
                 auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true, true>;
                 static DynLdsSlots slots;
                 ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
-                hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+                hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, rowblock);
                 return;
             }
             auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, true>;
             static DynLdsSlots slots;
             ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
-            hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+            hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, 0);
             return;
         }
     }
@@ -473,14 +488,14 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
         auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true>;
         static DynLdsSlots slots;
         ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
-        hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, rowblock);
         return;
     }
     if (stagger) {
         auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, false, true>;
         static DynLdsSlots slots;
         ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
-        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, 0);
         return;
     }
 #endif
@@ -488,13 +503,13 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
         auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, false, false, true>;
         static DynLdsSlots slots;
         ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
-        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, 0);
         return;
     }
     auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false>;
     static DynLdsSlots slots;
     ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, 0);
 }
 
 }  // namespace pk
