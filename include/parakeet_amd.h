@@ -474,6 +474,10 @@ pk_status pk_diag_gemm_bf16_a16(int M, int N, int K, const float *A, const float
 /* The small-M form of that product with the LayerNorm of its input rows folded in (kernels/gemm_smallm_bf16.hip; the streaming chunks of the
  * tolerance-class mode): out = epi(bf16(LayerNorm(A; gamma, beta, eps)) * bf16(W)^T + bias).  M <= 128, K = 256 * (1 .. 8; glu: .. 4).
  * PK_ERR_UNSUPPORTED for any other shape. */
+/* The bf16 diag products (pk_diag_gemm_bf16*, pk_diag_ln_gemm_bf16, pk_diag_glu_dwconv_bf16, pk_diag_ffn_bf16_smallm) hand the small-M kernel
+ * its weights ALSO as operand tiles (kernels.hpp GemmArgs::W_t16), as a streaming session does; on = 0 keeps the natural layout only.  Process-wide
+ * test switch; both give the same bits. */
+pk_status pk_diag_smallm_bf16_tiles(int on);
 pk_status pk_diag_ln_gemm_bf16(int M, int N, int K, const float *A, const float *gamma, const float *beta, float eps, const float *W,
                                const float *bias, int epi, const float *resid, float alpha, float *out);
 /* The conv module's first half on a streaming chunk of the tolerance-class mode: GLU(bf16(LayerNorm(A)) bf16(W)^T + bias) -> causal depthwise

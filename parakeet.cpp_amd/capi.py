@@ -277,6 +277,13 @@ def diag_ln_gemm_bf16(A, gamma, beta, W, bias=None, epi="none", resid=None, alph
     return out
 
 
+def diag_smallm_bf16_tiles(on):
+    """pk_diag_smallm_bf16_tiles: the bf16 diag products with / without the operand-tiled weight copy (test switch, process-wide)."""
+    L = lib()
+    L.pk_diag_smallm_bf16_tiles.argtypes = [C.c_int]
+    check(L.pk_diag_smallm_bf16_tiles(int(on)))
+
+
 def diag_ffn_bf16_smallm(x, gamma, beta, W1, b1, W2, b2, act_tiles, eps=1e-5):
     """pk_diag_ffn_bf16_smallm: x + 0.5 * ffn(LN(x)) of a streaming chunk on the small-M bf16 kernel; act_tiles = fc1 activations in 8-row operand tiles."""
     x, gamma, beta, W1, b1, W2, b2 = (_c(v) for v in (x, gamma, beta, W1, b1, W2, b2))

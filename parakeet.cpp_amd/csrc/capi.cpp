@@ -1,5 +1,6 @@
 // parakeet.cpp_amd/csrc/capi.cpp -- the extern "C" boundary declared in include/parakeet_amd.h.
 // Every entry point translates pk::Error / std::exception into a status code + thread-local message.
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -1780,6 +1781,17 @@ pk_status pk_diag_gemm(int M, int N, int K, const float *A, const float *W, cons
     });
 }
 
+// The bf16 diag products run as a streaming session runs them: weights also as operand tiles of the small-M kernel (GemmArgs::W_t16) where the
+// shape allows (rows % 16 == 0, K % 32 == 0).  pk_diag_smallm_bf16_tiles(0) keeps the natural layout only (both are tested, bit for bit).
+static std::atomic<int> g_diag_tiles{1};
+pk_status pk_diag_smallm_bf16_tiles(int on) { g_diag_tiles.store(on ? 1 : 0); return PK_OK; }
+static const float *diag_operand_tiles(DevBuf &buf, const float *w16, int64_t rows, int K) {
+    if (!g_diag_tiles.load() || rows % 16 != 0 || K % 32 != 0) return nullptr;
+    buf.reserve((size_t)rows * K * 2);
+    launch_tile_copy_bf16(w16, buf.as<float>(), rows, K, K, nullptr);
+    return buf.as<float>();
+}
+
 pk_status pk_diag_gemm_bf16(int M, int N, int K, const float *A, const float *W, const float *bias, int epi, const float *resid,
                             float alpha, float *out) {
     return guard([&] {
@@ -1808,6 +1820,8 @@ pk_status pk_diag_gemm_bf16(int M, int N, int K, const float *A, const float *W,
         if (resid) PK_HIP(hipMemcpy(s.d.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice));
         GemmArgs g{s.a.as<float>(), K, s.b.as<float>(), K, bias ? s.c.as<float>() : nullptr, s.e.as<float>(), N,
                    resid ? s.d.as<float>() : nullptr, N, alpha, M, N, K};
+        DevBuf wt_buf;
+        g.W_t16 = diag_operand_tiles(wt_buf, s.b.as<float>(), wrows, K);
         launch_gemm_bf16(g, epi, nullptr);
         PK_CHECK_LAUNCH();
         PK_HIP(hipMemcpy(out, s.e.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -1846,6 +1860,8 @@ pk_status pk_diag_gemm_bf16_a16(int M, int N, int K, const float *A, const float
         GemmArgs g{s.a.as<float>(), K, s.b.as<float>(), K, bias ? s.c.as<float>() : nullptr, s.e.as<float>(), N,
                    resid ? s.d.as<float>() : nullptr, N, alpha, M, N, K};
         g.a_bf16 = 1;
+        DevBuf wt_buf;
+        g.W_t16 = diag_operand_tiles(wt_buf, s.b.as<float>(), wrows, K);
         launch_gemm_bf16(g, epi, nullptr);
         PK_CHECK_LAUNCH();
         PK_HIP(hipMemcpy(out, s.e.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -1885,6 +1901,8 @@ pk_status pk_diag_ln_gemm_bf16(int M, int N, int K, const float *A, const float 
         GemmArgs g{s.a.as<float>(), K, s.b.as<float>(), K, bias ? s.c.as<float>() : nullptr, s.e.as<float>(), N,
                    resid ? s.d.as<float>() : nullptr, N, alpha, M, N, K};
         g.ln_g = gb.as<float>(); g.ln_b = gb.as<float>() + K; g.ln_eps = eps;
+        DevBuf wt_buf;
+        g.W_t16 = diag_operand_tiles(wt_buf, s.b.as<float>(), wrows, K);
         if (!gemm_smallm_bf16_ln_applies(g, epi)) fail(PK_ERR_UNSUPPORTED, "pk_diag_ln_gemm_bf16: M <= %d, K = 256 * (1 .. 8; glu: .. 4)", kSmallMRowsBf16);
         launch_gemm_bf16(g, epi, nullptr);
         PK_CHECK_LAUNCH();
@@ -1928,6 +1946,8 @@ pk_status pk_diag_glu_dwconv_bf16(int n_streams, int c, int d, const float *A, c
         if (gamma) { g.ln_g = gb.as<float>(); g.ln_b = gb.as<float>() + K; g.ln_eps = eps; }
         if (!(gamma ? gemm_smallm_bf16_ln_applies(g, EPI_GLU) : gemm_smallm_bf16_applies(g, EPI_GLU)))
             fail(PK_ERR_UNSUPPORTED, "pk_diag_glu_dwconv_bf16: M <= %d, d = 256 * (1 .. 4)", kSmallMRowsBf16);
+        DevBuf wt_buf;
+        g.W_t16 = diag_operand_tiles(wt_buf, w.as<float>(), 2 * N, K);
         DwTail tail{ci.as<float>(), co.as<float>(), has_cache, c, pp, pp + 9 * (size_t)d, pp + 10 * (size_t)d, pp + 11 * (size_t)d, pp + 12 * (size_t)d, pp + 13 * (size_t)d};
         if (fused) {
             if (!gemm_smallm_bf16_dw_applies(g, EPI_GLU, c, 9)) fail(PK_ERR_UNSUPPORTED, "pk_diag_glu_dwconv_bf16: the fused tail takes c = 1, 2 or 4 frames per stream");
@@ -1972,6 +1992,9 @@ pk_status pk_diag_ffn_bf16_smallm(int M, int d, int f, const float *x, const flo
         g1.ln_g = gb.as<float>(); g1.ln_b = gb.as<float>() + d; g1.ln_eps = eps; g1.out_bf16 = 1; g1.fast_act = 1; g1.out_t8 = act_tiles ? 1 : 0;
         GemmArgs g2{hb.as<float>(), f, w2b.as<float>(), f, b2b.as<float>(), ob.as<float>(), d, ob.as<float>(), d, 0.5f, M, d, f};
         g2.a_bf16 = 1; g2.a_t8 = act_tiles ? 1 : 0;
+        DevBuf wt1, wt2;
+        g1.W_t16 = diag_operand_tiles(wt1, w1b.as<float>(), f, d);
+        g2.W_t16 = diag_operand_tiles(wt2, w2b.as<float>(), d, f);
         if (!gemm_smallm_bf16_ln_applies(g1, EPI_SILU) || !gemm_smallm_bf16_applies(g2, EPI_RESID))
             fail(PK_ERR_UNSUPPORTED, "pk_diag_ffn_bf16_smallm: M <= %d (act_tiles: M %% 8 == 0), d = 256 * (1 .. 8), f %% 256 == 0", kSmallMRowsBf16);
         launch_gemm_bf16(g1, EPI_SILU, nullptr);

@@ -147,6 +147,13 @@ def test_bf16_smallm_gemm_with_folded_layernorm(M, N, K, epi):
     bias = (0.1 * rng.standard_normal(rows)).astype(np.float32)
     resid = rng.standard_normal((M, N)).astype(np.float32) if epi == "resid" else None
     got = capi.diag_ln_gemm_bf16(A, gamma, beta, W, bias, epi=epi, resid=resid, alpha=0.5, eps=1e-5)
+    # (as a streaming session runs it: weights in operand tiles, fp32 rows by LDS-DMA; the natural-layout path gives the same bits)
+    capi.diag_smallm_bf16_tiles(0)
+    try:
+        plain = capi.diag_ln_gemm_bf16(A, gamma, beta, W, bias, epi=epi, resid=resid, alpha=0.5, eps=1e-5)
+    finally:
+        capi.diag_smallm_bf16_tiles(1)
+    assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)), f"{int((got != plain).sum())} outputs differ between the weight layouts"
     A64 = A.astype(np.float64)
     mean = A64.mean(axis=1, keepdims=True)
     var = ((A64 - mean) ** 2).mean(axis=1, keepdims=True)
@@ -261,6 +268,12 @@ def test_bf16_glu_epilogue_with_depthwise_conv_tail_bit_identical(S, c, d, ln, h
     args = (A, W, bias, cache, has_cache, dw_w, dw_b, mu, rstd, bg, bb, c)
     out_f, cache_f = capi.diag_glu_dwconv_bf16(*args, fused=1, gamma=gamma, beta=beta)
     out_s, cache_s = capi.diag_glu_dwconv_bf16(*args, fused=0, gamma=gamma, beta=beta)
+    capi.diag_smallm_bf16_tiles(0)                                         # natural weight layout, per-lane row loads: the same bits
+    try:
+        out_n, cache_n = capi.diag_glu_dwconv_bf16(*args, fused=1, gamma=gamma, beta=beta)
+    finally:
+        capi.diag_smallm_bf16_tiles(1)
+    assert np.array_equal(out_f.view(np.uint32), out_n.view(np.uint32)) and np.array_equal(cache_f.view(np.uint32), cache_n.view(np.uint32))
     assert np.array_equal(out_f.view(np.uint32), out_s.view(np.uint32)), f"{int((out_f != out_s).sum())} activations differ"
     assert np.array_equal(cache_f.view(np.uint32), cache_s.view(np.uint32)), f"{int((cache_f != cache_s).sum())} cache words differ"
     # the new cache's tail IS the chunk's GLU rows (c <= 8): recover them and restate the conv in float64
@@ -287,6 +300,12 @@ def test_bf16_smallm_ffn_activation_operand_tiles_bit_identical(M, d, f):
     W2, b2 = (rng.standard_normal((d, f)) / np.sqrt(f)).astype(np.float32), (0.1 * rng.standard_normal(d)).astype(np.float32)
     tiled = capi.diag_ffn_bf16_smallm(x, gamma, beta, W1, b1, W2, b2, act_tiles=1)
     rows = capi.diag_ffn_bf16_smallm(x, gamma, beta, W1, b1, W2, b2, act_tiles=0)
+    capi.diag_smallm_bf16_tiles(0)
+    try:
+        plain = capi.diag_ffn_bf16_smallm(x, gamma, beta, W1, b1, W2, b2, act_tiles=0)
+    finally:
+        capi.diag_smallm_bf16_tiles(1)
+    assert np.array_equal(tiled.view(np.uint32), plain.view(np.uint32)), "operand-tiled weights / LDS-DMA rows vs the natural layouts"
     assert np.array_equal(tiled.view(np.uint32), rows.view(np.uint32)), f"{int((tiled != rows).sum())} outputs differ"
     x64 = x.astype(np.float64)
     mean = x64.mean(axis=1, keepdims=True)
