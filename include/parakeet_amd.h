@@ -480,6 +480,11 @@ pk_status pk_diag_gemm_bf16_a16(int M, int N, int K, const float *A, const float
 pk_status pk_diag_smallm_bf16_tiles(int on);
 pk_status pk_diag_ln_gemm_bf16(int M, int N, int K, const float *A, const float *gamma, const float *beta, float eps, const float *W,
                                const float *bias, int epi, const float *resid, float alpha, float *out);
+/* Two LayerNorms in front of a product (a block's final_norm_ folded, with the next block's first norm, into that block's fc1; streaming,
+ * tolerance-class mode): out = silu(bf16(LN(LN(A; pre_gamma, pre_beta); gamma, beta)) bf16(W)^T + bias), pre_out [M][K] = LN(A; pre_gamma, pre_beta)
+ * (the residual stream of the block that starts there).  M <= 128, K = 256 * (1 .. 8). */
+pk_status pk_diag_ln2_gemm_bf16(int M, int N, int K, const float *A, const float *pre_gamma, const float *pre_beta, const float *gamma, const float *beta,
+                                float eps, const float *W, const float *bias, float *out, float *pre_out);
 /* The conv module's first half on a streaming chunk of the tolerance-class mode: GLU(bf16(LayerNorm(A)) bf16(W)^T + bias) -> causal depthwise
  * conv (kernel 9) over [cache_in ; the c new rows] of every stream -> BatchNorm -> SiLU (reference src/streaming_encoder.cpp:41-78).  A = [n_streams * c][d]
  * rows, stream-major; W [2 d][d]; cache_in / cache_out [n_streams][8][d]; gamma = beta = NULL: A is taken as it is.  fused = 1: the conv runs in

@@ -277,6 +277,18 @@ def diag_ln_gemm_bf16(A, gamma, beta, W, bias=None, epi="none", resid=None, alph
     return out
 
 
+def diag_ln2_gemm_bf16(A, pre_gamma, pre_beta, gamma, beta, W, bias, eps=1e-5):
+    """pk_diag_ln2_gemm_bf16: silu(bf16(LN(LN(A; pre); gamma, beta)) bf16(W)^T + bias) and LN(A; pre) on the small-M bf16 kernel."""
+    A, W, pg, pb, g, b, bias = (_c(v) for v in (A, W, pre_gamma, pre_beta, gamma, beta, bias))
+    M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((M, N), np.float32); pre = np.empty((M, K), np.float32)
+    L = lib()
+    L.pk_diag_ln2_gemm_bf16.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float, f32p, f32p, f32p, f32p]
+    check(L.pk_diag_ln2_gemm_bf16(M, N, K, _f(A), _f(pg), _f(pb), _f(g), _f(b), eps, _f(W), _f(bias), _f(out), _f(pre)))
+    return out, pre
+
+
 def diag_smallm_bf16_tiles(on):
     """pk_diag_smallm_bf16_tiles: the bf16 diag products with / without the operand-tiled weight copy (test switch, process-wide)."""
     L = lib()

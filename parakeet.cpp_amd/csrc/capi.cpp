@@ -1910,6 +1910,41 @@ pk_status pk_diag_ln_gemm_bf16(int M, int N, int K, const float *A, const float 
     });
 }
 
+pk_status pk_diag_ln2_gemm_bf16(int M, int N, int K, const float *A, const float *pre_gamma, const float *pre_beta, const float *gamma, const float *beta,
+                                float eps, const float *W, const float *bias, float *out, float *pre_out) {
+    return guard([&] {
+        need(M > 0 && N > 0 && K > 0 && A && pre_gamma && pre_beta && gamma && beta && W && out && pre_out, "arguments");
+        diag_device();
+        std::vector<uint16_t> w16((size_t)N * K);
+        for (size_t i = 0; i < w16.size(); ++i) {
+            uint32_t u;
+            memcpy(&u, &W[i], 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            w16[i] = (uint16_t)(u >> 16);
+        }
+        DevBuf a, w, b, gb, o, po, wt_buf;
+        auto up = [&](DevBuf &buf, const void *src, size_t bytes) { buf.reserve(bytes); PK_HIP(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice)); };
+        up(a, A, (size_t)M * K * 4);
+        up(w, w16.data(), w16.size() * 2);
+        if (bias) up(b, bias, (size_t)N * 4);
+        gb.reserve((size_t)4 * K * 4);
+        const float *four[4] = {pre_gamma, pre_beta, gamma, beta};
+        for (int i = 0; i < 4; ++i) PK_HIP(hipMemcpy(gb.as<float>() + (size_t)i * K, four[i], (size_t)K * 4, hipMemcpyHostToDevice));
+        o.reserve((size_t)M * N * 4);
+        po.reserve((size_t)M * K * 4);
+        GemmArgs g{a.as<float>(), K, w.as<float>(), K, bias ? b.as<float>() : nullptr, o.as<float>(), N, nullptr, 0, 1.0f, M, N, K};
+        g.fast_act = 1;
+        g.pre_g = gb.as<float>(); g.pre_b = gb.as<float>() + K; g.ln_g = gb.as<float>() + 2 * (size_t)K; g.ln_b = gb.as<float>() + 3 * (size_t)K; g.ln_eps = eps;
+        g.pre_out = po.as<float>(); g.pre_ldo = K;
+        g.W_t16 = diag_operand_tiles(wt_buf, w.as<float>(), N, K);
+        if (!gemm_smallm_bf16_pre_applies(g, EPI_SILU)) fail(PK_ERR_UNSUPPORTED, "pk_diag_ln2_gemm_bf16: M <= %d, K = 256 * (1 .. 8)", kSmallMRowsBf16);
+        launch_gemm_bf16(g, EPI_SILU, nullptr);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpy(out, o.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(pre_out, po.p, (size_t)M * K * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 pk_status pk_diag_glu_dwconv_bf16(int n_streams, int c, int d, const float *A, const float *gamma, const float *beta, float eps, const float *W,
                                   const float *bias, const float *cache_in, int has_cache, const float *dw_w, const float *dw_bias,
                                   const float *bn_mean, const float *bn_rstd, const float *bn_g, const float *bn_b, int fused, float *out,

@@ -63,11 +63,13 @@ template <int EPI, int STEPS /* MFMA steps (32 k each) per K slice */, int RT /*
           int CT = 1 /* 16-column tiles per wave: the activation registers of a K slice feed CT weight tiles (round 5) */, bool NTW = false /* non-temporal weight loads */,
           bool WT = false /* weights from the operand-tile copy GemmArgs::W_t16 */, bool DW = false /* EPI_GLU: the depthwise-conv tail (DwTail) */,
           bool AT = false /* A16: the rows in 8-row operand tiles (GemmArgs::a_t8) */,
-          bool AL = false /* fp32 rows: the wave's K slice of the rows travels global -> LDS by DMA (1 KB of consecutive addresses per instruction) */>
+          bool AL = false /* fp32 rows: the wave's K slice of the rows travels global -> LDS by DMA (1 KB of consecutive addresses per instruction) */,
+          bool PRE = false /* LN: another LayerNorm in front of the folded one (GemmArgs::pre_g) */>
 __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(GemmArgs g, int split /* waves = K slices in flight */,
                                                                             int rvalid /* rows of a 16-row tile that exist: 16, or 8 (RT = 1) */,
                                                                             DwTail dw = DwTail{}) {
     static_assert(!DW || (EPI == EPI_GLU && RT == 1 && CT == 1), "the conv tail finishes the GLU tile of one wave");
+    static_assert(!PRE || (LN && RT == 1), "the norm in front of the folded norm: one row tile per wave");
     constexpr int NW = (EPI == EPI_GLU) ? 2 : 1;                    // weight tiles per column tile (GLU: value rows [0, N), gate rows [N, 2N))
     constexpr int SL = 32 * STEPS;
     static_assert(!LN || (!A16 && (STEPS == 8 || STEPS == 4)), "the folded LayerNorm reads fp32 rows in slices of 256 (128) k");
@@ -201,11 +203,16 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                     af[t][s][1] = *reinterpret_cast<const float4 *>(ap32[t] + k0 + 32 * s + 4);
                 }
             }
-        float4 g4 = {0.0f, 0.0f, 0.0f, 0.0f}, b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        float4 g4 = {0.0f, 0.0f, 0.0f, 0.0f}, b4 = {0.0f, 0.0f, 0.0f, 0.0f}, pg4 = {0.0f, 0.0f, 0.0f, 0.0f}, pb4 = {0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (LN) {
             if (4 * lane < SL) {
                 g4 = *reinterpret_cast<const float4 *>(g.ln_g + k0 + 4 * lane);
                 b4 = *reinterpret_cast<const float4 *>(g.ln_b + k0 + 4 * lane);
+                // the norm in front of it (GemmArgs::pre_g)
+                if constexpr (PRE) {
+                    pg4 = *reinterpret_cast<const float4 *>(g.pre_g + k0 + 4 * lane);
+                    pb4 = *reinterpret_cast<const float4 *>(g.pre_b + k0 + 4 * lane);
+                }
             }
         }
 #pragma unroll
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
         SB_STAMP(1);
         if constexpr (AL) {
             // the rows were requested first: they have landed when only the loads issued after them are outstanding (gamma / beta, the weights)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LN ? 2 : 0) + NW * CT * STEPS) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LN ? (PRE ? 4 : 2) : 0) + NW * CT * STEPS) : "memory");
             // (inline-asm reads: left to the compiler, an LDS read after an LDS-DMA write is preceded by s_waitcnt vmcnt(0) -- the whole weight
             //  stream would have to land before the LayerNorm starts)
             const unsigned ar = (unsigned)(size_t)(arows + ((size_t)wave * 16 + (r & (rvalid - 1))) * APITCH + 32 * kq);
@@ -242,52 +249,84 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
         }
 
         if constexpr (LN) {
-            // gamma / beta of this wave's slice: wave-private LDS rows, read back after the barriers below
-            if (4 * lane < SL) {
-                *reinterpret_cast<float4 *>(&gam[wave][4 * lane]) = g4;
-                *reinterpret_cast<float4 *>(&bet[wave][4 * lane]) = b4;
-            }
-            // statistics of the rows (oracle layer_norm: the mean, then the mean of the squared deviations), two passes over the registers
             const float inv_k = 1.0f / (float)g.K;
             float mean[RT], rstd[RT];
+            // gamma / beta of this wave's slice: wave-private LDS rows, read back after the barriers of row_stats
+            auto stage_gb = [&](const float4 &gv, const float4 &bv) {
+                if (4 * lane < SL) {
+                    *reinterpret_cast<float4 *>(&gam[wave][4 * lane]) = gv;
+                    *reinterpret_cast<float4 *>(&bet[wave][4 * lane]) = bv;
+                }
+            };
+            // statistics of the rows (oracle layer_norm: the mean, then the mean of the squared deviations), two passes over the registers; the
+            // slices' partial sums meet in LDS, added in wave order (two barriers, executed by every wave)
+            auto row_stats = [&]() {
 #pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                float p = 0.0f;
+                for (int t = 0; t < RT; ++t) {
+                    float p = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < STEPS; ++s) {
+                        const float4 lo = af[t][s][0], hi = af[t][s][1];
+                        p += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                    }
+                    p += __shfl_xor(p, 16);
+                    p += __shfl_xor(p, 32);
+                    if (kq == 0) st1[wave][t][r] = p;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    float sum = st1[0][t][r];
+                    for (int w2 = 1; w2 < split; ++w2) sum += st1[w2][t][r];
+                    mean[t] = sum * inv_k;
+                    float p = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < STEPS; ++s) {
+                        const float4 lo = af[t][s][0], hi = af[t][s][1];
+                        const float c0 = lo.x - mean[t], c1 = lo.y - mean[t], c2 = lo.z - mean[t], c3 = lo.w - mean[t];
+                        const float c4 = hi.x - mean[t], c5 = hi.y - mean[t], c6 = hi.z - mean[t], c7 = hi.w - mean[t];
+                        p += ((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) + ((c4 * c4 + c5 * c5) + (c6 * c6 + c7 * c7));
+                    }
+                    p += __shfl_xor(p, 16);
+                    p += __shfl_xor(p, 32);
+                    if (kq == 0) st2[wave][t][r] = p;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    float sum = st2[0][t][r];
+                    for (int w2 = 1; w2 < split; ++w2) sum += st2[w2][t][r];
+                    rstd[t] = 1.0f / sqrtf(sum * inv_k + g.ln_eps);
+                }
+            };
+            if constexpr (PRE) {
+                // A norm in front of the folded one (a block's final_norm_ in front of the next block's first: GemmArgs::pre_g): the rows are
+                // normalised in place (fp32) -- and written out by the workgroups of the first column tile: they are the residual stream from here on
+                stage_gb(pg4, pb4);
+                row_stats();
 #pragma unroll
                 for (int s = 0; s < STEPS; ++s) {
-                    const float4 lo = af[t][s][0], hi = af[t][s][1];
-                    p += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                    const float4 gl = *reinterpret_cast<const float4 *>(&gam[wave][32 * s + 8 * kq]), gh = *reinterpret_cast<const float4 *>(&gam[wave][32 * s + 8 * kq + 4]);
+                    const float4 bl = *reinterpret_cast<const float4 *>(&bet[wave][32 * s + 8 * kq]), bh = *reinterpret_cast<const float4 *>(&bet[wave][32 * s + 8 * kq + 4]);
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        const float4 lo = af[t][s][0], hi = af[t][s][1];
+                        const float m = mean[t], rs = rstd[t];
+                        const float4 ylo = {fmaf((lo.x - m) * rs, gl.x, bl.x), fmaf((lo.y - m) * rs, gl.y, bl.y), fmaf((lo.z - m) * rs, gl.z, bl.z), fmaf((lo.w - m) * rs, gl.w, bl.w)};
+                        const float4 yhi = {fmaf((hi.x - m) * rs, gh.x, bh.x), fmaf((hi.y - m) * rs, gh.y, bh.y), fmaf((hi.z - m) * rs, gh.z, bh.z), fmaf((hi.w - m) * rs, gh.w, bh.w)};
+                        af[t][s][0] = ylo; af[t][s][1] = yhi;
+                        const int row = m0 + 16 * t + r;
+                        if (blockIdx.x == 0 && g.pre_out && r < rvalid && row < g.M) {
+                            float *dst = g.pre_out + (int64_t)row * g.pre_ldo + k0 + 32 * s + 8 * kq;
+                            *reinterpret_cast<float4 *>(dst) = ylo;
+                            *reinterpret_cast<float4 *>(dst + 4) = yhi;
+                        }
+                    }
                 }
-                p += __shfl_xor(p, 16);
-                p += __shfl_xor(p, 32);
-                if (kq == 0) st1[wave][t][r] = p;
             }
+            stage_gb(g4, b4);                                       // (wave-private rows, LDS operations of a wave complete in order)
+            row_stats();
             SB_STAMP(2);
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                float sum = st1[0][t][r];
-                for (int w2 = 1; w2 < split; ++w2) sum += st1[w2][t][r];
-                mean[t] = sum * inv_k;
-                float p = 0.0f;
-#pragma unroll
-                for (int s = 0; s < STEPS; ++s) {
-                    const float4 lo = af[t][s][0], hi = af[t][s][1];
-                    const float c0 = lo.x - mean[t], c1 = lo.y - mean[t], c2 = lo.z - mean[t], c3 = lo.w - mean[t];
-                    const float c4 = hi.x - mean[t], c5 = hi.y - mean[t], c6 = hi.z - mean[t], c7 = hi.w - mean[t];
-                    p += ((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3)) + ((c4 * c4 + c5 * c5) + (c6 * c6 + c7 * c7));
-                }
-                p += __shfl_xor(p, 16);
-                p += __shfl_xor(p, 32);
-                if (kq == 0) st2[wave][t][r] = p;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                float sum = st2[0][t][r];
-                for (int w2 = 1; w2 < split; ++w2) sum += st2[w2][t][r];
-                rstd[t] = 1.0f / sqrtf(sum * inv_k + g.ln_eps);
-            }
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 const float4 gl = *reinterpret_cast<const float4 *>(&gam[wave][32 * s + 8 * kq]), gh = *reinterpret_cast<const float4 *>(&gam[wave][32 * s + 8 * kq + 4]);
@@ -422,6 +461,11 @@ bool gemm_smallm_bf16_applies(const GemmArgs &a, int epi) {
     if (a.a_t8 && !(a.a_bf16 && a.M % 8 == 0 && a.lda == a.K && epi == EPI_RESID)) return false;   // (instantiated for the product that takes them: fc2)
     return epi >= EPI_NONE && epi <= EPI_GLU;
 }
+bool gemm_smallm_bf16_pre_applies(const GemmArgs &a, int epi) {
+    if (epi != EPI_SILU || !a.pre_g || !a.pre_b || a.K / 256 > kSbMaxWaves || a.K % 256 != 0) return false;
+    if (a.pre_out && (a.pre_out == a.A || a.pre_ldo < a.K || (a.pre_ldo % 4) != 0)) return false;
+    return gemm_smallm_bf16_ln_applies(a, epi);
+}
 bool gemm_smallm_bf16_dw_applies(const GemmArgs &a, int epi, int c, int kc) {
     if (epi != EPI_GLU || kc != 9 || !(c == 1 || c == 2 || c == 4) || a.M % c != 0 || a.N % 16 != 0 || a.out_bf16) return false;
     return a.ln_g ? gemm_smallm_bf16_ln_applies(a, epi) : gemm_smallm_bf16_applies(a, epi);
@@ -465,13 +509,29 @@ static void launch_sb_ct(const GemmArgs &a, hipStream_t s, int R) {
     const int split = nslices < kSbMaxWaves ? nslices : kSbMaxWaves;
     const int tiles = (a.N + 16 * CT - 1) / (16 * CT);
     if (EPI == EPI_GLU && R == 32) R = 16;
-    if (R == 32 && (CT > 1 || split < 2)) R = 16;                   // two row tiles per wave: one column tile (registers), a wave per output tile
+    if (R == 32 && (CT > 1 || split < 2 || a.pre_g)) R = 16;                   // two row tiles per wave: one column tile (registers), a wave per output tile
     const dim3 grid(tiles, (a.M + R - 1) / R), block(64 * split);
     if constexpr (EPI == EPI_RESID && A16 && CT == 1 && !NTW) {
         if (a.a_t8 && R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, 1, false, WT, false, true>), grid, block, 0, s, a, split, 16, DwTail{}); return; }
     }
     if constexpr (EPI != EPI_GLU && CT == 1) {
         if (R == 32) { hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 2, A16, LN, CT, NTW, WT>), grid, block, 0, s, a, split, 16, DwTail{}); return; }
+    }
+    // a norm in front of the folded one (GemmArgs::pre_g; the caller checked gemm_smallm_bf16_pre_applies): fc1 of a streaming block
+    if constexpr (LN && EPI == EPI_SILU && !NTW && STEPS == 8) {
+        if (a.pre_g) {
+            if constexpr (WT) {
+                if (sb_tune().al) {
+                    constexpr size_t lds = (size_t)kSbMaxWaves * 16 * (4 * 32 * STEPS + 16);
+                    static DynLdsSlots slots_pre;
+                    ensure_dyn_lds(slots_pre, reinterpret_cast<const void *>(&gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, false, WT, false, false, true, true>), lds);
+                    hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, false, WT, false, false, true, true>), grid, block, lds, s, a, split, R, DwTail{});
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((gemm_smallm_bf16_kernel<EPI, STEPS, 1, A16, LN, CT, false, WT, false, false, false, true>), grid, block, 0, s, a, split, R, DwTail{});
+            return;
+        }
     }
     // fp32 rows of one row tile: the wave's slice of the rows by LDS-DMA (template AL) -- production: with the operand-tiled weights
     if constexpr (!A16 && STEPS == 8 && WT && !NTW) {

@@ -138,6 +138,11 @@ struct GemmArgs {
     // ln_b[K], ln_eps) of the product's input is applied while the rows are staged -- out = epi(LN(A) W^T + bias) (bf16 mode: bf16(LN(A)) W16^T).
     // Callers check gemm_smallm_bf16_ln_applies() / gemm_smallm_ln_applies().
     const float *ln_g = nullptr, *ln_b = nullptr; float ln_eps = 0.0f;
+    // small-M bf16 kernel with ln_g set only: ANOTHER LayerNorm in front of the folded one -- out = epi(bf16(LN(LN(A; pre_g, pre_b); ln_g, ln_b)) W16^T + bias):
+    // a block's final_norm_ folded into the first product of the next block (streaming, tolerance-class mode: one launch less per block).  pre_out
+    // (optional, fp32 [M][pre_ldo], NOT the buffer A lives in: other workgroups still read A) receives LN(A; pre_g, pre_b) -- the residual stream
+    // of the block that starts here -- written by the workgroups of the first column tile.
+    const float *pre_g = nullptr, *pre_b = nullptr; float *pre_out = nullptr; int64_t pre_ldo = 0;
     // small-M kernels with the LayerNorm folded in (exact mode) / small-M bf16 kernel, EPI_GLU only: HOST pointer to the depthwise-conv tail of
     // the epilogue (read during the launch call).  Callers check gemm_smallm_dw_applies() / gemm_smallm_bf16_dw_applies().
     const DwTail *dw_tail = nullptr;
@@ -167,7 +172,8 @@ void launch_gemm_bf16(const GemmArgs &a, int epi, hipStream_t s);
 constexpr int kSmallMRowsBf16 = 128;
 bool gemm_smallm_bf16_applies(const GemmArgs &a, int epi);
 bool gemm_smallm_bf16_dw_applies(const GemmArgs &a, int epi, int c, int kc);   // ... with GemmArgs::dw_tail: GLU, conv kernel 9, c = 1 / 2 / 4 frames per stream
-bool gemm_smallm_bf16_ln_applies(const GemmArgs &a, int epi);     // ... with GemmArgs::ln_g set: K = 256 * (1 .. 8 waves; GLU: 4), fp32 rows
+bool gemm_smallm_bf16_ln_applies(const GemmArgs &a, int epi);
+bool gemm_smallm_bf16_pre_applies(const GemmArgs &a, int epi);    // ... and GemmArgs::pre_g (a second norm in front): SiLU products, slices of 256 k     // ... with GemmArgs::ln_g set: K = 256 * (1 .. 8 waves; GLU: 4), fp32 rows
 void launch_gemm_smallm_bf16(const GemmArgs &a, int epi, hipStream_t s);
 double gemm_flops(const GemmArgs &a, int epi);
 

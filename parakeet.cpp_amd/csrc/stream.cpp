@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <utility>
 
 #include "stream.hpp"
 
@@ -34,6 +35,17 @@ static bool stream_fuse_dw() {
 static bool stream_act_tiles() {
 #ifdef PK_EXPERIMENTAL
     static const bool on = [] { const char *e = getenv("PK_STREAM_ACT_TILES"); return e ? atoi(e) != 0 : true; }();
+    return on;
+#else
+    return true;
+#endif
+}
+// Tolerance-class mode: a block's final_norm_ folded into the first product of the NEXT block (GemmArgs::pre_g: that product normalises twice and
+// its first column tile writes the normalised rows -- the next block's residual stream -- into the other of two buffers): one launch less per block.
+// EXPERIMENTAL builds: PK_STREAM_FUSE_FIN=0 keeps the separate LayerNorm launch.
+static bool stream_fuse_final() {
+#ifdef PK_EXPERIMENTAL
+    static const bool on = [] { const char *e = getenv("PK_STREAM_FUSE_FIN"); return e ? atoi(e) != 0 : true; }();
     return on;
 #else
     return true;
@@ -195,10 +207,20 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     const int f = cfg.ffn_intermediate;
     float *hb = ws_.hbuf.as<float>();
     // LayerNorm(x) -> n, then the product on n -- or, where the small-M bf16 kernel can fold the norm in, the product straight on x
+    // the previous block's final norm, when it rides on this block's first product (set at the end of a block, consumed by the next ffn1 fc1)
+    const float *pend_g = nullptr, *pend_b = nullptr;
+    float *x_other = nullptr;
     auto ln_gemm = [&](const char *name, const GemmArgs &g, int epi, const float *ng, const float *nb, bool norm_done) {
         if (!norm_done && stream_fuse_ln()) {
             GemmArgs fg = g;
             fg.A = x; fg.lda = d; fg.a_bf16 = 0; fg.a_sigma = 0; fg.ln_g = ng; fg.ln_b = nb; fg.ln_eps = 1e-5f;
+            if (pend_g) {                                            // (checked when it was set: gemm_smallm_bf16_pre_applies)
+                fg.pre_g = pend_g; fg.pre_b = pend_b; fg.pre_out = x_other; fg.pre_ldo = d;
+                m_.run_gemm(name, fg, epi, st);
+                std::swap(x, x_other);                               // the normalised rows are the residual stream from here on
+                pend_g = pend_b = nullptr;
+                return;
+            }
             // tolerance-class mode: gemm_smallm_bf16.hip; exact mode (tiled weight copies present): gemm_smallm_ln_kernel -- bit for bit norm + product
             if (a16 ? gemm_smallm_bf16_ln_applies(fg, epi) : (sg && gemm_smallm_ln_applies(fg, epi))) { m_.run_gemm(name, fg, epi, st); return; }
         }
@@ -212,6 +234,15 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         if (sg) pg.W_sig = (*sig_)[0].ffn1_w1;
         if (wt) pg.W_t16 = (*sig_)[0].ffn1_w1;
         ln_folds = a16 ? gemm_smallm_bf16_ln_applies(pg, EPI_SILU) : (sg && gemm_smallm_ln_applies(pg, EPI_SILU));
+    }
+    bool fin_folds = false;                                                                               // ... and the block's final norm with it
+    if (a16 && ln_folds && stream_fuse_final() && cfg.num_layers > 1) {
+        x_alt_.reserve((size_t)rows * d * 4);
+        x_other = x_alt_.as<float>();
+        GemmArgs pg{x, d, m_.layers[1].ffn1_w1, d, nullptr, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
+        pg.ln_g = m_.layers[1].ffn1_ng; pg.ln_b = m_.layers[1].ffn1_nb; pg.out_bf16 = 1;
+        pg.pre_g = m_.layers[0].fin_g; pg.pre_b = m_.layers[0].fin_b; pg.pre_out = x_other; pg.pre_ldo = d;
+        fin_folds = gemm_smallm_bf16_pre_applies(pg, EPI_SILU);
     }
     auto ffn = [&](const LayerW &L, const Model::SigW &Ls, bool second, bool norm_done) {                // FeedForward (src/encoder.cpp:36-46)
         GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
@@ -285,8 +316,11 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         if (l + 1 < cfg.num_layers && !ln_folds) {   // final_norm_ and the next block's ffn1_ norm in one pass over the rows (as the offline encoder)
             launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, m_.layers[l + 1].ffn1_ng, m_.layers[l + 1].ffn1_nb, 1e-5f, x, n, st, lnm);
             ffn1_norm_done = true;
+        } else if (l + 1 < cfg.num_layers && fin_folds) {
+            pend_g = L.fin_g; pend_b = L.fin_b;      // final_norm_ rides on the next block's fc1 (ln_gemm above)
         } else {                                     // (ln_folds: the next block's fc1 normalises its own input rows)
-            launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, st);                              // final_norm_
+            launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, ws_.x.as<float>(), st);            // final_norm_ (the last block's lands in ws_.x)
+            x = ws_.x.as<float>();
         }
     }
     PK_CHECK_LAUNCH();

@@ -44,6 +44,7 @@ class StreamBatch {
     Workspace wd_;              // decode workspace: h / c / token persist across chunks (never re-allocated)
     int dec_cap_frames_ = 0;
     DevBuf pre_, mel_dev_, mel_all_, enc_in_, force_, score_;
+    DevBuf x_alt_;              // second residual-stream buffer: a block's final norm folded into the next block's first product writes it (stream.cpp)
     std::map<int, std::unique_ptr<DevBuf>> pos_tables_;   // Tp -> pos_proj of every layer [L][2Tp-1][d], natural columns
     int encode_device(const float *d_mel, int n_frames);                    // -> ws_.x [S*c][d], returns c
     const float *pos_table(int Tp);

@@ -314,3 +314,40 @@ def test_bf16_smallm_ffn_activation_operand_tiles_bit_identical(M, d, f):
     h = bf16_round((h / (1.0 + np.exp(-h))).astype(np.float32)).astype(np.float64)
     want = x64 + 0.5 * (h @ bf16_round(W2).astype(np.float64).T + b2)
     assert np.abs(tiled - want).max() <= 2e-2 * (1.0 + np.abs(want).max()), f"max err {np.abs(tiled - want).max():.3e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 1024), (16, 4096, 1024), (32, 2048, 512), (6, 1536, 512), (128, 1024, 1024), (8, 256, 2048)])
+def test_bf16_smallm_gemm_with_two_folded_layernorms(M, N, K):
+    """A block's final_norm_ folded -- with the next block's first norm -- into that block's fc1 (GemmArgs::pre_g; streaming, tolerance-class mode:
+    one launch less per block).  The kernel normalises the rows twice (four LDS exchanges) and its first column tile writes LN(x; pre) -- the residual
+    stream from there on.  pre_out against float64 (fp32 LayerNorm class), the product against float64 of the operands the specification rounds, with
+    the flipped-rounding allowance of the single-norm test; operand-tiled and natural weight layouts bit-identical."""
+    from parakeet_cpp_amd import capi
+    rng = np.random.default_rng(7 * M + N + K)
+    A = (rng.standard_normal((M, K)) * rng.uniform(0.5, 3.0, (M, 1)) + rng.uniform(-2, 2, (M, 1))).astype(np.float32)
+    pg, pb = rng.uniform(0.5, 1.5, K).astype(np.float32), (0.2 * rng.standard_normal(K)).astype(np.float32)
+    g, b = rng.uniform(0.5, 1.5, K).astype(np.float32), (0.2 * rng.standard_normal(K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    got, pre = capi.diag_ln2_gemm_bf16(A, pg, pb, g, b, W, bias)
+    capi.diag_smallm_bf16_tiles(0)
+    try:
+        got0, pre0 = capi.diag_ln2_gemm_bf16(A, pg, pb, g, b, W, bias)
+    finally:
+        capi.diag_smallm_bf16_tiles(1)
+    assert np.array_equal(got.view(np.uint32), got0.view(np.uint32)) and np.array_equal(pre.view(np.uint32), pre0.view(np.uint32))
+
+    def ln(x, gam, bet):
+        m = x.mean(axis=1, keepdims=True)
+        return (x - m) / np.sqrt(((x - m) ** 2).mean(axis=1, keepdims=True) + 1e-5) * gam + bet
+    y = ln(A.astype(np.float64), pg, pb)
+    assert np.abs(pre - y).max() <= 2e-6 * (1.0 + np.abs(y).max()), f"pre_out max err {np.abs(pre - y).max():.3e}"
+    z = ln(pre.astype(np.float64), g, b).astype(np.float32)              # the second norm sees the fp32 rows the first one produced
+    zq, Wq = bf16_round(z).astype(np.float64), bf16_round(W).astype(np.float64)
+    acc = zq @ Wq.T + bias
+    mag = np.abs(zq) @ np.abs(Wq.T) + np.abs(bias)
+    flip = 4.0 * 2.0 ** -8 * (np.abs(zq).max(axis=1, keepdims=True) * np.abs(Wq).max(axis=1)[None, :])
+    want = acc / (1.0 + np.exp(-acc))
+    err = np.abs(got - want)
+    bound = 2e-6 * mag + flip + 1e-6 + 2e-3 * np.abs(want)               # (+ the hardware exp2 / rcp SiLU of the mode: 1-ulp class, generous)
+    assert np.all(err <= bound), f"max err {err.max():.3e} (bound there {float(bound.flat[err.argmax()]):.3e})"
