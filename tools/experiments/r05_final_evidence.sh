@@ -26,4 +26,5 @@ for m in fp32 bf16; do
 done
 timeout 300 python tools/bench_stream.py --chunks 100 --warmup 10 2>/dev/null | tail -1 > $o/bench_stream_fp32.json
 timeout 300 python tools/bench_stream.py --bf16 --chunks 100 --warmup 10 2>/dev/null | tail -1 > $o/bench_stream_bf16.json
+timeout 900 python -m pytest tests/test_gpu_stream.py tests/test_gpu_600m_depth.py -m gpu -q -s -k "teacher_forced or fp32_reference_path or stream_score" 2>&1 | grep -v "^$" | tail -40 > $o/teacher_forced_tests.txt
 ls -la $o; head -c 400 $o/bench.json; echo; head -8 $o/pmc_sq_600m_bf16.md; cat $o/pmc_hbm.json | head -c 600; echo; cat $o/pmc_hbm_600m_bf16.json | head -c 600
