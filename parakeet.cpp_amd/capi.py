@@ -365,7 +365,8 @@ class Stream:
         out = np.zeros((self.S, cap, self.model.cfg.hidden_size), np.float32)
         n = C.c_int(0)
         check(lib().pk_stream_encode(self._h, _f(mel), mel.shape[1], _f(out), cap, C.byref(n)))
-        return np.ascontiguousarray(out.reshape(-1)[: self.S * n.value * self.model.cfg.hidden_size].reshape(self.S, n.value, -1))
+        d = self.model.cfg.hidden_size
+        return np.ascontiguousarray(out.reshape(-1)[: self.S * n.value * d].reshape(self.S, n.value, d))
 
     def decode(self, enc, max_tokens=64):
         enc = _c(enc)

@@ -261,6 +261,39 @@ def test_stream_bf16_mode_vs_bf16_oracle(tmp_path_factory, orc, S):
     assert dev < gap, "the GPU should be closer to the bf16 oracle than the bf16 mode is to fp32"
 
 
+def test_stream_bf16_mode_rows_do_not_depend_on_the_session_count_or_the_fusions_taken(tmp_path_factory):
+    """Tolerance-class streaming: which layouts and fusions a chunk's products take depends on its shape -- 16 streams x 2 frames run the 8-row
+    activation tiles, two column tiles per wave, the conv tail and the folded final norm; 3 streams (rows not a multiple of 8) and chunks of 1, 3, 4
+    or 5 frames fall back to rows / the separate conv kernel / other row-tile heights.  Every one of them carries the same values through the same
+    k-slices: streams 0-2 of a 16-stream session and of a 3-stream session fed the same audio in the same ragged chunk schedule give the same
+    encoder bits and tokens, chunk by chunk."""
+    cfg = dataclasses.replace(pk.make_110m_config(), num_layers=3, gemm_bf16=True, name="110m-3L-stream-bf16-shapes")
+    W, om, gm = G.make_pair(tmp_path_factory.mktemp("sb16s"), cfg, seed=43)
+    sched = [2560, 1280, 5120, 3840, 2560, 2560, 6400, 1280, 1280, 3840, 5120, 2560] * 3            # 160 / 80 / 320 / 240 / 400 ms pushes
+    pcm = synth.synth_pcm(16, sum(sched), seed=91)
+    a, b = capi.Stream(gm, 16, 70, 1), capi.Stream(gm, 3, 70, 1)
+    at, n_enc, frames, toks = 0, 0, set(), 0
+    for i, n in enumerate(sched):
+        seg = pcm[:, at:at + n]; at += n
+        ma, mb = a.mel(seg), b.mel(seg[:3])
+        G.assert_bits_equal(ma[:3], mb, f"log-mel, push {i}")
+        if ma.shape[1] == 0:
+            continue
+        ea, eb = a.encode(ma), b.encode(mb)
+        assert ea.shape[1] == eb.shape[1]
+        if ea.shape[1] == 0:
+            continue
+        frames.add(ea.shape[1]); n_enc += ea.shape[1]
+        G.assert_bits_equal(ea[:3], eb, f"encoder rows of streams 0-2, push {i} ({ea.shape[1]} frames)")
+        ga, gb = a.decode(ea), b.decode(eb)
+        for s in range(3):
+            assert ga["ids"][s, : ga["lens"][s]].tolist() == gb["ids"][s, : gb["lens"][s]].tolist(), f"tokens of stream {s}, push {i}"
+            toks += int(ga["lens"][s])
+    a.close(); b.close()
+    assert len(frames) >= 4 and n_enc > 60, f"chunk shapes seen: {sorted(frames)}"
+    print(f"bf16 streaming, 16 vs 3 sessions on the same audio: {n_enc} encoder frames in chunks of {sorted(frames)} frames bit-identical, {toks} tokens identical")
+
+
 STREAM_GOLD_BF16 = os.path.join(ROOT, "tests", "golden", "nemotron600m_stream_bf16_depth24_seed42.npz")
 
 
