@@ -425,8 +425,8 @@ void Model::klaunch_end(hipStream_t s) {
 void Model::run_gemm(const char *name, const GemmArgs &g, int epi, hipStream_t s, bool fp32_weight) {
     if (g.ln_g && !((cfg.gemm_bf16 && !fp32_weight) ? gemm_smallm_bf16_ln_applies(g, epi) : gemm_smallm_ln_applies(g, epi)))
         fail(PK_ERR_INVALID, "%s: a folded LayerNorm needs one of the small-M kernels (gemm_smallm_ln_applies / gemm_smallm_bf16_ln_applies)", name);
-    if (g.pre_g && !(cfg.gemm_bf16 && !fp32_weight && gemm_smallm_bf16_pre_applies(g, epi)))
-        fail(PK_ERR_INVALID, "%s: a norm in front of the folded LayerNorm needs the small-M bf16 kernel (gemm_smallm_bf16_pre_applies)", name);
+    if (g.pre_g && !((cfg.gemm_bf16 && !fp32_weight) ? gemm_smallm_bf16_pre_applies(g, epi) : gemm_smallm_pre_applies(g, epi)))
+        fail(PK_ERR_INVALID, "%s: a norm in front of the folded LayerNorm needs one of the small-M kernels (gemm_smallm_pre_applies / gemm_smallm_bf16_pre_applies)", name);
     if (cfg.gemm_bf16 && !fp32_weight) {
         if (g.K % 64) fail(PK_ERR_UNSUPPORTED, "gemm_bf16 needs K %% 64 == 0 (%s has K = %d)", name, g.K);
         if (g.out_bf16 && (g.remap_rows != 0 || (g.ldo & 3) != 0 || (g.N & 3) != 0 || g.sigma_cols != 0 || epi == EPI_RESID || epi == EPI_GLU))

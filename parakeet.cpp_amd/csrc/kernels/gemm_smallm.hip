@@ -303,6 +303,38 @@ __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g, DwTail 
 #pragma unroll
             for (int j = 0; j < PER_LANE; ++j) v[rr][j] = xr[lane + 64 * j];
         }
+        // A norm in front of the folded one (GemmArgs::pre_g: a block's final_norm_ riding on the next block's first product; streaming): the wave
+        // normalises its rows exactly as layernorm_kernel would have (same sums, same fma) -- bit for bit the separate launch -- keeps them in
+        // registers, and the workgroups of the first column tile write them out: the residual stream of the block that starts here.
+        if (g.pre_g) {                                              // (kernel argument: uniform)
+#pragma unroll
+            for (int j = 0; j < PER_LANE; ++j) {
+                gv[j] = g.pre_g[lane + 64 * j];
+                bv[j] = g.pre_b[lane + 64 * j];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float p = 0.0f;
+#pragma unroll
+                for (int j = 0; j < PER_LANE; ++j) p = p + v[rr][j];
+                const float mean = wave_sum64(p) / (float)K;
+                float q = 0.0f;
+#pragma unroll
+                for (int j = 0; j < PER_LANE; ++j) {
+                    const float c = v[rr][j] - mean;
+                    q = q + c * c;
+                }
+                const float var = wave_sum64(q) / (float)K;
+                const float rstd = 1.0f / __builtin_sqrtf(var + g.ln_eps);
+                const int row = m0 + 4 * wave + rr;
+                const bool put = blockIdx.x == 0 && g.pre_out && row < g.M;
+#pragma unroll
+                for (int j = 0; j < PER_LANE; ++j) {
+                    v[rr][j] = __builtin_fmaf((v[rr][j] - mean) * rstd, gv[j], bv[j]);
+                    if (put) g.pre_out[(int64_t)row * g.pre_ldo + lane + 64 * j] = v[rr][j];
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < PER_LANE; ++j) {
             gv[j] = g.ln_g[lane + 64 * j];
@@ -418,6 +450,10 @@ __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g, DwTail 
     }
 }
 
+bool gemm_smallm_pre_applies(const GemmArgs &a, int epi) {
+    if (!a.pre_g || !a.pre_b || (a.pre_out && (a.pre_out == a.A || a.pre_ldo < a.K))) return false;
+    return gemm_smallm_ln_applies(a, epi);
+}
 bool gemm_smallm_dw_applies(const GemmArgs &a, int epi, int c, int kc) {
     if (epi != EPI_GLU || kc != 9 || !(c == 1 || c == 2 || c == 4) || a.M % c != 0 || a.remap_rows != 0 || a.sigma_cols != 0) return false;
     return gemm_smallm_ln_applies(a, epi);

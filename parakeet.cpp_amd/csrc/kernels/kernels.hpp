@@ -138,7 +138,7 @@ struct GemmArgs {
     // ln_b[K], ln_eps) of the product's input is applied while the rows are staged -- out = epi(LN(A) W^T + bias) (bf16 mode: bf16(LN(A)) W16^T).
     // Callers check gemm_smallm_bf16_ln_applies() / gemm_smallm_ln_applies().
     const float *ln_g = nullptr, *ln_b = nullptr; float ln_eps = 0.0f;
-    // small-M bf16 kernel with ln_g set only: ANOTHER LayerNorm in front of the folded one -- out = epi(bf16(LN(LN(A; pre_g, pre_b); ln_g, ln_b)) W16^T + bias):
+    // small-M kernels with ln_g set (gemm_smallm_bf16.hip; exact mode: gemm_smallm_ln_kernel, bit for bit the separate launch): ANOTHER LayerNorm in front of the folded one -- out = epi(bf16(LN(LN(A; pre_g, pre_b); ln_g, ln_b)) W16^T + bias):
     // a block's final_norm_ folded into the first product of the next block (streaming, tolerance-class mode: one launch less per block).  pre_out
     // (optional, fp32 [M][pre_ldo], NOT the buffer A lives in: other workgroups still read A) receives LN(A; pre_g, pre_b) -- the residual stream
     // of the block that starts here -- written by the workgroups of the first column tile.
@@ -162,6 +162,7 @@ bool gemm_bf16_blocked_handoff(int M, int N, int K, int epi, bool producer);
 // fp32 small-M chain kernel with GemmArgs::ln_g set (kernels/gemm_smallm.hip: gemm_smallm_ln_kernel): A = the un-normalised rows, K = 512 / 1024 = the
 // row length, tiled weights W_sig, epi none / relu / silu / glu -- bit for bit LayerNorm + product.  Callers check this first.
 bool gemm_smallm_ln_applies(const GemmArgs &a, int epi);
+bool gemm_smallm_pre_applies(const GemmArgs &a, int epi);                      // ... with GemmArgs::pre_g (a second norm in front, bit for bit the separate LayerNorm launch)
 bool gemm_smallm_dw_applies(const GemmArgs &a, int epi, int c, int kc);        // ... with GemmArgs::dw_tail (GLU, conv kernel 9, c = 1 / 2 / 4 frames per stream)
 // same contract with bf16 operands and fp32 accumulation: a.W points to bf16 weights [N][K] (rounded once at upload), A is
 // rounded to bf16 while it is staged; K % 64 == 0.  Not bit-identical to the fp32 chain (kernels/gemm_bf16.hpp).

@@ -40,8 +40,9 @@ static bool stream_act_tiles() {
     return true;
 #endif
 }
-// Tolerance-class mode: a block's final_norm_ folded into the first product of the NEXT block (GemmArgs::pre_g: that product normalises twice and
-// its first column tile writes the normalised rows -- the next block's residual stream -- into the other of two buffers): one launch less per block.
+// A block's final_norm_ folded into the first product of the NEXT block (GemmArgs::pre_g: that product normalises twice and
+// its first column tile writes the normalised rows -- the next block's residual stream -- into the other of two buffers): one launch less per block
+// (both modes; the exact mode's kernel normalises exactly as the separate launch does: bit-identical).
 // EXPERIMENTAL builds: PK_STREAM_FUSE_FIN=0 keeps the separate LayerNorm launch.
 static bool stream_fuse_final() {
 #ifdef PK_EXPERIMENTAL
@@ -236,13 +237,14 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         ln_folds = a16 ? gemm_smallm_bf16_ln_applies(pg, EPI_SILU) : (sg && gemm_smallm_ln_applies(pg, EPI_SILU));
     }
     bool fin_folds = false;                                                                               // ... and the block's final norm with it
-    if (a16 && ln_folds && stream_fuse_final() && cfg.num_layers > 1) {
+    if (ln_folds && stream_fuse_final() && cfg.num_layers > 1) {
         x_alt_.reserve((size_t)rows * d * 4);
         x_other = x_alt_.as<float>();
         GemmArgs pg{x, d, m_.layers[1].ffn1_w1, d, nullptr, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
-        pg.ln_g = m_.layers[1].ffn1_ng; pg.ln_b = m_.layers[1].ffn1_nb; pg.out_bf16 = 1;
+        pg.ln_g = m_.layers[1].ffn1_ng; pg.ln_b = m_.layers[1].ffn1_nb; pg.out_bf16 = a16; pg.ln_eps = 1e-5f;
+        if (sg) pg.W_sig = (*sig_)[1].ffn1_w1;
         pg.pre_g = m_.layers[0].fin_g; pg.pre_b = m_.layers[0].fin_b; pg.pre_out = x_other; pg.pre_ldo = d;
-        fin_folds = gemm_smallm_bf16_pre_applies(pg, EPI_SILU);
+        fin_folds = a16 ? gemm_smallm_bf16_pre_applies(pg, EPI_SILU) : (sg && gemm_smallm_pre_applies(pg, EPI_SILU));
     }
     auto ffn = [&](const LayerW &L, const Model::SigW &Ls, bool second, bool norm_done) {                // FeedForward (src/encoder.cpp:36-46)
         GemmArgs g1{n, d, second ? L.ffn2_w1 : L.ffn1_w1, d, second ? L.ffn2_b1 : L.ffn1_b1, hb, f, nullptr, 0, 1.0f, (int)rows, f, d};
