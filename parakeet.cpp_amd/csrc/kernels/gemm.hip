@@ -304,7 +304,10 @@ static int bf16_glds_persist() {
 }
 // Instantiation flags of the direct-to-LDS bf16 kernels (gemm_bf16_glds.hpp / gemm_bf16_ring.hpp), EXPERIMENTAL builds: PK_BF16_FLAGS bit 1 = STAGGER,
 // bit 2 = ASMFRAG (hand-counted fragment reads), bit 4 = row-block walk of the persistent form (XCD x owns a block of tile rows:
-// fetch bytes per fc1 launch 176 -> 150 MB, time +1.5 %: off -- profiles/r05_bf16_rowblock_ab.txt).
+// fetch bytes per fc1 launch 176 -> 150 MB, time +1.5 %: off -- profiles/r05_bf16_rowblock_ab.txt), bit 8 = residual products accumulate ONTO the residual (GemmArgs::resid_init:
+// the accumulators start from resid / alpha + bias, read beside the first K tiles, instead of 49 MB of residual reads next to the 49 MB of stores at
+// the tail).  Measured (profiles/r05_bf16_resid_init_ab.txt): fc2 123 -> 144 us, out_proj / pw2 24.5 -> 34.5 us -- in the MFMA's C layout the residual
+// arrives as 96 four-byte loads per wave in front of the first MFMA, dearer than the coalesced float4 reads of the LDS epilogue: off.
 // Production: 2 (ASMFRAG: bit-identical, -0.7 % per tdt-600m step, profiles/r05_bf16_asmfrag_ab.txt).  With PK_BF16_PERSIST=4 the low two bits select
 // the ring kernel's form instead: 0 plain, 1 STAGGER, 2 PHASED, 3 PHASED + s_setprio -- every one of them measured level with the persistent
 // form on fc1 (117 us) and behind it on the step (profiles/r05_bf16_ring_ab.txt, r05_bf16_phased_ab.txt): three different K-loop schedules, one
@@ -375,6 +378,15 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
                     }
                 }
 #endif
+                if constexpr (EPI == EPI_RESID) {
+                    if ((bf16_glds_flags() & 8) != 0 && a.alpha != 0.0f && a.remap_rows == 0) {                      // (bit 8: measured 16-42 % slower per product: off)
+                        GemmArgs b = a;
+                        b.resid_init = 1;
+                        if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(b, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
+                        else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(b, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
+                        return;
+                    }
+                }
                 if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
                 else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
                 return;

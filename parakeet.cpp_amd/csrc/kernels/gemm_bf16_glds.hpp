@@ -356,12 +356,34 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
     if (nk > 1) dma(src, 1, 1);
     for (;;) {
         GL_STAMP(tr_tile, 0);
+        bool resid_in_acc = false;
+        if constexpr (EPI == EPI_RESID && !DIRECT && !PERSIST) resid_in_acc = g.resid_init != 0;
+        if (resid_in_acc) {
+            // out = resid + alpha (A W^T + bias) accumulated ONTO the residual (GemmArgs::resid_init, tolerance-class mode): the accumulators start
+            // from resid / alpha + bias -- requested here, next to the first K tiles' DMA, instead of 49 MB of residual reads competing with the
+            // 49 MB of output stores at the kernel's tail -- and the epilogue stores alpha * acc.  C layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+            const float inv_alpha = 1.0f / g.alpha;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WN + j * 32 + (lane & 31);
+                const bool col_ok = col < g.N;
+                const float bs = (g.bias && col_ok) ? g.bias[col] : 0.0f;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        acc[i][j][r] = (col_ok && row < g.M) ? __builtin_fmaf(g.resid[(int64_t)row * g.ldr + col], inv_alpha, bs) : 0.0f;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        }
         // K tile 0 of this tile is in flight (or long landed) in buffer `cur`, K tile 1 in the other: wait for BOTH before the first
         // fragment read (the persistent path issued tile 0 an epilogue ago -- what is waited for here is tile 1's request, one DMA latency,
         // once per tile instead of two on a cold chip)
@@ -427,6 +449,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
             __syncthreads();               // every wave has read its last band out of the epilogue's buffer
             if (nk > 1) dma(src, 1, cur ^ 1);
         } else {
+            if constexpr (EPI == EPI_RESID) {
+                if (resid_in_acc) {                                 // bias and residual are in the accumulators: scale, then the plain LDS epilogue
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * g.alpha;
+                    GemmArgs g2 = g;
+                    g2.bias = nullptr;
+                    gp_epilogue<WGM, WGN, TM, TN, EPI_NONE, BUF, true>(g2, acc, smem_f, m0, n0);
+                    break;
+                }
+            }
             gp_epilogue<WGM, WGN, TM, TN, EPI, BUF, true>(g, acc, smem_f, m0, n0);      // 2 buffers x BUF bf16 = BUF floats
             break;
         }

@@ -116,6 +116,11 @@ struct GemmArgs {
     // a_blocked: `A` is read that way (lda = its row length).  Set by the engine for fc1 -> fc2 when gemm_bf16_blocked_handoff() says both take
     // those kernels.
     int out_blocked = 0, a_blocked = 0;
+    // bf16 mode, direct-to-LDS kernels, EPI_RESID on one tile per workgroup: the product is accumulated ONTO the residual -- the accumulators start
+    // from resid / alpha + bias (loaded beside the first K tiles) and the epilogue stores alpha * acc: the residual's bytes leave HBM while the K
+    // loop runs instead of at the tail next to the output stores.  Same value in real arithmetic; rounded differently (tolerance-class mode only).
+    // EXPERIMENT of round 5, measured slower (gemm.hip: bf16_glds_flags bit 8): never set by the production library.
+    int resid_init = 0;
     // small-M bf16 kernel only (gemm_smallm_bf16.hip): the bf16 activation rows between two of its products (fc1 -> fc2 of a streaming chunk) in
     // OPERAND TILES of 8 rows: per (8 rows, 32 k) 512 bytes [lane32 = (row & 7) + 8 * (k / 8 & 3)][8 bf16], tiles ordered [rows / 8][K / 32] -- the
     // consumer's load instruction reads whole lines (512 B, or two runs of 512 B for 16 rows) instead of 8 / 16 row segments of 64 bytes.

@@ -88,7 +88,12 @@ def test_bf16_glds_gemm_against_float64(M, N, K, epi):
     else:
         want = acc
     err = np.abs(got - want)
-    assert np.all(err <= 2e-6 * mag + 1e-6), f"max err {err.max():.3e} (bound {float((2e-6 * mag + 1e-6).max()):.3e}) at {np.unravel_index(err.argmax(), err.shape)}"
+    bound = 2e-6 * mag + 1e-6
+    if epi == "resid":
+        # (covers the EXPERIMENTAL form that accumulates the product ONTO the residual, GemmArgs::resid_init: accumulators starting from resid / alpha +
+        #  bias round a sum of that size once per MFMA step -- worst case half an ulp of |resid| / alpha per step, times alpha at the end)
+        bound = bound + 6e-8 * (K / 16) * np.abs(resid)
+    assert np.all(err <= bound), f"max err {err.max():.3e} (bound there {float(bound.flat[err.argmax()]):.3e}) at {np.unravel_index(err.argmax(), err.shape)}"
 
 
 @pytest.mark.parametrize("M,N,K,epi,a16", [(32, 4096, 1024, "silu", True), (32, 1024, 4096, "resid", True), (32, 3072, 1024, "none", True),
