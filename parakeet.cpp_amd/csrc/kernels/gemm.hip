@@ -378,6 +378,7 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
                     }
                 }
 #endif
+#ifdef PK_EXPERIMENTAL
                 if constexpr (EPI == EPI_RESID) {
                     if ((bf16_glds_flags() & 8) != 0 && a.alpha != 0.0f && a.remap_rows == 0) {                      // (bit 8: measured 16-42 % slower per product: off)
                         GemmArgs b = a;
@@ -387,6 +388,7 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
                         return;
                     }
                 }
+#endif
                 if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
                 else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
                 return;

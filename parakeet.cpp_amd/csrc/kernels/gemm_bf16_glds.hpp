@@ -356,8 +356,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
     if (nk > 1) dma(src, 1, 1);
     for (;;) {
         GL_STAMP(tr_tile, 0);
-        bool resid_in_acc = false;
+        bool resid_in_acc = false;                                  // (EXPERIMENTAL builds only: measured slower, gemm.hip bf16_glds_flags bit 8)
+#ifdef PK_EXPERIMENTAL
         if constexpr (EPI == EPI_RESID && !DIRECT && !PERSIST) resid_in_acc = g.resid_init != 0;
+#endif
         if (resid_in_acc) {
             // out = resid + alpha (A W^T + bias) accumulated ONTO the residual (GemmArgs::resid_init, tolerance-class mode): the accumulators start
             // from resid / alpha + bias -- requested here, next to the first K tiles' DMA, instead of 49 MB of residual reads competing with the
