@@ -243,7 +243,9 @@ __global__ __launch_bounds__(64) void gemm_smallm_rt2_kernel(GemmArgs g) {
 // normalisation.  Saves the LayerNorm launch (~5 us of a 32-row streaming chunk's ~360) for ~1 us in front of the chain.
 // DW (EPI_GLU; kernels.hpp DwTail): the streaming conv module's depthwise conv + BatchNorm + SiLU run by the lane that finishes (stream, channel) --
 // the same operations in the same order as stream_dwconv_kernel (kernels/stream.hip), one launch less per block.
-template <int EPI, int PER_LANE /* K / 64 */, bool DW = false>
+// PRE (GemmArgs::pre_g): another LayerNorm in front of the folded one.  Both are template parameters: as run-time branches they cost every
+// instantiation 64 VGPRs (K = 1024: 240 -> 304, one workgroup per CU instead of two -- 64 sessions ran 14 % slower for it).
+template <int EPI, int PER_LANE /* K / 64 */, bool DW = false, bool PRE = false>
 __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g, DwTail dw = DwTail{}) {
     static_assert(!DW || EPI == EPI_GLU, "the conv tail finishes a GLU tile");
     constexpr int K = 64 * PER_LANE, PITCH = K + 4, KC = 64, NKC = PER_LANE, DEPTH = 8;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g, DwTail 
         // A norm in front of the folded one (GemmArgs::pre_g: a block's final_norm_ riding on the next block's first product; streaming): the wave
         // normalises its rows exactly as layernorm_kernel would have (same sums, same fma) -- bit for bit the separate launch -- keeps them in
         // registers, and the workgroups of the first column tile write them out: the residual stream of the block that starts here.
-        if (g.pre_g) {                                              // (kernel argument: uniform)
+        if constexpr (PRE) {
 #pragma unroll
             for (int j = 0; j < PER_LANE; ++j) {
                 gv[j] = g.pre_g[lane + 64 * j];
@@ -450,13 +452,20 @@ __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g, DwTail 
     }
 }
 
+// The two fusions lengthen the chain kernel (a second normalisation in front, the conv behind) and cost it registers (K = 1024: one workgroup per
+// CU instead of two): they pay while the launch is a single round of workgroups -- 16 sessions x 2 frames: -1 % per fusion -- and lose beyond
+// (64 sessions: +3 %, 128: +5 %; profiles/r05_stream_fusions_by_streams.txt).
+static bool smallm_ln_one_round(const GemmArgs &a, int epi) {
+    const int tiles = a.N / 16;
+    return (int64_t)(epi == EPI_GLU ? tiles : (tiles + 1) / 2) * ((a.M + 15) / 16) <= 256;
+}
 bool gemm_smallm_pre_applies(const GemmArgs &a, int epi) {
-    if (!a.pre_g || !a.pre_b || (a.pre_out && (a.pre_out == a.A || a.pre_ldo < a.K))) return false;
-    return gemm_smallm_ln_applies(a, epi);
+    if (epi != EPI_SILU || !a.pre_g || !a.pre_b || (a.pre_out && (a.pre_out == a.A || a.pre_ldo < a.K))) return false;
+    return gemm_smallm_ln_applies(a, epi) && smallm_ln_one_round(a, epi);
 }
 bool gemm_smallm_dw_applies(const GemmArgs &a, int epi, int c, int kc) {
     if (epi != EPI_GLU || kc != 9 || !(c == 1 || c == 2 || c == 4) || a.M % c != 0 || a.remap_rows != 0 || a.sigma_cols != 0) return false;
-    return gemm_smallm_ln_applies(a, epi);
+    return gemm_smallm_ln_applies(a, epi) && smallm_ln_one_round(a, epi);
 }
 bool gemm_smallm_ln_applies(const GemmArgs &a, int epi) {
     if (!a.ln_g || !a.ln_b || !a.W_sig || a.a_bf16 || a.a_sigma) return false;
@@ -470,6 +479,19 @@ static void launch_smallm_ln(const GemmArgs &a, hipStream_t s) {
     const dim3 grid(EPI == EPI_GLU ? tiles : (tiles + 1) / 2, (a.M + 15) / 16), block(256);
     const size_t lds = (size_t)16 * (a.K + 4) * sizeof(float);
     static DynLdsSlots slots8, slots16;
+    if constexpr (EPI == EPI_SILU) {
+        if (a.pre_g) {
+            static DynLdsSlots pslots8, pslots16;
+            if (a.K == 512) {
+                ensure_dyn_lds(pslots8, reinterpret_cast<const void *>(&gemm_smallm_ln_kernel<EPI, 8, false, true>), lds);
+                hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 8, false, true>), grid, block, lds, s, a, DwTail{});
+            } else {
+                ensure_dyn_lds(pslots16, reinterpret_cast<const void *>(&gemm_smallm_ln_kernel<EPI, 16, false, true>), lds);
+                hipLaunchKernelGGL((gemm_smallm_ln_kernel<EPI, 16, false, true>), grid, block, lds, s, a, DwTail{});
+            }
+            return;
+        }
+    }
     if constexpr (EPI == EPI_GLU) {
         if (a.dw_tail) {
             static DynLdsSlots dslots8, dslots16;
