@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g, DwTail 
         }
         // A norm in front of the folded one (GemmArgs::pre_g: a block's final_norm_ riding on the next block's first product; streaming): the wave
         // normalises its rows exactly as layernorm_kernel would have (same sums, same fma) -- bit for bit the separate launch -- keeps them in
-        // registers, and the workgroups of the first column tile write them out: the residual stream of the block that starts here.
+        // registers, and the first K / 64 column-tile workgroups write them out, one 64-element chunk of every row each: the residual stream of the block that starts here.
         if constexpr (PRE) {
 #pragma unroll
             for (int j = 0; j < PER_LANE; ++j) {
@@ -329,11 +329,11 @@ __global__ __launch_bounds__(256) void gemm_smallm_ln_kernel(GemmArgs g, DwTail 
                 const float var = wave_sum64(q) / (float)K;
                 const float rstd = 1.0f / __builtin_sqrtf(var + g.ln_eps);
                 const int row = m0 + 4 * wave + rr;
-                const bool put = blockIdx.x == 0 && g.pre_out && row < g.M;
+                const bool put = g.pre_out && row < g.M;
 #pragma unroll
                 for (int j = 0; j < PER_LANE; ++j) {
                     v[rr][j] = __builtin_fmaf((v[rr][j] - mean) * rstd, gv[j], bv[j]);
-                    if (put) g.pre_out[(int64_t)row * g.pre_ldo + lane + 64 * j] = v[rr][j];
+                    if (put && (int)blockIdx.x == j) g.pre_out[(int64_t)row * g.pre_ldo + lane + 64 * j] = v[rr][j];   // (column tile j writes chunk j: gridDim.x >= PER_LANE)
                 }
             }
         }
@@ -460,7 +460,7 @@ static bool smallm_ln_one_round(const GemmArgs &a, int epi) {
     return (int64_t)(epi == EPI_GLU ? tiles : (tiles + 1) / 2) * ((a.M + 15) / 16) <= 256;
 }
 bool gemm_smallm_pre_applies(const GemmArgs &a, int epi) {
-    if (epi != EPI_SILU || !a.pre_g || !a.pre_b || (a.pre_out && (a.pre_out == a.A || a.pre_ldo < a.K))) return false;
+    if (epi != EPI_SILU || !a.pre_g || !a.pre_b || (a.pre_out && (a.pre_out == a.A || a.pre_ldo < a.K)) || a.N < 32 * 16) return false;   // (>= 16 column-tile pairs share the write-out)
     return gemm_smallm_ln_applies(a, epi) && smallm_ln_one_round(a, epi);
 }
 bool gemm_smallm_dw_applies(const GemmArgs &a, int epi, int c, int kc) {

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
             };
             if constexpr (PRE) {
                 // A norm in front of the folded one (a block's final_norm_ in front of the next block's first: GemmArgs::pre_g): the rows are
-                // normalised in place (fp32) -- and written out by the workgroups of the first column tile: they are the residual stream from here on
+                // normalised in place (fp32) -- and written out, one k-step of every slice by each of the first STEPS column tiles: they are the
+                // residual stream from here on
                 stage_gb(pg4, pb4);
                 row_stats();
 #pragma unroll
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
                         const float4 yhi = {fmaf((hi.x - m) * rs, gh.x, bh.x), fmaf((hi.y - m) * rs, gh.y, bh.y), fmaf((hi.z - m) * rs, gh.z, bh.z), fmaf((hi.w - m) * rs, gh.w, bh.w)};
                         af[t][s][0] = ylo; af[t][s][1] = yhi;
                         const int row = m0 + 16 * t + r;
-                        if (blockIdx.x == 0 && g.pre_out && r < rvalid && row < g.M) {
+                        if ((int)blockIdx.x == s && g.pre_out && r < rvalid && row < g.M) {   // (column tile s writes k-step s of every slice: gridDim.x >= STEPS)
                             float *dst = g.pre_out + (int64_t)row * g.pre_ldo + k0 + 32 * s + 8 * kq;
                             *reinterpret_cast<float4 *>(dst) = ylo;
                             *reinterpret_cast<float4 *>(dst + 4) = yhi;
@@ -462,7 +463,7 @@ bool gemm_smallm_bf16_applies(const GemmArgs &a, int epi) {
     return epi >= EPI_NONE && epi <= EPI_GLU;
 }
 bool gemm_smallm_bf16_pre_applies(const GemmArgs &a, int epi) {
-    if (epi != EPI_SILU || !a.pre_g || !a.pre_b || a.K / 256 > kSbMaxWaves || a.K % 256 != 0) return false;
+    if (epi != EPI_SILU || !a.pre_g || !a.pre_b || a.K / 256 > kSbMaxWaves || a.K % 256 != 0 || a.N < 256) return false;   // (>= 8 column tiles share the write-out)
     if (a.pre_out && (a.pre_out == a.A || a.pre_ldo < a.K || (a.pre_ldo % 4) != 0)) return false;
     return gemm_smallm_bf16_ln_applies(a, epi);
 }

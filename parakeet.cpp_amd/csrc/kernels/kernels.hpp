@@ -146,7 +146,7 @@ struct GemmArgs {
     // small-M kernels with ln_g set (gemm_smallm_bf16.hip; exact mode: gemm_smallm_ln_kernel, bit for bit the separate launch): ANOTHER LayerNorm in front of the folded one -- out = epi(bf16(LN(LN(A; pre_g, pre_b); ln_g, ln_b)) W16^T + bias):
     // a block's final_norm_ folded into the first product of the next block (streaming, tolerance-class mode: one launch less per block).  pre_out
     // (optional, fp32 [M][pre_ldo], NOT the buffer A lives in: other workgroups still read A) receives LN(A; pre_g, pre_b) -- the residual stream
-    // of the block that starts here -- written by the workgroups of the first column tile.
+    // of the block that starts here -- written by the first few column tiles, one k-step (chunk) of every row each.
     const float *pre_g = nullptr, *pre_b = nullptr; float *pre_out = nullptr; int64_t pre_ldo = 0;
     // small-M kernels with the LayerNorm folded in (exact mode) / small-M bf16 kernel, EPI_GLU only: HOST pointer to the depthwise-conv tail of
     // the epilogue (read during the launch call).  Callers check gemm_smallm_dw_applies() / gemm_smallm_bf16_dw_applies().
