@@ -97,14 +97,22 @@ void StreamBatch::reset() {
 }
 
 // ---- StreamingAudioPreprocessor::process_chunk --------------------------------------------------------------------------------
-int StreamBatch::mel(const float *pcm, int n, float *out, int cap_frames) {
+int StreamBatch::mel(const float *pcm, int n, float *out, int cap_frames) { return mel_impl(pcm, n, out, cap_frames, true); }
+
+int StreamBatch::mel_impl(const float *pcm, int n, float *out, int cap_frames, bool sync) {
     m_.require_gpu();
     if (n <= 0) fail(PK_ERR_INVALID, "n_samples");
     const int F = m_.cfg.mel_bins;
     const int total = (int)overlap_[0].size() + n;
-    std::vector<float> buf((size_t)S * total);
+    if ((size_t)S * total > pin_pcm_floats_) {                      // (no upload of an earlier call is in flight: every entry point ends synchronised)
+        if (pin_pcm_) { PK_HIP(hipHostFree(pin_pcm_)); pin_pcm_ = nullptr; pin_pcm_floats_ = 0; }
+        const size_t want = (size_t)S * total + (size_t)S * 1024;
+        PK_HIP(hipHostMalloc(reinterpret_cast<void **>(&pin_pcm_), want * 4, hipHostMallocDefault));
+        pin_pcm_floats_ = want;
+    }
+    float *const buf = pin_pcm_;
     for (int s = 0; s < S; ++s) {                                   // 1. pre-emphasis with the carried sample, 2. prepend the overlap (:204-214)
-        float *b = buf.data() + (size_t)s * total;
+        float *b = buf + (size_t)s * total;
         memcpy(b, overlap_[s].data(), overlap_[s].size() * 4);
         float last = preemph_last_[s];
         const float *src = pcm + (size_t)s * n;
@@ -118,20 +126,20 @@ int StreamBatch::mel(const float *pcm, int n, float *out, int cap_frames) {
     }
     const int n_frames = total < 400 ? 0 : (total - 400) / 160 + 1;
     if (n_frames <= 0) {                                            // :216-228 buffer everything
-        for (int s = 0; s < S; ++s) overlap_[s].assign(buf.begin() + (size_t)s * total, buf.begin() + (size_t)(s + 1) * total);
+        for (int s = 0; s < S; ++s) overlap_[s].assign(buf + (size_t)s * total, buf + (size_t)(s + 1) * total);
         return 0;
     }
     if (out && n_frames > cap_frames) fail(PK_ERR_INVALID, "mel output holds %d frames, chunk produces %d", cap_frames, n_frames);
     const int consumed = (n_frames - 1) * 160 + 400;               // :230-231
-    for (int s = 0; s < S; ++s) overlap_[s].assign(buf.begin() + (size_t)s * total + consumed, buf.begin() + (size_t)(s + 1) * total);
+    for (int s = 0; s < S; ++s) overlap_[s].assign(buf + (size_t)s * total + consumed, buf + (size_t)(s + 1) * total);
     pre_.reserve((size_t)S * consumed * 4);
     mel_dev_.reserve((size_t)S * n_frames * F * 4);
     hipStream_t st = m_.stream;
-    PK_HIP(hipMemcpy2DAsync(pre_.p, (size_t)consumed * 4, buf.data(), (size_t)total * 4, (size_t)consumed * 4, S, hipMemcpyHostToDevice, st));
+    PK_HIP(hipMemcpy2DAsync(pre_.p, (size_t)consumed * 4, buf, (size_t)total * 4, (size_t)consumed * 4, S, hipMemcpyHostToDevice, st));
     launch_mel_stream(pre_.as<float>(), S, consumed, n_frames, m_.mel, mel_dev_.as<float>(), st);
     PK_CHECK_LAUNCH();
     if (out) PK_HIP(hipMemcpyAsync(out, mel_dev_.p, (size_t)S * n_frames * F * 4, hipMemcpyDeviceToHost, st));
-    PK_HIP(hipStreamSynchronize(st));                               // `buf` is pageable host memory about to go out of scope
+    if (sync || out) PK_HIP(hipStreamSynchronize(st));              // (a push synchronises once, when it fetches the chunk's tokens)
     return n_frames;
 }
 
@@ -363,16 +371,37 @@ void StreamBatch::decode_device(const float *d_enc, int c, int max_tokens) {
     m_.run_tdt(wd_, d_enc, S, c, max_tokens, m_.stream, /*keep_state=*/true);
 }
 
+StreamBatch::~StreamBatch() {
+    if (pin_tok_) (void)hipHostFree(pin_tok_);
+    if (pin_pcm_) (void)hipHostFree(pin_pcm_);
+}
+void *StreamBatch::pinned_tokens(size_t bytes) {
+    if (bytes > pin_tok_bytes_) {
+        if (pin_tok_) { PK_HIP(hipHostFree(pin_tok_)); pin_tok_ = nullptr; pin_tok_bytes_ = 0; }
+        PK_HIP(hipHostMalloc(&pin_tok_, bytes, hipHostMallocDefault));
+        pin_tok_bytes_ = bytes;
+    }
+    return pin_tok_;
+}
+
+// `pin`: pinned staging of S * (1 + 4 * max_tokens) words (StreamBatch::pinned_tokens)
 static void fetch_tokens(Model &m, Workspace &wd, int S, int max_tokens, int frame_offset, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end,
-                         float *conf) {
+                         float *conf, void *pin) {
     hipStream_t st = m.stream;
-    const size_t nb = (size_t)S * max_tokens * 4;
-    PK_HIP(hipMemcpyAsync(lens, wd.lens.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
-    PK_HIP(hipMemcpyAsync(ids, wd.ids.p, nb, hipMemcpyDeviceToHost, st));
-    if (start) PK_HIP(hipMemcpyAsync(start, wd.start.p, nb, hipMemcpyDeviceToHost, st));
-    if (end) PK_HIP(hipMemcpyAsync(end, wd.end.p, nb, hipMemcpyDeviceToHost, st));
-    if (conf) PK_HIP(hipMemcpyAsync(conf, wd.conf.p, nb, hipMemcpyDeviceToHost, st));
+    const size_t nt = (size_t)S * max_tokens, nb = nt * 4;
+    int32_t *p_lens = static_cast<int32_t *>(pin), *p_ids = p_lens + S, *p_start = p_ids + nt, *p_end = p_start + nt;
+    float *p_conf = reinterpret_cast<float *>(p_end + nt);
+    PK_HIP(hipMemcpyAsync(p_lens, wd.lens.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+    PK_HIP(hipMemcpyAsync(p_ids, wd.ids.p, nb, hipMemcpyDeviceToHost, st));
+    if (start) PK_HIP(hipMemcpyAsync(p_start, wd.start.p, nb, hipMemcpyDeviceToHost, st));
+    if (end) PK_HIP(hipMemcpyAsync(p_end, wd.end.p, nb, hipMemcpyDeviceToHost, st));
+    if (conf) PK_HIP(hipMemcpyAsync(p_conf, wd.conf.p, nb, hipMemcpyDeviceToHost, st));
     PK_HIP(hipStreamSynchronize(st));
+    memcpy(lens, p_lens, (size_t)S * 4);
+    memcpy(ids, p_ids, nb);
+    if (start) memcpy(start, p_start, nb);
+    if (end) memcpy(end, p_end, nb);
+    if (conf) memcpy(conf, p_conf, nb);
     for (int s = 0; s < S; ++s) {
         if (lens[s] < 0) fail(PK_ERR_DECODE_CAP, "stream %d: TDT loop hit the safety cap", s);
         for (int i = 0; i < max_tokens; ++i) {
@@ -397,7 +426,7 @@ void StreamBatch::decode(const float *enc, int c, int max_tokens, int32_t *ids, 
     enc_in_.reserve((size_t)S * c * d * 4);
     PK_HIP(hipMemcpyAsync(enc_in_.p, enc, (size_t)S * c * d * 4, hipMemcpyHostToDevice, m_.stream));
     decode_device(enc_in_.as<float>(), c, max_tokens);
-    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf);
+    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf, pinned_tokens((size_t)S * (1 + 4 * (size_t)max_tokens) * 4));
     frame_offset_ += c;
 }
 
@@ -452,12 +481,12 @@ void StreamBatch::push(const float *pcm, int n_samples, int max_tokens, int32_t 
         fail(PK_ERR_UNSUPPORTED, "a push of %d samples exceeds the stream's decode workspace (%d encoder frames per chunk: at most %d samples)",
              n_samples, dec_cap_frames_, (dec_cap_frames_ - 2) * 8 * 160);
     for (int s = 0; s < S; ++s) lens[s] = 0;
-    const int n_frames = mel(pcm, n_samples, nullptr, 0);
+    const int n_frames = mel_impl(pcm, n_samples, nullptr, 0, /*sync=*/false);
     if (n_frames == 0) return;
     const int c = encode_device(mel_dev_.as<float>(), n_frames);
     if (c == 0) { PK_HIP(hipStreamSynchronize(m_.stream)); return; }
     decode_device(ws_.x.as<float>(), c, max_tokens);
-    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf);
+    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf, pinned_tokens((size_t)S * (1 + 4 * (size_t)max_tokens) * 4));
     frame_offset_ += c;
 }
 

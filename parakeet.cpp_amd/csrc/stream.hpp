@@ -11,6 +11,9 @@ namespace pk {
 class StreamBatch {
   public:
     StreamBatch(Model &m, int n_streams, int att_left, int att_right);
+    ~StreamBatch();
+    StreamBatch(const StreamBatch &) = delete;
+    StreamBatch &operator=(const StreamBatch &) = delete;
     void reset();
     // stage entry points (host buffers); each returns the number of frames it produced per stream (0: buffered / cached)
     int mel(const float *pcm, int n_samples, float *out /*[S][n_frames][F]*/, int cap_frames);
@@ -44,6 +47,16 @@ class StreamBatch {
     Workspace wd_;              // decode workspace: h / c / token persist across chunks (never re-allocated)
     int dec_cap_frames_ = 0;
     DevBuf pre_, mel_dev_, mel_all_, enc_in_, force_, score_;
+    // pinned host staging of a chunk's results: the five device-to-host copies of fetch_tokens then queue back to back behind the decode and cost ONE
+    // host round trip; into the caller's pageable arrays every one of them is a blocking copy of its own (~20 us each: 5 % of a 2 ms chunk)
+    void *pin_tok_ = nullptr;
+    size_t pin_tok_bytes_ = 0;
+    void *pinned_tokens(size_t bytes);
+    // ... and of a chunk's pre-emphasised samples on their way up: the upload is asynchronous, and a push goes on to enqueue the encoder without
+    // waiting for it (the pageable buffer it replaces forced a synchronisation in front of the encoder's launches)
+    float *pin_pcm_ = nullptr;
+    size_t pin_pcm_floats_ = 0;
+    int mel_impl(const float *pcm, int n_samples, float *out, int cap_frames, bool sync);
     DevBuf x_alt_;              // second residual-stream buffer: a block's final norm folded into the next block's first product writes it (stream.cpp)
     std::map<int, std::unique_ptr<DevBuf>> pos_tables_;   // Tp -> pos_proj of every layer [L][2Tp-1][d], natural columns
     int encode_device(const float *d_mel, int n_frames);                    // -> ws_.x [S*c][d], returns c
