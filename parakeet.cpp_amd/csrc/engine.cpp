@@ -1093,6 +1093,7 @@ void Model::run_tdt(Workspace &w, const float *d_enc, int B, int T, int max_toke
 // The greedy loop over w.ep = enc_proj of B utterances of T frames (rows b*T + t).  B may span several batches of the pipelined path
 // (capi.cpp: decode groups): the utterances are independent, a lock-step batch of 2B costs the same number of launches as one of B.
 void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t s, bool keep_state) {
+    w.poll_hit = false;
     const int Hp = cfg.pred_hidden, J = cfg.joint_hidden, V = cfg.vocab_size, D = cfg.rnnt_head ? 0 : cfg.num_durations;
     const int L = cfg.num_lstm_layers;
     if (V <= 0) fail(PK_ERR_UNSUPPORTED, "this model has no prediction net / joint (encoder-only configuration)");
@@ -1257,18 +1258,20 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         }
         for (int step = 0; step < st.max_steps; step += chunk) {
             PK_HIP(hipGraphLaunch(w.dec_graph, s));
+            if (w.before_poll) w.before_poll(s);
             PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));
             PK_HIP(hipStreamSynchronize(s));
-            if (*h_done >= B) break;
+            if (*h_done >= B) { w.poll_hit = true; break; }
         }
         return;
     }
     for (int step = 0; step < st.max_steps; ++step) {
         enqueue_step();
         if ((step + 1) % chunk == 0) {                                 // poll "all finished" once per chunk of steps
+            if (w.before_poll) w.before_poll(s);
             PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));
             PK_HIP(hipStreamSynchronize(s));
-            if (*h_done >= B) break;
+            if (*h_done >= B) { w.poll_hit = true; break; }
         }
     }
 }

@@ -78,6 +78,11 @@ struct Workspace {
     // Ragged runs: `ragged` set, rag / rv describe the batch; B = its clip count, T = max_tokens / T = the CAPACITY the output arrays are pitched
     // for (fixed at size_ragged), rows = packed encoder rows.  Uniform runs: rows = B * T.
     bool ragged = false;
+    // run_tdt's host poll ("all utterances finished"): called on the loop's stream right BEFORE the poll's copy is enqueued -- what it enqueues (a
+    // streaming chunk's result copies into pinned memory) rides on the poll's synchronisation; poll_hit: the loop ended on such a poll (nothing was
+    // enqueued after the hook's copies)
+    std::function<void(hipStream_t)> before_poll;
+    bool poll_hit = false;
     RagBatch rag;
     RagDev rv;
     DevBuf ragdev;                                // device copy of rag.image (+ the decode tables of a decode group)

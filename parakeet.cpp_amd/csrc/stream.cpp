@@ -384,10 +384,9 @@ void *StreamBatch::pinned_tokens(size_t bytes) {
     return pin_tok_;
 }
 
-// `pin`: pinned staging of S * (1 + 4 * max_tokens) words (StreamBatch::pinned_tokens)
-static void fetch_tokens(Model &m, Workspace &wd, int S, int max_tokens, int frame_offset, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end,
-                         float *conf, void *pin) {
-    hipStream_t st = m.stream;
+// `pin`: pinned staging of S * (1 + 4 * max_tokens) words (StreamBatch::pinned_tokens).  The copies are enqueued by the decode loop's poll hook
+// (Workspace::before_poll: they ride on the poll's synchronisation -- one host round trip per chunk) or, when the loop did not end on a poll, here.
+static void enqueue_token_copies(Workspace &wd, int S, int max_tokens, bool start, bool end, bool conf, void *pin, hipStream_t st) {
     const size_t nt = (size_t)S * max_tokens, nb = nt * 4;
     int32_t *p_lens = static_cast<int32_t *>(pin), *p_ids = p_lens + S, *p_start = p_ids + nt, *p_end = p_start + nt;
     float *p_conf = reinterpret_cast<float *>(p_end + nt);
@@ -396,7 +395,17 @@ static void fetch_tokens(Model &m, Workspace &wd, int S, int max_tokens, int fra
     if (start) PK_HIP(hipMemcpyAsync(p_start, wd.start.p, nb, hipMemcpyDeviceToHost, st));
     if (end) PK_HIP(hipMemcpyAsync(p_end, wd.end.p, nb, hipMemcpyDeviceToHost, st));
     if (conf) PK_HIP(hipMemcpyAsync(p_conf, wd.conf.p, nb, hipMemcpyDeviceToHost, st));
-    PK_HIP(hipStreamSynchronize(st));
+}
+static void fetch_tokens(Model &m, Workspace &wd, int S, int max_tokens, int frame_offset, int32_t *ids, int32_t *lens, int32_t *start, int32_t *end,
+                         float *conf, void *pin) {
+    hipStream_t st = m.stream;
+    const size_t nt = (size_t)S * max_tokens, nb = nt * 4;
+    int32_t *p_lens = static_cast<int32_t *>(pin), *p_ids = p_lens + S, *p_start = p_ids + nt, *p_end = p_start + nt;
+    float *p_conf = reinterpret_cast<float *>(p_end + nt);
+    if (!wd.poll_hit) {                                             // (the results are not on the host yet)
+        enqueue_token_copies(wd, S, max_tokens, start != nullptr, end != nullptr, conf != nullptr, pin, st);
+        PK_HIP(hipStreamSynchronize(st));
+    }
     memcpy(lens, p_lens, (size_t)S * 4);
     memcpy(ids, p_ids, nb);
     if (start) memcpy(start, p_start, nb);
@@ -425,8 +434,14 @@ void StreamBatch::decode(const float *enc, int c, int max_tokens, int32_t *ids, 
     const int d = m_.cfg.hidden_size;
     enc_in_.reserve((size_t)S * c * d * 4);
     PK_HIP(hipMemcpyAsync(enc_in_.p, enc, (size_t)S * c * d * 4, hipMemcpyHostToDevice, m_.stream));
-    decode_device(enc_in_.as<float>(), c, max_tokens);
-    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf, pinned_tokens((size_t)S * (1 + 4 * (size_t)max_tokens) * 4));
+    void *pin = pinned_tokens((size_t)S * (1 + 4 * (size_t)max_tokens) * 4);
+    {
+        struct Hook { Workspace &w; ~Hook() { w.before_poll = nullptr; } } hook{wd_};
+        wd_.poll_hit = false;
+        wd_.before_poll = [&](hipStream_t st) { enqueue_token_copies(wd_, S, max_tokens, start != nullptr, end != nullptr, conf != nullptr, pin, st); };
+        decode_device(enc_in_.as<float>(), c, max_tokens);
+    }
+    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf, pin);
     frame_offset_ += c;
 }
 
@@ -485,8 +500,14 @@ void StreamBatch::push(const float *pcm, int n_samples, int max_tokens, int32_t 
     if (n_frames == 0) return;
     const int c = encode_device(mel_dev_.as<float>(), n_frames);
     if (c == 0) { PK_HIP(hipStreamSynchronize(m_.stream)); return; }
-    decode_device(ws_.x.as<float>(), c, max_tokens);
-    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf, pinned_tokens((size_t)S * (1 + 4 * (size_t)max_tokens) * 4));
+    void *pin = pinned_tokens((size_t)S * (1 + 4 * (size_t)max_tokens) * 4);
+    {
+        struct Hook { Workspace &w; ~Hook() { w.before_poll = nullptr; } } hook{wd_};
+        wd_.poll_hit = false;
+        wd_.before_poll = [&](hipStream_t st) { enqueue_token_copies(wd_, S, max_tokens, start != nullptr, end != nullptr, conf != nullptr, pin, st); };
+        decode_device(ws_.x.as<float>(), c, max_tokens);
+    }
+    fetch_tokens(m_, wd_, S, max_tokens, frame_offset_, ids, lens, start, end, conf, pin);
     frame_offset_ += c;
 }
 
