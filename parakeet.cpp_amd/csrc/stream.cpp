@@ -52,6 +52,17 @@ static bool stream_fuse_final() {
     return true;
 #endif
 }
+// The block chain of a steady-state chunk as a hipGraph (stream.hpp EncGraph): built, correct (the streaming fixtures pass on it) and SLOWER on this
+// runtime -- median 1.79 -> 1.82 ms, p95 1.81 -> 2.6 ms per 16-session chunk (profiles/r05_stream_graph_ab.txt): hipGraphLaunch of ~250 kernel nodes costs
+// more host time than the launches it replaces, the same finding as for the decode loop's graph in round 3.  EXPERIMENTAL builds: PK_STREAM_GRAPH=1.
+static bool stream_graph() {
+#ifdef PK_EXPERIMENTAL
+    static const bool on = [] { const char *e = getenv("PK_STREAM_GRAPH"); return e ? atoi(e) != 0 : false; }();
+    return on;
+#else
+    return false;
+#endif
+}
 static bool stream_fuse_ln() {
 #ifdef PK_EXPERIMENTAL
     static const bool on = [] { const char *e = getenv("PK_STREAM_FUSE_LN"); return e ? atoi(e) != 0 : true; }();
@@ -270,6 +281,29 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
         g2.a_bf16 = a16; g2.a_t8 = t8;
         m_.run_gemm("ffn_fc2_resid", g2, EPI_RESID, st);
     };
+    // ---- hipGraph of the block chain (stream.hpp: EncGraph) ----
+    bool steady = stream_graph() && !m_.prof && left_ > 0 && cfg.num_layers > 0;
+    const int parity = layers_[0]->cur;
+    for (const auto &Lp : layers_) steady = steady && Lp->n_kv == left_ && Lp->has_conv == 1 && Lp->cur == parity && Lp->ccur == parity;
+    std::vector<uintptr_t> gkey;
+    if (steady) {
+        const void *ptrs[] = {ws_.x.p, ws_.n.p, ws_.hbuf.p, ws_.qkv.p, ws_.ctx.p, ws_.g.p, ws_.dwb.p, x_alt_.p, ptab, sig_, st, x_other};
+        for (const void *q : ptrs) gkey.push_back(reinterpret_cast<uintptr_t>(q));
+        const int ints[] = {S, c, (int)rows, left_, right_, sg, wt ? 1 : 0, a16, ln_folds ? 1 : 0, fin_folds ? 1 : 0, parity};
+        for (int v : ints) gkey.push_back((uintptr_t)v);
+        EncGraph &G = enc_graph_[parity];
+        if (G.exec && G.key == gkey) {
+            PK_HIP(hipGraphLaunch(G.exec, st));
+            for (auto &Lp : layers_) { Lp->cur ^= 1; Lp->ccur ^= 1; }     // what the captured chain does to the host-side state (full caches stay full)
+            return c;
+        }
+        if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+        PK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    }
+    struct CaptureGuard {                                           // an exception inside the captured region must not leave the stream capturing
+        hipStream_t st; bool on;
+        ~CaptureGuard() { if (on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); } }
+    } cap_guard{st, steady};
     bool ffn1_norm_done = false;
     for (int l = 0; l < cfg.num_layers; ++l) {
         const LayerW &L = m_.layers[l];
@@ -333,6 +367,17 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
             x = ws_.x.as<float>();
         }
     }
+    if (steady) {                                                   // the chain was recorded, not run: instantiate, keep, launch
+        hipGraph_t graph = nullptr;
+        cap_guard.on = false;
+        PK_HIP(hipStreamEndCapture(st, &graph));
+        EncGraph &G = enc_graph_[parity];
+        const hipError_t e = hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { G.exec = nullptr; fail(PK_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        G.key = gkey;
+        PK_HIP(hipGraphLaunch(G.exec, st));
+    }
     PK_CHECK_LAUNCH();
     return c;
 }
@@ -372,6 +417,7 @@ void StreamBatch::decode_device(const float *d_enc, int c, int max_tokens) {
 }
 
 StreamBatch::~StreamBatch() {
+    for (EncGraph &G : enc_graph_) if (G.exec) (void)hipGraphExecDestroy(G.exec);
     if (pin_tok_) (void)hipHostFree(pin_tok_);
     if (pin_pcm_) (void)hipHostFree(pin_pcm_);
 }

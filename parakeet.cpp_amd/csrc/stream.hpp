@@ -1,5 +1,6 @@
 // parakeet.cpp_amd/csrc/stream.hpp -- StreamBatch: S lock-step streams with cached encoder state (see stream.cpp).
 #pragma once
+#include <cstdint>
 #include <map>
 #include <memory>
 #include <vector>
@@ -57,6 +58,11 @@ class StreamBatch {
     float *pin_pcm_ = nullptr;
     size_t pin_pcm_floats_ = 0;
     int mel_impl(const float *pcm, int n_samples, float *out, int cap_frames, bool sync);
+    // The launch chain of a chunk's 24 blocks as a hipGraph (steady state of a session: full caches, the chunk shape of the last capture): one graph per
+    // parity of the double-buffered caches, keyed by every pointer and size the captured launches carry.  The host then submits ~250 dependent launches
+    // as one.  Measured slower than the launches it replaces (stream.cpp stream_graph(), profiles/r05_stream_graph_ab.txt): an opt-in of EXPERIMENTAL builds.
+    struct EncGraph { hipGraphExec_t exec = nullptr; std::vector<uintptr_t> key; };
+    EncGraph enc_graph_[2];
     DevBuf x_alt_;              // second residual-stream buffer: a block's final norm folded into the next block's first product writes it (stream.cpp)
     std::map<int, std::unique_ptr<DevBuf>> pos_tables_;   // Tp -> pos_proj of every layer [L][2Tp-1][d], natural columns
     int encode_device(const float *d_mel, int n_frames);                    // -> ws_.x [S*c][d], returns c
