@@ -1069,7 +1069,11 @@ static pk_batch *model_pipeline(Model &m, int max_clips, int64_t max_total, int6
     size_t tok = 0;
     for (auto &x : b->ws) tok += x.token_bytes();
     for (auto &G : b->grp) tok += G.w.token_bytes();
-    if (tok > kTokenShrinkBytes && max_clip * 2 <= w.rag_cap_clip) {
+    // ... and whenever transcribe_clips' segment rule would have cut here (clips four times shorter than what the arrays are pitched for AND
+    // one slot's arrays above kTokenShrinkBytes / 8): a segment cut is always followed by a re-pitch (round-5 advisor finding: between the two
+    // thresholds a cut used to happen with no shrink behind it, and every batch of the new segment still carried the long file's pitch).
+    const bool seg_rule = max_clip * 4 <= w.rag_cap_clip && w.token_bytes() > kTokenShrinkBytes / 8;
+    if ((tok > kTokenShrinkBytes && max_clip * 2 <= w.rag_cap_clip) || seg_rule) {
         for (auto &x : b->ws) x.release_tokens();
         for (auto &G : b->grp) { b->forget(&G.w); G.w.release_tokens(); }
         clip_cap = max_clip;

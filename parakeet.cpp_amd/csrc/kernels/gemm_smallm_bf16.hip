@@ -562,7 +562,11 @@ static void launch_sb_ct(const GemmArgs &a, hipStream_t s, int R) {
 
 template <int EPI, int STEPS, bool A16, bool LN, bool WT>
 static void launch_sb_wt(const GemmArgs &a, hipStream_t s) {
-    const SbTune t = sb_tune();
+    SbTune t = sb_tune();
+    // The folded second norm (pre_g), the depthwise-conv tail and the 8-row activation tiles exist only in the !NTW instantiations of launch_sb_ct: an
+    // A/B run with PK_SB_NT=1 keeps the default load policy for the products that carry one (round-5 advisor finding: they used to fall through to
+    // the generic kernel, which ignores all three -- wrong numbers, silently).
+    if (a.pre_g || a.dw_tail || a.a_t8 || a.out_t8) t.nt = 0;
     const int nslices = a.K / (32 * STEPS);
     const int split = nslices < kSbMaxWaves ? nslices : kSbMaxWaves;
     const int tiles1 = (a.N + 15) / 16;
@@ -626,7 +630,45 @@ void launch_tile_copy_bf16(const float *src16, float *dst16, int64_t rows, int K
                        reinterpret_cast<uint4 *>(dst16), n, K / 32, ld / 8);
 }
 
+#ifdef PK_EXPERIMENTAL
+// Round 6, verdict item 1 -- the CEILING of "take the weight fetch off the dependent chain": PK_SB_PREWARM=1 puts a launch in front of every product that
+// touches one dword of every 128-byte line of the product's operand tiles FROM THE XCD THAT WILL READ THEM (a toucher reads HW_REG_XCC_ID and takes the
+// column tiles x with x % 8 == its id: workgroup (x, y) of the product runs on XCD (y gridDim.x + x) % 8 = x % 8, gridDim.x a multiple of 8);
+// PK_SB_PREWARM=2 takes the tiles of XCD (id + 3) % 8 instead (lines in the memory-side cache only).  The product's own duration in a kernel trace is then
+// what it would cost if something had requested its weights for free (tools/experiments/r06_prewarm.sh; the toucher's own time is NOT free: this is a
+// measurement, never a production path).
+__global__ __launch_bounds__(256) void sb_prewarm_kernel(const char *base, int tile_bytes /* per column tile: K / 32 KB */, int ntiles, int shift, unsigned *sink) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    const int x = ((int)(id & 7) + shift) & 7;
+    const int per_xcd = gridDim.x / 8, sub = blockIdx.x / 8;
+    const int lines = tile_bytes / 128;
+    const long total = (long)((ntiles - x + 7) / 8) * lines;
+    unsigned acc = 0;
+    for (long i = (long)sub * 256 + threadIdx.x; i < total; i += (long)per_xcd * 256) {
+        const long t = i / lines, l = i - t * lines;
+        acc ^= *reinterpret_cast<const unsigned *>(base + (size_t)(x + 8 * t) * tile_bytes + (size_t)l * 128);
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;
+}
+static void sb_prewarm(const GemmArgs &a, int epi, hipStream_t s) {
+    static const int mode = [] { const char *e = getenv("PK_SB_PREWARM"); return e ? atoi(e) : 0; }();
+    if (!mode || !a.W_t16 || a.N % 16 != 0) return;
+    static unsigned *sink = nullptr;
+    if (!sink && hipMalloc(&sink, 64) != hipSuccess) return;
+    const int rows = epi == EPI_GLU ? 2 * a.N : a.N;
+    // (two column tiles per wave: workgroup x reads tiles 2x, 2x + 1 -- pairs of tiles alternate XCDs in pairs; granularity 2 tiles then)
+    const int tiles1 = (a.N + 15) / 16, nsl = a.K / 256;
+    const bool ct2 = !a.a_bf16 && epi != EPI_GLU && sb_rows_per_wg(a, nsl, false, tiles1) == 32 && nsl >= 2 && a.N % 32 == 0 && (tiles1 / 2) * ((a.M + 15) / 16) >= 192;   // launch_sb_wt's rule
+    const int g = ct2 ? 2 : 1;
+    hipLaunchKernelGGL(sb_prewarm_kernel, dim3(256), dim3(256), 0, s, reinterpret_cast<const char *>(a.W_t16), g * (a.K / 32) * 1024, rows / 16 / g, mode == 2 ? 3 : 0, sink);
+}
+#endif
+
 void launch_gemm_smallm_bf16(const GemmArgs &a, int epi, hipStream_t s) {
+#ifdef PK_EXPERIMENTAL
+    sb_prewarm(a, epi, s);
+#endif
     switch (epi) {
     case EPI_NONE: launch_sb_epi<EPI_NONE>(a, s); break;
     case EPI_RELU: launch_sb_epi<EPI_RELU>(a, s); break;

@@ -87,7 +87,8 @@ StreamBatch::StreamBatch(Model &m, int n_streams, int att_left, int att_right) :
             L.conv[i].reserve((size_t)S * (K - 1) * d * 4);
         }
     }
-    sig_ = &m_.sigma_weights();
+    // (the tiled weight copies -- Model::sigma_weights, +1.2 / 2.4 GB for the 600M models -- are built by the first chunk whose row count takes
+    //  the small-M kernels, encode_device: a session set that never qualifies, e.g. 128 streams x 2 frames in the bf16 mode, never pays for them)
     dec_cap_frames_ = 64;                                           // encoder frames per chunk the decode workspace is sized for
     wd_.size_for(m_.cfg, S, 0, 8 * (dec_cap_frames_ - 1) + 1);
     reset();
@@ -215,9 +216,11 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     const int cache_rows = left_ > 0 ? left_ : 1;
     // rows <= kSmallMRows: every product of the chunk is a gemm_smallm chain -- run them on the sigma-K weight copies with sigma-K activations (the
     // producers below write that layout; x, the residual stream, stays natural)
-    const int sg = (!cfg.gemm_bf16 && rows <= kSmallMRows && !sig_->empty()) ? 1 : 0;
+    if (!sig_ && rows <= (cfg.gemm_bf16 ? kSmallMRowsBf16 : kSmallMRows)) sig_ = &m_.sigma_weights();   // built once per model, on first use
+    const bool have_sig = sig_ && !sig_->empty();
+    const int sg = (!cfg.gemm_bf16 && rows <= kSmallMRows && have_sig) ? 1 : 0;
     // (tolerance-class mode: the copies are the bf16 operand tiles of the small-M bf16 kernel, GemmArgs::W_t16 -- a weight load reads one contiguous KB)
-    const bool wt = cfg.gemm_bf16 && rows <= kSmallMRowsBf16 && !sig_->empty();
+    const bool wt = cfg.gemm_bf16 && rows <= kSmallMRowsBf16 && have_sig;
     // Tolerance-class mode (pk_config.gemm_bf16; specification: the oracle's Stream in its gemm_bf16 mode): every product of the chunk takes bf16
     // operands (kernels/gemm_smallm_bf16.hip for these few rows); the rows that exist only as GEMM operands -- LayerNorm outputs, the fc1
     // activations -- are stored as bf16 by their producers (RNE, the rounding the GEMM would apply: same operand values, half the bytes);
@@ -283,9 +286,12 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     };
     // ---- hipGraph of the block chain (stream.hpp: EncGraph) ----
     bool steady = stream_graph() && !m_.prof && left_ > 0 && cfg.num_layers > 0;
-    const int parity = layers_[0]->cur;
-    for (const auto &Lp : layers_) steady = steady && Lp->n_kv == left_ && Lp->has_conv == 1 && Lp->cur == parity && Lp->ccur == parity;
+    int parity = 0;
     std::vector<uintptr_t> gkey;
+    if (steady) {                                                   // (EXPERIMENTAL builds with PK_STREAM_GRAPH=1 only: a production chunk skips all of this)
+        parity = layers_[0]->cur;
+        for (const auto &Lp : layers_) steady = steady && Lp->n_kv == left_ && Lp->has_conv == 1 && Lp->cur == parity && Lp->ccur == parity;
+    }
     if (steady) {
         const void *ptrs[] = {ws_.x.p, ws_.n.p, ws_.hbuf.p, ws_.qkv.p, ws_.ctx.p, ws_.g.p, ws_.dwb.p, x_alt_.p, ptab, sig_, st, x_other};
         for (const void *q : ptrs) gkey.push_back(reinterpret_cast<uintptr_t>(q));

@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)       # the rank's device (set by the --gpus parent)
     ap.add_argument("--oversubscribe", action="store_true", help="tests only: allow --gpus N > visible devices (ranks share devices; the line is marked)")
     ap.add_argument("--spawn", action="store_true", help="take the one-process-per-GPU path also at --gpus 1 (what the GPU test exercises)")
+    ap.add_argument("--layers", type=int, default=0, help="experiments: cut the encoder to this many blocks (a 4-block cut's bf16 weights stay in the 256 MB memory-side cache from chunk to chunk)")
     a = ap.parse_args()
     if a.gpus > 1 or a.spawn:
         return run_ranks(a)
@@ -79,10 +80,12 @@ def main():
     pk = pkload.load()
     from parakeet_cpp_amd import capi, synth, config
     import bench
+    import dataclasses
     cfg = config.PRESETS[a.config]()
+    if a.layers > 0:
+        cfg = dataclasses.replace(cfg, num_layers=a.layers, name=f"{cfg.name}_L{a.layers}")
     path, _ = bench.weights_file(cfg)
     if a.bf16:
-        import dataclasses
         cfg = dataclasses.replace(cfg, gemm_bf16=True)
     m = capi.Model(path, cfg, device=a.device)
     st = capi.Stream(m, a.streams, 70, a.latency_frames)
