@@ -499,6 +499,15 @@ pk_status pk_diag_glu_dwconv_bf16(int n_streams, int c, int d, const float *A, c
 pk_status pk_diag_ffn_bf16_smallm(int M, int d, int f, const float *x, const float *gamma, const float *beta, float eps, const float *W1, const float *b1,
                                   const float *W2, const float *b2, int act_tiles, float *out);
 pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *gamma, const float *beta, float eps, float *y);
+/* LayerNorm + product on a LARGE fp32 batch (round 6; reference src/encoder.cpp:40-41, :60-61, :182-183: norm, then Linear / pointwise conv):
+ * out = epi(LN(X; gamma, beta, eps) W^T + bias), X [M][K], W [N][K] (glu: [2N][K]), epi 0 none / 1 relu / 2 silu / 4 glu.
+ * fold = 0: the separate LayerNorm launch, then the tile GEMM on the normalised rows.  fold = 1: a statistics pass ({mean, rstd} per row) and the tile
+ * GEMM normalising while it stages its A tiles (kernels/gemm_pipe.hpp, LNA) -- what the encoder of a batch runs; bit for bit the same.
+ * pre_gamma / pre_beta (both or neither): X = LN(A; pre_gamma, pre_beta) first -- a block's final_norm_ in front of the next block's ffn1 norm; y1 (optional,
+ * [M][K]) receives X.  fold = 1 then writes X and takes the statistics of X's rows in one launch (launch_layernorm_then_stats).
+ * PK_ERR_UNSUPPORTED where the engine would not fold (M <= 1536, N < 1024 for the non-glu epilogues, K % 32). */
+pk_status pk_diag_ln_gemm(int M, int N, int K, const float *A, const float *pre_gamma, const float *pre_beta, const float *gamma, const float *beta, float eps,
+                          const float *W, const float *bias, int epi, int fold, float *out, float *y1);
 /* sum64 of each row of x[rows][n] (the canonical wavefront reduction). */
 pk_status pk_diag_sum64(const float *x, int rows, int n, float *out);
 

@@ -105,6 +105,7 @@ def lib():
     L.pk_diag_gemm_bf16.argtypes = L.pk_diag_gemm.argtypes
     L.pk_diag_gemm_bf16_a16.argtypes = L.pk_diag_gemm.argtypes
     L.pk_diag_layernorm.argtypes = [f32p, C.c_int64, C.c_int, f32p, f32p, C.c_float, f32p]
+    L.pk_diag_ln_gemm.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float, f32p, f32p, C.c_int, C.c_int, f32p, f32p]
     L.pk_diag_sum64.argtypes = [f32p, C.c_int, C.c_int, f32p]
     for name, at in _LATE_SIGNATURES.items():
         if hasattr(L, name):
@@ -548,6 +549,23 @@ def diag_layernorm(x, g, b, eps=1e-5):
     y = np.empty_like(x)
     check(lib().pk_diag_layernorm(_f(x), x.size // x.shape[-1], x.shape[-1], _f(g), _f(b), eps, _f(y)))
     return y
+
+
+def diag_ln_gemm(A, gamma, beta, W, bias=None, epi="none", fold=True, pre_gamma=None, pre_beta=None, eps=1e-5):
+    """out = epi(LN(X) W^T + bias) on a large fp32 batch, X = A or LN(A; pre_gamma, pre_beta); fold: the statistics pass + the tile GEMM that normalises
+    while staging A (what the engine runs), else LayerNorm launch + GEMM.  Returns (out, X or None)."""
+    A, W, gamma, beta = _c(A), _c(W), _c(gamma), _c(beta)
+    M, K = A.shape
+    e = EPI[epi]
+    N = W.shape[0] // 2 if epi == "glu" else W.shape[0]
+    out = np.empty((M, N), np.float32)
+    y1 = np.empty((M, K), np.float32) if pre_gamma is not None else None
+    pg = _c(pre_gamma) if pre_gamma is not None else None
+    pb = _c(pre_beta) if pre_beta is not None else None
+    bb = _c(bias) if bias is not None else None
+    check(lib().pk_diag_ln_gemm(M, N, K, _f(A), _f(pg) if pg is not None else None, _f(pb) if pb is not None else None, _f(gamma), _f(beta), eps, _f(W),
+                                _f(bb) if bb is not None else None, e, 1 if fold else 0, _f(out), _f(y1) if y1 is not None else None))
+    return out, y1
 
 
 def diag_sum64(x):

@@ -2061,6 +2061,44 @@ pk_status pk_diag_layernorm(const float *x, int64_t rows, int d, const float *ga
     });
 }
 
+pk_status pk_diag_ln_gemm(int M, int N, int K, const float *A, const float *pre_gamma, const float *pre_beta, const float *gamma, const float *beta, float eps,
+                          const float *W, const float *bias, int epi, int fold, float *out, float *y1) {
+    return guard([&] {
+        need(A && gamma && beta && W && out && M > 0 && N > 0 && K > 0 && K <= 1024, "A/gamma/beta/W/out/M/N/K (K <= 1024)");
+        need((pre_gamma == nullptr) == (pre_beta == nullptr), "pre_gamma and pre_beta: both or neither");
+        need(epi == EPI_NONE || epi == EPI_RELU || epi == EPI_SILU || epi == EPI_GLU, "epi: none / relu / silu / glu");
+        diag_device();
+        const int wrows = epi == EPI_GLU ? 2 * N : N;
+        DevBuf a, w, b, gb, o, n, x1;
+        auto up = [&](DevBuf &buf, const void *src, size_t bytes) { buf.reserve(bytes); PK_HIP(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice)); };
+        up(a, A, (size_t)M * K * 4);
+        up(w, W, (size_t)wrows * K * 4);
+        if (bias) up(b, bias, (size_t)wrows * 4);
+        gb.reserve((size_t)4 * K * 4);
+        const float *four[4] = {gamma, beta, pre_gamma, pre_beta};
+        for (int i = 0; i < 4; ++i) if (four[i]) PK_HIP(hipMemcpy(gb.as<float>() + (size_t)i * K, four[i], (size_t)K * 4, hipMemcpyHostToDevice));
+        const float *dg = gb.as<float>(), *db = dg + K, *dpg = dg + 2 * (size_t)K, *dpb = dg + 3 * (size_t)K;
+        o.reserve((size_t)M * N * 4);
+        n.reserve((size_t)M * K * 4);
+        x1.reserve((size_t)M * K * 4);
+        const float *X = a.as<float>();
+        GemmArgs g{n.as<float>(), K, w.as<float>(), K, bias ? b.as<float>() : nullptr, o.as<float>(), N, nullptr, 0, 1.0f, M, N, K};
+        if (fold) {
+            if (pre_gamma) { launch_layernorm_then_stats(X, M, K, dpg, dpb, eps, x1.as<float>(), n.as<float>(), nullptr); X = x1.as<float>(); }
+            else launch_layernorm_stats(X, M, K, eps, n.as<float>(), nullptr);
+            g.A = X; g.ln_g = dg; g.ln_b = db; g.ln_eps = eps; g.ln_stats = n.as<float>();
+            if (!gemm_ln_stats_applies(g, epi)) fail(PK_ERR_UNSUPPORTED, "pk_diag_ln_gemm: fold = 1 needs M > %d, K %% 32 == 0 and a wide (N >= 1024) or glu product", kSmallMRows);
+        } else {
+            if (pre_gamma) launch_layernorm2(X, M, K, dpg, dpb, dg, db, eps, x1.as<float>(), n.as<float>(), nullptr);
+            else launch_layernorm(X, M, K, dg, db, eps, n.as<float>(), nullptr);
+        }
+        launch_gemm(g, epi, nullptr);
+        PK_CHECK_LAUNCH();
+        PK_HIP(hipMemcpy(out, o.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        if (y1 && pre_gamma) PK_HIP(hipMemcpy(y1, x1.p, (size_t)M * K * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 pk_status pk_diag_sum64(const float *x, int rows, int n, float *out) {
     return guard([&] {
         need(x && out && rows > 0 && n > 0, "x/out/rows/n");

@@ -423,7 +423,10 @@ void Model::klaunch_end(hipStream_t s) {
 
 // every encoder-side product goes through here: fp32 chains, or bf16 operands when the model was loaded with gemm_bf16
 void Model::run_gemm(const char *name, const GemmArgs &g, int epi, hipStream_t s, bool fp32_weight) {
-    if (g.ln_g && !((cfg.gemm_bf16 && !fp32_weight) ? gemm_smallm_bf16_ln_applies(g, epi) : gemm_smallm_ln_applies(g, epi)))
+    if (g.ln_stats) {                                               // large fp32 batches: the norm applied from per-row statistics while the tile kernel stages A
+        if ((cfg.gemm_bf16 && !fp32_weight) || !gemm_ln_stats_applies(g, epi))
+            fail(PK_ERR_INVALID, "%s: a LayerNorm from row statistics needs the fp32 tile kernel (gemm_ln_stats_applies)", name);
+    } else if (g.ln_g && !((cfg.gemm_bf16 && !fp32_weight) ? gemm_smallm_bf16_ln_applies(g, epi) : gemm_smallm_ln_applies(g, epi)))
         fail(PK_ERR_INVALID, "%s: a folded LayerNorm needs one of the small-M kernels (gemm_smallm_ln_applies / gemm_smallm_bf16_ln_applies)", name);
     if (g.pre_g && !((cfg.gemm_bf16 && !fp32_weight) ? gemm_smallm_bf16_pre_applies(g, epi) : gemm_smallm_pre_applies(g, epi)))
         fail(PK_ERR_INVALID, "%s: a norm in front of the folded LayerNorm needs one of the small-M kernels (gemm_smallm_pre_applies / gemm_smallm_bf16_pre_applies)", name);
@@ -839,12 +842,41 @@ static constexpr int kLnFoldRows = 256;
 bool Model::ln_folds(const GemmArgs &g, int epi, int64_t rows) const {
     return !cfg.gemm_bf16 && rows <= kLnFoldRows && g.W_sig && gemm_smallm_ln_applies(g, epi);
 }
-void Model::ln_gemm(const char *name, const GemmArgs &g, int epi, const float *ng, const float *nb, bool norm_done, int ymode, const float *x, float *n,
+// Large fp32 batches (round 6; round-5 verdict item 4): the LayerNorm in front of a wide product as a STATISTICS pass (launch_layernorm_stats: one read of x,
+// {mean, rstd} per row into the buffer the normalised rows used to occupy) with the product's tile kernel normalising while it stages A (gemm_pipe.hpp: LNA)
+// -- the same values bit for bit (tests/test_gpu_primitives.py), without the write and the re-read of the normalised tensor.
+// MEASURED SLOWER, so OFF in production: the LayerNorm launches of a 64 x 10 s step go from 0.87 to 0.68 ms (statistics 7.2 us against 13 us per launch), but the
+// products that take the norm pay more than that -- fc1 152 -> 163 us with the three operations per element in front of the staging stores, 167 us with
+// them moved under the MFMAs of an earlier sub-step (the wait for the K tile in flight moves with them), qkv + 5 %, pw1 + 8-12 %: the step 18.46 -> 18.87 / 19.1 ms
+// (profiles/r06_ln_stats_fold_ab.txt).  The global -> VGPR -> LDS staging is what the fp32 loop is bound by; anything added to it costs more
+// than a memory-bound launch of 13 us.  EXPERIMENTAL builds: PK_LN_STATS=1 switches it on.
+static bool ln_stats_on() {
+#ifdef PK_EXPERIMENTAL
+    static const bool on = [] { const char *e = getenv("PK_LN_STATS"); return e ? atoi(e) != 0 : false; }();
+    return on;
+#else
+    return false;
+#endif
+}
+bool Model::ln_stats_folds(const GemmArgs &g, int epi, const float *ng, const float *nb, const float *x, const float *stats) const {
+    if (cfg.gemm_bf16 || !ln_stats_on()) return false;
+    GemmArgs fg = g;
+    fg.A = x; fg.lda = cfg.hidden_size; fg.a_sigma = 0; fg.a_bf16 = 0; fg.ln_g = ng; fg.ln_b = nb; fg.ln_eps = 1e-5f; fg.ln_stats = stats;
+    return fg.K == cfg.hidden_size && gemm_ln_stats_applies(fg, epi);
+}
+// norm_state: 0 = x is un-normalised, 1 = n holds the normalised rows (a previous kernel wrote them), 2 = n holds the rows' statistics for this norm
+void Model::ln_gemm(const char *name, const GemmArgs &g, int epi, const float *ng, const float *nb, int norm_state, int ymode, const float *x, float *n,
                     int64_t rows, hipStream_t s) {
     const int d = cfg.hidden_size;
-    if (!norm_done) {
+    if (norm_state != 1) {
         GemmArgs fg = g;
         fg.A = x; fg.lda = d; fg.a_sigma = 0; fg.a_bf16 = 0; fg.ln_g = ng; fg.ln_b = nb; fg.ln_eps = 1e-5f;
+        if (norm_state == 2 || ln_stats_folds(g, epi, ng, nb, x, n)) {
+            if (norm_state != 2) KL("layernorm_stats", 0.0, 1.0 * rows * d * 4, launch_layernorm_stats(x, rows, d, 1e-5f, n, s));
+            fg.ln_stats = n;
+            run_gemm(name, fg, epi, s);
+            return;
+        }
         if (ln_folds(fg, epi, rows)) { run_gemm(name, fg, epi, s); return; }
         KL("layernorm", 0.0, (cfg.gemm_bf16 ? 1.5 : 2.0) * rows * d * 4, launch_layernorm(x, rows, d, ng, nb, 1e-5f, n, s, ymode));
     }
@@ -852,7 +884,7 @@ void Model::ln_gemm(const char *name, const GemmArgs &g, int epi, const float *n
 }
 
 // FeedForward::forward (src/encoder.cpp:39-46): x += 0.5 * fc2(silu(fc1(LN(x))))
-void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done, const SigW *sg) {
+void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, int norm_state, const SigW *sg) {
     const int d = cfg.hidden_size, f = cfg.ffn_intermediate;
     float *x = w.x.as<float>(), *n = w.n.as<float>(), *h = w.hbuf.as<float>();
     // bf16 mode: the normalised rows and the fc1 activations exist only as GEMM operands -- their producers round them to bf16 (RNE, the
@@ -869,7 +901,7 @@ void Model::ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStr
     g1.out_blocked = blocked ? 1 : 0;
     if (sg) { g1.a_sigma = 1; g1.W_sig = second ? sg->ffn2_w1 : sg->ffn1_w1; g1.sigma_cols = f; }
     // (the first FFN's norm rides on the previous block's final_norm_ kernel, see run_layers -- unless the product folds it in: ln_gemm)
-    ln_gemm("ffn_fc1_silu", g1, EPI_SILU, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, norm_done, sg ? 2 : a16, x, n, rows, s);
+    ln_gemm("ffn_fc1_silu", g1, EPI_SILU, second ? L.ffn2_ng : L.ffn1_ng, second ? L.ffn2_nb : L.ffn1_nb, norm_state, sg ? 2 : a16, x, n, rows, s);
     GemmArgs g2{h, f, second ? L.ffn2_w2 : L.ffn1_w2, f, second ? L.ffn2_b2 : L.ffn1_b2, x, d, x, d, 0.5f, (int)rows, d, f};
     g2.a_bf16 = a16;
     g2.a_blocked = blocked ? 1 : 0;
@@ -924,14 +956,14 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
     const std::vector<SigW> *sigv = (!a16 && rows <= kSmallMRows) ? &sigma_weights() : nullptr;
     const bool sgm = sigv && !sigv->empty();
     const int ymode = sgm ? 2 : a16;                                 // LayerNorm / attention / conv output mode: 0 fp32, 1 bf16, 2 fp32 sigma
-    bool ffn1_norm_done = false;
+    int ffn1_norm_state = 0;                                         // (ln_gemm: 1 = n holds the next ffn1's normalised rows, 2 = their statistics)
     for (int l = first_layer; l < cfg.num_layers; ++l) {
         if (l > stop_layer || (l == stop_layer && stop_stage == 0)) break;
         const LayerW &L = layers[l];
         const int stage_cap = (l == stop_layer) ? stop_stage : 5;
         const SigW *sg = sgm ? &(*sigv)[l] : nullptr;
-        ffn(w, L, false, rows, s, ffn1_norm_done, sg);                               // ffn1_  :197
-        ffn1_norm_done = false;
+        ffn(w, L, false, rows, s, ffn1_norm_state, sg);                              // ffn1_  :197
+        ffn1_norm_state = 0;
         if (stage_cap == 1) break;
         // ConformerAttention::forward  :180-186
         {
@@ -941,7 +973,7 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             g.a_bf16 = a16;
             g.out_bf16 = att16 ? 1 : 0;
             if (sg) { g.a_sigma = 1; g.W_sig = sg->wqkv; }
-            ln_gemm("attn_qkv", g, EPI_NONE, L.att_ng, L.att_nb, false, ymode, x, n, rows, s);
+            ln_gemm("attn_qkv", g, EPI_NONE, L.att_ng, L.att_nb, 0, ymode, x, n, rows, s);
         }
         const int hd = d / cfg.num_heads;
         double fl = 0.0;                                             // QK^T + QP^T (needed band) + AV over every (utterance, head)
@@ -969,7 +1001,7 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             g.a_bf16 = a16;
             g.fast_act = a16;
             if (sg) { g.a_sigma = 1; g.W_sig = sg->pw1; }
-            ln_gemm("conv_pw1_glu", g, EPI_GLU, L.cv_ng, L.cv_nb, false, ymode, x, n, rows, s);
+            ln_gemm("conv_pw1_glu", g, EPI_GLU, L.cv_ng, L.cv_nb, 0, ymode, x, n, rows, s);
         }
         KL("dwconv_bn_silu", (double)rows * d * cfg.conv_kernel_size * 2.0, 2.0 * rows * d * 4,
            launch_dwconv_bn_silu(w.g.as<float>(), rg ? 1 : B, rg ? (int)rows : T, d, cfg.conv_kernel_size, L.dw_w, L.dw_b, L.bn_mean, L.bn_rstd, L.bn_g, L.bn_b,
@@ -981,7 +1013,7 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             run_gemm("conv_pw2_resid", g, EPI_RESID, s);
         }
         if (stage_cap == 3) break;
-        ffn(w, L, true, rows, s, false, sg);                                         // ffn2_  :201
+        ffn(w, L, true, rows, s, 0, sg);                                             // ffn2_  :201
         if (stage_cap == 4) break;
         const bool next_runs = l + 1 < cfg.num_layers && !(l + 1 > stop_layer || (l + 1 == stop_layer && stop_stage == 0));
         bool next_folds = false;   // the next block's fc1 folds its own norm in (small fp32 batches): final_norm_ alone here
@@ -990,10 +1022,18 @@ void Model::run_layers(Workspace &w, int B, int first_layer, int stop_layer, int
             pg.W_sig = (*sigv)[l + 1].ffn1_w1; pg.ln_g = layers[l + 1].ffn1_ng; pg.ln_b = layers[l + 1].ffn1_nb;
             next_folds = ln_folds(pg, EPI_SILU, rows);
         }
-        if (next_runs && !next_folds) {   // final_norm_ :202 and the next block's ffn1_ norm :40 in one pass over the rows
+        bool next_stats = false;   // large fp32 batches: the next block's fc1 normalises from row statistics -- final_norm_ written, its rows' statistics beside it
+        if (next_runs && !next_folds && !sg) {
+            GemmArgs pg{n, d, layers[l + 1].ffn1_w1, d, layers[l + 1].ffn1_b1, w.hbuf.as<float>(), cfg.ffn_intermediate, nullptr, 0, 1.0f, (int)rows, cfg.ffn_intermediate, d};
+            next_stats = ln_stats_folds(pg, EPI_SILU, layers[l + 1].ffn1_ng, layers[l + 1].ffn1_nb, x, n);
+        }
+        if (next_runs && next_stats) {
+            KL("layernorm_then_stats", 0.0, 2.0 * rows * d * 4, launch_layernorm_then_stats(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, n, s));
+            ffn1_norm_state = 2;
+        } else if (next_runs && !next_folds) {   // final_norm_ :202 and the next block's ffn1_ norm :40 in one pass over the rows
             KL("layernorm", 0.0, 3.0 * rows * d * 4,
                launch_layernorm2(x, rows, d, L.fin_g, L.fin_b, layers[l + 1].ffn1_ng, layers[l + 1].ffn1_nb, 1e-5f, x, n, s, ymode));
-            ffn1_norm_done = true;
+            ffn1_norm_state = 1;
         } else {
             KL("layernorm", 0.0, 2.0 * rows * d * 4, launch_layernorm(x, rows, d, L.fin_g, L.fin_b, 1e-5f, x, s));   // final_norm_ :202
         }

@@ -245,9 +245,11 @@ class Model {
               int M, int N, int K, int epi, const float *resid, int64_t ldr, float alpha, hipStream_t s, int a_bf16 = 0, int out_bf16 = 0);
     // LayerNorm + product, folded into one launch where the fp32 chain kernel can (engine.cpp)
     bool ln_folds(const GemmArgs &g, int epi, int64_t rows) const;
-    void ln_gemm(const char *name, const GemmArgs &g, int epi, const float *ng, const float *nb, bool norm_done, int ymode, const float *x, float *n,
+    // ... or, large fp32 batches, applied from per-row statistics while the tile kernel stages A (GemmArgs::ln_stats; engine.cpp)
+    bool ln_stats_folds(const GemmArgs &g, int epi, const float *ng, const float *nb, const float *x, const float *stats) const;
+    void ln_gemm(const char *name, const GemmArgs &g, int epi, const float *ng, const float *nb, int norm_state, int ymode, const float *x, float *n,
                  int64_t rows, hipStream_t s);
-    void ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, bool norm_done = false, const SigW *sg = nullptr);
+    void ffn(Workspace &w, const LayerW &L, bool second, int64_t rows, hipStream_t s, int norm_state = 0, const SigW *sg = nullptr);
 };
 
 // thread-local error slot of the C ABI

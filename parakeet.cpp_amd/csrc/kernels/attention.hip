@@ -119,11 +119,19 @@ __global__ __launch_bounds__(256, OCC) void relpos_attention_kernel(const float 
     };
     // one 16-row operand tile straight from global: lane (row l15, quarter kq) takes float4 #kq of every 16-feature block
     auto load_tile = [&](const float *base, int64_t ld, int row0, int limit, float4 (&f)[NQ4]) {
+#ifdef ATT_LINES_EXPERIMENT     // TIMING PROXY ONLY (wrong operands): the same number of 16-byte loads, but every instruction reads 8 rows x one whole 128-byte line
+        const int r = row0 + (lane >> 3);
+        const bool ok = r >= 0 && r + 8 < limit;
+        const float *p = base + (int64_t)(ok ? r : 0) * ld + 4 * (lane & 7);
+#pragma unroll
+        for (int q = 0; q < NQ4; ++q) f[q] = ok ? *reinterpret_cast<const float4 *>(p + (int64_t)(8 * (q & 1)) * ld + 32 * (q >> 1)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#else
         const int r = row0 + l15;
         const bool ok = r >= 0 && r < limit;
         const float *p = base + (int64_t)(ok ? r : 0) * ld + 4 * kq;
 #pragma unroll
         for (int q = 0; q < NQ4; ++q) f[q] = ok ? *reinterpret_cast<const float4 *>(p + 16 * q) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#endif
     };
     // two independent 16x16 accumulator chains over K = HD (natural k: step 4q+e consumes k = 16q + 4e + kq)
     auto mma_pair = [&](const float4 (&a)[NQ4], const float4 (&b0)[NQ4], const float4 (&b1)[NQ4], f32x4 &c0, f32x4 &c1) {

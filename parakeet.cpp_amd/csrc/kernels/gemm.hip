@@ -229,6 +229,9 @@ static void launch_epi(const GemmArgs &a, hipStream_t s) {
     // round 2: the SINGLE-buffered loop (template parameter NBUF = 1: half the LDS, two barriers per K tile) is ahead of the double-buffered
     // one on every large shape, in the micro-benchmark (tools/ubench/gemm_sweep ml: main loop 130-135 vs 118-125 TF) and, by less, in the
     // engine (fc2 -8 %, fc1 -3.6 %, qkv -5 %, GLU -3 %): gemm_variant_mask().
+    if constexpr (EPI == EPI_NONE || EPI == EPI_RELU || EPI == EPI_SILU) {
+        if (a.ln_stats) { launch_gemm_pipe<4, 2, 1, 2, 32, EPI, 1, true>(a, s); return; }    // (gemm_ln_stats_applies: the wide-output tile below, LayerNorm applied while staging A)
+    }
     if (a.M >= 1024 && (a.N >= 1024 || (a.M >= 65536 && a.N >= 256))) {
         // bit 128: 192x128 tiles (8 waves of 96x32) where they turn a fractional second round of the 512 resident 128x128 workgroups into one
         // full round (attn_qkv of the 110M model at 64 x 10 s: 63 x 12 = 756 tiles = 1.48 rounds -> 42 x 12 = 504)
@@ -253,7 +256,20 @@ static void launch_epi(const GemmArgs &a, hipStream_t s) {
 
 void launch_gemm_smallm(const GemmArgs &a, int epi, hipStream_t s);   // kernels/gemm_smallm.hip
 
+// The products whose LayerNorm can ride on the A staging of the fp32 tile kernel (GemmArgs::ln_stats): exactly the shapes launch_epi / launch_gemm
+// send to the single-buffered 128 x 128 / BK 32 tile -- wide outputs of large batches (fc1, qkv) and the GLU product.
+bool gemm_ln_stats_applies(const GemmArgs &a, int epi) {
+    if (!a.ln_g || !a.ln_b || !a.ln_stats || a.a_bf16 || a.out_bf16 || a.fast_act || a.a_sigma || a.W_sig) return false;
+    if (a.M <= kSmallMRows || a.K < 64 || a.K % 32 != 0 || (a.lda & 3) != 0 || (a.ldw & 3) != 0) return false;
+    if (epi == EPI_GLU) return true;
+    if (epi != EPI_NONE && epi != EPI_RELU && epi != EPI_SILU) return false;
+    const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.K >= 1024 && a.K % 64 == 0 && tiles128 <= 256 && a.N >= 256) return false;     // (the long-K single-round tile has no LNA instantiation)
+    return a.M >= 1024 && a.N >= 1024;
+}
+
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
+    if (a.ln_stats && !gemm_ln_stats_applies(a, epi)) { fprintf(stderr, "parakeet_amd: internal error: GemmArgs::ln_stats on a product the tile kernel does not fold it into\n"); abort(); }
     // up to a few hundred rows (streaming chunks, ONE utterance of up to a minute -- the reference's own benchmark protocol is batch 1):
     // one wavefront per 16x16 tile ((M/16)(N/16) independent waves) instead of a few dozen fat workgroups with a long K loop each.
     // Measured with tools/bench_reference_protocol.py: 10 s clip (M = 126) 6.3 -> 2.9 ms, 30 s (M = 376) 6.7 -> 4.3 ms per encoder pass.
@@ -265,6 +281,7 @@ void launch_gemm(const GemmArgs &a, int epi, hipStream_t s) {
     case EPI_RESID: launch_epi<EPI_RESID>(a, s); break;
     case EPI_GLU:
         if (a.K < 64) launch_one<128, 128, EPI_GLU>(a, s);
+        else if (a.ln_stats) launch_gemm_pipe<4, 2, 1, 2, 32, EPI_GLU, 1, true>(a, s);
         else if (gemm_variant_mask() & 8) launch_gemm_pipe<4, 2, 1, 2, 32, EPI_GLU, 1>(a, s);
         else launch_gemm_pipe<4, 2, 1, 2, 32, EPI_GLU>(a, s);
         break;

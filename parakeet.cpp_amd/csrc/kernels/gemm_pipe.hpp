@@ -217,7 +217,12 @@ __device__ __forceinline__ void gp_epilogue(const GemmArgs &g_, gp_f32x16 (&acc)
     else epilogue_scalar(m0, n0);
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, int EPI, int NBUF = 2>
+// LNA (round 6): the LayerNorm of the product's input rows applied WHILE THE A TILE IS STAGED -- A = the un-normalised rows, GemmArgs::ln_stats = {mean, rstd}
+// per row (launch_layernorm_stats: the canonical sum64 reductions of layernorm_kernel), ln_g / ln_b = gamma / beta over K (= the row length).  Between
+// the global load of a chunk and its LDS store every element goes through exactly layernorm_kernel's y = fma((x - mean) * rstd, gamma, beta): the
+// values that reach the MFMAs are bit for bit the ones the separate launch would have written -- but they are never written (nor read back): a
+// batch's LayerNorm becomes a statistics pass (one read of x, 8 bytes per row out) instead of a read + write of the whole tensor.
+template <int WGM, int WGN, int TM, int TN, int BK, int EPI, int NBUF = 2, bool LNA = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, int tiles_n, int n_tiles) {
     static_assert(NBUF == 1 || NBUF == 2, "LDS staging buffers");
     constexpr int NT = 64 * WGM * WGN;
@@ -244,6 +249,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     const float *a_src[A_CH];
     const float *w_src[W_CH];
     int a_dst[A_CH], w_dst[W_CH];
+    [[maybe_unused]] float a_mean[LNA ? A_CH : 1], a_rstd[LNA ? A_CH : 1];     // LNA: statistics of the row each staging chunk belongs to
+    [[maybe_unused]] const float *gam_src = nullptr, *bet_src = nullptr;      // LNA: gamma / beta of this thread's 4 k of every K tile (c % C4R is the same for all its chunks)
+    static_assert(!LNA || NT % C4R == 0, "LNA: a thread's chunks share their k offset");
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         const int c = tid + NT * i;
@@ -269,7 +277,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             int gr = m0 + chunk_row(c);
             gr = gr < g.M ? gr : g.M - 1;
             a_src[i] = g.A + (int64_t)gr * g.lda + (c % C4R) * 4;
+            if constexpr (LNA) {
+                const float2 st = *reinterpret_cast<const float2 *>(g.ln_stats + 2 * (int64_t)gr);
+                a_mean[i] = st.x; a_rstd[i] = st.y;
+            }
         }
+        if constexpr (LNA) { gam_src = g.ln_g + (tid % C4R) * 4; bet_src = g.ln_b + (tid % C4R) * 4; }
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) {
             const int c = tid + NT * i, v = chunk_row(c);
@@ -291,11 +304,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     };
 
     float4 ra[A_CH], rw[W_CH];
+    [[maybe_unused]] float4 rg4, rb4;
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const float4 *>(w_src[i] + kt * BK);
+        if constexpr (LNA) {
+            rg4 = *reinterpret_cast<const float4 *>(gam_src + kt * BK);
+            rb4 = *reinterpret_cast<const float4 *>(bet_src + kt * BK);
+        }
     };
     // Staging stores: {a, b} at p, {c, d} at p + BK/2 floats.  FOUR 4-byte stores, not one ds_write2_b64: on gfx950 the finer the LDS store
     // next to the fragment reads, the less it costs the loop -- 16-byte stores 98 TF, 8-byte pairs 134, 4-byte stores 141 TF of the 145 TF
@@ -311,6 +329,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             const unsigned addr = (unsigned)(size_t)p;              // low 32 bits of a flat LDS address = the LDS offset
             asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:%5\n\tds_write_b32 %0, %4 offset:%6"
                          ::"v"(addr), "v"(a), "v"(b), "v"(c), "v"(d), "n"(BK / 2 * 4), "n"(BK / 2 * 4 + 4) : "memory");
+        }
+    };
+    // LNA: the A chunks in flight (the K tile the NEXT lstore will publish) are normalised in their registers -- layernorm_kernel's expression, operation
+    // for operation (-ffp-contract=off: sub, mul, fma; two elements per instruction: v_pk_add / v_pk_mul / v_pk_fma_f32 are the same IEEE operations per
+    // element).  Called BEFORE the barrier that precedes lstore, under the MFMAs of a sub-step: inside lstore the 24 dependent VALU operations sat in the
+    // barrier-to-barrier section every wave of the workgroup has to leave before the next K tile can be read (first form of round 6: fc1 152 -> 163 us).
+    auto lnorm = [&]() {
+        if constexpr (LNA) {
+            typedef float f2_ __attribute__((ext_vector_type(2)));
+            const f2_ g01 = {rg4.x, rg4.y}, g23 = {rg4.z, rg4.w}, b01 = {rb4.x, rb4.y}, b23 = {rb4.z, rb4.w};
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const f2_ m = {a_mean[i], a_mean[i]}, r = {a_rstd[i], a_rstd[i]};
+                f2_ lo = {ra[i].x, ra[i].y}, hi = {ra[i].z, ra[i].w};
+                lo = __builtin_elementwise_fma((lo - m) * r, g01, b01);
+                hi = __builtin_elementwise_fma((hi - m) * r, g23, b23);
+                ra[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
         }
     };
     auto lstore = [&](int buf) {
@@ -358,10 +394,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     };
     auto epilogue = [&](int m0, int n0) { gp_epilogue<WGM, WGN, TM, TN, EPI, NBUF * BUF, false, true>(g, acc, smem, m0, n0); };
 #define GP_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef GP_LNORM_AT
+#define GP_LNORM_AT (NSUB - 2)          // the sub-step whose MFMAs cover the normalisation (the last one in front of the barrier: the loads have had the longest to land)
+#endif
 
     int m0, n0;
     set_tile(blockIdx.x, m0, n0);
     gload(0);
+    lnorm();
     lstore(0);
     lds_store_fence();
     __syncthreads();
@@ -379,6 +419,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
             for (int s = 0; s < NSUB - 1; ++s) {
                 fragload(0, s + 1, (s + 1) & 1);
                 GP_SB(); mma(s & 1); GP_SB();
+                if (LNA && s == GP_LNORM_AT && more1) { lnorm(); GP_SB(); }   // (K tile kt + 1, requested most of a K tile ago, under this sub-step's MFMAs)
             }
             __syncthreads();
             if (more1) lstore(0);
@@ -394,6 +435,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
 #pragma unroll
             for (int s = 0; s < NSUB - 1; ++s) {
                 fragload(cur, s + 1, (s + 1) & 1);
+                if (LNA && s == 0 && more1) lnorm();
                 if (s == NSUB - 2 && more1) lstore(cur ^ 1);
                 GP_SB(); mma(s & 1); GP_SB();
             }
@@ -409,7 +451,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
 #undef GP_SB
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, int EPI, int NBUF = 2>
+template <int WGM, int WGN, int TM, int TN, int BK, int EPI, int NBUF = 2, bool LNA = false>
 static void launch_gemm_pipe(const GemmArgs &a, hipStream_t s) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
@@ -417,7 +459,8 @@ static void launch_gemm_pipe(const GemmArgs &a, hipStream_t s) {
     const int n_tiles = tiles_m * tiles_n;
     constexpr size_t lds = NBUF * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     if (a.fast_act || a.out_bf16) { fprintf(stderr, "parakeet_amd: internal error: bf16-mode switches on the fp32 GEMM\n"); abort(); }
-    auto kern = &gemm_pipe_kernel<WGM, WGN, TM, TN, BK, EPI, NBUF>;
+    if (LNA != (a.ln_stats != nullptr)) { fprintf(stderr, "parakeet_amd: internal error: GemmArgs::ln_stats on a kernel without the folded LayerNorm (or the reverse)\n"); abort(); }
+    auto kern = &gemm_pipe_kernel<WGM, WGN, TM, TN, BK, EPI, NBUF, LNA>;
     static DynLdsSlots slots;
     ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles);

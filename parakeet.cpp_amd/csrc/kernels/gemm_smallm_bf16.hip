@@ -47,6 +47,9 @@ typedef float sb_f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 sb_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kSbMaxWaves = 8;      // waves per workgroup (2 per SIMD: 256 VGPRs each -- the up-front slices need them)
+#ifdef PK_EXPERIMENTAL
+__device__ int sb_sum_rev = 0;      // (set once from PK_SB_SUMREV by launch_gemm_smallm_bf16)
+#endif
 
 // Phase stamps for tools/ubench/smallm_bf16_trace.cpp (-DSB_TRACE): shader clock of lane 0 of every wave -- [workgroup][wave][8]: 0 kernel entry,
 // 1 every load of the slice issued, 2 activation rows arrived (first use), 3 LayerNorm applied / rows converted, 4 weights arrived + MFMAs issued,
@@ -383,11 +386,23 @@ __global__ __launch_bounds__(64 * kSbMaxWaves) void gemm_smallm_bf16_kernel(Gemm
     const int t = et;                                               // this wave finishes row tile et of column tile ec
     sb_f32x4 v = acc[0][0][0], gt = acc[NW - 1][0][0];              // (split == 1: RT = CT = 1)
     if (split > 1) {
+#ifdef PK_EXPERIMENTAL
+        if (sb_sum_rev) {                                           // PK_SB_SUMREV=1: the slices met in REVERSE wave order (round 6: how much of the mode's distance from fp32 is summation order)
+            v = part(split - 1, 0, ec, t)[lane];
+            for (int w2 = split - 2; w2 >= 0; --w2) v += part(w2, 0, ec, t)[lane];
+            if constexpr (EPI == EPI_GLU) {
+                gt = part(split - 1, 1, ec, t)[lane];
+                for (int w2 = split - 2; w2 >= 0; --w2) gt += part(w2, 1, ec, t)[lane];
+            }
+        } else
+#endif
+        {
         v = part(0, 0, ec, t)[lane];
         for (int w2 = 1; w2 < split; ++w2) v += part(w2, 0, ec, t)[lane];
         if constexpr (EPI == EPI_GLU) {
             gt = part(0, 1, ec, t)[lane];
             for (int w2 = 1; w2 < split; ++w2) gt += part(w2, 1, ec, t)[lane];
+        }
         }
     }
     if (col >= g.N) return;
@@ -667,6 +682,13 @@ static void sb_prewarm(const GemmArgs &a, int epi, hipStream_t s) {
 
 void launch_gemm_smallm_bf16(const GemmArgs &a, int epi, hipStream_t s) {
 #ifdef PK_EXPERIMENTAL
+    static const bool sumrev_set = [] {
+        const char *e = getenv("PK_SB_SUMREV");
+        const int v = e ? atoi(e) : 0;
+        if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(sb_sum_rev), &v, sizeof(v));
+        return true;
+    }();
+    (void)sumrev_set;
     sb_prewarm(a, epi, s);
 #endif
     switch (epi) {

@@ -143,6 +143,10 @@ struct GemmArgs {
     // ln_b[K], ln_eps) of the product's input is applied while the rows are staged -- out = epi(LN(A) W^T + bias) (bf16 mode: bf16(LN(A)) W16^T).
     // Callers check gemm_smallm_bf16_ln_applies() / gemm_smallm_ln_applies().
     const float *ln_g = nullptr, *ln_b = nullptr; float ln_eps = 0.0f;
+    // Tile kernel of the fp32 path (gemm_pipe.hpp, LNA; round 6): with ln_g / ln_b set, ln_stats = {mean, rstd} of every row of A (launch_layernorm_stats) and
+    // the normalisation y = fma((x - mean) * rstd, gamma, beta) is applied while the A tile is staged -- bit for bit the rows launch_layernorm would have
+    // written.  Callers check gemm_ln_stats_applies().
+    const float *ln_stats = nullptr;
     // small-M kernels with ln_g set (gemm_smallm_bf16.hip; exact mode: gemm_smallm_ln_kernel, bit for bit the separate launch): ANOTHER LayerNorm in front of the folded one -- out = epi(bf16(LN(LN(A; pre_g, pre_b); ln_g, ln_b)) W16^T + bias):
     // a block's final_norm_ folded into the first product of the next block (streaming, tolerance-class mode: one launch less per block).  pre_out
     // (optional, fp32 [M][pre_ldo], NOT the buffer A lives in: other workgroups still read A) receives LN(A; pre_g, pre_b) -- the residual stream
@@ -161,6 +165,9 @@ void launch_sigma_copy(const float *src, float *dst, int64_t rows, int K, int64_
 // bf16 src [rows][ld] -> dst rows x K bf16 in the W_t16 operand tiles (rows % 16 == 0, K % 32 == 0, ld % 8 == 0)
 void launch_tile_copy_bf16(const float *src16, float *dst16, int64_t rows, int K, int64_t ld, hipStream_t s);
 void launch_gemm(const GemmArgs &a, int epi, hipStream_t s);
+// fp32 tile kernel with the LayerNorm of its input rows applied from per-row statistics (GemmArgs::ln_stats): large batches (M > kSmallMRows), K = the row
+// length (a multiple of 32), wide outputs (the 128 x 128 single-buffered tile: fc1, qkv, pw1 + GLU), epilogues none / ReLU / SiLU / GLU
+bool gemm_ln_stats_applies(const GemmArgs &a, int epi);
 // bf16 mode: true when the product (M x N x K, bf16 A already in HBM, epilogue `epi`) runs on a direct-to-LDS kernel that can write
 // (producer = true: register epilogue) / read (producer = false: LDS-DMA) the blocked activation layout of GemmArgs::out_blocked / a_blocked
 bool gemm_bf16_blocked_handoff(int M, int N, int K, int epi, bool producer);
@@ -348,6 +355,11 @@ void launch_layernorm(const float *x, int64_t rows, int d, const float *g, const
 // y1 = LN(x; g1, b1), y2 = LN(y1; g2, b2) in one pass (y1 may alias x)
 void launch_layernorm2(const float *x, int64_t rows, int d, const float *g1, const float *b1, const float *g2, const float *b2, float eps,
                        float *y1, float *y2, hipStream_t s, int y2_bf16 = 0);
+// Statistics only (round 6): stats[row] = {mean, rstd} of x's rows -- layernorm_kernel's reductions (same sum64 butterflies, same divisions), no output tensor:
+// the consumer normalises while it stages the rows (GemmArgs::ln_stats).
+void launch_layernorm_stats(const float *x, int64_t rows, int d, float eps, float *stats, hipStream_t s);
+// y1 = LN(x; g1, b1) written out (may alias x) + the statistics of y1's rows (what launch_layernorm2's second pass would start from)
+void launch_layernorm_then_stats(const float *x, int64_t rows, int d, const float *g1, const float *b1, float eps, float *y1, float *stats, hipStream_t s);
 void launch_sum64_rows(const float *x, int rows, int n, float *out, hipStream_t s);
 void launch_math(int fn, const float *in, float *out, int64_t n, hipStream_t s);   // 0 exp 1 log 2 tanh 3 sigmoid 4 silu 5 sqrt 6 recip 7 relu
 void launch_math_exhaustive(int fn, unsigned long long *out3, hipStream_t s);   // out3 must hold {0, 0, 1 << 32} on entry

@@ -124,6 +124,69 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float *__restrict
         }
     }
 }
+// Statistics of the rows of x -- or, THEN = true, y1 = LN(x; g1, b1) written out and the statistics of y1's rows: the first half of layernorm_kernel /
+// the first one and a half passes of layernorm2_kernel, operation for operation (the same strided partial sums, the same wave_sum64 butterflies, the
+// same divisions and the same 1 / sqrt) -- stats[row] = {mean, rstd}.  The consumer (gemm_pipe.hpp, LNA) applies fma((x - mean) * rstd, gamma, beta).
+template <int PER_LANE, bool THEN>
+__global__ __launch_bounds__(256) void layernorm_stats_kernel(const float *__restrict__ x, int64_t rows, int d, const float *__restrict__ g1,
+                                                              const float *__restrict__ b1, float eps, float *__restrict__ y1, float *__restrict__ stats) {
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * d;
+    float v[PER_LANE];
+    [[maybe_unused]] float gv[THEN ? PER_LANE : 1], bv[THEN ? PER_LANE : 1];
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = i < d ? xr[i] : 0.0f;
+        if constexpr (THEN) { gv[j] = i < d ? g1[i] : 0.0f; bv[j] = i < d ? b1[i] : 0.0f; }
+    }
+#pragma unroll
+    for (int pass = 0; pass < (THEN ? 2 : 1); ++pass) {
+        float p = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j)
+            if (lane + 64 * j < d) p = p + v[j];
+        const float mean = wave_sum64(p) / (float)d;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j)
+            if (lane + 64 * j < d) {
+                const float c = v[j] - mean;
+                q = q + c * c;
+            }
+        const float var = wave_sum64(q) / (float)d;
+        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+        if (pass == (THEN ? 1 : 0)) {
+            if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(mean, rstd);
+        } else {
+            float *yr = y1 + row * d;
+#pragma unroll
+            for (int j = 0; j < PER_LANE; ++j) {
+                const int i = lane + 64 * j;
+                if (i < d) {
+                    v[j] = __builtin_fmaf((v[j] - mean) * rstd, gv[j], bv[j]);
+                    yr[i] = v[j];
+                }
+            }
+        }
+    }
+}
+void launch_layernorm_stats(const float *x, int64_t rows, int d, float eps, float *stats, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (d <= 128) hipLaunchKernelGGL((layernorm_stats_kernel<2, false>), grid, dim3(256), 0, s, x, rows, d, nullptr, nullptr, eps, nullptr, stats);
+    else if (d <= 512) hipLaunchKernelGGL((layernorm_stats_kernel<8, false>), grid, dim3(256), 0, s, x, rows, d, nullptr, nullptr, eps, nullptr, stats);
+    else hipLaunchKernelGGL((layernorm_stats_kernel<16, false>), grid, dim3(256), 0, s, x, rows, d, nullptr, nullptr, eps, nullptr, stats);
+}
+void launch_layernorm_then_stats(const float *x, int64_t rows, int d, const float *g1, const float *b1, float eps, float *y1, float *stats, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (d <= 128) hipLaunchKernelGGL((layernorm_stats_kernel<2, true>), grid, dim3(256), 0, s, x, rows, d, g1, b1, eps, y1, stats);
+    else if (d <= 512) hipLaunchKernelGGL((layernorm_stats_kernel<8, true>), grid, dim3(256), 0, s, x, rows, d, g1, b1, eps, y1, stats);
+    else hipLaunchKernelGGL((layernorm_stats_kernel<16, true>), grid, dim3(256), 0, s, x, rows, d, g1, b1, eps, y1, stats);
+}
+
 void launch_layernorm2(const float *x, int64_t rows, int d, const float *g1, const float *b1, const float *g2, const float *b2, float eps,
                        float *y1, float *y2, hipStream_t s, int y2_bf16) {
     const dim3 grid((unsigned)((rows + 3) / 4));

@@ -88,6 +88,52 @@ def test_mfma_gemm_is_natural_k_fma_chain(capi, orc, M, N, K):
     assert np.array_equal(bits(capi.diag_gemm(A, W, None)), bits(orc.linear(A, W, None)))
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(8064, 2048, 512, "silu"), (8064, 1536, 512, "none"), (8064, 512, 512, "glu"), (1600, 1024, 512, "relu"),
+                                       (12032, 4096, 1024, "silu"), (2001, 1100, 96, "none")])
+def test_layernorm_from_row_statistics_in_the_tile_gemm_bit_identical(capi, orc, M, N, K, epi):
+    """Round 6: on large fp32 batches the LayerNorm in front of a wide product is a statistics pass and the tile kernel normalises while it stages A
+    (gemm_pipe.hpp: LNA).  The headline's own shapes (fc1, qkv, pw1 + GLU of tdt-ctc-110m at 64 x 10 s; fc1 of tdt-600m; ragged sizes): the product
+    equals the ORACLE's layer_norm + linear bit for bit, and the un-folded pair of launches."""
+    rng = np.random.default_rng(M + N + K)
+    X = (rng.standard_normal((M, K)) * 2 + 0.3).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    rows = N * 2 if epi == "glu" else N
+    W = (rng.standard_normal((rows, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(rows).astype(np.float32)
+    y = orc.linear(orc.layer_norm(X, g, be), W, b)
+    if epi == "silu":
+        want = orc.math_v("silu", y)
+    elif epi == "relu":
+        want = np.where(y > 0, y, np.float32(0))
+    elif epi == "glu":
+        want = y[:, :N] * orc.math_v("sigmoid", y[:, N:])
+    else:
+        want = y
+    folded, _ = capi.diag_ln_gemm(X, g, be, W, b, epi, fold=True)
+    plain, _ = capi.diag_ln_gemm(X, g, be, W, b, epi, fold=False)
+    assert np.array_equal(bits(folded), bits(want)), "statistics pass + normalise-on-stage differs from the oracle"
+    assert np.array_equal(bits(plain), bits(want))
+
+
+def test_final_norm_then_statistics_of_the_next_norm_bit_identical(capi, orc):
+    """A block's final_norm_ written out with the statistics of ITS rows for the next block's ffn1 norm (launch_layernorm_then_stats), that norm applied
+    by fc1's tile kernel: the residual stream and the product equal layer_norm(layer_norm(x)) -> linear of the oracle bit for bit."""
+    rng = np.random.default_rng(77)
+    M, N, K = 8064, 2048, 512
+    A = (rng.standard_normal((M, K)) * 3 - 0.2).astype(np.float32)
+    pg, pb = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32), (0.1 * rng.standard_normal(K)).astype(np.float32)
+    g, be = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32), (0.1 * rng.standard_normal(K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    x1 = orc.layer_norm(A, pg, pb)
+    want = orc.math_v("silu", orc.linear(orc.layer_norm(x1, g, be), W, b))
+    for fold in (True, False):
+        out, y1 = capi.diag_ln_gemm(A, g, be, W, b, "silu", fold=fold, pre_gamma=pg, pre_beta=pb)
+        assert np.array_equal(bits(y1), bits(x1)), f"fold={fold}: residual stream after final_norm_"
+        assert np.array_equal(bits(out), bits(want)), f"fold={fold}: fc1 on the doubly normalised rows"
+
+
 def test_gemm_asymmetric_identity_detects_transposes(capi):
     # A = I, asymmetric W: out must be exactly W^T (catches row/col swaps in the MFMA C layout)
     K = 64
