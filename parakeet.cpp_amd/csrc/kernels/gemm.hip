@@ -332,10 +332,10 @@ static int bf16_glds_persist() {
 // not by how the pulls are scheduled.
 static int bf16_glds_flags() {
 #ifdef PK_EXPERIMENTAL
-    static const int m = [] { const char *e = getenv("PK_BF16_FLAGS"); return e ? atoi(e) : 2; }();
+    static const int m = [] { const char *e = getenv("PK_BF16_FLAGS"); return e ? atoi(e) : 18; }();
     return m;
 #else
-    return 2;
+    return 18;
 #endif
 }
 static int bf16_glds_mode() {
@@ -406,8 +406,10 @@ static void launch_bf16_epi(const GemmArgs &a, hipStream_t s) {
                     }
                 }
 #endif
-                if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
-                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0);
+                // bit 16 (round 6, production): residual products on the register epilogue with the accumulators started from the residual (gemm_bf16_glds.hpp)
+                const bool rd = (bf16_glds_flags() & 16) != 0;
+                if (!tall) launch_gemm_bf16_glds<2, 4, 3, 2, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0, rd);
+                else launch_gemm_bf16_glds<4, 2, 2, 4, EPI>(a, s, bf16_glds_persist(), (bf16_glds_flags() & 1) != 0, (bf16_glds_flags() & 2) != 0, (bf16_glds_flags() & 4) != 0, rd);
                 return;
             }
         }

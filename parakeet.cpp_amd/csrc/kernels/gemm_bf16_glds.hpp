@@ -174,6 +174,75 @@ __device__ __forceinline__ void gl_epilogue_direct(const GemmArgs &g, bg_f32x16 
     }
 }
 
+// Residual products with the register epilogue (round 6; round-5 verdict item 2: out_proj / pw2 42 us against a 27 us K loop, fc2 113 against 107).
+// out = resid + alpha (A W^T + bias) is formed as alpha (resid / alpha + bias + A W^T): in the swapped-operand accumulator layout (above) a lane owns output row lr
+// and, per register quad, FOUR CONSECUTIVE columns -- the residual arrives as 16-byte loads (24 per lane for a 192 x 256 tile on 8 waves), requested at the START
+// of the tile next to the first two K tiles' DMA, and the accumulators are initialised with fma(resid, 1 / alpha, bias) (the bias through the scalar cache).  After
+// the K loop the epilogue is 24 multiplications by alpha and 16-byte stores from registers: no LDS round trip, no barrier, no load -- the three-band LDS
+// epilogue with its residual reads at the start of every band was a third of the narrow products' time.  Round 5 had tried the accumulate-onto-the-residual idea
+// in the UN-swapped layout (GemmArgs::resid_init: the residual as 96 four-byte loads per wave in front of the first MFMA) and measured it 16-42 % slower; this is
+// the same arithmetic with 16-byte accesses.  alpha = 0.5 / 1: the scaling by 1 / alpha is exact; the K partial sums are added onto a value of the residual's
+// magnitude, i.e. rounded at ITS ulp (tolerance-class mode only: tests/test_gpu_bf16.py bounds it).  In place (out == resid): every lane reads and later writes its own elements.
+template <int WGM, int WGN, int TM, int TN>
+__device__ __forceinline__ void gl_resid_init(const GemmArgs &g, bg_f32x16 (&acc)[TM][TN], int m0, int n0) {
+    constexpr int WM = TM * 32, WN = TN * 32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WGN, wn = wave % WGN, lr = lane & 31, h = lane >> 5;
+    const int cw = __builtin_amdgcn_readfirstlane(n0 + wn * WN);
+    typedef float f32x8_ __attribute__((ext_vector_type(8)));
+    typedef const f32x8_ __attribute__((address_space(4))) *cf8p;
+    const bool has_bias = g.bias != nullptr;
+    const float inv_alpha = 1.0f / g.alpha;
+    int roff[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int row = m0 + wm * WM + i * 32 + lr;
+        row = row < g.M ? row : g.M - 1;                           // (rows past the end: a valid address, never stored)
+        roff[i] = row * (int)g.ldr + cw + 4 * h;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cb = cw + j * 32 + 8 * q;                     // wave-uniform; N % 16 == 0 (launcher): the 8-column group is inside N or outside
+            float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (cb < g.N && has_bias) {
+                const f32x8_ b8 = *(cf8p)(const void *)(g.bias + cb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bs[e] = h ? b8[4 + e] : b8[e];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (cb < g.N) r = *reinterpret_cast<const float4 *>(g.resid + roff[i] + j * 32 + 8 * q);
+                acc[i][j][4 * q] = __builtin_fmaf(r.x, inv_alpha, bs[0]); acc[i][j][4 * q + 1] = __builtin_fmaf(r.y, inv_alpha, bs[1]);
+                acc[i][j][4 * q + 2] = __builtin_fmaf(r.z, inv_alpha, bs[2]); acc[i][j][4 * q + 3] = __builtin_fmaf(r.w, inv_alpha, bs[3]);
+            }
+        }
+}
+template <int WGM, int WGN, int TM, int TN>
+__device__ __forceinline__ void gl_epilogue_resid_direct(const GemmArgs &g, bg_f32x16 (&acc)[TM][TN], int m0, int n0) {
+    constexpr int WM = TM * 32, WN = TN * 32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WGN, wn = wave % WGN, lr = lane & 31, h = lane >> 5;
+    const int cw = __builtin_amdgcn_readfirstlane(n0 + wn * WN);
+    const float alpha = g.alpha;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * WM + i * 32 + lr;
+        if (row >= g.M) continue;
+        float *orow = g.out + row * (int)g.ldo + cw + 4 * h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (cw + j * 32 + 8 * q >= g.N) continue;
+                *reinterpret_cast<float4 *>(orow + j * 32 + 8 * q) =
+                    make_float4(acc[i][j][4 * q] * alpha, acc[i][j][4 * q + 1] * alpha, acc[i][j][4 * q + 2] * alpha, acc[i][j][4 * q + 3] * alpha);
+            }
+    }
+}
+
 // PERSIST (round 4): ONE workgroup per CU walks its tiles inside the launch.  Measured in round 3 (tools/ubench/gemm_bf16_k.cpp): the K loop runs
 // at 1.25-1.3 PF, the products of this model lose ~14 us per ROUND of tiles -- a cold two-tile DMA prologue on every CU at once, the epilogue,
 // the re-dispatch -- on K loops of only 16 tiles.  Here the first K tile of tile i+1 is requested (DMA into the staging buffer the last K tile
@@ -360,7 +429,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
 #ifdef PK_EXPERIMENTAL
         if constexpr (EPI == EPI_RESID && !DIRECT && !PERSIST) resid_in_acc = g.resid_init != 0;
 #endif
-        if (resid_in_acc) {
+        if constexpr (DIRECT && EPI == EPI_RESID) {
+            gl_resid_init<WGM, WGN, TM, TN>(g, acc, m0, n0);        // (requested behind the first two K tiles' DMA: lands under the prologue wait)
+        } else if (resid_in_acc) {
             // out = resid + alpha (A W^T + bias) accumulated ONTO the residual (GemmArgs::resid_init, tolerance-class mode): the accumulators start
             // from resid / alpha + bias -- requested here, next to the first K tiles' DMA, instead of 49 MB of residual reads competing with the
             // 49 MB of output stores at the kernel's tail -- and the epilogue stores alpha * acc.  C layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -420,6 +491,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
         // `cur` = the buffer the last K tile did NOT use (free since the barrier of the last iteration); the other one is free too once every
         // wave has passed that barrier -- which the epilogue's own first barrier guarantees again
         GL_STAMP(tr_tile, 2 + nk);
+        static_assert(!(PERSIST && DIRECT && EPI == EPI_RESID), "the register residual epilogue runs one tile per workgroup");
         if constexpr (PERSIST && DIRECT) {
             const int em0 = m0, en0 = n0;
             loc += per_xcd;
@@ -434,6 +506,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
             GL_STAMP(tr_tile, 3 + nk);
             ++tr_tile;
             if (!more) break;
+        } else if constexpr (DIRECT && EPI == EPI_RESID) {
+            gl_epilogue_resid_direct<WGM, WGN, TM, TN>(g, acc, m0, n0);
+            break;
         } else if constexpr (DIRECT) {
             gl_epilogue_direct<WGM, WGN, TM, TN, EPI>(g, acc, m0, n0);
             break;
@@ -477,7 +552,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_glds_kernel(GemmArgs
 // persist: 0 = one tile per workgroup, 1 = persistent with the LDS epilogue (round 4), 2 = persistent (more than 256 tiles) with the DIRECT
 // register epilogue, 3 = the direct epilogue on one tile per workgroup
 template <int WGM, int WGN, int TM, int TN, int EPI>
-static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist = 0, bool stagger = false, bool asmfrag = false, bool rowblock_ok = false) {
+static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist = 0, bool stagger = false, bool asmfrag = false, bool rowblock_ok = false,
+                                  bool resid_direct = false) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int NOUT = (EPI == EPI_GLU) ? BN / 2 : BN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + NOUT - 1) / NOUT;
@@ -521,6 +597,26 @@ static void launch_gemm_bf16_glds(const GemmArgs &a, hipStream_t s, int persist 
         }
     }
     if (a.out_blocked) { fprintf(stderr, "parakeet_amd: internal error: blocked output on the LDS epilogue\n"); abort(); }
+    if constexpr (EPI == EPI_RESID) {
+        // the register residual epilogue (gl_resid_init / gl_epilogue_resid_direct): row-major fp32 in and out, whole 16-column groups, 32-bit offsets
+        const bool rd_ok = resid_direct && persist >= 2 && a.resid && a.alpha != 0.0f && !a.out_bf16 && !a.resid_init && a.sigma_cols == 0 && a.remap_rows == 0 &&
+                           (a.N % 16) == 0 && (a.ldo % 4) == 0 && (a.ldr % 4) == 0 && ((int64_t)(a.M + 31) * a.ldo < ((int64_t)1 << 31)) &&
+                           ((int64_t)(a.M + 31) * a.ldr < ((int64_t)1 << 31));
+        if (rd_ok) {
+            if (asmfrag) {
+                auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, true, false, true>;
+                static DynLdsSlots slots;
+                ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+                hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, 0);
+            } else {
+                auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, false, true>;
+                static DynLdsSlots slots;
+                ensure_dyn_lds(slots, reinterpret_cast<const void *>(kern), lds);
+                hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(64 * WGM * WGN), lds, s, a, tiles_n, n_tiles, 0);
+            }
+            return;
+        }
+    }
 #ifdef PK_EXPERIMENTAL
     if (persist == 1 && n_tiles > 256) {                                // more than one round of the 256 CUs: one persistent workgroup per CU
         auto kern = &gemm_bf16_glds_kernel<WGM, WGN, TM, TN, EPI, true>;

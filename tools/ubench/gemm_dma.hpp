@@ -112,6 +112,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(GemmArgs g, in
     float4 fa[2][TM], fb[2][TN];
     auto fragload = [&](int buf, int s, int slot) {            // sub-step s = k chunks 2s and 2s+1 = MFMA steps 4s .. 4s+3
         const float *base = smem + buf * BUF;
+#ifdef GD_B128_PROXY   // TIMING PROXY (round 6; wrong operands): what the loop would cost if BOTH operands lay in global memory in a k order whose 16-byte chunks
+        // are a lane's four consecutive MFMA steps (blocks of 8 k stored even-k-first) -- one ds_read_b128 per fragment instead of four 4-byte reads
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const float4 *>(base + (fa_base[i] - h) + ((8 * s + 4 * h) ^ fa_x[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const float4 *>(base + (fb_base[j] - h) + ((8 * s + 4 * h) ^ fb_x[j]));
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const float *p0 = base + fa_base[i] + ((8 * s) ^ fa_x[i]);

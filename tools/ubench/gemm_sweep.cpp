@@ -17,6 +17,7 @@
 #include "gemm_pd.hpp"
 #include "gemm_bf16p.hpp"
 #include "../../parakeet.cpp_amd/csrc/kernels/gemm_smallm.hip"   // first-generation kernel + launch_gemm
+#include "../../parakeet.cpp_amd/csrc/kernels/gemm_smallm_bf16.hip"   // (launch_gemm_bf16 routes small M there)
 
 using namespace pk;
 
