@@ -199,16 +199,17 @@ static void launch_one(const GemmArgs &a, hipStream_t s) {
 // products 128x64, everything else 64x64 (more resident workgroups to overlap one tile's epilogue with another's MFMAs).
 // Variant mask of the tile table.  Bits: 1 = long-K single-round products (fc2, sub_proj) on the single-buffered 128x128 / 8 waves of 32x64 /
 // BK 64 tile; 2 = wide outputs (fc1, qkv, sub_pw) single-buffered; 4 = out_proj / pw2 on sb 64x128 / 4 waves; 8 = GLU on sb; 16 = wide outputs
-// on sb BK 64; 64 = out_proj / pw2 on sb 128x128 / 8 waves.  75 = what the engine measurements of round 2 picked
+// on sb BK 64; 64 = out_proj / pw2 on sb 128x128 / 8 waves; 256 = the long-K single-round products (fc2, sub_proj) on 8 waves of 64x32 / BK 32 / sb (round 6: fc2 -1.4 %,
+// step -0.1 ms interleaved, profiles/r06_gemm_sweep_fc2_variants.txt).  331 = 75 + 256; 75 = what the engine measurements of round 2 picked
 // (profiles/r02_gemm_variant_ab.txt: step 20.44 -> 19.73 ms with 11; bit 4 is level; bit 64 takes out_proj / pw2 from 0.81 to 0.77 ms per step).
 // A production build has NO run-time switch: the mask is a constant.  Experiment builds (make EXPERIMENTAL=1 -> -DPK_EXPERIMENTAL) read
 // PK_GEMM_VARIANT for the interleaved A/B runs of tools/experiments/gemm_variant_ab.sh.
 static int gemm_variant_mask() {
 #ifdef PK_EXPERIMENTAL
-    static const int m = [] { const char *e = getenv("PK_GEMM_VARIANT"); return e ? atoi(e) : 75; }();
+    static const int m = [] { const char *e = getenv("PK_GEMM_VARIANT"); return e ? atoi(e) : 331; }();
     return m;
 #else
-    return 75;
+    return 331;
 #endif
 }
 
@@ -222,7 +223,9 @@ static void launch_epi(const GemmArgs &a, hipStream_t s) {
     // 8-wave workgroup per CU with BK = 64 -- half the barriers per k, nothing to share the CU with (-6 % vs two 128x64 workgroups)
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (a.M >= 1024 && a.N >= 256 && a.K >= 1024 && a.K % 64 == 0 && tiles128 <= 256) {
-        if (vm & 1) launch_gemm_pipe<4, 2, 1, 2, 64, EPI, 1>(a, s);
+        // bit 256 (round 6): 8 waves of 64 x 32, BK 32, single-buffered -- 2-3 % ahead of the BK 64 tile in the sweep (profiles/r06_gemm_sweep_fc2_variants.txt: 137 vs 140.5 us)
+        if (vm & 256) launch_gemm_pipe<2, 4, 2, 1, 32, EPI, 1>(a, s);
+        else if (vm & 1) launch_gemm_pipe<4, 2, 1, 2, 64, EPI, 1>(a, s);
         else launch_gemm_pipe<2, 4, 2, 1, 64, EPI>(a, s);
         return;
     }
