@@ -415,7 +415,7 @@ def test_stream_score_tiny_bit_identical_and_state_carried(tmp_path_factory, orc
 STREAM_SCORE = os.path.join(ROOT, "tests", "golden", "nemotron600m_stream_score_depth24_seed42.npz")
 S_LOGP_TOL, S_LOGP_MEAN = 3e-2, 8e-3   # bf16 streaming mode at depth 24: max / mean |log-prob(gpu) - log-prob(bf16 oracle)| along the oracle's path
 S_FP32_RATIO = 1.25                    # ... and its distance from the fp32 reference arithmetic, as a multiple of the bf16 oracle's own: the MAXIMUM (one value of ~14 k)
-S_FP32_RATIO_BODY = 1.10               # ... the mean and the 50th .. 99.9th percentiles of that distance (round 6: observed 0.99 .. 1.02)
+S_FP32_RATIO_BODY = 1.10               # ... the mean and the 50th .. 99.9th percentiles of that distance (round 6: observed 0.985 .. 1.013; <= 1.06 under every summation-order switch of the EXPERIMENTAL build)
 
 
 @pytest.fixture(scope="module")
