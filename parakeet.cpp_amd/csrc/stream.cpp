@@ -87,8 +87,8 @@ StreamBatch::StreamBatch(Model &m, int n_streams, int att_left, int att_right) :
             L.conv[i].reserve((size_t)S * (K - 1) * d * 4);
         }
     }
-    // (the tiled weight copies -- Model::sigma_weights, +1.2 / 2.4 GB for the 600M models -- are built by the first chunk whose row count takes
-    //  the small-M kernels, encode_device: a session set that never qualifies, e.g. 128 streams x 2 frames in the bf16 mode, never pays for them)
+    // (the tiled weight copies are built by the first chunk whose row count takes the small-M kernels, encode_device: a session set that never
+    //  qualifies, e.g. 128 streams x 2 frames in the bf16 mode, never pays for them -- round-5 advisor finding)
     dec_cap_frames_ = 64;                                           // encoder frames per chunk the decode workspace is sized for
     wd_.size_for(m_.cfg, S, 0, 8 * (dec_cap_frames_ - 1) + 1);
     reset();
@@ -192,6 +192,10 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     hipStream_t st = m_.stream;
     // CausalConvSubsampling::forward_cached (:348-385): prepend the leftover frames, consume a multiple of 8, keep the rest
     const int total = n_mel_cache_ + n_frames, consumable = (total / 8) * 8, leftover = total - consumable;
+    // The tiled weight copies (Model::sigma_weights: +1.2 / 2.4 GB for the 600M models) are built by the first chunk whose row count takes the small-M kernels
+    // -- HERE, before any carried state (mel leftovers, caches) is touched: an allocation failure leaves the streams exactly where they were.
+    // (rows of this chunk = S * consumable / 8: the three stride-2 stages of a multiple of 8 frames)
+    if (!sig_ && consumable > 0 && (int64_t)S * (consumable / 8) <= (cfg.gemm_bf16 ? kSmallMRowsBf16 : kSmallMRows)) sig_ = &m_.sigma_weights();
     mel_all_.reserve((size_t)S * (total > 0 ? total : 1) * F * 4);
     const size_t rowb = (size_t)F * 4;
     if (n_mel_cache_ > 0)
@@ -216,8 +220,7 @@ int StreamBatch::encode_device(const float *d_mel, int n_frames) {
     const int cache_rows = left_ > 0 ? left_ : 1;
     // rows <= kSmallMRows: every product of the chunk is a gemm_smallm chain -- run them on the sigma-K weight copies with sigma-K activations (the
     // producers below write that layout; x, the residual stream, stays natural)
-    if (!sig_ && rows <= (cfg.gemm_bf16 ? kSmallMRowsBf16 : kSmallMRows)) sig_ = &m_.sigma_weights();   // built once per model, on first use
-    const bool have_sig = sig_ && !sig_->empty();
+    const bool have_sig = sig_ && !sig_->empty();                  // (built at the top of this function by the first chunk that qualifies)
     const int sg = (!cfg.gemm_bf16 && rows <= kSmallMRows && have_sig) ? 1 : 0;
     // (tolerance-class mode: the copies are the bf16 operand tiles of the small-M bf16 kernel, GemmArgs::W_t16 -- a weight load reads one contiguous KB)
     const bool wt = cfg.gemm_bf16 && rows <= kSmallMRowsBf16 && have_sig;
