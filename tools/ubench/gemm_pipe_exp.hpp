@@ -292,13 +292,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) ad_nxt[q] = *reinterpret_cast<const float4 *>(p_ + 4 * q);
     };
+    // GP_EXP & 8192 (round 6, TIMING PROXY, results wrong): the W operand never passes through registers -- it goes global -> LDS by DMA (as if the weights had
+    // been copied once into a k order whose 16-byte chunks are a lane's four MFMA steps), two K tiles ahead into the free buffer of the DOUBLE-buffered loop; only
+    // the A rows keep the global -> VGPR -> ds_write staging.  Half the staging loads and stores of a K tile for BN / 8 / waves DMA instructions per wave.
+    constexpr bool WDMA = (GP_EXP & 8192) != 0 && NBUF == 2 && BK == 32;
+    auto wdma = [&](int kt, int buf, int n0) {
+        if constexpr (WDMA) {
+            constexpr int NWV = NT / 64, NBLK_W = BN / 8;             // 1 KB blocks (8 rows x 32 k) of the W tile
+            const int wv_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+            for (int i = 0; i < (NBLK_W + NWV - 1) / NWV; ++i) {
+                const int b_ = wv_ + NWV * i;
+                if (b_ < NBLK_W) {
+                    int wr_ = n0 + 8 * b_ + (lane >> 3);
+                    wr_ = wr_ < g.N ? wr_ : g.N - 1;
+                    const float *src_ = g.W + (int64_t)wr_ * g.ldw + kt * BK + 4 * (lane & 7);
+                    float *dst_ = smem + buf * BUF + BM * PITCH + b_ * 256;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_, (__attribute__((address_space(3))) void *)dst_, 16, 0, 0);
+                }
+            }
+        }
+    };
     auto gload = [&](int kt) {
         if (!ADIR) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const float4 *>(a_src[i] + kt * BK);
         }
+        if constexpr (!WDMA) {
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) rw[i] = *reinterpret_cast<const float4 *>(w_src[i] + kt * BK);
+        }
     };
     // Staging stores: {a, b} at p, {c, d} at p + BK/2 floats.  FOUR 4-byte stores, not one ds_write2_b64: on gfx950 the finer the LDS store
     // next to the fragment reads, the less it costs the loop -- 16-byte stores 98 TF, 8-byte pairs 134, 4-byte stores 141 TF of the 145 TF
@@ -322,8 +345,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) st2(base + a_dst[i], ra[i].x, ra[i].z, ra[i].y, ra[i].w);       // k = 4c, 4c+2 | k = 4c+1, 4c+3
         }
+        if constexpr (!WDMA) {
 #pragma unroll
         for (int i = 0; i < W_CH; ++i) st2(base + w_dst[i], rw[i].x, rw[i].z, rw[i].y, rw[i].w);
+        }
     };
 
     gp_f32x16 acc[TM][TN];
@@ -383,8 +408,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
     GP_STAMP(0);
     set_tile(blockIdx.x, m0, n0);
     gload(0);
+    if constexpr (WDMA) { wdma(0, 0, n0); wdma(1, 1, n0); }
     lstore(0);
     lds_store_fence();
+    if constexpr (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     GP_STAMP(1);
     gload(1);                      // nk >= 2 (K >= 2*BK, checked by the launcher)
@@ -450,7 +477,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pipe_kernel(GemmArgs g, i
 #endif
             if (!(GP_EXP & 64) && more1) fragload(cur ^ 1, 0, 0);
             if (!(GP_EXP & 32) && more2) gload(kt + 2);
+            if (WDMA && more2) wdma(kt + 2, cur, n0);               // (buffer `cur` is free: every wave holds its last fragments of tile kt)
             GP_SB(); if (!(GP_EXP & 128)) mma((NSUB - 1) & 1); GP_SB();
+            if constexpr (WDMA) {   // the DMA of tile kt + 1 (issued an iteration ago) must have landed before the next barrier publishes it; what was issued THIS iteration may fly on
+                constexpr int NEWER = A_CH + (BN / 8 + NT / 64 - 1) / (NT / 64);
+                if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             cur ^= 1;
         }
     }
