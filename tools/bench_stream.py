@@ -91,16 +91,26 @@ def main():
     st = capi.Stream(m, a.streams, 70, a.latency_frames)
     n = a.chunk_samples
     pcm = synth.synth_pcm(a.streams, n * (a.warmup + a.chunks), seed=99)
+    segs = [np.ascontiguousarray(pcm[:, i * n:(i + 1) * n]) for i in range(a.warmup + a.chunks)]      # (sliced before the clock starts)
     lat, toks = [], 0
-    for i in range(a.warmup + a.chunks):
-        seg = np.ascontiguousarray(pcm[:, i * n:(i + 1) * n])
-        t0 = time.perf_counter()
-        r = st.push(seg)
-        dt = time.perf_counter() - t0
-        if i >= a.warmup:
-            lat.append(dt)
-            toks += int(r["lens"].sum())
+    # The timed loop runs with the cyclic garbage collector off: a chunk is ~1.8 ms, a generation-2 collection of this process (numpy, torch and ctypes
+    # objects of the set-up) is of that order -- round 5's driver run had p95 2.25 ms against a 1.835 median that no box here reproduced (p95 1.83-1.85).
+    # p99 / max / the five slowest chunks ride in the line so that a tail, if one shows again, can be told from a uniform slowdown.
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        for i in range(a.warmup + a.chunks):
+            t0 = time.perf_counter()
+            r = st.push(segs[i])
+            dt = time.perf_counter() - t0
+            if i >= a.warmup:
+                lat.append(dt)
+                toks += int(r["lens"].sum())
+    finally:
+        gc.enable()
     lat = np.array(lat)
+    worst = np.argsort(lat)[-5:][::-1]
     chunk_s = n / 16000.0
     # bytes of encoder product weights one chunk streams (every Linear / 1x1-conv of every block, read once per chunk: 1.2 / 2.4 GB for the 600M models)
     d, f, L = cfg.hidden_size, cfg.ffn_intermediate, cfg.num_layers
@@ -108,6 +118,8 @@ def main():
     out = {"metric": f"streaming {a.config}: per-chunk latency and aggregate RTFx, {a.streams} lock-step streams/GPU, att_context_right={a.latency_frames}",
            "streams": a.streams, "chunk_ms": chunk_s * 1e3, "latency_ms_median": round(float(np.median(lat)) * 1e3, 3),
            "latency_ms_p95": round(float(np.percentile(lat, 95)) * 1e3, 3), "latency_ms_mean": round(float(lat.mean()) * 1e3, 3),
+           "latency_ms_p99": round(float(np.percentile(lat, 99)) * 1e3, 3), "latency_ms_max": round(float(lat.max()) * 1e3, 3),
+           "slowest_chunks": [[int(i), round(float(lat[i]) * 1e3, 3)] for i in worst],
            "aggregate_rtfx": round(a.streams * chunk_s / float(lat.mean()), 1),
            "encoder_weight_mbytes_per_chunk": round(wbytes / 1e6, 1), "weight_stream_tbps": round(wbytes / float(np.median(lat)) / 1e12, 3), "tokens_emitted": toks, "chunks": a.chunks,
            "dtype": "bf16 operands / f32 accumulate (tolerance-class mode)" if a.bf16 else "f32", "data": "synthetic"}
