@@ -217,10 +217,19 @@ void launch_joint_act(const float *ep, const int *t, int T, int J, const float *
 // BOOST (phrase boosting, src/phrase_boost.cpp:177-350): the label argmax runs over log-prob + boost for the tokens that continue
 // an active trie state (a V-bit mask in LDS, rebuilt from the CSR children every step); the confidence stays the raw log-prob
 // and the active set advances on every emission.
-template <bool BOOST, bool SCORE = false>
+template <bool BOOST, bool SCORE = false, bool FAST = false>
 __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // x[V+D], e[V+D], scratch[16] (+ BOOST: mask, active sets)
-    tdt_decide_one<BOOST, false, SCORE>(st, blockIdx.x, sm);
+    tdt_decide_one<BOOST, false, SCORE, FAST>(st, blockIdx.x, sm);
+}
+// The tolerance-class mode's plain greedy step on the register-resident form (decode_dev.hpp: FAST).  EXPERIMENTAL builds: PK_DEC_FAST=0 keeps the exact form.
+static bool decide_fast_on() {
+#ifdef PK_EXPERIMENTAL
+    static const bool on = [] { const char *e = getenv("PK_DEC_FAST"); return e ? atoi(e) != 0 : true; }();
+    return on;
+#else
+    return true;
+#endif
 }
 void launch_tdt_decide(const TdtState &st, hipStream_t s) {
     const size_t lds = (size_t)(2 * (st.V + st.D) + 16) * sizeof(float);
@@ -229,6 +238,8 @@ void launch_tdt_decide(const TdtState &st, hipStream_t s) {
         hipLaunchKernelGGL(tdt_decide_kernel<true>, dim3(st.B), dim3(256), lds + extra, s, st);
     } else if (st.force_label) {
         hipLaunchKernelGGL((tdt_decide_kernel<false, true>), dim3(st.B), dim3(256), lds, s, st);      // pk_tdt_score
+    } else if (st.h_bf16 && st.V + st.D <= 33 * 256 && st.V >= 2 && decide_fast_on()) {
+        hipLaunchKernelGGL((tdt_decide_kernel<false, false, true>), dim3(st.B), dim3(256), lds, s, st);
     } else {
         hipLaunchKernelGGL(tdt_decide_kernel<false>, dim3(st.B), dim3(256), lds, s, st);
     }

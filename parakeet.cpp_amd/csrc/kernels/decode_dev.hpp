@@ -297,8 +297,14 @@ __device__ __forceinline__ BestLP wave_logsoftmax_argmax(const float *__restrict
 // active sets).  COH: the words other workgroups of the same launch wrote / will read go through system-scope accesses.
 // SCORE: the teacher-forced form (pk_tdt_score, TdtState::force_label) -- compiled as its own kernel so that the decode loop's decision
 // kernel carries none of it (round 4: with the scoring code inline the V = 8193 decision went from 15.2 to 17.3 us per launch).
-template <bool BOOST, bool COH, bool SCORE = false>
+// FAST (round 6; round-5 verdict item 6): the tolerance-class mode's plain greedy step (TdtState::h_bf16, no boosting, no forced scoring).  The logits row stays in
+// REGISTERS after its one round trip: row maximum, sum of hardware exp2, arg-maximum (of the raw logits: log-softmax is monotone) and runner-up are per-thread
+// scans over the registers + ONE cross-wave exchange -- two barriers in all, no LDS sweep over the vocabulary (the exact form: four barriers and three sweeps, the
+// canonical single-wave sum64 among them; 17 us per step at vocabulary 8193).  Not bit-identical to the exact form (summation order, exp, ties of ROUNDED
+// log-probs): only where the mode is compared within a tolerance.  The duration head and everything behind the decision are the same code.
+template <bool BOOST, bool COH, bool SCORE = false, bool FAST = false>
 __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float *sm) {
+    static_assert(!FAST || (!BOOST && !COH && !SCORE), "the fast decision is the plain greedy step of the launch-per-phase loop");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (dd_ldi<COH>(st.done + b)) return;
     int n_force = 0;                                               // SCORE: steps of this utterance's given path, first element of its arrays
@@ -345,6 +351,88 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             if (i < n_h) hcar[q] = st.hn[((int64_t)(i / hp_h) * st.B + b) * hp_h + (i % hp_h)];
         }
     }
+    BestLP lab{0.0f, 0};
+    float sec = -__builtin_huge_valf();
+    int skip = 1;
+    if constexpr (FAST) {
+      auto fast = [&](auto nq_tag) {
+        constexpr int NQ = decltype(nq_tag)::value;                 // VD <= NQ x 256 (33: launch_tdt_decide checks)
+        float v[NQ];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int i = tid + 256 * u;
+            v[u] = lg[i < VD ? i : VD - 1];
+        }
+        float mx = -__builtin_huge_valf(), s2 = -__builtin_huge_valf();
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {                              // maximum, first arg-maximum and runner-up of this thread's values (increasing index)
+            const int i = tid + 256 * u;
+            if (i < st.V) {
+                if (v[u] > mx) { s2 = mx; mx = v[u]; bi = i; }
+                else s2 = fmaxf(s2, v[u]);
+            } else if (i < VD) {
+                x[i] = v[u];                                        // the few duration logits: wave 1 reads them from LDS below
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ob = __shfl_xor(mx, off, 64), os = __shfl_xor(s2, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            const bool take = ob > mx || (ob == mx && oi < bi);
+            s2 = fmaxf(fmaxf(s2, os), take ? mx : ob);
+            if (take) { mx = ob; bi = oi; }
+        }
+        if (lane == 0) { red[wave] = mx; red[8 + wave] = s2; red[12 + wave] = __int_as_float(bi); }
+        __syncthreads();
+        float m = red[0], s2b = red[8];
+        int bib = __float_as_int(red[12]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ob = red[w], os = red[8 + w];
+            const int oi = __float_as_int(red[12 + w]);
+            const bool take = ob > m || (ob == m && oi < bib);
+            s2b = fmaxf(fmaxf(s2b, os), take ? m : ob);
+            if (take) { m = ob; bib = oi; }
+        }
+        float p = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int i = tid + 256 * u;
+            if (i < st.V) p += __builtin_amdgcn_exp2f((v[u] - m) * 1.44269502162933349609375f);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
+        if (lane == 0) red[4 + wave] = p;                           // (red[4 .. 7]: the waves' partial sums)
+        if (wave == 1 && st.D > 0) {                                // duration head: a few values, one wavefront (the exact form's code)
+            const BestLP dur = wave_logsoftmax_argmax(x + st.V, st.D, e + st.V, lane);
+            if (lane == 0) e[0] = (float)(dur.idx < st.D ? st.durations[dur.idx] : 1);          // (e[0 .. V) is free in this form: the skip, the duration margin)
+            if (st.margin) {
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                float second = -__builtin_huge_valf();
+                for (int i = lane; i < st.D; i += 64)
+                    if (i != dur.idx) second = fmaxf(second, e[st.V + i]);
+                second = wave_max64(second);
+                if (lane == 0) e[1] = st.D > 1 ? dur.lp - second : __builtin_huge_valf();
+            }
+        }
+        __syncthreads();
+        const float lse = dlogf((red[4] + red[5]) + (red[6] + red[7]));
+        lab.idx = bib;
+        lab.lp = 0.0f - lse;                                        // (x_best - m) - lse with x_best == m
+        sec = (s2b - m) - lse;
+        if (st.margin && tid == 0) {
+            float mg = lab.lp - sec;
+            if (st.D > 0) mg = fminf(mg, e[1]);
+            const float old = st.margin[b];
+            st.margin[b] = mg < old ? mg : old;
+        }
+        if (st.D > 0) skip = (int)e[0];
+      };
+      if (VD <= 256 * 5) fast(std::integral_constant<int, 5>{});
+      else fast(std::integral_constant<int, 33>{});
+    } else {
     float m = -__builtin_huge_valf();
     // The logits row with ALL of a thread's loads in flight at once (one L2 / HBM round trip): written as a plain loop, every iteration
     // waited for its own trip -- 33 dependent trips at vocabulary 8193, 26 us for ~3 us of arithmetic (round 3).  Rows longer than 33 x 256
@@ -422,7 +510,6 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         const float lse = dlogf(wave_sum64(p));
         if (lane == 0) red[4] = lse;
     }
-    int skip = 1;
     if (wave == 1 && st.D > 0) {                                   // duration head: a few values, one wavefront
         const BestLP dur = wave_logsoftmax_argmax(x + st.V, st.D, e + st.V, lane);      // (log-probs into the free tail of e[]: read back for the margin)
         if (lane == 0) red[5] = (float)(dur.idx < st.D ? st.durations[dur.idx] : 1);
@@ -469,8 +556,8 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     }
     if (lane == 0) { red[8 + wave] = best; red[12 + wave] = __int_as_float(bi); red[wave] = second; }   // (red[0..3]: the wave maxima were consumed two barriers ago)
     __syncthreads();
-    BestLP lab{red[8], __float_as_int(red[12])};
-    float sec = red[0];
+    lab = BestLP{red[8], __float_as_int(red[12])};
+    sec = red[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
         const float ob = red[8 + w];
@@ -502,6 +589,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             if (st.D > 0) skip = st.durations[st.force_dur[force_off + k]];
         }
     }
+    }                                                               // (exact form)
     const int lane0 = tid;                                         // thread 0 writes the scalar state
     // scalar control (wave-uniform values; lane 0 writes)
     int t = t_in;
