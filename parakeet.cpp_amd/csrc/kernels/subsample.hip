@@ -121,6 +121,122 @@ __global__ __launch_bounds__(256) void sub_conv1_dw1_kernel(const float *__restr
     }
 }
 
+// Round 6: the same computation with TWO adjacent channels per thread on packed fp32 instructions.  The one-channel kernel is VALU-bound (SQ counters: the vector
+// ALUs ~90 % busy at four waves per SIMD) and every one of its fmas is a scalar-per-lane v_fma_f32 -- half the vector fp32 rate -- fed by one broadcast LDS read per
+// window value.  Here a lane carries channels (c, c + 1): weights, accumulators and the three conv1 rows are 2-vectors, the window value is the SAME for both
+// halves, so every tap is ONE v_pk_fma_f32 (weight pair, splat operand, accumulator pair) and one LDS read serves two channels; outputs leave as 8-byte stores.
+// Each half is the identical IEEE fma chain in the identical tap order: bit-identical results (tests/test_gpu_encoder.py, test_gpu_ragged.py).  Chunks of XC = 4
+// output columns (three rows of 9 two-vectors: 122 VGPRs, four waves per SIMD; chunks of 5 need 132 and measured 8 % slower).  80 mel bins: 0.250 -> 0.183 ms per
+// 64 x 10 s batch, 128 bins: 0.561 -> 0.420 ms per 32 x 30 s batch (profiles/r06_sub_conv_packed_ab.txt).
+template <int XC, int YS = 8>
+__global__ __launch_bounds__(256) void sub_conv1_dw1_c2_kernel(const float *__restrict__ feats, int Tm, int F, int C,
+                                                               const float *__restrict__ w1 /*[9][C]*/, const float *__restrict__ b1,
+                                                               const float *__restrict__ wd /*[9][C]*/, const float *__restrict__ bd,
+                                                               int H1, int W1, int H2, int W2, int n_xc, int n_ys, int64_t n_strips,
+                                                               float *__restrict__ out, SubRag rg) {
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    constexpr int NC = 2 * XC + 1;
+    constexpr int WR = 4 * YS + 3, WC = 4 * XC + 3, PW = (WC + 3) & ~3, TILE = WR * PW;   // input window per strip
+    extern __shared__ __attribute__((aligned(16))) float win[];       // [spb][WR][PW]
+    const int C2 = C >> 1, spb = 256 / C2;                             // threads per strip (two channels each), strips per block
+    for (int e = threadIdx.x; e < spb * TILE; e += 256) {              // window row wr <-> input row 4*y2_0 - 3 + wr, column wc <-> 4*x2_0 - 3 + wc
+        const int sl = e / TILE, rem = e % TILE, wr = rem / PW, wc = rem % PW;
+        const int64_t strip = (int64_t)blockIdx.x * spb + sl;
+        float v = 0.0f;
+        if (strip < n_strips && wc < WC) {
+            const int xc = (int)(strip % n_xc);
+            int y2s, tm_b;
+            int64_t frame0;
+            if (rg.strips.u) {
+                const RagUnit un = rg.strips.u[strip / n_xc];
+                y2s = un.r0; tm_b = rg.Tm[un.b]; frame0 = rg.Tm_off[un.b];
+            } else {
+                const int b = (int)(strip / ((int64_t)n_xc * n_ys));
+                y2s = (int)((strip / n_xc) % n_ys) * YS; tm_b = Tm; frame0 = (int64_t)b * Tm;
+            }
+            const int iy = 4 * y2s - 3 + wr, ix = 4 * xc * XC - 3 + wc;
+            if (iy >= 0 && iy < tm_b && ix >= 0 && ix < F) v = feats[(frame0 + iy) * F + ix];
+        }
+        win[e] = v;
+    }
+    __syncthreads();
+    const int c = 2 * (threadIdx.x % C2), sl = threadIdx.x / C2;
+    const int64_t strip = (int64_t)blockIdx.x * spb + sl;
+    if (strip >= n_strips) return;
+    const int xc = (int)(strip % n_xc);
+    int y2_0;
+    int64_t orow0;
+    if (rg.strips.u) {
+        const RagUnit un = rg.strips.u[strip / n_xc];
+        y2_0 = un.r0;
+        const int tm_b = rg.Tm[un.b];
+        H1 = (tm_b - 1) / 2 + 1;
+        H2 = rg.H2[un.b];
+        orow0 = rg.H2_off[un.b];
+    } else {
+        const int b = (int)(strip / ((int64_t)n_xc * n_ys));
+        y2_0 = (int)((strip / n_xc) % n_ys) * YS;
+        orow0 = (int64_t)b * H2;
+    }
+    const int x2_0 = xc * XC, x1_0 = 2 * x2_0 - 1;                     // r[j] holds conv1 column x1_0 + j
+    const float *tile = win + sl * TILE;
+    f2_ k1[9], kd[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float2 a = *reinterpret_cast<const float2 *>(w1 + i * C + c), d2 = *reinterpret_cast<const float2 *>(wd + i * C + c);
+        k1[i] = f2_{a.x, a.y}; kd[i] = f2_{d2.x, d2.y};
+    }
+    const float2 b1v = *reinterpret_cast<const float2 *>(b1 + c), bdv = *reinterpret_cast<const float2 *>(bd + c);
+    const f2_ bias1 = {b1v.x, b1v.y}, biasd = {bdv.x, bdv.y};
+    f2_ r0[NC], r1[NC], r2[NC];
+    auto conv_row = [&](int q, f2_ (&r)[NC]) {                       // conv1 + ReLU (src/encoder.cpp:223-224) of conv1 row y1 = 2*y2_0 - 1 + q
+        const int y1 = 2 * y2_0 - 1 + q;
+        const float *rp = tile + 2 * q * PW;
+        const bool row_ok = y1 >= 0 && y1 < H1;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            f2_ acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int jy = 0; jy < 3; ++jy)
+#pragma unroll
+                for (int jx = 0; jx < 3; ++jx) {
+                    const float v = rp[jy * PW + 2 * j + jx];
+                    acc = __builtin_elementwise_fma(k1[jy * 3 + jx], f2_{v, v}, acc);
+                }
+            f2_ v = acc + bias1;
+            v.x = v.x > 0.0f ? v.x : 0.0f;                             // ReLU :224
+            v.y = v.y > 0.0f ? v.y : 0.0f;
+            const int x1 = x1_0 + j;
+            r[j] = (row_ok && x1 >= 0 && x1 < W1) ? v : f2_{0.0f, 0.0f};
+        }
+    };
+    for (int yy = 0; yy < YS; ++yy) {
+        const int y2 = y2_0 + yy;
+        if (y2 >= H2) break;
+        if (yy == 0) {
+            conv_row(0, r0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) r0[j] = r2[j];
+        }
+        conv_row(2 * yy + 1, r1);
+        conv_row(2 * yy + 2, r2);
+        float *orow = out + ((orow0 + y2) * W2 + x2_0) * C + c;
+#pragma unroll
+        for (int xl = 0; xl < XC; ++xl) {
+            f2_ acc2 = {0.0f, 0.0f};                                   // dw1 :226, taps in (ky,kx) order
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc2 = __builtin_elementwise_fma(kd[kx], r0[2 * xl + kx], acc2);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc2 = __builtin_elementwise_fma(kd[3 + kx], r1[2 * xl + kx], acc2);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc2 = __builtin_elementwise_fma(kd[6 + kx], r2[2 * xl + kx], acc2);
+            const f2_ o = acc2 + biasd;
+            if (x2_0 + xl < W2) *reinterpret_cast<float2 *>(orow + (int64_t)xl * C) = make_float2(o.x, o.y);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sub_dw_kernel(const float *__restrict__ in, int H, int W, int C,
                                                      const float *__restrict__ wd /*[9][C]*/, const float *__restrict__ bd,
                                                      int Ho, int Wo, int64_t n_pix, float *__restrict__ out, SubRag rg) {
@@ -165,6 +281,27 @@ static void launch_c1d1(const float *feats, int B, int Tm, int F, int C, const f
     hipLaunchKernelGGL((sub_conv1_dw1_kernel<XC, YS>), dim3((unsigned)((n_strips + spb - 1) / spb)), dim3(256), lds, s, feats, Tm, F, C, w1, b1,
                        wd, bd, H1, W1, H2, W2, n_xc, n_ys, n_strips, out, rag);
 }
+template <int XC, int YS = 8>
+static void launch_c1d1_c2(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
+                           const float *bd, int H1, int W1, int H2, int W2, float *out, hipStream_t s, const SubRag &rag) {
+    constexpr int WR = 4 * YS + 3, PW = (4 * XC + 3 + 3) & ~3;
+    const int spb = 256 / (C / 2), n_ys = (H2 + YS - 1) / YS, n_xc = (W2 + XC - 1) / XC;
+    const int64_t n_strips = rag.strips.u ? (int64_t)rag.strips.count * n_xc : (int64_t)B * n_ys * n_xc;
+    const size_t lds = (size_t)spb * WR * PW * sizeof(float);
+    static DynLdsSlots slots;
+    ensure_dyn_lds(slots, reinterpret_cast<const void *>(&sub_conv1_dw1_c2_kernel<XC, YS>), lds);
+    hipLaunchKernelGGL((sub_conv1_dw1_c2_kernel<XC, YS>), dim3((unsigned)((n_strips + spb - 1) / spb)), dim3(256), lds, s, feats, Tm, F, C, w1, b1,
+                       wd, bd, H1, W1, H2, W2, n_xc, n_ys, n_strips, out, rag);
+}
+// the two-channel packed kernel on batches (EXPERIMENTAL builds: PK_SUB_C2=0 keeps the one-channel kernel)
+static bool sub_c2_on() {
+#ifdef PK_EXPERIMENTAL
+    static const bool on = [] { const char *e = getenv("PK_SUB_C2"); return e ? atoi(e) != 0 : true; }();
+    return on;
+#else
+    return true;
+#endif
+}
 static constexpr int64_t kSmallStripRows = 1024;
 int sub_conv1_dw1_strip_rows(int64_t total_h2_rows) { return total_h2_rows <= kSmallStripRows ? 2 : 8; }
 void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const float *w1, const float *b1, const float *wd,
@@ -177,11 +314,15 @@ void launch_sub_conv1_dw1(const float *feats, int B, int Tm, int F, int C, const
     // (1.5x the conv1 work, four times the workgroups, a quarter of the serial chain each: 77 -> ~25 us for one 10 s clip)
     // (ragged batch: the caller built rag.strips with rag.strip_rows = sub_conv1_dw1_strip_rows(total H2 rows) rows per unit)
     const bool small = rag.strips.u ? rag.strip_rows == 2 : (int64_t)B * H2 <= kSmallStripRows;
+    // batches: two channels per thread on packed fp32 (sub_conv1_dw1_c2_kernel), chunks of 4 columns; C even with 256 % (C / 2) == 0 (8-byte aligned weight pairs)
+    const bool c2 = !small && sub_c2_on() && C % 2 == 0 && C >= 64 && 256 % (C / 2) == 0;
     if (W2 <= 20 || W2 % 20 == 0) {
         if (small) launch_c1d1<20, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
+        else if (c2) launch_c1d1_c2<4>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
         else launch_c1d1<10>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
     } else {
         if (small) launch_c1d1<16, 2>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
+        else if (c2) launch_c1d1_c2<4>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
         else launch_c1d1<8>(feats, B, Tm, F, C, w1, b1, wd, bd, H1, W1, H2, W2, out, s, rag);
     }
 }
