@@ -1116,6 +1116,19 @@ void Model::run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_lo
                            w.start.as<int>(), w.end.as<int>(), w.conf.as<float>(), s, pitch, seq));
 }
 
+// Frame window of the small-batch decode loop (TdtState::F): the largest lock-step batch that gets one.  Measured (profiles/r06_dec_window_ab.txt, pk_transcribe_pcm,
+// median of 100 calls): one clip 4.96-5.00 -> 4.84 ms on the benchmark's clips (81 tokens in 112 decisions: a blank-poor case); two clips no change; four clips
+// + 4 % (the walked decisions of one utterance hold up the step of the other three, and a window of four frames ends at the first long blank) -> single
+// utterances only.  EXPERIMENTAL builds: PK_DEC_WIN=<largest batch> (0: off).
+static int decode_window_rows() {
+#ifdef PK_EXPERIMENTAL
+    static const int n = [] { const char *e = getenv("PK_DEC_WIN"); return e ? atoi(e) : 1; }();
+    return n;
+#else
+    return 1;
+#endif
+}
+
 // tdt_greedy_decode(_with_timestamps) / rnnt_greedy_decode  (src/tdt.cpp:36-201, src/rnnt.cpp:56-177)
 // enc_proj_ hoisted out of the symbol loop: one GEMM over all frames (the reference recomputes it per symbol, src/tdt.cpp:17)
 void Model::run_enc_proj(const float *d_enc, int64_t rows, float *ep_out, hipStream_t s) {
@@ -1176,8 +1189,16 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         st.need = ib + 6 * B + 8;                                    // (behind done_count and the persistent loop's two spare words)
         st.pp = w.pp.as<float>();
         st.ep = w.ep.as<float>();
-        st.z = w.z.as<float>();
         st.J = J;
+        // Frame window (TdtState::F): at B <= 8 the heads product's 16-row tile has room for the joint of the next frames under the unchanged prediction-net
+        // state, and the decision kernel walks through the blanks inside it.  Offline greedy decode of the exact fp32 phases only.
+        const bool dec16_ = cfg.gemm_bf16 && Hp % 32 == 0 && J % 32 == 0 && wld16;
+        if (B <= decode_window_rows() && !keep_state && !boost_on && !w.force_label && !dec16_ && !dec_nt_weights && J <= 1024 && V + D <= 5 * 256)
+            st.F = B <= 2 ? 8 : B <= 4 ? 4 : B <= 8 ? 2 : 1;
+        w.z.reserve((size_t)B * st.F * J * sizeof(float));
+        w.logits.reserve((size_t)B * st.F * (V + D) * sizeof(float));
+        st.logits = w.logits.as<float>();
+        st.z = w.z.as<float>();
     }
     if (!keep_state) {                                               // a streaming chunk continues from the carried LSTM state
         PK_HIP(hipMemsetAsync(w.h.p, 0, (size_t)L * B * Hp * 4, s));
@@ -1208,10 +1229,11 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         SkinnyArgs &a = P.act;
         a.X = w.hn.as<float>() + (size_t)(L - 1) * B * Hp; a.W = dec_wp_s; a.B = B; a.N = J; a.K = Hp; a.bias = dec.bp;
         a.out = w.z.as<float>(); a.ep = w.ep.as<float>(); a.t = st.t; a.T = T; a.Tb = st.Tb; a.row0 = st.row0;
+        a.F = st.F;
     }
     {
         SkinnyArgs &a = P.heads;
-        a.X = w.z.as<float>(); a.W = wld_s; a.B = B; a.N = V + D; a.K = J; a.bias = bld; a.out = w.logits.as<float>(); a.ldo = V + D;
+        a.X = w.z.as<float>(); a.W = wld_s; a.B = B * st.F; a.N = V + D; a.K = J; a.bias = bld; a.out = w.logits.as<float>(); a.ldo = V + D;   // (rows b * F + f)
     }
     for (int l = 0; l < L; ++l) P.cell[l].nt_weights = dec_nt_weights;
     P.act.nt_weights = P.heads.nt_weights = dec_nt_weights;
@@ -1264,7 +1286,10 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     // host polls "all finished" every `chunk` steps: 16 for whole utterances (4 / 64 / 128 measured: no difference, profiles/r02_decode_persistent.md);
     // a streaming chunk of 1-3 frames is done after T + (symbols of its busiest stream) steps -- every step launched beyond that is four no-op
     // kernels of ~6 us each, more than the poll costs
-    const int chunk = T + 2 < 4 ? 4 : (T + 2 < 16 ? T + 2 : 16);
+    int chunk = T + 2 < 4 ? 4 : (T + 2 < 16 ? T + 2 : 16);
+#ifdef PK_EXPERIMENTAL
+    { static const int c = [] { const char *e = getenv("PK_DEC_CHUNK"); return e ? atoi(e) : 0; }(); if (c > 0) chunk = c; }
+#endif
     auto skinny = [&](const SkinnyArgs &a, int epi) { if (dec16) launch_skinny_gemm_bf16(a, epi, s); else launch_skinny_gemm(a, epi, s); };
     auto enqueue_step = [&]() {
         for (int l = 0; l < L; ++l) {
@@ -1283,7 +1308,7 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         std::vector<unsigned char> key;
         auto put = [&key](const void *p, size_t n) { const unsigned char *c = static_cast<const unsigned char *>(p); key.insert(key.end(), c, c + n); };
         const void *ptrs[] = {this, s, st.logits, st.h, st.c, st.hn, st.cn, st.token, st.lens, st.ids, st.start, st.end, st.conf, P.act.ep, P.heads.W, P.act.W, P.cell[0].W, P.cell[0].gi, st.Tb, st.row0};
-        const int ints[] = {B, T, V, D, L, Hp, J, max_tokens, st.blank, st.max_symbols, st.max_steps, st.keep_state, boost_on ? 1 : 0, pred_cache ? 1 : 0};
+        const int ints[] = {B, T, V, D, L, Hp, J, max_tokens, st.blank, st.max_symbols, st.max_steps, st.keep_state, boost_on ? 1 : 0, pred_cache ? 1 : 0, st.F};
         put(ptrs, sizeof ptrs);
         put(ints, sizeof ints);
         if (!w.dec_graph || key != w.dec_graph_key) {

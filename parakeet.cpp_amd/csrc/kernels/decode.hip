@@ -9,6 +9,8 @@
 //        gemm  PP = h' W_pred^T         (MFMA)           -> joint_act   z = relu(enc_proj[t_b] + PP)
 //        gemm  LOG = z [W_label;W_dur]^T + b (MFMA)      -> tdt_decide  log-softmax, argmax, control,
 //                                                                        commit / revert of the LSTM state
+#include <cstdio>
+#include <cstdlib>
 #include "decode_dev.hpp"
 
 namespace pk {
@@ -107,12 +109,11 @@ __global__ __launch_bounds__(256) void ctc_boosted_kernel(const float *__restric
             const float v = frame[i] + (((mask[i >> 5] >> (i & 31)) & 1u) ? trie.boost : 0.0f);
             if (bi == 0x7fffffff || v > best) { best = v; bi = i; }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ob = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
+        wave_butterfly([&](auto off) {
+            const float ob = wave_xor<decltype(off)::value>(best);
+            const int oi = wave_xor_i<decltype(off)::value>(bi);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
+        });
         float *rd = red + 8 * (t & 1);                               // double-buffered: one barrier per frame
         if (lane == 0) { rd[wave] = best; rd[4 + wave] = __int_as_float(bi); }
         __syncthreads();
@@ -217,10 +218,10 @@ void launch_joint_act(const float *ep, const int *t, int T, int J, const float *
 // BOOST (phrase boosting, src/phrase_boost.cpp:177-350): the label argmax runs over log-prob + boost for the tokens that continue
 // an active trie state (a V-bit mask in LDS, rebuilt from the CSR children every step); the confidence stays the raw log-prob
 // and the active set advances on every emission.
-template <bool BOOST, bool SCORE = false, bool FAST = false>
+template <bool BOOST, bool SCORE = false, bool FAST = false, int NC = 12>
 __global__ __launch_bounds__(256) void tdt_decide_kernel(TdtState st) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // x[V+D], e[V+D], scratch[16] (+ BOOST: mask, active sets)
-    tdt_decide_one<BOOST, false, SCORE, FAST>(st, blockIdx.x, sm);
+    tdt_decide_one<BOOST, false, SCORE, FAST, NC>(st, blockIdx.x, sm);
 }
 // The tolerance-class mode's plain greedy step on the register-resident form (decode_dev.hpp: FAST).  EXPERIMENTAL builds: PK_DEC_FAST=0 keeps the exact form.
 static bool decide_fast_on() {
@@ -232,16 +233,23 @@ static bool decide_fast_on() {
 #endif
 }
 void launch_tdt_decide(const TdtState &st, hipStream_t s) {
-    const size_t lds = (size_t)(2 * (st.V + st.D) + 16) * sizeof(float);
+    const size_t lds = (size_t)(((st.F > 1 ? st.F : 1) + 1) * (st.V + st.D) + 16) * sizeof(float);     // (frame window: its F rows in front of the scratch)
+    if (st.F > 1 && (st.V + st.D > 5 * 256 || st.F > kDecWindowMax || st.trie.off || st.force_label || st.h_bf16)) {
+        fprintf(stderr, "parakeet_amd: decode window outside its conditions -- engine bug\n"); abort();
+    }
     if (st.trie.off) {
         const size_t extra = (size_t)((st.V + 31) / 32 + 2 * kTrieMaxActive + 1) * sizeof(int);
         hipLaunchKernelGGL(tdt_decide_kernel<true>, dim3(st.B), dim3(256), lds + extra, s, st);
     } else if (st.force_label) {
         hipLaunchKernelGGL((tdt_decide_kernel<false, true>), dim3(st.B), dim3(256), lds, s, st);      // pk_tdt_score
     } else if (st.h_bf16 && st.V + st.D <= 33 * 256 && st.V >= 2 && decide_fast_on()) {
-        hipLaunchKernelGGL((tdt_decide_kernel<false, false, true>), dim3(st.B), dim3(256), lds, s, st);
+        if (st.L * st.Hp <= 3 * 256) hipLaunchKernelGGL((tdt_decide_kernel<false, false, true, 3>), dim3(st.B), dim3(256), lds, s, st);
+        else if (st.L * st.Hp <= 6 * 256) hipLaunchKernelGGL((tdt_decide_kernel<false, false, true, 6>), dim3(st.B), dim3(256), lds, s, st);
+        else hipLaunchKernelGGL((tdt_decide_kernel<false, false, true>), dim3(st.B), dim3(256), lds, s, st);
     } else {
-        hipLaunchKernelGGL(tdt_decide_kernel<false>, dim3(st.B), dim3(256), lds, s, st);
+        if (st.L * st.Hp <= 3 * 256) hipLaunchKernelGGL((tdt_decide_kernel<false, false, false, 3>), dim3(st.B), dim3(256), lds, s, st);
+        else if (st.L * st.Hp <= 6 * 256) hipLaunchKernelGGL((tdt_decide_kernel<false, false, false, 6>), dim3(st.B), dim3(256), lds, s, st);
+        else hipLaunchKernelGGL(tdt_decide_kernel<false>, dim3(st.B), dim3(256), lds, s, st);
     }
 }
 

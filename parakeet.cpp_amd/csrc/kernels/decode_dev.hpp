@@ -5,6 +5,19 @@
 #include "kernels.hpp"
 #include <type_traits>
 
+// Phase stamps for tools/ubench/decide_trace.cpp (-DDEC_TRACE): shader clock of thread 0 at the phase boundaries of tdt_decide_one, kept in registers and written
+// behind the last one (a walked decision overwrites the stamps of the decision before it; [15] counts decisions).  Production: nothing.
+#ifdef DEC_TRACE
+__device__ long long *dec_trace;    // [16]
+#define DEC_STAMP(i) do { dec_st[i] = clock64(); } while (0)
+#define DEC_STAMPS_DECL long long dec_st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define DEC_STAMPS_FLUSH() do { if (dec_trace && threadIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) dec_trace[i_] = dec_st[i_]; } } while (0)
+#else
+#define DEC_STAMP(i) do { } while (0)
+#define DEC_STAMPS_DECL do { } while (0)
+#define DEC_STAMPS_FLUSH() do { } while (0)
+#endif
+
 namespace pk {
 
 // accesses to data exchanged between workgroups inside one launch: system scope (sc0 sc1) relaxed atomics, which the compiler
@@ -66,10 +79,15 @@ __device__ __forceinline__ int dd_build_rowlist(const int *need, int B, int *lst
     for (int i = 0; i < 8; ++i) bits |= (fl[i] != 0 ? 1u : 0u) << i;
     const int c = __builtin_popcount(bits);
     int x = c;                                                    // inclusive scan over the wave
+    if (F == 1) {                                                 // one flag per thread (B <= 256): a ballot and a population count, no lane exchange
+        const unsigned long long set = __ballot(c != 0);
+        x = __popcll(set & ((1ull << lane) - 1ull)) + c;
+    } else {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(x, off, 64);
-        if (lane >= off) x += y;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
     }
     if (lane == 63) wtot[wave] = x;
     __syncthreads();
@@ -90,7 +108,8 @@ __device__ __forceinline__ int dd_build_rowlist(const int *need, int B, int *lst
 // kernel (decode_persist.hip) runs every phase of a step inside one launch.
 // NTW: the weight stream is loaded non-temporally (streaming hint: the decode weights of the large heads -- 42 MB per symbol step for tdt-600m --
 // pass through each XCD's 4 MB L2 once per step and otherwise evict the operand tiles of the encoder GEMMs running beside the loop).
-template <int EPI, int NCH, bool COH, bool NTW = false>
+// WF > 1 (SK_ACT only): the frame-window form of the joint activation (TdtState::F) -- utterance b's rows b * F + f of z take relu(enc_proj[t_b + f] + pp), f < a.F <= WF.
+template <int EPI, int NCH, bool COH, bool NTW = false, int WF = 1>
 __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgroup, float (*tile)[16][17], const int *rows = nullptr, int n_rows = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
@@ -111,6 +130,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
     // dependent round trip to L2 / HBM that can hide under the 160-MFMA chain is ~1-2 us saved per launch.
     float e_gi[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_c = 0.0f;          // SK_CELL: lane -> (utterance lane>>2, unit lane&3)
     float e_ep[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_bias = 0.0f;       // SK_ACT / SK_BIAS: lane -> column `col`, utterances 4*kq+r
+    float e_epw[4][WF > 1 ? WF - 1 : 1];                           // SK_ACT window: enc_proj of the frames t + 1 .. t + F - 1
     int rb_cell = 0, rb_out[4] = {0, 0, 0, 0};                   // utterances of this lane's epilogue rows
     if (EPI == SK_CELL) {
         const int bi = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
@@ -139,6 +159,13 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
                         int tt = dd_ldi<COH>(a.t + b);
                         const int Tb = a.Tb ? a.Tb[b] : a.T;                                   // ragged batch: this utterance's frames / first enc_proj row
                         const int64_t r0 = a.row0 ? (int64_t)a.row0[b] : (int64_t)b * a.T;
+                        if constexpr (WF > 1) {
+#pragma unroll
+                            for (int f = 1; f < WF; ++f) {
+                                const int tf = tt + f < Tb ? tt + f : Tb - 1;
+                                e_epw[r][f - 1] = f < a.F ? a.ep[(r0 + tf) * a.N + n] : 0.0f;
+                            }
+                        }
                         tt = tt < Tb ? tt : Tb - 1;
                         e_ep[r] = a.ep[(r0 + tt) * a.N + n];
                     }
@@ -223,7 +250,19 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
                 if (a.bias) p = p + e_bias;
                 if (a.pp_out) a.pp_out[(int64_t)b * a.N + n] = p;           // cached for the steps after a blank (TdtState::pp)
                 const float s = e_ep[r] + p;
-                dd_stf<COH>(a.out + (int64_t)b * a.N + sigma16(n), s > 0.0f ? s : 0.0f);
+                if constexpr (WF > 1) {
+                    float *zr = a.out + (int64_t)b * a.F * a.N + sigma16(n);
+                    dd_stf<COH>(zr, s > 0.0f ? s : 0.0f);
+#pragma unroll
+                    for (int f = 1; f < WF; ++f) {
+                        if (f < a.F) {
+                            const float sf = e_epw[r][f - 1] + p;
+                            dd_stf<COH>(zr + (int64_t)f * a.N, sf > 0.0f ? sf : 0.0f);
+                        }
+                    }
+                } else {
+                    dd_stf<COH>(a.out + (int64_t)b * a.N + sigma16(n), s > 0.0f ? s : 0.0f);
+                }
             }
         }
     } else {
@@ -270,6 +309,27 @@ struct BestLP {
     int idx;
 };
 __device__ __forceinline__ BestLP wave_logsoftmax_argmax(const float *__restrict__ x, int n, float *__restrict__ lp_out, int lane) {
+    if (n <= 8) {
+        // a head of a few values (the TDT durations): lanes 8 .. 63 would carry the identities through the first three steps of every tree -- the last three
+        // steps give lanes 0 .. 7 the same bits (pk_devmath.h: wave_sum_low8); lanes >= 8 return what lane (l & 7) returns
+        const int i = lane & 7;
+        const bool in = i < n;
+        const float xi = in ? x[i] : -__builtin_huge_valf();
+        const float m = wave_max_low8(xi);
+        const float lse = dlogf(wave_sum_low8(in ? dexpf_nonpos(xi - m) : 0.0f));
+        float best = in ? (xi - m) - lse : -__builtin_huge_valf();
+        int bi = in ? i : 0x7fffffff;
+        if (lp_out && in && lane < 8) lp_out[i] = best;
+        auto step = [&](auto off) {
+            const float ob = wave_xor<decltype(off)::value>(best);
+            const int oi = wave_xor_i<decltype(off)::value>(bi);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        };
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 1>{});
+        return {best, bi};
+    }
     float m = -__builtin_huge_valf();
     for (int i = lane; i < n; i += 64) m = fmaxf(m, x[i]);
     m = wave_max64(m);
@@ -283,12 +343,11 @@ __device__ __forceinline__ BestLP wave_logsoftmax_argmax(const float *__restrict
         if (lp_out) lp_out[i] = l;
         if (bi == 0x7fffffff || l > best) { best = l; bi = i; }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
+    wave_butterfly([&](auto off) {
+        const float ob = wave_xor<decltype(off)::value>(best);
+        const int oi = wave_xor_i<decltype(off)::value>(bi);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
+    });
     return {best, bi};
 }
 
@@ -302,17 +361,25 @@ __device__ __forceinline__ BestLP wave_logsoftmax_argmax(const float *__restrict
 // scans over the registers + ONE cross-wave exchange -- two barriers in all, no LDS sweep over the vocabulary (the exact form: four barriers and three sweeps, the
 // canonical single-wave sum64 among them; 17 us per step at vocabulary 8193).  Not bit-identical to the exact form (summation order, exp, ties of ROUNDED
 // log-probs): only where the mode is compared within a tolerance.  The duration head and everything behind the decision are the same code.
-template <bool BOOST, bool COH, bool SCORE = false, bool FAST = false>
+// NC: 256-element slots of the candidate LSTM state a thread carries in registers (L * Hp <= NC * 256; 3 covers one layer of 640, the launcher picks) -- every slot is
+// a guarded load, a guarded store and their address arithmetic, emitted whether the model needs it or not.
+template <bool BOOST, bool COH, bool SCORE = false, bool FAST = false, int NC = 12>
 __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float *sm) {
     static_assert(!FAST || (!BOOST && !COH && !SCORE), "the fast decision is the plain greedy step of the launch-per-phase loop");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (dd_ldi<COH>(st.done + b)) return;
+    // A finished utterance leaves without a write.  Launch-per-phase loop: the flag travels WITH the step's other loads (state words, candidate LSTM
+    // state, logits row) and is looked at once they are all in flight -- as the first statement it was a round trip of its own (~1 us of a ~7 us launch).
+    DEC_STAMPS_DECL;
+    DEC_STAMP(0);                                                    // 0 entry
+    const int done_in = dd_ldi<COH>(st.done + b);
+    if constexpr (COH) { if (done_in) return; }
     int n_force = 0;                                               // SCORE: steps of this utterance's given path, first element of its arrays
     int64_t force_off = 0;
     if constexpr (SCORE) {
         n_force = st.n_force_b ? st.n_force_b[b] : st.n_force;
         force_off = (int64_t)b * st.force_stride;
         if (st.force_label && n_force <= 0) {                      // nothing to walk in this chunk: finished before the first decision
+            if (done_in) return;
             if (tid == 0) { st.lens[b] = 0; dd_sti<COH>(st.done + b, 1); atomicAdd(st.done_count, 1); if (st.need) dd_sti<COH>(st.need + b, 0); }
             return;
         }
@@ -322,7 +389,8 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     const int64_t ep_row0 = st.row0 ? (int64_t)st.row0[b] : (int64_t)b * st.T;
     const int max_steps_b = (st.Tb && st.max_steps > 0) ? Tb * (st.max_symbols + 1) + 16 : st.max_steps;
     const int VD = st.V + st.D;
-    float *x = sm, *e = sm + VD;
+    const int Fw = (!BOOST && !COH && !SCORE && st.F > 1) ? st.F : 1;      // frame window (below); its F logits rows sit in front of the scratch
+    float *x = sm, *e = sm + (int64_t)Fw * VD;                     // x: the row under decision (window: row f of the F staged rows)
     float *red = e + VD;                                           // [0..3] wave maxima, [4] lse, [8..11] best val, [12..15] best idx
     const int MW = (st.V + 31) >> 5;
     unsigned *mask = reinterpret_cast<unsigned *>(red + 16);       // [MW] boosted-token bits
@@ -334,26 +402,60 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         if (tid < n_act) acts[tid] = st.trie.act[(int64_t)b * kTrieMaxActive + tid];
         for (int i = tid; i < MW; i += 256) mask[i] = 0u;
     }
-    const float *lg = st.logits + (int64_t)b * VD;
+    // FRAME WINDOW (TdtState::F > 1, small lock-step batches; plain greedy step only): the heads product evaluated the joint for the F frames t .. t + F - 1 under
+    // the unchanged prediction-net state, so a blank decision whose successor frame lies inside the window is followed by the next decision at once -- the
+    // evaluations, their order, the counters and the running margin are those of the one-decision-per-launch loop; a run of blanks costs one launch.
+    // The F rows are staged in LDS by the first decision's load (one round trip for all of them; launch_tdt_decide sizes the scratch): a walked decision starts from
+    // LDS, not from memory.  F > 1 comes with V + D <= 5 x 256 (Model::run_tdt_loop).
+    const float *lg = st.logits + (int64_t)b * Fw * VD;
     // issue every independent global load up front (state words, candidate LSTM state): each dependent round trip to
     // L2/HBM costs ~1-2 us in this latency-bound kernel
     const int t_in = dd_ldi<COH>(st.t + b), steps_in = dd_ldi<COH>(st.steps + b), n_out_in = dd_ldi<COH>(st.n_out + b), nsym_in = dd_ldi<COH>(st.nsym + b);
-    constexpr int kMaxCarry = 12;                                  // L * Hp <= 12 * 256
+    constexpr int kMaxCarry = NC;                                  // L * Hp <= NC * 256
     float hcar[kMaxCarry], ccar[kMaxCarry];
     const int n_state = st.L * st.Hp;
     // tolerance-class mode (decode_gemv_bf16.hip): h / h' are bf16 arrays [L][B][Hp]; they are committed as Hp / 2 float-sized words per row
     const int hp_h = st.h_bf16 ? st.Hp / 2 : st.Hp, n_h = st.L * hp_h;
+    // element i of the [L][width] state of this utterance sits at ((l * B + b) * width + r), i = l * width + r: found by L - 1 compare-and-subtract steps (none for a
+    // one-layer net) -- as i / width and i % width these were 48 integer divisions, ~1 500 instructions in front of the loads of a kernel that is all latency
+    auto state_off = [&](int i, int width) -> int64_t {
+        int l = 0, r = i;
+        for (int k = 1; k < st.L; ++k) if (r >= width) { r -= width; ++l; }
+        return ((int64_t)l * st.B + b) * width + r;
+    };
     if constexpr (!COH) {                                          // (persistent kernel: copied at commit time instead -- 24 fewer live
 #pragma unroll                                                     //  registers, it has to fit beside the encoder's GEMM waves)
         for (int q = 0; q < kMaxCarry; ++q) {
             const int i = tid + 256 * q;
-            if (i < n_state) ccar[q] = st.cn[((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp)];
-            if (i < n_h) hcar[q] = st.hn[((int64_t)(i / hp_h) * st.B + b) * hp_h + (i % hp_h)];
+            if (i < n_state) ccar[q] = st.cn[state_off(i, st.Hp)];
+            if (i < n_h) hcar[q] = st.hn[state_off(i, hp_h)];
+        }
+    }
+    // the running margin's old value and the cached pred_proj row (blank steps form the next z from it): requested here, consumed after the decision
+    float mg_old = 0.0f;
+    if constexpr (!COH && !BOOST) { if (st.margin && tid == 0) mg_old = st.margin[b]; }
+    constexpr int kPpCarry = 4;                                    // J <= 4 * 256
+    float ppv[kPpCarry];
+    const bool pp_carried = !COH && st.need && st.J <= 256 * kPpCarry;
+    if (pp_carried) {
+#pragma unroll
+        for (int q = 0; q < kPpCarry; ++q) {
+            const int n = tid + 256 * q;
+            ppv[q] = n < st.J ? st.pp[(int64_t)b * st.J + n] : 0.0f;
         }
     }
     BestLP lab{0.0f, 0};
     float sec = -__builtin_huge_valf();
     int skip = 1;
+    int t_cur = t_in, steps_cur = steps_in, nsym_cur = nsym_in, f_cur = 0;     // the walk through the frame window
+    float vw[kDecWindowMax][5];                                                 // its F logits rows on their way from memory (exact form, V + D <= 5 x 256)
+    for (;;) {
+    DEC_STAMP(1);
+#ifdef DEC_TRACE
+    if (f_cur == 0) dec_st[11] = dec_st[1];
+    dec_st[15] += 1;
+#endif
+                                                    // evaluation start (loads issued on the first)
     if constexpr (FAST) {
       auto fast = [&](auto nq_tag) {
         constexpr int NQ = decltype(nq_tag)::value;                 // VD <= NQ x 256 (33: launch_tdt_decide checks)
@@ -363,6 +465,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             const int i = tid + 256 * u;
             v[u] = lg[i < VD ? i : VD - 1];
         }
+        if (done_in) return true;
         float mx = -__builtin_huge_valf(), s2 = -__builtin_huge_valf();
         int bi = 0x7fffffff;
 #pragma unroll
@@ -375,14 +478,14 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
                 x[i] = v[u];                                        // the few duration logits: wave 1 reads them from LDS below
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ob = __shfl_xor(mx, off, 64), os = __shfl_xor(s2, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
+        wave_butterfly([&](auto off) {
+            constexpr int O = decltype(off)::value;
+            const float ob = wave_xor<O>(mx), os = wave_xor<O>(s2);
+            const int oi = wave_xor_i<O>(bi);
             const bool take = ob > mx || (ob == mx && oi < bi);
             s2 = fmaxf(fmaxf(s2, os), take ? mx : ob);
             if (take) { mx = ob; bi = oi; }
-        }
+        });
         if (lane == 0) { red[wave] = mx; red[8 + wave] = s2; red[12 + wave] = __int_as_float(bi); }
         __syncthreads();
         float m = red[0], s2b = red[8];
@@ -401,8 +504,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             const int i = tid + 256 * u;
             if (i < st.V) p += __builtin_amdgcn_exp2f((v[u] - m) * 1.44269502162933349609375f);
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
+        p = wave_sum64(p);
         if (lane == 0) red[4 + wave] = p;                           // (red[4 .. 7]: the waves' partial sums)
         if (wave == 1 && st.D > 0) {                                // duration head: a few values, one wavefront (the exact form's code)
             const BestLP dur = wave_logsoftmax_argmax(x + st.V, st.D, e + st.V, lane);
@@ -413,7 +515,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
                 float second = -__builtin_huge_valf();
                 for (int i = lane; i < st.D; i += 64)
                     if (i != dur.idx) second = fmaxf(second, e[st.V + i]);
-                second = wave_max64(second);
+                second = st.D <= 8 ? wave_max_low8(second) : wave_max64(second);   // (lane 0 reads it; D <= 8: the same bits from the last three steps)
                 if (lane == 0) e[1] = st.D > 1 ? dur.lp - second : __builtin_huge_valf();
             }
         }
@@ -425,13 +527,13 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         if (st.margin && tid == 0) {
             float mg = lab.lp - sec;
             if (st.D > 0) mg = fminf(mg, e[1]);
-            const float old = st.margin[b];
-            st.margin[b] = mg < old ? mg : old;
+            mg_old = mg < mg_old ? mg : mg_old;
         }
         if (st.D > 0) skip = (int)e[0];
+        return false;
       };
-      if (VD <= 256 * 5) fast(std::integral_constant<int, 5>{});
-      else fast(std::integral_constant<int, 33>{});
+      if (VD <= 256 * 5) { if (fast(std::integral_constant<int, 5>{})) return; }
+      else if (fast(std::integral_constant<int, 33>{})) return;
     } else {
     float m = -__builtin_huge_valf();
     // The logits row with ALL of a thread's loads in flight at once (one L2 / HBM round trip): written as a plain loop, every iteration
@@ -445,6 +547,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             const int i = tid + 256 * u;
             v[u] = dd_ldf<COH>(lg + (i < VD ? i : VD - 1));
         }
+        if (done_in) return true;
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int i = tid + 256 * u;
@@ -453,12 +556,37 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
                 if (i < st.V) m = fmaxf(m, v[u]);
             }
         }
+        return false;
     };
-    if (!COH && VD <= 256 * 5) {
-        stage_row(std::integral_constant<int, 5>{});
+    if (Fw > 1) {
+        if (f_cur == 0) {
+            // row 0 first, the other rows behind it in the same queue: the first decision waits for ITS row only (loads return in order), the rest arrive under it
+            // and go to LDS when -- if -- the walk takes its first step
+#pragma unroll
+            for (int f = 0; f < kDecWindowMax; ++f)
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int i = tid + 256 * u;
+                    vw[f][u] = f < Fw ? lg[(int64_t)f * VD + (i < VD ? i : VD - 1)] : 0.0f;
+                }
+            if (done_in) return;
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int i = tid + 256 * u;
+                if (i < VD) sm[i] = vw[0][u];
+                if (i < st.V) m = fmaxf(m, vw[0][u]);
+            }
+        } else {
+            x = sm + (int64_t)f_cur * VD;                           // staged by the first decision, barriers since
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { const int i = tid + 256 * u; if (i < st.V) m = fmaxf(m, x[i]); }
+        }
+    } else if (!COH && VD <= 256 * 5) {
+        if (stage_row(std::integral_constant<int, 5>{})) return;
     } else if (!COH && VD <= 256 * 33) {
-        stage_row(std::integral_constant<int, 33>{});
+        if (stage_row(std::integral_constant<int, 33>{})) return;
     } else {
+        if (done_in) return;
         for (int i0 = tid; i0 < VD; i0 += 256 * 8) {
             float v8[8];
 #pragma unroll
@@ -476,10 +604,12 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             }
         }
     }
+    DEC_STAMP(2);                                                    // row arrived, staged
     m = wave_max64(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    DEC_STAMP(3);                                                    // maximum known
     for (int i0 = tid; i0 < st.V; i0 += 256 * 4) {                 // (4 independent LDS reads / exp chains per trip)
         float t4[4];
 #pragma unroll
@@ -498,6 +628,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         }
     }
     __syncthreads();
+    DEC_STAMP(4);                                                    // exps in LDS
     if (wave == 0) {
         float p = 0.0f;
         for (int i0 = lane; i0 < st.V; i0 += 64 * 8) {              // the canonical strided partial sum, its LDS reads 8 at a time; the adds stay in index order
@@ -519,11 +650,13 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             float second = -__builtin_huge_valf();
             for (int i = lane; i < st.D; i += 64)
                 if (i != dur.idx) second = fmaxf(second, e[st.V + i]);
-            second = wave_max64(second);
+            second = st.D <= 8 ? wave_max_low8(second) : wave_max64(second);   // (lane 0 reads it; D <= 8: the same bits from the last three steps)
             if (lane == 0) red[6] = st.D > 1 ? dur.lp - second : __builtin_huge_valf();
         }
     }
+    DEC_STAMP(5);                                                    // wave 0: sum, log done (before the barrier)
     __syncthreads();
+    DEC_STAMP(6);                                                    // lse known (duration head done)
     const float lse = red[4];
     float best = -__builtin_huge_valf();
     // `second` = the largest label log-prob that is NOT the winner's (ties with the winner count: margin 0).  It only feeds the optional
@@ -545,17 +678,18 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        const float os = __shfl_xor(second, off, 64);
+    wave_butterfly([&](auto off) {
+        constexpr int O = decltype(off)::value;
+        const float ob = wave_xor<O>(best);
+        const int oi = wave_xor_i<O>(bi);
+        const float os = wave_xor<O>(second);
         const bool take = ob > best || (ob == best && oi < bi);
         second = fmaxf(fmaxf(second, os), (oi == bi) ? -__builtin_huge_valf() : (take ? best : ob));   // the loser's maximum joins the rest
         if (take) { best = ob; bi = oi; }
-    }
+    });
     if (lane == 0) { red[8 + wave] = best; red[12 + wave] = __int_as_float(bi); red[wave] = second; }   // (red[0..3]: the wave maxima were consumed two barriers ago)
     __syncthreads();
+    DEC_STAMP(7);                                                    // argmax exchanged
     lab = BestLP{red[8], __float_as_int(red[12])};
     sec = red[0];
 #pragma unroll
@@ -570,32 +704,60 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         if (st.margin && tid == 0) {                               // running minimum over the utterance's decisions (SURVEY 8c early warning)
             float mg = lab.lp - sec;
             if (st.D > 0) mg = fminf(mg, red[6]);
-            const float old = dd_ldf<COH>(st.margin + b);
-            dd_stf<COH>(st.margin + b, mg < old ? mg : old);
+            if constexpr (COH) {
+                const float old = dd_ldf<COH>(st.margin + b);
+                dd_stf<COH>(st.margin + b, mg < old ? mg : old);
+            } else {
+                mg_old = mg < mg_old ? mg : mg_old;                  // (written once, behind the walk)
+            }
         }
     }
     if constexpr (BOOST) lab.lp = (x[lab.idx] - m) - lse;          // the confidence is the UNBOOSTED log-prob (phrase_boost.cpp:313-315)
     if (st.D > 0) skip = (int)red[5];
     if constexpr (SCORE && !BOOST) {
         if (st.score_lab) {                                        // teacher-forced scoring: the label log-prob row as the joint returns it (its own pass:
-            float *row = st.score_lab + (force_off + steps_in) * st.V;   // nothing of it sits in the decode loop's argmax sweep)
+            float *row = st.score_lab + (force_off + steps_cur) * st.V;   // nothing of it sits in the decode loop's argmax sweep)
             for (int i = tid; i < st.V; i += 256) row[i] = (x[i] - m) - lse;
         }
         if (st.force_label) {                                      // teacher-forced scoring (TdtState::force_label): the given decision, not the argmax
-            if (st.score_dur && tid < st.D) st.score_dur[(force_off + steps_in) * st.D + tid] = e[st.V + tid];
-            const int k = steps_in < n_force ? steps_in : n_force - 1;
+            if (st.score_dur && tid < st.D) st.score_dur[(force_off + steps_cur) * st.D + tid] = e[st.V + tid];
+            const int k = steps_cur < n_force ? steps_cur : n_force - 1;
             lab.idx = st.force_label[force_off + k];
             lab.lp = (x[lab.idx] - m) - lse;
             if (st.D > 0) skip = st.durations[st.force_dur[force_off + k]];
         }
     }
     }                                                               // (exact form)
+    if (Fw > 1 && lab.idx == st.blank) {                            // blank inside the window: the next frame's logits row is already there
+        const int adv = (st.D > 0) ? (skip > 1 ? skip : 1) : 1;
+        const bool capped = max_steps_b > 0 && steps_cur + 1 >= max_steps_b;
+        if (f_cur + adv < Fw && t_cur + adv < Tb && !capped) {
+            if constexpr (!FAST) {
+                if (f_cur == 0) {                                   // first step of the walk: the rows behind row 0 leave the registers
+#pragma unroll
+                    for (int f = 1; f < kDecWindowMax; ++f)
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            const int i = tid + 256 * u;
+                            if (f < Fw && i < VD) sm[(int64_t)f * VD + i] = vw[f][u];
+                        }
+                }
+            }
+            f_cur += adv; t_cur += adv; ++steps_cur; nsym_cur = 0;
+            __syncthreads();                                        // the decision scratch (x, e, red) is rewritten
+            continue;
+        }
+    }
+    break;
+    }                                                               // (window walk)
+    if constexpr (!COH && !BOOST) { if (st.margin && tid == 0) st.margin[b] = mg_old; }
+    DEC_STAMP(8);                                                    // walk over
     const int lane0 = tid;                                         // thread 0 writes the scalar state
     // scalar control (wave-uniform values; lane 0 writes)
-    int t = t_in;
-    const int nsteps = steps_in + 1;
+    int t = t_cur;
+    const int nsteps = steps_cur + 1;
     int n_out = n_out_in;
-    int nsym = nsym_in;
+    int nsym = nsym_cur;
     const bool commit = lab.idx != st.blank;
     if (!commit) {
         // blank: the LSTM state reverts -- the candidates hn/cn are simply not committed (src/tdt.cpp:88-93)
@@ -650,8 +812,8 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
 #pragma unroll
             for (int q = 0; q < kMaxCarry; ++q) {
                 const int i = tid + 256 * q;
-                if (i < n_state) st.c[((int64_t)(i / st.Hp) * st.B + b) * st.Hp + (i % st.Hp)] = ccar[q];
-                if (i < n_h) st.h[((int64_t)(i / hp_h) * st.B + b) * hp_h + (i % hp_h)] = hcar[q];
+                if (i < n_state) st.c[state_off(i, st.Hp)] = ccar[q];
+                if (i < n_h) st.h[state_off(i, hp_h)] = hcar[q];
             }
         }
     }
@@ -663,6 +825,36 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         if (tid == 0) dd_sti<COH>(st.need + b, (commit && !fin) ? 1 : 0);
         if (!commit && !fin) {
             const float *epr = st.ep + (ep_row0 + t) * st.J, *ppr = st.pp + (int64_t)b * st.J;
+            if (pp_carried) {
+                // the rows of the next window: frames t .. t + F - 1 (clamped as SK_ACT clamps).  EVERY load first, then the stores: row by row the loads of row
+                // f + 1 waited behind the stores of row f (the pointers may alias as far as the compiler knows) -- eight dependent round trips, ~8 us
+                float epv[kDecWindowMax][kPpCarry];
+#pragma unroll
+                for (int fw = 0; fw < kDecWindowMax; ++fw) {
+                    if (fw < Fw) {
+                        const int tt = t + fw < Tb ? t + fw : Tb - 1;
+                        const float *er = st.ep + (ep_row0 + tt) * st.J;
+#pragma unroll
+                        for (int q = 0; q < kPpCarry; ++q) { const int n = tid + 256 * q; epv[fw][q] = n < st.J ? er[n] : 0.0f; }
+                    }
+                }
+#pragma unroll
+                for (int fw = 0; fw < kDecWindowMax; ++fw) {
+                    if (fw < Fw) {
+                        const int64_t zr = ((int64_t)b * Fw + fw) * st.J;
+#pragma unroll
+                        for (int q = 0; q < kPpCarry; ++q) {
+                            const int n = tid + 256 * q;
+                            if (n < st.J) {
+                                const float sv = epv[fw][q] + ppv[q];
+                                const float zv = sv > 0.0f ? sv : 0.0f;
+                                if (st.h_bf16) reinterpret_cast<__bf16 *>(st.z)[zr + n] = (__bf16)zv;
+                                else dd_stf<COH>(st.z + zr + sigma16(n), zv);
+                            }
+                        }
+                    }
+                }
+            } else
             for (int n = tid; n < st.J; n += 256) {
                 const float sv = epr[n] + ppr[n];
                 const float zv = sv > 0.0f ? sv : 0.0f;
@@ -671,6 +863,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             }
         }
     }
+    DEC_STAMP(9);                                                    // commit / next z issued
     if (lane0 == 0) {
         bool finished = t >= Tb || (SCORE && st.force_label && nsteps >= n_force);
         int len = n_out < st.max_tokens ? n_out : st.max_tokens;
@@ -686,6 +879,8 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             else atomicAdd(st.done_count, 1);
         }
     }
+    DEC_STAMP(10);                                                  // state words issued
+    DEC_STAMPS_FLUSH();
 }
 
 }  // namespace pk

@@ -13,11 +13,13 @@
 //  * A workgroup = one 16-output tile x up to four 16-utterance tiles: the W tile is fetched from L2 once and hits in
 //    L1 for the other three waves; the per-XCD slice of the 10.8 MB of decode weights stays L2-resident across steps.
 //  * Epilogues: LSTM cell (gates -> c', h'), joint activation relu(enc_proj[t_b] + .), or bias.
+#include <cstdio>
+#include <cstdlib>
 #include "decode_dev.hpp"
 
 namespace pk {
 
-template <int EPI, int NCH, bool NTW>
+template <int EPI, int NCH, bool NTW, int WF = 1>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     __shared__ float tile[4][16][17];
     // grid.x is the tile count rounded up to a multiple of 8 (launch_skinny_gemm): workgroup id % 8 = XCD, so XCD x owns the output tiles
@@ -28,15 +30,23 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
         __shared__ int wtot[4];
         const int cnt = dd_build_rowlist<false>(a.need, a.B, lst, wtot);
         if ((int)blockIdx.y * 64 >= cnt) return;
-        skinny_tile<EPI, NCH, false, NTW>(a, blockIdx.x, blockIdx.y, tile, lst, cnt);
+        skinny_tile<EPI, NCH, false, NTW, WF>(a, blockIdx.x, blockIdx.y, tile, lst, cnt);
         return;
     }
-    skinny_tile<EPI, NCH, false, NTW>(a, blockIdx.x, blockIdx.y, tile);
+    skinny_tile<EPI, NCH, false, NTW, WF>(a, blockIdx.x, blockIdx.y, tile);
 }
 
 template <int EPI>
 static void launch_skinny_epi(const SkinnyArgs &a, dim3 grid, hipStream_t s) {
     const bool k640 = a.K == 640;
+    if constexpr (EPI == SK_ACT) {
+        if (a.F > 1) {                                               // frame window: its own instantiation (the extra enc_proj operands stay out of the batch kernel's registers)
+            if (a.F > kDecWindowMax || a.nt_weights) { fprintf(stderr, "parakeet_amd: decode window %d > %d (or nt weights) -- engine bug\n", a.F, kDecWindowMax); abort(); }
+            if (k640) hipLaunchKernelGGL((skinny_gemm_kernel<EPI, 10, false, kDecWindowMax>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((skinny_gemm_kernel<EPI, 0, false, kDecWindowMax>), grid, dim3(256), 0, s, a);
+            return;
+        }
+    }
     if (a.nt_weights) {
         if (k640) hipLaunchKernelGGL((skinny_gemm_kernel<EPI, 10, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((skinny_gemm_kernel<EPI, 0, true>), grid, dim3(256), 0, s, a);

@@ -286,6 +286,10 @@ struct TdtState {
     const float *ep = nullptr;      // enc_proj [B][T][J]
     float *z = nullptr;             // joint activation [B][J]: fp32 sigma layout, or bf16 natural when h_bf16
     int J = 0;
+    // Frame window (small lock-step batches, plain greedy step, prediction-net caching on; 1 = off): the joint is evaluated for the frames t .. t + F - 1 of every
+    // utterance in ONE heads product (rows b * F + f of z and logits; the 16-row MFMA tile is mostly empty at B <= 8), and tdt_decide walks through the blank
+    // decisions whose successor frame lies inside the window -- the same evaluations in the same order, a run of blanks in one launch instead of one each.
+    int F = 1;
     // ragged batches: utterance b has Tb[b] frames, its enc_proj rows start at row0[b] (null: T frames from row b * T); the safety cap on joint
     // evaluations is then per utterance, Tb[b] * (max_symbols + 1) + 16 -- what a single-clip run of that utterance would use
     const int *Tb = nullptr, *row0 = nullptr;
@@ -300,6 +304,7 @@ struct TdtState {
     const int *n_force_b = nullptr;
     int force_stride = 0;
 };
+constexpr int kDecWindowMax = 8;    // TdtState::F <= this
 constexpr int kMaxListRows = 2048;  // largest lock-step batch the compacted launches handle (larger batches run every row)
 void launch_tdt_init(const TdtState &st, hipStream_t s);
 // Tb_out[i] / row0_out[i], i < n: frames and first enc_proj row (row_base + its offset) of the utterances of one run; T == nullptr: a uniform
@@ -320,6 +325,7 @@ struct SkinnyArgs {
     float *out; int ldo;           // SK_BIAS: [B][ldo] natural ; SK_ACT: z [B][N] sigma ; SK_CELL: h' [B][Hp] sigma
     // SK_ACT
     const float *ep; const int *t; int T;
+    int F = 1;                     // SK_ACT frame window (TdtState::F): z rows b * F + f, f < F <= kDecWindowMax
     // SK_CELL (N = 4*Hp)
     const float *gi; int gi_ld; const int *gi_row; const float *c; float *cn; int Hp;
     // SK_CELL of an upper LSTM layer with the input projection fused in: gi = X2 W2^T + bias2 (X2 [B][K] sigma, W2 [4Hp][K] sigma); W2 null: gi is read

@@ -6,6 +6,7 @@
 // written specification independently.  Coefficients come from tools/fit_math.py.
 // All translation units are compiled with -ffp-contract=off: every fusion below is explicit.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 namespace pk {
@@ -210,14 +211,74 @@ __device__ __forceinline__ void lds_store_fence() { asm volatile("s_waitcnt lgkm
 
 // Butterfly stage of the canonical 64-lane sum ("sum64"): p += p(lane ^ off), off = 32,16,...,1.
 // Every lane ends with the same value (IEEE add commutes).
+// The value of lane (l ^ OFF), without the LDS crossbar: __shfl_xor is a ds_bpermute_b32 (address VALU + LDS round trip, ~100 clocks of dependent latency);
+// the same exchange is two quad permutes (1, 2), two bank-masked row shifts (4), a row rotation (8) -- DPP modifiers on a v_mov -- and the gfx950 row swaps
+// v_permlane16_swap / v_permlane32_swap (16, 32).  The values that meet in an add / max are the same, so every reduction built on it keeps its bits
+// (tools/ubench/wave_xor_probe.cpp pins the exchange against __shfl_xor and times both).
+template <int OFF>
+__device__ __forceinline__ int wave_xor_i(int x) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "one bit of the lane index");
+    int r;
+    if constexpr (OFF == 1) {
+        r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);          // quad_perm:[1,0,3,2]
+    } else if constexpr (OFF == 2) {
+        r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);          // quad_perm:[2,3,0,1]
+    } else if constexpr (OFF == 4) {
+        r = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);         // row_shl:4 into banks 0 and 2 (lanes 0-3, 8-11 of a row take lane + 4)
+        r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);         // row_shr:4 into banks 1 and 3 (lanes 4-7, 12-15 take lane - 4)
+    } else if constexpr (OFF == 8) {
+        r = __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);         // row_ror:8
+    } else if constexpr (OFF == 16) {
+        const auto s = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);   // [0]: rows 0, 0', 2, 2' ; [1]: rows 1, 1', 3, 3' of the input
+        r = (int)((threadIdx.x & 16) ? s[0] : s[1]);
+    } else {
+        const auto s = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);   // [0]: low half twice ; [1]: high half twice
+        r = (int)((threadIdx.x & 32) ? s[0] : s[1]);
+    }
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ float wave_xor(float v) { return __int_as_float(wave_xor_i<OFF>(__float_as_int(v))); }
+// `body(off_tag)` for the six offsets 32, 16, 8, 4, 2, 1 in the canonical butterfly order; decltype(off_tag)::value is the offset
+template <typename F>
+__device__ __forceinline__ void wave_butterfly(F &&body) {
+    body(std::integral_constant<int, 32>{});
+    body(std::integral_constant<int, 16>{});
+    body(std::integral_constant<int, 8>{});
+    body(std::integral_constant<int, 4>{});
+    body(std::integral_constant<int, 2>{});
+    body(std::integral_constant<int, 1>{});
+}
 __device__ __forceinline__ float wave_sum64(float p) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    p = p + wave_xor<32>(p);
+    p = p + wave_xor<16>(p);
+    p = p + wave_xor<8>(p);
+    p = p + wave_xor<4>(p);
+    p = p + wave_xor<2>(p);
+    p = p + wave_xor<1>(p);
+    return p;
+}
+// the last three steps of the trees: what wave_sum64 / wave_max64 return in lanes 0 .. 7 when lanes 8 .. 63 hold the identity (+0 for a sum of non-negative terms,
+// -inf for a maximum) -- the first three steps then add exact zeros / compare against -inf, so leaving them out keeps the bits
+__device__ __forceinline__ float wave_sum_low8(float p) {
+    p = p + wave_xor<4>(p);
+    p = p + wave_xor<2>(p);
+    p = p + wave_xor<1>(p);
+    return p;
+}
+__device__ __forceinline__ float wave_max_low8(float p) {
+    p = fmaxf(p, wave_xor<4>(p));
+    p = fmaxf(p, wave_xor<2>(p));
+    p = fmaxf(p, wave_xor<1>(p));
     return p;
 }
 __device__ __forceinline__ float wave_max64(float p) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) p = fmaxf(p, __shfl_xor(p, off, 64));
+    p = fmaxf(p, wave_xor<32>(p));
+    p = fmaxf(p, wave_xor<16>(p));
+    p = fmaxf(p, wave_xor<8>(p));
+    p = fmaxf(p, wave_xor<4>(p));
+    p = fmaxf(p, wave_xor<2>(p));
+    p = fmaxf(p, wave_xor<1>(p));
     return p;
 }
 

@@ -146,6 +146,60 @@ def test_persistent_loop_110m_heads_and_two_layers(tmp_path_factory):
         check_tdt(gm, om, enc)
 
 
+def _pair_with(tmpdir, cfg, seed, edit):
+    """make_pair with the synthetic weights edited before either model is built."""
+    import os
+    import oracle
+    from parakeet_cpp_amd import capi, synth
+    W = synth.synth_weights(cfg, seed=seed)
+    edit(W)
+    wp = os.path.join(str(tmpdir), f"{cfg.name}_{seed}.safetensors")
+    synth.save_weights(wp, W)
+    return oracle.Model(cfg, W), capi.Model(wp, cfg, device=0)
+
+
+def test_single_utterance_frame_window(tmp_path_factory):
+    """One utterance per call decodes through the frame window (TdtState::F: the joint of the next frames in the heads product's spare rows, tdt_decide walking
+    through the blanks inside it).  Every output word -- ids, frames, confidences, the count of joint evaluations -- against the oracle's one-decision-at-a-time loop:
+    ordinary weights, weights pushed towards blanks of duration 1 (long walks, windows that run out), blanks of duration 4 (the window ends at the first blank),
+    sequences shorter than the window, the RNNT head (no durations), two LSTM layers, and the 110m decoder shapes (K = 640 kernels, vocabulary 1025)."""
+    tmp = tmp_path_factory.mktemp("win")
+    pre = "tdt_joint_."
+
+    def towards(blank_bias, dur, dur_bias):
+        def edit(W):
+            b = W[pre + "label_proj_.bias"]; b[-1] += blank_bias
+            if dur is not None:
+                W[pre + "duration_proj_.bias"][dur] += dur_bias
+        return edit
+
+    cases = [("plain", G.tiny(name="tiny-win-plain"), lambda W: None),
+             ("blank-dur1", G.tiny(name="tiny-win-b1"), towards(1.5, 1, 3.0)),
+             ("blank-dur4", G.tiny(name="tiny-win-b4"), towards(1.5, 4, 3.0)),
+             ("all-blank", G.tiny(name="tiny-win-all"), towards(30.0, 1, 3.0)),
+             ("two-lstm", G.tiny(name="tiny-win-2l", num_lstm_layers=2), towards(1.0, 1, 1.0))]
+    n_blank_steps = 0
+    for tag, cfg, edit in cases:
+        om, gm = _pair_with(tmp, cfg, 21, edit)
+        for B, T, seed in ((1, 126, 1), (1, 57, 2), (1, 5, 3), (1, 1, 4), (2, 40, 5), (3, 33, 6)):
+            o = check_tdt(gm, om, enc_like(B, T, cfg.hidden_size, seed))
+            n_blank_steps += int(o["steps"].sum() - o["lens"].sum())
+    assert n_blank_steps > 200, "degenerate test: the walk was hardly taken"
+    cfg = G.tiny(head="rnnt", durations=[], joint_prefix="joint_.", ctc_vocab_size=0, name="tiny-win-rnnt")
+    om, gm = _pair_with(tmp, cfg, 22, lambda W: W["joint_.out_proj_.bias"].__setitem__(-1, W["joint_.out_proj_.bias"][-1] + 1.0))
+    for T, seed in ((50, 7), (3, 8)):
+        enc = enc_like(1, T, cfg.hidden_size, seed)
+        g, o = gm.tdt_decode(enc), om.rnnt_greedy(enc)
+        assert np.array_equal(g["lens"], o["lens"])
+        n = o["lens"][0]
+        assert np.array_equal(g["ids"][0, :n], o["ids"][0, :n]) and np.array_equal(g["start"][0, :n], o["start"][0, :n])
+    cfg = dataclasses.replace(pk.make_110m_config(), num_layers=1, name="110m-1L-win")
+    om, gm = _pair_with(tmp, cfg, 23, towards(2.0, 2, 2.0))
+    for T, seed in ((126, 9), (40, 10)):
+        o = check_tdt(gm, om, enc_like(1, T, cfg.hidden_size, seed))
+        assert o["steps"].sum() > o["lens"].sum()
+
+
 def test_teacher_forced_scores_bit_identical(tiny_pair):
     """pk_tdt_score == orc_tdt_score row for row: along the oracle's own greedy path (then the walk reproduces the greedy decode), and along
     an ARBITRARY path of random labels / durations (states no greedy decode visits) -- /root/reference/src/tdt.cpp:15-24,62-106."""
