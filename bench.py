@@ -33,8 +33,8 @@ D_MODEL, FFN, ENC_FRAMES = 512, 2048, 126
 FC1_KERNEL = {False: "gemm_pipe_kernel<4,2,1,2,32,EPI_SILU,1> (ffn_fc1_silu: fp32 v_mfma_f32_32x32x2_f32, 128x128 tile, 8 waves of 32x64, 1 LDS staging buffer, 4-byte staging stores)",
               True: "gemm_bf16_glds_kernel<4,2,2,4,EPI_SILU> (ffn_fc1_silu: v_mfma_f32_32x32x16_bf16 with swapped operands, 256x256 macro tile, 8 waves of 64x128, global_load_lds_dwordx4 staging into an XOR-swizzled LDS image, persistent one workgroup per CU, epilogue from registers into the blocked fc1 -> fc2 layout)"}
 # committed rocprofv3 --pmc summaries (HBM bytes per launch of the dominant kernel), newest first, per (config, bf16)
-PMC_FILES = {("tdt-600m", True): ("r06_m1_pmc_hbm_600m_bf16.json", "r05_m6_pmc_hbm_600m_bf16.json", "r05_m4_pmc_hbm_600m_bf16.json", "r05_m3_pmc_hbm_600m_bf16.json", "r05_m2_pmc_hbm_600m_bf16.json", "r05_m1_pmc_hbm_600m_bf16.json", "r04_m5_pmc_hbm_600m_bf16.json", "r04_m4_pmc_hbm_600m_bf16.json", "r04_m3_pmc_hbm_600m_bf16.json", "r04_m2_pmc_hbm_600m_bf16.json", "r04_m1_pmc_hbm_600m_bf16.json", "r03_m4_pmc_hbm_600m_bf16.json", "r03_m2_pmc_hbm_600m_bf16.json", "r03_m1_pmc_hbm_600m_bf16.json", "r02_pmc_hbm_600m_bf16.json"),
-             ("tdt-ctc-110m", False): ("r06_m1_pmc_hbm.json", "r05_m6_pmc_hbm.json", "r05_m4_pmc_hbm.json", "r05_m3_pmc_hbm.json", "r05_m2_pmc_hbm.json", "r05_m1_pmc_hbm.json", "r04_m5_pmc_hbm.json", "r04_m4_pmc_hbm.json", "r04_m3_pmc_hbm.json", "r04_m2_pmc_hbm.json", "r04_m1_pmc_hbm.json", "r03_m4_pmc_hbm.json", "r03_m2_pmc_hbm.json", "r03_m1_pmc_hbm.json", "r02_pmc_hbm_v4.json", "r02_pmc_hbm_v3.json", "r02_pmc_hbm_v2.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json")}
+PMC_FILES = {("tdt-600m", True): ("r06_m2_pmc_hbm_600m_bf16.json", "r05_m6_pmc_hbm_600m_bf16.json", "r05_m4_pmc_hbm_600m_bf16.json", "r05_m3_pmc_hbm_600m_bf16.json", "r05_m2_pmc_hbm_600m_bf16.json", "r05_m1_pmc_hbm_600m_bf16.json", "r04_m5_pmc_hbm_600m_bf16.json", "r04_m4_pmc_hbm_600m_bf16.json", "r04_m3_pmc_hbm_600m_bf16.json", "r04_m2_pmc_hbm_600m_bf16.json", "r04_m1_pmc_hbm_600m_bf16.json", "r03_m4_pmc_hbm_600m_bf16.json", "r03_m2_pmc_hbm_600m_bf16.json", "r03_m1_pmc_hbm_600m_bf16.json", "r02_pmc_hbm_600m_bf16.json"),
+             ("tdt-ctc-110m", False): ("r06_m2_pmc_hbm.json", "r05_m6_pmc_hbm.json", "r05_m4_pmc_hbm.json", "r05_m3_pmc_hbm.json", "r05_m2_pmc_hbm.json", "r05_m1_pmc_hbm.json", "r04_m5_pmc_hbm.json", "r04_m4_pmc_hbm.json", "r04_m3_pmc_hbm.json", "r04_m2_pmc_hbm.json", "r04_m1_pmc_hbm.json", "r03_m4_pmc_hbm.json", "r03_m2_pmc_hbm.json", "r03_m1_pmc_hbm.json", "r02_pmc_hbm_v4.json", "r02_pmc_hbm_v3.json", "r02_pmc_hbm_v2.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json")}
 
 
 def log(*a):

@@ -25,12 +25,12 @@ def test_stream_kernel_tbps_reads_a_kernel_table(tmp_path):
 
 def test_stream_kernel_tbps_on_the_committed_tables():
     for mode in ("bf16", "fp32"):
-        src = os.path.join(ROOT, "profiles", f"r06_m1_stream_{mode}_kernel_stats.md")
-        want = open(os.path.join(ROOT, "profiles", f"r06_m1_stream_{mode}_kernel_tbps.md")).read()
+        src = os.path.join(ROOT, "profiles", f"r06_m2_stream_{mode}_kernel_stats.md")
+        want = open(os.path.join(ROOT, "profiles", f"r06_m2_stream_{mode}_kernel_tbps.md")).read()
         assert os.path.exists(src)
-        got = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stream_kernel_tbps.py"), f"profiles/r06_m1_stream_{mode}_kernel_stats.md", mode],
+        got = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stream_kernel_tbps.py"), f"profiles/r06_m2_stream_{mode}_kernel_stats.md", mode],
                              capture_output=True, text=True, check=True, cwd=ROOT).stdout          # (the tool prints the path it was given: run from the root)
-        assert got == want, f"profiles/r06_m1_stream_{mode}_kernel_tbps.md is not what the tool writes from the committed kernel table"
+        assert got == want, f"profiles/r06_m2_stream_{mode}_kernel_tbps.md is not what the tool writes from the committed kernel table"
 
 
 def test_stream_gap_report_reads_a_kernel_trace(tmp_path):

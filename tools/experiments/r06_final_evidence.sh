@@ -2,9 +2,9 @@
 # tools/experiments/r06_final_evidence.sh TAG -- the evidence set of round 6 on the PRODUCTION library (same set as round 5's + the mixed-length distributions the
 # round-5 verdict asked to re-measure): measure_round.sh (bench line, rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE passes for configs[1] and configs[2]) + one SQ
 # counter pass each for configs[1], configs[2] bf16 and configs[4] in both modes + the streaming kernel tables + teacher-forced parity figures.
-#   gpurun -- bash tools/experiments/r06_final_evidence.sh r06_m1
+#   gpurun -- bash tools/experiments/r06_final_evidence.sh r06_m2
 export TMPDIR=/tmp
-tag=${1:-r06_m1}
+tag=${1:-r06_m2}
 bash tools/experiments/measure_round.sh $tag > gpurun_out/${tag}_measure.log 2>&1
 o=gpurun_out/$tag
 C="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE"
