@@ -531,7 +531,8 @@ void Workspace::reserve_decode(const pk_config &c) {
     max_tokens = T * (c.max_symbols_per_step > 0 ? c.max_symbols_per_step : 10);
     const int Hp = c.pred_hidden, J = c.joint_hidden, L = c.num_lstm_layers, VD = c.vocab_size + c.num_durations;
     ep.reserve(M * J * f); gh.reserve((size_t)B * 4 * Hp * f); gi.reserve((size_t)B * 4 * Hp * f); pp.reserve((size_t)B * J * f);
-    z.reserve((size_t)B * J * f); logits.reserve((size_t)B * VD * f);
+    const size_t Bw = B < kDecWindowMax ? kDecWindowMax : B;         // a single utterance decodes through a frame window of kDecWindowMax rows (TdtState::F)
+    z.reserve(Bw * J * f); logits.reserve(Bw * VD * f);
     h.reserve((size_t)L * B * Hp * f); this->c.reserve((size_t)L * B * Hp * f); hn.reserve((size_t)L * B * Hp * f); cn.reserve((size_t)L * B * Hp * f);
     ints.reserve((size_t)(8 * B + 8) * sizeof(int));
     const size_t tok = (size_t)B * max_tokens;

@@ -109,7 +109,10 @@ __device__ __forceinline__ int dd_build_rowlist(const int *need, int B, int *lst
 // NTW: the weight stream is loaded non-temporally (streaming hint: the decode weights of the large heads -- 42 MB per symbol step for tdt-600m --
 // pass through each XCD's 4 MB L2 once per step and otherwise evict the operand tiles of the encoder GEMMs running beside the loop).
 // WF > 1 (SK_ACT only): the frame-window form of the joint activation (TdtState::F) -- utterance b's rows b * F + f of z take relu(enc_proj[t_b + f] + pp), f < a.F <= WF.
-template <int EPI, int NCH, bool COH, bool NTW = false, int WF = 1>
+// PRED (a.need set, B <= 16: the whole batch is one row tile): no compacted row list -- the need flags are requested FIRST, together with every other operand, the
+// launch leaves after the first operand chunk is under way if no flag is set, and the epilogue stores only the flagged rows.  Building the list first put a memory
+// round trip (flags) in front of the launch's own loads: ~1 us of a ~5 us launch, twice per symbol step.  A row's chain does not depend on its neighbours: same bits.
+template <int EPI, int NCH, bool COH, bool NTW = false, int WF = 1, bool PRED = false>
 __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgroup, float (*tile)[16][17], const int *rows = nullptr, int n_rows = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
@@ -132,10 +135,13 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
     float e_ep[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e_bias = 0.0f;       // SK_ACT / SK_BIAS: lane -> column `col`, utterances 4*kq+r
     float e_epw[4][WF > 1 ? WF - 1 : 1];                           // SK_ACT window: enc_proj of the frames t + 1 .. t + F - 1
     int rb_cell = 0, rb_out[4] = {0, 0, 0, 0};                   // utterances of this lane's epilogue rows
+    int nd_cell = 1, nd_out[4] = {1, 1, 1, 1};                   // PRED: their need flags
+    bool pred_skip = false;
     if (EPI == SK_CELL) {
         const int bi = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
         const int b = bi < NB ? real(bi) : 0;
         rb_cell = b;
+        if constexpr (PRED) nd_cell = bi < NB ? dd_ldi<COH>(a.need + b) : 0;
         if (bi < NB && !a.W2) {
             const float *gir = a.gi + (int64_t)(a.gi_row ? dd_ldi<COH>(a.gi_row + b) : b) * a.gi_ld;
 #pragma unroll
@@ -148,6 +154,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
         for (int r = 0; r < 4; ++r) {
             const int bi = m0 + 4 * kq + r;
             rb_out[r] = bi < NB ? real(bi) : 0;
+            if constexpr (PRED) nd_out[r] = bi < NB ? dd_ldi<COH>(a.need + rb_out[r]) : 0;
         }
         if (n < a.N) {
             if (a.bias) e_bias = a.bias[n];
@@ -194,12 +201,19 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
     // one single-chain product acc = X W^T over K (natural k order) through the two-set prefetch ring
     auto chain = [&](const float4 *xq, const float4 *wq) -> f32x4 {
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (PRED) {
+            if (pred_skip) return acc;
+        }
         if constexpr (NCH > 0) {
             // two register sets, fully unrolled: chunk c+1 is in flight while chunk c feeds the MFMA chain (>= 640 cycles of cover).
             // A third set hid more latency but pushed the kernel past 96 VGPRs, and then a decode wave no longer fits next to the
             // four 104-VGPR waves per SIMD of the 128x128 GEMM of the NEXT batch's encoder (two-stream pipeline): every decode
             // workgroup had to wait for a GEMM workgroup to retire and then held that slot -- 2.0 ms per 64-clip batch.
             SK_LOAD(xa, wa, 0)
+            if constexpr (PRED) {                                    // (the flags were requested first: this waits for them, not for the chunk)
+                const bool mine = EPI == SK_CELL ? nd_cell != 0 : (nd_out[0] | nd_out[1] | nd_out[2] | nd_out[3]) != 0;
+                if (__builtin_amdgcn_ballot_w64(mine) == 0) { pred_skip = true; return acc; }
+            }
 #pragma unroll
             for (int c = 0; c < NCH; c += 2) {
                 if (c + 1 < NCH) { SK_LOAD(xb, wb, c + 1) }
@@ -209,6 +223,10 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
             }
         } else {
             SK_LOAD(xa, wa, 0)
+            if constexpr (PRED) {
+                const bool mine = EPI == SK_CELL ? nd_cell != 0 : (nd_out[0] | nd_out[1] | nd_out[2] | nd_out[3]) != 0;
+                if (__builtin_amdgcn_ballot_w64(mine) == 0) { pred_skip = true; return acc; }
+            }
             for (int c = 0; c < nchunks; c += 2) {
                 if (c + 1 < nchunks) { SK_LOAD(xb, wb, c + 1) }
                 SK_MMA(xa, wa)
@@ -227,6 +245,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
         acc2 = chain(reinterpret_cast<const float4 *>(a.X2 + (int64_t)xrow * a.K) + kq, reinterpret_cast<const float4 *>(a.W2 + (int64_t)wrow * a.K) + kq);
     }
     const f32x4 acc = chain(xp, wp);
+    if constexpr (PRED) { if (pred_skip) return; }
 #undef SK_LOAD
 #undef SK_MMA
     // C/D layout of 16x16x4: column = lane & 15, row (utterance) = 4 * (lane >> 4) + r
@@ -245,6 +264,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (m0 + 4 * kq + r >= NB) continue;
+                if constexpr (PRED) { if (!nd_out[r]) continue; }
                 const int b = rb_out[r];
                 float p = acc[r];
                 if (a.bias) p = p + e_bias;
@@ -269,7 +289,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
         // LSTMCell::forward: gates = (W_ih x + b) + W_hh h ; i,f,g,o ; c' = f*c + i*g ; h' = o*tanh(c')
         const int ul = lane >> 2, jj = lane & 3;
         const int j = 4 * nt + jj;
-        const bool row_ok = m0 + ul < NB;
+        const bool row_ok = m0 + ul < NB && (!PRED || nd_cell != 0);
         const int b = rb_cell;
         if (a.W2) {                                   // upper layer: gi = chain_ih + b_ih, through the same LDS transposition
 #pragma unroll

@@ -26,6 +26,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     // nt % 8 == x of EVERY utterance group and re-reads only its eighth of W from its own L2 step after step
     if ((EPI == SK_CELL ? 4 : 16) * (int)blockIdx.x >= (EPI == SK_CELL ? a.Hp : a.N)) return;
     if (a.need) {                                                // prediction-net caching: only the utterances whose flag is set (TdtState::need)
+        if (a.B <= 16) {                                         // one row tile: flags as predicates, no list in front of the loads (decode_dev.hpp: PRED)
+            if (blockIdx.y == 0) skinny_tile<EPI, NCH, false, NTW, WF, true>(a, blockIdx.x, 0, tile);
+            return;
+        }
         __shared__ int lst[kMaxListRows];
         __shared__ int wtot[4];
         const int cnt = dd_build_rowlist<false>(a.need, a.B, lst, wtot);
