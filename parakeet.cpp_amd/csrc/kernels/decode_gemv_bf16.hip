@@ -36,9 +36,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     __shared__ int lst[kMaxListRows];
     __shared__ int wtot[4];
     int NB = a.B;
-    const bool listed = a.need != nullptr;                       // (kernel argument: uniform)
+    // One row tile (B <= 16): the flags are predicates -- requested with the launch's other operands, looked at once the first operand chunk is under way, applied
+    // to the stores -- instead of a list whose round trip sits in front of every other load (decode_dev.hpp: PRED, the fp32 kernels' form of the same thing).
+    const bool pred = a.need != nullptr && a.B <= 16;            // (kernel arguments: uniform)
+    const bool listed = a.need != nullptr && !pred;
     if (listed) NB = dd_build_rowlist<false>(a.need, a.B, lst, wtot);
     auto real = [&](int i) { return listed ? lst[i] : i; };
+    int nd_cell = 1, nd_out[4] = {1, 1, 1, 1};
+    bool pred_skip = false;
     if (m0 >= NB) return;                                        // whole wave out of range (uniform)
     const __bf16 *X = reinterpret_cast<const __bf16 *>(a.X);
     // W (and W2) are TILED in this kernel's load order (engine.cpp upload_dec16): tile nt = nblk consecutive 1 KB blocks [lane][8 bf16];
@@ -54,6 +59,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
         const int bi = m0 + (lane >> 2), j = 4 * nt + (lane & 3);
         const int b = bi < NB ? real(bi) : 0;
         rb_cell = b;
+        if (pred) nd_cell = bi < NB ? a.need[b] : 0;
         if (bi < NB && !a.W2) {
             const float *gir = a.gi + (int64_t)(a.gi_row ? a.gi_row[b] : b) * a.gi_ld;
 #pragma unroll
@@ -66,6 +72,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int bi = m0 + 4 * kq + r;
             rb_out[r] = bi < NB ? real(bi) : 0;
+            if (pred) nd_out[r] = bi < NB ? a.need[rb_out[r]] : 0;
         }
         if (n < a.N) {
             if (a.bias) e_bias = a.bias[n];
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     constexpr int CH = 4;
     auto chain = [&](const __bf16 *xr, const void *wt) -> db_f32x4 {
         db_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (pred_skip) return acc;
         const db_bf16x8 *xq = reinterpret_cast<const db_bf16x8 *>(xr) + kq;                 // 32-k block i at [4 i]
         const db_bf16x8 *wq = reinterpret_cast<const db_bf16x8 *>(wt) + wtile;              // 32-k block i at [64 i]
         const int nblk = a.K / 32;
@@ -108,6 +116,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         };
         load(xa, wa, 0);
+        if (pred) {
+            const bool mine = EPI == SK_CELL ? nd_cell != 0 : (nd_out[0] | nd_out[1] | nd_out[2] | nd_out[3]) != 0;
+            if (__builtin_amdgcn_ballot_w64(mine) == 0) { pred_skip = true; return acc; }
+        }
         for (int c0 = 0; c0 < nblk; c0 += 2 * CH) {
             if (c0 + CH < nblk) load(xb, wb, c0 + CH);
             mma(xa, wa, c0);
@@ -121,6 +133,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
         acc2 = chain(reinterpret_cast<const __bf16 *>(a.X2) + (int64_t)xrow * a.K, a.W2);
     }
     const db_f32x4 acc = chain(X + (int64_t)xrow * a.K, a.W);
+    if (pred_skip) return;
     // C/D layout of 16x16: column = lane & 15, row (utterance) = 4 * (lane >> 4) + r
     if (EPI == SK_BIAS) {
         const int n = 16 * nt + col;
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
             __bf16 *z = reinterpret_cast<__bf16 *>(a.out);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (m0 + 4 * kq + r >= NB) continue;
+                if (m0 + 4 * kq + r >= NB || !nd_out[r]) continue;
                 const int b = rb_out[r];
                 float p = acc[r];
                 if (a.bias) p = p + e_bias;
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
         // LSTMCell::forward: gates = (W_ih x + b) + W_hh h ; i,f,g,o ; c' = f*c + i*g ; h' = o*tanh(c')
         const int ul = lane >> 2, jj = lane & 3;
         const int j = 4 * nt + jj;
-        const bool row_ok = m0 + ul < NB;
+        const bool row_ok = m0 + ul < NB && nd_cell != 0;
         const int b = rb_cell;
         if (a.W2) {
 #pragma unroll
