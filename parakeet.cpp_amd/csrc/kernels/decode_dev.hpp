@@ -390,7 +390,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     // A finished utterance leaves without a write.  Launch-per-phase loop: the flag travels WITH the step's other loads (state words, candidate LSTM
     // state, logits row) and is looked at once they are all in flight -- as the first statement it was a round trip of its own (~1 us of a ~7 us launch).
     DEC_STAMPS_DECL;
-    DEC_STAMP(0);                                                    // 0 entry
+    DEC_STAMP(0);                                                   // entry
     const int done_in = dd_ldi<COH>(st.done + b);
     if constexpr (COH) { if (done_in) return; }
     int n_force = 0;                                               // SCORE: steps of this utterance's given path, first element of its arrays
@@ -470,12 +470,11 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     int t_cur = t_in, steps_cur = steps_in, nsym_cur = nsym_in, f_cur = 0;     // the walk through the frame window
     float vw[kDecWindowMax][5];                                                 // its F logits rows on their way from memory (exact form, V + D <= 5 x 256)
     for (;;) {
-    DEC_STAMP(1);
+    DEC_STAMP(1);                                                   // a decision starts ([11]: the first one's start, [15]: decisions so far)
 #ifdef DEC_TRACE
     if (f_cur == 0) dec_st[11] = dec_st[1];
     dec_st[15] += 1;
 #endif
-                                                    // evaluation start (loads issued on the first)
     if constexpr (FAST) {
       auto fast = [&](auto nq_tag) {
         constexpr int NQ = decltype(nq_tag)::value;                 // VD <= NQ x 256 (33: launch_tdt_decide checks)
@@ -624,12 +623,12 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             }
         }
     }
-    DEC_STAMP(2);                                                    // row arrived, staged
+    DEC_STAMP(2);                                                   // row arrived, staged
     m = wave_max64(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    DEC_STAMP(3);                                                    // maximum known
+    DEC_STAMP(3);                                                   // maximum known
     for (int i0 = tid; i0 < st.V; i0 += 256 * 4) {                 // (4 independent LDS reads / exp chains per trip)
         float t4[4];
 #pragma unroll
@@ -648,7 +647,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
         }
     }
     __syncthreads();
-    DEC_STAMP(4);                                                    // exps in LDS
+    DEC_STAMP(4);                                                   // exps in LDS
     if (wave == 0) {
         float p = 0.0f;
         for (int i0 = lane; i0 < st.V; i0 += 64 * 8) {              // the canonical strided partial sum, its LDS reads 8 at a time; the adds stay in index order
@@ -674,9 +673,9 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             if (lane == 0) red[6] = st.D > 1 ? dur.lp - second : __builtin_huge_valf();
         }
     }
-    DEC_STAMP(5);                                                    // wave 0: sum, log done (before the barrier)
+    DEC_STAMP(5);                                                   // wave 0: sum, log done (before the barrier)
     __syncthreads();
-    DEC_STAMP(6);                                                    // lse known (duration head done)
+    DEC_STAMP(6);                                                   // lse known (duration head done)
     const float lse = red[4];
     float best = -__builtin_huge_valf();
     // `second` = the largest label log-prob that is NOT the winner's (ties with the winner count: margin 0).  It only feeds the optional
@@ -709,7 +708,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     });
     if (lane == 0) { red[8 + wave] = best; red[12 + wave] = __int_as_float(bi); red[wave] = second; }   // (red[0..3]: the wave maxima were consumed two barriers ago)
     __syncthreads();
-    DEC_STAMP(7);                                                    // argmax exchanged
+    DEC_STAMP(7);                                                   // argmax exchanged
     lab = BestLP{red[8], __float_as_int(red[12])};
     sec = red[0];
 #pragma unroll
@@ -771,7 +770,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
     break;
     }                                                               // (window walk)
     if constexpr (!COH && !BOOST) { if (st.margin && tid == 0) st.margin[b] = mg_old; }
-    DEC_STAMP(8);                                                    // walk over
+    DEC_STAMP(8);                                                   // walk over
     const int lane0 = tid;                                         // thread 0 writes the scalar state
     // scalar control (wave-uniform values; lane 0 writes)
     int t = t_cur;
@@ -883,7 +882,7 @@ __device__ __forceinline__ void tdt_decide_one(const TdtState &st, int b, float 
             }
         }
     }
-    DEC_STAMP(9);                                                    // commit / next z issued
+    DEC_STAMP(9);                                                   // commit / next z issued
     if (lane0 == 0) {
         bool finished = t >= Tb || (SCORE && st.force_label && nsteps >= n_force);
         int len = n_out < st.max_tokens ? n_out : st.max_tokens;
