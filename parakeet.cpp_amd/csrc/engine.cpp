@@ -1117,6 +1117,16 @@ void Model::run_ctc(Workspace &w, const float *d_enc, int B, int T, bool want_lo
                            w.start.as<int>(), w.end.as<int>(), w.conf.as<float>(), s, pitch, seq));
 }
 
+// The decode loop's poll ahead of the chunk's end (run_tdt_loop).  EXPERIMENTAL builds: PK_DEC_POLL_AHEAD=0 keeps the synchronising poll.
+static bool poll_ahead_on() {
+#ifdef PK_EXPERIMENTAL
+    static const bool on = [] { const char *e = getenv("PK_DEC_POLL_AHEAD"); return e ? atoi(e) != 0 : true; }();
+    return on;
+#else
+    return true;
+#endif
+}
+
 // Frame window of the small-batch decode loop (TdtState::F): the largest lock-step batch that gets one.  Measured (profiles/r06_dec_window_ab.txt, pk_transcribe_pcm,
 // median of 100 calls): one clip 4.96-5.00 -> 4.84 ms on the benchmark's clips (81 tokens in 112 decisions: a blank-poor case); two clips no change; four clips
 // + 4 % (the walked decisions of one utterance hold up the step of the other three, and a window of four frames ends at the first long blank) -> single
@@ -1331,13 +1341,28 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
         }
         return;
     }
+    // Offline loops: the poll's copy is enqueued `ahead` steps before the end of the chunk and the host waits for THAT copy (an event), not for the stream -- the
+    // steps behind it keep the GPU busy while the host wakes up and enqueues the next chunk (a wake-up measured at 20-24 us per poll in the single-clip
+    // trace, profiles/r06_single_clip_kernel_stats.md; if the copy says "finished", the steps behind it were two no-op steps).  A streaming chunk's loop
+    // (before_poll set: its result copies ride on the poll and must be the last thing enqueued) keeps the plain form.
+    const int ahead = (!w.before_poll && !keep_state && chunk >= 8 && poll_ahead_on()) ? 2 : 0;
+    if (ahead && !w.poll_ev) PK_HIP(hipEventCreateWithFlags(&w.poll_ev, hipEventDisableTiming));
     for (int step = 0; step < st.max_steps; ++step) {
         enqueue_step();
-        if ((step + 1) % chunk == 0) {                                 // poll "all finished" once per chunk of steps
-            if (w.before_poll) w.before_poll(s);
+        const int k = (step + 1) % chunk;
+        if (ahead && k == chunk - ahead) {
             PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));
-            PK_HIP(hipStreamSynchronize(s));
-            if (*h_done >= B) { w.poll_hit = true; break; }
+            PK_HIP(hipEventRecord(w.poll_ev, s));
+        }
+        if (k == 0) {                                                  // poll "all finished" once per chunk of steps
+            if (ahead) {
+                PK_HIP(hipEventSynchronize(w.poll_ev));
+            } else {
+                if (w.before_poll) w.before_poll(s);
+                PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));
+                PK_HIP(hipStreamSynchronize(s));
+            }
+            if (*h_done >= B) { w.poll_hit = ahead == 0; break; }
         }
     }
 }

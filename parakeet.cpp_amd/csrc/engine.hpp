@@ -89,6 +89,7 @@ struct Workspace {
     int32_t *rag_pinned = nullptr;                // pinned staging of the image (async upload on the run's stream)
     size_t rag_pinned_words = 0;
     hipEvent_t rag_copied = nullptr;              // the last upload out of rag_pinned has executed
+    hipEvent_t poll_ev = nullptr;                 // run_tdt_loop: the poll's copy has executed (the host waits for it, not for the steps enqueued behind it)
     // teacher-forced scoring (pk_tdt_score, one utterance): device arrays of the given decisions and of the recorded joint outputs (TdtState)
     const int *force_label = nullptr, *force_dur = nullptr;
     int n_force = 0;
@@ -110,6 +111,7 @@ struct Workspace {
         if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
         if (rag_pinned) (void)hipHostFree(rag_pinned);
         if (rag_copied) (void)hipEventDestroy(rag_copied);
+        if (poll_ev) (void)hipEventDestroy(poll_ev);
     }
     Workspace() = default;
     Workspace(const Workspace &) = delete;
