@@ -121,7 +121,11 @@ __device__ __forceinline__ void skinny_tile(const SkinnyArgs &a, int nt, int mgr
     // is utterance rows[i]
     const int NB = rows ? n_rows : a.B;
     auto real = [&](int i) { return rows ? rows[i] : i; };
-    if (m0 >= NB) return;                                        // whole wave out of range (uniform)
+    if constexpr (PRED) {
+        if (wave) return;                                        // one row tile (1 <= B <= 16): wave 0 has it -- decided without an argument in front of the argument loads
+    } else {
+        if (m0 >= NB) return;                                    // whole wave out of range (uniform)
+    }
     int wrow;
     if (EPI == SK_CELL) wrow = (col >> 2) * a.Hp + 4 * nt + (col & 3);   // tile columns = (gate, unit): rows g*Hp + j
     else { wrow = 16 * nt + col; wrow = wrow < a.N ? wrow : a.N - 1; }
