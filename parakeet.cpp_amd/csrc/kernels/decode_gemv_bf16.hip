@@ -22,13 +22,17 @@ namespace pk {
 typedef float db_f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 db_bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int EPI>
+// MODE / CHK: chosen by the launcher from the arguments (0 every row, 1 need flags as predicates, 2 compacted row list; CHK: padded grid), as in decode_gemv.hip -- a branch on
+// an argument in front of the kernel's argument loads splits them into dependent pieces.
+template <int EPI, int MODE = 0, bool CHK = false>
 __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     __shared__ float tile[4][16][17];
     const int nt = blockIdx.x, mgroup = blockIdx.y;
     // grid.x is the tile count rounded up to a multiple of 8: workgroup id % 8 = XCD, so XCD x owns the output tiles nt % 8 == x of EVERY
     // utterance group and re-reads only its eighth of W (1.3 of the 10.5 MB of the 8198-row heads) from its own L2 step after step
-    if ((EPI == SK_CELL ? 4 : 16) * nt >= (EPI == SK_CELL ? a.Hp : a.N)) return;
+    if constexpr (CHK) {
+        if ((EPI == SK_CELL ? 4 : 16) * nt >= (EPI == SK_CELL ? a.Hp : a.N)) return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int m0 = (mgroup * 4 + wave) * 16;
@@ -38,13 +42,16 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     int NB = a.B;
     // One row tile (B <= 16): the flags are predicates -- requested with the launch's other operands, looked at once the first operand chunk is under way, applied
     // to the stores -- instead of a list whose round trip sits in front of every other load (decode_dev.hpp: PRED, the fp32 kernels' form of the same thing).
-    const bool pred = a.need != nullptr && a.B <= 16;            // (kernel arguments: uniform)
-    const bool listed = a.need != nullptr && !pred;
+    constexpr bool pred = MODE == 1, listed = MODE == 2;
     if (listed) NB = dd_build_rowlist<false>(a.need, a.B, lst, wtot);
     auto real = [&](int i) { return listed ? lst[i] : i; };
     int nd_cell = 1, nd_out[4] = {1, 1, 1, 1};
     bool pred_skip = false;
-    if (m0 >= NB) return;                                        // whole wave out of range (uniform)
+    if constexpr (pred) {
+        if (wave) return;                                        // one row tile: wave 0 has it
+    } else {
+        if (m0 >= NB) return;                                    // whole wave out of range (uniform)
+    }
     const __bf16 *X = reinterpret_cast<const __bf16 *>(a.X);
     // W (and W2) are TILED in this kernel's load order (engine.cpp upload_dec16): tile nt = nblk consecutive 1 KB blocks [lane][8 bf16];
     // SK_CELL: the tile's columns are the (gate, unit) pairs g * Hp + 4 nt + j
@@ -195,13 +202,26 @@ __global__ __launch_bounds__(256) void skinny_gemm_bf16_kernel(SkinnyArgs a) {
     }
 }
 
+template <int EPI>
+static void launch_skinny_bf16_epi(const SkinnyArgs &a, dim3 grid, hipStream_t s) {
+    const int n_tiles = EPI == SK_CELL ? a.Hp / 4 : (a.N + 15) / 16;
+    const bool chk = n_tiles % 8 != 0;
+    const int mode = a.need ? (a.B <= 16 ? 1 : 2) : 0;
+#define PK_SB16(M_) do { if (chk) hipLaunchKernelGGL((skinny_gemm_bf16_kernel<EPI, M_, true>), grid, dim3(256), 0, s, a); \
+                         else hipLaunchKernelGGL((skinny_gemm_bf16_kernel<EPI, M_, false>), grid, dim3(256), 0, s, a); } while (0)
+    if (mode == 1) PK_SB16(1);
+    else if (mode == 2) PK_SB16(2);
+    else PK_SB16(0);
+#undef PK_SB16
+}
+
 void launch_skinny_gemm_bf16(const SkinnyArgs &a, int epi, hipStream_t s) {
     const int n_tiles = epi == SK_CELL ? a.Hp / 4 : (a.N + 15) / 16;
     dim3 grid((n_tiles + 7) & ~7, (a.B + 63) / 64);
     switch (epi) {
-    case SK_BIAS: hipLaunchKernelGGL((skinny_gemm_bf16_kernel<SK_BIAS>), grid, dim3(256), 0, s, a); break;
-    case SK_ACT: hipLaunchKernelGGL((skinny_gemm_bf16_kernel<SK_ACT>), grid, dim3(256), 0, s, a); break;
-    case SK_CELL: hipLaunchKernelGGL((skinny_gemm_bf16_kernel<SK_CELL>), grid, dim3(256), 0, s, a); break;
+    case SK_BIAS: launch_skinny_bf16_epi<SK_BIAS>(a, grid, s); break;
+    case SK_ACT: launch_skinny_bf16_epi<SK_ACT>(a, grid, s); break;
+    case SK_CELL: launch_skinny_bf16_epi<SK_CELL>(a, grid, s); break;
     default: break;
     }
 }
