@@ -1347,16 +1347,19 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
     // (before_poll set: its result copies ride on the poll and must be the last thing enqueued) keeps the plain form.
     const int ahead = (!w.before_poll && !keep_state && chunk >= 8 && poll_ahead_on()) ? 2 : 0;
     if (ahead && !w.poll_ev) PK_HIP(hipEventCreateWithFlags(&w.poll_ev, hipEventDisableTiming));
+    bool copy_pending = false;                                         // a poll's copy into h_done is enqueued and has not been waited for
     for (int step = 0; step < st.max_steps; ++step) {
         enqueue_step();
         const int k = (step + 1) % chunk;
         if (ahead && k == chunk - ahead) {
             PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));
             PK_HIP(hipEventRecord(w.poll_ev, s));
+            copy_pending = true;
         }
         if (k == 0) {                                                  // poll "all finished" once per chunk of steps
             if (ahead) {
                 PK_HIP(hipEventSynchronize(w.poll_ev));
+                copy_pending = false;
             } else {
                 if (w.before_poll) w.before_poll(s);
                 PK_HIP(hipMemcpyAsync(h_done, st.done_count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1365,6 +1368,7 @@ void Model::run_tdt_loop(Workspace &w, int B, int T, int max_tokens, hipStream_t
             if (*h_done >= B) { w.poll_hit = ahead == 0; break; }
         }
     }
+    if (copy_pending) PK_HIP(hipEventSynchronize(w.poll_ev));           // (the step cap ended the loop between a copy and its wait: h_done is the model's one word -- no copy may outlive the loop)
 }
 
 }  // namespace pk
